@@ -1,0 +1,57 @@
+"""ctypes binding of libpicopose_hip.so — the C ABI declared in include/picopose_hip.h.
+
+There is deliberately no CPU or eager-torch fallback: if the HIP library is
+missing the import of any compute entry point raises.
+"""
+import ctypes
+import os
+import re
+
+from .build import LIB
+
+_HEADER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "picopose_hip.h")
+
+PP_OK = 0
+PP_MATCH_EXACT = 0
+PP_MATCH_FAST = 1
+
+_lib = None
+
+
+class PicoPoseHipError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every function name declared in include/picopose_hip.h."""
+    text = open(_HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise PicoPoseHipError(
+                f"{LIB} not found: build it with `python -m picopose_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        L = ctypes.CDLL(LIB)
+        c = ctypes
+        vp, i32, f32, sz = c.c_void_p, c.c_int, c.c_float, c.c_size_t
+        L.pp_strerror.restype = c.c_char_p
+        L.pp_strerror.argtypes = [i32]
+        L.pp_version.restype = i32
+        L.pp_stage1_workspace_bytes.argtypes = [i32, i32, i32, c.POINTER(sz)]
+        L.pp_stage1_scores.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, vp, vp]
+        L.pp_topk.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+        L.pp_stage1_match.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz,
+                                      vp, vp, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != PP_OK:
+        raise PicoPoseHipError(f"{what} failed: {lib().pp_strerror(rc).decode()} (code {rc})")

@@ -1,0 +1,88 @@
+"""Host side of stage-1/stage-2 matching — mirrors reference utils/matching.py.
+
+`matching_templates` keeps the reference signature and return values
+(utils/matching.py:29-69) but runs as ONE fused HIP pass over the bank
+(picopose_amd/csrc/pp_stage1.hip) through the C ABI; nothing here computes on
+the CPU and there is no torch fallback.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+# arithmetic of the 256x256xC contraction: "fast" (fp16 MFMA + exact fp32
+# re-evaluation of near-tie decisions) or "exact" (fp32 MFMA, an fma chain).
+DEFAULT_MODE = "fast"
+_MODES = {"exact": _lib.PP_MATCH_EXACT, "fast": _lib.PP_MATCH_FAST}
+
+_ws_cache = {}
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _workspace(B, N, C, device):
+    need = ctypes.c_size_t()
+    _lib.check(_lib.lib().pp_stage1_workspace_bytes(B, N, C, ctypes.byref(need)), "pp_stage1_workspace_bytes")
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < need.value:
+        ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws, need.value
+
+
+def _check_inputs(src_feats, tar_feat, tar_mask):
+    if not (src_feats.is_cuda and tar_feat.is_cuda and tar_mask.is_cuda):
+        raise _lib.PicoPoseHipError("picopose_amd runs on the GPU only: inputs must be CUDA(HIP) tensors")
+    B, N, C, H, W = src_feats.shape
+    assert H == W  # reference utils/matching.py:35
+    if H != 16:
+        raise _lib.PicoPoseHipError("the HIP stage-1 kernel is built for 16x16 patch grids")
+    assert tar_feat.shape == (B, C, H, W), (tar_feat.shape, src_feats.shape)
+    assert tar_mask.dim() == 3 and tar_mask.shape[0] == B
+    return B, N, C
+
+
+def template_scores(src_feats, tar_feat, tar_mask, mode=None, eps=0.0, return_stats=False):
+    """sim_avg (B,N) of utils/matching.py:38-66 for a (B,N,C,16,16) bank."""
+    B, N, C = _check_inputs(src_feats, tar_feat, tar_mask)
+    mode_id = _MODES[mode or DEFAULT_MODE]
+    bank = src_feats.contiguous().float()
+    query = tar_feat.contiguous().float()
+    mask = tar_mask.contiguous().float()
+    ws, nbytes = _workspace(B, N, C, bank.device)
+    sim_avg = torch.empty(B, N, dtype=torch.float32, device=bank.device)
+    stats = torch.zeros(4, dtype=torch.int32, device=bank.device) if return_stats else None
+    rc = _lib.lib().pp_stage1_scores(
+        bank.data_ptr(), query.data_ptr(), mask.data_ptr(), mask.shape[1], mask.shape[2],
+        B, N, C, mode_id, float(eps), ws.data_ptr(), nbytes, sim_avg.data_ptr(),
+        stats.data_ptr() if stats is not None else None, _stream_ptr())
+    _lib.check(rc, "pp_stage1_scores")
+    return (sim_avg, stats) if return_stats else sim_avg
+
+
+def topk_templates(sim_avg, topk):
+    """torch.topk(sim_avg, topk, dim=1) (utils/matching.py:68), ties -> lower id."""
+    B, N = sim_avg.shape
+    if topk > N:
+        raise RuntimeError(f"selected index k out of range: topk={topk} > N={N}")
+    sim_avg = sim_avg.contiguous().float()
+    score = torch.empty(B, topk, dtype=torch.float32, device=sim_avg.device)
+    index = torch.empty(B, topk, dtype=torch.int64, device=sim_avg.device)
+    rc = _lib.lib().pp_topk(sim_avg.data_ptr(), B, N, topk, score.data_ptr(), index.data_ptr(), _stream_ptr())
+    _lib.check(rc, "pp_topk")
+    return score, index
+
+
+def matching_templates(src_feats, tar_feat, src_masks, tar_mask, topk=5, mode=None):
+    """Drop-in for reference utils/matching.py:29-69.
+
+    src_feats (B,N,C,16,16), tar_feat (B,C,16,16), tar_mask (B,H,W);
+    `src_masks` is accepted and unused, exactly as in the reference.
+    Returns (pred_score_src (B,topk) f32, pred_id_src (B,topk) i64).
+    """
+    sim_avg = template_scores(src_feats, tar_feat, tar_mask, mode=mode)
+    return topk_templates(sim_avg, topk)
