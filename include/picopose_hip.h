@@ -41,6 +41,13 @@ extern "C" {
 const char* pp_strerror(int code);
 int pp_version(void);
 
+/* Measurement hooks (bench.py): after pp_prof_enable(n) every call that launches a
+ * roofline kernel (stage 1: the fused similarity kernel) brackets exactly that launch with
+ * two hipEvents on the caller's stream, up to n records; pp_prof_collect waits for them and
+ * returns the durations in ms.  pp_prof_enable(0) switches the hooks off. */
+int pp_prof_enable(int max_records);
+int pp_prof_collect(float* out_ms, int max_out, int* count);
+
 /* ------------------------------------------------------------------------- *
  * Stage 1: template matching — utils/matching.py:29-69 (matching_templates)
  * called from model/picopose.py:102-104.

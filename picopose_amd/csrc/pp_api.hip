@@ -15,4 +15,38 @@ const char* pp_strerror(int code) {
 
 int pp_version(void) { return 100; }
 
+// ---- optional in-library timing of the dominant kernel (bench.py's roofline leg) ----------
+}  // extern "C"
+static PpProf g_prof;
+PpProf* pp_prof_state() { return &g_prof; }  // internal (C++ linkage, hidden from the header)
+extern "C" {
+
+int pp_prof_enable(int max_records) {
+    PpProf& p = g_prof;
+    for (int i = 0; i < p.capacity * 2; ++i) (void)hipEventDestroy(p.ev[i]);
+    delete[] p.ev;
+    p.ev = nullptr;
+    p.capacity = p.count = 0;
+    if (max_records <= 0) return PP_OK;
+    p.ev = new hipEvent_t[2 * max_records];
+    for (int i = 0; i < 2 * max_records; ++i)
+        if (hipEventCreate(&p.ev[i]) != hipSuccess) return PP_ELAUNCH;
+    p.capacity = max_records;
+    return PP_OK;
+}
+
+int pp_prof_collect(float* out_ms, int max_out, int* count) {
+    PpProf& p = g_prof;
+    if (!out_ms || !count) return PP_EINVAL;
+    int n = p.count < max_out ? p.count : max_out;
+    for (int i = 0; i < n; ++i) {
+        if (hipEventSynchronize(p.ev[2 * i + 1]) != hipSuccess) return PP_ELAUNCH;
+        if (hipEventElapsedTime(&out_ms[i], p.ev[2 * i], p.ev[2 * i + 1]) != hipSuccess)
+            return PP_ELAUNCH;
+    }
+    *count = n;
+    p.count = 0;
+    return PP_OK;
+}
+
 }  // extern "C"

@@ -11,4 +11,30 @@
 
 static inline int pp_last_launch() { return hipGetLastError() == hipSuccess ? PP_OK : PP_ELAUNCH; }
 
+
+// Timing hooks: when enabled (pp_prof_enable) the entry point that launches a roofline
+// kernel brackets exactly that launch with two hipEvents on the caller's stream.
+struct PpProf {
+    hipEvent_t* ev = nullptr;
+    int capacity = 0;
+    int count = 0;
+};
+PpProf* pp_prof_state();
+
+struct PpProfScope {
+    PpProf* p;
+    hipStream_t s;
+    bool on;
+    PpProfScope(hipStream_t stream) : p(pp_prof_state()), s(stream) {
+        on = p->capacity > 0 && p->count < p->capacity;
+        if (on) (void)hipEventRecord(p->ev[2 * p->count], s);
+    }
+    ~PpProfScope() {
+        if (on) {
+            (void)hipEventRecord(p->ev[2 * p->count + 1], s);
+            p->count++;
+        }
+    }
+};
+
 #endif

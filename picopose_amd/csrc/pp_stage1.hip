@@ -52,12 +52,14 @@ struct S1Ws {
     _Float16* qh;   // (B, C/32, 2, 8, 64, 8) fp16 A-fragment order, normalised*mask
     float* qf;      // (B, C, 256) fp32 normalised*mask
     float* m16;     // (B, 256) sampled mask
-    float* rowmax;  // (B*N, 2, 256) per-half row maxima
+    float* denom;   // (B, 256) max(||q_t||, 1e-12)
+    float4* rowrec; // (B*N, 2, 256) per-half row records over s > 0: {best, second, arg bits, -}
     float* simt0;   // (B*N, 256) sim[t,0]
-    float* colmax;  // (B*N, 256) column maxima
+    float* colmax;  // (B*N, 256) column maxima over t > 0
     float* sim0s;   // (B*N, 256) sim[0,s]
-    int32_t* counter;  // [0]=#entries [1]=#rows [2]=#cols
-    uint32_t* flags;   // fix-up entries: bn<<9 | kind<<8 | index
+    int32_t* counter;  // [0]=#full entries [1]=#candidate rows [2]=#full rows [3]=#full columns
+    uint2* flags;      // candidate-row entries {bn, t<<8 | s}
+    uint2* full;       // full row/column entries {bn, kind<<16 | index<<8}
     size_t total;
 };
 
@@ -72,12 +74,14 @@ __host__ S1Ws carve(void* base, int B, int N, int C) {
     w.qh = (_Float16*)take((size_t)B * C * P * 2);
     w.qf = (float*)take((size_t)B * C * P * 4);
     w.m16 = (float*)take((size_t)B * P * 4);
-    w.rowmax = (float*)take(BN * 2 * P * 4);
+    w.denom = (float*)take((size_t)B * P * 4);
+    w.rowrec = (float4*)take(BN * 2 * P * 16);
     w.simt0 = (float*)take(BN * P * 4);
     w.colmax = (float*)take(BN * P * 4);
     w.sim0s = (float*)take(BN * P * 4);
     w.counter = (int32_t*)take(64);
-    w.flags = (uint32_t*)take(BN * 2 * P * 4);
+    w.flags = (uint2*)take(BN * P * 8);
+    w.full = (uint2*)take(BN * 2 * P * 8);
     w.total = off;
     return w;
 }
@@ -85,41 +89,69 @@ __host__ S1Ws carve(void* base, int B, int N, int C) {
 // ---------------------------------------------------------------------------
 // Query pre-pack: F.normalize(tar_feat, dim=1) (matching.py:40), the nearest
 // 16x16 resample of the mask (matching.py:38-39) and the row mask multiply
-// (matching.py:48) folded into the A operand.  One workgroup per crop.
+// (matching.py:48) folded into the A operand.
+//   s1_qnorm : grid (B,4)   — ||q_t|| for 64 patches per workgroup, fixed-order reduction
+//   s1_qpack : grid (B,C/32) — 32 channels x 256 patches per workgroup
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void s1_prepack(const float* __restrict__ query,
-                                                  const float* __restrict__ mask, int mh, int mw,
-                                                  int C, _Float16* __restrict__ qh,
-                                                  float* __restrict__ qf, float* __restrict__ m16) {
-    const int b = blockIdx.x, t = threadIdx.x;
-    // nearest: src = min(floor(dst * (float)in/out), in-1)   (ATen nearest_idx)
-    const int py = t >> 4, px = t & 15;
-    const float sy = (float)mh / 16.0f, sx = (float)mw / 16.0f;
-    int iy = (int)floorf((float)py * sy);
-    int ix = (int)floorf((float)px * sx);
-    iy = iy < mh - 1 ? iy : mh - 1;
-    ix = ix < mw - 1 ? ix : mw - 1;
-    const float m = mask[((size_t)b * mh + iy) * mw + ix];
-    m16[b * P + t] = m;
-
+__global__ __launch_bounds__(1024) void s1_qnorm(const float* __restrict__ query,
+                                                 const float* __restrict__ mask, int mh, int mw,
+                                                 int C, float* __restrict__ denom,
+                                                 float* __restrict__ m16) {
+    __shared__ float part[16][64];
+    const int b = blockIdx.x, tq = blockIdx.y;
+    const int tl = threadIdx.x & 63, cs = threadIdx.x >> 6;
+    const int t = tq * 64 + tl;
     const float* q = query + (size_t)b * C * P + t;
     float ss = 0.f;
-    for (int c = 0; c < C; ++c) {
-        float v = q[(size_t)c * P];
-        ss = fmaf(v, v, ss);
+    for (int c0 = cs; c0 < C; c0 += 64) {  // this thread: channels == cs (mod 16); C % 64 == 0
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = q[(size_t)(c0 + 16 * j) * P];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ss = fmaf(v[j], v[j], ss);
     }
-    const float denom = fmaxf(sqrtf(ss), 1e-12f);
+    part[cs][tl] = ss;
+    __syncthreads();
+    if (cs == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tot += part[j][tl];
+        denom[b * P + t] = fmaxf(sqrtf(tot), 1e-12f);
+        // nearest: src = min(floor(dst * (float)in/out), in-1)   (ATen nearest_idx)
+        const int py = t >> 4, px = t & 15;
+        const float sy = (float)mh / 16.0f, sx = (float)mw / 16.0f;
+        int iy = (int)floorf((float)py * sy);
+        int ix = (int)floorf((float)px * sx);
+        iy = iy < mh - 1 ? iy : mh - 1;
+        ix = ix < mw - 1 ? ix : mw - 1;
+        m16[b * P + t] = mask[((size_t)b * mh + iy) * mw + ix];
+    }
+}
+
+__global__ __launch_bounds__(256) void s1_qpack(const float* __restrict__ query,
+                                                const float* __restrict__ denom,
+                                                const float* __restrict__ m16, int C,
+                                                _Float16* __restrict__ qh, float* __restrict__ qf) {
+    const int b = blockIdx.x, ks = blockIdx.y, t = threadIdx.x;
     const int KT = C >> 5;
+    const float d = denom[b * P + t], m = m16[b * P + t];
+    const float* q = query + ((size_t)b * C + ks * 32) * P + t;
+    float* qo = qf + ((size_t)b * C + ks * 32) * P + t;
     const int tb = t >> 5, tl = t & 31;
-    for (int c8 = 0; c8 < C; c8 += 8) {
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) v[j] = q[(size_t)j * P];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        v[j] = (v[j] / d) * m;
+        qo[(size_t)j * P] = v[j];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // 8 consecutive channels -> one 16-byte A-fragment piece
         h8 pk;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = (q[(size_t)(c8 + j) * P] / denom) * m;
-            qf[((size_t)b * C + c8 + j) * P + t] = v;
-            pk[j] = (_Float16)v;
-        }
-        const int ks = c8 >> 5, kh = (c8 >> 4) & 1, hh = (c8 >> 3) & 1;
+        for (int j = 0; j < 8; ++j) pk[j] = (_Float16)v[g * 8 + j];
+        const int kh = g >> 1, hh = g & 1;
         const size_t off = ((((size_t)b * KT + ks) * 2 + kh) * 8 + tb) * 512 + (tl + 32 * hh) * 8;
         *(h8*)(qh + off) = pk;
     }
@@ -161,7 +193,7 @@ template <int MODE>
 __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank,
                                                   const _Float16* __restrict__ qh,
                                                   const float* __restrict__ qf, int B, int N, int C,
-                                                  float* __restrict__ rowmax,
+                                                  float4* __restrict__ rowrec,
                                                   float* __restrict__ simt0,
                                                   float* __restrict__ colmax,
                                                   float* __restrict__ sim0s) {
@@ -221,22 +253,31 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
     else
         qptr = (const u4*)(qf + (size_t)b * C * P) + tid;              // + ks*1024 + j*256
 
-    f4 xa[K::XL], xb[K::XL];
-    u4 qa[4], qb[4];
+#ifndef PP_S1_XDEPTH
+#define PP_S1_XDEPTH 2
+#endif
+    f4 x0[K::XL], x1[K::XL];  // X tiles of the next PP_S1_XDEPTH K-steps, in flight
+#if PP_S1_XDEPTH == 3
+    f4 x2[K::XL];
+#endif
+    u4 qr[4];                              // query tile of the next K-step (L2 resident)
 
-#define LOAD_STEP(ks_, x_, q_)                                                        \
+#define LOAD_X(ks_, x_)                                                               \
     do {                                                                              \
         _Pragma("unroll") for (int j = 0; j < K::XL; ++j) x_[j] =                     \
-            *(const f4*)(xptr + (size_t)((ks_) * K::KS + 8 * j) * P);             \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) q_[j] =                         \
+            *(const f4*)(xptr + (size_t)((ks_) * K::KS + 8 * j) * P);                 \
+    } while (0)
+#define LOAD_Q(ks_)                                                                   \
+    do {                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) qr[j] =                         \
             qptr[(size_t)(ks_) * 1024 + j * 256];                                     \
     } while (0)
 
-#define STORE_STEP(Xs_, Qs_, x_, q_)                                                  \
+#define STORE_STEP(Xs_, Qs_, x_)                                                      \
     do {                                                                              \
         if (MODE == PP_MATCH_FAST) {                                                  \
             _Pragma("unroll") for (int j = 0; j < K::XL; ++j) {                       \
-                const f4 v = x_[j];                                               \
+                const f4 v = x_[j];                                                   \
                 ssq0 = fmaf(v.x, v.x, ssq0);                                          \
                 ssq1 = fmaf(v.y, v.y, ssq1);                                          \
                 ssq2 = fmaf(v.z, v.z, ssq2);                                          \
@@ -250,10 +291,21 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
             }                                                                         \
         } else {                                                                      \
             _Pragma("unroll") for (int j = 0; j < K::XL; ++j)                         \
-                *(f4*)((Xs_) + ((8 * j + 2 * w + lh) * 128 + 4 * l31) * 4) = x_[j]; \
+                *(f4*)((Xs_) + ((8 * j + 2 * w + lh) * 128 + 4 * l31) * 4) = x_[j];   \
         }                                                                             \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                 \
-            *(u4*)((Qs_) + (j * 256 + tid) * 16) = q_[j];                          \
+            *(u4*)((Qs_) + (j * 256 + tid) * 16) = qr[j];                             \
+    } while (0)
+
+// one K-step: publish tile ks (registers -> LDS buffer ks&1), refill the registers with
+// tiles ks+XDEPTH (X) and ks+1 (Q), one barrier, MFMAs on the published tile
+#define STEP(ks_, x_, Xs_, Qs_)                                                       \
+    do {                                                                              \
+        STORE_STEP(Xs_, Qs_, x_);                                                     \
+        if ((ks_) + PP_S1_XDEPTH < KT) LOAD_X((ks_) + PP_S1_XDEPTH, x_);                                    \
+        if ((ks_) + 1 < KT) LOAD_Q((ks_) + 1);                                        \
+        __syncthreads();                                                              \
+        mfma_step(Xs_, Qs_);                                                          \
     } while (0)
 
     auto mfma_step = [&](const char* Xs, const char* Qs) __attribute__((always_inline)) {
@@ -309,20 +361,35 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
         }
     };
 
-    // ---- main loop: register prefetch two K-steps ahead, LDS double buffer, one barrier/step
-    LOAD_STEP(0, xa, qa);
-    LOAD_STEP(1, xb, qb);
-    for (int ks = 0; ks < KT; ks += 2) {
-        STORE_STEP(Xs0, Qs0, xa, qa);
-        if (ks + 2 < KT) LOAD_STEP(ks + 2, xa, qa);
-        __syncthreads();
-        mfma_step(Xs0, Qs0);
-        STORE_STEP(Xs1, Qs1, xb, qb);
-        if (ks + 3 < KT) LOAD_STEP(ks + 3, xb, qb);
-        __syncthreads();
-        mfma_step(Xs1, Qs1);
+    // ---- main loop: X prefetched XDEPTH K-steps ahead in registers (Q one step: it is L2
+    //      resident), LDS double buffer, one barrier per K-step.  KT is even (C % 64 == 0).
+    LOAD_X(0, x0);
+    LOAD_X(1, x1);
+#if PP_S1_XDEPTH == 3
+    if (2 < KT) LOAD_X(2, x2);
+    LOAD_Q(0);
+    for (int ks = 0; ks < KT; ks += 6) {  // 6 = lcm(3 register sets, 2 LDS buffers)
+        STEP(ks, x0, Xs0, Qs0);
+        STEP(ks + 1, x1, Xs1, Qs1);
+        if (ks + 2 < KT) {
+            STEP(ks + 2, x2, Xs0, Qs0);
+            STEP(ks + 3, x0, Xs1, Qs1);
+        }
+        if (ks + 4 < KT) {
+            STEP(ks + 4, x1, Xs0, Qs0);
+            STEP(ks + 5, x2, Xs1, Qs1);
+        }
     }
-#undef LOAD_STEP
+#else
+    LOAD_Q(0);
+    for (int ks = 0; ks < KT; ks += 2) {
+        STEP(ks, x0, Xs0, Qs0);
+        STEP(ks + 1, x1, Xs1, Qs1);
+    }
+#endif
+#undef STEP
+#undef LOAD_X
+#undef LOAD_Q
 #undef STORE_STEP
     __syncthreads();
 
@@ -359,7 +426,8 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
     }
     __syncthreads();
 
-    // 2. scale columns, 3. column maxima over this wave's 128 rows
+    // 2. scale columns, 3. column maxima over this wave's 128 rows, row t = 0 excluded
+    //    (i2[s] != 0  <=>  max_{t>0} sim[t,s] > sim[0,s]); row 0 is tb 0, register 0, lanes 0..31
     float cm[2];
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
@@ -370,20 +438,23 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 acc[tb][sb][e] *= r;
-                m = fmaxf(m, acc[tb][sb][e]);
+                if (tb != 0 || e != 0) m = fmaxf(m, acc[tb][sb][e]);
             }
+        if (!(wr == 0 && lh == 0)) m = fmaxf(m, acc[0][sb][0]);
         cm[sb] = fmaxf(m, __shfl_xor(m, 32));
     }
     if (lh == 0) {
         colp[wr * 128 + wc * 64 + l31] = cm[0];
         colp[wr * 128 + wc * 64 + 32 + l31] = cm[1];
-        if (wr == 0) {  // row t = 0 lives in tb 0, register 0, lanes 0..31
+        if (wr == 0) {
             sim0[wc * 64 + l31] = acc[0][0][0];
             sim0[wc * 64 + 32 + l31] = acc[0][1][0];
         }
     }
 
-    // 4. row maxima over this workgroup's 128 columns: transpose through LDS, two rounds
+    // 4. row maxima over this workgroup's 128 columns, column s = 0 excluded
+    //    (i1[t] != 0  <=>  max_{s>0} sim[t,s] > sim[t,0]): transpose through LDS, two rounds
+    const bool zlane = (half == 0 && wc == 0 && l31 == 0);
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
 #pragma unroll
@@ -392,23 +463,35 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rl = tbb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                T[(w * 64 + rl) * TROW + l31] = fmaxf(acc[tb][0][e], acc[tb][1][e]);
+                // column s = 0 (half 0, wc 0, lane column 0, sb 0) stays out of the row maximum
+                T[(w * 64 + rl) * TROW + l31] =
+                    zlane ? acc[tb][1][e] : fmaxf(acc[tb][0][e], acc[tb][1][e]);
                 if (wc == 0 && l31 == 0) st0[wr * 128 + round * 64 + rl] = acc[tb][0][e];
             }
         }
         __syncthreads();
         if (tid < 128) {
+            // Row record over this half's 64 transpose entries (entry = max of columns s, s+32):
+            //   .x best entry   .y second best entry   .z column s of the best entry (int bits)
             const int wrr = tid >> 6, rl = tid & 63;
-            const float4* r0 = (const float4*)(T + ((2 * wrr) * 64 + rl) * TROW);
-            const float4* r1 = (const float4*)(T + ((2 * wrr + 1) * 64 + rl) * TROW);
-            float m = -INFINITY;
+            const float* r0 = T + ((2 * wrr) * 64 + rl) * TROW;
+            const float* r1 = T + ((2 * wrr + 1) * 64 + rl) * TROW;
+            float a1 = -INFINITY, a2 = -INFINITY;
+            int p1 = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float4 u = r0[i], v = r1[i];
-                m = fmaxf(m, fmaxf(fmaxf(u.x, u.y), fmaxf(u.z, u.w)));
-                m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            for (int i = 0; i < 16; ++i) {
+                const f4 u = *(const f4*)((i < 8 ? r0 : r1) + 4 * (i & 7));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float val = u[e];
+                    a2 = fmaxf(a2, fminf(a1, val));
+                    p1 = val > a1 ? 4 * i + e : p1;
+                    a1 = fmaxf(a1, val);
+                }
             }
-            rowmax[(bn * 2 + half) * P + wrr * 128 + round * 64 + rl] = m;
+            const int scol = half * 128 + (p1 >> 5) * 64 + (p1 & 31);
+            rowrec[(bn * 2 + half) * P + wrr * 128 + round * 64 + rl] =
+                make_float4(a1, a2, __int_as_float(scol), 0.f);
         }
         __syncthreads();
     }
@@ -421,78 +504,170 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
 
 // ---------------------------------------------------------------------------
 // FAST mode: find the rows/columns whose "arg-max is patch 0" decision is
-// within eps of a tie and queue them for exact re-evaluation.
+// within eps of a tie and queue them for exact fp32 re-evaluation.
+//   kind 0: row t, candidate columns {0, s, s+32}: every other column is more
+//           than 2*eps below the best of s/s+32, so the exact max over s > 0 is
+//           one of them
+//   kind 1: row t, all columns        kind 2: column s, all rows
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void s1_detect(const float* __restrict__ m16, int N, float eps,
-                                                 const float* __restrict__ rowmax,
+                                                 const float4* __restrict__ rowrec,
                                                  const float* __restrict__ simt0,
                                                  const float* __restrict__ colmax,
                                                  const float* __restrict__ sim0s,
                                                  int32_t* __restrict__ counter,
-                                                 uint32_t* __restrict__ flags) {
+                                                 uint2* __restrict__ flags,
+                                                 uint2* __restrict__ full) {
     const size_t bn = blockIdx.x;
     const int b = (int)(bn / N), i = threadIdx.x;
     const float m = m16[b * P + i];
     if (m == 0.f) return;  // mask_all[i] = 0 whatever the decisions are
-    const float rm = fmaxf(rowmax[(bn * 2) * P + i], rowmax[(bn * 2 + 1) * P + i]);
+    const float4 r0 = rowrec[(bn * 2) * P + i], r1 = rowrec[(bn * 2 + 1) * P + i];
+    const float rm = fmaxf(r0.x, r1.x);  // best over s > 0
     if (fabsf(rm - simt0[bn * P + i]) <= eps) {
-        const int k = atomicAdd(&counter[0], 1);
-        flags[k] = ((uint32_t)bn << 9) | (uint32_t)i;
-        atomicAdd(&counter[1], 1);
+        const bool w0 = r0.x >= r1.x;
+        const float second = fmaxf(w0 ? r1.x : r0.x, w0 ? r0.y : r1.y);
+        const int scol = __float_as_int(w0 ? r0.z : r1.z);
+        if (second < rm - 2.f * eps) {
+            const int k = atomicAdd(&counter[1], 1);
+            flags[k] = make_uint2((uint32_t)bn, ((uint32_t)i << 8) | (uint32_t)scol);
+        } else {
+            const int k = atomicAdd(&counter[0], 1);
+            full[k] = make_uint2((uint32_t)bn, (1u << 16) | ((uint32_t)i << 8));
+            atomicAdd(&counter[2], 1);
+        }
     }
     if (fabsf(colmax[bn * P + i] - sim0s[bn * P + i]) <= eps) {
         const int k = atomicAdd(&counter[0], 1);
-        flags[k] = ((uint32_t)bn << 9) | 256u | (uint32_t)i;
-        atomicAdd(&counter[2], 1);
+        full[k] = make_uint2((uint32_t)bn, (2u << 16) | ((uint32_t)i << 8));
+        atomicAdd(&counter[3], 1);
     }
 }
 
-// Exact fp32 re-evaluation of one row (all s for query patch i) or one column
-// (all t for template patch i): the same c-ordered fma chain as EXACT mode.
-__global__ __launch_bounds__(256) void s1_fixup(const float* __restrict__ bank,
-                                                const float* __restrict__ qf, int N, int C,
-                                                const int32_t* __restrict__ counter,
-                                                const uint32_t* __restrict__ flags,
-                                                float* __restrict__ rowmax,
-                                                float* __restrict__ simt0,
-                                                float* __restrict__ colmax,
-                                                float* __restrict__ sim0s) {
-    __shared__ float wmax[4];
-    const int cnt = counter[0];
-    const int tid = threadIdx.x;
-    for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
-        const uint32_t f = flags[e];
-        const size_t bn = f >> 9;
-        const int kind = (f >> 8) & 1, i = f & 255;
+// Exact re-evaluation.  The arithmetic repeats EXACT mode's: the dot product is the
+// c-ordered fp32 fma chain of v_mfma_f32_32x32x2_f32, the column norm is the sum of an
+// even-channel and an odd-channel fma chain, sim = dot * (1 / max(sqrt(ss), 1e-12)).
+//
+// s1_fixup_rows: one wave per candidate-row entry; the wave stages 4 channel vectors
+// (q[:,t], x[:,0], x[:,s+32], x[:,s]) in LDS with all loads in flight at once, then
+// three lanes run the chains.
+__global__ __launch_bounds__(256) void s1_fixup_rows(const float* __restrict__ bank,
+                                                     const float* __restrict__ qf, int N, int C,
+                                                     const int32_t* __restrict__ counter,
+                                                     const uint2* __restrict__ flags,
+                                                     float4* __restrict__ rowrec,
+                                                     float* __restrict__ simt0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cnt = counter[1];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* L = (float*)smem + (size_t)wv * 4 * C;  // [4][C]: q, x[:,0], x[:,s+32], x[:,s]
+    for (int e = blockIdx.x * 4 + wv; e < cnt; e += gridDim.x * 4) {
+        const uint2 f = flags[e];
+        const size_t bn = f.x;
+        const int i = (f.y >> 8) & 255, sc = f.y & 255;
         const int b = (int)(bn / N);
         const float* X = bank + bn * (size_t)C * P;
         const float* Q = qf + (size_t)b * C * P;
-        float dot = 0.f, ss = 0.f;
-        if (kind == 0) {  // row i: thread = template patch s
-            for (int c = 0; c < C; ++c) {
-                const float x = X[(size_t)c * P + tid];
-                dot = fmaf(Q[(size_t)c * P + i], x, dot);
-                ss = fmaf(x, x, ss);
+        const int cols[3] = {0, sc + 32, sc};
+        for (int c0 = 0; c0 < C; c0 += 64 * 4) {
+            float vq[4], vx[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // 16 loads in flight; the tail re-reads channel C-1
+                const int c = min(c0 + 64 * j + lane, C - 1);
+                vq[j] = Q[(size_t)c * P + i];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) vx[k][j] = X[(size_t)c * P + cols[k]];
             }
-        } else {  // column i: thread = query patch t
-            for (int c = 0; c < C; ++c) {
-                const float x = X[(size_t)c * P + i];
-                dot = fmaf(Q[(size_t)c * P + tid], x, dot);
-                ss = fmaf(x, x, ss);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + 64 * j + lane;
+                if (c < C) {
+                    L[c] = vq[j];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) L[(k + 1) * C + c] = vx[k][j];
+                }
             }
         }
-        const float sim = dot * (1.0f / fmaxf(sqrtf(ss), 1e-12f));
-        float m = sim;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS stores are done
+        __builtin_amdgcn_wave_barrier();
+        float sim = -INFINITY;
+        if (lane < 3) {
+            const float* xv = L + (lane + 1) * C;
+            float dot = 0.f, se = 0.f, so = 0.f;
+#pragma unroll 8
+            for (int c = 0; c < C; c += 2) {
+                const float x0 = xv[c], x1 = xv[c + 1];
+                dot = fmaf(L[c], x0, dot);
+                dot = fmaf(L[c + 1], x1, dot);
+                se = fmaf(x0, x0, se);
+                so = fmaf(x1, x1, so);
+            }
+            sim = dot * (1.0f / fmaxf(sqrtf(se + so), 1e-12f));
+        }
+        const float s0 = __shfl(sim, 0), s1 = __shfl(sim, 1), s2 = __shfl(sim, 2);
+        const float mx = sc == 0 ? s1 : fmaxf(s1, s2);  // sc == 0: entry {0, 32}, 0 excluded
+        if (lane == 0) {
+            rowrec[(bn * 2) * P + i].x = mx;
+            rowrec[(bn * 2 + 1) * P + i].x = -INFINITY;
+            simt0[bn * P + i] = s0;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// s1_fixup_full: one workgroup per entry, thread o = output index (template patch for a
+// row entry, query patch for a column entry); 32 channels of loads in flight per thread.
+__global__ __launch_bounds__(256) void s1_fixup_full(const float* __restrict__ bank,
+                                                     const float* __restrict__ qf, int N, int C,
+                                                     const int32_t* __restrict__ counter,
+                                                     const uint2* __restrict__ full,
+                                                     float4* __restrict__ rowrec,
+                                                     float* __restrict__ simt0,
+                                                     float* __restrict__ colmax,
+                                                     float* __restrict__ sim0s) {
+    __shared__ float wmax[4];
+    const int cnt = counter[0];
+    const int o = threadIdx.x;
+    for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
+        const uint2 f = full[e];
+        const size_t bn = f.x;
+        const int kind = (int)(f.y >> 16), i = (f.y >> 8) & 255;
+        const int b = (int)(bn / N);
+        const float* X = bank + bn * (size_t)C * P;
+        const float* Q = qf + (size_t)b * C * P;
+        // row entry: a = q[:,i] (uniform), x = X[:,o];  column entry: a = q[:,o], x = X[:,i]
+        const float* ap = Q + (kind == 1 ? i : o);
+        const float* xp = X + (kind == 1 ? o : i);
+        float dot = 0.f, se = 0.f, so = 0.f;
+        for (int c0 = 0; c0 < C; c0 += 32) {
+            float a[32], x[32];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            for (int j = 0; j < 32; ++j) {
+                a[j] = ap[(size_t)(c0 + j) * P];
+                x[j] = xp[(size_t)(c0 + j) * P];
+            }
+#pragma unroll
+            for (int j = 0; j < 32; j += 2) {
+                dot = fmaf(a[j], x[j], dot);
+                dot = fmaf(a[j + 1], x[j + 1], dot);
+                se = fmaf(x[j], x[j], se);
+                so = fmaf(x[j + 1], x[j + 1], so);
+            }
+        }
+        const float sim = dot * (1.0f / fmaxf(sqrtf(se + so), 1e-12f));
+        float m = o == 0 ? -INFINITY : sim;  // index 0 is the other side of the decision
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
         __syncthreads();
-        if ((tid & 63) == 0) wmax[tid >> 6] = m;
+        if ((o & 63) == 0) wmax[o >> 6] = m;
         __syncthreads();
-        if (tid == 0) {
+        if (o == 0) {
             const float mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            if (kind == 0) {
-                rowmax[(bn * 2) * P + i] = mx;
-                rowmax[(bn * 2 + 1) * P + i] = -INFINITY;
+            if (kind == 1) {
+                rowrec[(bn * 2) * P + i].x = mx;
+                rowrec[(bn * 2 + 1) * P + i].x = -INFINITY;
                 simt0[bn * P + i] = sim;
             } else {
                 colmax[bn * P + i] = mx;
@@ -504,7 +679,7 @@ __global__ __launch_bounds__(256) void s1_fixup(const float* __restrict__ bank,
 
 // sim_avg (matching.py:53-66).  One workgroup per (b,n).
 __global__ __launch_bounds__(256) void s1_finalize(const float* __restrict__ m16, int N,
-                                                   const float* __restrict__ rowmax,
+                                                   const float4* __restrict__ rowrec,
                                                    const float* __restrict__ simt0,
                                                    const float* __restrict__ colmax,
                                                    const float* __restrict__ sim0s,
@@ -513,8 +688,10 @@ __global__ __launch_bounds__(256) void s1_finalize(const float* __restrict__ m16
     const size_t bn = blockIdx.x;
     const int b = (int)(bn / N), i = threadIdx.x;
     const float m = m16[b * P + i];
-    const float rm = fmaxf(rowmax[(bn * 2) * P + i], rowmax[(bn * 2 + 1) * P + i]);
-    const float rnz = rm > simt0[bn * P + i] ? 1.f : 0.f;
+    const float rme = fmaxf(rowrec[(bn * 2) * P + i].x, rowrec[(bn * 2 + 1) * P + i].x);
+    const float st0 = simt0[bn * P + i];
+    const float rnz = rme > st0 ? 1.f : 0.f;  // idx_tar2src != 0 (first max wins ties)
+    const float rm = fmaxf(rme, st0);         // score_tar2src
     const float cnz = colmax[bn * P + i] > sim0s[bn * P + i] ? 1.f : 0.f;
     const float mall = m * cnz * rnz;
     float s = rm * mall, ms = mall;
@@ -612,35 +789,47 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask, i
     if (!bank || !query || !mask || !sim_avg || !workspace) return PP_EINVAL;
     if (B <= 0 || N <= 0 || C <= 0 || mask_h <= 0 || mask_w <= 0) return PP_EINVAL;
     if (mode != PP_MATCH_EXACT && mode != PP_MATCH_FAST) return PP_EINVAL;
-    if (C % 64 != 0) return PP_EINVAL;
+    if (C % 64 != 0 || C > 2048) return PP_EINVAL;
     if ((size_t)B * N >= (1u << 23)) return PP_EINVAL;
     if (((uintptr_t)workspace & 255) != 0) return PP_EWORKSPACE;
     if (((uintptr_t)bank & 15) != 0) return PP_EINVAL;
     S1Ws w = carve(workspace, B, N, C);
     if (workspace_bytes < w.total) return PP_EWORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
-    if (eps <= 0.f) eps = 2e-4f;
+    // default band: 8 sigma of the fp16 rounding error of a score difference,
+    // sigma ~ sqrt(2) * 2.8e-4 / sqrt(C) for unit vectors with spread-out energy
+    if (eps <= 0.f) eps = 3.2e-3f / sqrtf((float)C);
 
-    hipLaunchKernelGGL(s1_prepack, dim3(B), dim3(256), 0, stream, query, mask, mask_h, mask_w, C,
-                       w.qh, w.qf, w.m16);
+    hipLaunchKernelGGL(s1_qnorm, dim3(B, 4), dim3(1024), 0, stream, query, mask, mask_h, mask_w, C,
+                       w.denom, w.m16);
+    hipLaunchKernelGGL(s1_qpack, dim3(B, C / 32), dim3(256), 0, stream, query, w.denom, w.m16, C,
+                       w.qh, w.qf);
     const int grid = (B >= 8) ? 8 * ((B + 7) / 8) * 2 * N : B * 2 * N;
     if (mode == PP_MATCH_FAST) {
-        hipLaunchKernelGGL(s1_main<PP_MATCH_FAST>, dim3(grid), dim3(256), SMEM_BYTES, stream, bank,
-                           w.qh, w.qf, B, N, C, w.rowmax, w.simt0, w.colmax, w.sim0s);
+        {
+            PpProfScope prof(stream);  // roofline kernel of stage 1 (bench.py)
+            hipLaunchKernelGGL(s1_main<PP_MATCH_FAST>, dim3(grid), dim3(256), SMEM_BYTES, stream,
+                               bank, w.qh, w.qf, B, N, C, w.rowrec, w.simt0, w.colmax, w.sim0s);
+        }
         PP_CHECK_HIP(hipMemsetAsync(w.counter, 0, 64, stream));
-        hipLaunchKernelGGL(s1_detect, dim3(B * N), dim3(256), 0, stream, w.m16, N, eps, w.rowmax,
-                           w.simt0, w.colmax, w.sim0s, w.counter, w.flags);
-        hipLaunchKernelGGL(s1_fixup, dim3(2048), dim3(256), 0, stream, bank, w.qf, N, C, w.counter,
-                           w.flags, w.rowmax, w.simt0, w.colmax, w.sim0s);
+        hipLaunchKernelGGL(s1_detect, dim3(B * N), dim3(256), 0, stream, w.m16, N, eps, w.rowrec,
+                           w.simt0, w.colmax, w.sim0s, w.counter, w.flags, w.full);
+        hipLaunchKernelGGL(s1_fixup_rows, dim3(512), dim3(256), (size_t)4 * 4 * C * sizeof(float),
+                           stream, bank, w.qf, N, C, w.counter, w.flags, w.rowrec, w.simt0);
+        hipLaunchKernelGGL(s1_fixup_full, dim3(512), dim3(256), 0, stream, bank, w.qf, N, C,
+                           w.counter, w.full, w.rowrec, w.simt0, w.colmax, w.sim0s);
         if (stats)
-            PP_CHECK_HIP(hipMemcpyAsync(stats, w.counter + 1, 2 * sizeof(int32_t),
+            PP_CHECK_HIP(hipMemcpyAsync(stats, w.counter + 1, 3 * sizeof(int32_t),
                                         hipMemcpyDeviceToDevice, stream));
     } else {
-        hipLaunchKernelGGL(s1_main<PP_MATCH_EXACT>, dim3(grid), dim3(256), SMEM_BYTES, stream, bank,
-                           w.qh, w.qf, B, N, C, w.rowmax, w.simt0, w.colmax, w.sim0s);
-        if (stats) PP_CHECK_HIP(hipMemsetAsync(stats, 0, 2 * sizeof(int32_t), stream));
+        {
+            PpProfScope prof(stream);
+            hipLaunchKernelGGL(s1_main<PP_MATCH_EXACT>, dim3(grid), dim3(256), SMEM_BYTES, stream,
+                               bank, w.qh, w.qf, B, N, C, w.rowrec, w.simt0, w.colmax, w.sim0s);
+        }
+        if (stats) PP_CHECK_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(int32_t), stream));
     }
-    hipLaunchKernelGGL(s1_finalize, dim3(B * N), dim3(256), 0, stream, w.m16, N, w.rowmax, w.simt0,
+    hipLaunchKernelGGL(s1_finalize, dim3(B * N), dim3(256), 0, stream, w.m16, N, w.rowrec, w.simt0,
                        w.colmax, w.sim0s, sim_avg);
     return pp_last_launch();
 }

@@ -61,3 +61,77 @@ def test_mask_variants(mode, mask):
     ref, got = _check(2, 6, 384, seed=5, mode=mode, mask=mask)
     if mask == "zeros":
         assert torch.count_nonzero(got) == 0
+
+
+@gpu
+@pytest.mark.parametrize("mask", ["bernoulli", "disk"])
+def test_fast_mode_resolves_near_ties_like_exact_mode(mask):
+    """Plant near-ties with patch 0 in rows and columns: the fp16 pass cannot decide them,
+    the fix-up pass must, and then fast == exact far below one decision's weight (~4e-4)."""
+    from picopose_amd.utils import matching as hm
+
+    B, N, C = 2, 12, 384
+    bank, query, m = _inputs(B, N, C, 77, mask)
+    g = torch.Generator().manual_seed(78)
+    bank = bank.reshape(B, N, C, 256).clone()
+    query = query.reshape(B, C, 256).clone()
+    # template patches 5, 40, 200 become near-copies of template patch 0 (row decisions) ...
+    for s in (5, 40, 200):
+        bank[:, :, :, s] = bank[:, :, :, 0] * (1.0 + 2e-5 * torch.randn(B, N, C, generator=g))
+    # ... and query patches 7, 130 near-copies of query patch 0 (column decisions)
+    for t in (7, 130):
+        query[:, :, t] = query[:, :, 0] * (1.0 + 2e-5 * torch.randn(B, C, generator=g))
+    m[:, 0, 0] = 1.0  # keep query patch 0 unmasked so its row takes part in the column arg-max
+    m[:, 14 * 0, 14 * 7] = 1.0
+    m[:, 14 * 8, 14 * 2] = 1.0
+    bank = bank.reshape(B, N, C, 16, 16).cuda()
+    query = query.reshape(B, C, 16, 16).cuda()
+    m = m.cuda()
+    exact = hm.template_scores(bank, query, m, mode="exact")
+    fast, stats = hm.template_scores(bank, query, m, mode="fast", return_stats=True)
+    stats = stats.tolist()
+    assert stats[0] + stats[1] > 0, stats  # row fix-ups ran
+    assert stats[2] > 0, stats  # column fix-ups ran
+    assert (exact - fast).abs().max().item() <= 1e-5
+    # and without the fix-ups (eps ~ 0) the fp16 pass does get decisions wrong
+    raw = hm.template_scores(bank, query, m, mode="fast", eps=1e-12)
+    assert (exact - raw).abs().max().item() > 1e-4
+
+
+@gpu
+def test_matching_templates_api_matches_oracle_topk():
+    from picopose_amd.utils import matching as hm
+
+    bank, query, m = _inputs(4, 42, 384, 11, "disk")
+    rs, ri = om.matching_templates(bank, query, None, m, topk=5)
+    for mode in ("exact", "fast"):
+        gs, gi = hm.matching_templates(bank.cuda(), query.cuda(), None, m.cuda(), topk=5, mode=mode)
+        assert gi.dtype == torch.int64 and gs.dtype == torch.float32
+        assert torch.equal(gi.cpu(), ri), mode  # gaps between adjacent scores here are >> 1e-5
+        assert (gs.cpu() - rs).abs().max().item() <= 1e-5
+
+
+@gpu
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_golden_fixtures_from_the_reference(mode, golden_dir):
+    """The reference's own outputs (tests/golden, generated from /root/reference)."""
+    import os
+
+    import numpy as np
+
+    from picopose_amd.utils import matching as hm
+
+    z = np.load(os.path.join(golden_dir, "stage1_matching_templates.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    for name in names:
+        c = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(name + "/")}
+        bank, query, mask = (torch.from_numpy(c[k]) for k in ("bank", "query", "mask"))
+        k = int(c["topk"])
+        gs, gi = hm.matching_templates(bank.cuda(), query.cuda(), None, mask.cuda(), topk=k, mode=mode)
+        gs, gi = gs.cpu().numpy(), gi.cpu().numpy()
+        tol = 2e-6 if mode == "exact" else 2e-5
+        assert np.abs(gs - c["score"]).max() <= tol, (name, np.abs(gs - c["score"]).max())
+        if name == "all_masked":
+            assert np.count_nonzero(gs) == 0
+            continue  # all scores tie at 0: torch's tie order is unspecified, ours is lowest-id-first
+        assert np.array_equal(gi, c["index"]), name
