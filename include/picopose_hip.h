@@ -63,8 +63,8 @@ int pp_prof_collect(float* out_ms, int max_out, int* count);
  * lower template id; pp_stage1_match is scores followed by topk.
  * `eps` is the half-width of the fast mode's re-evaluation band (ignored in
  * exact mode; <=0 selects the default 2e-4).
- * stats (optional, may be NULL): device int32[4] = {rows re-evaluated,
- * columns re-evaluated, 0, 0}.
+ * stats (optional, may be NULL): device int32[4] = {rows re-evaluated on their
+ * candidate columns, rows re-evaluated in full, columns re-evaluated, 0}.
  * ------------------------------------------------------------------------- */
 int pp_stage1_workspace_bytes(int B, int N, int C, size_t* bytes);
 

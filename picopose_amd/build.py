@@ -11,7 +11,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libpicopose_hip.so")
+# tuning experiments: PP_LIB_SUFFIX=_nt PP_HIPCC_FLAGS="-DPP_S1_NT=1" builds a side-by-side variant
+SUFFIX = os.environ.get("PP_LIB_SUFFIX", "")
+LIB = os.path.join(LIBDIR, f"libpicopose_hip{SUFFIX}.so")
 ARCH = "gfx950"
 
 
@@ -40,7 +42,7 @@ def build_lib(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     objs = []
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj" + SUFFIX)
     os.makedirs(objdir, exist_ok=True)
     procs = []
     for src in sources():
@@ -52,7 +54,8 @@ def build_lib(force=False, verbose=False):
             os.path.getmtime(os.path.join(HERE, "..", "include", "picopose_hip.h")),
         ):
             continue
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"]
+        cmd += os.environ.get("PP_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

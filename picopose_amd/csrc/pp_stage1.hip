@@ -42,11 +42,26 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
+#ifndef PP_S1_QDEPTH
+#define PP_S1_QDEPTH 1
+#endif
+#ifndef PP_S1_EPI
+#define PP_S1_EPI 0  // 1: tuning build that skips the epilogue (wrong results, K-loop ceiling)
+#endif
+#ifndef PP_S1_NT
+#define PP_S1_NT 0
+#endif
+#if PP_S1_NT
+#define PP_S1_LDX(p) __builtin_nontemporal_load(p)  // bank tiles are read once: keep them out of L2
+#else
+#define PP_S1_LDX(p) (*(p))
+#endif
+
 constexpr int P = 256;           // patches per image (16x16), fixed by the reference
 constexpr int XROW_F16 = 320;    // bytes per k-row of the fp16 X tile (256 + 64 pad:
                                  // the 4 rows of a ds_read_b64_tr_b16 block land on
                                  // disjoint 16-dword bank groups)
-constexpr int TROW = 36;         // floats per row of the epilogue transpose tile
+constexpr int TROW = 12;         // floats per row of the epilogue transpose tile (8 used)
 
 struct S1Ws {
     _Float16* qh;   // (B, C/32, 2, 8, 64, 8) fp16 A-fragment order, normalised*mask
@@ -57,9 +72,6 @@ struct S1Ws {
     float* simt0;   // (B*N, 256) sim[t,0]
     float* colmax;  // (B*N, 256) column maxima over t > 0
     float* sim0s;   // (B*N, 256) sim[0,s]
-    int32_t* counter;  // [0]=#full entries [1]=#candidate rows [2]=#full rows [3]=#full columns
-    uint2* flags;      // candidate-row entries {bn, t<<8 | s}
-    uint2* full;       // full row/column entries {bn, kind<<16 | index<<8}
     size_t total;
 };
 
@@ -79,9 +91,6 @@ __host__ S1Ws carve(void* base, int B, int N, int C) {
     w.simt0 = (float*)take(BN * P * 4);
     w.colmax = (float*)take(BN * P * 4);
     w.sim0s = (float*)take(BN * P * 4);
-    w.counter = (int32_t*)take(64);
-    w.flags = (uint2*)take(BN * P * 8);
-    w.full = (uint2*)take(BN * 2 * P * 8);
     w.total = off;
     return w;
 }
@@ -165,7 +174,7 @@ struct Cfg;
 template <>
 struct Cfg<PP_MATCH_EXACT> {
     static constexpr int KS = 16;                 // channels per K-step
-    static constexpr int XL = 2;                  // float4 X loads per thread per step
+    static constexpr int XL = 2;                  // 16-byte X loads per thread per step
     static constexpr int XS_BYTES = 16 * 128 * 4; // [16][128] fp32
     static constexpr int QS_BYTES = 16 * 256 * 4; // [16][256] fp32
 };
@@ -177,18 +186,28 @@ struct Cfg<PP_MATCH_FAST> {
     static constexpr int QS_BYTES = 16 * 1024;      // 16 fragment chunks of 1 KB
 };
 
-constexpr int EPI_T_BYTES = 4 * 64 * TROW * 4;  // 36864
-constexpr int EPI_RED = EPI_T_BYTES;            // float[8][128]
-constexpr int EPI_RS = EPI_RED + 8 * 128 * 4;   // float[128]
-constexpr int EPI_COLP = EPI_RS + 128 * 4;      // float[2][128]
+constexpr int EPI_T_BYTES = 4 * 128 * TROW * 4;   // float[4 waves][128 rows][TROW]
+constexpr int EPI_RED = EPI_T_BYTES;              // float[8][128]
+constexpr int EPI_RS = EPI_RED + 8 * 128 * 4;     // float[128]
+constexpr int EPI_COLP = EPI_RS + 128 * 4;        // float[2][128]
 constexpr int EPI_SIM0 = EPI_COLP + 2 * 128 * 4;  // float[128]
-constexpr int EPI_ST0 = EPI_SIM0 + 128 * 4;     // float[256]
+constexpr int EPI_ST0 = EPI_SIM0 + 128 * 4;       // float[256]
 constexpr int EPI_BYTES = EPI_ST0 + 256 * 4;
 constexpr int SMEM_BYTES = 53248;
 static_assert(EPI_BYTES <= SMEM_BYTES, "epilogue LDS overflow");
 static_assert(2 * Cfg<PP_MATCH_FAST>::XS_BYTES + 2 * Cfg<PP_MATCH_FAST>::QS_BYTES <= SMEM_BYTES, "");
 static_assert(2 * Cfg<PP_MATCH_EXACT>::XS_BYTES + 2 * Cfg<PP_MATCH_EXACT>::QS_BYTES <= SMEM_BYTES, "");
 
+// max with the value of lane^1 / lane^2 (DPP quad permutes, no LDS traffic)
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+}
+
+// One 256-thread workgroup (4 waves, 2x2) = (crop b, template n, half): all 256 query patches
+// x 128 template patches; each wave holds a 128x64 fp32 tile in 128 accumulator registers.
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank,
                                                   const _Float16* __restrict__ qh,
@@ -200,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
     using K = Cfg<MODE>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    // ---- workgroup -> (crop, template, half); crops of one XCD label stay together
+    // ---- workgroup -> (crop, template, half); crops of one XCD label (blockIdx % 8) stay
+    //      together so the crop's query operand is served by that XCD's L2
     int b, n, half;
     {
         const int bid = blockIdx.x;
@@ -226,7 +246,6 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
     const int l31 = lane & 31, lh = lane >> 5;
 
     const size_t bn = (size_t)b * N + n;
-    const float* Xg = bank + bn * (size_t)C * P + half * 128;
     const int KT = C / K::KS;
 
     char* Xs0 = smem;
@@ -246,34 +265,27 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
     float ssq0 = 0.f, ssq1 = 0.f, ssq2 = 0.f, ssq3 = 0.f;
 
     // per-thread global pointers of the K-step loads
-    const float* xptr = Xg + (size_t)(2 * w + lh) * P + 4 * l31;          // + (ks*KS + 8j)*P
-    const u4* qptr;
-    if (MODE == PP_MATCH_FAST)
-        qptr = (const u4*)(qh + (size_t)b * C * P) + tid;              // + ks*1024 + j*256
-    else
-        qptr = (const u4*)(qf + (size_t)b * C * P) + tid;              // + ks*1024 + j*256
+    const float* xptr = bank + bn * (size_t)C * P + half * 128 + (size_t)(2 * w + lh) * P + 4 * l31;
+    const u4* qptr = (MODE == PP_MATCH_FAST ? (const u4*)(qh + (size_t)b * C * P)
+                                            : (const u4*)(qf + (size_t)b * C * P)) + tid;
 
-#ifndef PP_S1_XDEPTH
-#define PP_S1_XDEPTH 2
+    f4 x0[K::XL], x1[K::XL];  // X tiles of the next two K-steps, in flight
+    u4 q0[4];                 // query tile(s) of the next K-step(s) (L2 / Infinity Cache)
+#if PP_S1_QDEPTH == 2
+    u4 q1[4];
 #endif
-    f4 x0[K::XL], x1[K::XL];  // X tiles of the next PP_S1_XDEPTH K-steps, in flight
-#if PP_S1_XDEPTH == 3
-    f4 x2[K::XL];
-#endif
-    u4 qr[4];                              // query tile of the next K-step (L2 resident)
 
 #define LOAD_X(ks_, x_)                                                               \
     do {                                                                              \
         _Pragma("unroll") for (int j = 0; j < K::XL; ++j) x_[j] =                     \
-            *(const f4*)(xptr + (size_t)((ks_) * K::KS + 8 * j) * P);                 \
+            PP_S1_LDX((const f4*)(xptr + (size_t)((ks_) * K::KS + 8 * j) * P));       \
     } while (0)
-#define LOAD_Q(ks_)                                                                   \
+#define LOAD_Q(ks_, q_)                                                               \
     do {                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) qr[j] =                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) q_[j] =                         \
             qptr[(size_t)(ks_) * 1024 + j * 256];                                     \
     } while (0)
-
-#define STORE_STEP(Xs_, Qs_, x_)                                                      \
+#define STORE_STEP(Xs_, Qs_, x_, q_)                                                    \
     do {                                                                              \
         if (MODE == PP_MATCH_FAST) {                                                  \
             _Pragma("unroll") for (int j = 0; j < K::XL; ++j) {                       \
@@ -294,19 +306,31 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
                 *(f4*)((Xs_) + ((8 * j + 2 * w + lh) * 128 + 4 * l31) * 4) = x_[j];   \
         }                                                                             \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                 \
-            *(u4*)((Qs_) + (j * 256 + tid) * 16) = qr[j];                             \
+            *(u4*)((Qs_) + (j * 256 + tid) * 16) = q_[j];                             \
     } while (0)
-
 // one K-step: publish tile ks (registers -> LDS buffer ks&1), refill the registers with
-// tiles ks+XDEPTH (X) and ks+1 (Q), one barrier, MFMAs on the published tile
-#define STEP(ks_, x_, Xs_, Qs_)                                                       \
+// tiles ks+2 (X) and ks+PP_S1_QDEPTH (Q), one barrier, MFMAs on the published tile
+#if PP_S1_QDEPTH == 2
+#define STEP(ks_, x_, q_, Xs_, Qs_)                                                   \
     do {                                                                              \
-        STORE_STEP(Xs_, Qs_, x_);                                                     \
-        if ((ks_) + PP_S1_XDEPTH < KT) LOAD_X((ks_) + PP_S1_XDEPTH, x_);                                    \
-        if ((ks_) + 1 < KT) LOAD_Q((ks_) + 1);                                        \
+        STORE_STEP(Xs_, Qs_, x_, q_);                                                 \
+        if ((ks_) + 2 < KT) {                                                         \
+            LOAD_X((ks_) + 2, x_);                                                    \
+            LOAD_Q((ks_) + 2, q_);                                                    \
+        }                                                                             \
         __syncthreads();                                                              \
         mfma_step(Xs_, Qs_);                                                          \
     } while (0)
+#else
+#define STEP(ks_, x_, q_, Xs_, Qs_)                                                   \
+    do {                                                                              \
+        STORE_STEP(Xs_, Qs_, x_, q0);                                                 \
+        if ((ks_) + 2 < KT) LOAD_X((ks_) + 2, x_);                                    \
+        if ((ks_) + 1 < KT) LOAD_Q((ks_) + 1, q0);                                    \
+        __syncthreads();                                                              \
+        mfma_step(Xs_, Qs_);                                                          \
+    } while (0)
+#endif
 
     auto mfma_step = [&](const char* Xs, const char* Qs) __attribute__((always_inline)) {
         if (MODE == PP_MATCH_FAST) {
@@ -361,37 +385,36 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
         }
     };
 
-    // ---- main loop: X prefetched XDEPTH K-steps ahead in registers (Q one step: it is L2
-    //      resident), LDS double buffer, one barrier per K-step.  KT is even (C % 64 == 0).
+    // ---- K loop: both operands prefetched two K-steps ahead in registers, LDS double buffer,
+    //      one barrier per K-step.  KT is even (C % 64 == 0).
     LOAD_X(0, x0);
+    LOAD_Q(0, q0);
     LOAD_X(1, x1);
-#if PP_S1_XDEPTH == 3
-    if (2 < KT) LOAD_X(2, x2);
-    LOAD_Q(0);
-    for (int ks = 0; ks < KT; ks += 6) {  // 6 = lcm(3 register sets, 2 LDS buffers)
-        STEP(ks, x0, Xs0, Qs0);
-        STEP(ks + 1, x1, Xs1, Qs1);
-        if (ks + 2 < KT) {
-            STEP(ks + 2, x2, Xs0, Qs0);
-            STEP(ks + 3, x0, Xs1, Qs1);
-        }
-        if (ks + 4 < KT) {
-            STEP(ks + 4, x1, Xs0, Qs0);
-            STEP(ks + 5, x2, Xs1, Qs1);
-        }
-    }
-#else
-    LOAD_Q(0);
-    for (int ks = 0; ks < KT; ks += 2) {
-        STEP(ks, x0, Xs0, Qs0);
-        STEP(ks + 1, x1, Xs1, Qs1);
-    }
+#if PP_S1_QDEPTH == 2
+    LOAD_Q(1, q1);
 #endif
+    for (int ks = 0; ks < KT; ks += 2) {
+        STEP(ks, x0, q0, Xs0, Qs0);
+        STEP(ks + 1, x1, q1, Xs1, Qs1);
+    }
 #undef STEP
 #undef LOAD_X
 #undef LOAD_Q
 #undef STORE_STEP
     __syncthreads();
+#if PP_S1_EPI == 1
+    {
+        float tsum = ssq0 + ssq1 + ssq2 + ssq3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tsum += acc[i][j][r];
+        simt0[bn * P + tid] = tsum;
+        return;
+    }
+#endif
 
     // ---------------------------------------------------------------- epilogue
     float* T = (float*)smem;
@@ -403,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
 
     // 1. column norms -> 1/max(||x_s||, 1e-12)   (F.normalize, matching.py:43)
     if (MODE == PP_MATCH_FAST) {
-        *(float4*)(red + (2 * w + lh) * 128 + 4 * l31) = make_float4(ssq0, ssq1, ssq2, ssq3);
+        *(f4*)(red + (2 * w + lh) * 128 + 4 * l31) = f4{ssq0, ssq1, ssq2, ssq3};
     } else {
         const float s0 = ssq0 + __shfl_xor(ssq0, 32);
         const float s1 = ssq1 + __shfl_xor(ssq1, 32);
@@ -453,47 +476,60 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
     }
 
     // 4. row maxima over this workgroup's 128 columns, column s = 0 excluded
-    //    (i1[t] != 0  <=>  max_{s>0} sim[t,s] > sim[t,0]): transpose through LDS, two rounds
-    const bool zlane = (half == 0 && wc == 0 && l31 == 0);
+    //    (i1[t] != 0  <=>  max_{s>0} sim[t,s] > sim[t,0]).
+    //    In registers: max over the two column blocks, then a two-step reduce-scatter over
+    //    the lane quad (DPP): afterwards lane q of a quad owns rows 4i+q and each value is the
+    //    max of 8 columns {c..c+3, c+32..c+35}, c = 4*(lane column / 4).  The 16 "entries" of
+    //    a row (8 per wave column) are transposed through LDS and scanned by one thread.
+    const bool zlane = (half == 0 && wc == 0 && l31 == 0);  // holds column s = 0 in sb 0
+    if (wc == 0 && l31 == 0) {
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {
+        for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-        for (int tbb = 0; tbb < 2; ++tbb) {
-            const int tb = round * 2 + tbb;
+            for (int e = 0; e < 16; ++e)
+                st0[wr * 128 + tb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh] = acc[tb][0][e];
+    }
+    {
+        const bool odd = lane & 1, bit1 = (lane >> 1) & 1;
+        const int q = lane & 3;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rl = tbb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                // column s = 0 (half 0, wc 0, lane column 0, sb 0) stays out of the row maximum
-                T[(w * 64 + rl) * TROW + l31] =
-                    zlane ? acc[tb][1][e] : fmaxf(acc[tb][0][e], acc[tb][1][e]);
-                if (wc == 0 && l31 == 0) st0[wr * 128 + round * 64 + rl] = acc[tb][0][e];
+        for (int i = 0; i < 16; ++i) {  // rows r = 4i..4i+3  (r = tb*16 + e)
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * i + k, tb = r >> 4, e = r & 15;
+                v[k] = zlane ? acc[tb][1][e] : fmaxf(acc[tb][0][e], acc[tb][1][e]);
+            }
+            const float u0 = fmaxf(odd ? v[1] : v[0], dpp_xor1(odd ? v[0] : v[1]));  // row 4i + odd
+            const float u1 = fmaxf(odd ? v[3] : v[2], dpp_xor1(odd ? v[2] : v[3]));  // row 4i+2+odd
+            const float wv = fmaxf(bit1 ? u1 : u0, dpp_xor2(bit1 ? u0 : u1));        // row 4i + q
+            // row r = 4i+q: tb = i>>2, e = 4*(i&3)+q -> t_local = tb*32 + (e&3) + 8*(e>>2) + 4*lh
+            const int tl = (i >> 2) * 32 + q + 8 * (i & 3) + 4 * lh;
+            T[(w * 128 + tl) * TROW + (l31 >> 2)] = wv;
+        }
+    }
+    __syncthreads();
+    {
+        // Row record over this half's 16 entries:
+        //   .x best entry   .y second best entry   .z first column of the best entry (int bits)
+        const int wrr = tid >> 7, tl = tid & 127;
+        const float* r0 = T + ((2 * wrr) * 128 + tl) * TROW;
+        const float* r1 = T + ((2 * wrr + 1) * 128 + tl) * TROW;
+        float a1 = -INFINITY, a2 = -INFINITY;
+        int p1 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f4 u = *(const f4*)((i < 2 ? r0 : r1) + 4 * (i & 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float val = u[e];
+                a2 = fmaxf(a2, fminf(a1, val));
+                p1 = val > a1 ? 4 * i + e : p1;
+                a1 = fmaxf(a1, val);
             }
         }
-        __syncthreads();
-        if (tid < 128) {
-            // Row record over this half's 64 transpose entries (entry = max of columns s, s+32):
-            //   .x best entry   .y second best entry   .z column s of the best entry (int bits)
-            const int wrr = tid >> 6, rl = tid & 63;
-            const float* r0 = T + ((2 * wrr) * 64 + rl) * TROW;
-            const float* r1 = T + ((2 * wrr + 1) * 64 + rl) * TROW;
-            float a1 = -INFINITY, a2 = -INFINITY;
-            int p1 = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const f4 u = *(const f4*)((i < 8 ? r0 : r1) + 4 * (i & 7));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float val = u[e];
-                    a2 = fmaxf(a2, fminf(a1, val));
-                    p1 = val > a1 ? 4 * i + e : p1;
-                    a1 = fmaxf(a1, val);
-                }
-            }
-            const int scol = half * 128 + (p1 >> 5) * 64 + (p1 & 31);
-            rowrec[(bn * 2 + half) * P + wrr * 128 + round * 64 + rl] =
-                make_float4(a1, a2, __int_as_float(scol), 0.f);
-        }
-        __syncthreads();
+        const int scol = half * 128 + (p1 >> 3) * 64 + 4 * (p1 & 7);
+        rowrec[(bn * 2 + half) * P + tid] = make_float4(a1, a2, __int_as_float(scol), 0.f);
     }
     if (tid < 128) {
         colmax[bn * P + half * 128 + tid] = fmaxf(colp[tid], colp[128 + tid]);
@@ -503,196 +539,161 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
 }
 
 // ---------------------------------------------------------------------------
-// FAST mode: find the rows/columns whose "arg-max is patch 0" decision is
-// within eps of a tie and queue them for exact fp32 re-evaluation.
-//   kind 0: row t, candidate columns {0, s, s+32}: every other column is more
-//           than 2*eps below the best of s/s+32, so the exact max over s > 0 is
-//           one of them
-//   kind 1: row t, all columns        kind 2: column s, all rows
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void s1_detect(const float* __restrict__ m16, int N, float eps,
-                                                 const float4* __restrict__ rowrec,
-                                                 const float* __restrict__ simt0,
-                                                 const float* __restrict__ colmax,
-                                                 const float* __restrict__ sim0s,
-                                                 int32_t* __restrict__ counter,
-                                                 uint2* __restrict__ flags,
-                                                 uint2* __restrict__ full) {
-    const size_t bn = blockIdx.x;
-    const int b = (int)(bn / N), i = threadIdx.x;
-    const float m = m16[b * P + i];
-    if (m == 0.f) return;  // mask_all[i] = 0 whatever the decisions are
-    const float4 r0 = rowrec[(bn * 2) * P + i], r1 = rowrec[(bn * 2 + 1) * P + i];
-    const float rm = fmaxf(r0.x, r1.x);  // best over s > 0
-    if (fabsf(rm - simt0[bn * P + i]) <= eps) {
-        const bool w0 = r0.x >= r1.x;
-        const float second = fmaxf(w0 ? r1.x : r0.x, w0 ? r0.y : r1.y);
-        const int scol = __float_as_int(w0 ? r0.z : r1.z);
-        if (second < rm - 2.f * eps) {
-            const int k = atomicAdd(&counter[1], 1);
-            flags[k] = make_uint2((uint32_t)bn, ((uint32_t)i << 8) | (uint32_t)scol);
-        } else {
-            const int k = atomicAdd(&counter[0], 1);
-            full[k] = make_uint2((uint32_t)bn, (1u << 16) | ((uint32_t)i << 8));
-            atomicAdd(&counter[2], 1);
-        }
-    }
-    if (fabsf(colmax[bn * P + i] - sim0s[bn * P + i]) <= eps) {
-        const int k = atomicAdd(&counter[0], 1);
-        full[k] = make_uint2((uint32_t)bn, (2u << 16) | ((uint32_t)i << 8));
-        atomicAdd(&counter[3], 1);
-    }
-}
-
-// Exact re-evaluation.  The arithmetic repeats EXACT mode's: the dot product is the
-// c-ordered fp32 fma chain of v_mfma_f32_32x32x2_f32, the column norm is the sum of an
-// even-channel and an odd-channel fma chain, sim = dot * (1 / max(sqrt(ss), 1e-12)).
+// s1_resolve: per (b,n) — FAST mode's exact re-evaluation of near-tie decisions, then
+// sim_avg (matching.py:53-66).
 //
-// s1_fixup_rows: one wave per candidate-row entry; the wave stages 4 channel vectors
-// (q[:,t], x[:,0], x[:,s+32], x[:,s]) in LDS with all loads in flight at once, then
-// three lanes run the chains.
-__global__ __launch_bounds__(256) void s1_fixup_rows(const float* __restrict__ bank,
-                                                     const float* __restrict__ qf, int N, int C,
-                                                     const int32_t* __restrict__ counter,
-                                                     const uint2* __restrict__ flags,
-                                                     float4* __restrict__ rowrec,
-                                                     float* __restrict__ simt0) {
+// A decision "arg-max is patch 0" is near a tie when |best_other - sim_0| <= eps.  Rows:
+//   kind 0: the best entry is more than 2*eps above every other entry -> the exact max over
+//           s > 0 is one of its 8 columns {c..c+3, c+32..c+35}; re-evaluate those and column 0
+//   kind 1: several entries are close -> re-evaluate the whole row
+// Columns (kind 2): re-evaluate the whole column.
+// The arithmetic repeats EXACT mode's: the dot product is the c-ordered fp32 fma chain of
+// v_mfma_f32_32x32x2_f32, the column norm is the sum of an even-channel and an odd-channel
+// fma chain, sim = dot * (1 / max(sqrt(ss), 1e-12)) — so the decisions equal EXACT mode's.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void s1_resolve(const float* __restrict__ bank,
+                                                  const float* __restrict__ qf,
+                                                  const float* __restrict__ m16, int N, int C,
+                                                  int fast, float eps,
+                                                  const float4* __restrict__ rowrec,
+                                                  const float* __restrict__ simt0,
+                                                  const float* __restrict__ colmax,
+                                                  const float* __restrict__ sim0s,
+                                                  float* __restrict__ sim_avg,
+                                                  int32_t* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int cnt = counter[1];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* L = (float*)smem + (size_t)wv * 4 * C;  // [4][C]: q, x[:,0], x[:,s+32], x[:,s]
-    for (int e = blockIdx.x * 4 + wv; e < cnt; e += gridDim.x * 4) {
-        const uint2 f = flags[e];
-        const size_t bn = f.x;
-        const int i = (f.y >> 8) & 255, sc = f.y & 255;
-        const int b = (int)(bn / N);
-        const float* X = bank + bn * (size_t)C * P;
-        const float* Q = qf + (size_t)b * C * P;
-        const int cols[3] = {0, sc + 32, sc};
-        for (int c0 = 0; c0 < C; c0 += 64 * 4) {
-            float vq[4], vx[3][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {  // 16 loads in flight; the tail re-reads channel C-1
-                const int c = min(c0 + 64 * j + lane, C - 1);
-                vq[j] = Q[(size_t)c * P + i];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) vx[k][j] = X[(size_t)c * P + cols[k]];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = c0 + 64 * j + lane;
-                if (c < C) {
-                    L[c] = vq[j];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) L[(k + 1) * C + c] = vx[k][j];
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS stores are done
-        __builtin_amdgcn_wave_barrier();
-        float sim = -INFINITY;
-        if (lane < 3) {
-            const float* xv = L + (lane + 1) * C;
-            float dot = 0.f, se = 0.f, so = 0.f;
-#pragma unroll 8
-            for (int c = 0; c < C; c += 2) {
-                const float x0 = xv[c], x1 = xv[c + 1];
-                dot = fmaf(L[c], x0, dot);
-                dot = fmaf(L[c + 1], x1, dot);
-                se = fmaf(x0, x0, se);
-                so = fmaf(x1, x1, so);
-            }
-            sim = dot * (1.0f / fmaxf(sqrtf(se + so), 1e-12f));
-        }
-        const float s0 = __shfl(sim, 0), s1 = __shfl(sim, 1), s2 = __shfl(sim, 2);
-        const float mx = sc == 0 ? s1 : fmaxf(s1, s2);  // sc == 0: entry {0, 32}, 0 excluded
-        if (lane == 0) {
-            rowrec[(bn * 2) * P + i].x = mx;
-            rowrec[(bn * 2 + 1) * P + i].x = -INFINITY;
-            simt0[bn * P + i] = s0;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// s1_fixup_full: one workgroup per entry, thread o = output index (template patch for a
-// row entry, query patch for a column entry); 32 channels of loads in flight per thread.
-__global__ __launch_bounds__(256) void s1_fixup_full(const float* __restrict__ bank,
-                                                     const float* __restrict__ qf, int N, int C,
-                                                     const int32_t* __restrict__ counter,
-                                                     const uint2* __restrict__ full,
-                                                     float4* __restrict__ rowrec,
-                                                     float* __restrict__ simt0,
-                                                     float* __restrict__ colmax,
-                                                     float* __restrict__ sim0s) {
-    __shared__ float wmax[4];
-    const int cnt = counter[0];
-    const int o = threadIdx.x;
-    for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
-        const uint2 f = full[e];
-        const size_t bn = f.x;
-        const int kind = (int)(f.y >> 16), i = (f.y >> 8) & 255;
-        const int b = (int)(bn / N);
-        const float* X = bank + bn * (size_t)C * P;
-        const float* Q = qf + (size_t)b * C * P;
-        // row entry: a = q[:,i] (uniform), x = X[:,o];  column entry: a = q[:,o], x = X[:,i]
-        const float* ap = Q + (kind == 1 ? i : o);
-        const float* xp = X + (kind == 1 ? o : i);
-        float dot = 0.f, se = 0.f, so = 0.f;
-        for (int c0 = 0; c0 < C; c0 += 32) {
-            float a[32], x[32];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                a[j] = ap[(size_t)(c0 + j) * P];
-                x[j] = xp[(size_t)(c0 + j) * P];
-            }
-#pragma unroll
-            for (int j = 0; j < 32; j += 2) {
-                dot = fmaf(a[j], x[j], dot);
-                dot = fmaf(a[j + 1], x[j + 1], dot);
-                se = fmaf(x[j], x[j], se);
-                so = fmaf(x[j + 1], x[j + 1], so);
-            }
-        }
-        const float sim = dot * (1.0f / fmaxf(sqrtf(se + so), 1e-12f));
-        float m = o == 0 ? -INFINITY : sim;  // index 0 is the other side of the decision
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-        __syncthreads();
-        if ((o & 63) == 0) wmax[o >> 6] = m;
-        __syncthreads();
-        if (o == 0) {
-            const float mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            if (kind == 1) {
-                rowrec[(bn * 2) * P + i].x = mx;
-                rowrec[(bn * 2 + 1) * P + i].x = -INFINITY;
-                simt0[bn * P + i] = sim;
-            } else {
-                colmax[bn * P + i] = mx;
-                sim0s[bn * P + i] = sim;
-            }
-        }
-    }
-}
-
-// sim_avg (matching.py:53-66).  One workgroup per (b,n).
-__global__ __launch_bounds__(256) void s1_finalize(const float* __restrict__ m16, int N,
-                                                   const float4* __restrict__ rowrec,
-                                                   const float* __restrict__ simt0,
-                                                   const float* __restrict__ colmax,
-                                                   const float* __restrict__ sim0s,
-                                                   float* __restrict__ sim_avg) {
-    __shared__ float ps[4], pm[4];
+    float* L = (float*)smem;  // [10][C]: q[:,t], x[:,0], x[:,c..c+3], x[:,c+32..c+35]
+    __shared__ int nent;
+    __shared__ unsigned ent[512];
+    __shared__ float res[12];
+    __shared__ float wred[8];
     const size_t bn = blockIdx.x;
     const int b = (int)(bn / N), i = threadIdx.x;
+    const int lane = i & 63;
     const float m = m16[b * P + i];
-    const float rme = fmaxf(rowrec[(bn * 2) * P + i].x, rowrec[(bn * 2 + 1) * P + i].x);
-    const float st0 = simt0[bn * P + i];
-    const float rnz = rme > st0 ? 1.f : 0.f;  // idx_tar2src != 0 (first max wins ties)
-    const float rm = fmaxf(rme, st0);         // score_tar2src
-    const float cnz = colmax[bn * P + i] > sim0s[bn * P + i] ? 1.f : 0.f;
+    const float4 r0 = rowrec[(bn * 2) * P + i], r1 = rowrec[(bn * 2 + 1) * P + i];
+    float rme = fmaxf(r0.x, r1.x);  // best over s > 0 (row i)
+    float st = simt0[bn * P + i];   // sim[i, 0]
+    float cme = colmax[bn * P + i]; // best over t > 0 (column i)
+    float s0 = sim0s[bn * P + i];   // sim[0, i]
+
+    if (fast) {
+        if (i == 0) nent = 0;
+        __syncthreads();
+        if (m != 0.f) {  // mask_all[i] = 0 whatever the decisions are when m[i] = 0
+            if (fabsf(rme - st) <= eps) {
+                const bool w0 = r0.x >= r1.x;
+                const float second = fmaxf(w0 ? r1.x : r0.x, w0 ? r0.y : r1.y);
+                const unsigned scol = (unsigned)__float_as_int(w0 ? r0.z : r1.z);
+                const unsigned kind = second < rme - 2.f * eps ? 0u : 1u;
+                ent[atomicAdd(&nent, 1)] = (kind << 16) | ((unsigned)i << 8) | scol;
+            }
+            if (fabsf(cme - s0) <= eps) ent[atomicAdd(&nent, 1)] = (2u << 16) | ((unsigned)i << 8);
+        }
+        __syncthreads();
+        const int ne = nent;
+        const float* X = bank + bn * (size_t)C * P;
+        const float* Q = qf + (size_t)b * C * P;
+        for (int e = 0; e < ne; ++e) {
+            const unsigned f = ent[e];
+            const int kind = (int)(f >> 16), idx = (f >> 8) & 255, sc = f & 255;
+            if (kind == 0) {
+                // stage the 10 channel vectors with every load in flight at once
+                for (int c0 = 0; c0 < C; c0 += 1024) {
+                    float v[4][10];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = min(c0 + 256 * j + i, C - 1);
+                        v[j][0] = Q[(size_t)c * P + idx];
+                        v[j][1] = X[(size_t)c * P];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            v[j][2 + k] = X[(size_t)c * P + sc + k];
+                            v[j][6 + k] = X[(size_t)c * P + sc + 32 + k];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = c0 + 256 * j + i;
+                        if (c < C) {
+#pragma unroll
+                            for (int k = 0; k < 10; ++k) L[k * C + c] = v[j][k];
+                        }
+                    }
+                }
+                __syncthreads();
+                if (i < 9) {
+                    const float* xv = L + (i + 1) * C;
+                    float dot = 0.f, se = 0.f, so = 0.f;
+#pragma unroll 8
+                    for (int c = 0; c < C; c += 2) {
+                        const float x0 = xv[c], x1 = xv[c + 1];
+                        dot = fmaf(L[c], x0, dot);
+                        dot = fmaf(L[c + 1], x1, dot);
+                        se = fmaf(x0, x0, se);
+                        so = fmaf(x1, x1, so);
+                    }
+                    res[i] = dot * (1.0f / fmaxf(sqrtf(se + so), 1e-12f));
+                }
+                __syncthreads();
+                if (i == idx) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int col = sc + (k & 3) + 32 * (k >> 2);
+                        if (col != 0) mx = fmaxf(mx, res[1 + k]);  // column 0 is the other side
+                    }
+                    rme = mx;
+                    st = res[0];
+                }
+                __syncthreads();
+            } else {
+                // thread o = i: row entry: a = q[:,idx] (uniform), x = X[:,o];
+                //               column entry: a = q[:,o], x = X[:,idx]
+                const float* ap = Q + (kind == 1 ? idx : i);
+                const float* xp = X + (kind == 1 ? i : idx);
+                float dot = 0.f, se = 0.f, so = 0.f;
+                for (int c0 = 0; c0 < C; c0 += 32) {
+                    float a[32], x[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) {
+                        a[j] = ap[(size_t)(c0 + j) * P];
+                        x[j] = xp[(size_t)(c0 + j) * P];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 32; j += 2) {
+                        dot = fmaf(a[j], x[j], dot);
+                        dot = fmaf(a[j + 1], x[j + 1], dot);
+                        se = fmaf(x[j], x[j], se);
+                        so = fmaf(x[j + 1], x[j + 1], so);
+                    }
+                }
+                const float sim = dot * (1.0f / fmaxf(sqrtf(se + so), 1e-12f));
+                float mx = i == 0 ? -INFINITY : sim;  // index 0 is the other side
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+                if (lane == 0) wred[i >> 6] = mx;
+                if (i == 0) res[0] = sim;
+                __syncthreads();
+                if (i == idx) {
+                    const float mxa = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+                    if (kind == 1) {
+                        rme = mxa;
+                        st = res[0];
+                    } else {
+                        cme = mxa;
+                        s0 = res[0];
+                    }
+                }
+                __syncthreads();
+            }
+            if (stats && i == 0) atomicAdd(&stats[kind], 1);
+        }
+    }
+
+    const float rnz = rme > st ? 1.f : 0.f;   // idx_tar2src != 0 (first max wins ties)
+    const float cnz = cme > s0 ? 1.f : 0.f;   // idx_src2tar != 0
+    const float rm = fmaxf(rme, st);          // score_tar2src
     const float mall = m * cnz * rnz;
     float s = rm * mall, ms = mall;
 #pragma unroll
@@ -700,14 +701,14 @@ __global__ __launch_bounds__(256) void s1_finalize(const float* __restrict__ m16
         s += __shfl_xor(s, o);
         ms += __shfl_xor(ms, o);
     }
-    if ((i & 63) == 0) {
-        ps[i >> 6] = s;
-        pm[i >> 6] = ms;
+    if (lane == 0) {
+        wred[i >> 6] = s;
+        wred[4 + (i >> 6)] = ms;
     }
     __syncthreads();
     if (i == 0) {
-        const float tot = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-        const float mt = (pm[0] + pm[1]) + (pm[2] + pm[3]);
+        const float tot = (wred[0] + wred[1]) + (wred[2] + wred[3]);
+        const float mt = (wred[4] + wred[5]) + (wred[6] + wred[7]);
         sim_avg[bn] = mt > 0.f ? tot / 256.0f : 0.f;
     }
 }
@@ -805,32 +806,19 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask, i
     hipLaunchKernelGGL(s1_qpack, dim3(B, C / 32), dim3(256), 0, stream, query, w.denom, w.m16, C,
                        w.qh, w.qf);
     const int grid = (B >= 8) ? 8 * ((B + 7) / 8) * 2 * N : B * 2 * N;
-    if (mode == PP_MATCH_FAST) {
-        {
-            PpProfScope prof(stream);  // roofline kernel of stage 1 (bench.py)
+    {
+        PpProfScope prof(stream);  // roofline kernel of stage 1 (bench.py)
+        if (mode == PP_MATCH_FAST)
             hipLaunchKernelGGL(s1_main<PP_MATCH_FAST>, dim3(grid), dim3(256), SMEM_BYTES, stream,
                                bank, w.qh, w.qf, B, N, C, w.rowrec, w.simt0, w.colmax, w.sim0s);
-        }
-        PP_CHECK_HIP(hipMemsetAsync(w.counter, 0, 64, stream));
-        hipLaunchKernelGGL(s1_detect, dim3(B * N), dim3(256), 0, stream, w.m16, N, eps, w.rowrec,
-                           w.simt0, w.colmax, w.sim0s, w.counter, w.flags, w.full);
-        hipLaunchKernelGGL(s1_fixup_rows, dim3(512), dim3(256), (size_t)4 * 4 * C * sizeof(float),
-                           stream, bank, w.qf, N, C, w.counter, w.flags, w.rowrec, w.simt0);
-        hipLaunchKernelGGL(s1_fixup_full, dim3(512), dim3(256), 0, stream, bank, w.qf, N, C,
-                           w.counter, w.full, w.rowrec, w.simt0, w.colmax, w.sim0s);
-        if (stats)
-            PP_CHECK_HIP(hipMemcpyAsync(stats, w.counter + 1, 3 * sizeof(int32_t),
-                                        hipMemcpyDeviceToDevice, stream));
-    } else {
-        {
-            PpProfScope prof(stream);
+        else
             hipLaunchKernelGGL(s1_main<PP_MATCH_EXACT>, dim3(grid), dim3(256), SMEM_BYTES, stream,
                                bank, w.qh, w.qf, B, N, C, w.rowrec, w.simt0, w.colmax, w.sim0s);
-        }
-        if (stats) PP_CHECK_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(int32_t), stream));
     }
-    hipLaunchKernelGGL(s1_finalize, dim3(B * N), dim3(256), 0, stream, w.m16, N, w.rowrec, w.simt0,
-                       w.colmax, w.sim0s, sim_avg);
+    if (stats) PP_CHECK_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(s1_resolve, dim3(B * N), dim3(256), (size_t)10 * C * sizeof(float), stream,
+                       bank, w.qf, w.m16, N, C, mode == PP_MATCH_FAST ? 1 : 0, eps, w.rowrec,
+                       w.simt0, w.colmax, w.sim0s, sim_avg, stats);
     return pp_last_launch();
 }
 
