@@ -2,7 +2,7 @@
 process on ONE device (guide rule 24).  usage: tools_ab.py B N C suffix1 suffix2 ...  ('' = default)"""
 import ctypes, os, sys, statistics
 import torch
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B, N, C = (int(x) for x in sys.argv[1:4])
 variants = [v if v != "default" else "" for v in sys.argv[4:]] or [""]
 dev = "cuda"

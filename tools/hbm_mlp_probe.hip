@@ -1,0 +1,69 @@
+// Measurement aid: stage-1 access pattern (half-template workgroups) at a given memory-level
+// parallelism: NB 16-byte loads per thread per batch, DEPTH batches in flight, WGs/CU capped by LDS.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int NB, int DEPTH>
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ bank, int C, float* out) {
+    extern __shared__ char smem[];
+    const int item = blockIdx.x, half = item & 1;
+    const size_t bn = item >> 1;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    const float* xp = bank + bn * (size_t)C * 256 + half * 128 + (size_t)(2 * w + lh) * 256 + 4 * l31;
+    f4 acc = {0, 0, 0, 0};
+    f4 v[DEPTH][NB];
+    const int steps = C / (8 * NB);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) v[d][j] = *(const f4*)(xp + (size_t)((d * NB + j) * 8) * 256);
+    for (int s = 0; s < steps; s += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc += v[d][j];
+            const int ns = s + d + DEPTH;
+            const int cs = ns < steps ? ns : 0;  // tail re-reads step 0 (keeps the loop branch-free)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) v[d][j] = *(const f4*)(xp + (size_t)((cs * NB + j) * 8) * 256);
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = smem[0];
+}
+int main() {
+    const int BN = 32 * 162, C = 768;
+    const size_t n = (size_t)BN * C * 256;
+    float *bank, *out;
+    (void)hipMalloc(&bank, n * 4);
+    (void)hipMalloc(&out, 4);
+    (void)hipMemset(bank, 0x11, n * 4);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    auto time = [&](const char* name, auto launch) {
+        for (int i = 0; i < 3; ++i) launch();
+        (void)hipDeviceSynchronize();
+        float tot = 0;
+        for (int r = 0; r < 10; ++r) {
+            (void)hipEventRecord(e0);
+            launch();
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            tot += ms;
+        }
+        printf("%-44s avg %.3f ms -> %.0f GB/s\n", name, tot / 10, n * 4 / (tot / 10) / 1e6);
+    };
+#define RUN(NB, D, LDS, label) time(label, [&] { hipLaunchKernelGGL((probe<NB, D>), dim3(BN * 2), dim3(256), LDS, 0, bank, C, out); })
+    // 2 WGs/CU (LDS 70 KB each), as the stage-1 kernel
+    RUN(4, 1, 70 * 1024, "2 WG/CU, 16 KB x1 per WG (32 KB/CU)");
+    RUN(4, 2, 70 * 1024, "2 WG/CU, 16 KB x2 per WG (64 KB/CU)");
+    RUN(4, 3, 70 * 1024, "2 WG/CU, 16 KB x3 per WG (96 KB/CU)");
+    RUN(4, 4, 70 * 1024, "2 WG/CU, 16 KB x4 per WG (128 KB/CU)");
+    RUN(4, 6, 70 * 1024, "2 WG/CU, 16 KB x6 per WG (192 KB/CU)");
+    RUN(4, 2, 50 * 1024, "3 WG/CU, 16 KB x2 per WG (96 KB/CU)");
+    RUN(4, 2, 36 * 1024, "4 WG/CU, 16 KB x2 per WG (128 KB/CU)");
+    RUN(4, 2, 0, "8 WG/CU, 16 KB x2 per WG (256 KB/CU)");
+    return 0;
+}
