@@ -158,6 +158,12 @@ def main():
         assert out[1].shape == (B, 5) and out[1].dtype == torch.int64
         ms = dt / a.steps * 1e3
         kbytes = algorithmic_bytes(B, n_local, C)  # bytes the roofline kernel launch streams on this rank
+        traffic = None  # HBM bytes per launch from the PMC passes of the same command (profiles/, tools/pmc.sh)
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_stage1.json")
+        if world == 1 and a.mode == "fast" and os.path.exists(pmc):
+            rec = json.load(open(pmc))
+            if rec.get("workload") == a.workload:
+                traffic = rec["hbm_bytes_per_launch"]
         achieved = kbytes / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "image-crops/sec (224x224, 162 templates), stage-1 template matching",
@@ -169,7 +175,7 @@ def main():
                        "global_batch": B, "templates": N, "channels": C, "mode": a.mode,
                        "parallelism": "single GPU" if world == 1 else f"template-shard x{world} + 1 RCCL all-gather of (B,N/G) scores"},
             "roofline": {"bound": "hbm", "kernel": f"s1_main<{a.mode}>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kbytes},
         }
         if world == 1 and not a.no_cpu_baseline:
