@@ -82,6 +82,47 @@ int pp_stage1_match(const float* bank, const float* query, const float* mask,
                     float* sim_avg, float* out_score, int64_t* out_index,
                     int32_t* stats, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Stage 2/3 glue around the networks (picopose_amd/csrc/pp_geom.hip).
+ * ------------------------------------------------------------------------- */
+
+/* utils/matching.py:6-26 matching_features_similarity (model/picopose.py:81).
+ * src_feat/tar_feat (B,C,16,16) template/query features, src_mask (B,mh,mw) template mask;
+ * out (B,256,16,16): out[b,s,h,w] = relu(cos(query patch t=w*16+h, template patch s) * mask_s). */
+int pp_similarity_volume(const float* src_feat, const float* tar_feat, const float* src_mask,
+                         int mask_h, int mask_w, int B, int C, float* out, void* stream);
+
+/* utils/torch_utils.py:39-51 calc_pred_Ms (model/picopose.py:84): pred_scale (B), pred_inplane
+ * (B,2) cos/sin, pred_translation (B,2), tem_pose (B,4,4), tem_K/tem_M (B,3,3) -> pred_Ms (B,3,3). */
+int pp_calc_pred_Ms(const float* pred_scale, const float* pred_inplane, const float* pred_translation,
+                    const float* tem_pose, const float* tem_K, const float* tem_M, int B,
+                    float trans_scale, float* pred_Ms, void* stream);
+
+/* utils/pose_recovery.py:9-65 pose_recovery_2d_prediction (model/picopose.py:86-89) -> (B,4,4).
+ * Contract (asserted on the host by the reference, torch_utils.py:100-101): query_M is a crop
+ * affine with M01 = M10 = 0 and M00 = M11. */
+int pp_pose_recovery_2d(const float* query_M, const float* query_K, const float* pred_Ms,
+                        const float* tem_K, const float* tem_M, const float* tem_pose, int B,
+                        float* pred_pose, void* stream);
+
+/* utils/correspondence.py:10-26 compute_init_correspondences (model/picopose.py:91):
+ * pred_Ms (B,3,3), tem_mask (B,mh,mw) square -> init_flow (B,2,16,16) [ch0 = x], init_certainty
+ * (B,1,16,16). */
+int pp_init_correspondences(const float* pred_Ms, const float* tem_mask, int mask_h, int mask_w, int B,
+                            float* init_flow, float* init_certainty, void* stream);
+
+/* utils/correspondence.py:28-59 compute_stage3_correspondences (model/picopose.py:93):
+ * pred_flow (B,2,H,W), pred_certainty (B,1,H,W) -> tar_pts, src_pts (B,H*W,2) int64, entry
+ * k = w*H + h = (x,y) or (-1,-1). */
+int pp_stage3_correspondences(const float* pred_flow, const float* pred_certainty, int B, int H, int W,
+                              float threshold, int64_t* tar_pts, int64_t* src_pts, void* stream);
+
+/* utils/torch_utils.py:257-284 gather, as used at utils/pose_recovery.py:76-77: features
+ * (B,C,H,W), index_patches (B,N,2) int64 (x,y) with -1 padding -> out (B,N,C) whose first count[b]
+ * rows are features[b,:,y,x] of the valid entries in order; count (B) int32. */
+int pp_gather_valid(const float* features, const int64_t* index_patches, int B, int C, int H, int W,
+                    int N, float* out, int32_t* count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

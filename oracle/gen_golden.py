@@ -90,7 +90,72 @@ def gen_stage1():
     print("stage1/stage2-similarity fixtures written")
 
 
-GENERATORS = {"stage1": gen_stage1}
+def _rot(B, g):
+    q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+    return q * torch.sign(torch.det(q))[:, None, None]
+
+
+def gen_geometry():
+    """calc_pred_Ms, pose_recovery_2d_prediction, compute_init_correspondences,
+    compute_stage3_correspondences and gather — outputs of the reference functions."""
+    _ref()
+    import types
+
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))  # utils/pose_recovery.py imports cv2 at module level
+    from utils.correspondence import compute_init_correspondences, compute_stage3_correspondences
+    from utils.pose_recovery import pose_recovery_2d_prediction
+    from utils.torch_utils import calc_pred_Ms, gather
+
+    g = torch.Generator().manual_seed(4321)
+    B = 6
+    scale = torch.rand(B, generator=g) + 0.5
+    inplane = torch.nn.functional.normalize(torch.randn(B, 2, generator=g), dim=1)
+    trans = torch.randn(B, 2, generator=g)
+    pose = torch.eye(4).repeat(B, 1, 1)
+    pose[:, :3, :3] = _rot(B, g)
+    pose[:, :3, 3] = torch.tensor([0.01, -0.02, 0.8]) + 0.05 * torch.randn(B, 3, generator=g)
+    K = torch.tensor([[572.4114, 0, 320], [0, 573.57043, 240], [0, 0, 1.0]]).repeat(B, 1, 1)
+    K[:, 0, 0] += 10 * torch.randn(B, generator=g)
+    tM = torch.eye(3).repeat(B, 1, 1)
+    tM[:, 0, 0] = tM[:, 1, 1] = 1.5
+    tM[:, :2, 2] = torch.tensor([-300.0, -200.0]) + 5 * torch.randn(B, 2, generator=g)
+    qM = torch.eye(3).repeat(B, 1, 1)
+    qM[:, 0, 0] = qM[:, 1, 1] = 2.0
+    qM[:, :2, 2] = torch.tensor([-100.0, -80.0]) + 5 * torch.randn(B, 2, generator=g)
+    Ms = calc_pred_Ms(scale, inplane, trans, pose, K, tM)
+    poses = pose_recovery_2d_prediction(qM, K, Ms, K, tM, pose)
+    mask = (torch.rand(B, 224, 224, generator=g) > 0.4).float()
+    flow0, cert0 = compute_init_correspondences(Ms, mask)
+    eye = torch.eye(3).repeat(2, 1, 1)
+    flow_id, cert_id = compute_init_correspondences(eye, torch.ones(2, 224, 224))  # identity -> 0.5 everywhere
+    # keypoint selection with edge cases: logits at +-eps, targets on the bounds, far outside
+    flow = 3 * torch.randn(B, 2, 64, 64, generator=g)
+    cert = torch.randn(B, 1, 64, 64, generator=g)
+    cert[0, 0, 0, :8] = torch.tensor([0.0, 1e-9, -1e-9, 1e-6, -1e-6, 1e-3, -1e-3, 5e-8])
+    flow[1, :, 10, 10] = torch.tensor([-10.0, -10.0])     # tar exactly (0,0): excluded (strict >)
+    flow[1, :, 11, 11] = torch.tensor([52.0 - 11, 63.0 - 11])  # y == H-1: excluded (strict <)
+    flow[1, :, 12, 12] = torch.tensor([0.25 - 12, 0.75 - 12])  # inside, truncates to (0,0)
+    flow[1, :, 13, 13] = torch.tensor([62.999 - 13, 1.5 - 13])
+    flow[2] = 200.0                                            # everything out of bounds
+    cert[3] = -5.0                                             # nothing certain
+    tar, src = compute_stage3_correspondences(flow, cert)
+    feat2 = torch.randn(1, 2, 64, 64, generator=g)
+    feat3 = torch.randn(1, 3, 64, 64, generator=g)
+    g2 = gather(feat2, tar[:1])
+    g3 = gather(feat3, src[:1])
+    g_empty = gather(feat3, src[2:3])
+    np.savez_compressed(
+        os.path.join(OUT, "geometry.npz"),
+        scale=scale.numpy(), inplane=inplane.numpy(), trans=trans.numpy(), tem_pose=pose.numpy(), K=K.numpy(),
+        tem_M=tM.numpy(), query_M=qM.numpy(), pred_Ms=Ms.numpy(), pred_poses=poses.numpy(), mask=mask.numpy(),
+        init_flow=flow0.numpy(), init_cert=cert0.numpy(), init_flow_identity=flow_id.numpy(),
+        init_cert_identity=cert_id.numpy(), flow=flow.numpy(), cert=cert.numpy(), tar_pts=tar.numpy(),
+        src_pts=src.numpy(), feat2=feat2.numpy(), feat3=feat3.numpy(), gather2=g2.numpy(), gather3=g3.numpy(),
+        gather_empty=g_empty.numpy())
+    print("geometry fixtures written")
+
+
+GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

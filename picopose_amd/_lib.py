@@ -50,8 +50,30 @@ def lib():
         L.pp_topk.argtypes = [vp, i32, i32, i32, vp, vp, vp]
         L.pp_stage1_match.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz,
                                       vp, vp, vp, vp, vp]
+        L.pp_similarity_volume.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
+        L.pp_calc_pred_Ms.argtypes = [vp, vp, vp, vp, vp, vp, i32, f32, vp, vp]
+        L.pp_pose_recovery_2d.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp]
+        L.pp_init_correspondences.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+        L.pp_stage3_correspondences.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp]
+        L.pp_gather_valid.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
         _lib = L
     return _lib
+
+
+def stream_ptr():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_f32(*tensors):
+    """Contiguous fp32 device views of the inputs (the ABI takes raw device pointers)."""
+    out = []
+    for t in tensors:
+        if not t.is_cuda:
+            raise PicoPoseHipError("picopose_amd runs on the GPU only: inputs must be CUDA(HIP) tensors")
+        out.append(t.contiguous().float())
+    return out
 
 
 def check(rc, what):

@@ -86,3 +86,19 @@ def matching_templates(src_feats, tar_feat, src_masks, tar_mask, topk=5, mode=No
     """
     sim_avg = template_scores(src_feats, tar_feat, tar_mask, mode=mode)
     return topk_templates(sim_avg, topk)
+
+
+def matching_features_similarity(src_feat, tar_feat, src_mask, tar_mask):
+    """Drop-in for reference utils/matching.py:6-26 (`tar_mask` is unused there as well).
+
+    src_feat/tar_feat (B,C,16,16), src_mask (B,H,W) -> (B,256,16,16)."""
+    B, C, H, W = src_feat.shape
+    assert H == W  # reference utils/matching.py:10
+    if H != 16:
+        raise _lib.PicoPoseHipError("the HIP similarity-volume kernel is built for 16x16 patch grids")
+    src, tar, mask = _lib.dev_f32(src_feat, tar_feat, src_mask)
+    out = torch.empty(B, H * W, H, W, dtype=torch.float32, device=src.device)
+    rc = _lib.lib().pp_similarity_volume(src.data_ptr(), tar.data_ptr(), mask.data_ptr(), mask.shape[1],
+                                         mask.shape[2], B, C, out.data_ptr(), _lib.stream_ptr())
+    _lib.check(rc, "pp_similarity_volume")
+    return out
