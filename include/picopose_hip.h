@@ -123,6 +123,59 @@ int pp_stage3_correspondences(const float* pred_flow, const float* pred_certaint
 int pp_gather_valid(const float* features, const int64_t* index_patches, int B, int C, int H, int W,
                     int N, float* out, int32_t* count, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Network engine (picopose_amd/csrc/pp_gemm.hip): fp32 MFMA GEMM / implicit-GEMM convolution
+ * and the row-wise kernels around it.  Device tensors are token-major / NHWC: a row is a token
+ * or a pixel, channels are contiguous.  These entries replace the stock torch ops (nn.Linear,
+ * nn.Conv2d, nn.ConvTranspose2d, nn.LayerNorm, softmax, nn.GroupNorm) the reference's modules
+ * call: model/stage1/layers/{attention.py:44-62,mlp.py:30-41,patch_embed.py:66-82,block.py:56-106},
+ * model/stage2/affine_regressor.py:72-84, model/stage3/{dpt.py:252-272,flow_decoder.py:58-94,
+ * raft_decoder.py:147-161,287-289}.
+ * ------------------------------------------------------------------------- */
+#define PP_ACT_NONE 0
+#define PP_ACT_RELU 1
+#define PP_ACT_GELU 2    /* exact erf GELU (nn.GELU default) */
+#define PP_ACT_LEAKY01 3 /* LeakyReLU(0.1) */
+#define PP_ACT_TANH 4
+
+/* C[m,n] = residual[m,n] + gamma[n] * act(alpha * sum_k A(m,k) * B(n,k) + bias[n])
+ * for every batch index z = z0*batch1 + z1 (operand offsets z0*bs0 + z1*bs1, in floats). */
+typedef struct PpGemmDesc {
+    const float* A;        /* dense: [M][lda]; conv: NHWC image (conv_b, conv_h, conv_w, lda>=conv_cin) */
+    const float* B;        /* [N][ldb] (k contiguous) or, if b_kn, [K][ldb] (n contiguous)            */
+    float* C;              /* [M][ldc]; with shuffle_r: NHWC image (b, h*r, w*r, ldc)                 */
+    const float* bias;     /* [N] or NULL */
+    const float* gamma;    /* [N] or NULL (LayerScale) */
+    const float* residual; /* laid out like C, or NULL */
+    int M, N, K;
+    int lda, ldb, ldc;
+    int b_kn;
+    int batch0, batch1;
+    long long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
+    float alpha;
+    int act;
+    int relu_in;           /* apply ReLU to A while loading (ResidualConvUnit, dpt.py:82-86)           */
+    /* implicit im2col (conv_kh == 0: dense A): k = (ky*conv_kw + kx)*conv_cin + ci                    */
+    int conv_kh, conv_kw, conv_cin, conv_stride, conv_pad, conv_h, conv_w, conv_ho, conv_wo;
+    /* ConvTranspose2d(kernel = stride = shuffle_r): rows are the pixels of (b, shuffle_h, shuffle_w),
+     * column n = (dy*r + dx)*Cout + co is stored at pixel (y*r+dy, x*r+dx), channel co               */
+    int shuffle_r, shuffle_h, shuffle_w;
+} PpGemmDesc;
+
+int pp_gemm(const PpGemmDesc* desc, void* stream);
+
+/* nn.LayerNorm(C, eps) over rows of a [rows][C] matrix. */
+int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps,
+                 float* y, void* stream);
+/* softmax(dim=-1) in place over rows of a [rows][ld] matrix (n valid columns). */
+int pp_softmax_rows(float* x, int rows, int n, int ld, void* stream);
+/* nn.GroupNorm(groups, C, eps) (+ReLU when relu != 0) on an NHWC tensor (B, HW, C). */
+int pp_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, int B, int HW, int C,
+                      int groups, float eps, int relu, float* y, void* stream);
+/* out[b, c, col_off + r] = in[b, r, c]: (B,R,C) -> (B,C,ld_out); NCHW <-> NHWC at the API boundary. */
+int pp_transpose_batched(const float* in, int B, int R, int C, float* out, int ld_out, int col_off,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

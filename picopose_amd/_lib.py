@@ -18,6 +18,23 @@ PP_MATCH_FAST = 1
 _lib = None
 
 
+class PpGemmDesc(ctypes.Structure):
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("gamma", ctypes.c_void_p), ("residual", ctypes.c_void_p),
+        ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
+        ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int), ("b_kn", ctypes.c_int),
+        ("batch0", ctypes.c_int), ("batch1", ctypes.c_int),
+        ("a_bs0", ctypes.c_longlong), ("a_bs1", ctypes.c_longlong), ("b_bs0", ctypes.c_longlong),
+        ("b_bs1", ctypes.c_longlong), ("c_bs0", ctypes.c_longlong), ("c_bs1", ctypes.c_longlong),
+        ("alpha", ctypes.c_float), ("act", ctypes.c_int), ("relu_in", ctypes.c_int),
+        ("conv_kh", ctypes.c_int), ("conv_kw", ctypes.c_int), ("conv_cin", ctypes.c_int),
+        ("conv_stride", ctypes.c_int), ("conv_pad", ctypes.c_int), ("conv_h", ctypes.c_int),
+        ("conv_w", ctypes.c_int), ("conv_ho", ctypes.c_int), ("conv_wo", ctypes.c_int),
+        ("shuffle_r", ctypes.c_int), ("shuffle_h", ctypes.c_int), ("shuffle_w", ctypes.c_int),
+    ]
+
+
 class PicoPoseHipError(RuntimeError):
     pass
 
@@ -56,6 +73,11 @@ def lib():
         L.pp_init_correspondences.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
         L.pp_stage3_correspondences.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp]
         L.pp_gather_valid.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+        L.pp_gemm.argtypes = [c.POINTER(PpGemmDesc), vp]
+        L.pp_layernorm.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp]
+        L.pp_softmax_rows.argtypes = [vp, i32, i32, i32, vp]
+        L.pp_groupnorm_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp]
+        L.pp_transpose_batched.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp]
         _lib = L
     return _lib
 

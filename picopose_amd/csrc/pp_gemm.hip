@@ -1,0 +1,385 @@
+// fp32 MFMA GEMM / implicit-GEMM convolution engine for the network parts of the path
+// (DINOv2 ViT linears and attention products, AffineRegressor, DPT head, flow decoder).
+//
+//   C[m, n] = epilogue( alpha * sum_k A(m, k) * B(n, k) )
+//
+// Everything is token-major / NHWC on the device: a "row" m is a token or an output pixel, k
+// runs over input channels (times filter taps for a convolution), n over output channels.
+// A is either a dense row-major matrix or an implicit im2col view of an NHWC image
+// (zero padding, stride), so 1x1 / 3x3 / 7x7 / 14x14 convolutions, nn.Linear and the attention
+// products all run on this one kernel; ConvTranspose2d with kernel == stride is the same GEMM
+// with a pixel-shuffle store.  Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 products and
+// accumulation) — the reference computes in fp32 and parity comes first; the fp16/bf16 MFMA
+// variants are a later round's lever.
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile 128x128, K step 32, each wave a 64x64 tile
+// (2x2 MFMA tiles, 64 accumulator registers).  LDS tiles are [128][36] floats (row stride 36
+// keeps ds_read_b128 fragment reads conflict-free); each lane reads 16 consecutive k per row
+// (4 x ds_read_b128), lanes 0-31 the first half of the K step and lanes 32-63 the second, which
+// is the k-pair v_mfma_f32_32x32x2 consumes per issue.  Next tile is prefetched into registers
+// while the MFMAs of the current one run.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/picopose_hip.h"
+#include "pp_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 32, LDT = 36;
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case PP_ACT_RELU: return v > 0.f ? v : 0.f;
+        case PP_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case PP_ACT_LEAKY01: return v > 0.f ? v : 0.1f * v;
+        case PP_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+// one A element group: 4 consecutive k of row m (zero outside the matrix / image)
+template <bool VEC4>
+__device__ __forceinline__ f4 load_a(const PpGemmDesc& d, const float* __restrict__ A, int m, int k,
+                                     int b_img, int oy, int ox) {
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m >= d.M) return v;
+    if (d.conv_kh == 0) {  // dense rows
+        const float* p = A + (size_t)m * d.lda + k;
+        if (VEC4) {
+            if (k + 3 < d.K) v = *(const f4*)p;
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (k + i < d.K) v[i] = p[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (k + i < d.K) v[i] = p[i];
+        }
+    } else {  // implicit im2col of an NHWC image: k = (ky*KW + kx)*Cin + ci
+        if (VEC4) {  // Cin % 4 == 0: the 4 elements share a tap
+            if (k < d.K) {
+                const int tap = k / d.conv_cin, ci = k - tap * d.conv_cin;
+                const int ky = tap / d.conv_kw, kx = tap - ky * d.conv_kw;
+                const int iy = oy * d.conv_stride - d.conv_pad + ky, ix = ox * d.conv_stride - d.conv_pad + kx;
+                if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w)
+                    v = *(const f4*)(A + (((size_t)b_img * d.conv_h + iy) * d.conv_w + ix) * d.lda + ci);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = k + i;
+                if (kk < d.K) {
+                    const int tap = kk / d.conv_cin, ci = kk - tap * d.conv_cin;
+                    const int ky = tap / d.conv_kw, kx = tap - ky * d.conv_kw;
+                    const int iy = oy * d.conv_stride - d.conv_pad + ky, ix = ox * d.conv_stride - d.conv_pad + kx;
+                    if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w)
+                        v[i] = A[(((size_t)b_img * d.conv_h + iy) * d.conv_w + ix) * d.lda + ci];
+                }
+            }
+        }
+    }
+    if (d.relu_in) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+    }
+    return v;
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void gemm_kernel(const PpGemmDesc d) {
+    __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int z = blockIdx.z, z0 = z / d.batch1, z1 = z - z0 * d.batch1;
+    const float* A = d.A + (size_t)z0 * d.a_bs0 + (size_t)z1 * d.a_bs1;
+    const float* Bm = d.B + (size_t)z0 * d.b_bs0 + (size_t)z1 * d.b_bs1;
+    float* C = d.C + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1;
+    const float* R = d.residual ? d.residual + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1 : nullptr;
+
+    // this thread's 4 (row, k-quad) slots of the A and B tiles: idx = tid + 256 j -> row idx>>3, quad idx&7
+    int arow[4], ab[4], aoy[4], aox[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j;
+        arow[j] = idx >> 3;
+        const int m = m0 + arow[j];
+        ab[j] = aoy[j] = aox[j] = 0;
+        if (d.conv_kh != 0 && m < d.M) {
+            const int per = d.conv_ho * d.conv_wo;
+            ab[j] = m / per;
+            const int r = m - ab[j] * per;
+            aoy[j] = r / d.conv_wo;
+            aox[j] = r - aoy[j] * d.conv_wo;
+        }
+    }
+    const int kq = (tid & 7) * 4;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f4 ra[4], rb[4];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ra[j] = load_a<VEC4>(d, A, m0 + arow[j], k0 + kq, ab[j], aoy[j], aox[j]);
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            const int n = n0 + arow[j], k = k0 + kq;
+            if (n < d.N) {
+                if (d.b_kn) {  // B stored [K][N]
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (k + i < d.K) v[i] = Bm[(size_t)(k + i) * d.ldb + n];
+                } else {
+                    const float* p = Bm + (size_t)n * d.ldb + k;
+                    if (VEC4 && k + 3 < d.K) v = *(const f4*)p;
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (k + i < d.K) v[i] = p[i];
+                    }
+                }
+            }
+            rb[j] = v;
+        }
+    };
+
+    const int nk = (d.K + BK - 1) / BK;
+    fetch(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(f4*)(As + arow[j] * LDT + kq) = ra[j];
+            *(f4*)(Bs + arow[j] * LDT + kq) = rb[j];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) fetch((kt + 1) * BK);
+        f4 af[2][4], bf[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                af[i][q] = *(const f4*)(As + (wr * 64 + i * 32 + l31) * LDT + lh * 16 + 4 * q);
+                bf[i][q] = *(const f4*)(Bs + (wc * 64 + i * 32 + l31) * LDT + lh * 16 + 4 * q);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q][e], bf[j][q][e], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue: out = residual + gamma * act(alpha * acc + bias)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wc * 64 + j * 32 + l31;
+        if (n >= d.N) continue;
+        const float bias = d.bias ? d.bias[n] : 0.f;
+        const float gamma = d.gamma ? d.gamma[n] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m >= d.M) continue;
+                float v = act_apply(acc[i][j][e] * d.alpha + bias, d.act) * gamma;
+                size_t off;
+                if (d.shuffle_r == 0) {
+                    off = (size_t)m * d.ldc + n;
+                } else {
+                    // ConvTranspose2d(kernel = stride = r): row m = input pixel (b, y, x) of an
+                    // (shuffle_h x shuffle_w) image, column n = (dy*r + dx)*Cout + co
+                    const int r = d.shuffle_r, cout = d.N / (r * r);
+                    const int sub = n / cout, co = n - sub * cout, dy = sub / r, dx = sub - dy * r;
+                    const int per = d.shuffle_h * d.shuffle_w;
+                    const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
+                    off = (((size_t)b * d.shuffle_h * r + y * r + dy) * (d.shuffle_w * r) + x * r + dx) * d.ldc + co;
+                }
+                if (R) v += R[off];
+                C[off] = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Row-wise kernels around the GEMMs
+// ---------------------------------------------------------------------------
+
+// nn.LayerNorm(eps) over the last dimension: one wave per row (model/stage1 block.py:56,68)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, int rows, int C, float eps,
+                                                        float* __restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float dlt = xr[c] - mean;
+        v = fmaf(dlt, dlt, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v / (float)C + eps);
+    float* yr = y + (size_t)row * C;
+    for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mean) * rstd * g[c] + b[c];
+}
+
+// softmax over the last dimension, in place: one wave per row (layers/attention.py:57)
+__global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ x, int rows, int n, int ld) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* xr = x + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < n; c += 64) mx = fmaxf(mx, xr[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float s = 0.f;
+    for (int c = lane; c < n; c += 64) {
+        const float e = expf(xr[c] - mx);
+        xr[c] = e;
+        s += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float inv = 1.0f / s;
+    for (int c = lane; c < n; c += 64) xr[c] *= inv;
+}
+
+// nn.GroupNorm(G, C, eps) on an NHWC image (+ optional ReLU): one workgroup per (image, group)
+__global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, int HW, int C, int G, float eps,
+                                                        int relu, float* __restrict__ y) {
+    __shared__ float red[8];
+    const int img = blockIdx.x / G, grp = blockIdx.x % G, cg = C / G, tid = threadIdx.x;
+    const float* xi = x + (size_t)img * HW * C + grp * cg;
+    float* yi = y + (size_t)img * HW * C + grp * cg;
+    const int n = HW * cg;
+    float s = 0.f;
+    for (int i = tid; i < n; i += 256) s += xi[(size_t)(i / cg) * C + (i % cg)];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+    float v = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float dlt = xi[(size_t)(i / cg) * C + (i % cg)] - mean;
+        v = fmaf(dlt, dlt, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = v;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)n + eps);
+    for (int i = tid; i < n; i += 256) {
+        const int c = i % cg;
+        const size_t off = (size_t)(i / cg) * C + c;
+        float o = (xi[off] - mean) * rstd * g[grp * cg + c] + b[grp * cg + c];
+        if (relu) o = o > 0.f ? o : 0.f;
+        yi[off] = o;
+    }
+}
+
+// (B, C, H*W) <-> (B, H*W, C) through a 32x33 LDS tile
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int R, int Cc,
+                                                        float* __restrict__ out, int ld_out, int col_off) {
+    __shared__ float t[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float* ib = in + (size_t)b * R * Cc;
+    float* ob = out + (size_t)b * Cc * ld_out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < R && c < Cc) t[ty + 8 * i][tx] = ib[(size_t)r * Cc + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < R && c < Cc) ob[(size_t)c * ld_out + col_off + r] = t[tx][ty + 8 * i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pp_gemm(const PpGemmDesc* desc, void* stream) {
+    if (!desc || !desc->A || !desc->B || !desc->C) return PP_EINVAL;
+    PpGemmDesc d = *desc;
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch0 <= 0 || d.batch1 <= 0) return PP_EINVAL;
+    if (d.act < 0 || d.act > PP_ACT_TANH) return PP_EINVAL;
+    if (d.conv_kh != 0) {
+        if (d.conv_kw <= 0 || d.conv_cin <= 0 || d.conv_stride <= 0 || d.conv_h <= 0 || d.conv_w <= 0 ||
+            d.conv_ho <= 0 || d.conv_wo <= 0 || d.K != d.conv_kh * d.conv_kw * d.conv_cin)
+            return PP_EINVAL;
+    }
+    if (d.shuffle_r != 0 && (d.N % (d.shuffle_r * d.shuffle_r) != 0 || d.shuffle_h * d.shuffle_w <= 0))
+        return PP_EINVAL;
+    // 16-byte vector loads need aligned rows: K-contiguous operands with lda/ldb/Cin % 4 == 0
+    bool vec = ((uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.B % 16 == 0) && d.lda % 4 == 0 &&
+               (d.b_kn || d.ldb % 4 == 0) && d.a_bs0 % 4 == 0 && d.a_bs1 % 4 == 0 && d.b_bs0 % 4 == 0 &&
+               d.b_bs1 % 4 == 0;
+    if (d.conv_kh != 0 && d.conv_cin % 4 != 0) vec = false;
+    const dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch0 * d.batch1);
+    if (vec)
+        hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, d);
+    else
+        hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, d);
+    return pp_last_launch();
+}
+
+int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
+                 void* stream) {
+    if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0) return PP_EINVAL;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                       rows, C, eps, y);
+    return pp_last_launch();
+}
+
+int pp_softmax_rows(float* x, int rows, int n, int ld, void* stream) {
+    if (!x || rows <= 0 || n <= 0 || ld < n) return PP_EINVAL;
+    hipLaunchKernelGGL(softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, n, ld);
+    return pp_last_launch();
+}
+
+int pp_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, int B, int HW, int C, int groups,
+                      float eps, int relu, float* y, void* stream) {
+    if (!x || !gamma || !beta || !y || B <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0)
+        return PP_EINVAL;
+    hipLaunchKernelGGL(groupnorm_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, HW,
+                       C, groups, eps, relu, y);
+    return pp_last_launch();
+}
+
+int pp_transpose_batched(const float* in, int B, int R, int C, float* out, int ld_out, int col_off, void* stream) {
+    if (!in || !out || B <= 0 || R <= 0 || C <= 0 || ld_out < R + col_off - 0 || col_off < 0) return PP_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, B), dim3(256), 0,
+                       (hipStream_t)stream, in, R, C, out, ld_out, col_off);
+    return pp_last_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""Thin host wrappers over the network engine of libpicopose_hip.so (pp_gemm.hip, pp_sample.hip).
+
+All activations are token-major / NHWC fp32 device tensors: (rows, C) or (B, H, W, C).  Nothing
+here computes with torch ops — torch only allocates the outputs."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import PpGemmDesc
+
+ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "leaky01": 3, "tanh": 4}
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _run(d, what="pp_gemm"):
+    _lib.check(_lib.lib().pp_gemm(ctypes.byref(d), _lib.stream_ptr()), what)
+
+
+def _desc(**kw):
+    d = PpGemmDesc()
+    d.batch0 = d.batch1 = 1
+    d.alpha = 1.0
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, relu_in=False):
+    """y = residual + gamma * act(x @ weight.T + bias); x (M,K) with row stride, weight (N,K)."""
+    M, K = x.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K and x.stride(1) == 1 and weight.is_contiguous()
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    assert out.stride(1) == 1
+    if residual is not None:
+        assert residual.shape == out.shape and residual.stride() == out.stride()
+    _run(_desc(A=_p(x), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual), M=M, N=N, K=K,
+               lda=x.stride(0), ldb=K, ldc=out.stride(0), act=ACT[act], relu_in=int(relu_in)))
+    return out
+
+
+def bmm_nt(a, b, alpha=1.0, out=None):
+    """out[z0,z1] = alpha * a[z0,z1] @ b[z0,z1].T for 4-D strided views (Z0,Z1,M,K) x (Z0,Z1,N,K)."""
+    Z0, Z1, M, K = a.shape
+    N = b.shape[2]
+    assert a.stride(3) == 1 and b.stride(3) == 1
+    if out is None:
+        out = torch.empty(Z0, Z1, M, N, dtype=torch.float32, device=a.device)
+    _run(_desc(A=_p(a), B=_p(b), C=_p(out), M=M, N=N, K=K, lda=a.stride(2), ldb=b.stride(2), ldc=out.stride(2),
+               batch0=Z0, batch1=Z1, a_bs0=a.stride(0), a_bs1=a.stride(1), b_bs0=b.stride(0), b_bs1=b.stride(1),
+               c_bs0=out.stride(0), c_bs1=out.stride(1), alpha=float(alpha)))
+    return out
+
+
+def bmm_nn(a, b, out):
+    """out[z0,z1] = a[z0,z1] @ b[z0,z1] for (Z0,Z1,M,K) x (Z0,Z1,K,N) strided views (b: n contiguous)."""
+    Z0, Z1, M, K = a.shape
+    N = b.shape[3]
+    assert a.stride(3) == 1 and b.stride(3) == 1 and out.stride(3) == 1
+    _run(_desc(A=_p(a), B=_p(b), C=_p(out), M=M, N=N, K=K, lda=a.stride(2), ldb=b.stride(2), ldc=out.stride(2), b_kn=1,
+               batch0=Z0, batch1=Z1, a_bs0=a.stride(0), a_bs1=a.stride(1), b_bs0=b.stride(0), b_bs1=b.stride(1),
+               c_bs0=out.stride(0), c_bs1=out.stride(1)))
+    return out
+
+
+def pack_conv_weight(w):
+    """(Cout, Cin, KH, KW) torch layout -> (Cout, KH*KW*Cin) rows in the engine's k order."""
+    co, ci, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).contiguous()
+
+
+def pack_convT_weight(w, bias):
+    """ConvTranspose2d(kernel = stride = r) weight (Cin, Cout, r, r) -> ((r*r*Cout, Cin), bias tiled r*r)."""
+    ci, co, r, r2 = w.shape
+    assert r == r2
+    wp = w.permute(2, 3, 1, 0).reshape(r * r * co, ci).contiguous()
+    return wp, (bias.repeat(r * r).contiguous() if bias is not None else None)
+
+
+def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residual=None, out=None, cin=None):
+    """NHWC convolution. x (B,H,W,Cx) (channel-contiguous, may be a channel slice: cin <= Cx stride),
+    wp (Cout, k*k*cin) from pack_conv_weight.  out may be a channel slice of a wider NHWC buffer."""
+    B, H, W, Cx = x.shape
+    cin = cin or Cx
+    Cout = wp.shape[0]
+    assert wp.shape[1] == ksize * ksize * cin and x.stride(3) == 1
+    ld_in = x.stride(2)
+    assert x.stride(1) == W * ld_in and x.stride(0) == H * W * ld_in
+    Ho = (H + 2 * pad - ksize) // stride + 1
+    Wo = (W + 2 * pad - ksize) // stride + 1
+    if out is None:
+        out = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
+    ldc = out.stride(2)
+    assert out.stride(3) == 1 and out.stride(1) == Wo * ldc and out.stride(0) == Ho * Wo * ldc
+    if residual is not None:
+        assert residual.stride() == out.stride()
+    _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual), M=B * Ho * Wo, N=Cout,
+               K=ksize * ksize * cin, lda=ld_in, ldb=wp.shape[1], ldc=ldc, act=ACT[act], relu_in=int(relu_in),
+               conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride, conv_pad=pad, conv_h=H, conv_w=W,
+               conv_ho=Ho, conv_wo=Wo))
+    return out
+
+
+def conv_transpose2d(x, wp, bias_tiled, r):
+    """ConvTranspose2d(kernel = stride = r, padding 0) on NHWC: (B,H,W,Cin) -> (B,H*r,W*r,Cout)."""
+    B, H, W, Cin = x.shape
+    assert x.is_contiguous()
+    Cout = wp.shape[0] // (r * r)
+    out = torch.empty(B, H * r, W * r, Cout, dtype=torch.float32, device=x.device)
+    _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin, lda=Cin, ldb=Cin,
+               ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W))
+    return out
+
+
+def layernorm(x, weight, bias, eps):
+    rows, C = x.shape
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().pp_layernorm(_p(x), _p(weight), _p(bias), rows, C, float(eps), _p(y), _lib.stream_ptr()),
+               "pp_layernorm")
+    return y
+
+
+def softmax_rows_(x):
+    """In-place softmax over the last dim of a contiguous (..., n) tensor."""
+    assert x.is_contiguous()
+    n = x.shape[-1]
+    _lib.check(_lib.lib().pp_softmax_rows(_p(x), x.numel() // n, n, n, _lib.stream_ptr()), "pp_softmax_rows")
+    return x
+
+
+def groupnorm(x, weight, bias, groups, eps=1e-5, relu=False):
+    B, H, W, C = x.shape
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().pp_groupnorm_nhwc(_p(x), _p(weight), _p(bias), B, H * W, C, groups, float(eps), int(relu),
+                                            _p(y), _lib.stream_ptr()), "pp_groupnorm_nhwc")
+    return y
+
+
+def to_nhwc(x):
+    """(B,C,H,W) -> (B,H,W,C)."""
+    B, C, H, W = x.shape
+    x = x.contiguous().float()
+    out = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().pp_transpose_batched(_p(x), B, C, H * W, _p(out), C, 0, _lib.stream_ptr()),
+               "pp_transpose_batched")
+    return out
+
+
+def to_nchw(x):
+    """(B,H,W,C) -> (B,C,H,W)."""
+    B, H, W, C = x.shape
+    assert x.is_contiguous()
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().pp_transpose_batched(_p(x), B, H * W, C, _p(out), H * W, 0, _lib.stream_ptr()),
+               "pp_transpose_batched")
+    return out

@@ -1,0 +1,122 @@
+"""GPU numerics of the network engine (GEMM / implicit-GEMM conv / norms) against plain PyTorch
+fp32 CPU references of the same ops."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+gpu = pytest.mark.gpu
+TOL = 2e-4  # fp32 products/accumulation on both sides; differences are summation order only
+
+
+def _close(a, b, tol=TOL):
+    a, b = a.cpu(), b.cpu()
+    scale = max(1.0, float(b.abs().max()))
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, (err, scale)
+
+
+@gpu
+@pytest.mark.parametrize("M,K,N", [(257, 384, 1152), (8224 // 8, 768, 768), (5, 16384, 1024), (130, 75, 256), (64, 256, 2), (1, 256, 1)])
+@pytest.mark.parametrize("act", [None, "relu", "gelu", "leaky01", "tanh"])
+def test_linear(M, K, N, act):
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(M + K + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    ref = F.linear(x, w, b)
+    ref = {None: lambda t: t, "relu": F.relu, "gelu": F.gelu, "leaky01": lambda t: F.leaky_relu(t, 0.1),
+           "tanh": torch.tanh}[act](ref)
+    _close(ops.linear(x.cuda(), w.cuda(), b.cuda(), act=act), ref)
+
+
+@gpu
+def test_linear_layerscale_residual_and_strided_rows():
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(300, 3 * 64, generator=g)
+    w, b = torch.randn(96, 64, generator=g) / 8, torch.randn(96, generator=g)
+    gamma, res = torch.randn(96, generator=g), torch.randn(300, 96, generator=g)
+    xs = x[:, 64:128]  # a column slice: row stride 192
+    ref = res + gamma * F.linear(xs, w, b)
+    _close(ops.linear(x.cuda()[:, 64:128], w.cuda(), b.cuda(), gamma=gamma.cuda(), residual=res.cuda()), ref)
+
+
+@gpu
+@pytest.mark.parametrize("cin,cout,k,s,p,hw", [(256, 256, 1, 1, 0, 16), (256, 256, 3, 2, 1, 16), (640, 512, 3, 1, 1, 32),
+                                              (2, 128, 7, 1, 3, 32), (75, 256, 1, 1, 0, 16), (3, 64, 14, 14, 0, 28),
+                                              (256, 2, 3, 1, 1, 16), (256, 1, 1, 1, 0, 64), (192 + 64, 126, 3, 1, 1, 16)])
+def test_conv2d_vs_torch(cin, cout, k, s, p, hw):
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    B = 2
+    x = torch.randn(B, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x, w, b, stride=s, padding=p))
+    out = ops.conv2d(ops.to_nhwc(x.cuda()), ops.pack_conv_weight(w.cuda()), b.cuda(), k, s, p, act="relu")
+    _close(ops.to_nchw(out), ref)
+
+
+@gpu
+def test_conv2d_relu_in_residual_and_concat_slices():
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    B, C, H = 2, 64, 16
+    x = torch.randn(B, C, H, H, generator=g)
+    w, b = torch.randn(C, C, 3, 3, generator=g) / 24, torch.randn(C, generator=g)
+    ref = F.conv2d(F.relu(x), w, b, padding=1) + x  # ResidualConvUnit pattern (dpt.py:82-95)
+    xh = ops.to_nhwc(x.cuda())
+    out = ops.conv2d(xh, ops.pack_conv_weight(w.cuda()), b.cuda(), 3, 1, 1, relu_in=True, residual=xh)
+    _close(ops.to_nchw(out), ref)
+    # read from / write into channel slices of wider NHWC buffers (the 640-channel concat of the flow decoder)
+    wide_in = torch.randn(B, H, H, 3 * C, generator=g).cuda()
+    wide_out = torch.zeros(B, H, H, 2 * C).cuda()
+    ops.conv2d(wide_in[..., C:2 * C], ops.pack_conv_weight(w.cuda()), b.cuda(), 3, 1, 1, out=wide_out[..., C:], cin=C)
+    ref2 = F.conv2d(wide_in[..., C:2 * C].permute(0, 3, 1, 2).cpu(), w, b, padding=1)
+    _close(wide_out[..., C:].permute(0, 3, 1, 2), ref2)
+    assert float(wide_out[..., :C].abs().max()) == 0.0
+
+
+@gpu
+@pytest.mark.parametrize("r,cin,cout", [(4, 256, 256), (2, 512, 512), (2, 64, 96)])
+def test_conv_transpose(r, cin, cout):
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(r)
+    x = torch.randn(2, cin, 16, 16, generator=g)
+    w, b = torch.randn(cin, cout, r, r, generator=g) / cin ** 0.5, torch.randn(cout, generator=g)
+    ref = F.conv_transpose2d(x, w, b, stride=r)
+    wp, bp = ops.pack_convT_weight(w.cuda(), b.cuda())
+    _close(ops.to_nchw(ops.conv_transpose2d(ops.to_nhwc(x.cuda()), wp, bp, r)), ref)
+
+
+@gpu
+def test_attention_products_softmax_layernorm_groupnorm():
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    B, T, h, hd = 3, 257, 6, 64
+    qkv = torch.randn(B, T, 3, h, hd, generator=g)
+    q, k, v = qkv[:, :, 0].permute(0, 2, 1, 3), qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3)
+    att = ((q * hd ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)
+    ref = (att @ v).transpose(1, 2).reshape(B, T, h * hd)
+    d = qkv.cuda()
+    qd, kd, vd = d[:, :, 0].permute(0, 2, 1, 3), d[:, :, 1].permute(0, 2, 1, 3), d[:, :, 2].permute(0, 2, 1, 3)
+    s = ops.bmm_nt(qd, kd, alpha=hd ** -0.5)
+    _close(s, (q * hd ** -0.5) @ k.transpose(-2, -1))
+    ops.softmax_rows_(s)
+    _close(s, att, 1e-5)
+    o = torch.empty(B, T, h, hd, device="cuda")
+    ops.bmm_nn(s, vd, o.permute(0, 2, 1, 3))
+    _close(o.reshape(B, T, h * hd), ref)
+    x = torch.randn(500, 384, generator=g) * 3 + 1
+    w, b = torch.randn(384, generator=g), torch.randn(384, generator=g)
+    _close(ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6), F.layer_norm(x, (384,), w, b, 1e-6), 1e-5)
+    xi = torch.randn(2, 256, 16, 16, generator=g)
+    wg, bg = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    _close(ops.to_nchw(ops.groupnorm(ops.to_nhwc(xi.cuda()), wg.cuda(), bg.cuda(), 32, relu=True)),
+           F.relu(F.group_norm(xi, 32, wg, bg)), 1e-5)
