@@ -147,6 +147,7 @@ typedef struct PpGemmDesc {
     const float* bias;     /* [N] or NULL */
     const float* gamma;    /* [N] or NULL (LayerScale) */
     const float* residual; /* laid out like C, or NULL */
+    const float* residual2; /* second addend laid out like C, or NULL (FeatureFusionBlock, dpt.py:139-141) */
     int M, N, K;
     int lda, ldb, ldc;
     int b_kn;
@@ -157,6 +158,7 @@ typedef struct PpGemmDesc {
     int relu_in;           /* apply ReLU to A while loading (ResidualConvUnit, dpt.py:82-86)           */
     /* implicit im2col (conv_kh == 0: dense A): k = (ky*conv_kw + kx)*conv_cin + ci                    */
     int conv_kh, conv_kw, conv_cin, conv_stride, conv_pad, conv_h, conv_w, conv_ho, conv_wo;
+    long long conv_bstride; /* floats between consecutive images of A (0: conv_h*conv_w*lda)           */
     /* ConvTranspose2d(kernel = stride = shuffle_r): rows are the pixels of (b, shuffle_h, shuffle_w),
      * column n = (dy*r + dx)*Cout + co is stored at pixel (y*r+dy, x*r+dx), channel co               */
     int shuffle_r, shuffle_h, shuffle_w;
@@ -172,9 +174,36 @@ int pp_softmax_rows(float* x, int rows, int n, int ld, void* stream);
 /* nn.GroupNorm(groups, C, eps) (+ReLU when relu != 0) on an NHWC tensor (B, HW, C). */
 int pp_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, int B, int HW, int C,
                       int groups, float eps, int relu, float* y, void* stream);
-/* out[b, c, col_off + r] = in[b, r, c]: (B,R,C) -> (B,C,ld_out); NCHW <-> NHWC at the API boundary. */
-int pp_transpose_batched(const float* in, int B, int R, int C, float* out, int ld_out, int col_off,
-                         void* stream);
+/* out[b, c, col_off + r] = in[b, r, c]: (B,R,C) -> (B,C,ld_out); NCHW <-> NHWC at the API boundary.
+ * Batch strides in floats (0: dense). */
+int pp_transpose_batched(const float* in, long long in_batch_stride, int B, int R, int C, float* out,
+                         long long out_batch_stride, int ld_out, int col_off, void* stream);
+/* vision_transformer.py:209-216: tokens (B,T+1,C) = [cls; patches (B,T,C)] + pos (T+1,C). */
+int pp_assemble_tokens(const float* patches, const float* cls_token, const float* pos, int B, int T, int C,
+                       float* tokens, void* stream);
+/* F.normalize(x, dim=1) for [rows][n<=64]. */
+int pp_normalize_rows(const float* x, int rows, int n, float eps, float* y, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Stage-3 sampling kernels (picopose_amd/csrc/pp_sample.hip), NHWC.
+ * ------------------------------------------------------------------------- */
+/* F.interpolate(mode="bilinear", align_corners=True) (dpt.py:150-152, flow_decoder.py:88-92); the
+ * result is multiplied by `mul` (the 2x of the flow up-sampling). */
+int pp_resize_bilinear_nhwc(const float* in, int B, int H, int W, int C, int Ho, int Wo, float mul,
+                            float* out, void* stream);
+/* FlowDecoder.feature_sample (flow_decoder.py:49-56): out[b,p,:] = bilinear(feat[b], p + flow[b,p]),
+ * zeros padding, align_corners=True.  flow rows have ld_flow floats (x, y first), out rows ld_out. */
+int pp_warp_nhwc(const float* feat, const float* flow, int B, int H, int W, int C, int ld_flow,
+                 float* out, int ld_out, void* stream);
+/* nn.AvgPool2d(2,2) on NHWC. */
+int pp_avgpool2_nhwc(const float* in, int B, int H, int W, int C, float* out, void* stream);
+/* CorrelationPyramid (raft_decoder.py:30-53) + CorrLookup (corr_lookup.py:100-134) without the
+ * (B*HW, HW) volume: f1 (B,H,W,C), f2_l{0,1,2} = f2 and its 2x2 average pools, flow (B,H,W,ld_flow);
+ * out (B,H,W,ld_out) with channel l*(2r+1)^2 + a*(2r+1) + b = corr_l sampled at x offset a-r,
+ * y offset b-r around (p + flow)/2^l. */
+int pp_corr_lookup_nhwc(const float* f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
+                        const float* flow, int B, int H, int W, int C, int levels, int radius,
+                        int ld_flow, float* out, int ld_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ _lib = None
 class PpGemmDesc(ctypes.Structure):
     _fields_ = [
         ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
-        ("gamma", ctypes.c_void_p), ("residual", ctypes.c_void_p),
+        ("gamma", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("residual2", ctypes.c_void_p),
         ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
         ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int), ("b_kn", ctypes.c_int),
         ("batch0", ctypes.c_int), ("batch1", ctypes.c_int),
@@ -31,6 +31,7 @@ class PpGemmDesc(ctypes.Structure):
         ("conv_kh", ctypes.c_int), ("conv_kw", ctypes.c_int), ("conv_cin", ctypes.c_int),
         ("conv_stride", ctypes.c_int), ("conv_pad", ctypes.c_int), ("conv_h", ctypes.c_int),
         ("conv_w", ctypes.c_int), ("conv_ho", ctypes.c_int), ("conv_wo", ctypes.c_int),
+        ("conv_bstride", ctypes.c_longlong),
         ("shuffle_r", ctypes.c_int), ("shuffle_h", ctypes.c_int), ("shuffle_w", ctypes.c_int),
     ]
 
@@ -77,7 +78,13 @@ def lib():
         L.pp_layernorm.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp]
         L.pp_softmax_rows.argtypes = [vp, i32, i32, i32, vp]
         L.pp_groupnorm_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp]
-        L.pp_transpose_batched.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp]
+        L.pp_transpose_batched.argtypes = [vp, c.c_longlong, i32, i32, i32, vp, c.c_longlong, i32, i32, vp]
+        L.pp_assemble_tokens.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+        L.pp_normalize_rows.argtypes = [vp, i32, i32, f32, vp, vp]
+        L.pp_resize_bilinear_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp]
+        L.pp_warp_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]
+        L.pp_avgpool2_nhwc.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+        L.pp_corr_lookup_nhwc.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
         _lib = L
     return _lib
 

@@ -68,7 +68,7 @@ __device__ __forceinline__ f4 load_a(const PpGemmDesc& d, const float* __restric
                 const int ky = tap / d.conv_kw, kx = tap - ky * d.conv_kw;
                 const int iy = oy * d.conv_stride - d.conv_pad + ky, ix = ox * d.conv_stride - d.conv_pad + kx;
                 if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w)
-                    v = *(const f4*)(A + (((size_t)b_img * d.conv_h + iy) * d.conv_w + ix) * d.lda + ci);
+                    v = *(const f4*)(A + (size_t)b_img * d.conv_bstride + ((size_t)iy * d.conv_w + ix) * d.lda + ci);
             }
         } else {
 #pragma unroll
@@ -79,7 +79,7 @@ __device__ __forceinline__ f4 load_a(const PpGemmDesc& d, const float* __restric
                     const int ky = tap / d.conv_kw, kx = tap - ky * d.conv_kw;
                     const int iy = oy * d.conv_stride - d.conv_pad + ky, ix = ox * d.conv_stride - d.conv_pad + kx;
                     if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w)
-                        v[i] = A[(((size_t)b_img * d.conv_h + iy) * d.conv_w + ix) * d.lda + ci];
+                        v[i] = A[(size_t)b_img * d.conv_bstride + ((size_t)iy * d.conv_w + ix) * d.lda + ci];
                 }
             }
         }
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const PpGemmDesc d) {
     const float* Bm = d.B + (size_t)z0 * d.b_bs0 + (size_t)z1 * d.b_bs1;
     float* C = d.C + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1;
     const float* R = d.residual ? d.residual + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1 : nullptr;
+    const float* R2 = d.residual2 ? d.residual2 + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1 : nullptr;
 
     // this thread's 4 (row, k-quad) slots of the A and B tiles: idx = tid + 256 j -> row idx>>3, quad idx&7
     int arow[4], ab[4], aoy[4], aox[4];
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const PpGemmDesc d) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q][e], bf[j][q][e], acc[i][j], 0, 0, 0);
     }
 
-    // ---- epilogue: out = residual + gamma * act(alpha * acc + bias)
+    // ---- epilogue: out = residual + residual2 + gamma * act(alpha * acc + bias)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wc * 64 + j * 32 + l31;
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const PpGemmDesc d) {
                     off = (((size_t)b * d.shuffle_h * r + y * r + dy) * (d.shuffle_w * r) + x * r + dx) * d.ldc + co;
                 }
                 if (R) v += R[off];
+                if (R2) v += R2[off];
                 C[off] = v;
             }
     }
@@ -303,13 +305,14 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict_
 }
 
 // (B, C, H*W) <-> (B, H*W, C) through a 32x33 LDS tile
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int R, int Cc,
-                                                        float* __restrict__ out, int ld_out, int col_off) {
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, long long in_bs, int R,
+                                                        int Cc, float* __restrict__ out, long long out_bs,
+                                                        int ld_out, int col_off) {
     __shared__ float t[32][33];
     const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    const float* ib = in + (size_t)b * R * Cc;
-    float* ob = out + (size_t)b * Cc * ld_out;
+    const float* ib = in + (size_t)b * in_bs;
+    float* ob = out + (size_t)b * out_bs;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + ty + 8 * i, c = c0 + tx;
@@ -321,6 +324,29 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
         const int c = c0 + ty + 8 * i, r = r0 + tx;
         if (r < R && c < Cc) ob[(size_t)c * ld_out + col_off + r] = t[tx][ty + 8 * i];
     }
+}
+
+// DinoVisionTransformer.prepare_tokens_with_masks (vision_transformer.py:209-216):
+// tokens[b,0] = cls + pos[0]; tokens[b,1+p] = patch[b,p] + pos[1+p]
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ patches,
+                                                              const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, int T, int C,
+                                                              float* __restrict__ tokens) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const float* src = t == 0 ? cls : patches + ((size_t)b * T + (t - 1)) * C;
+    float* dst = tokens + ((size_t)b * (T + 1) + t) * C;
+    for (int c = threadIdx.x; c < C; c += 256) dst[c] = src[c] + pos[(size_t)t * C + c];
+}
+
+// F.normalize(x, dim=1) for short rows (affine_regressor.py:83)
+__global__ void normalize_rows_kernel(const float* __restrict__ x, int rows, int n, float eps,
+                                      float* __restrict__ y) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s = fmaf(x[(size_t)r * n + i], x[(size_t)r * n + i], s);
+    const float d = fmaxf(sqrtf(s), eps);
+    for (int i = 0; i < n; ++i) y[(size_t)r * n + i] = x[(size_t)r * n + i] / d;
 }
 
 }  // namespace
@@ -339,11 +365,12 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     }
     if (d.shuffle_r != 0 && (d.N % (d.shuffle_r * d.shuffle_r) != 0 || d.shuffle_h * d.shuffle_w <= 0))
         return PP_EINVAL;
+    if (d.conv_kh != 0 && d.conv_bstride == 0) d.conv_bstride = (long long)d.conv_h * d.conv_w * d.lda;
     // 16-byte vector loads need aligned rows: K-contiguous operands with lda/ldb/Cin % 4 == 0
     bool vec = ((uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.B % 16 == 0) && d.lda % 4 == 0 &&
                (d.b_kn || d.ldb % 4 == 0) && d.a_bs0 % 4 == 0 && d.a_bs1 % 4 == 0 && d.b_bs0 % 4 == 0 &&
                d.b_bs1 % 4 == 0;
-    if (d.conv_kh != 0 && d.conv_cin % 4 != 0) vec = false;
+    if (d.conv_kh != 0 && (d.conv_cin % 4 != 0 || d.conv_bstride % 4 != 0)) vec = false;
     const dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch0 * d.batch1);
     if (vec)
         hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, d);
@@ -375,10 +402,28 @@ int pp_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, int
     return pp_last_launch();
 }
 
-int pp_transpose_batched(const float* in, int B, int R, int C, float* out, int ld_out, int col_off, void* stream) {
-    if (!in || !out || B <= 0 || R <= 0 || C <= 0 || ld_out < R + col_off - 0 || col_off < 0) return PP_EINVAL;
+int pp_transpose_batched(const float* in, long long in_batch_stride, int B, int R, int C, float* out,
+                         long long out_batch_stride, int ld_out, int col_off, void* stream) {
+    if (!in || !out || B <= 0 || R <= 0 || C <= 0 || ld_out < R + col_off || col_off < 0) return PP_EINVAL;
+    if (in_batch_stride == 0) in_batch_stride = (long long)R * C;
+    if (out_batch_stride == 0) out_batch_stride = (long long)C * ld_out;
     hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, B), dim3(256), 0,
-                       (hipStream_t)stream, in, R, C, out, ld_out, col_off);
+                       (hipStream_t)stream, in, in_batch_stride, R, C, out, out_batch_stride, ld_out, col_off);
+    return pp_last_launch();
+}
+
+int pp_assemble_tokens(const float* patches, const float* cls_token, const float* pos, int B, int T, int C,
+                       float* tokens, void* stream) {
+    if (!patches || !cls_token || !pos || !tokens || B <= 0 || T <= 0 || C <= 0) return PP_EINVAL;
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(T + 1, B), dim3(256), 0, (hipStream_t)stream, patches,
+                       cls_token, pos, T, C, tokens);
+    return pp_last_launch();
+}
+
+int pp_normalize_rows(const float* x, int rows, int n, float eps, float* y, void* stream) {
+    if (!x || !y || rows <= 0 || n <= 0 || n > 64) return PP_EINVAL;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, x,
+                       rows, n, eps, y);
     return pp_last_launch();
 }
 

@@ -1,0 +1,214 @@
+// Sampling kernels of stage 3 (NHWC): bilinear resize (align_corners=True), the feature warp
+// (grid_sample, zeros padding) and the on-demand local correlation lookup that replaces the
+// reference's materialised correlation pyramid.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/picopose_hip.h"
+#include "pp_common.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// F.interpolate(mode="bilinear", align_corners=True) — dpt.py:150-152, flow_decoder.py:88-92.
+// ATen: src = dst * (in-1)/(out-1); i0 = floor, i1 = min(i0+1, in-1), lambda = src - i0.
+__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ in, int H, int W, int C,
+                                                     int Ho, int Wo, float mul, float* __restrict__ out) {
+    const int b = blockIdx.z, oy = blockIdx.y, tid = threadIdx.x;
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const float fy = sy * (float)oy;
+    const int y0 = (int)fy, y1 = y0 + (y0 < H - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, hy = 1.f - ly;
+    const float* ib = in + (size_t)b * H * W * C;
+    float* ob = out + ((size_t)b * Ho + oy) * Wo * C;
+    for (int i = blockIdx.x * 256 + tid; i < Wo * C; i += gridDim.x * 256) {
+        const int ox = i / C, c = i - ox * C;
+        const float fx = sx * (float)ox;
+        const int x0 = (int)fx, x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float lx = fx - (float)x0, hx = 1.f - lx;
+        const float v = hy * (hx * ib[((size_t)y0 * W + x0) * C + c] + lx * ib[((size_t)y0 * W + x1) * C + c]) +
+                        ly * (hx * ib[((size_t)y1 * W + x0) * C + c] + lx * ib[((size_t)y1 * W + x1) * C + c]);
+        ob[i] = v * mul;
+    }
+}
+
+// coordinate round trip of the reference: bilinear_sample scales pixel coords to [-1,1]
+// (corr_lookup.py:61-63) and grid_sample(align_corners=True) maps them back
+__device__ __forceinline__ float roundtrip(float x, int size) {
+    const float n = x * 2.f / (float)(size - 1 > 1 ? size - 1 : 1) - 1.f;
+    return ((n + 1.f) / 2.f) * (float)(size - 1);
+}
+
+// FlowDecoder.feature_sample — flow_decoder.py:49-56: out[p] = bilinear(feat, p + flow[p]), zeros padding.
+// One wave per pixel, lanes over channels (float4).
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ feat, const float* __restrict__ flow,
+                                                   int H, int W, int C, int ld_flow, float* __restrict__ out,
+                                                   int ld_out) {
+    const int b = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    const float* fl = flow + ((size_t)b * H * W + p) * ld_flow;
+    const float ix = roundtrip((float)x + fl[0], W), iy = roundtrip((float)y + fl[1], H);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix, wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
+    const float* fb = feat + (size_t)b * H * W * C;
+    float* o = out + ((size_t)b * H * W + p) * ld_out;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+    for (int c = lane * 4; c < C; c += 256) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (vy0 && vx0) acc += *(const f4*)(fb + ((size_t)y0 * W + x0) * C + c) * (wx0 * wy0);
+        if (vy0 && vx1) acc += *(const f4*)(fb + ((size_t)y0 * W + x0 + 1) * C + c) * (wx1 * wy0);
+        if (vy1 && vx0) acc += *(const f4*)(fb + ((size_t)(y0 + 1) * W + x0) * C + c) * (wx0 * wy1);
+        if (vy1 && vx1) acc += *(const f4*)(fb + ((size_t)(y0 + 1) * W + x0 + 1) * C + c) * (wx1 * wy1);
+        *(f4*)(o + c) = acc;
+    }
+}
+
+// nn.AvgPool2d(2, 2) on NHWC (the pyramid levels of raft_decoder.py:49-51, applied to the
+// feature map instead of the correlation volume: the mean commutes with the dot product)
+__global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ in, int H, int W, int C,
+                                                       float* __restrict__ out) {
+    const int Ho = H / 2, Wo = W / 2, b = blockIdx.y;
+    const size_t n = (size_t)Ho * Wo * C;
+    const float* ib = in + (size_t)b * H * W * C;
+    float* ob = out + (size_t)b * n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t q = i / C;
+        const int ox = (int)(q % Wo), oy = (int)(q / Wo);
+        const float* p = ib + ((size_t)(2 * oy) * W + 2 * ox) * C + c;
+        ob[i] = ((p[0] + p[C]) + (p[(size_t)W * C] + p[(size_t)W * C + C])) * 0.25f;
+    }
+}
+
+// CorrelationPyramid + CorrLookup fused — raft_decoder.py:30-53, corr_lookup.py:100-134.
+// corr_l[p, q] = <f1[p], pool_l(f2)[q]> / sqrt(C); for every pixel p and level l the (2r+1)^2
+// window around (p + flow[p]) / 2^l is bilinearly sampled (zeros padding).  Output channel
+// l*(2r+1)^2 + a*(2r+1) + b samples at x offset a-r, y offset b-r (the reference's transposed
+// window order).  One wave per pixel: the (2r+2)^2 integer neighbours per level are dotted by
+// one lane each (C sequential fmas, f1[p] broadcast from LDS), then lanes blend the 4 corners.
+constexpr int MAXR = 2, TW = 2 * MAXR + 2, MAXL = 3;
+__global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ f1,
+                                                          const float* __restrict__ f2l0,
+                                                          const float* __restrict__ f2l1,
+                                                          const float* __restrict__ f2l2,
+                                                          const float* __restrict__ flow, int H, int W, int C,
+                                                          int L, int r, int ld_flow, float inv_sqrt_c,
+                                                          float* __restrict__ out, int ld_out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* a = sm + (size_t)wv * (C + MAXL * TW * TW);  // f1[p] then the corr tables
+    float* tab = a + C;
+    const int b = blockIdx.y, p = blockIdx.x * 4 + wv;
+    const bool live = p < H * W;
+    const int y = live ? p / W : 0, x = live ? p - y * W : 0;
+    const int tw = 2 * r + 2, win = 2 * r + 1;
+    if (live) {
+        const float* src = f1 + ((size_t)b * H * W + p) * C;
+        for (int c = lane * 4; c < C; c += 256) *(f4*)(a + c) = *(const f4*)(src + c);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    float cx[MAXL], cy[MAXL];
+    int bx[MAXL], by[MAXL];
+    if (live) {
+        const float* fl = flow + ((size_t)b * H * W + p) * ld_flow;
+        const float gx = (float)x + fl[0], gy = (float)y + fl[1];
+        for (int l = 0; l < L; ++l) {
+            const int Hl = H >> l, Wl = W >> l;
+            const float sc = (float)(1 << l);
+            // centre sample (offset 0): its integer corner anchors the table, offsets shift by integers
+            cx[l] = roundtrip(gx / sc, Wl);
+            cy[l] = roundtrip(gy / sc, Hl);
+            bx[l] = (int)floorf(cx[l]) - r;
+            by[l] = (int)floorf(cy[l]) - r;
+        }
+        const int npos = L * tw * tw;
+        for (int i = lane; i < npos; i += 64) {
+            const int l = i / (tw * tw), rem = i - l * tw * tw, dy = rem / tw, dx = rem - dy * tw;
+            const int Hl = H >> l, Wl = W >> l;
+            const int qx = bx[l] + dx, qy = by[l] + dy;
+            float dot = 0.f;
+            if (qx >= 0 && qx < Wl && qy >= 0 && qy < Hl) {
+                const float* f2 = l == 0 ? f2l0 : (l == 1 ? f2l1 : f2l2);
+                const float* q = f2 + (((size_t)b * Hl + qy) * Wl + qx) * C;
+                for (int c = 0; c < C; c += 4) {
+                    const f4 u = *(const f4*)(a + c), v = *(const f4*)(q + c);
+                    dot = fmaf(u.x, v.x, dot);
+                    dot = fmaf(u.y, v.y, dot);
+                    dot = fmaf(u.z, v.z, dot);
+                    dot = fmaf(u.w, v.w, dot);
+                }
+            }
+            tab[i] = dot * inv_sqrt_c;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    if (live) {
+        float* o = out + ((size_t)b * H * W + p) * ld_out;
+        const int nout = L * win * win;
+        for (int i = lane; i < nout; i += 64) {
+            const int l = i / (win * win), rem = i - l * win * win, ai = rem / win, bi = rem - ai * win;
+            const float wx1 = cx[l] - floorf(cx[l]), wy1 = cy[l] - floorf(cy[l]);
+            const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+            const float* t = tab + l * tw * tw + bi * tw + ai;  // x offset a-r -> dx = ai, y offset b-r -> dy = bi
+            o[i] = t[0] * (wx0 * wy0) + t[1] * (wx1 * wy0) + t[tw] * (wx0 * wy1) + t[tw + 1] * (wx1 * wy1);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pp_resize_bilinear_nhwc(const float* in, int B, int H, int W, int C, int Ho, int Wo, float mul, float* out,
+                            void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return PP_EINVAL;
+    const int gx = (Wo * C + 255) / 256;
+    hipLaunchKernelGGL(resize_kernel, dim3(gx < 64 ? gx : 64, Ho, B), dim3(256), 0, (hipStream_t)stream, in, H, W,
+                       C, Ho, Wo, mul, out);
+    return pp_last_launch();
+}
+
+int pp_warp_nhwc(const float* feat, const float* flow, int B, int H, int W, int C, int ld_flow, float* out,
+                 int ld_out, void* stream) {
+    if (!feat || !flow || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || ld_flow < 2 ||
+        ld_out < C || ld_out % 4 != 0 || ((uintptr_t)out % 16) != 0)
+        return PP_EINVAL;
+    hipLaunchKernelGGL(warp_kernel, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, flow, H, W,
+                       C, ld_flow, out, ld_out);
+    return pp_last_launch();
+}
+
+int pp_avgpool2_nhwc(const float* in, int B, int H, int W, int C, float* out, void* stream) {
+    if (!in || !out || B <= 0 || H < 2 || W < 2 || C <= 0 || H % 2 != 0 || W % 2 != 0) return PP_EINVAL;
+    const size_t n = (size_t)(H / 2) * (W / 2) * C;
+    const int gx = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, in, H, W, C, out);
+    return pp_last_launch();
+}
+
+int pp_corr_lookup_nhwc(const float* f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
+                        const float* flow, int B, int H, int W, int C, int levels, int radius, int ld_flow,
+                        float* out, int ld_out, void* stream) {
+    if (!f1 || !f2_l0 || !flow || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return PP_EINVAL;
+    if (levels < 1 || levels > MAXL || radius < 1 || radius > MAXR) return PP_EINVAL;
+    if ((levels > 1 && !f2_l1) || (levels > 2 && !f2_l2)) return PP_EINVAL;
+    if ((H >> (levels - 1)) < 1 || (W >> (levels - 1)) < 1 || ld_flow < 2) return PP_EINVAL;
+    const int win = 2 * radius + 1;
+    if (ld_out < levels * win * win) return PP_EINVAL;
+    const size_t smem = (size_t)4 * (C + MAXL * TW * TW) * sizeof(float);
+    hipLaunchKernelGGL(corr_lookup_kernel, dim3((H * W + 3) / 4, B), dim3(256), smem, (hipStream_t)stream, f1,
+                       f2_l0, f2_l1, f2_l2, flow, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out,
+                       ld_out);
+    return pp_last_launch();
+}
+
+}  // extern "C"

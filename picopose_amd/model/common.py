@@ -1,0 +1,92 @@
+"""Parameter containers with the reference's state_dict names, and the pack-once cache.
+
+The modules below hold exactly the tensors the reference's nn.Modules hold (same names, shapes and
+buffers, so the authors' Lightning checkpoint loads unchanged — SURVEY.md §8b) but no torch compute:
+`forward` runs on the HIP engine (picopose_amd/ops.py).  Weights are re-laid-out once per load
+("packing": conv filters to (Cout, KH*KW*Cin), eval BatchNorm folded into the preceding conv, ...)."""
+import torch
+import torch.nn as nn
+
+
+class Holder(nn.Module):
+    """A bare named container (children / parameters are attached by the builders below)."""
+
+
+def linear_p(cin, cout, bias=True):
+    m = Holder()
+    m.weight = nn.Parameter(torch.zeros(cout, cin))
+    if bias:
+        m.bias = nn.Parameter(torch.zeros(cout))
+    return m
+
+
+def conv_p(cin, cout, k, bias=True):
+    m = Holder()
+    m.weight = nn.Parameter(torch.zeros(cout, cin, k, k))
+    if bias:
+        m.bias = nn.Parameter(torch.zeros(cout))
+    return m
+
+
+def convT_p(cin, cout, k):
+    m = Holder()
+    m.weight = nn.Parameter(torch.zeros(cin, cout, k, k))
+    m.bias = nn.Parameter(torch.zeros(cout))
+    return m
+
+
+def norm_p(c):
+    m = Holder()
+    m.weight = nn.Parameter(torch.ones(c))
+    m.bias = nn.Parameter(torch.zeros(c))
+    return m
+
+
+def bn_p(c):
+    m = norm_p(c)
+    m.register_buffer("running_mean", torch.zeros(c))
+    m.register_buffer("running_var", torch.ones(c))
+    m.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+    return m
+
+
+def seq(*mods, skip=()):
+    """nn.Sequential-like numbering with holes (activation slots own no tensors): returns a ModuleDict-backed
+    container whose children are named by their index in the reference's Sequential/ModuleList."""
+    m = Holder()
+    for i, sub in mods:
+        m.add_module(str(i), sub)
+    return m
+
+
+def fold_bn(w, b, bn, eps=1e-5):
+    """Conv (weight (Cout,...), bias or None) followed by eval BatchNorm2d -> equivalent conv."""
+    s = bn.weight / torch.sqrt(bn.running_var + eps)
+    w2 = w * s.reshape(-1, *([1] * (w.dim() - 1)))
+    b0 = b if b is not None else torch.zeros_like(bn.running_mean)
+    return w2, (b0 - bn.running_mean) * s + bn.bias
+
+
+class Packed(nn.Module):
+    """Mixin: `self.packed()` returns the cached device-side re-layout of the weights."""
+
+    def __init__(self):
+        super().__init__()
+        self._pack_cache = None
+
+    def _apply(self, fn, *a, **k):
+        self._pack_cache = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._pack_cache = None
+        for m in self.modules():
+            if isinstance(m, Packed):
+                m._pack_cache = None
+        return super().load_state_dict(*a, **k)
+
+    def packed(self):
+        if self._pack_cache is None:
+            with torch.no_grad():
+                self._pack_cache = self._pack()
+        return self._pack_cache

@@ -1,0 +1,142 @@
+"""Stage 1 backbone: DINOv2 ViT feature extractor on the HIP engine.
+
+Mirrors model/stage1/feature_extractor.py:82-109 (FeatureExtractor) over
+model/stage1/vision_transformer.py:44-228 and layers/{attention,block,mlp,layer_scale,patch_embed}.py:
+patch-embed conv 14x14/s14, cls token, bicubic-resampled position embedding, `depth` pre-norm
+blocks  x += ls1 * proj(softmax(q k^T / sqrt(d)) v);  x += ls2 * fc2(gelu(fc1(LN(x)))),
+returning the PRE-norm outputs of the blocks listed in cfg.interaction_indexes as (B,C,16,16)."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .common import Holder, Packed, conv_p, linear_p, norm_p
+
+ARCH = {  # vision_transformer.py:336-392
+    "vit_small": (384, 12, 6),
+    "vit_base": (768, 12, 12),
+    "vit_large": (1024, 24, 16),
+    "vit_giant2": (1536, 40, 24),
+}
+DESCRIPTOR_MAP = {  # feature_extractor.py:12-18
+    "dinov2_vits14": "vit_small",
+    "dinov2_vitb14": "vit_base",
+    "dinov2_vitl14": "vit_large",
+    "dinov2_vitg14": "vit_giant2",
+    "gigapose_dinov2": "vit_large",
+}
+
+
+def _block(dim):
+    b = Holder()
+    b.norm1 = norm_p(dim)
+    b.attn = Holder()
+    b.attn.qkv = linear_p(dim, 3 * dim)
+    b.attn.proj = linear_p(dim, dim)
+    b.ls1 = Holder()
+    b.ls1.gamma = nn.Parameter(torch.ones(dim))
+    b.norm2 = norm_p(dim)
+    b.mlp = Holder()
+    b.mlp.fc1 = linear_p(dim, 4 * dim)
+    b.mlp.fc2 = linear_p(4 * dim, dim)
+    b.ls2 = Holder()
+    b.ls2.gamma = nn.Parameter(torch.ones(dim))
+    return b
+
+
+class DinoViT(Holder):
+    def __init__(self, dim, depth, heads, img_size=518, patch=14):
+        super().__init__()
+        self.embed_dim = self.num_features = dim
+        self.num_heads = heads
+        self.patch_size = patch
+        self.interpolate_offset = 0.1
+        self.patch_embed = Holder()
+        self.patch_embed.proj = conv_p(3, dim, patch)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, (img_size // patch) ** 2 + 1, dim))
+        self.blocks = nn.ModuleList([_block(dim) for _ in range(depth)])
+        self.norm = norm_p(dim)  # unused on this path (pre-norm outputs) but part of the checkpoint
+        self.mask_token = nn.Parameter(torch.zeros(1, dim))
+
+
+class FeatureExtractor(Packed):
+    def __init__(self, cfg, freeze=False):
+        super().__init__()
+        self.cfg = cfg
+        self.blocks_to_take = [blocks[-1] for blocks in cfg.interaction_indexes]
+        dim, depth, heads = ARCH[DESCRIPTOR_MAP[cfg.vit_type]]
+        self.dinov2 = DinoViT(dim, depth, heads)
+        self.num_features = dim
+        self.patch_size = self.dinov2.patch_size
+
+    # ---- weights -------------------------------------------------------------------------
+    def _pos_embed(self, w0, h0):
+        """interpolate_pos_encoding (vision_transformer.py:179-207): bicubic, scale_factor=(w0+0.1)/sqrt(N).
+        A constant of the weights and the input size: resampled once at pack time."""
+        v = self.dinov2
+        pos = v.pos_embed.float()
+        N = pos.shape[1] - 1
+        if w0 * h0 == N:
+            return pos[0]
+        sq = int(math.sqrt(N))
+        sx, sy = float(w0 + v.interpolate_offset) / math.sqrt(N), float(h0 + v.interpolate_offset) / math.sqrt(N)
+        grid = F.interpolate(pos[:, 1:].reshape(1, sq, sq, -1).permute(0, 3, 1, 2), scale_factor=(sx, sy),
+                             mode="bicubic", antialias=False)
+        assert grid.shape[-2] == w0 and grid.shape[-1] == h0
+        return torch.cat([pos[0, :1], grid.permute(0, 2, 3, 1).reshape(w0 * h0, -1)], dim=0)
+
+    def _pack(self):
+        v = self.dinov2
+        return {
+            "patch_w": ops.pack_conv_weight(v.patch_embed.proj.weight.float()),
+            "pos": {},
+        }
+
+    def _pos(self, w0, h0):
+        pk = self.packed()
+        key = (w0, h0)
+        if key not in pk["pos"]:
+            with torch.no_grad():
+                pk["pos"][key] = self._pos_embed(w0, h0).contiguous()
+        return pk["pos"][key]
+
+    # ---- forward -------------------------------------------------------------------------
+    def forward_tokens(self, x):
+        """(B,3,H,W) -> list of token tensors (B, 1+hw, C) at the taken blocks (cls row first)."""
+        v = self.dinov2
+        B, _, H, W = x.shape
+        p = v.patch_size
+        assert H % p == 0 and W % p == 0  # patch_embed.py:73-74
+        h0, w0 = H // p, W // p
+        C, heads = v.embed_dim, v.num_heads
+        hd = C // heads
+        pk = self.packed()
+        img = ops.to_nhwc(x)
+        patches = ops.conv2d(img, pk["patch_w"], v.patch_embed.proj.bias, p, stride=p)        # (B,h0,w0,C)
+        tok = ops.assemble_tokens(patches.view(B, h0 * w0, C), v.cls_token.reshape(C), self._pos(h0, w0))
+        T = tok.shape[1]
+        xs = tok.view(B * T, C)
+        outs = []
+        for i, blk in enumerate(v.blocks):
+            h = ops.layernorm(xs, blk.norm1.weight, blk.norm1.bias, 1e-6)
+            qkv = ops.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias).view(B, T, 3, heads, hd)
+            q, k, val = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))                  # (B,heads,T,hd) views
+            att = ops.softmax_rows_(ops.bmm_nt(q, k, alpha=hd ** -0.5))                       # (B,heads,T,T)
+            o = torch.empty(B, T, heads, hd, dtype=torch.float32, device=x.device)
+            ops.bmm_nn(att, val, o.permute(0, 2, 1, 3))
+            xs = ops.linear(o.view(B * T, C), blk.attn.proj.weight, blk.attn.proj.bias, gamma=blk.ls1.gamma, residual=xs)
+            h = ops.layernorm(xs, blk.norm2.weight, blk.norm2.bias, 1e-6)
+            f = ops.linear(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act="gelu")
+            xs = ops.linear(f, blk.mlp.fc2.weight, blk.mlp.fc2.bias, gamma=blk.ls2.gamma, residual=xs)
+            if i in self.blocks_to_take:
+                outs.append(xs.view(B, T, C))
+        return outs, (h0, w0)
+
+    def forward(self, x):
+        """Drop-in for feature_extractor.py:93-109: (B,3,224,224) -> 4 x (B,C,16,16)."""
+        with torch.no_grad():
+            toks, (h0, w0) = self.forward_tokens(x)
+            return [ops.tokens_to_nchw(t, 1, h0, w0) for t in toks]

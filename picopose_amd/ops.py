@@ -82,7 +82,8 @@ def pack_convT_weight(w, bias):
     return wp, (bias.repeat(r * r).contiguous() if bias is not None else None)
 
 
-def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residual=None, out=None, cin=None):
+def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residual=None, out=None, cin=None,
+           residual2=None):
     """NHWC convolution. x (B,H,W,Cx) (channel-contiguous, may be a channel slice: cin <= Cx stride),
     wp (Cout, k*k*cin) from pack_conv_weight.  out may be a channel slice of a wider NHWC buffer."""
     B, H, W, Cx = x.shape
@@ -90,16 +91,18 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     Cout = wp.shape[0]
     assert wp.shape[1] == ksize * ksize * cin and x.stride(3) == 1
     ld_in = x.stride(2)
-    assert x.stride(1) == W * ld_in and x.stride(0) == H * W * ld_in
+    assert x.stride(1) == W * ld_in  # images may be spaced apart (tokens with a cls row): x.stride(0) is free
     Ho = (H + 2 * pad - ksize) // stride + 1
     Wo = (W + 2 * pad - ksize) // stride + 1
     if out is None:
         out = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
     ldc = out.stride(2)
     assert out.stride(3) == 1 and out.stride(1) == Wo * ldc and out.stride(0) == Ho * Wo * ldc
-    if residual is not None:
-        assert residual.stride() == out.stride()
-    _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual), M=B * Ho * Wo, N=Cout,
+    for r_ in (residual, residual2):
+        if r_ is not None:
+            assert r_.stride() == out.stride()
+    _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual), residual2=_p(residual2),
+               conv_bstride=x.stride(0), M=B * Ho * Wo, N=Cout,
                K=ksize * ksize * cin, lda=ld_in, ldb=wp.shape[1], ldc=ldc, act=ACT[act], relu_in=int(relu_in),
                conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride, conv_pad=pad, conv_h=H, conv_w=W,
                conv_ho=Ho, conv_wo=Wo))
@@ -148,7 +151,7 @@ def to_nhwc(x):
     B, C, H, W = x.shape
     x = x.contiguous().float()
     out = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().pp_transpose_batched(_p(x), B, C, H * W, _p(out), C, 0, _lib.stream_ptr()),
+    _lib.check(_lib.lib().pp_transpose_batched(_p(x), 0, B, C, H * W, _p(out), 0, C, 0, _lib.stream_ptr()),
                "pp_transpose_batched")
     return out
 
@@ -158,6 +161,79 @@ def to_nchw(x):
     B, H, W, C = x.shape
     assert x.is_contiguous()
     out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().pp_transpose_batched(_p(x), B, H * W, C, _p(out), H * W, 0, _lib.stream_ptr()),
+    _lib.check(_lib.lib().pp_transpose_batched(_p(x), 0, B, H * W, C, _p(out), 0, H * W, 0, _lib.stream_ptr()),
                "pp_transpose_batched")
     return out
+
+
+def resize_bilinear(x, Ho, Wo, mul=1.0):
+    """F.interpolate(bilinear, align_corners=True) on NHWC, result times `mul`."""
+    B, H, W, C = x.shape
+    assert x.is_contiguous()
+    out = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().pp_resize_bilinear_nhwc(_p(x), B, H, W, C, Ho, Wo, float(mul), _p(out), _lib.stream_ptr()),
+               "pp_resize_bilinear_nhwc")
+    return out
+
+
+def warp(feat, flow, out=None):
+    """grid_sample warp of NHWC `feat` by NHWC `flow` (B,H,W,>=2 with x,y first); out may be a channel slice."""
+    B, H, W, C = feat.shape
+    assert feat.is_contiguous() and flow.stride(3) == 1 and flow.stride(2) * W == flow.stride(1)
+    if out is None:
+        out = torch.empty_like(feat)
+    _lib.check(_lib.lib().pp_warp_nhwc(_p(feat), _p(flow), B, H, W, C, flow.stride(2), _p(out), out.stride(2),
+                                       _lib.stream_ptr()), "pp_warp_nhwc")
+    return out
+
+
+def avgpool2(x):
+    B, H, W, C = x.shape
+    assert x.is_contiguous()
+    out = torch.empty(B, H // 2, W // 2, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().pp_avgpool2_nhwc(_p(x), B, H, W, C, _p(out), _lib.stream_ptr()), "pp_avgpool2_nhwc")
+    return out
+
+
+def corr_lookup(f1, f2, flow, levels, radius):
+    """Correlation pyramid + lookup, NHWC: (B,H,W,C) x2, flow (B,H,W,>=2) -> (B,H,W,levels*(2r+1)^2)."""
+    B, H, W, C = f1.shape
+    assert f1.is_contiguous() and f2.is_contiguous() and flow.stride(3) == 1
+    pyr = [f2]
+    for _ in range(levels - 1):
+        pyr.append(avgpool2(pyr[-1]))
+    n = levels * (2 * radius + 1) ** 2
+    out = torch.empty(B, H, W, n, dtype=torch.float32, device=f1.device)
+    _lib.check(_lib.lib().pp_corr_lookup_nhwc(_p(f1), _p(pyr[0]), _p(pyr[1]) if levels > 1 else None,
+                                              _p(pyr[2]) if levels > 2 else None, _p(flow), B, H, W, C, levels, radius,
+                                              flow.stride(2), _p(out), n, _lib.stream_ptr()), "pp_corr_lookup_nhwc")
+    return out
+
+
+def tokens_to_nchw(tokens, skip, H, W):
+    """(B,T,C) token rows [skip: skip+H*W] -> (B,C,H,W)  (FeatureExtractor output, feature_extractor.py:105-107)."""
+    B, T, C = tokens.shape
+    assert tokens.is_contiguous()
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=tokens.device)
+    src = tokens[:, skip:]
+    _lib.check(_lib.lib().pp_transpose_batched(_p(src), T * C, B, H * W, C, _p(out), 0, H * W, 0, _lib.stream_ptr()),
+               "pp_transpose_batched")
+    return out
+
+
+def assemble_tokens(patches, cls_token, pos):
+    """patches (B,T,C), cls (C), pos (T+1,C) -> tokens (B,T+1,C)."""
+    B, T, C = patches.shape
+    assert patches.is_contiguous() and pos.is_contiguous() and cls_token.is_contiguous()
+    out = torch.empty(B, T + 1, C, dtype=torch.float32, device=patches.device)
+    _lib.check(_lib.lib().pp_assemble_tokens(_p(patches), _p(cls_token), _p(pos), B, T, C, _p(out), _lib.stream_ptr()),
+               "pp_assemble_tokens")
+    return out
+
+
+def normalize_rows(x, eps=1e-12):
+    rows, n = x.shape
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().pp_normalize_rows(_p(x), rows, n, float(eps), _p(y), _lib.stream_ptr()), "pp_normalize_rows")
+    return y
