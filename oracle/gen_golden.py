@@ -155,7 +155,81 @@ def gen_geometry():
     print("geometry fixtures written")
 
 
-GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry}
+def _small_cfg():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from netcfg import small_cfg
+
+    return small_cfg()
+
+
+def gen_nets():
+    """Reference modules (FeatureExtractor, AffineRegressor, DPTHead, FlowDecoder, CorrLookup) with weights from
+    oracle/weights.seeded_state_dict: only the seed, the small inputs and the outputs are stored."""
+    _ref()
+    sys.path.insert(0, os.path.join(REF, "model"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import ref_shims
+
+    ref_shims.install()
+    from model.stage1.feature_extractor import FeatureExtractor
+    from model.stage2.affine_regressor import AffineRegressor
+    from model.stage3.offset_regressor import OffsetRegressor
+    from utils.corr_lookup import CorrLookup
+    from model.stage3.raft_decoder import CorrelationPyramid
+
+    from oracle.weights import seeded_state_dict
+
+    cfg = _small_cfg()
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    with torch.no_grad():
+        fe = FeatureExtractor(cfg.stage1).eval()
+        fe.load_state_dict(seeded_state_dict(fe.state_dict(), 11))
+        x = torch.randn(1, 3, 224, 224, generator=g)
+        feats = fe(x)
+        out["vit/seed"] = np.int64(11)
+        out["vit/x"] = x.numpy()
+        out["vit/feat_last"] = feats[-1].numpy()
+        out["vit/feat_probe"] = torch.stack([f[0, :, 3, 5] for f in feats]).numpy()   # one pixel of every level
+
+        ar = AffineRegressor(cfg.stage2).eval()
+        ar.load_state_dict(seeded_state_dict(ar.state_dict(), 12))
+        sim = torch.rand(3, 256, 16, 16, generator=g)
+        t, s, ip = ar(sim)
+        out.update({"aff/seed": np.int64(12), "aff/sim": sim.numpy(), "aff/translation": t.numpy(), "aff/scale": s.numpy(),
+                    "aff/inplane": ip.numpy()})
+
+        orr = OffsetRegressor(cfg.stage3).eval()
+        orr.load_state_dict(seeded_state_dict(orr.state_dict(), 13))
+        ft = [0.5 * torch.randn(1, 384, 16, 16, generator=g) for _ in range(4)]
+        fr = [0.5 * torch.randn(1, 384, 16, 16, generator=g) for _ in range(4)]
+        dt = orr.dpt_head(ft)
+        dr = orr.dpt_head(fr)
+        flow0 = 0.5 + torch.randn(1, 2, 16, 16, generator=g)
+        cert0 = (torch.rand(1, 1, 16, 16, generator=g) > 0.3).float()
+        fl, ce = orr.flow_decoder(dt, dr, flow0, cert0)
+        out.update({"s3/seed": np.int64(13), "s3/init_flow": flow0.numpy(), "s3/init_cert": cert0.numpy()})
+        for i in range(4):
+            out[f"s3/ft{i}"] = ft[i].numpy()
+            out[f"s3/fr{i}"] = fr[i].numpy()
+        out["s3/dpt_t_path4"] = dt[0].numpy()
+        out["s3/dpt_t_path3_probe"] = dt[1][0, :, ::8, ::8].numpy()
+        out["s3/dpt_t_path2_probe"] = dt[2][0, :, ::16, ::16].numpy()
+        for i in range(3):
+            out[f"s3/flow{i}"] = fl[i].numpy()
+            out[f"s3/cert{i}"] = ce[i].numpy()
+
+        # correlation pyramid + lookup on its own (3 levels, radius 2, flows that leave the image)
+        f1 = torch.randn(2, 64, 16, 16, generator=g)
+        f2 = torch.randn(2, 64, 16, 16, generator=g)
+        fw = 3 * torch.randn(2, 2, 16, 16, generator=g)
+        look = CorrLookup(radius=2)(CorrelationPyramid(num_levels=3)(f1, f2), fw)
+        out.update({"corr/f1": f1.numpy(), "corr/f2": f2.numpy(), "corr/flow": fw.numpy(), "corr/out": look.numpy()})
+    np.savez_compressed(os.path.join(OUT, "nets.npz"), **out)
+    print("nets fixtures written")
+
+
+GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry, "nets": gen_nets}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

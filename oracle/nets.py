@@ -58,3 +58,122 @@ def vit_features(sd, x, heads, blocks_to_take, prefix="feature_extractor.dinov2.
         if i in blocks_to_take:
             outs.append(t[:, 1:].permute(0, 2, 1).reshape(B, C, h0, w0).contiguous())
     return outs
+
+
+# ------------------------------------------------------------------------------------------ stage 2
+def _mlp3(sd, p, x, last=None):
+    x = F.relu(F.linear(x, sd[p + "0.weight"], sd[p + "0.bias"]))
+    x = F.relu(F.linear(x, sd[p + "2.weight"], sd[p + "2.bias"]))
+    x = F.linear(x, sd[p + "4.weight"], sd[p + "4.bias"])
+    return last(x) if last else x
+
+
+def affine_regressor(sd, x, prefix="affine_regressor."):
+    p = prefix
+    x = F.relu(F.group_norm(F.conv2d(x, sd[p + "features.0.weight"], sd[p + "features.0.bias"]), 32,
+                            sd[p + "features.1.weight"], sd[p + "features.1.bias"]))
+    x = F.relu(F.group_norm(F.conv2d(x, sd[p + "features.3.weight"], None, stride=2, padding=1), 32,
+                            sd[p + "features.4.weight"], sd[p + "features.4.bias"]))
+    x = x.flatten(1)
+    x = F.leaky_relu(F.linear(x, sd[p + "fc1.weight"], sd[p + "fc1.bias"]), 0.1)
+    x = F.leaky_relu(F.linear(x, sd[p + "fc2.weight"], sd[p + "fc2.bias"]), 0.1)
+    t = _mlp3(sd, p + "translation_predictor.", x)
+    s = _mlp3(sd, p + "scale_predictor.", x)
+    ip = F.normalize(_mlp3(sd, p + "inplane_predictor.", x, torch.tanh), dim=1)
+    return t, s.squeeze(1), ip
+
+
+# ------------------------------------------------------------------------------------------ stage 3
+def _bn(sd, p, x):
+    return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, 0.0, 1e-5)
+
+
+def _rcu(sd, p, x):
+    h = _bn(sd, p + "bn1.", F.conv2d(F.relu(x), sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1))
+    h = _bn(sd, p + "bn2.", F.conv2d(F.relu(h), sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1))
+    return h + x
+
+
+def _fusion(sd, p, size, x0, x1=None):
+    out = x0 if x1 is None else x0 + _rcu(sd, p + "resConfUnit1.", x1)
+    out = _rcu(sd, p + "resConfUnit2.", out)
+    out = F.interpolate(out, size=size, mode="bilinear", align_corners=True)
+    return F.conv2d(out, sd[p + "out_conv.weight"], sd[p + "out_conv.bias"])
+
+
+def dpt_head(sd, feats, prefix="offset_regressor.dpt_head."):
+    p = prefix
+    x = [F.conv2d(f, sd[f"{p}projects.{i}.weight"], sd[f"{p}projects.{i}.bias"]) for i, f in enumerate(feats)]
+    l1 = F.conv_transpose2d(x[0], sd[p + "resize_layers.0.weight"], sd[p + "resize_layers.0.bias"], stride=4)
+    l2 = F.conv_transpose2d(x[1], sd[p + "resize_layers.1.weight"], sd[p + "resize_layers.1.bias"], stride=2)
+    l3 = x[2]
+    l4 = F.conv2d(x[3], sd[p + "resize_layers.3.weight"], sd[p + "resize_layers.3.bias"], stride=2, padding=1)
+    rn = [F.conv2d(l, sd[f"{p}scratch.layer{i + 1}_rn.weight"], None, padding=1) for i, l in enumerate((l1, l2, l3, l4))]
+    p4 = _fusion(sd, p + "scratch.refinenet4.", rn[2].shape[2:], rn[3])
+    p3 = _fusion(sd, p + "scratch.refinenet3.", rn[1].shape[2:], p4, rn[2])
+    p2 = _fusion(sd, p + "scratch.refinenet2.", rn[0].shape[2:], p3, rn[1])
+    return [p4, p3, p2]
+
+
+def _pixel_grid(B, H, W):
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    return torch.stack([xs, ys], dim=0).float()[None].repeat(B, 1, 1, 1)
+
+
+def _sample(feat, coords_xy):
+    """bilinear_sample (corr_lookup.py:29-65): pixel coords (..., 2) -> grid_sample(align_corners=True, zeros)."""
+    H, W = feat.shape[-2:]
+    gx = coords_xy[..., 0] * 2.0 / max(W - 1, 1) - 1.0
+    gy = coords_xy[..., 1] * 2.0 / max(H - 1, 1) - 1.0
+    return F.grid_sample(feat, torch.stack([gx, gy], dim=-1), "bilinear", "zeros", True)
+
+
+def corr_lookup(f1, f2, flow, levels, r):
+    """CorrelationPyramid + CorrLookup: (B,C,H,W) x2, flow (B,2,H,W) -> (B, levels*(2r+1)^2, H, W)."""
+    B, C, H, W = f1.shape
+    corr = (f1.reshape(B, C, -1).permute(0, 2, 1) @ f2.reshape(B, C, -1)).reshape(B * H * W, 1, H, W)
+    corr = corr / torch.sqrt(torch.tensor(C).float())
+    pyr = [corr]
+    for _ in range(levels - 1):
+        pyr.append(F.avg_pool2d(pyr[-1], 2, 2))
+    grid = (_pixel_grid(B, H, W) + flow).permute(0, 2, 3, 1).reshape(B * H * W, 1, 1, 2)
+    d = torch.linspace(-r, r, 2 * r + 1)
+    delta = torch.stack(torch.meshgrid(d, d, indexing="ij"), dim=-1).reshape(1, 2 * r + 1, 2 * r + 1, 2)
+    out = []
+    for i, c in enumerate(pyr):
+        out.append(_sample(c, grid / 2 ** i + delta).reshape(B, H, W, -1))
+    return torch.cat(out, dim=-1).permute(0, 3, 1, 2).contiguous()
+
+
+def _cm(sd, p, x, pad):
+    return F.relu(F.conv2d(x, sd[p + "conv.weight"], sd[p + "conv.bias"], padding=pad))
+
+
+def flow_decoder(sd, feat_render_list, feat_real_list, init_flow, init_cert, num_levels=3, radius=4,
+                 prefix="offset_regressor.flow_decoder."):
+    r = int(radius / 2)
+    flow, cert = init_flow, init_cert
+    flows, certs = [], []
+    for l in range(num_levels):
+        p = f"{prefix}proj.{l}."
+        proj = lambda t: _bn(sd, p + "1.", F.conv2d(t, sd[p + "0.weight"], sd[p + "0.bias"]))  # noqa: E731
+        fr, fq = proj(feat_render_list[l]), proj(feat_real_list[l])
+        B, _, H, W = fr.shape
+        corr = corr_lookup(fr, fq, flow, l + 1, r)
+        e = f"{prefix}encoder.{l}."
+        cf = _cm(sd, e + "corr_net.1.", _cm(sd, e + "corr_net.0.", corr, 0), 1)
+        ff = _cm(sd, e + "flow_net.1.", _cm(sd, e + "flow_net.0.", flow, 3), 1)
+        motion = torch.cat([_cm(sd, e + "out_net.0.", torch.cat([cf, ff], dim=1), 1), flow], dim=1)
+        warped = _sample(fq, (_pixel_grid(B, H, W) + flow).permute(0, 2, 3, 1))
+        x = torch.cat([fr, warped, motion], dim=1)
+        fp, mp = f"{prefix}flow_pred.{l}.", f"{prefix}mask_pred.{l}."
+        h = _cm(sd, fp + "layers.1.", _cm(sd, fp + "layers.0.", x, 1), 1)
+        flow = flow + F.conv2d(h, sd[fp + "predict_layer.weight"], sd[fp + "predict_layer.bias"], padding=1)
+        h = _cm(sd, mp + "layers.1.", _cm(sd, mp + "layers.0.", x, 1), 1)
+        cert = cert + F.conv2d(h, sd[mp + "predict_layer.weight"], sd[mp + "predict_layer.bias"])
+        flows.append(flow)
+        certs.append(cert)
+        if l != num_levels - 1:
+            flow = 2 * F.interpolate(flow, scale_factor=(2, 2), mode="bilinear", align_corners=True)
+            cert = F.interpolate(cert, scale_factor=(2, 2), mode="bilinear", align_corners=True)
+    return flows, certs

@@ -1,0 +1,204 @@
+"""Stage 3: OffsetRegressor = DPTHead + FlowDecoder on the HIP engine (NHWC inside).
+
+Mirrors model/stage3/offset_regressor.py:9-19, dpt.py:171-272 (FeatureFusionBlock :98-156,
+ResidualConvUnit :40-95), flow_decoder.py:9-94, raft_decoder.py:14-53,56-161,251-289 and
+utils/corr_lookup.py:69-134.  Eval BatchNorms are folded into their convolutions; the correlation
+pyramid is never materialised (ops.corr_lookup); channel concatenations are written in place into
+one (B,H,W,640) buffer by the producing kernels."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .common import Holder, Packed, bn_p, conv_p, convT_p, fold_bn, seq
+
+
+# ------------------------------------------------------------------------------------------ DPT head
+def _rcu(c):
+    m = Holder()
+    m.conv1, m.conv2 = conv_p(c, c, 3), conv_p(c, c, 3)
+    m.bn1, m.bn2 = bn_p(c), bn_p(c)
+    return m
+
+
+def _fusion(c):
+    m = Holder()
+    m.out_conv = conv_p(c, c, 1)
+    m.resConfUnit1, m.resConfUnit2 = _rcu(c), _rcu(c)
+    return m
+
+
+class DPTHead(Packed):
+    def __init__(self, nclass, in_channels, features=256, use_bn=False, out_channels=(256, 512, 1024, 1024),
+                 use_clstoken=False):
+        super().__init__()
+        oc = list(out_channels)
+        self.projects = nn.ModuleList([conv_p(in_channels, c, 1) for c in oc])
+        self.resize_layers = seq((0, convT_p(oc[0], oc[0], 4)), (1, convT_p(oc[1], oc[1], 2)), (3, conv_p(oc[3], oc[3], 3)))
+        s = Holder()
+        for i in range(4):
+            setattr(s, f"layer{i + 1}_rn", conv_p(oc[i], features, 3, bias=False))
+        for i in range(4):
+            setattr(s, f"refinenet{i + 1}", _fusion(features))
+        s.output_conv1 = conv_p(features, features // 2, 3)        # dead weights of the checkpoint (dpt.py:241-249)
+        s.output_conv2 = seq((0, conv_p(features // 2, 32, 3)), (2, conv_p(32, 1, 1)))
+        self.scratch = s
+
+    def _pack(self):
+        pk = {}
+        for i, p in enumerate(self.projects):
+            pk[f"proj{i}"] = ops.pack_conv_weight(p.weight.float())
+        r = self.resize_layers
+        pk["up0"], pk["up0_b"] = ops.pack_convT_weight(getattr(r, "0").weight.float(), getattr(r, "0").bias.float())
+        pk["up1"], pk["up1_b"] = ops.pack_convT_weight(getattr(r, "1").weight.float(), getattr(r, "1").bias.float())
+        pk["down3"] = ops.pack_conv_weight(getattr(r, "3").weight.float())
+        for i in range(4):
+            pk[f"rn{i + 1}"] = ops.pack_conv_weight(getattr(self.scratch, f"layer{i + 1}_rn").weight.float())
+        for i in (2, 3, 4):
+            f = getattr(self.scratch, f"refinenet{i}")
+            pk[f"f{i}_out"] = ops.pack_conv_weight(f.out_conv.weight.float())
+            for j in (1, 2):
+                u = getattr(f, f"resConfUnit{j}")
+                for c in (1, 2):
+                    w, b = fold_bn(getattr(u, f"conv{c}").weight.float(), getattr(u, f"conv{c}").bias.float(),
+                                   getattr(u, f"bn{c}"))
+                    pk[f"f{i}_u{j}_c{c}"], pk[f"f{i}_u{j}_b{c}"] = ops.pack_conv_weight(w), b.contiguous()
+        return pk
+
+    def _rcu(self, pk, key, x, extra=None):
+        """ResidualConvUnit (dpt.py:72-95): bn2(conv2(relu(bn1(conv1(relu(x)))))) + x (+ extra)."""
+        h = ops.conv2d(x, pk[key + "_c1"], pk[key + "_b1"], 3, pad=1, relu_in=True)
+        return ops.conv2d(h, pk[key + "_c2"], pk[key + "_b2"], 3, pad=1, relu_in=True, residual=x, residual2=extra)
+
+    def _fuse(self, pk, i, size, x0, x1=None):
+        """FeatureFusionBlock (dpt.py:129-156)."""
+        out = x0 if x1 is None else self._rcu(pk, f"f{i}_u1", x1, extra=x0)
+        out = self._rcu(pk, f"f{i}_u2", out)
+        out = ops.resize_bilinear(out, size[0], size[1])
+        return ops.conv2d(out, pk[f"f{i}_out"], getattr(self.scratch, f"refinenet{i}").out_conv.bias, 1)
+
+    def forward_nhwc(self, feats):
+        """feats: 4 NHWC maps (B,16,16,C) (may be views with a free batch stride) -> [path_4, path_3, path_2] NHWC."""
+        pk, r = self.packed(), self.resize_layers
+        x = [ops.conv2d(f, pk[f"proj{i}"], self.projects[i].bias, 1) for i, f in enumerate(feats)]
+        l1 = ops.conv_transpose2d(x[0], pk["up0"], pk["up0_b"], 4)
+        l2 = ops.conv_transpose2d(x[1], pk["up1"], pk["up1_b"], 2)
+        l3 = x[2]
+        l4 = ops.conv2d(x[3], pk["down3"], getattr(r, "3").bias, 3, stride=2, pad=1)
+        rn = [ops.conv2d(l, pk[f"rn{i + 1}"], None, 3, pad=1) for i, l in enumerate((l1, l2, l3, l4))]
+        p4 = self._fuse(pk, 4, rn[2].shape[1:3], rn[3])
+        p3 = self._fuse(pk, 3, rn[1].shape[1:3], p4, rn[2])
+        p2 = self._fuse(pk, 2, rn[0].shape[1:3], p3, rn[1])
+        return [p4, p3, p2]
+
+    def forward(self, out_features):
+        """Drop-in for dpt.py:252-272: 4 x (B,C,16,16) -> [(B,256,16,16), (B,256,32,32), (B,256,64,64)]."""
+        with torch.no_grad():
+            return [ops.to_nchw(p) for p in self.forward_nhwc([ops.to_nhwc(f) for f in out_features])]
+
+
+# ------------------------------------------------------------------------------------------ flow decoder
+def _cm(cin, cout, k):
+    m = Holder()  # mmcv ConvModule(norm_cfg=None): `.conv` (bias) + ReLU
+    m.conv = conv_p(cin, cout, k)
+    return m
+
+
+def _motion_encoder(levels, radius):
+    m = Holder()
+    m.corr_net = seq((0, _cm(levels * (2 * radius + 1) ** 2, 256, 1)), (1, _cm(256, 192, 3)))
+    m.flow_net = seq((0, _cm(2, 128, 7)), (1, _cm(128, 64, 3)))
+    m.out_net = seq((0, _cm(256, 126, 3)))
+    return m
+
+
+def _xhead(cin, kind):
+    m = Holder()
+    m.layers = seq((0, _cm(cin, 512, 3)), (1, _cm(512, 256, 3)))
+    m.predict_layer = conv_p(256, 2, 3) if kind == "flow" else conv_p(256, 1, 1)
+    return m
+
+
+class FlowDecoder(Packed):
+    def __init__(self, num_levels, radius):
+        super().__init__()
+        self.num_levels, self.radius = num_levels, radius
+        self.r = int(radius / 2)  # flow_decoder.py:24
+        self.proj = nn.ModuleList([seq((0, conv_p(256, 256, 1)), (1, bn_p(256))) for _ in range(num_levels)])
+        self.encoder = nn.ModuleList([_motion_encoder(l + 1, self.r) for l in range(num_levels)])
+        self.flow_pred = nn.ModuleList([_xhead(640, "flow") for _ in range(num_levels)])
+        self.mask_pred = nn.ModuleList([_xhead(640, "mask") for _ in range(num_levels)])
+
+    def _pack(self):
+        pk = {}
+        for l in range(self.num_levels):
+            w, b = fold_bn(getattr(self.proj[l], "0").weight.float(), getattr(self.proj[l], "0").bias.float(),
+                           getattr(self.proj[l], "1"))
+            pk[f"proj{l}"], pk[f"proj{l}_b"] = ops.pack_conv_weight(w), b.contiguous()
+            e = self.encoder[l]
+            for name, net in (("corr", e.corr_net), ("flow", e.flow_net), ("out", e.out_net)):
+                for idx, sub in net.named_children():
+                    pk[f"e{l}_{name}{idx}"] = ops.pack_conv_weight(sub.conv.weight.float())
+            for name, head in (("fp", self.flow_pred[l]), ("mp", self.mask_pred[l])):
+                for idx, sub in head.layers.named_children():
+                    pk[f"{name}{l}_{idx}"] = ops.pack_conv_weight(sub.conv.weight.float())
+                pk[f"{name}{l}_p"] = ops.pack_conv_weight(head.predict_layer.weight.float())
+        return pk
+
+    def forward_nhwc(self, feat_render_list, feat_real_list, flow, cert):
+        """NHWC everywhere: lists of (B,H,W,256); flow (B,16,16,2), cert (B,16,16,1) -> lists of per-level flow/cert."""
+        pk = self.packed()
+        flows, certs = [], []
+        for l in range(self.num_levels):
+            fr_in, fq_in = feat_render_list[l], feat_real_list[l]
+            B, H, W, _ = fr_in.shape
+            X = torch.empty(B, H, W, 640, dtype=torch.float32, device=fr_in.device)  # [render | warped real | motion]
+            fq = ops.conv2d(fq_in, pk[f"proj{l}"], pk[f"proj{l}_b"], 1)
+            e = self.encoder[l]
+            fr = ops.conv2d(fr_in, pk[f"proj{l}"], pk[f"proj{l}_b"], 1)   # contiguous copy for the lookup
+            corr = ops.corr_lookup(fr, fq, flow, l + 1, self.r)
+            cf = torch.empty(B, H, W, 256, dtype=torch.float32, device=fr_in.device)  # [corr feat 192 | flow feat 64]
+            c1 = ops.conv2d(corr, pk[f"e{l}_corr0"], getattr(e.corr_net, "0").conv.bias, 1, act="relu")
+            ops.conv2d(c1, pk[f"e{l}_corr1"], getattr(e.corr_net, "1").conv.bias, 3, pad=1, act="relu", out=cf[..., 0:192])
+            f1 = ops.conv2d(flow, pk[f"e{l}_flow0"], getattr(e.flow_net, "0").conv.bias, 7, pad=3, act="relu")
+            ops.conv2d(f1, pk[f"e{l}_flow1"], getattr(e.flow_net, "1").conv.bias, 3, pad=1, act="relu", out=cf[..., 192:256])
+            ops.conv2d(cf, pk[f"e{l}_out0"], getattr(e.out_net, "0").conv.bias, 3, pad=1, act="relu", out=X[..., 512:638])
+            X[..., 0:256] = fr
+            X[..., 638:640] = flow                                  # cat([out, flow]) (raft_decoder.py:161)
+            ops.warp(fq, flow, out=X[..., 256:512])                 # feature_sample (flow_decoder.py:49-56)
+            fp, mp = self.flow_pred[l], self.mask_pred[l]
+            h = ops.conv2d(X, pk[f"fp{l}_0"], getattr(fp.layers, "0").conv.bias, 3, pad=1, act="relu")
+            h = ops.conv2d(h, pk[f"fp{l}_1"], getattr(fp.layers, "1").conv.bias, 3, pad=1, act="relu")
+            flow = ops.conv2d(h, pk[f"fp{l}_p"], fp.predict_layer.bias, 3, pad=1, residual=flow)      # flow + delta
+            h = ops.conv2d(X, pk[f"mp{l}_0"], getattr(mp.layers, "0").conv.bias, 3, pad=1, act="relu")
+            h = ops.conv2d(h, pk[f"mp{l}_1"], getattr(mp.layers, "1").conv.bias, 3, pad=1, act="relu")
+            cert = ops.conv2d(h, pk[f"mp{l}_p"], mp.predict_layer.bias, 1, residual=cert)             # certainty + delta
+            flows.append(flow)
+            certs.append(cert)
+            if l != self.num_levels - 1:
+                flow = ops.resize_bilinear(flow, 2 * H, 2 * W, mul=2.0)
+                cert = ops.resize_bilinear(cert, 2 * H, 2 * W)
+        return flows, certs
+
+    def forward(self, feat_render_list, feat_real_list, init_flow, init_certainty, iters=1):
+        """Drop-in for flow_decoder.py:74-94 (NCHW in / out)."""
+        assert iters == 1
+        with torch.no_grad():
+            fl, ce = self.forward_nhwc([ops.to_nhwc(f) for f in feat_render_list], [ops.to_nhwc(f) for f in feat_real_list],
+                                       ops.to_nhwc(init_flow), ops.to_nhwc(init_certainty))
+            return [ops.to_nchw(f) for f in fl], [ops.to_nchw(c) for c in ce]
+
+
+class OffsetRegressor(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dpt_head = DPTHead(cfg.nclass, cfg.in_channels, features=256, use_bn=True,
+                                out_channels=[256, 512, 1024, 1024], use_clstoken=False)  # offset_regressor.py:13
+        self.flow_decoder = FlowDecoder(cfg.num_levels, cfg.radius)
+
+    def forward_nhwc(self, feats_tem, feats_real, init_flow, init_cert):
+        return self.flow_decoder.forward_nhwc(self.dpt_head.forward_nhwc(feats_tem), self.dpt_head.forward_nhwc(feats_real),
+                                              init_flow, init_cert)
+
+    def forward(self, features_tem, features_real, init_flow, init_certainty):
+        """Drop-in for offset_regressor.py:16-19."""
+        return self.flow_decoder(self.dpt_head(features_tem), self.dpt_head(features_real), init_flow, init_certainty)

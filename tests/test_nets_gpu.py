@@ -35,3 +35,74 @@ def test_feature_extractor_matches_oracle():
     assert len(got) == 4 and got[0].shape == (2, 384, 16, 16)
     for r, o in zip(ref, got):
         assert _rel(o, r) <= 2e-4, _rel(o, r)  # fp32 both sides; 12 blocks of reassociation noise
+
+
+def _golden(golden_dir):
+    import numpy as np
+
+    z = np.load(os.path.join(golden_dir, "nets.npz"))
+    return z, {k: torch.from_numpy(z[k]).cuda() for k in z.files if z[k].dtype == np.float32}
+
+
+def _close(a, ref, tol):
+    import numpy as np
+
+    err = float(np.abs(a.cpu().numpy() - ref).max())
+    assert err <= tol * max(1.0, float(np.abs(ref).max())), err
+
+
+@gpu
+def test_feature_extractor_vs_reference_golden(golden_dir):
+    from picopose_amd.model.stage1 import FeatureExtractor
+
+    z, t = _golden(golden_dir)
+    fe = FeatureExtractor(small_cfg().stage1)
+    fe.load_state_dict(seeded_state_dict(fe.state_dict(), int(z["vit/seed"])))
+    feats = fe.cuda().eval()(t["vit/x"])
+    _close(feats[-1], z["vit/feat_last"], 2e-4)
+    _close(torch.stack([f[0, :, 3, 5] for f in feats]), z["vit/feat_probe"], 2e-4)
+
+
+@gpu
+def test_affine_regressor_vs_reference_golden(golden_dir):
+    from picopose_amd.model.stage2 import AffineRegressor
+
+    z, t = _golden(golden_dir)
+    ar = AffineRegressor(small_cfg().stage2)
+    ar.load_state_dict(seeded_state_dict(ar.state_dict(), int(z["aff/seed"])))
+    tr, sc, ip = ar.cuda().eval()(t["aff/sim"])
+    assert tr.shape == (3, 2) and sc.shape == (3,) and ip.shape == (3, 2)
+    _close(tr, z["aff/translation"], 1e-4)
+    _close(sc, z["aff/scale"], 1e-4)
+    _close(ip, z["aff/inplane"], 1e-4)
+
+
+@gpu
+def test_corr_lookup_vs_reference_golden(golden_dir):
+    from picopose_amd import ops
+
+    z, t = _golden(golden_dir)
+    out = ops.corr_lookup(ops.to_nhwc(t["corr/f1"]), ops.to_nhwc(t["corr/f2"]), ops.to_nhwc(t["corr/flow"]), 3, 2)
+    _close(ops.to_nchw(out), z["corr/out"], 2e-5)
+
+
+@gpu
+def test_offset_regressor_vs_reference_golden(golden_dir):
+    from picopose_amd.model.stage3 import OffsetRegressor
+
+    z, t = _golden(golden_dir)
+    orr = OffsetRegressor(small_cfg().stage3)
+    orr.load_state_dict(seeded_state_dict(orr.state_dict(), int(z["s3/seed"])))
+    orr = orr.cuda().eval()
+    ft, fr = [t[f"s3/ft{i}"] for i in range(4)], [t[f"s3/fr{i}"] for i in range(4)]
+    dt = orr.dpt_head(ft)
+    assert [tuple(d.shape) for d in dt] == [(1, 256, 16, 16), (1, 256, 32, 32), (1, 256, 64, 64)]
+    _close(dt[0], z["s3/dpt_t_path4"], 2e-4)
+    _close(dt[1][0, :, ::8, ::8], z["s3/dpt_t_path3_probe"], 2e-4)
+    _close(dt[2][0, :, ::16, ::16], z["s3/dpt_t_path2_probe"], 2e-4)
+    fl, ce = orr(ft, fr, t["s3/init_flow"], t["s3/init_cert"])
+    assert [tuple(f.shape) for f in fl] == [(1, 2, 16, 16), (1, 2, 32, 32), (1, 2, 64, 64)]
+    for i in range(3):
+        # offsets in pixels / certainty logits: stated tolerance 5e-4 relative to the tensor's max (fp32 both sides)
+        _close(fl[i], z[f"s3/flow{i}"], 5e-4)
+        _close(ce[i], z[f"s3/cert{i}"], 5e-4)
