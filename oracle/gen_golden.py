@@ -229,7 +229,41 @@ def gen_nets():
     print("nets fixtures written")
 
 
-GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry, "nets": gen_nets}
+def gen_e2e():
+    """Reference Net.forward (eval) end to end: BASELINE configs[0]-like (1 crop vs 4 templates, hyp 2, ViT-S).
+    Inputs and weights are regenerated from seeds by tests/netcfg.make_end_points / oracle.weights."""
+    _ref()
+    sys.path.insert(0, os.path.join(REF, "model"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import ref_shims
+
+    ref_shims.install()
+    import picopose as ref_picopose
+
+    from oracle.weights import seeded_state_dict
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from netcfg import make_end_points
+
+    cfg = _small_cfg()
+    out = {}
+    with torch.no_grad():
+        net = ref_picopose.Net(cfg).eval()
+        net.load_state_dict(seeded_state_dict(net.state_dict(), 21))
+        for tag, (B, N, hyp, seed) in {"b1n4": (1, 4, 2, 31), "b2n3": (2, 3, 3, 32)}.items():
+            ep = make_end_points(B, N, seed, feature_fn=net.feature_extractor)
+            res = net({k: v.clone() for k, v in ep.items()}, hyp)
+            out[f"{tag}/meta"] = np.array([B, N, hyp, seed, 21], dtype=np.int64)
+            out[f"{tag}/template_feature_probe"] = ep["template_feature"][:, :, ::16, 3, 5].numpy()
+            out[f"{tag}/tem_pose_all"] = ep["tem_pose"].numpy()
+            for k, o in enumerate(res):
+                for key, val in o.items():
+                    out[f"{tag}/h{k}/{key}"] = val.numpy()
+    np.savez_compressed(os.path.join(OUT, "e2e.npz"), **out)
+    print("e2e fixtures written")
+
+
+GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry, "nets": gen_nets, "e2e": gen_e2e}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

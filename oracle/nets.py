@@ -177,3 +177,37 @@ def flow_decoder(sd, feat_render_list, feat_real_list, init_flow, init_cert, num
             flow = 2 * F.interpolate(flow, scale_factor=(2, 2), mode="bilinear", align_corners=True)
             cert = F.interpolate(cert, scale_factor=(2, 2), mode="bilinear", align_corners=True)
     return flows, certs
+
+
+# ------------------------------------------------------------------------------------------ whole path
+def net_forward_test(sd, end_points, hyp, heads, blocks_to_take, num_levels=3, radius=4):
+    """model/picopose.py:97-112 + :72-95 restated on the oracle pieces.  Returns (outputs, aux) where aux
+    keeps the tensors a parity test needs to reason about discontinuous outputs (scores, final flow/logits)."""
+    from . import geometry as og
+    from . import matching as om
+
+    feats_real = vit_features(sd, end_points["real_rgb"], heads, blocks_to_take)
+    bank = end_points["template_feature"]
+    bank = bank / bank.norm(dim=2, keepdim=True).clamp_min(1e-12)           # picopose.py:99
+    sim_avg = om.template_scores(bank, feats_real[-1], end_points["real_mask"])
+    score, ids = torch.topk(sim_avg, hyp, dim=1)
+    B = ids.shape[0]
+    rows = torch.arange(B)
+    outputs, aux = [], {"sim_avg": sim_avg, "ids": ids, "flow": [], "cert": []}
+    for k in range(hyp):
+        sel = {key: end_points[key][rows, ids[:, k]] for key in ("tem_pose", "tem_K", "tem_M", "tem_mask", "tem_rgb", "tem_pts3d")}
+        out = {"tem_pose": sel["tem_pose"], "tar_pts_2d": end_points["real_pts2d"].permute(0, 3, 2, 1),
+               "src_pts_3d": sel["tem_pts3d"].permute(0, 3, 1, 2)}
+        feats_tem = vit_features(sd, sel["tem_rgb"], heads, blocks_to_take)
+        sim = om.matching_features_similarity(feats_tem[-1], feats_real[-1], sel["tem_mask"], None)
+        t, s, ip = affine_regressor(sd, sim)
+        Ms = og.calc_pred_Ms(s, ip, t, sel["tem_pose"], sel["tem_K"], sel["tem_M"])
+        out["pred_poses"] = og.pose_recovery_2d_prediction(end_points["real_M"], end_points["real_K"], Ms, sel["tem_K"],
+                                                           sel["tem_M"], sel["tem_pose"])
+        f0, c0 = og.compute_init_correspondences(Ms, sel["tem_mask"])
+        fl, ce = flow_decoder(sd, dpt_head(sd, feats_tem), dpt_head(sd, feats_real), f0, c0, num_levels, radius)
+        out["pred_tar_pts"], out["pred_src_pts"] = og.compute_stage3_correspondences(fl[-1], ce[-1], 0.5)
+        aux["flow"].append(fl[-1])
+        aux["cert"].append(ce[-1])
+        outputs.append(out)
+    return outputs, aux

@@ -1,0 +1,87 @@
+"""Top-level model — drop-in for the reference's model/picopose.py (`Net`).
+
+Same constructor (`Net(cfg)` with cfg.stage1/2/3), same sub-module names (identical state_dict, so
+`Lite.load_from_checkpoint(..., network=model)` loads the authors' checkpoint), same eval call
+`model(end_points, hyp)` -> list of `hyp` dicts (model/picopose.py:97-112, 72-95), and
+`model.feature_extractor(x)` usable on its own (run_test.py:130).  All arithmetic runs in
+libpicopose_hip.so; the training branch is not part of this path."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .model.stage1 import FeatureExtractor
+from .model.stage2 import AffineRegressor
+from .model.stage3 import OffsetRegressor
+from .utils.correspondence import compute_init_correspondences, compute_stage3_correspondences
+from .utils.matching import matching_features_similarity, matching_templates
+from .utils.pose_recovery import pose_recovery_2d_prediction
+from .utils.torch_utils import calc_pred_Ms
+
+
+class Net(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.feature_extractor = FeatureExtractor(cfg.stage1)
+        self.affine_regressor = AffineRegressor(cfg.stage2)
+        self.offset_regressor = OffsetRegressor(cfg.stage3)
+        self.match_mode = None  # None -> picopose_amd.utils.matching.DEFAULT_MODE ("fast")
+
+    # model/picopose.py:52-70 — pick hypothesis k's template for every crop (pure indexing)
+    def select_template_data(self, end_points, pred_id_src, k):
+        idx = pred_id_src[:, k]
+        rows = torch.arange(idx.shape[0], device=idx.device)
+        sel = {key: end_points[key][rows, idx] for key in ("tem_pose", "tem_K", "tem_M", "tem_mask", "tem_rgb", "tem_pts3d")}
+        for key in ("real_pts2d", "real_K", "real_M", "real_mask", "real_pose"):
+            sel[key] = end_points[key]
+        return sel
+
+    # model/picopose.py:72-95
+    def forward_test_hyp(self, end_points, real):
+        """`real` = (token maps of the query at the 4 taken blocks, (h0, w0)) from forward_tokens."""
+        fe = self.feature_extractor
+        real_tok, (h0, w0) = real
+        output = {"tem_pose": end_points["tem_pose"]}
+        output["tar_pts_2d"] = end_points["real_pts2d"].permute(0, 3, 2, 1)
+        output["src_pts_3d"] = end_points["tem_pts3d"].permute(0, 3, 1, 2)
+        # stage 1: template features
+        tem_tok, _ = fe.forward_tokens(end_points["tem_rgb"])
+        # stage 2
+        sim = matching_features_similarity(ops.tokens_to_nchw(tem_tok[-1], 1, h0, w0),
+                                           ops.tokens_to_nchw(real_tok[-1], 1, h0, w0),
+                                           end_points["tem_mask"], end_points["real_mask"])
+        pred_translation, pred_scale, pred_inplane = self.affine_regressor(sim)
+        pred_Ms = calc_pred_Ms(pred_scale, pred_inplane, pred_translation, end_points["tem_pose"], end_points["tem_K"],
+                               end_points["tem_M"])
+        output["pred_poses"] = pose_recovery_2d_prediction(end_points["real_M"], end_points["real_K"], pred_Ms,
+                                                           end_points["tem_K"], end_points["tem_M"], end_points["tem_pose"])
+        # stage 3 (NHWC inside; the token maps are read in place, cls row skipped)
+        init_flow, init_certainty = compute_init_correspondences(pred_Ms, end_points["tem_mask"])
+        B, C = tem_tok[0].shape[0], tem_tok[0].shape[2]
+        as_img = lambda t: t[:, 1:].unflatten(1, (h0, w0))  # noqa: E731  (B,h0,w0,C) view, batch stride (1+h0*w0)*C
+        flows, certs = self.offset_regressor.forward_nhwc([as_img(t) for t in tem_tok], [as_img(t) for t in real_tok],
+                                                          ops.to_nhwc(init_flow), ops.to_nhwc(init_certainty))
+        output["pred_tar_pts"], output["pred_src_pts"] = compute_stage3_correspondences(
+            ops.to_nchw(flows[-1]), ops.to_nchw(certs[-1]), threshold=0.5)
+        return output
+
+    # model/picopose.py:97-112
+    def forward_test(self, end_points, hyp=5):
+        with torch.no_grad():
+            real = self.feature_extractor.forward_tokens(end_points["real_rgb"])
+            real_tok, (h0, w0) = real
+            # matching.py normalises the bank itself; the reference's extra F.normalize of the whole bank
+            # (picopose.py:99) is idempotent up to rounding and is not materialised here
+            pred_score_src, pred_id_src = matching_templates(
+                end_points["template_feature"], ops.tokens_to_nchw(real_tok[-1], 1, h0, w0), end_points["tem_mask"],
+                end_points["real_mask"], topk=hyp, mode=self.match_mode)
+            outputs = []
+            for k in range(hyp):
+                outputs.append(self.forward_test_hyp(self.select_template_data(end_points, pred_id_src, k), real))
+            return outputs
+
+    def forward(self, end_points, hyp=5):
+        if self.training:
+            raise NotImplementedError("picopose_amd implements the inference path (model/picopose.py:97-112); "
+                                      "forward_train (:114-137) is out of scope (SURVEY.md §8f)")
+        return self.forward_test(end_points, hyp)

@@ -1,0 +1,94 @@
+"""End to end: Net.forward (eval) — oracle (CPU) and HIP model (GPU) against the REFERENCE Net's outputs
+(tests/golden/e2e.npz).  Inputs/weights are regenerated from the stored seeds."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from netcfg import HEADS, TAKE, make_end_points, small_cfg  # noqa: E402
+
+from oracle import nets as on  # noqa: E402
+from oracle.weights import seeded_state_dict  # noqa: E402
+
+gpu = pytest.mark.gpu
+CASES = ["b1n4", "b2n3"]
+
+
+def _load(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, "e2e.npz"))
+    B, N, hyp, seed, wseed = (int(v) for v in z[f"{tag}/meta"])
+    ref = [{k.split("/", 2)[2]: z[k] for k in z.files if k.startswith(f"{tag}/h{h}/")} for h in range(hyp)]
+    return z, B, N, hyp, seed, wseed, ref
+
+
+def _keypoint_mismatch_is_explained(got_tar, got_src, ref_tar, ref_src, flow, cert, rel=5e-4):
+    """Keypoint lists are discontinuous in (flow, logit): entries may differ only where the oracle's logit is
+    within the float tolerance of 0 or a target coordinate is within it of an integer / of the bounds.  The
+    tolerance is the one stated for the offset tensors: rel * max|tensor| (tests/test_nets_gpu.py)."""
+    bad = (got_tar != ref_tar).any(-1) | (got_src != ref_src).any(-1)       # (B, H*W), k = w*H + h
+    if not bad.any():
+        return 0
+    B, _, H, W = flow.shape
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    tx, ty = flow[:, 0] + xs, flow[:, 1] + ys
+    frac = np.minimum(np.abs(tx - np.round(tx)), np.abs(ty - np.round(ty)))
+    tol_f, tol_c = rel * max(1.0, float(np.abs(flow).max())), rel * max(1.0, float(np.abs(cert).max()))
+    fragile = (np.abs(cert[:, 0]) < tol_c) | (frac < tol_f)                 # (B,H,W)
+    fragile_k = fragile.transpose(0, 2, 1).reshape(B, H * W)
+    assert not (bad & ~fragile_k).any(), int((bad & ~fragile_k).sum())
+    return int(bad.sum())
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_oracle_forward_vs_reference(golden_dir, tag):
+    from picopose_amd.picopose import Net
+
+    torch.set_num_threads(8)
+    z, B, N, hyp, seed, wseed, ref = _load(golden_dir, tag)
+    sd = seeded_state_dict(Net(small_cfg()).state_dict(), wseed)
+    fe = lambda x: on.vit_features(sd, x, HEADS, TAKE)  # noqa: E731
+    ep = make_end_points(B, N, seed, feature_fn=fe, tem_pose=torch.from_numpy(z[f"{tag}/tem_pose_all"]))
+    assert np.abs(ep["template_feature"][:, :, ::16, 3, 5].numpy() - z[f"{tag}/template_feature_probe"]).max() < 1e-4
+    outs, aux = on.net_forward_test(sd, ep, hyp, HEADS, TAKE)
+    for h in range(hyp):
+        assert np.array_equal(outs[h]["tem_pose"].numpy(), ref[h]["tem_pose"])        # same templates picked
+        assert np.abs(outs[h]["pred_poses"].numpy() - ref[h]["pred_poses"]).max() <= 1e-4
+        _keypoint_mismatch_is_explained(outs[h]["pred_tar_pts"].numpy(), outs[h]["pred_src_pts"].numpy(),
+                                        ref[h]["pred_tar_pts"], ref[h]["pred_src_pts"], aux["flow"][h].numpy(),
+                                        aux["cert"][h].numpy(), rel=2e-5)
+
+
+@gpu
+@pytest.mark.parametrize("tag", CASES)
+def test_hip_forward_vs_reference(golden_dir, tag):
+    from picopose_amd.picopose import Net
+
+    torch.set_num_threads(8)
+    z, B, N, hyp, seed, wseed, ref = _load(golden_dir, tag)
+    net = Net(small_cfg())
+    sd = seeded_state_dict(net.state_dict(), wseed)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    ep = make_end_points(B, N, seed, tem_pose=torch.from_numpy(z[f"{tag}/tem_pose_all"]))
+    dev = {k: v.cuda() for k, v in ep.items()}
+    # the bank is precomputed with the model's own feature extractor, exactly as run_test.py:120-134 does
+    dev["template_feature"] = torch.stack([net.feature_extractor(dev["tem_rgb"][b])[-1] for b in range(B)])
+    assert np.abs(dev["template_feature"][:, :, ::16, 3, 5].cpu().numpy() - z[f"{tag}/template_feature_probe"]).max() < 2e-3
+    outs = net(dev, hyp)
+    assert isinstance(outs, list) and len(outs) == hyp
+    # oracle run for the margins of the discontinuous outputs
+    ep["template_feature"] = dev["template_feature"].cpu()
+    _, aux = on.net_forward_test(sd, ep, hyp, HEADS, TAKE)
+    total_bad = 0
+    for h in range(hyp):
+        o = {k: v.cpu().numpy() for k, v in outs[h].items()}
+        assert set(o) == set(ref[h]) and all(o[k].shape == ref[h][k].shape and o[k].dtype == ref[h][k].dtype for k in o)
+        assert np.array_equal(o["tem_pose"], ref[h]["tem_pose"])                        # template ids: exact
+        assert np.array_equal(o["tar_pts_2d"], ref[h]["tar_pts_2d"]) and np.array_equal(o["src_pts_3d"], ref[h]["src_pts_3d"])
+        assert np.abs(o["pred_poses"] - ref[h]["pred_poses"]).max() <= 1e-4             # north_star tolerance
+        total_bad += _keypoint_mismatch_is_explained(o["pred_tar_pts"], o["pred_src_pts"], ref[h]["pred_tar_pts"],
+                                                     ref[h]["pred_src_pts"], aux["flow"][h].numpy(), aux["cert"][h].numpy())
+    assert total_bad <= 0.002 * hyp * B * 4096
