@@ -205,6 +205,21 @@ int pp_corr_lookup_nhwc(const float* f1, const float* f2_l0, const float* f2_l1,
                         const float* flow, int B, int H, int W, int C, int levels, int radius,
                         int ld_flow, float* out, int ld_out, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * utils/pose_recovery.py:68-105 pose_recovery_ransac_pnp, batched over P = instances x hypotheses
+ * (run_test.py:168-184 calls it once per pair): gather of the valid 2D/3D correspondences, object-frame
+ * transform, RANSAC (5-point samples, `iterations`, squared reprojection error <= threshold^2) with EPnP
+ * as the model solver and an EPnP refit on the inliers (picopose_amd/csrc/pp_pnp.hip).
+ *   tar_pts_2d (P,2,H,W), src_pts_3d (P,3,H,W), K (P,3,3), tem_pose (P,4,4) fp32;
+ *   tar_pts, src_pts (P,N,2) int64 (x,y) with -1 padding, N <= 4096;
+ *   out: rot (P,3,3) f64, tvec (P,3) f64, inlier_ratio (P) f64, success (P) int32 (0: the reference's
+ *   failure outputs I, [0,0,1], 0.0), num_points (P) int32.
+ * ------------------------------------------------------------------------- */
+int pp_pnp_ransac(const float* tar_pts_2d, const float* src_pts_3d, const float* K, const float* tem_pose,
+                  const int64_t* tar_pts, const int64_t* src_pts, int P, int H, int W, int N, int iterations,
+                  float reproj_threshold, double* rot, double* tvec, double* inlier_ratio, int32_t* success,
+                  int32_t* num_points, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

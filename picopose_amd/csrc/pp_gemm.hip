@@ -66,7 +66,7 @@ __device__ __forceinline__ f4 load_a(const PpGemmDesc& d, const float* __restric
             if (k < d.K) {
                 const int tap = k / d.conv_cin, ci = k - tap * d.conv_cin;
                 const int ky = tap / d.conv_kw, kx = tap - ky * d.conv_kw;
-                const int iy = oy * d.conv_stride - d.conv_pad + ky, ix = ox * d.conv_stride - d.conv_pad + kx;
+                const int iy = oy + ky, ix = ox + kx;  // (oy, ox): top-left input pixel of the window
                 if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w)
                     v = *(const f4*)(A + (size_t)b_img * d.conv_bstride + ((size_t)iy * d.conv_w + ix) * d.lda + ci);
             }
@@ -77,7 +77,7 @@ __device__ __forceinline__ f4 load_a(const PpGemmDesc& d, const float* __restric
                 if (kk < d.K) {
                     const int tap = kk / d.conv_cin, ci = kk - tap * d.conv_cin;
                     const int ky = tap / d.conv_kw, kx = tap - ky * d.conv_kw;
-                    const int iy = oy * d.conv_stride - d.conv_pad + ky, ix = ox * d.conv_stride - d.conv_pad + kx;
+                    const int iy = oy + ky, ix = ox + kx;
                     if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w)
                         v[i] = A[(size_t)b_img * d.conv_bstride + ((size_t)iy * d.conv_w + ix) * d.lda + ci];
                 }
@@ -107,21 +107,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(const PpGemmDesc d) {
 
     // this thread's 4 (row, k-quad) slots of the A and B tiles: idx = tid + 256 j -> row idx>>3, quad idx&7
     int arow[4], ab[4], aoy[4], aox[4];
+    long long abase[4];  // VEC4 conv: element offset of input pixel (oy*stride - pad, ox*stride - pad) of the row's image
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int idx = tid + 256 * j;
         arow[j] = idx >> 3;
         const int m = m0 + arow[j];
         ab[j] = aoy[j] = aox[j] = 0;
+        abase[j] = 0;
         if (d.conv_kh != 0 && m < d.M) {
             const int per = d.conv_ho * d.conv_wo;
             ab[j] = m / per;
             const int r = m - ab[j] * per;
             aoy[j] = r / d.conv_wo;
             aox[j] = r - aoy[j] * d.conv_wo;
+            aoy[j] = aoy[j] * d.conv_stride - d.conv_pad;  // top-left input pixel of the window
+            aox[j] = aox[j] * d.conv_stride - d.conv_pad;
+            abase[j] = (long long)ab[j] * d.conv_bstride + ((long long)aoy[j] * d.conv_w + aox[j]) * d.lda;
         }
     }
     const int kq = (tid & 7) * 4;
+    // VEC4 conv: the tap (ky, kx) and channel ci of this thread's k = k0 + kq, advanced by BK per K step
+    // without divisions (all four rows of the thread share k)
+    int tky = 0, tkx = 0, tci = 0;
+    if (VEC4 && d.conv_kh != 0) {
+        const int tap = kq / d.conv_cin;
+        tci = kq - tap * d.conv_cin;
+        tky = tap / d.conv_kw;
+        tkx = tap - tky * d.conv_kw;
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -133,11 +147,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const PpGemmDesc d) {
 
     f4 ra[4], rb[4];
     auto fetch = [&](int k0) __attribute__((always_inline)) {
+        const int k = k0 + kq;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            ra[j] = load_a<VEC4>(d, A, m0 + arow[j], k0 + kq, ab[j], aoy[j], aox[j]);
+            if (VEC4 && d.conv_kh != 0) {
+                f4 v = {0.f, 0.f, 0.f, 0.f};
+                const int iy = aoy[j] + tky, ix = aox[j] + tkx;
+                if (m0 + arow[j] < d.M && k < d.K && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w)
+                    v = *(const f4*)(A + abase[j] + ((long long)tky * d.conv_w + tkx) * d.lda + tci);
+                if (d.relu_in) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                }
+                ra[j] = v;
+            } else {
+                ra[j] = load_a<VEC4>(d, A, m0 + arow[j], k, ab[j], aoy[j], aox[j]);
+            }
             f4 v = {0.f, 0.f, 0.f, 0.f};
-            const int n = n0 + arow[j], k = k0 + kq;
+            const int n = n0 + arow[j];
             if (n < d.N) {
                 if (d.b_kn) {  // B stored [K][N]
 #pragma unroll
@@ -154,6 +181,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const PpGemmDesc d) {
                 }
             }
             rb[j] = v;
+        }
+        if (VEC4 && d.conv_kh != 0) {  // advance the tap by BK channels
+            tci += BK;
+            while (tci >= d.conv_cin) {
+                tci -= d.conv_cin;
+                if (++tkx == d.conv_kw) {
+                    tkx = 0;
+                    ++tky;
+                }
+            }
         }
     };
 

@@ -16,3 +16,36 @@ def pose_recovery_2d_prediction(query_M, query_K, pred_Ms, template_K, template_
                                         tp.data_ptr(), B, out.data_ptr(), _lib.stream_ptr())
     _lib.check(rc, "pp_pose_recovery_2d")
     return out
+
+
+def pose_recovery_ransac_pnp_batched(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations=150,
+                                     reproj_error=2.0):
+    """All (instance, hypothesis) problems of a batch in ONE launch and ONE device->host copy
+    (the reference loops over them on the host with a sync each, run_test.py:168-184).
+
+    tar_pts_2d (P,2,H,W), src_pts_3d (P,3,H,W), K (P,3,3), tem_pose (P,4,4), tar_pts/src_pts (P,N,2) int64
+    -> rot (P,3,3) f64, tvec (P,3,1) f64, inliers_ratio (P) f64, success (P) bool   (numpy arrays)."""
+    t2, s3, Kd, pose = _lib.dev_f32(tar_pts_2d, src_pts_3d, K, tem_pose)
+    tp, sp = tar_pts.contiguous().long(), src_pts.contiguous().long()
+    P, _, H, W = t2.shape
+    N = tp.shape[1]
+    dev = t2.device
+    rot = torch.empty(P, 3, 3, dtype=torch.float64, device=dev)
+    tvec = torch.empty(P, 3, dtype=torch.float64, device=dev)
+    ratio = torch.empty(P, dtype=torch.float64, device=dev)
+    ok = torch.empty(P, dtype=torch.int32, device=dev)
+    npts = torch.empty(P, dtype=torch.int32, device=dev)
+    rc = _lib.lib().pp_pnp_ransac(t2.data_ptr(), s3.data_ptr(), Kd.data_ptr(), pose.data_ptr(), tp.data_ptr(), sp.data_ptr(),
+                                  P, H, W, N, int(iterations), float(reproj_error), rot.data_ptr(), tvec.data_ptr(),
+                                  ratio.data_ptr(), ok.data_ptr(), npts.data_ptr(), _lib.stream_ptr())
+    _lib.check(rc, "pp_pnp_ransac")
+    return (rot.cpu().numpy(), tvec.cpu().numpy().reshape(P, 3, 1), ratio.cpu().numpy(), ok.cpu().numpy().astype(bool))
+
+
+def pose_recovery_ransac_pnp(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts):
+    """Drop-in for reference utils/pose_recovery.py:68-105 (one instance/hypothesis):
+    -> (rot ndarray(3,3), tvecs ndarray(3,1), inliers_ratio float, success bool); never raises for bad
+    geometry — failure returns (I, [0,0,1]^T, 0.0, False) like the reference's except branch."""
+    rot, tvec, ratio, ok = pose_recovery_ransac_pnp_batched(tar_pts_2d[None], src_pts_3d[None], K[None], tem_pose[None],
+                                                           tar_pts[None], src_pts[None])
+    return rot[0], tvec[0], float(ratio[0]), bool(ok[0])

@@ -1,0 +1,99 @@
+"""Known-answer tests of the GPU PnP/RANSAC (utils/pose_recovery.py:68-105).  cv2 is not available, so
+parity with OpenCV is unpinned: correctness is defined on synthetic correspondences."""
+import numpy as np
+import pytest
+import torch
+
+gpu = pytest.mark.gpu
+K0 = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1.0]])
+
+
+def _rot(rng):
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    return q * np.sign(np.linalg.det(q))
+
+
+def _problem(rng, n_pts, n_out=0, noise=0.0):
+    """Build the function's inputs for one problem: template-frame 3-D map, original-image 2-D map, index lists."""
+    R_tem, t_tem = _rot(rng), np.array([0.02, -0.01, 0.8])
+    R_gt, t_gt = _rot(rng), np.array([0.05, -0.03, 0.9]) + 0.05 * rng.standard_normal(3)
+    H = W = 64
+    src3d = np.zeros((3, H, W), np.float32)
+    tar2d = np.zeros((2, H, W), np.float32)
+    tar_pts = -np.ones((H * W, 2), np.int64)
+    src_pts = -np.ones((H * W, 2), np.int64)
+    cells = rng.permutation(H * W)[:n_pts]
+    tcells = rng.permutation(H * W)[:n_pts]
+    slots = np.sort(rng.permutation(H * W)[:n_pts])
+    obj = (rng.random((n_pts, 3)) - 0.5) * 0.2
+    cam_tem = obj @ R_tem.T + t_tem
+    cam_gt = obj @ R_gt.T + t_gt
+    uv = (cam_gt / cam_gt[:, 2:]) @ K0.T
+    uv = uv[:, :2] + noise * rng.standard_normal((n_pts, 2))
+    outl = rng.permutation(n_pts)[:n_out]
+    uv[outl] = rng.random((n_out, 2)) * np.array([640, 480])
+    for i in range(n_pts):
+        sy, sx = divmod(int(cells[i]), W)
+        ty, tx = divmod(int(tcells[i]), W)
+        src3d[:, sy, sx] = cam_tem[i]
+        tar2d[:, ty, tx] = uv[i]
+        src_pts[slots[i]] = (sx, sy)
+        tar_pts[slots[i]] = (tx, ty)
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3], pose[:3, 3] = R_tem, t_tem
+    inl = np.ones(n_pts, bool)
+    inl[outl] = False
+    return dict(tar2d=tar2d, src3d=src3d, K=K0.astype(np.float32), pose=pose, tar_pts=tar_pts, src_pts=src_pts,
+                R=R_gt, t=t_gt, n_in=int(inl.sum()))
+
+
+def _run(problems):
+    from picopose_amd.utils.pose_recovery import pose_recovery_ransac_pnp_batched
+
+    st = lambda k, dt=None: torch.from_numpy(np.stack([p[k] for p in problems])).cuda()  # noqa: E731
+    return pose_recovery_ransac_pnp_batched(st("tar2d"), st("src3d"), st("K"), st("pose"), st("tar_pts"), st("src_pts"))
+
+
+@gpu
+def test_noise_free_recovers_ground_truth_pose():
+    rng = np.random.default_rng(0)
+    probs = [_problem(rng, n) for n in (6, 20, 200, 1500, 4096)]
+    rot, tvec, ratio, ok = _run(probs)
+    for i, p in enumerate(probs):
+        assert ok[i] and rot.dtype == np.float64 and tvec.shape[1:] == (3, 1)
+        assert np.abs(rot[i] - p["R"]).max() < 1e-4, (i, np.abs(rot[i] - p["R"]).max())   # float32 inputs
+        assert np.abs(tvec[i, :, 0] - p["t"]).max() < 1e-4
+        assert abs(np.linalg.det(rot[i]) - 1.0) < 1e-9 and np.abs(rot[i] @ rot[i].T - np.eye(3)).max() < 1e-9
+        assert ratio[i] == 1.0
+
+
+@gpu
+def test_planted_outliers_are_rejected():
+    rng = np.random.default_rng(1)
+    probs = [_problem(rng, 400, n_out=120), _problem(rng, 2000, n_out=900), _problem(rng, 60, n_out=20, noise=0.2)]
+    rot, tvec, ratio, ok = _run(probs)
+    for i, p in enumerate(probs):
+        n = 400 if i == 0 else (2000 if i == 1 else 60)
+        assert ok[i]
+        # random outliers land within 2 px of their true projection with probability ~1e-4
+        assert abs(ratio[i] * n - p["n_in"]) <= (1 if i < 2 else 3), (ratio[i] * n, p["n_in"])
+        tol = 1e-4 if i < 2 else 5e-3
+        assert np.abs(rot[i] - p["R"]).max() < tol and np.abs(tvec[i, :, 0] - p["t"]).max() < tol
+
+
+@gpu
+def test_failure_outputs_and_single_problem_api():
+    from picopose_amd.utils.pose_recovery import pose_recovery_ransac_pnp
+
+    rng = np.random.default_rng(2)
+    few = _problem(rng, 3)       # fewer correspondences than a minimal sample -> the reference's except branch
+    none = _problem(rng, 0)
+    rot, tvec, ratio, ok = _run([few, none])
+    for i in range(2):
+        assert not ok[i] and ratio[i] == 0.0
+        assert np.array_equal(rot[i], np.eye(3)) and np.array_equal(tvec[i], np.array([[0.0], [0.0], [1.0]]))
+    p = _problem(rng, 300, n_out=50)
+    t = lambda k: torch.from_numpy(p[k]).cuda()  # noqa: E731
+    r, tv, ra, success = pose_recovery_ransac_pnp(t("tar2d"), t("src3d"), t("K"), t("pose"), t("tar_pts"), t("src_pts"))
+    assert success and isinstance(ra, float) and r.shape == (3, 3) and tv.shape == (3, 1)
+    assert np.abs(r - p["R"]).max() < 1e-4 and abs(ra * 300 - p["n_in"]) <= 1
