@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the PicoPose hot path on MI355X (driver contract: one JSON line).
+"""bench.py — throughput of the PicoPose correspondence hot path on MI355X (driver contract: ONE JSON line).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--mode fast|exact]
 
-A "step" is one pass of stage-1 template matching (reference utils/matching.py:29-69:
-normalise, 256x256xC similarity per template, masked best-match mean, top-k) over one batch of
-synthetic crops with a per-crop fp32 template bank resident in HBM.  Default workload =
-BASELINE.json configs[2]'s stage-1 shape (batch 32, 162 templates, ViT-B width 768: a 4.08 GB
-bank, larger than the 256 MiB Infinity Cache so the HBM roofline is honest).  Stages 2-3 are
-not yet on the HIP path ("scope of this round"), so `config.workload` says stage 1.
+Default workload `full_b32_n162_vitb` = BASELINE.json configs[2] (the configuration the metric is quoted
+on): batch 32 synthetic 224x224 crops, 162 templates per crop, DINOv2 ViT-B/14, hyp 5 — one step is
+`Net.forward` (query ViT, stage-1 template matching over the 4.08 GB per-crop feature bank, 5 x [template
+ViT, stage-2 affine regression, stage-3 DPT + flow decoder, keypoint selection]) followed by the batched
+PnP/RANSAC of all 160 (crop, hypothesis) pairs and the copy of the poses to the host.  All inputs and the
+bank are resident in HBM before the timed region (the bank is precomputed as run_test.py:120-134 does).
+`stage1_*` workloads time reference utils/matching.py:29-69 alone (configs[1] and the stage-1 shape of
+configs[2]).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the template axis is
-sharded over the ranks and the global batch grows with N (32*N crops per step), so per-GPU
-bank bytes are fixed ("weak"); the only exchange is one all-gather of the (B, N/G) scores.
+N > 1 (torch.distributed.run, one rank per GPU, RCCL): weak scaling — every rank owns 32 crops (global
+batch 32*N); the template FEATURE bank is sharded over the ranks along N (each rank scores its slice of all
+crops), exchanged with all-gathers of the query features/masks and of the (B, N/G) score slices; stages 2-3
+and PnP run data-parallel on the rank's own crops.
+
+JSON extras: `roofline` (stage-1 fused similarity kernel vs the HBM roofline, measured live with HIP events
+around exactly that launch inside the timed steps), `mfma` (whole-step FLOP rate vs the fp32 MFMA peak),
+`cpu_baseline` (the CPU oracle — a port of the reference's torch-CPU path — on a bounded sample).
 """
 import argparse
 import ctypes
@@ -20,19 +27,29 @@ import json
 import os
 import sys
 import time
+import types
 
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+ns = types.SimpleNamespace
 
-WORKLOADS = {
-    # name: (crops per GPU-step, templates, channels, BASELINE config it is the stage-1 shape of)
-    "stage1_b32_n162_c768": (32, 162, 768, "configs[2] stage-1 (batch 32, 162 templates, ViT-B/14)"),
-    "stage1_b8_n42_c384": (8, 42, 384, "configs[1] (batch 8, 42 templates, ViT-S/14, stage-1 only)"),
-    "stage1_b32_n162_c1024": (32, 162, 1024, "base.yaml shape (ViT-L/14) stage-1"),
+VIT = {  # name: (channels, heads, interaction_indexes, GFLOP per image)  — SURVEY.md §6.2
+    "dinov2_vits14": (384, 6, [[0, 2], [3, 5], [6, 8], [9, 11]], 12.2),
+    "dinov2_vitb14": (768, 12, [[0, 2], [3, 5], [6, 8], [9, 11]], 46.3),
+    "dinov2_vitl14": (1024, 16, [[0, 5], [6, 11], [12, 17], [18, 23]], 162.0),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured achievable
+WORKLOADS = {
+    # name: (kind, crops per GPU-step, templates, vit, description)
+    "full_b32_n162_vitb": ("full", 32, 162, "dinov2_vitb14", "configs[2]: batch 32, 162 templates, ViT-B/14, stage1+2+3 + PnP/RANSAC, hyp 5"),
+    "full_b8_n42_vits": ("full", 8, 42, "dinov2_vits14", "batch 8, 42 templates, ViT-S/14, stage1+2+3 + PnP/RANSAC, hyp 5"),
+    "stage1_b32_n162_c768": ("stage1", 32, 162, "dinov2_vitb14", "configs[2] stage-1 shape: matching_templates only"),
+    "stage1_b8_n42_c384": ("stage1", 8, 42, "dinov2_vits14", "configs[1]: batch 8, 42 templates, ViT-S/14, stage-1 matching only"),
+    "stage1_b32_n162_c1024": ("stage1", 32, 162, "dinov2_vitl14", "base.yaml shape (ViT-L/14), stage-1 matching only"),
+}
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a read-only probe reaches 6.2-6.4 TB/s
+MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32), the arithmetic of the network engine
 
 
 def disk_mask(B, device):
@@ -41,54 +58,116 @@ def disk_mask(B, device):
     return m[None].repeat(B, 1, 1).to(device)
 
 
-def make_inputs(B, N, C, device, seed):
-    g = torch.Generator(device=device).manual_seed(seed)
-    bank = torch.randn(B, N, C, 16, 16, device=device, generator=g)
-    query = torch.randn(B, C, 16, 16, device=device, generator=g)
-    return bank, query, disk_mask(B, device)
+def cpu_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))  # one GPU's job owns a 16-core share of the host
 
 
-def algorithmic_bytes(B, N, C):
+def stage1_bytes(B, N, C):
     # per crop N*C*256*4 (bank, read once) + C*256*4 (query) + 256*4 (mask) + k*12
     return B * (N * C * 256 * 4 + C * 256 * 4 + 256 * 4 + 5 * 12)
 
 
-def cpu_baseline(N, C, seconds_budget=20.0):
-    """The CPU oracle (a port of the reference's torch-CPU path) on a bounded sample."""
+def full_gflop_per_crop(N, vit, hyp=5):
+    C = VIT[vit][0]
+    dpt = {"dinov2_vits14": 18.5, "dinov2_vitb14": 19.0, "dinov2_vitl14": 19.4}[vit]
+    return (1 + hyp) * VIT[vit][3] + 2 * hyp * dpt + hyp * 108.4 + hyp * 0.14 + N * 2 * 256 * 256 * C / 1e9
+
+
+def make_cfg(vit):
+    C, _, idx, _ = VIT[vit]
+    return ns(hypothesis=5, stage1=ns(vit_type=vit, pretrained=False, interaction_indexes=idx),
+              stage2=ns(in_channel=256, hidden_dim=256),
+              stage3=ns(nclass=1, in_channels=C, use_bn=True, out_channels=[256, 512, 1024, 1024], num_levels=3, radius=4))
+
+
+def seeded_weights(net, seed):
+    """Random-init weights of the architecture (no network for checkpoints): oracle/weights.py recipe."""
+    from oracle.weights import seeded_state_dict
+
+    sd = seeded_state_dict(net.state_dict(), seed)
+    net.load_state_dict(sd)
+    return sd
+
+
+def make_end_points(B, N, device, seed):
+    """Synthetic eval inputs of SURVEY.md §8(d), generated on the device (N(0,1) crops/templates, disk masks, BOP K)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    K = torch.tensor([[572.4114, 0, 320], [0, 573.57043, 240], [0, 0, 1.0]], device=device)
+    c = torch.arange(64, device=device).float() * 3.5 + 1.75
+    gy, gx = torch.meshgrid(c, c, indexing="ij")
+    pts = (torch.stack([gx, gy], dim=-1) - torch.tensor([-100.0, -80.0], device=device)) / 2.0
+    ang = torch.rand(B, N, generator=g, device=device) * 6.2831853
+    pose = torch.eye(4, device=device)[None, None].repeat(B, N, 1, 1)
+    pose[..., 0, 0], pose[..., 0, 1], pose[..., 1, 0], pose[..., 1, 1] = ang.cos(), -ang.sin(), ang.sin(), ang.cos()
+    pose[..., 2, 3] = 0.8
+    return {
+        "real_rgb": torch.randn(B, 3, 224, 224, device=device, generator=g),
+        "real_mask": disk_mask(B, device), "real_K": K[None].repeat(B, 1, 1),
+        "real_M": torch.tensor([[2.0, 0, -100.0], [0, 2.0, -80.0], [0, 0, 1.0]], device=device)[None].repeat(B, 1, 1),
+        "real_pose": torch.eye(4, device=device)[None].repeat(B, 1, 1), "real_pts2d": pts[None].repeat(B, 1, 1, 1),
+        "tem_rgb": torch.randn(B, N, 3, 224, 224, device=device, generator=g),
+        "tem_mask": disk_mask(1, device)[None].repeat(B, N, 1, 1),
+        "tem_pts3d": (torch.rand(B, N, 64, 64, 3, device=device, generator=g) - 0.5) * 0.2, "tem_pose": pose,
+        "tem_K": K[None, None].repeat(B, N, 1, 1),
+        "tem_M": torch.tensor([[1.5, 0, -300.0], [0, 1.5, -200.0], [0, 0, 1.0]], device=device)[None, None].repeat(B, N, 1, 1),
+    }
+
+
+def cpu_baseline_stage1(N, C, budget=20.0):
     from oracle import matching as om
 
-    # the GPU box hands one GPU's job a 16-core share of the host; never oversubscribe it
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
+    cores = cpu_cores()
     torch.set_num_threads(cores)
     Bs = 4
     g = torch.Generator().manual_seed(1)
-    bank = torch.randn(Bs, N, C, 16, 16, generator=g)
-    query = torch.randn(Bs, C, 16, 16, generator=g)
+    bank, query = torch.randn(Bs, N, C, 16, 16, generator=g), torch.randn(Bs, C, 16, 16, generator=g)
     mask = disk_mask(Bs, "cpu")
-    om.matching_templates(bank, query, None, mask, topk=5)  # warm-up
-    t0 = time.perf_counter()
-    reps = 0
+    om.matching_templates(bank, query, None, mask, topk=5)
+    t0, reps = time.perf_counter(), 0
     while True:
         om.matching_templates(bank, query, None, mask, topk=5)
         reps += 1
         dt = time.perf_counter() - t0
-        if dt > seconds_budget or reps >= 8:
+        if dt > budget or reps >= 8:
             break
     return {"value": Bs * reps / dt, "unit": "crops/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x matching_templates on {Bs} crops x {N} templates x C={C} (same shape, "
-                      f"smaller batch), torch CPU fp32, {cores} threads"}
+            "sample": f"{reps} x matching_templates on {Bs} crops x {N} templates x C={C}, torch CPU fp32, {cores} threads"}
+
+
+def cpu_baseline_full(N, vit, sd, budget=25.0):
+    """Oracle Net.forward on ONE crop of the same shape (N templates, hyp 5); PnP excluded (cv2 is not available)."""
+    from oracle import nets as on
+
+    cores = cpu_cores()
+    torch.set_num_threads(cores)
+    C, heads, idx, _ = VIT[vit]
+    take = [b[-1] for b in idx]
+    ep = {k: v.cpu() for k, v in make_end_points(1, N, "cpu", 7).items()}
+    with torch.no_grad():
+        # the bank is precomputed outside the measure (as on the GPU); its values do not change the timing
+        ep["template_feature"] = torch.randn(1, N, C, 16, 16, generator=torch.Generator().manual_seed(8))
+        t0, reps = time.perf_counter(), 0
+        while True:
+            on.net_forward_test(sd, ep, 5, heads, take)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or reps >= 3:
+                break
+    return {"value": reps / dt, "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x oracle Net.forward (stage1->stage3, hyp 5, no PnP: cv2 absent) on 1 crop x {N} templates, {vit}, "
+                      f"torch CPU fp32, {cores} threads (feature bank precomputed, as on the GPU)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="stage1_b32_n162_c768", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="full_b32_n162_vitb", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -110,22 +189,52 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from picopose_amd import _lib
-    from picopose_amd.dist import shard_bounds, sharded_matching_templates
+    from picopose_amd.dist import shard_bounds, sharded_forward, sharded_matching_templates
     from picopose_amd.utils import matching as hm
 
-    Bg, N, C, cfg_name = WORKLOADS[a.workload]
-    B = Bg * world  # global batch: every rank scores its template slice of ALL crops
+    kind, Bl, N, vit, desc = WORKLOADS[a.workload]
+    C = VIT[vit][0]
+    B = Bl * world                      # global batch
     lo, hi = shard_bounds(N, world, rank)
     n_local = hi - lo
-    # identical query/mask on every rank (seed 0); this rank's slice of every crop's bank (seed 1+rank)
-    _, query, mask = make_inputs(B, 1, C, dev, 0)
-    gb = torch.Generator(device=dev).manual_seed(1 + rank)
-    bank = torch.randn(B, n_local, C, 16, 16, device=dev, generator=gb)
+    sd = None
 
-    def step():
+    if kind == "stage1":
+        g0 = torch.Generator(device=dev).manual_seed(0)
+        query = torch.randn(B, C, 16, 16, device=dev, generator=g0)     # identical on every rank
+        mask = disk_mask(B, dev)
+        bank = torch.randn(B, n_local, C, 16, 16, device=dev, generator=torch.Generator(device=dev).manual_seed(1 + rank))
+
+        def step():
+            if distributed:
+                return sharded_matching_templates(bank, query, mask, N, topk=5, mode=a.mode)
+            return hm.matching_templates(bank, query, None, mask, topk=5, mode=a.mode)
+    else:
+        from picopose_amd.picopose import Net
+        from picopose_amd.pipeline import pnp_for_outputs
+
+        net = Net(make_cfg(vit))
+        sd = seeded_weights(net, 4)
+        net = net.to(dev).eval()
+        net.match_mode = a.mode
+        ep = make_end_points(Bl, N, dev, 100 + rank)                     # this rank's crops + their raw templates
+        fe = net.feature_extractor
+        # feature bank (outside the timed region, run_test.py:120-134): this rank's template slice of ALL crops.
+        # Synthetic stand-in for the other ranks' crops: features of this rank's own renders (same shapes/bytes).
+        with torch.no_grad():
+            feats = torch.stack([torch.cat([fe(ep["tem_rgb"][b, s:min(s + 54, hi)])[-1] for s in range(lo, hi, 54)])
+                                 for b in range(Bl)])
         if distributed:
-            return sharded_matching_templates(bank, query, mask, N, topk=5, mode=a.mode)
-        return hm.matching_templates(bank, query, None, mask, topk=5, mode=a.mode)
+            bank = feats.repeat(world, 1, 1, 1, 1).contiguous()
+        else:
+            ep["template_feature"] = feats
+
+        def step():
+            if distributed:
+                outs = sharded_forward(net, ep, bank, N, hyp=5)
+            else:
+                outs = net(ep, 5)
+            return outs, pnp_for_outputs(outs, ep["real_K"])            # PnP/RANSAC + D2H of the poses
 
     for _ in range(a.warmup):
         out = step()
@@ -155,31 +264,35 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        assert out[1].shape == (B, 5) and out[1].dtype == torch.int64
         ms = dt / a.steps * 1e3
-        kbytes = algorithmic_bytes(B, n_local, C)  # bytes the roofline kernel launch streams on this rank
-        traffic = None  # HBM bytes per launch from the PMC passes of the same command (profiles/, tools/pmc.sh)
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_stage1.json")
-        if world == 1 and a.mode == "fast" and os.path.exists(pmc):
-            rec = json.load(open(pmc))
-            if rec.get("workload") == a.workload:
-                traffic = rec["hbm_bytes_per_launch"]
+        kbytes = stage1_bytes(B, n_local, C)        # bytes one launch of the stage-1 kernel streams on this rank
         achieved = kbytes / (kern_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the PMC passes (profiles/, tools/pmc.sh): same kernel, same shape
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_stage1.json")
+        if world == 1 and a.mode == "fast" and (B, N, C) == (32, 162, 768) and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         line = {
-            "metric": "image-crops/sec (224x224, 162 templates), stage-1 template matching",
-            "value": B / (dt / a.steps), "unit": "crops/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 in / f16 MFMA operands / f32 accumulate" if a.mode == "fast" else "f32",
+            "metric": "image-crops/sec (224x224, 162 templates)" + ("" if kind == "full" else ", stage-1 template matching only"),
+            "value": B / (dt / a.steps), "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (networks: fp32 MFMA; stage-1 contraction: f16 MFMA operands, f32 accumulate, exact f32 re-evaluation of near-ties; PnP f64)"
+                     if a.mode == "fast" else "f32 (PnP f64)",
             "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {cfg_name}; matching_templates only (stages 2-3 not on the HIP path yet)",
-                       "global_batch": B, "templates": N, "channels": C, "mode": a.mode,
-                       "parallelism": "single GPU" if world == 1 else f"template-shard x{world} + 1 RCCL all-gather of (B,N/G) scores"},
-            "roofline": {"bound": "hbm", "kernel": f"s1_main<{a.mode}>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "config": {"workload": f"{a.workload}: {desc}", "global_batch": B, "templates": N, "backbone": vit, "channels": C,
+                       "hypotheses": 5, "mode": a.mode, "weights": "seeded random init",
+                       "parallelism": "single GPU" if world == 1 else
+                       f"crops data-parallel x{world}; feature bank template-sharded x{world} + RCCL all-gathers (query features, scores)"},
+            "roofline": {"bound": "hbm", "kernel": f"s1_main<{a.mode}> (stage-1 fused similarity)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kbytes},
         }
+        if kind == "full":
+            tf = Bl * full_gflop_per_crop(N, vit) / (dt / a.steps) / 1e3   # per GPU
+            line["mfma"] = {"bound": "mfma", "scope": "whole step, all kernels (gemm_kernel = fp32 MFMA is >90 % of it)",
+                            "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                            "gflop_per_crop": full_gflop_per_crop(N, vit)}
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(N, C)
+            line["cpu_baseline"] = cpu_baseline_full(N, vit, sd) if kind == "full" else cpu_baseline_stage1(N, C)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

@@ -54,3 +54,42 @@ def sharded_matching_templates(local_bank, tar_feat, tar_mask, n_total, topk=5, 
     local = score_fn(local_bank, tar_feat, tar_mask)
     full = gather_scores(local, n_total, group=group)
     return topk_fn(full, topk)
+
+
+def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=None, features_fn=None, scores_fn=None,
+                    topk_fn=None, tail_fn=None):
+    """Net.forward (eval) with the template FEATURE bank sharded over the ranks and the crops data-parallel.
+
+    Every rank owns `b_local` crops (`local_end_points`, with the raw template data of ITS crops) and the slice
+    [shard_bounds) of the feature bank of ALL crops: local_bank (world*b_local, n_local, C, 16, 16), crops ordered
+    rank-major.  Exchange steps: all-gather of the query features and masks (every rank scores its template slice
+    against all crops) and the all-gather of the (B_total, n_local) score slices; stages 2-3 run on the rank's own
+    crops.  *_fn default to the HIP model; tests inject CPU stand-ins to run under gloo.
+    Returns the list (hyp) of output dicts for the rank's own crops."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if features_fn is None:
+        from .utils import matching as hm
+
+        from . import ops
+
+        def features_fn(x):
+            toks, (h0, w0) = net.feature_extractor.forward_tokens(x)
+            return (toks, (h0, w0)), ops.tokens_to_nchw(toks[-1], 1, h0, w0)
+
+        scores_fn = lambda b, q, m: hm.template_scores(b, q, m, mode=net.match_mode)  # noqa: E731
+        topk_fn = hm.topk_templates
+        tail_fn = lambda ep, ids, real: [net.forward_test_hyp(net.select_template_data(ep, ids, k), real)  # noqa: E731
+                                         for k in range(ids.shape[1])]
+    with torch.no_grad():
+        real, q_local = features_fn(local_end_points["real_rgb"])          # (state for stages 2-3, (b,C,16,16))
+        b_local = q_local.shape[0]
+        q_all = q_local.new_empty((world * b_local,) + tuple(q_local.shape[1:]))
+        dist.all_gather_into_tensor(q_all, q_local.contiguous(), group=group)
+        m_local = local_end_points["real_mask"].contiguous()
+        m_all = m_local.new_empty((world * b_local,) + tuple(m_local.shape[1:]))
+        dist.all_gather_into_tensor(m_all, m_local, group=group)
+        lo, hi = shard_bounds(n_total, world, rank)
+        assert local_bank.shape[0] == world * b_local and local_bank.shape[1] == hi - lo
+        full = gather_scores(scores_fn(local_bank, q_all, m_all), n_total, group=group)      # (B_total, N)
+        _, ids = topk_fn(full[rank * b_local:(rank + 1) * b_local].contiguous(), hyp)
+        return tail_fn(local_end_points, ids, real)

@@ -1,0 +1,38 @@
+"""Per-batch inference as the reference's evaluator runs it (run_test.py:151-186): network forward, then
+PnP/RANSAC for every (instance, hypothesis), hypotheses ranked by inlier ratio, stage-2 pose as the
+fallback when PnP fails.  One batched PnP launch and one device->host copy per batch instead of the
+reference's B*hyp host round trips."""
+import numpy as np
+import torch
+
+from .utils.pose_recovery import pose_recovery_ransac_pnp_batched
+
+
+def pnp_for_outputs(outputs, real_K):
+    """outputs: list (hyp) of Net.forward dicts; real_K (B,3,3) -> rot (hyp,B,3,3), tvec (hyp,B,3,1), ratio, ok."""
+    hyp, B = len(outputs), outputs[0]["pred_poses"].shape[0]
+    cat = lambda k: torch.cat([o[k] for o in outputs], dim=0)  # noqa: E731
+    rot, tvec, ratio, ok = pose_recovery_ransac_pnp_batched(cat("tar_pts_2d"), cat("src_pts_3d"), real_K.repeat(hyp, 1, 1),
+                                                           cat("tem_pose"), cat("pred_tar_pts"), cat("pred_src_pts"))
+    return (rot.reshape(hyp, B, 3, 3), tvec.reshape(hyp, B, 3, 1), ratio.reshape(hyp, B), ok.reshape(hyp, B))
+
+
+def infer_batch(net, end_points, hyp=5):
+    """-> per-instance pose hypotheses sorted by inlier ratio (run_test.py:168-186):
+    list over instances of list over hypotheses of dict(R (3,3), t (3,), inliers_ratio, pnp_success)."""
+    outputs = net(end_points, hyp)
+    rot, tvec, ratio, ok = pnp_for_outputs(outputs, end_points["real_K"])
+    stage2 = np.stack([o["pred_poses"].cpu().numpy() for o in outputs])            # (hyp,B,4,4)
+    B = stage2.shape[1]
+    results = []
+    for b in range(B):
+        hyps = []
+        for k in range(hyp):
+            if ok[k, b]:
+                hyps.append(dict(R=rot[k, b], t=tvec[k, b, :, 0], inliers_ratio=float(ratio[k, b]), pnp_success=True))
+            else:  # run_test.py:177-179: fall back to the stage-2 pose
+                hyps.append(dict(R=stage2[k, b, :3, :3].astype(np.float64), t=stage2[k, b, :3, 3].astype(np.float64),
+                                 inliers_ratio=0.0, pnp_success=False))
+        hyps.sort(key=lambda h: h["inliers_ratio"], reverse=True)                   # run_test.py:186
+        results.append(hyps)
+    return results

@@ -27,6 +27,23 @@ def main():
         topk_fn=lambda sc, k: torch.topk(sc, k, dim=1))
     rs, ri = om.matching_templates(bank, query, None, mask, topk=4)
     ok = torch.equal(i, ri) and float((s - rs).abs().max()) <= 1e-6
+
+    # full-path orchestration (crops data-parallel, feature bank template-sharded): CPU stand-ins for the stages
+    from picopose_amd.dist import sharded_forward
+
+    bl = 2                                            # crops per rank
+    g2 = torch.Generator().manual_seed(9)
+    Bt = bl * world
+    bank_all = torch.randn(Bt, N, C, 16, 16, generator=g2)
+    rgb_all = torch.randn(Bt, C, 16, 16, generator=g2)     # stand-in "image": the feature extractor is the identity
+    mask_all = (torch.rand(Bt, 224, 224, generator=g2) < 0.7).float()
+    own = slice(rank * bl, (rank + 1) * bl)
+    ep = {"real_rgb": rgb_all[own], "real_mask": mask_all[own]}
+    outs = sharded_forward(None, ep, bank_all[:, lo:hi].contiguous(), N, hyp=3,
+                           features_fn=lambda x: ("state", x), scores_fn=lambda b, qq, m: om.template_scores(b, qq, m),
+                           topk_fn=lambda sc, k: torch.topk(sc, k, dim=1), tail_fn=lambda e, ids, real: ids)
+    _, want = om.matching_templates(bank_all[own], rgb_all[own], None, mask_all[own], topk=3)
+    ok = ok and torch.equal(outs, want)
     print(f"RANK{rank} {'OK' if ok else 'MISMATCH'}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
