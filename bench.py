@@ -74,7 +74,8 @@ def stage1_bytes(B, N, C):
 def full_gflop_per_crop(N, vit, hyp=5):
     C = VIT[vit][0]
     dpt = {"dinov2_vits14": 18.5, "dinov2_vitb14": 19.0, "dinov2_vitl14": 19.4}[vit]
-    return (1 + hyp) * VIT[vit][3] + 2 * hyp * dpt + hyp * 108.4 + hyp * 0.14 + N * 2 * 256 * 256 * C / 1e9
+    # executed work: the query-side DPT head runs once per forward, not once per hypothesis (picopose_amd/picopose.py)
+    return (1 + hyp) * VIT[vit][3] + (1 + hyp) * dpt + hyp * 108.4 + hyp * 0.14 + N * 2 * 256 * 256 * C / 1e9
 
 
 def make_cfg(vit):

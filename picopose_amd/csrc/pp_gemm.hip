@@ -21,6 +21,11 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <mutex>
+#include <string>
+#include <unordered_map>
 #include "../../include/picopose_hip.h"
 #include "pp_common.h"
 
@@ -29,7 +34,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDT = 36;
+constexpr int BM = 128, BK = 32, LDT = 36;  // BN = 64 * NJ (template): 128x128 or 128x64 block tiles
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
@@ -91,8 +96,11 @@ __device__ __forceinline__ f4 load_a(const PpGemmDesc& d, const float* __restric
     return v;
 }
 
-template <bool VEC4>
-__global__ __launch_bounds__(256) void gemm_kernel(const PpGemmDesc d) {
+// OCC = workgroups per CU the register allocation is held to: the 128x128 tile runs ~10 % faster per tile at 2
+// (no spills, 200 VGPRs) than at 3 (168 VGPRs); which one wins depends on how the tile count fills the slots.
+template <bool VEC4, int NJ, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_kernel(const PpGemmDesc d) {
+    constexpr int BN = 64 * NJ;
     __shared__ __attribute__((aligned(16))) float As[BM * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -105,25 +113,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const PpGemmDesc d) {
     const float* R = d.residual ? d.residual + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1 : nullptr;
     const float* R2 = d.residual2 ? d.residual2 + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1 : nullptr;
 
-    // this thread's 4 (row, k-quad) slots of the A and B tiles: idx = tid + 256 j -> row idx>>3, quad idx&7
-    int arow[4], ab[4], aoy[4], aox[4];
-    long long abase[4];  // VEC4 conv: element offset of input pixel (oy*stride - pad, ox*stride - pad) of the row's image
+    // this thread's 4 (row, k-quad) slots of the A and B tiles: idx = tid + 256 j -> row (tid>>3) + 32 j, quad tid&7
+    const int arow0 = tid >> 3;
+#define AROW(j) (arow0 + 32 * (j))
+    int aoy[4], aox[4];
+    int abase[4];  // VEC4 conv: element offset of input pixel (oy*stride - pad, ox*stride - pad) of the row's image
+    int ab[VEC4 ? 1 : 4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int idx = tid + 256 * j;
-        arow[j] = idx >> 3;
-        const int m = m0 + arow[j];
-        ab[j] = aoy[j] = aox[j] = 0;
-        abase[j] = 0;
+        const int m = m0 + AROW(j);
+        aoy[j] = aox[j] = abase[j] = 0;
+        if (!VEC4) ab[j] = 0;
         if (d.conv_kh != 0 && m < d.M) {
             const int per = d.conv_ho * d.conv_wo;
-            ab[j] = m / per;
-            const int r = m - ab[j] * per;
+            const int bi = m / per;
+            const int r = m - bi * per;
             aoy[j] = r / d.conv_wo;
             aox[j] = r - aoy[j] * d.conv_wo;
             aoy[j] = aoy[j] * d.conv_stride - d.conv_pad;  // top-left input pixel of the window
             aox[j] = aox[j] * d.conv_stride - d.conv_pad;
-            abase[j] = (long long)ab[j] * d.conv_bstride + ((long long)aoy[j] * d.conv_w + aox[j]) * d.lda;
+            abase[j] = (int)((long long)bi * d.conv_bstride + ((long long)aoy[j] * d.conv_w + aox[j]) * d.lda);
+            if (!VEC4) ab[j] = bi;
         }
     }
     const int kq = (tid & 7) * 4;
@@ -137,15 +147,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const PpGemmDesc d) {
         tkx = tap - tky * d.conv_kw;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f4 ra[4], rb[4];
+    f4 ra[4], rb[2 * NJ];
     auto fetch = [&](int k0) __attribute__((always_inline)) {
         const int k = k0 + kq;
 #pragma unroll
@@ -153,18 +163,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const PpGemmDesc d) {
             if (VEC4 && d.conv_kh != 0) {
                 f4 v = {0.f, 0.f, 0.f, 0.f};
                 const int iy = aoy[j] + tky, ix = aox[j] + tkx;
-                if (m0 + arow[j] < d.M && k < d.K && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w)
-                    v = *(const f4*)(A + abase[j] + ((long long)tky * d.conv_w + tkx) * d.lda + tci);
+                if (m0 + AROW(j) < d.M && k < d.K && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w)
+                    v = *(const f4*)(A + (long long)abase[j] + (tky * d.conv_w + tkx) * d.lda + tci);
                 if (d.relu_in) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
                 }
                 ra[j] = v;
             } else {
-                ra[j] = load_a<VEC4>(d, A, m0 + arow[j], k, ab[j], aoy[j], aox[j]);
+                ra[j] = load_a<VEC4>(d, A, m0 + AROW(j), k, ab[VEC4 ? 0 : j], aoy[j], aox[j]);
             }
+            if (j >= 2 * NJ) continue;  // the B tile has BN = 64*NJ rows
             f4 v = {0.f, 0.f, 0.f, 0.f};
-            const int n = n0 + arow[j];
+            const int n = n0 + AROW(j);
             if (n < d.N) {
                 if (d.b_kn) {  // B stored [K][N]
 #pragma unroll
@@ -200,34 +211,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(const PpGemmDesc d) {
         __syncthreads();  // previous tile fully consumed
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            *(f4*)(As + arow[j] * LDT + kq) = ra[j];
-            *(f4*)(Bs + arow[j] * LDT + kq) = rb[j];
+            *(f4*)(As + AROW(j) * LDT + kq) = ra[j];
+            if (j < 2 * NJ) *(f4*)(Bs + AROW(j) * LDT + kq) = rb[j];
         }
         __syncthreads();
         if (kt + 1 < nk) fetch((kt + 1) * BK);
-        f4 af[2][4], bf[2][4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int q = 0; q < 4; ++q) {  // 4 k-pairs per fragment read: keeps only 4 fragment registers sets live
+            f4 af[2], bf[NJ];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                af[i][q] = *(const f4*)(As + (wr * 64 + i * 32 + l31) * LDT + lh * 16 + 4 * q);
-                bf[i][q] = *(const f4*)(Bs + (wc * 64 + i * 32 + l31) * LDT + lh * 16 + 4 * q);
-            }
+            for (int i = 0; i < 2; ++i) af[i] = *(const f4*)(As + (wr * 64 + i * 32 + l31) * LDT + lh * 16 + 4 * q);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int j = 0; j < NJ; ++j)
+                bf[j] = *(const f4*)(Bs + (wc * 32 * NJ + j * 32 + l31) * LDT + lh * 16 + 4 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q][e], bf[j][q][e], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
     }
 
     // ---- epilogue: out = residual + residual2 + gamma * act(alpha * acc + bias)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wc * 64 + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wc * 32 * NJ + j * 32 + l31;
         if (n >= d.N) continue;
         const float bias = d.bias ? d.bias[n] : 0.f;
         const float gamma = d.gamma ? d.gamma[n] : 1.f;
@@ -403,16 +413,78 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     if (d.shuffle_r != 0 && (d.N % (d.shuffle_r * d.shuffle_r) != 0 || d.shuffle_h * d.shuffle_w <= 0))
         return PP_EINVAL;
     if (d.conv_kh != 0 && d.conv_bstride == 0) d.conv_bstride = (long long)d.conv_h * d.conv_w * d.lda;
+    if (d.conv_kh != 0) {  // the conv loader keeps 32-bit element offsets per row
+        const long long imgs = (d.M + (long long)d.conv_ho * d.conv_wo - 1) / ((long long)d.conv_ho * d.conv_wo);
+        if (imgs * d.conv_bstride >= (1LL << 31)) return PP_EINVAL;
+    }
     // 16-byte vector loads need aligned rows: K-contiguous operands with lda/ldb/Cin % 4 == 0
     bool vec = ((uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.B % 16 == 0) && d.lda % 4 == 0 &&
                (d.b_kn || d.ldb % 4 == 0) && d.a_bs0 % 4 == 0 && d.a_bs1 % 4 == 0 && d.b_bs0 % 4 == 0 &&
                d.b_bs1 % 4 == 0;
     if (d.conv_kh != 0 && (d.conv_cin % 4 != 0 || d.conv_bstride % 4 != 0)) vec = false;
-    const dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch0 * d.batch1);
-    if (vec)
-        hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, d);
-    else
-        hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, d);
+    // block tile 128x128 (3 workgroups/CU) or 128x64 (4/CU): take the one with the shorter makespan
+    // rounds(tiles / resident slots) x relative tile time — fixes the wave-quantisation tail of mid-size GEMMs
+    int dev = 0, cus = 256;
+    PP_CHECK_HIP(hipGetDevice(&dev));
+    PP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const long long rows = (d.M + BM - 1) / BM, z = (long long)d.batch0 * d.batch1;
+    hipStream_t st = (hipStream_t)stream;
+    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU
+        const bool narrow = cfg == 2;
+        const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
+        if (!vec) {  // scalar-load path (Cin not a multiple of 4: the small 7x7 / 1x1 / patch-embed layers)
+            if (narrow) hipLaunchKernelGGL((gemm_kernel<false, 1, 2>), grid, dim3(256), 0, st, d);
+            else hipLaunchKernelGGL((gemm_kernel<false, 2, 2>), grid, dim3(256), 0, st, d);
+        } else if (narrow) {
+            hipLaunchKernelGGL((gemm_kernel<true, 1, 4>), grid, dim3(256), 0, st, d);
+        } else if (cfg == 0) {
+            hipLaunchKernelGGL((gemm_kernel<true, 2, 2>), grid, dim3(256), 0, st, d);
+        } else {
+            hipLaunchKernelGGL((gemm_kernel<true, 2, 3>), grid, dim3(256), 0, st, d);
+        }
+    };
+    // Which block tile / occupancy is fastest depends on how the tile count fills the CUs (wave quantisation)
+    // and on K; it is measured once per problem shape (three timed launches of the same GEMM — idempotent
+    // unless the output aliases a residual) and remembered.  PP_GEMM_AUTOTUNE=0 keeps the static choice.
+    int cfg = d.N <= 64 ? 2 : 0;
+    const bool alias = d.residual == d.C || d.residual2 == d.C;
+    static const bool tune = [] { const char* e = getenv("PP_GEMM_AUTOTUNE"); return !(e && e[0] == '0'); }();
+    if (tune && !alias && d.N > 64) {
+        static std::mutex mu;
+        static std::unordered_map<std::string, int> best;
+        char key[160];
+        snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%lld.%d.%d.%d.%d.%d", d.M, d.N, d.K, (int)vec, d.b_kn, z, d.conv_kh,
+                 d.conv_cin, d.conv_stride, d.conv_h, d.shuffle_r);
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = best.find(key);
+        if (it == best.end()) {
+            hipEvent_t e0, e1;
+            PP_CHECK_HIP(hipEventCreate(&e0));
+            PP_CHECK_HIP(hipEventCreate(&e1));
+            float bt = 1e30f;
+            int bc = 0;
+            for (int c = 0; c < (vec ? 3 : 1) + (vec ? 0 : 1); ++c) {
+                const int cand = vec ? c : (c == 0 ? 0 : 2);
+                launch(cand);  // warm
+                (void)hipEventRecord(e0, st);
+                launch(cand);
+                (void)hipEventRecord(e1, st);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (ms < bt) {
+                    bt = ms;
+                    bc = cand;
+                }
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            best[key] = bc;
+            return pp_last_launch();  // the last timed launch already produced the result
+        }
+        cfg = it->second;
+    }
+    launch(cfg);
     return pp_last_launch();
 }
 

@@ -74,7 +74,8 @@ def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=Non
 
         def features_fn(x):
             toks, (h0, w0) = net.feature_extractor.forward_tokens(x)
-            return (toks, (h0, w0)), ops.tokens_to_nchw(toks[-1], 1, h0, w0)
+            dpt = net.offset_regressor.dpt_head.forward_nhwc([t[:, 1:].unflatten(1, (h0, w0)) for t in toks])
+            return (toks, (h0, w0), dpt), ops.tokens_to_nchw(toks[-1], 1, h0, w0)
 
         scores_fn = lambda b, q, m: hm.template_scores(b, q, m, mode=net.match_mode)  # noqa: E731
         topk_fn = hm.topk_templates
