@@ -138,6 +138,10 @@ int pp_gather_valid(const float* features, const int64_t* index_patches, int B, 
 #define PP_ACT_LEAKY01 3 /* LeakyReLU(0.1) */
 #define PP_ACT_TANH 4
 
+/* arithmetic of the GEMM engine */
+#define PP_PREC_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate                       */
+#define PP_PREC_F16X3 1 /* operands scaled and split into 2 fp16 terms, 3 x v_mfma_f32_32x32x16_f16, fp32 acc. */
+
 /* C[m,n] = residual[m,n] + gamma[n] * act(alpha * sum_k A(m,k) * B(n,k) + bias[n])
  * for every batch index z = z0*batch1 + z1 (operand offsets z0*bs0 + z1*bs1, in floats). */
 typedef struct PpGemmDesc {
@@ -162,9 +166,16 @@ typedef struct PpGemmDesc {
     /* ConvTranspose2d(kernel = stride = shuffle_r): rows are the pixels of (b, shuffle_h, shuffle_w),
      * column n = (dy*r + dx)*Cout + co is stored at pixel (y*r+dy, x*r+dx), channel co               */
     int shuffle_r, shuffle_h, shuffle_w;
+    int prec;              /* PP_PREC_*                                                               */
+    const void* B_hi;      /* optional pre-split weights for PP_PREC_F16X3: fp16 [N][ldb], hi term    */
+    const void* B_lo;      /* ... lo term (pp_split_f16x3)                                            */
+    float b_scale;         /* power-of-two scale the pre-split weights were multiplied by             */
 } PpGemmDesc;
 
 int pp_gemm(const PpGemmDesc* desc, void* stream);
+/* Split n fp32 weights once at load time: scale[0] = 2^k with max|scale*w| in [512,1024) (device float),
+ * hi = f16(scale*w), lo = f16(scale*w - hi). */
+int pp_split_f16x3(const float* w, long long n, void* hi, void* lo, float* scale, void* stream);
 
 /* nn.LayerNorm(C, eps) over rows of a [rows][C] matrix. */
 int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps,

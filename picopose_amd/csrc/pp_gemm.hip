@@ -33,6 +33,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128, BK = 32, LDT = 36;  // BN = 64 * NJ (template): 128x128 or 128x64 block tiles
 
@@ -268,6 +270,242 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(const PpGemmDesc d) {
 }
 
 // ---------------------------------------------------------------------------
+// Split-precision variant ("f16x3"): every fp32 operand v is scaled by a power of two s and split on the
+// fly into two fp16 numbers   hi = f16(s v),  lo = f16(s v - hi)   (s v - hi is exact in fp32), and the
+// product a*b is evaluated as hi_a*hi_b + hi_a*lo_b + lo_a*hi_b on v_mfma_f32_32x32x16_f16 — fp16 x fp16
+// products are exact in the fp32 accumulator, the dropped lo*lo term is 2^-22 relative.  For |s v| >= 2^-3
+// lo is a normal fp16 and 22 operand bits survive; below that lo is subnormal and the operand keeps an
+// ABSOLUTE accuracy of 2^-25 / s — what fp32 gives an element of magnitude ~0.25/s — so the scales are
+// chosen to put the bulk of the data above 2^-3: activations s_a = 4 (|v| up to 16376 before hi saturates;
+// no NaN, the excess stays in lo), weights s_b = 2^k per tensor with max |s_b w| in [512, 1024).  The result
+// is multiplied by 1/(s_a s_b) in the epilogue (exact).  Three MFMAs at 16x the fp32-MFMA rate.  Weights
+// can be handed over pre-split (d.B_hi / d.B_lo / d.b_scale from pp_split_f16x3).
+// LDS: hi/lo planes of [rows][32 k] halfs with an 80-byte row stride (conflict-free ds_read_b128).
+// ---------------------------------------------------------------------------
+constexpr float A_SCALE = 4.f;  // activation operand scale of the f16x3 engine
+
+__device__ __forceinline__ void split_f16x4(const f4 v, float s, h4& hi, h4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = v[i] * s;
+        const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+        hi[i] = h;
+        lo[i] = (_Float16)fminf(fmaxf(x - (float)h, -65504.f), 65504.f);
+    }
+}
+
+template <int NJ, int OCC, bool BSPLIT>
+__global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const PpGemmDesc d) {
+    constexpr bool VEC4 = true;
+    constexpr int BN = 64 * NJ;
+    constexpr int LDH = 40;  // halfs per LDS row (32 used): 80-byte stride
+    __shared__ __attribute__((aligned(16))) _Float16 Ah[BM * LDH], Al[BM * LDH], Bh[BN * LDH], Bl[BN * LDH];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int z = blockIdx.z, z0 = z / d.batch1, z1 = z - z0 * d.batch1;
+    const float* A = d.A + (size_t)z0 * d.a_bs0 + (size_t)z1 * d.a_bs1;
+    const float* Bm = d.B + (size_t)z0 * d.b_bs0 + (size_t)z1 * d.b_bs1;
+    constexpr bool bsplit = BSPLIT;  // pre-split weights: [N][ldb] halfs, no batch
+    const _Float16* Bhg = (const _Float16*)d.B_hi;
+    const _Float16* Blg = (const _Float16*)d.B_lo;
+    float* C = d.C + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1;
+    const float* R = d.residual ? d.residual + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1 : nullptr;
+    const float* R2 = d.residual2 ? d.residual2 + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1 : nullptr;
+
+    // this thread's 4 (row, k-quad) slots of the A and B tiles: idx = tid + 256 j -> row (tid>>3) + 32 j, quad tid&7
+    const int arow0 = tid >> 3;
+#define AROW(j) (arow0 + 32 * (j))
+    int aoy[4], aox[4];
+    int abase[4];  // VEC4 conv: element offset of input pixel (oy*stride - pad, ox*stride - pad) of the row's image
+    int ab[VEC4 ? 1 : 4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + AROW(j);
+        aoy[j] = aox[j] = abase[j] = 0;
+        if (!VEC4) ab[j] = 0;
+        if (d.conv_kh != 0 && m < d.M) {
+            const int per = d.conv_ho * d.conv_wo;
+            const int bi = m / per;
+            const int r = m - bi * per;
+            aoy[j] = r / d.conv_wo;
+            aox[j] = r - aoy[j] * d.conv_wo;
+            aoy[j] = aoy[j] * d.conv_stride - d.conv_pad;  // top-left input pixel of the window
+            aox[j] = aox[j] * d.conv_stride - d.conv_pad;
+            abase[j] = (int)((long long)bi * d.conv_bstride + ((long long)aoy[j] * d.conv_w + aox[j]) * d.lda);
+            if (!VEC4) ab[j] = bi;
+        }
+    }
+    const int kq = (tid & 7) * 4;
+    // VEC4 conv: the tap (ky, kx) and channel ci of this thread's k = k0 + kq, advanced by BK per K step
+    // without divisions (all four rows of the thread share k)
+    int tky = 0, tkx = 0, tci = 0;
+    if (VEC4 && d.conv_kh != 0) {
+        const int tap = kq / d.conv_cin;
+        tci = kq - tap * d.conv_cin;
+        tky = tap / d.conv_kw;
+        tkx = tap - tky * d.conv_kw;
+    }
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float b_scale = bsplit ? d.b_scale : A_SCALE;  // on-the-fly B operands are activations
+    const float descale = 1.0f / (A_SCALE * b_scale);
+
+    f4 ra[4], rb[BSPLIT ? 1 : 2 * NJ];
+    h4 rbh[BSPLIT ? 2 * NJ : 1], rbl[BSPLIT ? 2 * NJ : 1];  // pre-split B
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+        const int k = k0 + kq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (VEC4 && d.conv_kh != 0) {
+                f4 v = {0.f, 0.f, 0.f, 0.f};
+                const int iy = aoy[j] + tky, ix = aox[j] + tkx;
+                if (m0 + AROW(j) < d.M && k < d.K && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w)
+                    v = *(const f4*)(A + (long long)abase[j] + (tky * d.conv_w + tkx) * d.lda + tci);
+                if (d.relu_in) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                }
+                ra[j] = v;
+            } else {
+                ra[j] = load_a<VEC4>(d, A, m0 + AROW(j), k, ab[VEC4 ? 0 : j], aoy[j], aox[j]);
+            }
+            if (j >= 2 * NJ) continue;  // the B tile has BN = 64*NJ rows
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            const int n = n0 + AROW(j);
+            if (bsplit) {
+                h4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
+                if (n < d.N && k < d.K) {  // K % 4 == 0 is checked on the host for pre-split weights
+                    vh = *(const h4*)(Bhg + (size_t)n * d.ldb + k);
+                    vl = *(const h4*)(Blg + (size_t)n * d.ldb + k);
+                }
+                rbh[BSPLIT ? j : 0] = vh;
+                rbl[BSPLIT ? j : 0] = vl;
+                continue;
+            }
+            if (n < d.N) {
+                if (d.b_kn) {  // B stored [K][N]
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (k + i < d.K) v[i] = Bm[(size_t)(k + i) * d.ldb + n];
+                } else {
+                    const float* p = Bm + (size_t)n * d.ldb + k;
+                    if (VEC4 && k + 3 < d.K) v = *(const f4*)p;
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (k + i < d.K) v[i] = p[i];
+                    }
+                }
+            }
+            rb[BSPLIT ? 0 : j] = v;
+        }
+        if (VEC4 && d.conv_kh != 0) {  // advance the tap by BK channels
+            tci += BK;
+            while (tci >= d.conv_cin) {
+                tci -= d.conv_cin;
+                if (++tkx == d.conv_kw) {
+                    tkx = 0;
+                    ++tky;
+                }
+            }
+        }
+    };
+
+    const int nk = (d.K + BK - 1) / BK;
+    fetch(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h4 hh, ll;
+            split_f16x4(ra[j], A_SCALE, hh, ll);
+            *(h4*)(Ah + AROW(j) * LDH + kq) = hh;
+            *(h4*)(Al + AROW(j) * LDH + kq) = ll;
+            if (j < 2 * NJ) {
+                if (bsplit) {
+                    hh = rbh[BSPLIT ? j : 0];
+                    ll = rbl[BSPLIT ? j : 0];
+                } else {
+                    split_f16x4(rb[BSPLIT ? 0 : j], A_SCALE, hh, ll);
+                }
+                *(h4*)(Bh + AROW(j) * LDH + kq) = hh;
+                *(h4*)(Bl + AROW(j) * LDH + kq) = ll;
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) fetch((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {  // two 16-deep MFMA steps per K tile; lane half lh holds k = 8 lh .. 8 lh + 7
+            h8 ah[2], al[2], bh[NJ], bl[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *(const h8*)(Ah + (wr * 64 + i * 32 + l31) * LDH + ks * 16 + lh * 8);
+                al[i] = *(const h8*)(Al + (wr * 64 + i * 32 + l31) * LDH + ks * 16 + lh * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                bh[j] = *(const h8*)(Bh + (wc * 32 * NJ + j * 32 + l31) * LDH + ks * 16 + lh * 8);
+                bl[j] = *(const h8*)(Bl + (wc * 32 * NJ + j * 32 + l31) * LDH + ks * 16 + lh * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= descale;
+
+    // ---- epilogue: out = residual + residual2 + gamma * act(alpha * acc + bias)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wc * 32 * NJ + j * 32 + l31;
+        if (n >= d.N) continue;
+        const float bias = d.bias ? d.bias[n] : 0.f;
+        const float gamma = d.gamma ? d.gamma[n] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m >= d.M) continue;
+                float v = act_apply(acc[i][j][e] * d.alpha + bias, d.act) * gamma;
+                size_t off;
+                if (d.shuffle_r == 0) {
+                    off = (size_t)m * d.ldc + n;
+                } else {
+                    // ConvTranspose2d(kernel = stride = r): row m = input pixel (b, y, x) of an
+                    // (shuffle_h x shuffle_w) image, column n = (dy*r + dx)*Cout + co
+                    const int r = d.shuffle_r, cout = d.N / (r * r);
+                    const int sub = n / cout, co = n - sub * cout, dy = sub / r, dx = sub - dy * r;
+                    const int per = d.shuffle_h * d.shuffle_w;
+                    const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
+                    off = (((size_t)b * d.shuffle_h * r + y * r + dy) * (d.shuffle_w * r) + x * r + dx) * d.ldc + co;
+                }
+                if (R) v += R[off];
+                if (R2) v += R2[off];
+                C[off] = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Row-wise kernels around the GEMMs
 // ---------------------------------------------------------------------------
 
@@ -396,9 +634,51 @@ __global__ void normalize_rows_kernel(const float* __restrict__ x, int rows, int
     for (int i = 0; i < n; ++i) y[(size_t)r * n + i] = x[(size_t)r * n + i] / d;
 }
 
+// max |w| -> power-of-two scale with max |s w| in [512, 1024)
+__global__ __launch_bounds__(1024) void absmax_scale_kernel(const float* __restrict__ w, long long n,
+                                                            float* __restrict__ scale) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+        int e = 0;
+        if (m > 0.f && m < INFINITY) {
+            (void)frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)
+            e = 10 - e;           // s m in [512, 1024)
+        }
+        e = e > 30 ? 30 : (e < -30 ? -30 : e);
+        scale[0] = ldexpf(1.f, e);
+    }
+}
+
+__global__ void split_f16x3_kernel(const float* __restrict__ w, long long n, const float* __restrict__ scale,
+                                   _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+    const float s = scale[0];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = w[i] * s;
+        const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+        hi[i] = h;
+        lo[i] = (_Float16)(x - (float)h);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pp_split_f16x3(const float* w, long long n, void* hi, void* lo, float* scale, void* stream) {
+    if (!w || !hi || !lo || !scale || n <= 0) return PP_EINVAL;
+    hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, n, scale);
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(split_f16x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, n, scale, (_Float16*)hi,
+                       (_Float16*)lo);
+    return pp_last_launch();
+}
 
 int pp_gemm(const PpGemmDesc* desc, void* stream) {
     if (!desc || !desc->A || !desc->B || !desc->C) return PP_EINVAL;
@@ -429,10 +709,23 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     PP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const long long rows = (d.M + BM - 1) / BM, z = (long long)d.batch0 * d.batch1;
     hipStream_t st = (hipStream_t)stream;
+    const bool split = d.prec == PP_PREC_F16X3 && vec;  // unaligned (tiny) layers stay on the fp32 kernel
+    if (d.B_hi && (!d.B_lo || d.b_kn || d.ldb % 4 != 0 || d.K % 4 != 0 || z != 1 || !(d.b_scale > 0.f))) return PP_EINVAL;
+    if (d.B_hi && !split) d.B_hi = d.B_lo = nullptr;  // unaligned layer: the fp32 kernel reads d.B
     auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU
         const bool narrow = cfg == 2;
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
-        if (!vec) {  // scalar-load path (Cin not a multiple of 4: the small 7x7 / 1x1 / patch-embed layers)
+        if (split) {
+            if (d.B_hi) {
+                if (narrow) hipLaunchKernelGGL((gemm_f16x3_kernel<1, 4, true>), grid, dim3(256), 0, st, d);
+                else if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, true>), grid, dim3(256), 0, st, d);
+                else hipLaunchKernelGGL((gemm_f16x3_kernel<2, 3, true>), grid, dim3(256), 0, st, d);
+            } else {
+                if (narrow) hipLaunchKernelGGL((gemm_f16x3_kernel<1, 4, false>), grid, dim3(256), 0, st, d);
+                else if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, false>), grid, dim3(256), 0, st, d);
+                else hipLaunchKernelGGL((gemm_f16x3_kernel<2, 3, false>), grid, dim3(256), 0, st, d);
+            }
+        } else if (!vec) {  // scalar-load path (Cin not a multiple of 4: the small 7x7 / 1x1 / patch-embed layers)
             if (narrow) hipLaunchKernelGGL((gemm_kernel<false, 1, 2>), grid, dim3(256), 0, st, d);
             else hipLaunchKernelGGL((gemm_kernel<false, 2, 2>), grid, dim3(256), 0, st, d);
         } else if (narrow) {
@@ -453,8 +746,8 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         static std::mutex mu;
         static std::unordered_map<std::string, int> best;
         char key[160];
-        snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%lld.%d.%d.%d.%d.%d", d.M, d.N, d.K, (int)vec, d.b_kn, z, d.conv_kh,
-                 d.conv_cin, d.conv_stride, d.conv_h, d.shuffle_r);
+        snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%lld.%d.%d.%d.%d.%d.%d", d.M, d.N, d.K, (int)vec, d.b_kn, z, d.conv_kh,
+                 d.conv_cin, d.conv_stride, d.conv_h, d.shuffle_r, (int)split + 2 * (d.B_hi != nullptr));
         std::lock_guard<std::mutex> lock(mu);
         auto it = best.find(key);
         if (it == best.end()) {
@@ -463,7 +756,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             PP_CHECK_HIP(hipEventCreate(&e1));
             float bt = 1e30f;
             int bc = 0;
-            for (int c = 0; c < (vec ? 3 : 1) + (vec ? 0 : 1); ++c) {
+            for (int c = 0; c < (vec ? 3 : 2); ++c) {
                 const int cand = vec ? c : (c == 0 ? 0 : 2);
                 launch(cand);  // warm
                 (void)hipEventRecord(e0, st);

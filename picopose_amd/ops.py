@@ -11,6 +11,40 @@ from ._lib import PpGemmDesc
 
 ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "leaky01": 3, "tanh": 4}
 
+# Arithmetic of the GEMM engine (include/picopose_hip.h PP_PREC_*):
+#   "f32"   v_mfma_f32_32x32x2_f32 — exact fp32 products;
+#   "f16x3" every operand split into two fp16 terms (22 bits), 3 fp16 MFMAs, fp32 accumulate: fp32-grade results
+#           (operand rounding 2^-22 instead of 2^-24) at a fraction of the matrix-pipe time.
+PRECISION = "f16x3"
+_PREC = {"f32": 0, "f16x3": 1}
+_split_cache = {}
+
+
+def split_weight(w):
+    """(hi, lo, scale) — fp16 planes and power-of-two scale of a weight matrix for the f16x3 engine; split once per
+    tensor version (one host sync to read the scale back)."""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _split_cache.get(key)
+    if hit is None:
+        assert w.is_contiguous()
+        hi = torch.empty(w.shape, dtype=torch.float16, device=w.device)
+        lo = torch.empty(w.shape, dtype=torch.float16, device=w.device)
+        scale = torch.empty(1, dtype=torch.float32, device=w.device)
+        _lib.check(_lib.lib().pp_split_f16x3(_p(w), w.numel(), _p(hi), _p(lo), _p(scale), _lib.stream_ptr()),
+                   "pp_split_f16x3")
+        if len(_split_cache) > 4096:
+            _split_cache.clear()
+        hit = _split_cache[key] = (hi, lo, float(scale.item()), w)  # keep w alive so its address is not reused
+    return hit[0], hit[1], hit[2]
+
+
+def _weight_args(w, K):
+    """desc fields for a weight operand under the current precision (pre-split planes when it is aligned)."""
+    if PRECISION == "f16x3" and K % 4 == 0 and w.data_ptr() % 16 == 0:
+        hi, lo, scale = split_weight(w)
+        return dict(prec=1, B_hi=_p(hi), B_lo=_p(lo), b_scale=scale)
+    return dict(prec=_PREC[PRECISION])
+
 
 def _p(t):
     return t.data_ptr() if t is not None else None
@@ -40,7 +74,7 @@ def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, 
     if residual is not None:
         assert residual.shape == out.shape and residual.stride() == out.stride()
     _run(_desc(A=_p(x), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual), M=M, N=N, K=K,
-               lda=x.stride(0), ldb=K, ldc=out.stride(0), act=ACT[act], relu_in=int(relu_in)))
+               lda=x.stride(0), ldb=K, ldc=out.stride(0), act=ACT[act], relu_in=int(relu_in), **_weight_args(weight, K)))
     return out
 
 
@@ -53,7 +87,7 @@ def bmm_nt(a, b, alpha=1.0, out=None):
         out = torch.empty(Z0, Z1, M, N, dtype=torch.float32, device=a.device)
     _run(_desc(A=_p(a), B=_p(b), C=_p(out), M=M, N=N, K=K, lda=a.stride(2), ldb=b.stride(2), ldc=out.stride(2),
                batch0=Z0, batch1=Z1, a_bs0=a.stride(0), a_bs1=a.stride(1), b_bs0=b.stride(0), b_bs1=b.stride(1),
-               c_bs0=out.stride(0), c_bs1=out.stride(1), alpha=float(alpha)))
+               c_bs0=out.stride(0), c_bs1=out.stride(1), alpha=float(alpha), prec=_PREC[PRECISION]))
     return out
 
 
@@ -64,7 +98,7 @@ def bmm_nn(a, b, out):
     assert a.stride(3) == 1 and b.stride(3) == 1 and out.stride(3) == 1
     _run(_desc(A=_p(a), B=_p(b), C=_p(out), M=M, N=N, K=K, lda=a.stride(2), ldb=b.stride(2), ldc=out.stride(2), b_kn=1,
                batch0=Z0, batch1=Z1, a_bs0=a.stride(0), a_bs1=a.stride(1), b_bs0=b.stride(0), b_bs1=b.stride(1),
-               c_bs0=out.stride(0), c_bs1=out.stride(1)))
+               c_bs0=out.stride(0), c_bs1=out.stride(1), prec=_PREC[PRECISION]))
     return out
 
 
@@ -105,7 +139,7 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
                conv_bstride=x.stride(0), M=B * Ho * Wo, N=Cout,
                K=ksize * ksize * cin, lda=ld_in, ldb=wp.shape[1], ldc=ldc, act=ACT[act], relu_in=int(relu_in),
                conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride, conv_pad=pad, conv_h=H, conv_w=W,
-               conv_ho=Ho, conv_wo=Wo))
+               conv_ho=Ho, conv_wo=Wo, **_weight_args(wp, ksize * ksize * cin)))
     return out
 
 
@@ -116,7 +150,7 @@ def conv_transpose2d(x, wp, bias_tiled, r):
     Cout = wp.shape[0] // (r * r)
     out = torch.empty(B, H * r, W * r, Cout, dtype=torch.float32, device=x.device)
     _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin, lda=Cin, ldb=Cin,
-               ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W))
+               ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W, **_weight_args(wp, Cin)))
     return out
 
 

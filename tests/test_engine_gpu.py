@@ -8,6 +8,17 @@ gpu = pytest.mark.gpu
 TOL = 2e-4  # fp32 products/accumulation on both sides; differences are summation order only
 
 
+@pytest.fixture(autouse=True, params=["f32", "f16x3"])
+def engine_precision(request):
+    """Every engine test runs in both arithmetic modes of pp_gemm (same tolerance: f16x3 keeps 22 operand bits)."""
+    from picopose_amd import ops
+
+    old = ops.PRECISION
+    ops.PRECISION = request.param
+    yield request.param
+    ops.PRECISION = old
+
+
 def _close(a, b, tol=TOL):
     a, b = a.cpu(), b.cpu()
     scale = max(1.0, float(b.abs().max()))
