@@ -170,12 +170,18 @@ typedef struct PpGemmDesc {
     const void* B_hi;      /* optional pre-split weights for PP_PREC_F16X3: fp16 [N][ldb], hi term    */
     const void* B_lo;      /* ... lo term (pp_split_f16x3)                                            */
     float b_scale;         /* power-of-two scale the pre-split weights were multiplied by             */
+    const void* A_hi;      /* optional pre-split activation operand (pp_split_activation): fp16 planes */
+    const void* A_lo;      /* indexed like A (dense [M][lda] / NHWC image); then A may be NULL         */
 } PpGemmDesc;
 
 int pp_gemm(const PpGemmDesc* desc, void* stream);
 /* Split n fp32 weights once at load time: scale[0] = 2^k with max|scale*w| in [512,1024) (device float),
  * hi = f16(scale*w), lo = f16(scale*w - hi). */
 int pp_split_f16x3(const float* w, long long n, void* hi, void* lo, float* scale, void* stream);
+/* Split an activation tensor x (B, P, C) fp32 (batch / row strides in floats, channels contiguous) once into
+ * contiguous fp16 planes hi, lo (B*P, C) for PP_PREC_F16X3 (fixed activation scale 4; optional ReLU first). */
+int pp_split_activation(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu,
+                        void* hi, void* lo, void* stream);
 
 /* nn.LayerNorm(C, eps) over rows of a [rows][C] matrix. */
 int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps,

@@ -506,6 +506,198 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const PpGemmDesc d
 }
 
 // ---------------------------------------------------------------------------
+// f16x3 with BOTH operands pre-split: the activation operand is split once by pp_split_activation
+// (instead of by every column-tile workgroup and, for a 3x3 convolution, nine times per element), so this
+// kernel has no conversion work at all: 16-byte loads of the hi/lo planes (8 k per lane), ds_write_b128 into
+// the 80-byte-stride LDS planes, 3 MFMAs per fragment pair.  A planes are indexed exactly like the fp32
+// operand would be (dense [M][lda] or an NHWC image for the implicit im2col); Cin % 8 == 0.
+// ---------------------------------------------------------------------------
+template <int NJ, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc d) {
+    constexpr int BN = 64 * NJ, LDH = 40;
+    __shared__ __attribute__((aligned(16))) _Float16 Ah[BM * LDH], Al[BM * LDH], Bh[BN * LDH], Bl[BN * LDH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const _Float16* Ahg = (const _Float16*)d.A_hi;
+    const _Float16* Alg = (const _Float16*)d.A_lo;
+    const _Float16* Bhg = (const _Float16*)d.B_hi;
+    const _Float16* Blg = (const _Float16*)d.B_lo;
+    float* C = d.C;
+    const float* R = d.residual;
+    const float* R2 = d.residual2;
+
+    // this thread's slots: rows r0 + 64 j, 8 consecutive k starting at k8
+    const int r0 = tid >> 2, k8 = (tid & 3) * 8;
+    int aoy[2], aox[2], abase[2];
+    bool arow_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + r0 + 64 * j;
+        arow_ok[j] = m < d.M;
+        aoy[j] = aox[j] = 0;
+        abase[j] = arow_ok[j] ? m * d.lda : 0;
+        if (d.conv_kh != 0 && arow_ok[j]) {
+            const int per = d.conv_ho * d.conv_wo;
+            const int bi = m / per, r = m - bi * per;
+            aoy[j] = (r / d.conv_wo) * d.conv_stride - d.conv_pad;
+            aox[j] = (r % d.conv_wo) * d.conv_stride - d.conv_pad;
+            abase[j] = (int)((long long)bi * d.conv_bstride + ((long long)aoy[j] * d.conv_w + aox[j]) * d.lda);
+        }
+    }
+    int tky = 0, tkx = 0, tci = 0;  // tap and channel of k = k0 + k8 (conv), advanced by BK per step
+    if (d.conv_kh != 0) {
+        const int tap = k8 / d.conv_cin;
+        tci = k8 - tap * d.conv_cin;
+        tky = tap / d.conv_kw;
+        tkx = tap - tky * d.conv_kw;
+    }
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    h8 rah[2], ral[2], rbh[NJ], rbl[NJ];
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+        const int k = k0 + k8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            rah[j] = zero8;
+            ral[j] = zero8;
+            if (arow_ok[j] && k < d.K) {
+                if (d.conv_kh == 0) {
+                    rah[j] = *(const h8*)(Ahg + (size_t)abase[j] + k);
+                    ral[j] = *(const h8*)(Alg + (size_t)abase[j] + k);
+                } else {
+                    const int iy = aoy[j] + tky, ix = aox[j] + tkx;
+                    if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) {
+                        const long long off = (long long)abase[j] + (tky * d.conv_w + tkx) * d.lda + tci;
+                        rah[j] = *(const h8*)(Ahg + off);
+                        ral[j] = *(const h8*)(Alg + off);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + r0 + 64 * j;
+            rbh[j] = zero8;
+            rbl[j] = zero8;
+            if (n < d.N && k < d.K) {
+                rbh[j] = *(const h8*)(Bhg + (size_t)n * d.ldb + k);
+                rbl[j] = *(const h8*)(Blg + (size_t)n * d.ldb + k);
+            }
+        }
+        if (d.conv_kh != 0) {
+            tci += BK;
+            while (tci >= d.conv_cin) {
+                tci -= d.conv_cin;
+                if (++tkx == d.conv_kw) {
+                    tkx = 0;
+                    ++tky;
+                }
+            }
+        }
+    };
+
+    const int nk = (d.K + BK - 1) / BK;
+    fetch(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *(h8*)(Ah + (r0 + 64 * j) * LDH + k8) = rah[j];
+            *(h8*)(Al + (r0 + 64 * j) * LDH + k8) = ral[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            *(h8*)(Bh + (r0 + 64 * j) * LDH + k8) = rbh[j];
+            *(h8*)(Bl + (r0 + 64 * j) * LDH + k8) = rbl[j];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) fetch((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8 ah[2], al[2], bh[NJ], bl[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *(const h8*)(Ah + (wr * 64 + i * 32 + l31) * LDH + ks * 16 + lh * 8);
+                al[i] = *(const h8*)(Al + (wr * 64 + i * 32 + l31) * LDH + ks * 16 + lh * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                bh[j] = *(const h8*)(Bh + (wc * 32 * NJ + j * 32 + l31) * LDH + ks * 16 + lh * 8);
+                bl[j] = *(const h8*)(Bl + (wc * 32 * NJ + j * 32 + l31) * LDH + ks * 16 + lh * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    const float descale = d.alpha / (A_SCALE * d.b_scale);
+    // ---- epilogue: out = residual + residual2 + gamma * act(alpha * acc + bias)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wc * 32 * NJ + j * 32 + l31;
+        if (n >= d.N) continue;
+        const float bias = d.bias ? d.bias[n] : 0.f;
+        const float gamma = d.gamma ? d.gamma[n] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m >= d.M) continue;
+                float v = act_apply(acc[i][j][e] * descale + bias, d.act) * gamma;
+                size_t off;
+                if (d.shuffle_r == 0) {
+                    off = (size_t)m * d.ldc + n;
+                } else {
+                    const int r = d.shuffle_r, cout = d.N / (r * r);
+                    const int sub = n / cout, co = n - sub * cout, dy = sub / r, dx = sub - dy * r;
+                    const int per = d.shuffle_h * d.shuffle_w;
+                    const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
+                    off = (((size_t)b * d.shuffle_h * r + y * r + dy) * (d.shuffle_w * r) + x * r + dx) * d.ldc + co;
+                }
+                if (R) v += R[off];
+                if (R2) v += R2[off];
+                C[off] = v;
+            }
+    }
+}
+
+// activation pre-split: x (B, P, C) fp32 with batch / row strides -> contiguous hi, lo planes (B*P, C)
+__global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict__ x, long long bstride, int P, int ld,
+                                                        int C, long long total4, int relu, _Float16* __restrict__ hi,
+                                                        _Float16* __restrict__ lo) {
+    const int c4n = C >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long row = i / c4n;
+        const int c = (int)(i - row * c4n) * 4;
+        const long long b = row / P, p = row - b * P;
+        f4 v = *(const f4*)(x + b * bstride + p * ld + c);
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        }
+        h4 hh, ll;
+        split_f16x4(v, A_SCALE, hh, ll);
+        *(h4*)(hi + row * C + c) = hh;
+        *(h4*)(lo + row * C + c) = ll;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Row-wise kernels around the GEMMs
 // ---------------------------------------------------------------------------
 
@@ -680,8 +872,20 @@ int pp_split_f16x3(const float* w, long long n, void* hi, void* lo, float* scale
     return pp_last_launch();
 }
 
+int pp_split_activation(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu, void* hi,
+                        void* lo, void* stream) {
+    if (!x || !hi || !lo || B <= 0 || P <= 0 || C <= 0 || C % 4 != 0 || row_stride % 4 != 0 || batch_stride % 4 != 0 ||
+        ((uintptr_t)x % 16) != 0)
+        return PP_EINVAL;
+    const long long total4 = (long long)B * P * (C / 4);
+    const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, batch_stride, P, row_stride, C,
+                       total4, relu, (_Float16*)hi, (_Float16*)lo);
+    return pp_last_launch();
+}
+
 int pp_gemm(const PpGemmDesc* desc, void* stream) {
-    if (!desc || !desc->A || !desc->B || !desc->C) return PP_EINVAL;
+    if (!desc || (!desc->A && !desc->A_hi) || !desc->B || !desc->C) return PP_EINVAL;
     PpGemmDesc d = *desc;
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch0 <= 0 || d.batch1 <= 0) return PP_EINVAL;
     if (d.act < 0 || d.act > PP_ACT_TANH) return PP_EINVAL;
@@ -698,7 +902,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         if (imgs * d.conv_bstride >= (1LL << 31)) return PP_EINVAL;
     }
     // 16-byte vector loads need aligned rows: K-contiguous operands with lda/ldb/Cin % 4 == 0
-    bool vec = ((uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.B % 16 == 0) && d.lda % 4 == 0 &&
+    bool vec = (d.A_hi || (uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.B % 16 == 0) && d.lda % 4 == 0 &&
                (d.b_kn || d.ldb % 4 == 0) && d.a_bs0 % 4 == 0 && d.a_bs1 % 4 == 0 && d.b_bs0 % 4 == 0 &&
                d.b_bs1 % 4 == 0;
     if (d.conv_kh != 0 && (d.conv_cin % 4 != 0 || d.conv_bstride % 4 != 0)) vec = false;
@@ -710,12 +914,25 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     const long long rows = (d.M + BM - 1) / BM, z = (long long)d.batch0 * d.batch1;
     hipStream_t st = (hipStream_t)stream;
     const bool split = d.prec == PP_PREC_F16X3 && vec;  // unaligned (tiny) layers stay on the fp32 kernel
+    const bool asplit = d.A_hi != nullptr;
+    if (asplit) {
+        const bool ok = d.A_lo && d.B_hi && d.B_lo && d.prec == PP_PREC_F16X3 && z == 1 && !d.b_kn && !d.relu_in &&
+                        d.K % 8 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.b_scale > 0.f &&
+                        (d.conv_kh == 0 || (d.conv_cin % 8 == 0 && d.conv_bstride % 8 == 0)) &&
+                        ((uintptr_t)d.A_hi % 16 == 0) && ((uintptr_t)d.A_lo % 16 == 0) && ((uintptr_t)d.B_hi % 16 == 0) &&
+                        ((uintptr_t)d.B_lo % 16 == 0) && (long long)d.M * d.lda < (1LL << 31);
+        if (!ok) return PP_EINVAL;
+    }
     if (d.B_hi && (!d.B_lo || d.b_kn || d.ldb % 4 != 0 || d.K % 4 != 0 || z != 1 || !(d.b_scale > 0.f))) return PP_EINVAL;
     if (d.B_hi && !split) d.B_hi = d.B_lo = nullptr;  // unaligned layer: the fp32 kernel reads d.B
     auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU
         const bool narrow = cfg == 2;
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
-        if (split) {
+        if (asplit) {
+            if (narrow) hipLaunchKernelGGL((gemm_f16x3s_kernel<1, 4>), grid, dim3(256), 0, st, d);
+            else if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3s_kernel<2, 2>), grid, dim3(256), 0, st, d);
+            else hipLaunchKernelGGL((gemm_f16x3s_kernel<2, 3>), grid, dim3(256), 0, st, d);
+        } else if (split) {
             if (d.B_hi) {
                 if (narrow) hipLaunchKernelGGL((gemm_f16x3_kernel<1, 4, true>), grid, dim3(256), 0, st, d);
                 else if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, true>), grid, dim3(256), 0, st, d);
@@ -747,7 +964,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         static std::unordered_map<std::string, int> best;
         char key[160];
         snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%lld.%d.%d.%d.%d.%d.%d", d.M, d.N, d.K, (int)vec, d.b_kn, z, d.conv_kh,
-                 d.conv_cin, d.conv_stride, d.conv_h, d.shuffle_r, (int)split + 2 * (d.B_hi != nullptr));
+                 d.conv_cin, d.conv_stride, d.conv_h, d.shuffle_r, (int)split + 2 * (d.B_hi != nullptr) + 4 * (int)asplit);
         std::lock_guard<std::mutex> lock(mu);
         auto it = best.find(key);
         if (it == best.end()) {

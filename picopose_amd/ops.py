@@ -38,6 +38,20 @@ def split_weight(w):
     return hit[0], hit[1], hit[2]
 
 
+def split_activation(x, B, P, C, batch_stride, row_stride, relu=False):
+    """Pre-split an activation operand (B, P, C) into contiguous fp16 planes (B*P, C) for the f16x3 engine."""
+    hi = torch.empty(B * P, C, dtype=torch.float16, device=x.device)
+    lo = torch.empty(B * P, C, dtype=torch.float16, device=x.device)
+    _lib.check(_lib.lib().pp_split_activation(_p(x), batch_stride, B, P, row_stride, C, int(relu), _p(hi), _p(lo),
+                                              _lib.stream_ptr()), "pp_split_activation")
+    return hi, lo
+
+
+def _can_presplit(x, K, C, *strides):
+    return (PRECISION == "f16x3" and K % 8 == 0 and C % 8 == 0 and x.data_ptr() % 16 == 0
+            and all(st % 4 == 0 for st in strides))
+
+
 def _weight_args(w, K):
     """desc fields for a weight operand under the current precision (pre-split planes when it is aligned)."""
     if PRECISION == "f16x3" and K % 4 == 0 and w.data_ptr() % 16 == 0:
@@ -73,8 +87,14 @@ def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, 
     assert out.stride(1) == 1
     if residual is not None:
         assert residual.shape == out.shape and residual.stride() == out.stride()
+    wargs = _weight_args(weight, K)
+    if "B_hi" in wargs and N > 64 and _can_presplit(x, K, K, x.stride(0)) and M * K < 2 ** 31:
+        hi, lo = split_activation(x, 1, M, K, 0, x.stride(0), relu=relu_in)      # every column tile reuses the split
+        _run(_desc(A_hi=_p(hi), A_lo=_p(lo), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual),
+                   M=M, N=N, K=K, lda=K, ldb=K, ldc=out.stride(0), act=ACT[act], **wargs))
+        return out
     _run(_desc(A=_p(x), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual), M=M, N=N, K=K,
-               lda=x.stride(0), ldb=K, ldc=out.stride(0), act=ACT[act], relu_in=int(relu_in), **_weight_args(weight, K)))
+               lda=x.stride(0), ldb=K, ldc=out.stride(0), act=ACT[act], relu_in=int(relu_in), **wargs))
     return out
 
 
@@ -135,11 +155,20 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     for r_ in (residual, residual2):
         if r_ is not None:
             assert r_.stride() == out.stride()
+    wargs = _weight_args(wp, ksize * ksize * cin)
+    if ("B_hi" in wargs and (Cout > 64 or ksize > 1) and _can_presplit(x, ksize * ksize * cin, cin, ld_in, x.stride(0))
+            and B * H * W * cin < 2 ** 31):
+        hi, lo = split_activation(x, B, H * W, cin, x.stride(0), ld_in, relu=relu_in)  # once, not per tap / column tile
+        _run(_desc(A_hi=_p(hi), A_lo=_p(lo), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual),
+                   residual2=_p(residual2), conv_bstride=H * W * cin, M=B * Ho * Wo, N=Cout, K=ksize * ksize * cin, lda=cin,
+                   ldb=wp.shape[1], ldc=ldc, act=ACT[act], conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride,
+                   conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo, **wargs))
+        return out
     _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual), residual2=_p(residual2),
                conv_bstride=x.stride(0), M=B * Ho * Wo, N=Cout,
                K=ksize * ksize * cin, lda=ld_in, ldb=wp.shape[1], ldc=ldc, act=ACT[act], relu_in=int(relu_in),
                conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride, conv_pad=pad, conv_h=H, conv_w=W,
-               conv_ho=Ho, conv_wo=Wo, **_weight_args(wp, ksize * ksize * cin)))
+               conv_ho=Ho, conv_wo=Wo, **wargs))
     return out
 
 
@@ -149,8 +178,14 @@ def conv_transpose2d(x, wp, bias_tiled, r):
     assert x.is_contiguous()
     Cout = wp.shape[0] // (r * r)
     out = torch.empty(B, H * r, W * r, Cout, dtype=torch.float32, device=x.device)
+    wargs = _weight_args(wp, Cin)
+    if "B_hi" in wargs and _can_presplit(x, Cin, Cin) and x.numel() < 2 ** 31:
+        hi, lo = split_activation(x, 1, B * H * W, Cin, 0, Cin)
+        _run(_desc(A_hi=_p(hi), A_lo=_p(lo), B=_p(wp), C=_p(out), bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin,
+                   lda=Cin, ldb=Cin, ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W, **wargs))
+        return out
     _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin, lda=Cin, ldb=Cin,
-               ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W, **_weight_args(wp, Cin)))
+               ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W, **wargs))
     return out
 
 
