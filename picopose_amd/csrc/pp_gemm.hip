@@ -508,14 +508,21 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const PpGemmDesc d
 // ---------------------------------------------------------------------------
 // f16x3 with BOTH operands pre-split: the activation operand is split once by pp_split_activation
 // (instead of by every column-tile workgroup and, for a 3x3 convolution, nine times per element), so this
-// kernel has no conversion work at all: 16-byte loads of the hi/lo planes (8 k per lane), ds_write_b128 into
-// the 80-byte-stride LDS planes, 3 MFMAs per fragment pair.  A planes are indexed exactly like the fp32
-// operand would be (dense [M][lda] or an NHWC image for the implicit im2col); Cin % 8 == 0.
+// kernel has no conversion work at all.  A planes are indexed exactly like the fp32 operand would be (dense
+// [M][lda] or an NHWC image for the implicit im2col); Cin % 8 == 0.
+//   - 16-byte loads of the hi/lo planes (8 k per lane), next K tile prefetched into registers;
+//   - LDS: four planes of [rows][32 k] halfs (64-byte rows, no padding), double buffered; the 16-byte chunk c
+//     of row r sits at chunk c ^ ((r >> 2) & 3), which makes both the ds_write_b128 of a tile and the
+//     ds_read_b128 of the MFMA fragments bank-conflict free;
+//   - one barrier per K tile: the stores of tile k+1 overlap the MFMAs of tile k;
+//   - 3 x v_mfma_f32_32x32x16_f16 per fragment pair.
 // ---------------------------------------------------------------------------
 template <int NJ, int OCC>
 __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc d) {
-    constexpr int BN = 64 * NJ, LDH = 40;
-    __shared__ __attribute__((aligned(16))) _Float16 Ah[BM * LDH], Al[BM * LDH], Bh[BN * LDH], Bl[BN * LDH];
+    constexpr int BN = 64 * NJ;
+    constexpr int PLANE_A = BM * 32, PLANE_B = BN * 32;           // halfs per plane
+    constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;              // halfs per stage
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -523,34 +530,55 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
     const _Float16* Alg = (const _Float16*)d.A_lo;
     const _Float16* Bhg = (const _Float16*)d.B_hi;
     const _Float16* Blg = (const _Float16*)d.B_lo;
-    float* C = d.C;
-    const float* R = d.residual;
-    const float* R2 = d.residual2;
 
-    // this thread's slots: rows r0 + 64 j, 8 consecutive k starting at k8
+    // this thread's slots: rows r0 + 64 j, chunk (tid & 3) = 8 consecutive k starting at k8
     const int r0 = tid >> 2, k8 = (tid & 3) * 8;
-    int aoy[2], aox[2], abase[2];
+    const int wchunk = ((tid & 3) ^ ((r0 >> 2) & 3)) * 8;       // swizzled chunk position (halfs) of the stores
+    int aoy[2], aox[2];
+    long long abase[2];
     bool arow_ok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = m0 + r0 + 64 * j;
         arow_ok[j] = m < d.M;
         aoy[j] = aox[j] = 0;
-        abase[j] = arow_ok[j] ? m * d.lda : 0;
+        abase[j] = arow_ok[j] ? (long long)m * d.lda : 0;
         if (d.conv_kh != 0 && arow_ok[j]) {
             const int per = d.conv_ho * d.conv_wo;
             const int bi = m / per, r = m - bi * per;
             aoy[j] = (r / d.conv_wo) * d.conv_stride - d.conv_pad;
             aox[j] = (r % d.conv_wo) * d.conv_stride - d.conv_pad;
-            abase[j] = (int)((long long)bi * d.conv_bstride + ((long long)aoy[j] * d.conv_w + aox[j]) * d.lda);
+            abase[j] = (long long)bi * d.conv_bstride + ((long long)aoy[j] * d.conv_w + aox[j]) * d.lda;
         }
     }
-    int tky = 0, tkx = 0, tci = 0;  // tap and channel of k = k0 + k8 (conv), advanced by BK per step
+    // conv: tap (tky, tkx) and channel tci of k = k0 + k8; offsets/validity are refreshed only when the tap moves
+    int tky = 0, tkx = 0, tci = 0;
+    long long aoff[2] = {abase[0] + k8, abase[1] + k8};
+    bool aval[2] = {arow_ok[0], arow_ok[1]};
+    auto refresh_tap = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int iy = aoy[j] + tky, ix = aox[j] + tkx;
+            aval[j] = arow_ok[j] && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w;
+            aoff[j] = abase[j] + (long long)(tky * d.conv_w + tkx) * d.lda + tci;
+        }
+    };
     if (d.conv_kh != 0) {
         const int tap = k8 / d.conv_cin;
         tci = k8 - tap * d.conv_cin;
         tky = tap / d.conv_kw;
         tkx = tap - tky * d.conv_kw;
+        refresh_tap();
+    }
+    const _Float16* bph[NJ];
+    const _Float16* bpl[NJ];
+    bool bval[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + r0 + 64 * j;
+        bval[j] = n < d.N;
+        bph[j] = Bhg + (bval[j] ? (size_t)n * d.ldb : 0) + k8;
+        bpl[j] = Blg + (bval[j] ? (size_t)n * d.ldb : 0) + k8;
     }
 
     f32x16 acc[2][NJ];
@@ -563,76 +591,87 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
 
     h8 rah[2], ral[2], rbh[NJ], rbl[NJ];
     const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto fetch = [&](int k0) __attribute__((always_inline)) {
-        const int k = k0 + k8;
+    int kcur = k8;  // k of this thread's slot in the tile being fetched
+    auto fetch = [&]() __attribute__((always_inline)) {
+        const bool kin = kcur < d.K;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             rah[j] = zero8;
             ral[j] = zero8;
-            if (arow_ok[j] && k < d.K) {
-                if (d.conv_kh == 0) {
-                    rah[j] = *(const h8*)(Ahg + (size_t)abase[j] + k);
-                    ral[j] = *(const h8*)(Alg + (size_t)abase[j] + k);
-                } else {
-                    const int iy = aoy[j] + tky, ix = aox[j] + tkx;
-                    if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) {
-                        const long long off = (long long)abase[j] + (tky * d.conv_w + tkx) * d.lda + tci;
-                        rah[j] = *(const h8*)(Ahg + off);
-                        ral[j] = *(const h8*)(Alg + off);
-                    }
-                }
+            if (aval[j] && kin) {
+                rah[j] = *(const h8*)(Ahg + aoff[j]);
+                ral[j] = *(const h8*)(Alg + aoff[j]);
             }
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + r0 + 64 * j;
             rbh[j] = zero8;
             rbl[j] = zero8;
-            if (n < d.N && k < d.K) {
-                rbh[j] = *(const h8*)(Bhg + (size_t)n * d.ldb + k);
-                rbl[j] = *(const h8*)(Blg + (size_t)n * d.ldb + k);
+            if (bval[j] && kin) {
+                rbh[j] = *(const h8*)(bph[j]);
+                rbl[j] = *(const h8*)(bpl[j]);
+            }
+            bph[j] += BK;
+            bpl[j] += BK;
+        }
+        kcur += BK;
+        if (d.conv_kh == 0) {
+            aoff[0] += BK;
+            aoff[1] += BK;
+        } else {
+            tci += BK;
+            if (tci >= d.conv_cin) {  // the tap moves (for Cin % 32 == 0: in every lane at once)
+                while (tci >= d.conv_cin) {
+                    tci -= d.conv_cin;
+                    if (++tkx == d.conv_kw) {
+                        tkx = 0;
+                        ++tky;
+                    }
+                }
+                refresh_tap();
+            } else {
+                aoff[0] += BK;
+                aoff[1] += BK;
             }
         }
-        if (d.conv_kh != 0) {
-            tci += BK;
-            while (tci >= d.conv_cin) {
-                tci -= d.conv_cin;
-                if (++tkx == d.conv_kw) {
-                    tkx = 0;
-                    ++tky;
-                }
-            }
+    };
+    auto stash = [&](int buf) __attribute__((always_inline)) {
+        _Float16* st = lds + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *(h8*)(st + (r0 + 64 * j) * 32 + wchunk) = rah[j];
+            *(h8*)(st + PLANE_A + (r0 + 64 * j) * 32 + wchunk) = ral[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            *(h8*)(st + 2 * PLANE_A + (r0 + 64 * j) * 32 + wchunk) = rbh[j];
+            *(h8*)(st + 2 * PLANE_A + PLANE_B + (r0 + 64 * j) * 32 + wchunk) = rbl[j];
         }
     };
 
     const int nk = (d.K + BK - 1) / BK;
-    fetch(0);
+    const int sw = (l31 >> 2) & 3;  // read-side swizzle of this lane's rows
+    fetch();
+    stash(0);
+    if (nk > 1) fetch();
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *(h8*)(Ah + (r0 + 64 * j) * LDH + k8) = rah[j];
-            *(h8*)(Al + (r0 + 64 * j) * LDH + k8) = ral[j];
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            *(h8*)(Bh + (r0 + 64 * j) * LDH + k8) = rbh[j];
-            *(h8*)(Bl + (r0 + 64 * j) * LDH + k8) = rbl[j];
-        }
-        __syncthreads();
-        if (kt + 1 < nk) fetch((kt + 1) * BK);
+        const _Float16* st = lds + (kt & 1) * STAGE;
+        if (kt + 1 < nk) stash((kt + 1) & 1);  // buffer (kt+1)&1 was last read before the previous barrier
+        if (kt + 2 < nk) fetch();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ((ks * 2 + lh) ^ sw) * 8;
             h8 ah[2], al[2], bh[NJ], bl[NJ];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                ah[i] = *(const h8*)(Ah + (wr * 64 + i * 32 + l31) * LDH + ks * 16 + lh * 8);
-                al[i] = *(const h8*)(Al + (wr * 64 + i * 32 + l31) * LDH + ks * 16 + lh * 8);
+                ah[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * 32 + ch);
+                al[i] = *(const h8*)(st + PLANE_A + (wr * 64 + i * 32 + l31) * 32 + ch);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                bh[j] = *(const h8*)(Bh + (wc * 32 * NJ + j * 32 + l31) * LDH + ks * 16 + lh * 8);
-                bl[j] = *(const h8*)(Bl + (wc * 32 * NJ + j * 32 + l31) * LDH + ks * 16 + lh * 8);
+                bh[j] = *(const h8*)(st + 2 * PLANE_A + (wc * 32 * NJ + j * 32 + l31) * 32 + ch);
+                bl[j] = *(const h8*)(st + 2 * PLANE_A + PLANE_B + (wc * 32 * NJ + j * 32 + l31) * 32 + ch);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -643,7 +682,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
+        __syncthreads();
     }
+    float* C = d.C;
+    const float* R = d.residual;
+    const float* R2 = d.residual2;
     const float descale = d.alpha / (A_SCALE * d.b_scale);
     // ---- epilogue: out = residual + residual2 + gamma * act(alpha * acc + bias)
 #pragma unroll
@@ -920,7 +963,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                         d.K % 8 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.b_scale > 0.f &&
                         (d.conv_kh == 0 || (d.conv_cin % 8 == 0 && d.conv_bstride % 8 == 0)) &&
                         ((uintptr_t)d.A_hi % 16 == 0) && ((uintptr_t)d.A_lo % 16 == 0) && ((uintptr_t)d.B_hi % 16 == 0) &&
-                        ((uintptr_t)d.B_lo % 16 == 0) && (long long)d.M * d.lda < (1LL << 31);
+                        ((uintptr_t)d.B_lo % 16 == 0);
         if (!ok) return PP_EINVAL;
     }
     if (d.B_hi && (!d.B_lo || d.b_kn || d.ldb % 4 != 0 || d.K % 4 != 0 || z != 1 || !(d.b_scale > 0.f))) return PP_EINVAL;
@@ -929,9 +972,8 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         const bool narrow = cfg == 2;
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
         if (asplit) {
-            if (narrow) hipLaunchKernelGGL((gemm_f16x3s_kernel<1, 4>), grid, dim3(256), 0, st, d);
-            else if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3s_kernel<2, 2>), grid, dim3(256), 0, st, d);
-            else hipLaunchKernelGGL((gemm_f16x3s_kernel<2, 3>), grid, dim3(256), 0, st, d);
+            if (narrow) hipLaunchKernelGGL((gemm_f16x3s_kernel<1, 3>), grid, dim3(256), 0, st, d);
+            else hipLaunchKernelGGL((gemm_f16x3s_kernel<2, 2>), grid, dim3(256), 0, st, d);  // 64 KB LDS: 2 per CU
         } else if (split) {
             if (d.B_hi) {
                 if (narrow) hipLaunchKernelGGL((gemm_f16x3_kernel<1, 4, true>), grid, dim3(256), 0, st, d);
@@ -973,8 +1015,8 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             PP_CHECK_HIP(hipEventCreate(&e1));
             float bt = 1e30f;
             int bc = 0;
-            for (int c = 0; c < (vec ? 3 : 2); ++c) {
-                const int cand = vec ? c : (c == 0 ? 0 : 2);
+            for (int c = 0; c < ((vec && !asplit) ? 3 : 2); ++c) {
+                const int cand = (vec && !asplit) ? c : (c == 0 ? 0 : 2);
                 launch(cand);  // warm
                 (void)hipEventRecord(e0, st);
                 launch(cand);
