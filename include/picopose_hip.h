@@ -183,6 +183,10 @@ int pp_split_f16x3(const float* w, long long n, void* hi, void* lo, float* scale
 int pp_split_activation(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu,
                         void* hi, void* lo, void* stream);
 
+/* Fused multi-head self-attention (model/stage1/layers/attention.py:49-62): qkv (B,T,3,heads,64) as the qkv
+ * linear produces it -> out (B,T,heads*64) = softmax((q*scale) k^T) v per head; exact fp32 MFMA, flash style. */
+int pp_attention(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* stream);
+
 /* nn.LayerNorm(C, eps) over rows of a [rows][C] matrix. */
 int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps,
                  float* y, void* stream);

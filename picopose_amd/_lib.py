@@ -78,6 +78,7 @@ def lib():
         L.pp_gemm.argtypes = [c.POINTER(PpGemmDesc), vp]
         L.pp_split_f16x3.argtypes = [vp, c.c_longlong, vp, vp, vp, vp]
         L.pp_split_activation.argtypes = [vp, c.c_longlong, i32, i32, i32, i32, i32, vp, vp, vp]
+        L.pp_attention.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
         L.pp_layernorm.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp]
         L.pp_softmax_rows.argtypes = [vp, i32, i32, i32, vp]
         L.pp_groupnorm_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp]

@@ -949,6 +949,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                (d.b_kn || d.ldb % 4 == 0) && d.a_bs0 % 4 == 0 && d.a_bs1 % 4 == 0 && d.b_bs0 % 4 == 0 &&
                d.b_bs1 % 4 == 0;
     if (d.conv_kh != 0 && (d.conv_cin % 4 != 0 || d.conv_bstride % 4 != 0)) vec = false;
+    static const bool dbg = getenv("PP_GEMM_DEBUG") != nullptr;
+    if (dbg && !vec)
+        fprintf(stderr, "[pp_gemm] scalar path: M=%d N=%d K=%d lda=%d ldb=%d conv=%dx%d cin=%d b_kn=%d batch=%d A%%16=%d B%%16=%d\n", d.M, d.N, d.K, d.lda,
+                d.ldb, d.conv_kh, d.conv_kw, d.conv_cin, d.b_kn, d.batch0 * d.batch1, (int)((uintptr_t)d.A % 16), (int)((uintptr_t)d.B % 16));
     // block tile 128x128 (3 workgroups/CU) or 128x64 (4/CU): take the one with the shorter makespan
     // rounds(tiles / resident slots) x relative tile time — fixes the wave-quantisation tail of mid-size GEMMs
     int dev = 0, cus = 256;

@@ -122,12 +122,9 @@ class FeatureExtractor(Packed):
         outs = []
         for i, blk in enumerate(v.blocks):
             h = ops.layernorm(xs, blk.norm1.weight, blk.norm1.bias, 1e-6)
-            qkv = ops.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias).view(B, T, 3, heads, hd)
-            q, k, val = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))                  # (B,heads,T,hd) views
-            att = ops.softmax_rows_(ops.bmm_nt(q, k, alpha=hd ** -0.5))                       # (B,heads,T,T)
-            o = torch.empty(B, T, heads, hd, dtype=torch.float32, device=x.device)
-            ops.bmm_nn(att, val, o.permute(0, 2, 1, 3))
-            xs = ops.linear(o.view(B * T, C), blk.attn.proj.weight, blk.attn.proj.bias, gamma=blk.ls1.gamma, residual=xs)
+            qkv = ops.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias)                       # (B*T, 3*heads*hd)
+            o = ops.attention(qkv, B, T, heads, hd)                                           # fused QK^T/softmax/PV
+            xs = ops.linear(o, blk.attn.proj.weight, blk.attn.proj.bias, gamma=blk.ls1.gamma, residual=xs)
             h = ops.layernorm(xs, blk.norm2.weight, blk.norm2.bias, 1e-6)
             f = ops.linear(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act="gelu")
             xs = ops.linear(f, blk.mlp.fc2.weight, blk.mlp.fc2.bias, gamma=blk.ls2.gamma, residual=xs)

@@ -189,6 +189,14 @@ def conv_transpose2d(x, wp, bias_tiled, r):
     return out
 
 
+def attention(qkv, B, T, heads, hd):
+    """qkv (B*T, 3*heads*hd) from the qkv linear -> (B*T, heads*hd): softmax((q hd^-1/2) k^T) v per head, fused."""
+    assert qkv.is_contiguous()
+    out = torch.empty(B * T, heads * hd, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().pp_attention(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, _p(out), _lib.stream_ptr()), "pp_attention")
+    return out
+
+
 def layernorm(x, weight, bias, eps):
     rows, C = x.shape
     assert x.is_contiguous()

@@ -124,6 +124,8 @@ def test_attention_products_softmax_layernorm_groupnorm():
     o = torch.empty(B, T, h, hd, device="cuda")
     ops.bmm_nn(s, vd, o.permute(0, 2, 1, 3))
     _close(o.reshape(B, T, h * hd), ref)
+    fused = ops.attention(d.reshape(B * T, 3 * h * hd), B, T, h, hd)       # the fused kernel the ViT uses
+    _close(fused.reshape(B, T, h * hd), ref, 1e-5)
     x = torch.randn(500, 384, generator=g) * 3 + 1
     w, b = torch.randn(384, generator=g), torch.randn(384, generator=g)
     _close(ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6), F.layer_norm(x, (384,), w, b, 1e-6), 1e-5)
