@@ -91,7 +91,7 @@ class FeatureExtractor(Packed):
     def _pack(self):
         v = self.dinov2
         return {
-            "patch_w": ops.pack_conv_weight(v.patch_embed.proj.weight.float()),
+            "patch_w": ops.pack_conv_weight(v.patch_embed.proj.weight.float(), cin_pad=8),  # RGB + 5 zero channels
             "pos": {},
         }
 
@@ -114,7 +114,7 @@ class FeatureExtractor(Packed):
         C, heads = v.embed_dim, v.num_heads
         hd = C // heads
         pk = self.packed()
-        img = ops.to_nhwc(x)
+        img = ops.to_nhwc(x, c_pad=8)
         patches = ops.conv2d(img, pk["patch_w"], v.patch_embed.proj.bias, p, stride=p)        # (B,h0,w0,C)
         tok = ops.assemble_tokens(patches.view(B, h0 * w0, C), v.cls_token.reshape(C), self._pos(h0, w0))
         T = tok.shape[1]

@@ -137,7 +137,10 @@ class FlowDecoder(Packed):
             e = self.encoder[l]
             for name, net in (("corr", e.corr_net), ("flow", e.flow_net), ("out", e.out_net)):
                 for idx, sub in net.named_children():
-                    pk[f"e{l}_{name}{idx}"] = ops.pack_conv_weight(sub.conv.weight.float())
+                    w = sub.conv.weight.float()
+                    # 25(l+1)-channel correlation / 2-channel flow inputs are zero-padded to a multiple of 8 channels
+                    pad = -(-w.shape[1] // 8) * 8 if w.shape[1] % 8 else None
+                    pk[f"e{l}_{name}{idx}"] = ops.pack_conv_weight(w, cin_pad=pad)
             for name, head in (("fp", self.flow_pred[l]), ("mp", self.mask_pred[l])):
                 for idx, sub in head.layers.named_children():
                     pk[f"{name}{l}_{idx}"] = ops.pack_conv_weight(sub.conv.weight.float())
@@ -155,11 +158,14 @@ class FlowDecoder(Packed):
             fq = ops.conv2d(fq_in, pk[f"proj{l}"], pk[f"proj{l}_b"], 1)
             e = self.encoder[l]
             fr = ops.conv2d(fr_in, pk[f"proj{l}"], pk[f"proj{l}_b"], 1)   # contiguous copy for the lookup
-            corr = ops.corr_lookup(fr, fq, flow, l + 1, self.r)
+            ncorr = (l + 1) * (2 * self.r + 1) ** 2
+            corr = ops.corr_lookup(fr, fq, flow, l + 1, self.r, c_pad=-(-ncorr // 8) * 8)
             cf = torch.empty(B, H, W, 256, dtype=torch.float32, device=fr_in.device)  # [corr feat 192 | flow feat 64]
             c1 = ops.conv2d(corr, pk[f"e{l}_corr0"], getattr(e.corr_net, "0").conv.bias, 1, act="relu")
             ops.conv2d(c1, pk[f"e{l}_corr1"], getattr(e.corr_net, "1").conv.bias, 3, pad=1, act="relu", out=cf[..., 0:192])
-            f1 = ops.conv2d(flow, pk[f"e{l}_flow0"], getattr(e.flow_net, "0").conv.bias, 7, pad=3, act="relu")
+            flow8 = torch.zeros(B, H, W, 8, dtype=torch.float32, device=fr_in.device)
+            flow8[..., 0:2] = flow
+            f1 = ops.conv2d(flow8, pk[f"e{l}_flow0"], getattr(e.flow_net, "0").conv.bias, 7, pad=3, act="relu")
             ops.conv2d(f1, pk[f"e{l}_flow1"], getattr(e.flow_net, "1").conv.bias, 3, pad=1, act="relu", out=cf[..., 192:256])
             ops.conv2d(cf, pk[f"e{l}_out0"], getattr(e.out_net, "0").conv.bias, 3, pad=1, act="relu", out=X[..., 512:638])
             X[..., 0:256] = fr

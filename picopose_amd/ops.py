@@ -122,10 +122,16 @@ def bmm_nn(a, b, out):
     return out
 
 
-def pack_conv_weight(w):
-    """(Cout, Cin, KH, KW) torch layout -> (Cout, KH*KW*Cin) rows in the engine's k order."""
+def pack_conv_weight(w, cin_pad=None):
+    """(Cout, Cin, KH, KW) torch layout -> (Cout, KH*KW*Cin) rows in the engine's k order.  cin_pad > Cin appends
+    zero input channels (the matching activation buffer carries zero-filled pad channels), which keeps layers with
+    odd channel counts (3, 2, 25, 50, 75) on the vector-load / split-precision path."""
     co, ci, kh, kw = w.shape
-    return w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).contiguous()
+    w = w.permute(0, 2, 3, 1)
+    if cin_pad is not None and cin_pad > ci:
+        w = torch.cat([w, w.new_zeros(co, kh, kw, cin_pad - ci)], dim=3)
+        ci = cin_pad
+    return w.reshape(co, kh * kw * ci).contiguous()
 
 
 def pack_convT_weight(w, bias):
@@ -223,12 +229,13 @@ def groupnorm(x, weight, bias, groups, eps=1e-5, relu=False):
     return y
 
 
-def to_nhwc(x):
-    """(B,C,H,W) -> (B,H,W,C)."""
+def to_nhwc(x, c_pad=None):
+    """(B,C,H,W) -> (B,H,W,C); with c_pad > C the result has c_pad channels, the extra ones zero."""
     B, C, H, W = x.shape
     x = x.contiguous().float()
-    out = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().pp_transpose_batched(_p(x), 0, B, C, H * W, _p(out), 0, C, 0, _lib.stream_ptr()),
+    Cp = c_pad if c_pad and c_pad > C else C
+    out = (torch.zeros if Cp > C else torch.empty)(B, H, W, Cp, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().pp_transpose_batched(_p(x), 0, B, C, H * W, _p(out), 0, Cp, 0, _lib.stream_ptr()),
                "pp_transpose_batched")
     return out
 
@@ -272,18 +279,20 @@ def avgpool2(x):
     return out
 
 
-def corr_lookup(f1, f2, flow, levels, radius):
-    """Correlation pyramid + lookup, NHWC: (B,H,W,C) x2, flow (B,H,W,>=2) -> (B,H,W,levels*(2r+1)^2)."""
+def corr_lookup(f1, f2, flow, levels, radius, c_pad=None):
+    """Correlation pyramid + lookup, NHWC: (B,H,W,C) x2, flow (B,H,W,>=2) -> (B,H,W,levels*(2r+1)^2)
+    (c_pad: channel count of the result, zero-filled beyond the levels*(2r+1)^2 real channels)."""
     B, H, W, C = f1.shape
     assert f1.is_contiguous() and f2.is_contiguous() and flow.stride(3) == 1
     pyr = [f2]
     for _ in range(levels - 1):
         pyr.append(avgpool2(pyr[-1]))
     n = levels * (2 * radius + 1) ** 2
-    out = torch.empty(B, H, W, n, dtype=torch.float32, device=f1.device)
+    np_ = c_pad if c_pad and c_pad > n else n
+    out = (torch.zeros if np_ > n else torch.empty)(B, H, W, np_, dtype=torch.float32, device=f1.device)
     _lib.check(_lib.lib().pp_corr_lookup_nhwc(_p(f1), _p(pyr[0]), _p(pyr[1]) if levels > 1 else None,
                                               _p(pyr[2]) if levels > 2 else None, _p(flow), B, H, W, C, levels, radius,
-                                              flow.stride(2), _p(out), n, _lib.stream_ptr()), "pp_corr_lookup_nhwc")
+                                              flow.stride(2), _p(out), np_, _lib.stream_ptr()), "pp_corr_lookup_nhwc")
     return out
 
 
