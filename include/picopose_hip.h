@@ -172,6 +172,7 @@ typedef struct PpGemmDesc {
     float b_scale;         /* power-of-two scale the pre-split weights were multiplied by             */
     const void* A_hi;      /* optional pre-split activation operand (pp_split_activation): fp16 planes */
     const void* A_lo;      /* indexed like A (dense [M][lda] / NHWC image); then A may be NULL         */
+    long long a_plane_bytes, b_plane_bytes; /* filled in by pp_gemm (extent of the planes)            */
 } PpGemmDesc;
 
 int pp_gemm(const PpGemmDesc* desc, void* stream);

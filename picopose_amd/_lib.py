@@ -34,6 +34,7 @@ class PpGemmDesc(ctypes.Structure):
         ("conv_bstride", ctypes.c_longlong),
         ("shuffle_r", ctypes.c_int), ("shuffle_h", ctypes.c_int), ("shuffle_w", ctypes.c_int),
         ("prec", ctypes.c_int), ("B_hi", ctypes.c_void_p), ("B_lo", ctypes.c_void_p), ("b_scale", ctypes.c_float), ("A_hi", ctypes.c_void_p), ("A_lo", ctypes.c_void_p),
+        ("a_plane_bytes", ctypes.c_longlong), ("b_plane_bytes", ctypes.c_longlong),
     ]
 
 

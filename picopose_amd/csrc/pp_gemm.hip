@@ -35,6 +35,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BK = 32, LDT = 36;  // BN = 64 * NJ (template): 128x128 or 128x64 block tiles
 
@@ -526,10 +527,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const _Float16* Ahg = (const _Float16*)d.A_hi;
-    const _Float16* Alg = (const _Float16*)d.A_lo;
-    const _Float16* Bhg = (const _Float16*)d.B_hi;
-    const _Float16* Blg = (const _Float16*)d.B_lo;
+    // operand planes are read with raw buffer loads: an out-of-range offset (0xFFFFFFFF for the padded taps,
+    // the row / column / K tails) returns zeros, so the loads need neither branches nor selects
+    const __amdgpu_buffer_rsrc_t Ahr = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hi, 0, (int)d.a_plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Alr = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_lo, 0, (int)d.a_plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Bhr = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hi, 0, (int)d.b_plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Blr = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_lo, 0, (int)d.b_plane_bytes, 0x00020000);
 
     // this thread's slots: rows r0 + 64 j, chunk (tid & 3) = 8 consecutive k starting at k8
     const int r0 = tid >> 2, k8 = (tid & 3) * 8;
@@ -570,15 +573,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
         tkx = tap - tky * d.conv_kw;
         refresh_tap();
     }
-    const _Float16* bph[NJ];
-    const _Float16* bpl[NJ];
-    bool bval[NJ];
+    unsigned boff[NJ];  // byte offset of this thread's B slot (0xFFFFFFFF: column past N)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + r0 + 64 * j;
-        bval[j] = n < d.N;
-        bph[j] = Bhg + (bval[j] ? (size_t)n * d.ldb : 0) + k8;
-        bpl[j] = Blg + (bval[j] ? (size_t)n * d.ldb : 0) + k8;
+        boff[j] = n < d.N ? (unsigned)(((long long)n * d.ldb + k8) * 2) : 0xFFFFFFFFu;
     }
 
     f32x16 acc[2][NJ];
@@ -589,30 +588,26 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    h8 rah[2], ral[2], rbh[NJ], rbl[NJ];
-    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // three K tiles in flight in registers (a tile's MFMAs are ~1000 cycles, an L2/HBM round trip is longer)
+    struct Stage {
+        u4 ah[2], al[2], bh[NJ], bl[NJ];
+    };
+    Stage s0, s1, s2;
     int kcur = k8;  // k of this thread's slot in the tile being fetched
-    auto fetch = [&]() __attribute__((always_inline)) {
-        const bool kin = kcur < d.K;
+    auto fetch = [&](Stage& sg) __attribute__((always_inline)) {
+        const bool kin = kcur < d.K;  // tiles past the end read zeros (never consumed)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            rah[j] = zero8;
-            ral[j] = zero8;
-            if (aval[j] && kin) {
-                rah[j] = *(const h8*)(Ahg + aoff[j]);
-                ral[j] = *(const h8*)(Alg + aoff[j]);
-            }
+            const unsigned off = (aval[j] && kin) ? (unsigned)(aoff[j] * 2) : 0xFFFFFFFFu;
+            sg.ah[j] = __builtin_amdgcn_raw_buffer_load_b128(Ahr, off, 0, 0);
+            sg.al[j] = __builtin_amdgcn_raw_buffer_load_b128(Alr, off, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            rbh[j] = zero8;
-            rbl[j] = zero8;
-            if (bval[j] && kin) {
-                rbh[j] = *(const h8*)(bph[j]);
-                rbl[j] = *(const h8*)(bpl[j]);
-            }
-            bph[j] += BK;
-            bpl[j] += BK;
+            const unsigned off = kin ? boff[j] : 0xFFFFFFFFu;
+            sg.bh[j] = __builtin_amdgcn_raw_buffer_load_b128(Bhr, off, 0, 0);
+            sg.bl[j] = __builtin_amdgcn_raw_buffer_load_b128(Blr, off, 0, 0);
+            boff[j] = boff[j] == 0xFFFFFFFFu ? boff[j] : boff[j] + 2 * BK;
         }
         kcur += BK;
         if (d.conv_kh == 0) {
@@ -635,30 +630,24 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
             }
         }
     };
-    auto stash = [&](int buf) __attribute__((always_inline)) {
+    auto stash = [&](int buf, const Stage& sg) __attribute__((always_inline)) {
         _Float16* st = lds + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            *(h8*)(st + (r0 + 64 * j) * 32 + wchunk) = rah[j];
-            *(h8*)(st + PLANE_A + (r0 + 64 * j) * 32 + wchunk) = ral[j];
+            *(u4*)(st + (r0 + 64 * j) * 32 + wchunk) = sg.ah[j];
+            *(u4*)(st + PLANE_A + (r0 + 64 * j) * 32 + wchunk) = sg.al[j];
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            *(h8*)(st + 2 * PLANE_A + (r0 + 64 * j) * 32 + wchunk) = rbh[j];
-            *(h8*)(st + 2 * PLANE_A + PLANE_B + (r0 + 64 * j) * 32 + wchunk) = rbl[j];
+            *(u4*)(st + 2 * PLANE_A + (r0 + 64 * j) * 32 + wchunk) = sg.bh[j];
+            *(u4*)(st + 2 * PLANE_A + PLANE_B + (r0 + 64 * j) * 32 + wchunk) = sg.bl[j];
         }
     };
 
     const int nk = (d.K + BK - 1) / BK;
     const int sw = (l31 >> 2) & 3;  // read-side swizzle of this lane's rows
-    fetch();
-    stash(0);
-    if (nk > 1) fetch();
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const _Float16* st = lds + (kt & 1) * STAGE;
-        if (kt + 1 < nk) stash((kt + 1) & 1);  // buffer (kt+1)&1 was last read before the previous barrier
-        if (kt + 2 < nk) fetch();
+    auto mma = [&](int buf) __attribute__((always_inline)) {
+        const _Float16* st = lds + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int ch = ((ks * 2 + lh) ^ sw) * 8;
@@ -682,7 +671,32 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
+    };
+    // tile t lives in register stage t % 3; LDS buffer t & 1.  Per tile: publish tile t+1 into the other LDS
+    // buffer (last read before the previous barrier), refill its registers with tile t+4, MFMAs on tile t, barrier.
+    fetch(s0);       // tile 0
+    stash(0, s0);
+    fetch(s1);       // tile 1
+    fetch(s2);       // tile 2
+    fetch(s0);       // tile 3
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 3) {
+        stash((kt + 1) & 1, s1);
+        fetch(s1);   // tile kt + 4
+        mma(kt & 1);
         __syncthreads();
+        if (kt + 1 < nk) {
+            stash((kt + 2) & 1, s2);
+            fetch(s2);
+            mma((kt + 1) & 1);
+            __syncthreads();
+        }
+        if (kt + 2 < nk) {
+            stash((kt + 3) & 1, s0);
+            fetch(s0);
+            mma((kt + 2) & 1);
+            __syncthreads();
+        }
     }
     float* C = d.C;
     const float* R = d.residual;
@@ -969,6 +983,15 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                         ((uintptr_t)d.A_hi % 16 == 0) && ((uintptr_t)d.A_lo % 16 == 0) && ((uintptr_t)d.B_hi % 16 == 0) &&
                         ((uintptr_t)d.B_lo % 16 == 0);
         if (!ok) return PP_EINVAL;
+        // extents of the planes for the bounds-checked buffer loads (bytes, < 2 GiB)
+        const long long a_elems = d.conv_kh != 0
+            ? ((long long)((d.M + (long long)d.conv_ho * d.conv_wo - 1) / ((long long)d.conv_ho * d.conv_wo) - 1) * d.conv_bstride +
+               (long long)d.conv_h * d.conv_w * d.lda)
+            : (long long)(d.M - 1) * d.lda + d.K;
+        const long long b_elems = (long long)(d.N - 1) * d.ldb + d.K;
+        if (a_elems * 2 >= (1LL << 31) || b_elems * 2 >= (1LL << 31)) return PP_EINVAL;
+        d.a_plane_bytes = a_elems * 2;
+        d.b_plane_bytes = b_elems * 2;
     }
     if (d.B_hi && (!d.B_lo || d.b_kn || d.ldb % 4 != 0 || d.K % 4 != 0 || z != 1 || !(d.b_scale > 0.f))) return PP_EINVAL;
     if (d.B_hi && !split) d.B_hi = d.B_lo = nullptr;  // unaligned layer: the fp32 kernel reads d.B
