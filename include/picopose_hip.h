@@ -47,6 +47,13 @@ int pp_version(void);
  * returns the durations in ms.  pp_prof_enable(0) switches the hooks off. */
 int pp_prof_enable(int max_records);
 int pp_prof_collect(float* out_ms, int max_out, int* count);
+/* The same for the contraction engine: after pp_prof_gemm_enable(n) every pp_gemm launch (up to n; the
+ * autotuner's trial launches excluded) is bracketed by two hipEvents on its stream and its 2*M*N*K*batch flop
+ * count is kept.  pp_prof_gemm_collect sums durations (ms), flops and launches into 2-element arrays:
+ * [0] = launches of the pre-split f16x3 kernel (the dominant kernel of the full path), [1] = all other
+ * GEMM kernels.  pp_prof_gemm_enable(0) switches the hooks off. */
+int pp_prof_gemm_enable(int max_records);
+int pp_prof_gemm_collect(double* ms, double* flops, int* launches);
 
 /* ------------------------------------------------------------------------- *
  * Stage 1: template matching — utils/matching.py:29-69 (matching_templates)

@@ -19,6 +19,8 @@ int pp_version(void) { return 100; }
 }  // extern "C"
 static PpProf g_prof;
 PpProf* pp_prof_state() { return &g_prof; }  // internal (C++ linkage, hidden from the header)
+static PpGemmProf g_gemm_prof;
+PpGemmProf* pp_gemm_prof_state() { return &g_gemm_prof; }
 extern "C" {
 
 int pp_prof_enable(int max_records) {
@@ -45,6 +47,46 @@ int pp_prof_collect(float* out_ms, int max_out, int* count) {
             return PP_ELAUNCH;
     }
     *count = n;
+    p.count = 0;
+    return PP_OK;
+}
+
+int pp_prof_gemm_enable(int max_records) {
+    PpGemmProf& p = g_gemm_prof;
+    for (int i = 0; i < p.capacity * 2; ++i) (void)hipEventDestroy(p.ev[i]);
+    delete[] p.ev;
+    delete[] p.flops;
+    delete[] p.kind;
+    p.ev = nullptr;
+    p.flops = nullptr;
+    p.kind = nullptr;
+    p.capacity = p.count = 0;
+    if (max_records <= 0) return PP_OK;
+    p.ev = new hipEvent_t[2 * max_records];
+    p.flops = new double[max_records];
+    p.kind = new int[max_records];
+    for (int i = 0; i < 2 * max_records; ++i)
+        if (hipEventCreate(&p.ev[i]) != hipSuccess) return PP_ELAUNCH;
+    p.capacity = max_records;
+    return PP_OK;
+}
+
+int pp_prof_gemm_collect(double* ms, double* flops, int* launches) {
+    PpGemmProf& p = g_gemm_prof;
+    if (!ms || !flops || !launches) return PP_EINVAL;
+    for (int k = 0; k < 2; ++k) {
+        ms[k] = flops[k] = 0.0;
+        launches[k] = 0;
+    }
+    for (int i = 0; i < p.count; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(p.ev[2 * i + 1]) != hipSuccess) return PP_ELAUNCH;
+        if (hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]) != hipSuccess) return PP_ELAUNCH;
+        const int k = p.kind[i];
+        ms[k] += t;
+        flops[k] += p.flops[i];
+        launches[k]++;
+    }
     p.count = 0;
     return PP_OK;
 }

@@ -37,4 +37,15 @@ struct PpProfScope {
     }
 };
 
+// Same idea for the contraction engine (pp_gemm): one event pair + the launch's flop count per record;
+// kind 0 = gemm_f16x3s_kernel (both operands pre-split), 1 = the other GEMM kernels.
+struct PpGemmProf {
+    hipEvent_t* ev = nullptr;
+    double* flops = nullptr;
+    int* kind = nullptr;
+    int capacity = 0;
+    int count = 0;
+};
+PpGemmProf* pp_gemm_prof_state();
+
 #endif

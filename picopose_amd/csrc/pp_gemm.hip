@@ -733,6 +733,207 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
     }
 }
 
+// ---------------------------------------------------------------------------
+// f16x3, both operands pre-split, LARGE problems: 256x128 block tile, 8 waves (4 x 2, 64x64 each), one
+// workgroup per CU.  The operand tiles go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging
+// registers, no ds_write pass (the VGPR->LDS store path was the busiest unit of the register-staged kernel).
+//   - LDS ring of 3 stages x 48 KB (A hi/lo 256x32, B hi/lo 128x32 halfs; 64-byte rows); an LDS-DMA wave
+//     instruction fills 1 KB = 16 rows lane-linearly, so the bank swizzle (chunk c of row r at position
+//     c ^ ((r >> 2) & 3)) is applied to the per-lane SOURCE address;
+//   - two K tiles in flight across the barrier: counted `s_waitcnt vmcnt(6)` (6 DMA per wave per tile) retires
+//     tile t, the raw s_barrier publishes it (and proves tile t-1 is no longer read), then tile t+2 is issued
+//     into the stage tile t-1 occupied and the MFMAs of tile t run; one barrier per K tile;
+//   - padded taps / row, column and K tails: an out-of-range buffer offset makes the DMA write zeros;
+//   - workgroup ids are remapped so the column tiles of one row tile (which share the A rows) and neighbouring
+//     row tiles (3x3 halo) run on the same XCD and hit its L2.
+// ---------------------------------------------------------------------------
+constexpr int GBM = 256, GBN = 128;
+constexpr int G_PLANE_A = GBM * 32, G_PLANE_B = GBN * 32;      // halfs per plane
+constexpr int G_STAGE = 2 * G_PLANE_A + 2 * G_PLANE_B;         // 24576 halfs = 48 KB
+constexpr int G_STAGES = 3;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d, int gx, int gy) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
+    // XCD-aware (bijective) remap: ids that land on one XCD (id % 8) walk consecutive tiles
+    const int nwg = gx * gy, orig = blockIdx.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int m0 = (wg / gx) * GBM, n0 = (wg % gx) * GBN;
+    const __amdgpu_buffer_rsrc_t Ahr = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hi, 0, (int)d.a_plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Alr = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_lo, 0, (int)d.a_plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Bhr = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hi, 0, (int)d.b_plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Blr = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_lo, 0, (int)d.b_plane_bytes, 0x00020000);
+
+    // loader slots of this lane: A rows (q*8 + w)*16 + (lane >> 2), q = 0, 1; B row w*16 + (lane >> 2); LDS chunk
+    // position lane & 3 holds source chunk (lane & 3) ^ ((row >> 2) & 3) (the same for all three rows)
+    const int lr = lane >> 2;
+    const int k8 = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    int aoy[2], aox[2];
+    long long abase[2];
+    bool arow_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + (j * 8 + w) * 16 + lr;
+        arow_ok[j] = m < d.M;
+        aoy[j] = aox[j] = 0;
+        abase[j] = arow_ok[j] ? (long long)m * d.lda : 0;
+        if (d.conv_kh != 0 && arow_ok[j]) {
+            const int per = d.conv_ho * d.conv_wo;
+            const int bi = m / per, r = m - bi * per;
+            aoy[j] = (r / d.conv_wo) * d.conv_stride - d.conv_pad;
+            aox[j] = (r % d.conv_wo) * d.conv_stride - d.conv_pad;
+            abase[j] = (long long)bi * d.conv_bstride + ((long long)aoy[j] * d.conv_w + aox[j]) * d.lda;
+        }
+    }
+    int tky = 0, tkx = 0, tci = 0;
+    long long aoff[2] = {abase[0] + k8, abase[1] + k8};
+    bool aval[2] = {arow_ok[0], arow_ok[1]};
+    auto refresh_tap = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int iy = aoy[j] + tky, ix = aox[j] + tkx;
+            aval[j] = arow_ok[j] && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w;
+            aoff[j] = abase[j] + (long long)(tky * d.conv_w + tkx) * d.lda + tci;
+        }
+    };
+    if (d.conv_kh != 0) {
+        const int tap = k8 / d.conv_cin;
+        tci = k8 - tap * d.conv_cin;
+        tky = tap / d.conv_kw;
+        tkx = tap - tky * d.conv_kw;
+        refresh_tap();
+    }
+    const int nb = n0 + w * 16 + lr;
+    unsigned boff = nb < d.N ? (unsigned)(((long long)nb * d.ldb + k8) * 2) : 0xFFFFFFFFu;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int kcur = k8;
+    // issue the 6 LDS-DMA loads of the next K tile into ring stage `stage` (wave-uniform)
+    auto fetch = [&](int stage) __attribute__((always_inline)) {
+        _Float16* st = glds + stage * G_STAGE;
+        const bool kin = kcur < d.K;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned off = (aval[j] && kin) ? (unsigned)(aoff[j] * 2) : 0xFFFFFFFFu;
+            _Float16* dst = st + ((j * 8 + w) * 16) * 32;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Ahr, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Alr, (lds_ptr_t)(dst + G_PLANE_A), 16, off, 0, 0, 0);
+        }
+        {
+            const unsigned off = kin ? boff : 0xFFFFFFFFu;
+            _Float16* dst = st + 2 * G_PLANE_A + (w * 16) * 32;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Bhr, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Blr, (lds_ptr_t)(dst + G_PLANE_B), 16, off, 0, 0, 0);
+            boff = boff == 0xFFFFFFFFu ? boff : boff + 2 * BK;
+        }
+        kcur += BK;
+        if (d.conv_kh == 0) {
+            aoff[0] += BK;
+            aoff[1] += BK;
+        } else {
+            tci += BK;
+            if (tci >= d.conv_cin) {
+                while (tci >= d.conv_cin) {
+                    tci -= d.conv_cin;
+                    if (++tkx == d.conv_kw) {
+                        tkx = 0;
+                        ++tky;
+                    }
+                }
+                refresh_tap();
+            } else {
+                aoff[0] += BK;
+                aoff[1] += BK;
+            }
+        }
+    };
+    const int sw = (l31 >> 2) & 3;
+    auto mma = [&](int stage) __attribute__((always_inline)) {
+        const _Float16* st = glds + stage * G_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ((ks * 2 + lh) ^ sw) * 8;
+            h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * 32 + ch);
+                al[i] = *(const h8*)(st + G_PLANE_A + (wr * 64 + i * 32 + l31) * 32 + ch);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *(const h8*)(st + 2 * G_PLANE_A + (wc * 64 + j * 32 + l31) * 32 + ch);
+                bl[j] = *(const h8*)(st + 2 * G_PLANE_A + G_PLANE_B + (wc * 64 + j * 32 + l31) * 32 + ch);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    const int nk = (d.K + BK - 1) / BK;
+    fetch(0);  // tile 0
+    fetch(1);  // tile 1 (zeros if nk == 1)
+    int cur = 0, nxt = 2;  // ring stage of tile kt / of tile kt + 2
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's DMA of tile kt has landed once at most tile kt+1's 6 loads are outstanding; after the
+        // barrier so has every wave's, and nobody reads tile kt-1's stage (= nxt) any more
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        fetch(nxt);  // tile kt + 2 (tiles past the end: zeros, never read)
+        mma(cur);
+        cur = cur == G_STAGES - 1 ? 0 : cur + 1;
+        nxt = nxt == G_STAGES - 1 ? 0 : nxt + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS at exit
+
+    float* C = d.C;
+    const float* R = d.residual;
+    const float* R2 = d.residual2;
+    const float descale = d.alpha / (A_SCALE * d.b_scale);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wc * 64 + j * 32 + l31;
+        if (n >= d.N) continue;
+        const float bias = d.bias ? d.bias[n] : 0.f;
+        const float gamma = d.gamma ? d.gamma[n] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m >= d.M) continue;
+                float v = act_apply(acc[i][j][e] * descale + bias, d.act) * gamma;
+                size_t off;
+                if (d.shuffle_r == 0) {
+                    off = (size_t)m * d.ldc + n;
+                } else {
+                    const int r = d.shuffle_r, cout = d.N / (r * r);
+                    const int sub = n / cout, co = n - sub * cout, dy = sub / r, dx = sub - dy * r;
+                    const int per = d.shuffle_h * d.shuffle_w;
+                    const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
+                    off = (((size_t)b * d.shuffle_h * r + y * r + dy) * (d.shuffle_w * r) + x * r + dx) * d.ldc + co;
+                }
+                if (R) v += R[off];
+                if (R2) v += R2[off];
+                C[off] = v;
+            }
+    }
+}
+
 // activation pre-split: x (B, P, C) fp32 with batch / row strides -> contiguous hi, lo planes (B*P, C)
 __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict__ x, long long bstride, int P, int ld,
                                                         int C, long long total4, int relu, _Float16* __restrict__ hi,
@@ -995,10 +1196,18 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     }
     if (d.B_hi && (!d.B_lo || d.b_kn || d.ldb % 4 != 0 || d.K % 4 != 0 || z != 1 || !(d.b_scale > 0.f))) return PP_EINVAL;
     if (d.B_hi && !split) d.B_hi = d.B_lo = nullptr;  // unaligned layer: the fp32 kernel reads d.B
-    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU
+    static const bool big_ok = [] {
+        return hipFuncSetAttribute((const void*)gemm_f16x3g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   G_STAGES * G_STAGE * 2) == hipSuccess;
+    }();
+    if (!big_ok) return PP_ELAUNCH;
+    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA
         const bool narrow = cfg == 2;
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
-        if (asplit) {
+        if (asplit && cfg == 3) {
+            const int gx = (d.N + GBN - 1) / GBN, gy = (d.M + GBM - 1) / GBM;
+            hipLaunchKernelGGL(gemm_f16x3g_kernel, dim3(gx * gy), dim3(512), G_STAGES * G_STAGE * 2, st, d, gx, gy);
+        } else if (asplit) {
             if (narrow) hipLaunchKernelGGL((gemm_f16x3s_kernel<1, 3>), grid, dim3(256), 0, st, d);
             else hipLaunchKernelGGL((gemm_f16x3s_kernel<2, 2>), grid, dim3(256), 0, st, d);  // 64 KB LDS: 2 per CU
         } else if (split) {
@@ -1026,6 +1235,13 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     // and on K; it is measured once per problem shape (three timed launches of the same GEMM — idempotent
     // unless the output aliases a residual) and remembered.  PP_GEMM_AUTOTUNE=0 keeps the static choice.
     int cfg = d.N <= 64 ? 2 : 0;
+    if (const char* f = getenv("PP_GEMM_FORCE_CFG")) {  // tests: pin one kernel configuration (3 needs pre-split operands)
+        const int fc = atoi(f);
+        if (fc >= 0 && fc <= 3 && (fc != 3 || asplit) && (fc != 1 || !asplit)) {
+            launch(fc);
+            return pp_last_launch();
+        }
+    }
     const bool alias = d.residual == d.C || d.residual2 == d.C;
     static const bool tune = [] { const char* e = getenv("PP_GEMM_AUTOTUNE"); return !(e && e[0] == '0'); }();
     if (tune && !alias && d.N > 64) {
@@ -1042,8 +1258,11 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             PP_CHECK_HIP(hipEventCreate(&e1));
             float bt = 1e30f;
             int bc = 0;
-            for (int c = 0; c < ((vec && !asplit) ? 3 : 2); ++c) {
-                const int cand = (vec && !asplit) ? c : (c == 0 ? 0 : 2);
+            // pre-split operands: 128x128, 128x64 and (for problems that fill the chip with 256x128 tiles) the LDS-DMA kernel
+            const bool big = asplit && (long long)((d.M + GBM - 1) / GBM) * ((d.N + GBN - 1) / GBN) >= cus / 2;
+            for (int c = 0; c < ((vec || big) ? 3 : 2); ++c) {
+                const int cand = asplit ? (c == 0 ? 0 : c == 1 ? 2 : 3) : (vec ? c : (c == 0 ? 0 : 2));
+                if (cand == 3 && !big) continue;
                 launch(cand);  // warm
                 (void)hipEventRecord(e0, st);
                 launch(cand);
@@ -1063,7 +1282,16 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         }
         cfg = it->second;
     }
+    PpGemmProf* gp = pp_gemm_prof_state();
+    const bool rec = gp->capacity > 0 && gp->count < gp->capacity;
+    if (rec) (void)hipEventRecord(gp->ev[2 * gp->count], st);
     launch(cfg);
+    if (rec) {
+        (void)hipEventRecord(gp->ev[2 * gp->count + 1], st);
+        gp->flops[gp->count] = 2.0 * d.M * d.N * d.K * (double)z;
+        gp->kind[gp->count] = asplit ? 0 : 1;
+        gp->count++;
+    }
     return pp_last_launch();
 }
 

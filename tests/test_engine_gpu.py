@@ -133,3 +133,32 @@ def test_attention_products_softmax_layernorm_groupnorm():
     wg, bg = torch.randn(256, generator=g), torch.randn(256, generator=g)
     _close(ops.to_nchw(ops.groupnorm(ops.to_nhwc(xi.cuda()), wg.cuda(), bg.cuda(), 32, relu=True)),
            F.relu(F.group_norm(xi, 32, wg, bg)), 1e-5)
+
+
+@gpu
+def test_lds_dma_kernel_pinned(monkeypatch, engine_precision):
+    """The 256x128 LDS-DMA kernel (normally chosen by the autotuner for chip-filling problems only) pinned on
+    shapes with row / column / K tails, padded and strided taps, a Cin that is not a multiple of the K tile
+    and the pixel-shuffle store."""
+    if engine_precision != "f16x3":
+        pytest.skip("pre-split operands exist in f16x3 mode only")
+    from picopose_amd import ops
+
+    monkeypatch.setenv("PP_GEMM_FORCE_CFG", "3")
+    g = torch.Generator().manual_seed(77)
+    for M, K, N in [(257, 384, 1152), (1000, 768, 768), (300, 72, 130), (5, 4096, 64), (513, 32, 129)]:
+        x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+        _close(ops.linear(x.cuda(), w.cuda(), b.cuda(), act="gelu"), F.gelu(F.linear(x, w, b)))
+    for cin, cout, k, s, p, hw in [(640, 512, 3, 1, 1, 32), (256, 256, 3, 2, 1, 16), (256, 256, 1, 1, 0, 16), (72, 136, 3, 1, 1, 20),
+                                   (8, 64, 7, 1, 3, 32)]:
+        x = torch.randn(3, cin, hw, hw, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        b = torch.randn(cout, generator=g)
+        res = torch.randn(3, cout, (hw + 2 * p - k) // s + 1, (hw + 2 * p - k) // s + 1, generator=g)
+        ref = res + F.relu(F.conv2d(x, w, b, stride=s, padding=p))
+        out = ops.conv2d(ops.to_nhwc(x.cuda()), ops.pack_conv_weight(w.cuda()), b.cuda(), k, s, p, act="relu",
+                         residual=ops.to_nhwc(res.cuda()))
+        _close(ops.to_nchw(out), ref)
+    x, w, b = torch.randn(2, 64, 16, 16, generator=g), torch.randn(64, 96, 2, 2, generator=g) / 16, torch.randn(96, generator=g)
+    wp, bp = ops.pack_convT_weight(w.cuda(), b.cuda())
+    _close(ops.to_nchw(ops.conv_transpose2d(ops.to_nhwc(x.cuda()), wp, bp, 2)), F.conv_transpose2d(x, w, b, stride=2))
