@@ -1,4 +1,6 @@
 // Library-level entry points of the C ABI (include/picopose_hip.h).
+#include <cstdio>
+#include <cstdlib>
 #include "pp_common.h"
 
 extern "C" {
@@ -57,6 +59,8 @@ int pp_prof_gemm_enable(int max_records) {
     delete[] p.ev;
     delete[] p.flops;
     delete[] p.kind;
+    delete[] p.shape;
+    p.shape = nullptr;
     p.ev = nullptr;
     p.flops = nullptr;
     p.kind = nullptr;
@@ -65,6 +69,7 @@ int pp_prof_gemm_enable(int max_records) {
     p.ev = new hipEvent_t[2 * max_records];
     p.flops = new double[max_records];
     p.kind = new int[max_records];
+    p.shape = new int[max_records][5];
     for (int i = 0; i < 2 * max_records; ++i)
         if (hipEventCreate(&p.ev[i]) != hipSuccess) return PP_ELAUNCH;
     p.capacity = max_records;
@@ -78,11 +83,15 @@ int pp_prof_gemm_collect(double* ms, double* flops, int* launches) {
         ms[k] = flops[k] = 0.0;
         launches[k] = 0;
     }
+    const bool trace = getenv("PP_GEMM_TRACE") != nullptr;
     for (int i = 0; i < p.count; ++i) {
         float t = 0.f;
         if (hipEventSynchronize(p.ev[2 * i + 1]) != hipSuccess) return PP_ELAUNCH;
         if (hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]) != hipSuccess) return PP_ELAUNCH;
         const int k = p.kind[i];
+        if (trace)
+            fprintf(stderr, "[pp_gemm] kind=%d M=%d N=%d K=%d k=%d cfg=%d %.4f ms %.1f TFLOP/s\n", k, p.shape[i][0], p.shape[i][1],
+                    p.shape[i][2], p.shape[i][3], p.shape[i][4], t, p.flops[i] / (t * 1e-3) / 1e12);
         ms[k] += t;
         flops[k] += p.flops[i];
         launches[k]++;

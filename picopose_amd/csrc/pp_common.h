@@ -43,6 +43,7 @@ struct PpGemmProf {
     hipEvent_t* ev = nullptr;
     double* flops = nullptr;
     int* kind = nullptr;
+    int (*shape)[5] = nullptr;  // M, N, K, conv kernel size, chosen configuration (PP_GEMM_TRACE dump)
     int capacity = 0;
     int count = 0;
 };

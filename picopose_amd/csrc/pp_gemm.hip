@@ -808,6 +808,25 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
     }
     const int nb = n0 + w * 16 + lr;
     unsigned boff = nb < d.N ? (unsigned)(((long long)nb * d.ldb + k8) * 2) : 0xFFFFFFFFu;
+    // Convolutions with Cin % 32 == 0 walk K channel-tile-major: for each 32-channel slice all kh*kw taps back to
+    // back.  The taps of one slice re-read the same pixels shifted by a row or a column, so all but the first are
+    // L2 hits (tap-major order re-reads them Cin/32 tiles later, after the L2 has turned over).  Only the fp32
+    // summation order differs.  Per row: a bit mask of the taps that fall inside the image.
+    const int ntaps = d.conv_kh * d.conv_kw;
+    const bool cmajor = d.conv_kh != 0 && d.conv_cin % BK == 0 && ntaps <= 32;
+    unsigned vmask[2] = {0u, 0u}, abyte[2] = {0u, 0u};
+    const unsigned bbyte = boff;
+    if (cmajor) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            for (int t = 0; t < ntaps; ++t) {
+                const int iy = aoy[j] + t / d.conv_kw, ix = aox[j] + t % d.conv_kw;
+                if (arow_ok[j] && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) vmask[j] |= 1u << t;
+            }
+            abyte[j] = (unsigned)((abase[j] + k8) * 2);
+        }
+    }
+    int ctap = 0, cky = 0, ckx = 0, cci = 0;  // wave-uniform position of the next tile in channel-major order
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -821,6 +840,31 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
     // issue the 6 LDS-DMA loads of the next K tile into ring stage `stage` (wave-uniform)
     auto fetch = [&](int stage) __attribute__((always_inline)) {
         _Float16* st = glds + stage * G_STAGE;
+        if (cmajor) {
+            const bool kin = cci < d.conv_cin;
+            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci) * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned off = (((vmask[j] >> ctap) & 1u) && kin) ? abyte[j] + tapoff : 0xFFFFFFFFu;
+                _Float16* dst = st + ((j * 8 + w) * 16) * 32;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(Ahr, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(Alr, (lds_ptr_t)(dst + G_PLANE_A), 16, off, 0, 0, 0);
+            }
+            const unsigned off = (kin && bbyte != 0xFFFFFFFFu) ? bbyte + (unsigned)((ctap * d.conv_cin + cci) * 2) : 0xFFFFFFFFu;
+            _Float16* dst = st + 2 * G_PLANE_A + (w * 16) * 32;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Bhr, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Blr, (lds_ptr_t)(dst + G_PLANE_B), 16, off, 0, 0, 0);
+            ++ctap;
+            if (++ckx == d.conv_kw) {
+                ckx = 0;
+                if (++cky == d.conv_kh) {
+                    cky = 0;
+                    ctap = 0;
+                    cci += BK;
+                }
+            }
+            return;
+        }
         const bool kin = kcur < d.K;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -858,44 +902,57 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
         }
     };
     const int sw = (l31 >> 2) & 3;
-    auto mma = [&](int stage) __attribute__((always_inline)) {
+    struct Frag {
+        h8 ah[2], al[2], bh[2], bl[2];
+    };
+    // fragments of K half `ks` (16 k) of the tile in ring stage `stage`: 8 conflict-free ds_read_b128
+    auto load_frag = [&](Frag& f, int stage, int ks) __attribute__((always_inline)) {
         const _Float16* st = glds + stage * G_STAGE;
+        const int ch = ((ks * 2 + lh) ^ sw) * 8;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ch = ((ks * 2 + lh) ^ sw) * 8;
-            h8 ah[2], al[2], bh[2], bl[2];
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * 32 + ch);
+            f.al[i] = *(const h8*)(st + G_PLANE_A + (wr * 64 + i * 32 + l31) * 32 + ch);
+        }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * 32 + ch);
-                al[i] = *(const h8*)(st + G_PLANE_A + (wr * 64 + i * 32 + l31) * 32 + ch);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bh[j] = *(const h8*)(st + 2 * G_PLANE_A + (wc * 64 + j * 32 + l31) * 32 + ch);
-                bl[j] = *(const h8*)(st + 2 * G_PLANE_A + G_PLANE_B + (wc * 64 + j * 32 + l31) * 32 + ch);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
+        for (int j = 0; j < 2; ++j) {
+            f.bh[j] = *(const h8*)(st + 2 * G_PLANE_A + (wc * 64 + j * 32 + l31) * 32 + ch);
+            f.bl[j] = *(const h8*)(st + 2 * G_PLANE_A + G_PLANE_B + (wc * 64 + j * 32 + l31) * 32 + ch);
         }
     };
+    auto mma = [&](const Frag& f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+    // Ring: tile t lives in stage t % 3.  Iteration t holds tile t (being read), t+1 and t+2 (DMA in flight).  In the
+    // middle of the iteration — after the second-half fragments of tile t are in registers — `vmcnt(6)` retires
+    // this wave's loads of tile t+1 (tile t+2's six stay in flight), the barrier publishes tile t+1 and frees
+    // tile t's stage, tile t+3 is issued into it, and the first-half fragments of tile t+1 are read while the
+    // second-half MFMAs of tile t run: the LDS read latency never sits between a barrier and the MFMAs.
     const int nk = (d.K + BK - 1) / BK;
-    fetch(0);  // tile 0
-    fetch(1);  // tile 1 (zeros if nk == 1)
-    int cur = 0, nxt = 2;  // ring stage of tile kt / of tile kt + 2
+    fetch(0);
+    fetch(1);
+    fetch(2);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frag f0, f1;
+    load_frag(f0, 0, 0);
+    int cur = 0, nxt = 1;  // ring stage of tile kt / of tile kt + 1
     for (int kt = 0; kt < nk; ++kt) {
-        // this wave's DMA of tile kt has landed once at most tile kt+1's 6 loads are outstanding; after the
-        // barrier so has every wave's, and nobody reads tile kt-1's stage (= nxt) any more
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        load_frag(f1, cur, 1);
+        mma(f0);
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        fetch(nxt);  // tile kt + 2 (tiles past the end: zeros, never read)
-        mma(cur);
-        cur = cur == G_STAGES - 1 ? 0 : cur + 1;
+        fetch(cur);  // tile kt + 3 (tiles past the end: zeros, never used)
+        load_frag(f0, nxt, 0);
+        mma(f1);
+        cur = nxt;
         nxt = nxt == G_STAGES - 1 ? 0 : nxt + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS at exit
@@ -1290,6 +1347,11 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         (void)hipEventRecord(gp->ev[2 * gp->count + 1], st);
         gp->flops[gp->count] = 2.0 * d.M * d.N * d.K * (double)z;
         gp->kind[gp->count] = asplit ? 0 : 1;
+        gp->shape[gp->count][0] = d.M;
+        gp->shape[gp->count][1] = d.N;
+        gp->shape[gp->count][2] = d.K;
+        gp->shape[gp->count][3] = d.conv_kh;
+        gp->shape[gp->count][4] = cfg;
         gp->count++;
     }
     return pp_last_launch();

@@ -79,8 +79,7 @@ def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=Non
 
         scores_fn = lambda b, q, m: hm.template_scores(b, q, m, mode=net.match_mode)  # noqa: E731
         topk_fn = hm.topk_templates
-        tail_fn = lambda ep, ids, real: [net.forward_test_hyp(net.select_template_data(ep, ids, k), real)  # noqa: E731
-                                         for k in range(ids.shape[1])]
+        tail_fn = net.forward_hypotheses
     with torch.no_grad():
         real, q_local = features_fn(local_end_points["real_rgb"])          # (state for stages 2-3, (b,C,16,16))
         b_local = q_local.shape[0]

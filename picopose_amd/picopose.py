@@ -26,6 +26,7 @@ class Net(nn.Module):
         self.affine_regressor = AffineRegressor(cfg.stage2)
         self.offset_regressor = OffsetRegressor(cfg.stage3)
         self.match_mode = None  # None -> picopose_amd.utils.matching.DEFAULT_MODE ("fast")
+        self.batch_hypotheses = True  # run the hyp candidates of all crops as one batch (same values, larger launches)
 
     # model/picopose.py:52-70 — pick hypothesis k's template for every crop (pure indexing)
     def select_template_data(self, end_points, pred_id_src, k):
@@ -72,6 +73,27 @@ class Net(nn.Module):
             ops.to_nchw(flows[-1]), ops.to_nchw(certs[-1]), threshold=0.5)
         return output
 
+    def forward_hypotheses(self, end_points, pred_id_src, real):
+        """The loop of model/picopose.py:106-108 over the top-k templates of every crop -> list of k output dicts."""
+        hyp = pred_id_src.shape[1]
+        if not self.batch_hypotheses:
+            return [self.forward_test_hyp(self.select_template_data(end_points, pred_id_src, k), real) for k in range(hyp)]
+        # All hypotheses as ONE batch of hyp*B samples (hypothesis-major).  Every op on this path is per-sample
+        # (eval-mode BatchNorm is folded, GroupNorm is per sample) and a GEMM row does not depend on the other
+        # rows, so each hypothesis gets exactly the values the per-hypothesis loop gives it — with 5x larger
+        # launches that fill the 256 CUs evenly.
+        real_tok, hw = real[0], real[1]
+        real_dpt = real[2] if len(real) > 2 and real[2] is not None else None
+        B = pred_id_src.shape[0]
+        idx = pred_id_src.t().reshape(-1)
+        rows = torch.arange(B, device=idx.device).repeat(hyp)
+        rep = lambda t: t.repeat(hyp, *([1] * (t.dim() - 1)))  # noqa: E731
+        sel = {key: end_points[key][rows, idx] for key in ("tem_pose", "tem_K", "tem_M", "tem_mask", "tem_rgb", "tem_pts3d")}
+        for key in ("real_pts2d", "real_K", "real_M", "real_mask", "real_pose"):
+            sel[key] = rep(end_points[key])
+        out = self.forward_test_hyp(sel, ([rep(t) for t in real_tok], hw, None if real_dpt is None else [rep(t) for t in real_dpt]))
+        return [{key: v[k * B:(k + 1) * B] for key, v in out.items()} for k in range(hyp)]
+
     # model/picopose.py:97-112
     def forward_test(self, end_points, hyp=5):
         with torch.no_grad():
@@ -83,10 +105,7 @@ class Net(nn.Module):
             pred_score_src, pred_id_src = matching_templates(
                 end_points["template_feature"], ops.tokens_to_nchw(real_tok[-1], 1, h0, w0), end_points["tem_mask"],
                 end_points["real_mask"], topk=hyp, mode=self.match_mode)
-            outputs = []
-            for k in range(hyp):
-                outputs.append(self.forward_test_hyp(self.select_template_data(end_points, pred_id_src, k), real))
-            return outputs
+            return self.forward_hypotheses(end_points, pred_id_src, real)
 
     def forward(self, end_points, hyp=5):
         if self.training:
