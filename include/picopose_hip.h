@@ -180,6 +180,10 @@ typedef struct PpGemmDesc {
     const void* A_hi;      /* optional pre-split activation operand (pp_split_activation): fp16 planes */
     const void* A_lo;      /* indexed like A (dense [M][lda] / NHWC image); then A may be NULL         */
     long long a_plane_bytes, b_plane_bytes; /* filled in by pp_gemm (extent of the planes)            */
+    void* C_hi;            /* optional: ALSO (or, with C == NULL, only) write the output as f16x3 operand  */
+    void* C_lo;            /* planes [M][ldc_h] for the next GEMM (no pixel shuffle, no batch)            */
+    int ldc_h;             /* row stride of the planes in halfs                                         */
+    int c_relu;            /* planes hold split(max(out, 0)): the consumer's input ReLU folded in       */
 } PpGemmDesc;
 
 int pp_gemm(const PpGemmDesc* desc, void* stream);
@@ -194,10 +198,17 @@ int pp_split_activation(const float* x, long long batch_stride, int B, int P, in
 /* Fused multi-head self-attention (model/stage1/layers/attention.py:49-62): qkv (B,T,3,heads,64) as the qkv
  * linear produces it -> out (B,T,heads*64) = softmax((q*scale) k^T) v per head; exact fp32 MFMA, flash style. */
 int pp_attention(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* stream);
+/* Same, writing the output (also) as f16x3 operand planes (B*T, heads*head_dim) fp16 for the projection GEMM;
+ * out may be NULL. */
+int pp_attention_split(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* out_hi,
+                       void* out_lo, void* stream);
 
 /* nn.LayerNorm(C, eps) over rows of a [rows][C] matrix. */
 int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps,
                  float* y, void* stream);
+/* Same, writing the result (also) as f16x3 operand planes [rows][C] fp16 (hi, lo); y may be NULL. */
+int pp_layernorm_split(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
+                       void* hi, void* lo, void* stream);
 /* softmax(dim=-1) in place over rows of a [rows][ld] matrix (n valid columns). */
 int pp_softmax_rows(float* x, int rows, int n, int ld, void* stream);
 /* nn.GroupNorm(groups, C, eps) (+ReLU when relu != 0) on an NHWC tensor (B, HW, C). */

@@ -22,7 +22,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int HD = 64, KC = 32, KLD = 68;  // head dim, keys per chunk, floats per LDS row of the K chunk
 
 __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv, int T, int heads, float scale,
-                                                   float* __restrict__ out) {
+                                                   float* __restrict__ out, _Float16* __restrict__ out_hi,
+                                                   _Float16* __restrict__ out_lo) {
     __shared__ __attribute__((aligned(16))) float Ks[KC * KLD];
     __shared__ __attribute__((aligned(16))) float Vs[KC * HD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -113,12 +114,24 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
     }
     if (q < T) {
         const float inv = 1.0f / lrun;
-        float* op = out + ((size_t)b * T + q) * (heads * HD) + h * HD;
+        const size_t obase = ((size_t)b * T + q) * (heads * HD) + h * HD;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int d = (e & 3) + 8 * (e >> 2) + 4 * lh;
-            op[d] = o0[e] * inv;
-            op[32 + d] = o1[e] * inv;
+            const float a0 = o0[e] * inv, a1 = o1[e] * inv;
+            if (out) {
+                out[obase + d] = a0;
+                out[obase + 32 + d] = a1;
+            }
+            if (out_hi) {  // f16x3 operand planes of the output projection
+                _Float16 hh, ll;
+                pp_split_f16(a0, hh, ll);
+                out_hi[obase + d] = hh;
+                out_lo[obase + d] = ll;
+                pp_split_f16(a1, hh, ll);
+                out_hi[obase + 32 + d] = hh;
+                out_lo[obase + 32 + d] = ll;
+            }
         }
     }
 }
@@ -131,7 +144,16 @@ int pp_attention(const float* qkv, int B, int T, int heads, int head_dim, float 
     if (!qkv || !out || B <= 0 || T <= 0 || heads <= 0) return PP_EINVAL;
     if (head_dim != HD || ((uintptr_t)qkv % 16) != 0) return PP_EINVAL;
     hipLaunchKernelGGL(attn_kernel, dim3((T + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, qkv, T, heads,
-                       scale, out);
+                       scale, out, (_Float16*)nullptr, (_Float16*)nullptr);
+    return pp_last_launch();
+}
+
+int pp_attention_split(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* out_hi,
+                       void* out_lo, void* stream) {
+    if (!qkv || !out_hi || !out_lo || B <= 0 || T <= 0 || heads <= 0) return PP_EINVAL;
+    if (head_dim != HD || ((uintptr_t)qkv % 16) != 0) return PP_EINVAL;
+    hipLaunchKernelGGL(attn_kernel, dim3((T + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, qkv, T, heads,
+                       scale, out, (_Float16*)out_hi, (_Float16*)out_lo);
     return pp_last_launch();
 }
 

@@ -9,6 +9,14 @@
         if ((expr) != hipSuccess) return PP_ELAUNCH; \
     } while (0)
 
+// f16x3 activation operand: v -> hi = f16(4 v), lo = f16(4 v - hi) (saturated); the same split in every producer
+#define PP_A_SCALE 4.f
+__device__ __forceinline__ void pp_split_f16(float v, _Float16& hi, _Float16& lo) {
+    const float x = v * PP_A_SCALE;
+    hi = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+    lo = (_Float16)fminf(fmaxf(x - (float)hi, -65504.f), 65504.f);
+}
+
 static inline int pp_last_launch() { return hipGetLastError() == hipSuccess ? PP_OK : PP_ELAUNCH; }
 
 

@@ -101,6 +101,34 @@ __device__ __forceinline__ f4 load_a(const PpGemmDesc& d, const float* __restric
 
 // OCC = workgroups per CU the register allocation is held to: the 128x128 tile runs ~10 % faster per tile at 2
 // (no spills, 200 VGPRs) than at 3 (168 VGPRs); which one wins depends on how the tile count fills the slots.
+// Store one output element: out = residual + residual2 + v at (m, n) of C (row-major, or the pixel-shuffled layout
+// of a ConvTranspose2d(kernel = stride = r)), and/or its f16x3 operand planes (C_hi / C_lo, [M][ldc_h], with the
+// consumer's input ReLU folded in) so the next GEMM needs no separate split pass.
+__device__ __forceinline__ void epilogue_store(const PpGemmDesc& d, float* C, const float* R, const float* R2, int m, int n,
+                                               float v) {
+    size_t off;
+    if (d.shuffle_r == 0) {
+        off = (size_t)m * d.ldc + n;
+    } else {
+        // row m = input pixel (b, y, x) of an (shuffle_h x shuffle_w) image, column n = (dy*r + dx)*Cout + co
+        const int r = d.shuffle_r, cout = d.N / (r * r);
+        const int sub = n / cout, co = n - sub * cout, dy = sub / r, dx = sub - dy * r;
+        const int per = d.shuffle_h * d.shuffle_w;
+        const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
+        off = (((size_t)b * d.shuffle_h * r + y * r + dy) * (d.shuffle_w * r) + x * r + dx) * d.ldc + co;
+    }
+    if (R) v += R[off];
+    if (R2) v += R2[off];
+    if (C) C[off] = v;
+    if (d.C_hi) {
+        _Float16 h, l;
+        pp_split_f16(d.c_relu ? fmaxf(v, 0.f) : v, h, l);
+        const size_t ho = (size_t)m * d.ldc_h + n;
+        ((_Float16*)d.C_hi)[ho] = h;
+        ((_Float16*)d.C_lo)[ho] = l;
+    }
+}
+
 template <bool VEC4, int NJ, int OCC>
 __global__ __launch_bounds__(256, OCC) void gemm_kernel(const PpGemmDesc d) {
     constexpr int BN = 64 * NJ;
@@ -251,21 +279,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(const PpGemmDesc d) {
                 const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (m >= d.M) continue;
                 float v = act_apply(acc[i][j][e] * d.alpha + bias, d.act) * gamma;
-                size_t off;
-                if (d.shuffle_r == 0) {
-                    off = (size_t)m * d.ldc + n;
-                } else {
-                    // ConvTranspose2d(kernel = stride = r): row m = input pixel (b, y, x) of an
-                    // (shuffle_h x shuffle_w) image, column n = (dy*r + dx)*Cout + co
-                    const int r = d.shuffle_r, cout = d.N / (r * r);
-                    const int sub = n / cout, co = n - sub * cout, dy = sub / r, dx = sub - dy * r;
-                    const int per = d.shuffle_h * d.shuffle_w;
-                    const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
-                    off = (((size_t)b * d.shuffle_h * r + y * r + dy) * (d.shuffle_w * r) + x * r + dx) * d.ldc + co;
-                }
-                if (R) v += R[off];
-                if (R2) v += R2[off];
-                C[off] = v;
+                epilogue_store(d, C, R, R2, m, n, v);
             }
     }
 }
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(const PpGemmDesc d) {
 // can be handed over pre-split (d.B_hi / d.B_lo / d.b_scale from pp_split_f16x3).
 // LDS: hi/lo planes of [rows][32 k] halfs with an 80-byte row stride (conflict-free ds_read_b128).
 // ---------------------------------------------------------------------------
-constexpr float A_SCALE = 4.f;  // activation operand scale of the f16x3 engine
+constexpr float A_SCALE = PP_A_SCALE;  // activation operand scale of the f16x3 engine
 
 __device__ __forceinline__ void split_f16x4(const f4 v, float s, h4& hi, h4& lo) {
 #pragma unroll
@@ -487,21 +501,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const PpGemmDesc d
                 const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (m >= d.M) continue;
                 float v = act_apply(acc[i][j][e] * d.alpha + bias, d.act) * gamma;
-                size_t off;
-                if (d.shuffle_r == 0) {
-                    off = (size_t)m * d.ldc + n;
-                } else {
-                    // ConvTranspose2d(kernel = stride = r): row m = input pixel (b, y, x) of an
-                    // (shuffle_h x shuffle_w) image, column n = (dy*r + dx)*Cout + co
-                    const int r = d.shuffle_r, cout = d.N / (r * r);
-                    const int sub = n / cout, co = n - sub * cout, dy = sub / r, dx = sub - dy * r;
-                    const int per = d.shuffle_h * d.shuffle_w;
-                    const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
-                    off = (((size_t)b * d.shuffle_h * r + y * r + dy) * (d.shuffle_w * r) + x * r + dx) * d.ldc + co;
-                }
-                if (R) v += R[off];
-                if (R2) v += R2[off];
-                C[off] = v;
+                epilogue_store(d, C, R, R2, m, n, v);
             }
     }
 }
@@ -716,19 +716,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
                 const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (m >= d.M) continue;
                 float v = act_apply(acc[i][j][e] * descale + bias, d.act) * gamma;
-                size_t off;
-                if (d.shuffle_r == 0) {
-                    off = (size_t)m * d.ldc + n;
-                } else {
-                    const int r = d.shuffle_r, cout = d.N / (r * r);
-                    const int sub = n / cout, co = n - sub * cout, dy = sub / r, dx = sub - dy * r;
-                    const int per = d.shuffle_h * d.shuffle_w;
-                    const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
-                    off = (((size_t)b * d.shuffle_h * r + y * r + dy) * (d.shuffle_w * r) + x * r + dx) * d.ldc + co;
-                }
-                if (R) v += R[off];
-                if (R2) v += R2[off];
-                C[off] = v;
+                epilogue_store(d, C, R, R2, m, n, v);
             }
     }
 }
@@ -974,19 +962,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
                 const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (m >= d.M) continue;
                 float v = act_apply(acc[i][j][e] * descale + bias, d.act) * gamma;
-                size_t off;
-                if (d.shuffle_r == 0) {
-                    off = (size_t)m * d.ldc + n;
-                } else {
-                    const int r = d.shuffle_r, cout = d.N / (r * r);
-                    const int sub = n / cout, co = n - sub * cout, dy = sub / r, dx = sub - dy * r;
-                    const int per = d.shuffle_h * d.shuffle_w;
-                    const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
-                    off = (((size_t)b * d.shuffle_h * r + y * r + dy) * (d.shuffle_w * r) + x * r + dx) * d.ldc + co;
-                }
-                if (R) v += R[off];
-                if (R2) v += R2[off];
-                C[off] = v;
+                epilogue_store(d, C, R, R2, m, n, v);
             }
     }
 }
@@ -1019,7 +995,8 @@ __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict_
 // nn.LayerNorm(eps) over the last dimension: one wave per row (model/stage1 block.py:56,68)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ b, int rows, int C, float eps,
-                                                        float* __restrict__ y) {
+                                                        float* __restrict__ y, _Float16* __restrict__ hi,
+                                                        _Float16* __restrict__ lo) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (size_t)row * C;
@@ -1036,8 +1013,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     const float rstd = 1.0f / sqrtf(v / (float)C + eps);
-    float* yr = y + (size_t)row * C;
-    for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mean) * rstd * g[c] + b[c];
+    for (int c = lane; c < C; c += 64) {
+        const float o = (xr[c] - mean) * rstd * g[c] + b[c];
+        if (y) y[(size_t)row * C + c] = o;
+        if (hi) {  // f16x3 operand planes of the following linear layer
+            _Float16 h, l;
+            pp_split_f16(o, h, l);
+            hi[(size_t)row * C + c] = h;
+            lo[(size_t)row * C + c] = l;
+        }
+    }
 }
 
 // softmax over the last dimension, in place: one wave per row (layers/attention.py:57)
@@ -1200,7 +1185,9 @@ int pp_split_activation(const float* x, long long batch_stride, int B, int P, in
 }
 
 int pp_gemm(const PpGemmDesc* desc, void* stream) {
-    if (!desc || (!desc->A && !desc->A_hi) || !desc->B || !desc->C) return PP_EINVAL;
+    if (!desc || (!desc->A && !desc->A_hi) || !desc->B || (!desc->C && !desc->C_hi)) return PP_EINVAL;
+    if (desc->C_hi && (!desc->C_lo || desc->shuffle_r != 0 || desc->ldc_h < desc->N || desc->batch0 * desc->batch1 != 1))
+        return PP_EINVAL;
     PpGemmDesc d = *desc;
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch0 <= 0 || d.batch1 <= 0) return PP_EINVAL;
     if (d.act < 0 || d.act > PP_ACT_TANH) return PP_EINVAL;
@@ -1361,7 +1348,15 @@ int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows
                  void* stream) {
     if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0) return PP_EINVAL;
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                       rows, C, eps, y);
+                       rows, C, eps, y, (_Float16*)nullptr, (_Float16*)nullptr);
+    return pp_last_launch();
+}
+
+int pp_layernorm_split(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
+                       void* hi, void* lo, void* stream) {
+    if (!x || !gamma || !beta || !hi || !lo || rows <= 0 || C <= 0) return PP_EINVAL;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                       rows, C, eps, y, (_Float16*)hi, (_Float16*)lo);
     return pp_last_launch();
 }
 

@@ -121,12 +121,13 @@ class FeatureExtractor(Packed):
         xs = tok.view(B * T, C)
         outs = []
         for i, blk in enumerate(v.blocks):
-            h = ops.layernorm(xs, blk.norm1.weight, blk.norm1.bias, 1e-6)
+            # out_split: on the f16x3 engine each producer writes the next linear's operand planes directly
+            h = ops.layernorm(xs, blk.norm1.weight, blk.norm1.bias, 1e-6, out_split=True)
             qkv = ops.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias)                       # (B*T, 3*heads*hd)
-            o = ops.attention(qkv, B, T, heads, hd)                                           # fused QK^T/softmax/PV
+            o = ops.attention(qkv, B, T, heads, hd, out_split=True)                           # fused QK^T/softmax/PV
             xs = ops.linear(o, blk.attn.proj.weight, blk.attn.proj.bias, gamma=blk.ls1.gamma, residual=xs)
-            h = ops.layernorm(xs, blk.norm2.weight, blk.norm2.bias, 1e-6)
-            f = ops.linear(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act="gelu")
+            h = ops.layernorm(xs, blk.norm2.weight, blk.norm2.bias, 1e-6, out_split=True)
+            f = ops.linear(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act="gelu", out_split=True)
             xs = ops.linear(f, blk.mlp.fc2.weight, blk.mlp.fc2.bias, gamma=blk.ls2.gamma, residual=xs)
             if i in self.blocks_to_take:
                 outs.append(xs.view(B, T, C))

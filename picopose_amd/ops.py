@@ -38,6 +38,33 @@ def split_weight(w):
     return hit[0], hit[1], hit[2]
 
 
+class Split:
+    """An activation that exists only as the f16x3 engine's operand planes: hi, lo (rows, C) fp16, contiguous.
+    Producers (layernorm, attention, a GEMM epilogue) write it directly, so the consuming GEMM needs no split pass
+    and the fp32 tensor is never stored."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    @property
+    def device(self):
+        return self.hi.device
+
+    @staticmethod
+    def empty(rows, C, device):
+        return Split(torch.empty(rows, C, dtype=torch.float16, device=device),
+                     torch.empty(rows, C, dtype=torch.float16, device=device))
+
+
+def _split_ok(C):
+    return PRECISION == "f16x3" and C % 8 == 0
+
+
 def split_activation(x, B, P, C, batch_stride, row_stride, relu=False):
     """Pre-split an activation operand (B, P, C) into contiguous fp16 planes (B*P, C) for the f16x3 engine."""
     hi = torch.empty(B * P, C, dtype=torch.float16, device=x.device)
@@ -77,25 +104,42 @@ def _desc(**kw):
     return d
 
 
-def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, relu_in=False):
-    """y = residual + gamma * act(x @ weight.T + bias); x (M,K) with row stride, weight (N,K)."""
+def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, relu_in=False, out_split=False):
+    """y = residual + gamma * act(x @ weight.T + bias); x (M,K) fp32 with row stride or a Split, weight (N,K).
+    out_split (f16x3 engine only; ignored otherwise): return y as a Split for the next linear instead of fp32."""
     M, K = x.shape
     N = weight.shape[0]
-    assert weight.shape[1] == K and x.stride(1) == 1 and weight.is_contiguous()
-    if out is None:
-        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    assert out.stride(1) == 1
-    if residual is not None:
-        assert residual.shape == out.shape and residual.stride() == out.stride()
+    assert weight.shape[1] == K and weight.is_contiguous()
     wargs = _weight_args(weight, K)
+    sargs, ret = {}, None
+    if out_split and "B_hi" in wargs and _split_ok(N) and out is None:
+        ret = Split.empty(M, N, x.device)
+        sargs = dict(C_hi=_p(ret.hi), C_lo=_p(ret.lo), ldc_h=N)
+    elif out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    ldc = N if out is None else out.stride(0)
+    if out is not None:
+        assert out.stride(1) == 1
+        ret = out
+    if residual is not None:
+        assert tuple(residual.shape) == (M, N) and residual.stride(1) == 1 and residual.stride(0) == ldc
+    if isinstance(x, Split):
+        assert "B_hi" in wargs
+        _run(_desc(A_hi=_p(x.hi), A_lo=_p(x.lo), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual),
+                   M=M, N=N, K=K, lda=K, ldb=K, ldc=ldc, act=ACT[act], **wargs, **sargs))
+        return ret
+    assert x.stride(1) == 1
     if "B_hi" in wargs and N > 64 and _can_presplit(x, K, K, x.stride(0)) and M * K < 2 ** 31:
         hi, lo = split_activation(x, 1, M, K, 0, x.stride(0), relu=relu_in)      # every column tile reuses the split
         _run(_desc(A_hi=_p(hi), A_lo=_p(lo), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual),
-                   M=M, N=N, K=K, lda=K, ldb=K, ldc=out.stride(0), act=ACT[act], **wargs))
-        return out
+                   M=M, N=N, K=K, lda=K, ldb=K, ldc=ldc, act=ACT[act], **wargs, **sargs))
+        return ret
+    if sargs:  # the fp32-operand kernels write planes too, but keep this rare path simple: fp32 out + split pass
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        ret, ldc, sargs = out, N, {}
     _run(_desc(A=_p(x), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual), M=M, N=N, K=K,
-               lda=x.stride(0), ldb=K, ldc=out.stride(0), act=ACT[act], relu_in=int(relu_in), **wargs))
-    return out
+               lda=x.stride(0), ldb=K, ldc=ldc, act=ACT[act], relu_in=int(relu_in), **wargs))
+    return ret
 
 
 def bmm_nt(a, b, alpha=1.0, out=None):
@@ -195,17 +239,29 @@ def conv_transpose2d(x, wp, bias_tiled, r):
     return out
 
 
-def attention(qkv, B, T, heads, hd):
-    """qkv (B*T, 3*heads*hd) from the qkv linear -> (B*T, heads*hd): softmax((q hd^-1/2) k^T) v per head, fused."""
+def attention(qkv, B, T, heads, hd, out_split=False):
+    """qkv (B*T, 3*heads*hd) from the qkv linear -> (B*T, heads*hd): softmax((q hd^-1/2) k^T) v per head, fused.
+    out_split: return the result as a Split (f16x3 engine only)."""
     assert qkv.is_contiguous()
+    if out_split and _split_ok(heads * hd):
+        sp = Split.empty(B * T, heads * hd, qkv.device)
+        _lib.check(_lib.lib().pp_attention_split(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, None, _p(sp.hi), _p(sp.lo),
+                                                 _lib.stream_ptr()), "pp_attention_split")
+        return sp
     out = torch.empty(B * T, heads * hd, dtype=torch.float32, device=qkv.device)
     _lib.check(_lib.lib().pp_attention(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, _p(out), _lib.stream_ptr()), "pp_attention")
     return out
 
 
-def layernorm(x, weight, bias, eps):
+def layernorm(x, weight, bias, eps, out_split=False):
+    """nn.LayerNorm over the last dim of (rows, C); out_split: return a Split (f16x3 engine only)."""
     rows, C = x.shape
     assert x.is_contiguous()
+    if out_split and _split_ok(C):
+        sp = Split.empty(rows, C, x.device)
+        _lib.check(_lib.lib().pp_layernorm_split(_p(x), _p(weight), _p(bias), rows, C, float(eps), None, _p(sp.hi), _p(sp.lo),
+                                                 _lib.stream_ptr()), "pp_layernorm_split")
+        return sp
     y = torch.empty_like(x)
     _lib.check(_lib.lib().pp_layernorm(_p(x), _p(weight), _p(bias), rows, C, float(eps), _p(y), _lib.stream_ptr()),
                "pp_layernorm")

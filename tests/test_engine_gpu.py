@@ -162,3 +162,35 @@ def test_lds_dma_kernel_pinned(monkeypatch, engine_precision):
     x, w, b = torch.randn(2, 64, 16, 16, generator=g), torch.randn(64, 96, 2, 2, generator=g) / 16, torch.randn(96, generator=g)
     wp, bp = ops.pack_convT_weight(w.cuda(), b.cuda())
     _close(ops.to_nchw(ops.conv_transpose2d(ops.to_nhwc(x.cuda()), wp, bp, 2)), F.conv_transpose2d(x, w, b, stride=2))
+
+
+@gpu
+def test_fused_operand_planes_equal_separate_split(engine_precision):
+    """layernorm / attention / GEMM epilogues that write the next GEMM's f16x3 operand planes directly give
+    bit-identical results to the fp32 tensor + separate split pass."""
+    if engine_precision != "f16x3":
+        pytest.skip("operand planes exist in f16x3 mode only")
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    B, T, heads, hd = 3, 257, 6, 64
+    C = heads * hd
+    x = torch.randn(B * T, C, generator=g).cuda()
+    lw, lb = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    wqkv, bqkv = (torch.randn(3 * C, C, generator=g) / C ** 0.5).cuda(), torch.randn(3 * C, generator=g).cuda()
+    wp = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    w1, b1 = (torch.randn(4 * C, C, generator=g) / C ** 0.5).cuda(), torch.randn(4 * C, generator=g).cuda()
+    w2 = (torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5).cuda()
+
+    def chain(fused):
+        h = ops.layernorm(x, lw, lb, 1e-6, out_split=fused)
+        assert isinstance(h, ops.Split) == fused
+        qkv = ops.linear(h, wqkv, bqkv)
+        o = ops.attention(qkv, B, T, heads, hd, out_split=fused)
+        y = ops.linear(o, wp, None, residual=x)
+        f = ops.linear(ops.layernorm(y, lw, lb, 1e-6, out_split=fused), w1, b1, act="gelu", out_split=fused)
+        assert isinstance(f, ops.Split) == fused
+        return ops.linear(f, w2, None, residual=y)
+
+    a, b = chain(True), chain(False)
+    assert torch.equal(a, b)
