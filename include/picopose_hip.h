@@ -202,6 +202,11 @@ int pp_attention(const float* qkv, int B, int T, int heads, int head_dim, float 
  * out may be NULL. */
 int pp_attention_split(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* out_hi,
                        void* out_lo, void* stream);
+/* General form: prec = PP_PREC_F32 (exact fp32 products, as the two entries above) or PP_PREC_F16X3 (q, k, v and
+ * the probabilities split into 2 fp16 terms, 3 fp16 MFMAs per product, fp32 soft-max statistics and accumulation);
+ * out and/or the (out_hi, out_lo) operand planes. */
+int pp_attention_ex(const float* qkv, int B, int T, int heads, int head_dim, float scale, int prec, float* out, void* out_hi,
+                    void* out_lo, void* stream);
 
 /* nn.LayerNorm(C, eps) over rows of a [rows][C] matrix. */
 int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps,

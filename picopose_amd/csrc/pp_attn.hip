@@ -136,25 +136,234 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
     }
 }
 
+// ---------------------------------------------------------------------------
+// f16x3 variant (the engine's default arithmetic): q, k, v and the probabilities are split into two
+// fp16 terms (22 bits) and every product runs as 3 x v_mfma_f32_32x32x16_f16 with fp32 accumulation; the soft-max
+// statistics stay fp32.  Same transposed-score structure as above:
+//   S^T = K Q^T   A = K chunk (lane: key l31, 8 consecutive d), B = Q (registers, pre-scaled)      4 x 3 MFMA
+//   O^T += V^T P^T A = V^T (lane: d l31, 8 keys), B = P in accumulator layout (registers 8s..8s+7)  4 x 3 MFMA
+// The k-slot <-> key assignment of the second product is free as long as both operands agree: slot (lh, i) of
+// step s is key 16 s + 4 lh + (i & 3) + 8 (i >> 2) — exactly the keys accumulator registers 8s..8s+7 of a lane
+// hold — so P needs no data movement and V is staged transposed with its keys in that order.
+// A workgroup = WPB waves x 32 queries sharing the staged K / V chunk; the host picks WPB so the query tiles
+// divide evenly (T = 257: 9 tiles = 3 workgroups of 3 waves).  The output leaves through LDS as full rows.
+// ---------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr int KHLD = 72;   // halfs per K row in LDS (64 + 8 pad: 144-byte stride, conflict-free ds_read_b128)
+constexpr int VTLD = 40;   // halfs per V^T row (32 key slots + 8 pad: 80-byte stride)
+constexpr int OLD = 68;    // floats per staged output row
+constexpr float P_SCALE = 1024.f;
+
+__device__ __forceinline__ int vt_slot(int key) {  // key (0..31) of a chunk -> k-slot order of the P registers
+    const int s = key >> 4, r = key & 15;
+    return s * 16 + ((r >> 2) & 1) * 8 + (r & 3) + 4 * (r >> 3);
+}
+
+__global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict__ qkv, int T, int heads, float scale,
+                                                         float* __restrict__ out, _Float16* __restrict__ out_hi,
+                                                         _Float16* __restrict__ out_lo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* Kh = (_Float16*)smem;            // [KC][KHLD]
+    _Float16* Kl = Kh + KC * KHLD;
+    _Float16* Vh = Kl + KC * KHLD;             // [HD][VTLD]  (V^T, permuted key slots)
+    _Float16* Vl = Vh + HD * VTLD;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.y / heads, h = blockIdx.y % heads;
+    const int C3 = 3 * heads * HD;
+    const float* base = qkv + (size_t)b * T * C3 + h * HD;
+    const int q = (blockIdx.x * (nthr >> 6) + w) * 32 + l31;
+    const int qc = q < T ? q : T - 1;
+
+    // Q fragments: step s holds d = 16 s + 8 lh .. + 7 of query l31, pre-scaled, split
+    h8 qh[4], ql[4];
+    {
+        const float* qp = base + (size_t)qc * C3;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f4 a = *(const f4*)(qp + 16 * s + 8 * lh), c = *(const f4*)(qp + 16 * s + 8 * lh + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                _Float16 hh, ll;
+                pp_split_f16(a[i] * scale, hh, ll);
+                qh[s][i] = hh;
+                ql[s][i] = ll;
+                pp_split_f16(c[i] * scale, hh, ll);
+                qh[s][4 + i] = hh;
+                ql[s][4 + i] = ll;
+            }
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o0[e] = o1[e] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+    const float* kp = base + heads * HD;
+    const float* vp = base + 2 * heads * HD;
+    constexpr float S_DESCALE = 1.0f / (PP_A_SCALE * PP_A_SCALE);
+    constexpr float O_RESCALE = 1.0f / (PP_A_SCALE * P_SCALE);
+
+    for (int k0 = 0; k0 < T; k0 += KC) {
+        __syncthreads();
+        for (int idx = tid; idx < KC * (HD / 4); idx += nthr) {  // 512 float4 per tensor
+            const int row = idx >> 4, c4 = (idx & 15) * 4;
+            f4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + row < T) {
+                kv = *(const f4*)(kp + (size_t)(k0 + row) * C3 + c4);
+                vv = *(const f4*)(vp + (size_t)(k0 + row) * C3 + c4);
+            }
+            const int slot = vt_slot(row);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                _Float16 hh, ll;
+                pp_split_f16(kv[i], hh, ll);
+                Kh[row * KHLD + c4 + i] = hh;
+                Kl[row * KHLD + c4 + i] = ll;
+                pp_split_f16(vv[i], hh, ll);
+                Vh[(c4 + i) * VTLD + slot] = hh;
+                Vl[(c4 + i) * VTLD + slot] = ll;
+            }
+        }
+        __syncthreads();
+        f32x16 sacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const h8 kh = *(const h8*)(Kh + l31 * KHLD + 16 * s + 8 * lh);
+            const h8 kl = *(const h8*)(Kl + l31 * KHLD + 16 * s + 8 * lh);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            sacc[e] = key < T ? sacc[e] * S_DESCALE : -INFINITY;
+            mx = fmaxf(mx, sacc[e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = expf(mrun - mnew);
+        float ls = 0.f;
+        h8 ph[2], pl[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pe = expf(sacc[e] - mnew);
+            ls += pe;
+            const float x = pe * P_SCALE;  // <= 1024: no saturation needed
+            const _Float16 hh = (_Float16)x;
+            ph[e >> 3][e & 7] = hh;
+            pl[e >> 3][e & 7] = (_Float16)(x - (float)hh);
+        }
+        ls += __shfl_xor(ls, 32);
+        lrun = lrun * alpha + ls;
+        mrun = mnew;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            o0[e] *= alpha;
+            o1[e] *= alpha;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const h8 v0h = *(const h8*)(Vh + l31 * VTLD + 16 * s + 8 * lh);
+            const h8 v0l = *(const h8*)(Vl + l31 * VTLD + 16 * s + 8 * lh);
+            const h8 v1h = *(const h8*)(Vh + (32 + l31) * VTLD + 16 * s + 8 * lh);
+            const h8 v1l = *(const h8*)(Vl + (32 + l31) * VTLD + 16 * s + 8 * lh);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph[s], o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl[s], o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph[s], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph[s], o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl[s], o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph[s], o1, 0, 0, 0);
+        }
+    }
+    // output through LDS: O^T registers (lane = query) -> rows of 64 floats per query, written as full lines
+    __syncthreads();
+    float* Os = (float*)smem + w * 32 * OLD;
+    const float inv = O_RESCALE / lrun;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f4 a, c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = o0[4 * g + i] * inv;
+            c[i] = o1[4 * g + i] * inv;
+        }
+        *(f4*)(Os + l31 * OLD + 8 * g + 4 * lh) = a;
+        *(f4*)(Os + l31 * OLD + 32 + 8 * g + 4 * lh) = c;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave reads only what it wrote itself
+    const int qr = lane >> 1, half = lane & 1;
+    const int qo = (blockIdx.x * (nthr >> 6) + w) * 32 + qr;
+    if (qo < T) {
+        const size_t obase = ((size_t)b * T + qo) * (heads * HD) + h * HD + 32 * half;
+        const float* src = Os + qr * OLD + 32 * half;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f4 v = *(const f4*)(src + 4 * j);
+            if (out) *(f4*)(out + obase + 4 * j) = v;
+            if (out_hi) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 hh, ll;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    _Float16 a, c;
+                    pp_split_f16(v[i], a, c);
+                    hh[i] = a;
+                    ll[i] = c;
+                }
+                *(h4*)(out_hi + obase + 4 * j) = hh;
+                *(h4*)(out_lo + obase + 4 * j) = ll;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
-int pp_attention(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* stream) {
-    if (!qkv || !out || B <= 0 || T <= 0 || heads <= 0) return PP_EINVAL;
+static int attention_launch(const float* qkv, int B, int T, int heads, int head_dim, float scale, int prec, float* out,
+                            void* out_hi, void* out_lo, void* stream) {
+    if (!qkv || (!out && !out_hi) || (out_hi && !out_lo) || B <= 0 || T <= 0 || heads <= 0) return PP_EINVAL;
     if (head_dim != HD || ((uintptr_t)qkv % 16) != 0) return PP_EINVAL;
-    hipLaunchKernelGGL(attn_kernel, dim3((T + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, qkv, T, heads,
-                       scale, out, (_Float16*)nullptr, (_Float16*)nullptr);
+    if (prec == PP_PREC_F16X3) {
+        // waves per workgroup: the split of the ceil(T/32) query tiles that wastes the fewest wave slots
+        const int tiles = (T + 31) / 32;
+        int wpb = 4, best = 1 << 30;
+        for (int c = 4; c >= 2; --c) {
+            const int waste = (tiles + c - 1) / c * c - tiles;
+            if (waste < best) {
+                best = waste;
+                wpb = c;
+            }
+        }
+        const size_t kv = (size_t)(2 * KC * KHLD + 2 * HD * VTLD) * sizeof(_Float16), os = (size_t)wpb * 32 * OLD * sizeof(float);
+        hipLaunchKernelGGL(attn_f16x3_kernel, dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
+                           (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hi, (_Float16*)out_lo);
+    } else {
+        hipLaunchKernelGGL(attn_kernel, dim3((T + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, qkv, T, heads,
+                           scale, out, (_Float16*)out_hi, (_Float16*)out_lo);
+    }
     return pp_last_launch();
+}
+
+int pp_attention(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* stream) {
+    if (!out) return PP_EINVAL;
+    return attention_launch(qkv, B, T, heads, head_dim, scale, PP_PREC_F32, out, nullptr, nullptr, stream);
 }
 
 int pp_attention_split(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* out_hi,
                        void* out_lo, void* stream) {
-    if (!qkv || !out_hi || !out_lo || B <= 0 || T <= 0 || heads <= 0) return PP_EINVAL;
-    if (head_dim != HD || ((uintptr_t)qkv % 16) != 0) return PP_EINVAL;
-    hipLaunchKernelGGL(attn_kernel, dim3((T + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, qkv, T, heads,
-                       scale, out, (_Float16*)out_hi, (_Float16*)out_lo);
-    return pp_last_launch();
+    if (!out_hi) return PP_EINVAL;
+    return attention_launch(qkv, B, T, heads, head_dim, scale, PP_PREC_F32, out, out_hi, out_lo, stream);
+}
+
+int pp_attention_ex(const float* qkv, int B, int T, int heads, int head_dim, float scale, int prec, float* out, void* out_hi,
+                    void* out_lo, void* stream) {
+    if (prec != PP_PREC_F32 && prec != PP_PREC_F16X3) return PP_EINVAL;
+    return attention_launch(qkv, B, T, heads, head_dim, scale, prec, out, out_hi, out_lo, stream);
 }
 
 }  // extern "C"

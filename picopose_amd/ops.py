@@ -240,17 +240,18 @@ def conv_transpose2d(x, wp, bias_tiled, r):
 
 
 def attention(qkv, B, T, heads, hd, out_split=False):
-    """qkv (B*T, 3*heads*hd) from the qkv linear -> (B*T, heads*hd): softmax((q hd^-1/2) k^T) v per head, fused.
-    out_split: return the result as a Split (f16x3 engine only)."""
+    """qkv (B*T, 3*heads*hd) from the qkv linear -> (B*T, heads*hd): softmax((q hd^-1/2) k^T) v per head, fused,
+    in the engine's current arithmetic.  out_split: return the result as a Split (f16x3 engine only)."""
     assert qkv.is_contiguous()
+    sp = out = None
     if out_split and _split_ok(heads * hd):
         sp = Split.empty(B * T, heads * hd, qkv.device)
-        _lib.check(_lib.lib().pp_attention_split(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, None, _p(sp.hi), _p(sp.lo),
-                                                 _lib.stream_ptr()), "pp_attention_split")
-        return sp
-    out = torch.empty(B * T, heads * hd, dtype=torch.float32, device=qkv.device)
-    _lib.check(_lib.lib().pp_attention(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, _p(out), _lib.stream_ptr()), "pp_attention")
-    return out
+    else:
+        out = torch.empty(B * T, heads * hd, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().pp_attention_ex(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, _PREC[PRECISION], _p(out),
+                                          _p(sp.hi) if sp else None, _p(sp.lo) if sp else None, _lib.stream_ptr()),
+               "pp_attention_ex")
+    return sp if sp is not None else out
 
 
 def layernorm(x, weight, bias, eps, out_split=False):
