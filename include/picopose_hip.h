@@ -174,46 +174,47 @@ typedef struct PpGemmDesc {
      * column n = (dy*r + dx)*Cout + co is stored at pixel (y*r+dy, x*r+dx), channel co               */
     int shuffle_r, shuffle_h, shuffle_w;
     int prec;              /* PP_PREC_*                                                               */
-    const void* B_hi;      /* optional pre-split weights for PP_PREC_F16X3: fp16 [N][ldb], hi term    */
-    const void* B_lo;      /* ... lo term (pp_split_f16x3)                                            */
+    /* Pre-split f16x3 operands ("hl" format): a matrix [rows][ld] of fp32 becomes fp16 [rows][ld/8][2][8] —
+     * for every group of 8 consecutive k the 8 hi terms then the 8 lo terms (32 contiguous bytes), so that a K
+     * tile of 32 is one 128-byte segment per row.  element (r, k), term p: r*2*ld + (k/8)*16 + p*8 + k%8.
+     * ld % 8 == 0; the buffers are indexed exactly like the fp32 operand would be (dense / NHWC image).   */
+    const void* B_hl;      /* optional pre-split weights for PP_PREC_F16X3 ([N][ldb], pp_split_f16x3)  */
     float b_scale;         /* power-of-two scale the pre-split weights were multiplied by             */
-    const void* A_hi;      /* optional pre-split activation operand (pp_split_activation): fp16 planes */
-    const void* A_lo;      /* indexed like A (dense [M][lda] / NHWC image); then A may be NULL         */
-    long long a_plane_bytes, b_plane_bytes; /* filled in by pp_gemm (extent of the planes)            */
-    void* C_hi;            /* optional: ALSO (or, with C == NULL, only) write the output as f16x3 operand  */
-    void* C_lo;            /* planes [M][ldc_h] for the next GEMM (no pixel shuffle, no batch)            */
-    int ldc_h;             /* row stride of the planes in halfs                                         */
-    int c_relu;            /* planes hold split(max(out, 0)): the consumer's input ReLU folded in       */
+    const void* A_hl;      /* optional pre-split activation operand (pp_split_activation); A may be NULL */
+    long long a_hl_bytes, b_hl_bytes; /* filled in by pp_gemm (extent of the buffers)                  */
+    void* C_hl;            /* optional: ALSO (or, with C == NULL, only) write the output as an hl operand */
+    int ldc_h;             /* [M][ldc_h] for the next GEMM (no pixel shuffle, no batch); ldc_h % 8 == 0  */
+    int c_relu;            /* C_hl holds split(max(out, 0)): the consumer's input ReLU folded in        */
 } PpGemmDesc;
 
 int pp_gemm(const PpGemmDesc* desc, void* stream);
-/* Split n fp32 weights once at load time: scale[0] = 2^k with max|scale*w| in [512,1024) (device float),
- * hi = f16(scale*w), lo = f16(scale*w - hi). */
-int pp_split_f16x3(const float* w, long long n, void* hi, void* lo, float* scale, void* stream);
-/* Split an activation tensor x (B, P, C) fp32 (batch / row strides in floats, channels contiguous) once into
- * contiguous fp16 planes hi, lo (B*P, C) for PP_PREC_F16X3 (fixed activation scale 4; optional ReLU first). */
+/* Split n fp32 weights (rows of a multiple of 8 elements) once at load time into an hl buffer of 2n halfs:
+ * scale[0] = 2^k with max|scale*w| in [512,1024) (device float), hi = f16(scale*w), lo = f16(scale*w - hi). */
+int pp_split_f16x3(const float* w, long long n, void* hl, float* scale, void* stream);
+/* Split an activation tensor x (B, P, C) fp32 (batch / row strides in floats, channels contiguous, C % 8 == 0)
+ * once into a contiguous hl buffer (B*P rows, ld = C) for PP_PREC_F16X3 (activation scale 4; optional ReLU first). */
 int pp_split_activation(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu,
-                        void* hi, void* lo, void* stream);
+                        void* hl, void* stream);
 
 /* Fused multi-head self-attention (model/stage1/layers/attention.py:49-62): qkv (B,T,3,heads,64) as the qkv
  * linear produces it -> out (B,T,heads*64) = softmax((q*scale) k^T) v per head; exact fp32 MFMA, flash style. */
 int pp_attention(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* stream);
-/* Same, writing the output (also) as f16x3 operand planes (B*T, heads*head_dim) fp16 for the projection GEMM;
+/* Same, writing the output (also) as an hl operand (B*T rows, ld = heads*head_dim) for the projection GEMM;
  * out may be NULL. */
-int pp_attention_split(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* out_hi,
-                       void* out_lo, void* stream);
+int pp_attention_split(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* out_hl,
+                       void* stream);
 /* General form: prec = PP_PREC_F32 (exact fp32 products, as the two entries above) or PP_PREC_F16X3 (q, k, v and
  * the probabilities split into 2 fp16 terms, 3 fp16 MFMAs per product, fp32 soft-max statistics and accumulation);
- * out and/or the (out_hi, out_lo) operand planes. */
-int pp_attention_ex(const float* qkv, int B, int T, int heads, int head_dim, float scale, int prec, float* out, void* out_hi,
-                    void* out_lo, void* stream);
+ * out and/or the hl operand out_hl. */
+int pp_attention_ex(const float* qkv, int B, int T, int heads, int head_dim, float scale, int prec, float* out, void* out_hl,
+                    void* stream);
 
 /* nn.LayerNorm(C, eps) over rows of a [rows][C] matrix. */
 int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps,
                  float* y, void* stream);
-/* Same, writing the result (also) as f16x3 operand planes [rows][C] fp16 (hi, lo); y may be NULL. */
+/* Same, writing the result (also) as an hl operand (rows, ld = C; C % 8 == 0); y may be NULL. */
 int pp_layernorm_split(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
-                       void* hi, void* lo, void* stream);
+                       void* hl, void* stream);
 /* softmax(dim=-1) in place over rows of a [rows][ld] matrix (n valid columns). */
 int pp_softmax_rows(float* x, int rows, int n, int ld, void* stream);
 /* nn.GroupNorm(groups, C, eps) (+ReLU when relu != 0) on an NHWC tensor (B, HW, C). */

@@ -33,9 +33,9 @@ class PpGemmDesc(ctypes.Structure):
         ("conv_w", ctypes.c_int), ("conv_ho", ctypes.c_int), ("conv_wo", ctypes.c_int),
         ("conv_bstride", ctypes.c_longlong),
         ("shuffle_r", ctypes.c_int), ("shuffle_h", ctypes.c_int), ("shuffle_w", ctypes.c_int),
-        ("prec", ctypes.c_int), ("B_hi", ctypes.c_void_p), ("B_lo", ctypes.c_void_p), ("b_scale", ctypes.c_float), ("A_hi", ctypes.c_void_p), ("A_lo", ctypes.c_void_p),
-        ("a_plane_bytes", ctypes.c_longlong), ("b_plane_bytes", ctypes.c_longlong),
-        ("C_hi", ctypes.c_void_p), ("C_lo", ctypes.c_void_p), ("ldc_h", ctypes.c_int), ("c_relu", ctypes.c_int),
+        ("prec", ctypes.c_int), ("B_hl", ctypes.c_void_p), ("b_scale", ctypes.c_float), ("A_hl", ctypes.c_void_p),
+        ("a_hl_bytes", ctypes.c_longlong), ("b_hl_bytes", ctypes.c_longlong),
+        ("C_hl", ctypes.c_void_p), ("ldc_h", ctypes.c_int), ("c_relu", ctypes.c_int),
     ]
 
 
@@ -80,13 +80,13 @@ def lib():
         L.pp_stage3_correspondences.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp]
         L.pp_gather_valid.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
         L.pp_gemm.argtypes = [c.POINTER(PpGemmDesc), vp]
-        L.pp_split_f16x3.argtypes = [vp, c.c_longlong, vp, vp, vp, vp]
-        L.pp_split_activation.argtypes = [vp, c.c_longlong, i32, i32, i32, i32, i32, vp, vp, vp]
+        L.pp_split_f16x3.argtypes = [vp, c.c_longlong, vp, vp, vp]
+        L.pp_split_activation.argtypes = [vp, c.c_longlong, i32, i32, i32, i32, i32, vp, vp]
         L.pp_attention.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
-        L.pp_attention_split.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]
-        L.pp_attention_ex.argtypes = [vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp]
+        L.pp_attention_split.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, vp]
+        L.pp_attention_ex.argtypes = [vp, i32, i32, i32, i32, f32, i32, vp, vp, vp]
         L.pp_layernorm.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp]
-        L.pp_layernorm_split.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
+        L.pp_layernorm_split.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp]
         L.pp_softmax_rows.argtypes = [vp, i32, i32, i32, vp]
         L.pp_groupnorm_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp]
         L.pp_transpose_batched.argtypes = [vp, c.c_longlong, i32, i32, i32, vp, c.c_longlong, i32, i32, vp]

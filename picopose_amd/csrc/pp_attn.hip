@@ -22,8 +22,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int HD = 64, KC = 32, KLD = 68;  // head dim, keys per chunk, floats per LDS row of the K chunk
 
 __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv, int T, int heads, float scale,
-                                                   float* __restrict__ out, _Float16* __restrict__ out_hi,
-                                                   _Float16* __restrict__ out_lo) {
+                                                   float* __restrict__ out, _Float16* __restrict__ out_hl) {
     __shared__ __attribute__((aligned(16))) float Ks[KC * KLD];
     __shared__ __attribute__((aligned(16))) float Vs[KC * HD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -123,14 +122,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
                 out[obase + d] = a0;
                 out[obase + 32 + d] = a1;
             }
-            if (out_hi) {  // f16x3 operand planes of the output projection
+            if (out_hl) {  // f16x3 operand of the output projection (obase is a multiple of 8)
                 _Float16 hh, ll;
                 pp_split_f16(a0, hh, ll);
-                out_hi[obase + d] = hh;
-                out_lo[obase + d] = ll;
+                out_hl[2 * obase + pp_hl_col(d, 0)] = hh;
+                out_hl[2 * obase + pp_hl_col(d, 1)] = ll;
                 pp_split_f16(a1, hh, ll);
-                out_hi[obase + 32 + d] = hh;
-                out_lo[obase + 32 + d] = ll;
+                out_hl[2 * obase + pp_hl_col(32 + d, 0)] = hh;
+                out_hl[2 * obase + pp_hl_col(32 + d, 1)] = ll;
             }
         }
     }
@@ -160,8 +159,7 @@ __device__ __forceinline__ int vt_slot(int key) {  // key (0..31) of a chunk -> 
 }
 
 __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict__ qkv, int T, int heads, float scale,
-                                                         float* __restrict__ out, _Float16* __restrict__ out_hi,
-                                                         _Float16* __restrict__ out_lo) {
+                                                         float* __restrict__ out, _Float16* __restrict__ out_hl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Kh = (_Float16*)smem;            // [KC][KHLD]
     _Float16* Kl = Kh + KC * KHLD;
@@ -303,7 +301,7 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
         for (int j = 0; j < 8; ++j) {
             const f4 v = *(const f4*)(src + 4 * j);
             if (out) *(f4*)(out + obase + 4 * j) = v;
-            if (out_hi) {
+            if (out_hl) {  // columns obase + 4 j .. + 3 (obase % 32 == 0): half a group of 8
                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                 h4 hh, ll;
 #pragma unroll
@@ -313,8 +311,9 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
                     hh[i] = a;
                     ll[i] = c;
                 }
-                *(h4*)(out_hi + obase + 4 * j) = hh;
-                *(h4*)(out_lo + obase + 4 * j) = ll;
+                _Float16* hp = out_hl + 2 * obase + pp_hl_col(4 * j, 0);
+                *(h4*)hp = hh;
+                *(h4*)(hp + 8) = ll;
             }
         }
     }
@@ -325,8 +324,8 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
 extern "C" {
 
 static int attention_launch(const float* qkv, int B, int T, int heads, int head_dim, float scale, int prec, float* out,
-                            void* out_hi, void* out_lo, void* stream) {
-    if (!qkv || (!out && !out_hi) || (out_hi && !out_lo) || B <= 0 || T <= 0 || heads <= 0) return PP_EINVAL;
+                            void* out_hl, void* stream) {
+    if (!qkv || (!out && !out_hl) || B <= 0 || T <= 0 || heads <= 0) return PP_EINVAL;
     if (head_dim != HD || ((uintptr_t)qkv % 16) != 0) return PP_EINVAL;
     if (prec == PP_PREC_F16X3) {
         // waves per workgroup: the split of the ceil(T/32) query tiles that wastes the fewest wave slots
@@ -341,29 +340,29 @@ static int attention_launch(const float* qkv, int B, int T, int heads, int head_
         }
         const size_t kv = (size_t)(2 * KC * KHLD + 2 * HD * VTLD) * sizeof(_Float16), os = (size_t)wpb * 32 * OLD * sizeof(float);
         hipLaunchKernelGGL(attn_f16x3_kernel, dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
-                           (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hi, (_Float16*)out_lo);
+                           (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl);
     } else {
         hipLaunchKernelGGL(attn_kernel, dim3((T + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, qkv, T, heads,
-                           scale, out, (_Float16*)out_hi, (_Float16*)out_lo);
+                           scale, out, (_Float16*)out_hl);
     }
     return pp_last_launch();
 }
 
 int pp_attention(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* stream) {
     if (!out) return PP_EINVAL;
-    return attention_launch(qkv, B, T, heads, head_dim, scale, PP_PREC_F32, out, nullptr, nullptr, stream);
+    return attention_launch(qkv, B, T, heads, head_dim, scale, PP_PREC_F32, out, nullptr, stream);
 }
 
-int pp_attention_split(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* out_hi,
-                       void* out_lo, void* stream) {
-    if (!out_hi) return PP_EINVAL;
-    return attention_launch(qkv, B, T, heads, head_dim, scale, PP_PREC_F32, out, out_hi, out_lo, stream);
+int pp_attention_split(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* out_hl,
+                       void* stream) {
+    if (!out_hl) return PP_EINVAL;
+    return attention_launch(qkv, B, T, heads, head_dim, scale, PP_PREC_F32, out, out_hl, stream);
 }
 
-int pp_attention_ex(const float* qkv, int B, int T, int heads, int head_dim, float scale, int prec, float* out, void* out_hi,
-                    void* out_lo, void* stream) {
+int pp_attention_ex(const float* qkv, int B, int T, int heads, int head_dim, float scale, int prec, float* out, void* out_hl,
+                    void* stream) {
     if (prec != PP_PREC_F32 && prec != PP_PREC_F16X3) return PP_EINVAL;
-    return attention_launch(qkv, B, T, heads, head_dim, scale, prec, out, out_hi, out_lo, stream);
+    return attention_launch(qkv, B, T, heads, head_dim, scale, prec, out, out_hl, stream);
 }
 
 }  // extern "C"

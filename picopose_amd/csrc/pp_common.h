@@ -17,6 +17,9 @@ __device__ __forceinline__ void pp_split_f16(float v, _Float16& hi, _Float16& lo
     lo = (_Float16)fminf(fmaxf(x - (float)hi, -65504.f), 65504.f);
 }
 
+// "hl" operand format (include/picopose_hip.h): half index of element (k, term p) inside a row
+__device__ __forceinline__ int pp_hl_col(int k, int p) { return ((k >> 3) << 4) + (p << 3) + (k & 7); }
+
 static inline int pp_last_launch() { return hipGetLastError() == hipSuccess ? PP_OK : PP_ELAUNCH; }
 
 

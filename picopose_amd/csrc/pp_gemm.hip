@@ -102,7 +102,7 @@ __device__ __forceinline__ f4 load_a(const PpGemmDesc& d, const float* __restric
 // OCC = workgroups per CU the register allocation is held to: the 128x128 tile runs ~10 % faster per tile at 2
 // (no spills, 200 VGPRs) than at 3 (168 VGPRs); which one wins depends on how the tile count fills the slots.
 // Store one output element: out = residual + residual2 + v at (m, n) of C (row-major, or the pixel-shuffled layout
-// of a ConvTranspose2d(kernel = stride = r)), and/or its f16x3 operand planes (C_hi / C_lo, [M][ldc_h], with the
+// of a ConvTranspose2d(kernel = stride = r)), and/or as the f16x3 "hl" operand C_hl ([M][ldc_h], with the
 // consumer's input ReLU folded in) so the next GEMM needs no separate split pass.
 __device__ __forceinline__ void epilogue_store(const PpGemmDesc& d, float* C, const float* R, const float* R2, int m, int n,
                                                float v) {
@@ -120,12 +120,12 @@ __device__ __forceinline__ void epilogue_store(const PpGemmDesc& d, float* C, co
     if (R) v += R[off];
     if (R2) v += R2[off];
     if (C) C[off] = v;
-    if (d.C_hi) {
+    if (d.C_hl) {
         _Float16 h, l;
         pp_split_f16(d.c_relu ? fmaxf(v, 0.f) : v, h, l);
-        const size_t ho = (size_t)m * d.ldc_h + n;
-        ((_Float16*)d.C_hi)[ho] = h;
-        ((_Float16*)d.C_lo)[ho] = l;
+        _Float16* hp = (_Float16*)d.C_hl + (size_t)m * 2 * d.ldc_h + pp_hl_col(n, 0);
+        hp[0] = h;
+        hp[8] = l;
     }
 }
 
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(const PpGemmDesc d) {
 // chosen to put the bulk of the data above 2^-3: activations s_a = 4 (|v| up to 16376 before hi saturates;
 // no NaN, the excess stays in lo), weights s_b = 2^k per tensor with max |s_b w| in [512, 1024).  The result
 // is multiplied by 1/(s_a s_b) in the epilogue (exact).  Three MFMAs at 16x the fp32-MFMA rate.  Weights
-// can be handed over pre-split (d.B_hi / d.B_lo / d.b_scale from pp_split_f16x3).
+// can be handed over pre-split (d.B_hl / d.b_scale from pp_split_f16x3).
 // LDS: hi/lo planes of [rows][32 k] halfs with an 80-byte row stride (conflict-free ds_read_b128).
 // ---------------------------------------------------------------------------
 constexpr float A_SCALE = PP_A_SCALE;  // activation operand scale of the f16x3 engine
@@ -323,8 +323,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const PpGemmDesc d
     const float* A = d.A + (size_t)z0 * d.a_bs0 + (size_t)z1 * d.a_bs1;
     const float* Bm = d.B + (size_t)z0 * d.b_bs0 + (size_t)z1 * d.b_bs1;
     constexpr bool bsplit = BSPLIT;  // pre-split weights: [N][ldb] halfs, no batch
-    const _Float16* Bhg = (const _Float16*)d.B_hi;
-    const _Float16* Blg = (const _Float16*)d.B_lo;
+    const _Float16* Bhl = (const _Float16*)d.B_hl;
     float* C = d.C + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1;
     const float* R = d.residual ? d.residual + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1 : nullptr;
     const float* R2 = d.residual2 ? d.residual2 + (size_t)z0 * d.c_bs0 + (size_t)z1 * d.c_bs1 : nullptr;
@@ -397,9 +396,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const PpGemmDesc d
             const int n = n0 + AROW(j);
             if (bsplit) {
                 h4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
-                if (n < d.N && k < d.K) {  // K % 4 == 0 is checked on the host for pre-split weights
-                    vh = *(const h4*)(Bhg + (size_t)n * d.ldb + k);
-                    vl = *(const h4*)(Blg + (size_t)n * d.ldb + k);
+                if (n < d.N && k < d.K) {  // K % 8 == 0 is checked on the host for pre-split weights
+                    const _Float16* bp = Bhl + (size_t)n * 2 * d.ldb + pp_hl_col(k, 0);
+                    vh = *(const h4*)bp;
+                    vl = *(const h4*)(bp + 8);
                 }
                 rbh[BSPLIT ? j : 0] = vh;
                 rbl[BSPLIT ? j : 0] = vl;
@@ -529,10 +529,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     // operand planes are read with raw buffer loads: an out-of-range offset (0xFFFFFFFF for the padded taps,
     // the row / column / K tails) returns zeros, so the loads need neither branches nor selects
-    const __amdgpu_buffer_rsrc_t Ahr = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hi, 0, (int)d.a_plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Alr = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_lo, 0, (int)d.a_plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Bhr = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hi, 0, (int)d.b_plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Blr = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_lo, 0, (int)d.b_plane_bytes, 0x00020000);
+    // hl operands: element offset e of the fp32 view (a multiple of 8) -> byte 4 e, hi term; lo term 16 bytes on
+    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
 
     // this thread's slots: rows r0 + 64 j, chunk (tid & 3) = 8 consecutive k starting at k8
     const int r0 = tid >> 2, k8 = (tid & 3) * 8;
@@ -577,7 +576,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + r0 + 64 * j;
-        boff[j] = n < d.N ? (unsigned)(((long long)n * d.ldb + k8) * 2) : 0xFFFFFFFFu;
+        boff[j] = n < d.N ? (unsigned)(((long long)n * d.ldb + k8) * 4) : 0xFFFFFFFFu;
     }
 
     f32x16 acc[2][NJ];
@@ -598,16 +597,18 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
         const bool kin = kcur < d.K;  // tiles past the end read zeros (never consumed)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const unsigned off = (aval[j] && kin) ? (unsigned)(aoff[j] * 2) : 0xFFFFFFFFu;
-            sg.ah[j] = __builtin_amdgcn_raw_buffer_load_b128(Ahr, off, 0, 0);
-            sg.al[j] = __builtin_amdgcn_raw_buffer_load_b128(Alr, off, 0, 0);
+            const bool ok = aval[j] && kin;
+            const unsigned off = ok ? (unsigned)(aoff[j] * 4) : 0xFFFFFFFFu;
+            sg.ah[j] = __builtin_amdgcn_raw_buffer_load_b128(Ar, off, 0, 0);
+            sg.al[j] = __builtin_amdgcn_raw_buffer_load_b128(Ar, ok ? off + 16 : off, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const unsigned off = kin ? boff[j] : 0xFFFFFFFFu;
-            sg.bh[j] = __builtin_amdgcn_raw_buffer_load_b128(Bhr, off, 0, 0);
-            sg.bl[j] = __builtin_amdgcn_raw_buffer_load_b128(Blr, off, 0, 0);
-            boff[j] = boff[j] == 0xFFFFFFFFu ? boff[j] : boff[j] + 2 * BK;
+            const bool ok = kin && boff[j] != 0xFFFFFFFFu;
+            const unsigned off = ok ? boff[j] : 0xFFFFFFFFu;
+            sg.bh[j] = __builtin_amdgcn_raw_buffer_load_b128(Br, off, 0, 0);
+            sg.bl[j] = __builtin_amdgcn_raw_buffer_load_b128(Br, ok ? off + 16 : off, 0, 0);
+            boff[j] = boff[j] == 0xFFFFFFFFu ? boff[j] : boff[j] + 4 * BK;
         }
         kcur += BK;
         if (d.conv_kh == 0) {
@@ -725,19 +726,27 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
 // f16x3, both operands pre-split, LARGE problems: 256x128 block tile, 8 waves (4 x 2, 64x64 each), one
 // workgroup per CU.  The operand tiles go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging
 // registers, no ds_write pass (the VGPR->LDS store path was the busiest unit of the register-staged kernel).
-//   - LDS ring of 3 stages x 48 KB (A hi/lo 256x32, B hi/lo 128x32 halfs; 64-byte rows); an LDS-DMA wave
-//     instruction fills 1 KB = 16 rows lane-linearly, so the bank swizzle (chunk c of row r at position
-//     c ^ ((r >> 2) & 3)) is applied to the per-lane SOURCE address;
-//   - two K tiles in flight across the barrier: counted `s_waitcnt vmcnt(6)` (6 DMA per wave per tile) retires
-//     tile t, the raw s_barrier publishes it (and proves tile t-1 is no longer read), then tile t+2 is issued
-//     into the stage tile t-1 occupied and the MFMAs of tile t run; one barrier per K tile;
+//   - hl operands: a K tile of 32 is ONE 128-byte segment per row (hi and lo terms interleaved per 8 k), so an
+//     LDS-DMA wave instruction (1 KB) moves 8 full cache lines; with separate hi / lo planes the same bytes were
+//     64-byte segments and the L2 -> LDS delivery (tools/dma_probe.hip: 12.6 vs 18.8 TB/s), not the MFMAs, set
+//     the pace of the K loop;
+//   - LDS ring of 3 stages x 48 KB (A 256 rows, B 128 rows of 128 bytes); a DMA instruction fills 8 rows
+//     lane-linearly, so the bank swizzle (16-byte chunk c of row r at position c ^ ((r >> 1) & 7): conflict-free
+//     ds_read_b128 fragments) is applied to the per-lane SOURCE address;
+//   - two K tiles in flight across the barrier: in the middle of iteration t — after the second-half fragments
+//     of tile t are in registers — a counted `s_waitcnt vmcnt(6)` (6 DMA per wave per tile) retires this wave's
+//     loads of tile t+1, the raw s_barrier publishes it and frees tile t's stage, tile t+3 is issued into it and
+//     the first-half fragments of tile t+1 are read while the second-half MFMAs of tile t run; one barrier per tile;
 //   - padded taps / row, column and K tails: an out-of-range buffer offset makes the DMA write zeros;
-//   - workgroup ids are remapped so the column tiles of one row tile (which share the A rows) and neighbouring
-//     row tiles (3x3 halo) run on the same XCD and hit its L2.
+//   - convolutions with Cin % 32 == 0 walk K channel-slice-major (all taps of a 32-channel slice back to back:
+//     the taps re-read L2-resident pixels); only the fp32 summation order differs;
+//   - workgroup ids are remapped bijectively so the column tiles of one row tile (which share the A rows) and
+//     neighbouring row tiles (3x3 halo) run on the same XCD and hit its L2.
 // ---------------------------------------------------------------------------
 constexpr int GBM = 256, GBN = 128;
-constexpr int G_PLANE_A = GBM * 32, G_PLANE_B = GBN * 32;      // halfs per plane
-constexpr int G_STAGE = 2 * G_PLANE_A + 2 * G_PLANE_B;         // 24576 halfs = 48 KB
+constexpr int G_ROWH = 64;                                      // halfs per LDS row: 32 k x (hi, lo)
+constexpr int G_A_H = GBM * G_ROWH, G_B_H = GBN * G_ROWH;        // halfs per operand per stage
+constexpr int G_STAGE = G_A_H + G_B_H;                          // 24576 halfs = 48 KB
 constexpr int G_STAGES = 3;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -750,21 +759,22 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
     const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int m0 = (wg / gx) * GBM, n0 = (wg % gx) * GBN;
-    const __amdgpu_buffer_rsrc_t Ahr = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hi, 0, (int)d.a_plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Alr = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_lo, 0, (int)d.a_plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Bhr = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hi, 0, (int)d.b_plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Blr = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_lo, 0, (int)d.b_plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
 
-    // loader slots of this lane: A rows (q*8 + w)*16 + (lane >> 2), q = 0, 1; B row w*16 + (lane >> 2); LDS chunk
-    // position lane & 3 holds source chunk (lane & 3) ^ ((row >> 2) & 3) (the same for all three rows)
-    const int lr = lane >> 2;
-    const int k8 = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
-    int aoy[2], aox[2];
-    long long abase[2];
-    bool arow_ok[2];
+    // DMA slots of this lane: instruction q of the wave fills rows (q*8 + w)*8 + (lane >> 3) (A: q = 0..3, B: q = 0, 1);
+    // LDS chunk position lane & 7 holds source chunk sc = (lane & 7) ^ ((row >> 1) & 7) — the same for all six rows —
+    // = term (sc & 1) of the 8 k starting at 8 (sc >> 1)
+    const int lr = lane >> 3;
+    const int sc = (lane & 7) ^ ((((w & 1) << 2) + (lr >> 1)) & 7);
+    const int k8 = (sc >> 1) * 8;                // first k of this lane's chunk inside a K tile
+    const unsigned pbyte = (unsigned)(sc & 1) * 16;  // hi / lo term: byte offset inside the 32-byte group
+    int aoy[4], aox[4];
+    long long abase[4];
+    bool arow_ok[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = m0 + (j * 8 + w) * 16 + lr;
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + (j * 8 + w) * 8 + lr;
         arow_ok[j] = m < d.M;
         aoy[j] = aox[j] = 0;
         abase[j] = arow_ok[j] ? (long long)m * d.lda : 0;
@@ -776,12 +786,18 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
             abase[j] = (long long)bi * d.conv_bstride + ((long long)aoy[j] * d.conv_w + aox[j]) * d.lda;
         }
     }
+    // natural K order (k = (ky*kw + kx)*Cin + ci): per-lane tap / channel of k = k0 + k8, refreshed when the tap moves
     int tky = 0, tkx = 0, tci = 0;
-    long long aoff[2] = {abase[0] + k8, abase[1] + k8};
-    bool aval[2] = {arow_ok[0], arow_ok[1]};
+    long long aoff[4];
+    bool aval[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        aoff[j] = abase[j] + k8;
+        aval[j] = arow_ok[j];
+    }
     auto refresh_tap = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const int iy = aoy[j] + tky, ix = aox[j] + tkx;
             aval[j] = arow_ok[j] && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w;
             aoff[j] = abase[j] + (long long)(tky * d.conv_w + tkx) * d.lda + tci;
@@ -794,24 +810,25 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
         tkx = tap - tky * d.conv_kw;
         refresh_tap();
     }
-    const int nb = n0 + w * 16 + lr;
-    unsigned boff = nb < d.N ? (unsigned)(((long long)nb * d.ldb + k8) * 2) : 0xFFFFFFFFu;
-    // Convolutions with Cin % 32 == 0 walk K channel-tile-major: for each 32-channel slice all kh*kw taps back to
-    // back.  The taps of one slice re-read the same pixels shifted by a row or a column, so all but the first are
-    // L2 hits (tap-major order re-reads them Cin/32 tiles later, after the L2 has turned over).  Only the fp32
-    // summation order differs.  Per row: a bit mask of the taps that fall inside the image.
+    unsigned boff[2];  // byte offset of this lane's B chunks (0xFFFFFFFF: column past N)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nb = n0 + (j * 8 + w) * 8 + lr;
+        boff[j] = nb < d.N ? (unsigned)(((long long)nb * d.ldb + k8) * 4) + pbyte : 0xFFFFFFFFu;
+    }
+    // channel-slice-major K order for convolutions with Cin % 32 == 0: per row a bit mask of the taps inside the image
     const int ntaps = d.conv_kh * d.conv_kw;
     const bool cmajor = d.conv_kh != 0 && d.conv_cin % BK == 0 && ntaps <= 32;
-    unsigned vmask[2] = {0u, 0u}, abyte[2] = {0u, 0u};
-    const unsigned bbyte = boff;
+    unsigned vmask[4] = {0u, 0u, 0u, 0u}, abyte[4] = {0u, 0u, 0u, 0u};
+    const unsigned bbyte[2] = {boff[0], boff[1]};
     if (cmajor) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 4; ++j) {
             for (int t = 0; t < ntaps; ++t) {
                 const int iy = aoy[j] + t / d.conv_kw, ix = aox[j] + t % d.conv_kw;
                 if (arow_ok[j] && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) vmask[j] |= 1u << t;
             }
-            abyte[j] = (unsigned)((abase[j] + k8) * 2);
+            abyte[j] = (unsigned)((abase[j] + k8) * 4) + pbyte;
         }
     }
     int ctap = 0, cky = 0, ckx = 0, cci = 0;  // wave-uniform position of the next tile in channel-major order
@@ -830,18 +847,18 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
         _Float16* st = glds + stage * G_STAGE;
         if (cmajor) {
             const bool kin = cci < d.conv_cin;
-            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci) * 2);
+            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned off = (((vmask[j] >> ctap) & 1u) && kin) ? abyte[j] + tapoff : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(st + ((j * 8 + w) * 8) * G_ROWH), 16, off, 0, 0, 0);
+            }
+            const unsigned koff = (unsigned)((ctap * d.conv_cin + cci) * 4);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const unsigned off = (((vmask[j] >> ctap) & 1u) && kin) ? abyte[j] + tapoff : 0xFFFFFFFFu;
-                _Float16* dst = st + ((j * 8 + w) * 16) * 32;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(Ahr, (lds_ptr_t)dst, 16, off, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(Alr, (lds_ptr_t)(dst + G_PLANE_A), 16, off, 0, 0, 0);
+                const unsigned off = (kin && bbyte[j] != 0xFFFFFFFFu) ? bbyte[j] + koff : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(st + G_A_H + ((j * 8 + w) * 8) * G_ROWH), 16, off, 0, 0, 0);
             }
-            const unsigned off = (kin && bbyte != 0xFFFFFFFFu) ? bbyte + (unsigned)((ctap * d.conv_cin + cci) * 2) : 0xFFFFFFFFu;
-            _Float16* dst = st + 2 * G_PLANE_A + (w * 16) * 32;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(Bhr, (lds_ptr_t)dst, 16, off, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(Blr, (lds_ptr_t)(dst + G_PLANE_B), 16, off, 0, 0, 0);
             ++ctap;
             if (++ckx == d.conv_kw) {
                 ckx = 0;
@@ -853,25 +870,22 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
             }
             return;
         }
-        const bool kin = kcur < d.K;
+        const bool kin = kcur < d.K;  // tiles past the end read zeros (never consumed)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned off = (aval[j] && kin) ? (unsigned)(aoff[j] * 4) + pbyte : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(st + ((j * 8 + w) * 8) * G_ROWH), 16, off, 0, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const unsigned off = (aval[j] && kin) ? (unsigned)(aoff[j] * 2) : 0xFFFFFFFFu;
-            _Float16* dst = st + ((j * 8 + w) * 16) * 32;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(Ahr, (lds_ptr_t)dst, 16, off, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(Alr, (lds_ptr_t)(dst + G_PLANE_A), 16, off, 0, 0, 0);
-        }
-        {
-            const unsigned off = kin ? boff : 0xFFFFFFFFu;
-            _Float16* dst = st + 2 * G_PLANE_A + (w * 16) * 32;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(Bhr, (lds_ptr_t)dst, 16, off, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(Blr, (lds_ptr_t)(dst + G_PLANE_B), 16, off, 0, 0, 0);
-            boff = boff == 0xFFFFFFFFu ? boff : boff + 2 * BK;
+            const unsigned off = kin ? boff[j] : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(st + G_A_H + ((j * 8 + w) * 8) * G_ROWH), 16, off, 0, 0, 0);
+            boff[j] = boff[j] == 0xFFFFFFFFu ? boff[j] : boff[j] + 4 * BK;
         }
         kcur += BK;
         if (d.conv_kh == 0) {
-            aoff[0] += BK;
-            aoff[1] += BK;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) aoff[j] += BK;
         } else {
             tci += BK;
             if (tci >= d.conv_cin) {
@@ -884,28 +898,28 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
                 }
                 refresh_tap();
             } else {
-                aoff[0] += BK;
-                aoff[1] += BK;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) aoff[j] += BK;
             }
         }
     };
-    const int sw = (l31 >> 2) & 3;
+    const int sw = (l31 >> 1) & 7;  // read-side swizzle of this lane's rows (tile row offsets are multiples of 16)
     struct Frag {
         h8 ah[2], al[2], bh[2], bl[2];
     };
     // fragments of K half `ks` (16 k) of the tile in ring stage `stage`: 8 conflict-free ds_read_b128
     auto load_frag = [&](Frag& f, int stage, int ks) __attribute__((always_inline)) {
         const _Float16* st = glds + stage * G_STAGE;
-        const int ch = ((ks * 2 + lh) ^ sw) * 8;
+        const int ch = (((ks * 2 + lh) * 2) ^ sw) * 8, cl = (((ks * 2 + lh) * 2 + 1) ^ sw) * 8;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            f.ah[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * 32 + ch);
-            f.al[i] = *(const h8*)(st + G_PLANE_A + (wr * 64 + i * 32 + l31) * 32 + ch);
+            f.ah[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * G_ROWH + ch);
+            f.al[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * G_ROWH + cl);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f.bh[j] = *(const h8*)(st + 2 * G_PLANE_A + (wc * 64 + j * 32 + l31) * 32 + ch);
-            f.bl[j] = *(const h8*)(st + 2 * G_PLANE_A + G_PLANE_B + (wc * 64 + j * 32 + l31) * 32 + ch);
+            f.bh[j] = *(const h8*)(st + G_A_H + (wc * 64 + j * 32 + l31) * G_ROWH + ch);
+            f.bl[j] = *(const h8*)(st + G_A_H + (wc * 64 + j * 32 + l31) * G_ROWH + cl);
         }
     };
     auto mma = [&](const Frag& f) __attribute__((always_inline)) {
@@ -918,11 +932,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
             }
     };
-    // Ring: tile t lives in stage t % 3.  Iteration t holds tile t (being read), t+1 and t+2 (DMA in flight).  In the
-    // middle of the iteration — after the second-half fragments of tile t are in registers — `vmcnt(6)` retires
-    // this wave's loads of tile t+1 (tile t+2's six stay in flight), the barrier publishes tile t+1 and frees
-    // tile t's stage, tile t+3 is issued into it, and the first-half fragments of tile t+1 are read while the
-    // second-half MFMAs of tile t run: the LDS read latency never sits between a barrier and the MFMAs.
+    // Ring: tile t lives in stage t % 3.  Iteration t holds tile t (being read), t+1 and t+2 (DMA in flight).
     const int nk = (d.K + BK - 1) / BK;
     fetch(0);
     fetch(1);
@@ -967,24 +977,32 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
     }
 }
 
-// activation pre-split: x (B, P, C) fp32 with batch / row strides -> contiguous hi, lo planes (B*P, C)
+// activation pre-split: x (B, P, C) fp32 with batch / row strides -> contiguous hl operand (B*P rows, ld = C):
+// one thread = 8 channels = 32 bytes in, 32 contiguous bytes (8 hi + 8 lo) out
 __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict__ x, long long bstride, int P, int ld,
-                                                        int C, long long total4, int relu, _Float16* __restrict__ hi,
-                                                        _Float16* __restrict__ lo) {
-    const int c4n = C >> 2;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
-        const long long row = i / c4n;
-        const int c = (int)(i - row * c4n) * 4;
+                                                        int C, long long total8, int relu, _Float16* __restrict__ hl) {
+    const int c8n = C >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+        const long long row = i / c8n;
+        const int c = (int)(i - row * c8n) * 8;
         const long long b = row / P, p = row - b * P;
-        f4 v = *(const f4*)(x + b * bstride + p * ld + c);
+        const float* xp = x + b * bstride + p * ld + c;
+        f4 v0 = *(const f4*)xp, v1 = *(const f4*)(xp + 4);
         if (relu) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+            for (int k = 0; k < 4; ++k) {
+                v0[k] = v0[k] > 0.f ? v0[k] : 0.f;
+                v1[k] = v1[k] > 0.f ? v1[k] : 0.f;
+            }
         }
-        h4 hh, ll;
-        split_f16x4(v, A_SCALE, hh, ll);
-        *(h4*)(hi + row * C + c) = hh;
-        *(h4*)(lo + row * C + c) = ll;
+        h4 h0, l0, h1, l1;
+        split_f16x4(v0, A_SCALE, h0, l0);
+        split_f16x4(v1, A_SCALE, h1, l1);
+        _Float16* o = hl + row * 2 * C + 2 * c;
+        *(h4*)o = h0;
+        *(h4*)(o + 4) = h1;
+        *(h4*)(o + 8) = l0;
+        *(h4*)(o + 12) = l1;
     }
 }
 
@@ -995,8 +1013,7 @@ __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict_
 // nn.LayerNorm(eps) over the last dimension: one wave per row (model/stage1 block.py:56,68)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ b, int rows, int C, float eps,
-                                                        float* __restrict__ y, _Float16* __restrict__ hi,
-                                                        _Float16* __restrict__ lo) {
+                                                        float* __restrict__ y, _Float16* __restrict__ hl) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (size_t)row * C;
@@ -1016,11 +1033,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int c = lane; c < C; c += 64) {
         const float o = (xr[c] - mean) * rstd * g[c] + b[c];
         if (y) y[(size_t)row * C + c] = o;
-        if (hi) {  // f16x3 operand planes of the following linear layer
+        if (hl) {  // f16x3 operand of the following linear layer
             _Float16 h, l;
             pp_split_f16(o, h, l);
-            hi[(size_t)row * C + c] = h;
-            lo[(size_t)row * C + c] = l;
+            _Float16* hp = hl + (size_t)row * 2 * C + pp_hl_col(c, 0);
+            hp[0] = h;
+            hp[8] = l;
         }
     }
 }
@@ -1149,13 +1167,14 @@ __global__ __launch_bounds__(1024) void absmax_scale_kernel(const float* __restr
 }
 
 __global__ void split_f16x3_kernel(const float* __restrict__ w, long long n, const float* __restrict__ scale,
-                                   _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+                                   _Float16* __restrict__ hl) {
     const float s = scale[0];
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float x = w[i] * s;
         const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
-        hi[i] = h;
-        lo[i] = (_Float16)(x - (float)h);
+        _Float16* p = hl + ((i >> 3) << 4) + (i & 7);  // rows are multiples of 8 long: groups never straddle rows
+        p[0] = h;
+        p[8] = (_Float16)(x - (float)h);
     }
 }
 
@@ -1163,30 +1182,29 @@ __global__ void split_f16x3_kernel(const float* __restrict__ w, long long n, con
 
 extern "C" {
 
-int pp_split_f16x3(const float* w, long long n, void* hi, void* lo, float* scale, void* stream) {
-    if (!w || !hi || !lo || !scale || n <= 0) return PP_EINVAL;
+int pp_split_f16x3(const float* w, long long n, void* hl, float* scale, void* stream) {
+    if (!w || !hl || !scale || n <= 0 || n % 8 != 0) return PP_EINVAL;
     hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, n, scale);
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(split_f16x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, n, scale, (_Float16*)hi,
-                       (_Float16*)lo);
+    hipLaunchKernelGGL(split_f16x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, n, scale, (_Float16*)hl);
     return pp_last_launch();
 }
 
-int pp_split_activation(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu, void* hi,
-                        void* lo, void* stream) {
-    if (!x || !hi || !lo || B <= 0 || P <= 0 || C <= 0 || C % 4 != 0 || row_stride % 4 != 0 || batch_stride % 4 != 0 ||
-        ((uintptr_t)x % 16) != 0)
+int pp_split_activation(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu, void* hl,
+                        void* stream) {
+    if (!x || !hl || B <= 0 || P <= 0 || C <= 0 || C % 8 != 0 || row_stride % 4 != 0 || batch_stride % 4 != 0 ||
+        ((uintptr_t)x % 16) != 0 || ((uintptr_t)hl % 16) != 0)
         return PP_EINVAL;
-    const long long total4 = (long long)B * P * (C / 4);
-    const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+    const long long total8 = (long long)B * P * (C / 8);
+    const int grid = (int)((total8 + 255) / 256 < 8192 ? (total8 + 255) / 256 : 8192);
     hipLaunchKernelGGL(split_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, batch_stride, P, row_stride, C,
-                       total4, relu, (_Float16*)hi, (_Float16*)lo);
+                       total8, relu, (_Float16*)hl);
     return pp_last_launch();
 }
 
 int pp_gemm(const PpGemmDesc* desc, void* stream) {
-    if (!desc || (!desc->A && !desc->A_hi) || !desc->B || (!desc->C && !desc->C_hi)) return PP_EINVAL;
-    if (desc->C_hi && (!desc->C_lo || desc->shuffle_r != 0 || desc->ldc_h < desc->N || desc->batch0 * desc->batch1 != 1))
+    if (!desc || (!desc->A && !desc->A_hl) || !desc->B || (!desc->C && !desc->C_hl)) return PP_EINVAL;
+    if (desc->C_hl && (desc->shuffle_r != 0 || desc->ldc_h < desc->N || desc->ldc_h % 8 != 0 || desc->batch0 * desc->batch1 != 1))
         return PP_EINVAL;
     PpGemmDesc d = *desc;
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch0 <= 0 || d.batch1 <= 0) return PP_EINVAL;
@@ -1204,7 +1222,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         if (imgs * d.conv_bstride >= (1LL << 31)) return PP_EINVAL;
     }
     // 16-byte vector loads need aligned rows: K-contiguous operands with lda/ldb/Cin % 4 == 0
-    bool vec = (d.A_hi || (uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.B % 16 == 0) && d.lda % 4 == 0 &&
+    bool vec = (d.A_hl || (uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.B % 16 == 0) && d.lda % 4 == 0 &&
                (d.b_kn || d.ldb % 4 == 0) && d.a_bs0 % 4 == 0 && d.a_bs1 % 4 == 0 && d.b_bs0 % 4 == 0 &&
                d.b_bs1 % 4 == 0;
     if (d.conv_kh != 0 && (d.conv_cin % 4 != 0 || d.conv_bstride % 4 != 0)) vec = false;
@@ -1220,26 +1238,26 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     const long long rows = (d.M + BM - 1) / BM, z = (long long)d.batch0 * d.batch1;
     hipStream_t st = (hipStream_t)stream;
     const bool split = d.prec == PP_PREC_F16X3 && vec;  // unaligned (tiny) layers stay on the fp32 kernel
-    const bool asplit = d.A_hi != nullptr;
+    const bool asplit = d.A_hl != nullptr;
     if (asplit) {
-        const bool ok = d.A_lo && d.B_hi && d.B_lo && d.prec == PP_PREC_F16X3 && z == 1 && !d.b_kn && !d.relu_in &&
+        const bool ok = d.B_hl && d.prec == PP_PREC_F16X3 && z == 1 && !d.b_kn && !d.relu_in &&
                         d.K % 8 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.b_scale > 0.f &&
                         (d.conv_kh == 0 || (d.conv_cin % 8 == 0 && d.conv_bstride % 8 == 0)) &&
-                        ((uintptr_t)d.A_hi % 16 == 0) && ((uintptr_t)d.A_lo % 16 == 0) && ((uintptr_t)d.B_hi % 16 == 0) &&
-                        ((uintptr_t)d.B_lo % 16 == 0);
+                        ((uintptr_t)d.A_hl % 16 == 0) && ((uintptr_t)d.B_hl % 16 == 0);
         if (!ok) return PP_EINVAL;
-        // extents of the planes for the bounds-checked buffer loads (bytes, < 2 GiB)
+        // extents of the hl buffers for the bounds-checked buffer loads
         const long long a_elems = d.conv_kh != 0
             ? ((long long)((d.M + (long long)d.conv_ho * d.conv_wo - 1) / ((long long)d.conv_ho * d.conv_wo) - 1) * d.conv_bstride +
                (long long)d.conv_h * d.conv_w * d.lda)
             : (long long)(d.M - 1) * d.lda + d.K;
         const long long b_elems = (long long)(d.N - 1) * d.ldb + d.K;
-        if (a_elems * 2 >= (1LL << 31) || b_elems * 2 >= (1LL << 31)) return PP_EINVAL;
-        d.a_plane_bytes = a_elems * 2;
-        d.b_plane_bytes = b_elems * 2;
+        // (32-bit byte offsets; 0xFFFFFFFF is the "reads zero" marker)
+        if (a_elems * 4 >= 0xFFFFFF00LL || b_elems * 4 >= 0xFFFFFF00LL) return PP_EINVAL;
+        d.a_hl_bytes = a_elems * 4;
+        d.b_hl_bytes = b_elems * 4;
     }
-    if (d.B_hi && (!d.B_lo || d.b_kn || d.ldb % 4 != 0 || d.K % 4 != 0 || z != 1 || !(d.b_scale > 0.f))) return PP_EINVAL;
-    if (d.B_hi && !split) d.B_hi = d.B_lo = nullptr;  // unaligned layer: the fp32 kernel reads d.B
+    if (d.B_hl && (d.b_kn || d.ldb % 8 != 0 || d.K % 8 != 0 || z != 1 || !(d.b_scale > 0.f))) return PP_EINVAL;
+    if (d.B_hl && !split) d.B_hl = nullptr;  // unaligned layer: the fp32 kernel reads d.B
     static const bool big_ok = [] {
         return hipFuncSetAttribute((const void*)gemm_f16x3g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    G_STAGES * G_STAGE * 2) == hipSuccess;
@@ -1255,7 +1273,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             if (narrow) hipLaunchKernelGGL((gemm_f16x3s_kernel<1, 3>), grid, dim3(256), 0, st, d);
             else hipLaunchKernelGGL((gemm_f16x3s_kernel<2, 2>), grid, dim3(256), 0, st, d);  // 64 KB LDS: 2 per CU
         } else if (split) {
-            if (d.B_hi) {
+            if (d.B_hl) {
                 if (narrow) hipLaunchKernelGGL((gemm_f16x3_kernel<1, 4, true>), grid, dim3(256), 0, st, d);
                 else if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, true>), grid, dim3(256), 0, st, d);
                 else hipLaunchKernelGGL((gemm_f16x3_kernel<2, 3, true>), grid, dim3(256), 0, st, d);
@@ -1293,7 +1311,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         static std::unordered_map<std::string, int> best;
         char key[160];
         snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%lld.%d.%d.%d.%d.%d.%d", d.M, d.N, d.K, (int)vec, d.b_kn, z, d.conv_kh,
-                 d.conv_cin, d.conv_stride, d.conv_h, d.shuffle_r, (int)split + 2 * (d.B_hi != nullptr) + 4 * (int)asplit);
+                 d.conv_cin, d.conv_stride, d.conv_h, d.shuffle_r, (int)split + 2 * (d.B_hl != nullptr) + 4 * (int)asplit);
         std::lock_guard<std::mutex> lock(mu);
         auto it = best.find(key);
         if (it == best.end()) {
@@ -1348,15 +1366,15 @@ int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows
                  void* stream) {
     if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0) return PP_EINVAL;
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                       rows, C, eps, y, (_Float16*)nullptr, (_Float16*)nullptr);
+                       rows, C, eps, y, (_Float16*)nullptr);
     return pp_last_launch();
 }
 
 int pp_layernorm_split(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
-                       void* hi, void* lo, void* stream) {
-    if (!x || !gamma || !beta || !hi || !lo || rows <= 0 || C <= 0) return PP_EINVAL;
+                       void* hl, void* stream) {
+    if (!x || !gamma || !beta || !hl || rows <= 0 || C <= 0 || C % 8 != 0) return PP_EINVAL;
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                       rows, C, eps, y, (_Float16*)hi, (_Float16*)lo);
+                       rows, C, eps, y, (_Float16*)hl);
     return pp_last_launch();
 }
 

@@ -21,44 +21,41 @@ _split_cache = {}
 
 
 def split_weight(w):
-    """(hi, lo, scale) — fp16 planes and power-of-two scale of a weight matrix for the f16x3 engine; split once per
-    tensor version (one host sync to read the scale back)."""
+    """(hl, scale) — the f16x3 "hl" operand (fp16 (N, 2K): per 8 k the hi then the lo terms) and power-of-two scale
+    of a weight matrix; split once per tensor version (one host sync to read the scale back)."""
     key = (w.data_ptr(), w._version, tuple(w.shape))
     hit = _split_cache.get(key)
     if hit is None:
         assert w.is_contiguous()
-        hi = torch.empty(w.shape, dtype=torch.float16, device=w.device)
-        lo = torch.empty(w.shape, dtype=torch.float16, device=w.device)
+        hl = torch.empty(w.shape[0], 2 * w.shape[1], dtype=torch.float16, device=w.device)
         scale = torch.empty(1, dtype=torch.float32, device=w.device)
-        _lib.check(_lib.lib().pp_split_f16x3(_p(w), w.numel(), _p(hi), _p(lo), _p(scale), _lib.stream_ptr()),
-                   "pp_split_f16x3")
+        _lib.check(_lib.lib().pp_split_f16x3(_p(w), w.numel(), _p(hl), _p(scale), _lib.stream_ptr()), "pp_split_f16x3")
         if len(_split_cache) > 4096:
             _split_cache.clear()
-        hit = _split_cache[key] = (hi, lo, float(scale.item()), w)  # keep w alive so its address is not reused
-    return hit[0], hit[1], hit[2]
+        hit = _split_cache[key] = (hl, float(scale.item()), w)  # keep w alive so its address is not reused
+    return hit[0], hit[1]
 
 
 class Split:
-    """An activation that exists only as the f16x3 engine's operand planes: hi, lo (rows, C) fp16, contiguous.
-    Producers (layernorm, attention, a GEMM epilogue) write it directly, so the consuming GEMM needs no split pass
-    and the fp32 tensor is never stored."""
-    __slots__ = ("hi", "lo")
+    """An activation that exists only as the f16x3 engine's "hl" operand: fp16 (rows, 2C), per 8 channels the 8 hi
+    terms then the 8 lo terms (include/picopose_hip.h).  Producers (layernorm, attention, a GEMM epilogue) write it
+    directly, so the consuming GEMM needs no split pass and the fp32 tensor is never stored."""
+    __slots__ = ("hl",)
 
-    def __init__(self, hi, lo):
-        self.hi, self.lo = hi, lo
+    def __init__(self, hl):
+        self.hl = hl
 
     @property
     def shape(self):
-        return self.hi.shape
+        return torch.Size((self.hl.shape[0], self.hl.shape[1] // 2))
 
     @property
     def device(self):
-        return self.hi.device
+        return self.hl.device
 
     @staticmethod
     def empty(rows, C, device):
-        return Split(torch.empty(rows, C, dtype=torch.float16, device=device),
-                     torch.empty(rows, C, dtype=torch.float16, device=device))
+        return Split(torch.empty(rows, 2 * C, dtype=torch.float16, device=device))
 
 
 def _split_ok(C):
@@ -66,12 +63,11 @@ def _split_ok(C):
 
 
 def split_activation(x, B, P, C, batch_stride, row_stride, relu=False):
-    """Pre-split an activation operand (B, P, C) into contiguous fp16 planes (B*P, C) for the f16x3 engine."""
-    hi = torch.empty(B * P, C, dtype=torch.float16, device=x.device)
-    lo = torch.empty(B * P, C, dtype=torch.float16, device=x.device)
-    _lib.check(_lib.lib().pp_split_activation(_p(x), batch_stride, B, P, row_stride, C, int(relu), _p(hi), _p(lo),
+    """Pre-split an activation operand (B, P, C) into a contiguous hl buffer (B*P, 2C) for the f16x3 engine."""
+    hl = torch.empty(B * P, 2 * C, dtype=torch.float16, device=x.device)
+    _lib.check(_lib.lib().pp_split_activation(_p(x), batch_stride, B, P, row_stride, C, int(relu), _p(hl),
                                               _lib.stream_ptr()), "pp_split_activation")
-    return hi, lo
+    return hl
 
 
 def _can_presplit(x, K, C, *strides):
@@ -81,9 +77,9 @@ def _can_presplit(x, K, C, *strides):
 
 def _weight_args(w, K):
     """desc fields for a weight operand under the current precision (pre-split planes when it is aligned)."""
-    if PRECISION == "f16x3" and K % 4 == 0 and w.data_ptr() % 16 == 0:
-        hi, lo, scale = split_weight(w)
-        return dict(prec=1, B_hi=_p(hi), B_lo=_p(lo), b_scale=scale)
+    if PRECISION == "f16x3" and K % 8 == 0 and w.data_ptr() % 16 == 0:
+        hl, scale = split_weight(w)
+        return dict(prec=1, B_hl=_p(hl), b_scale=scale)
     return dict(prec=_PREC[PRECISION])
 
 
@@ -112,9 +108,9 @@ def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, 
     assert weight.shape[1] == K and weight.is_contiguous()
     wargs = _weight_args(weight, K)
     sargs, ret = {}, None
-    if out_split and "B_hi" in wargs and _split_ok(N) and out is None:
+    if out_split and "B_hl" in wargs and _split_ok(N) and out is None:
         ret = Split.empty(M, N, x.device)
-        sargs = dict(C_hi=_p(ret.hi), C_lo=_p(ret.lo), ldc_h=N)
+        sargs = dict(C_hl=_p(ret.hl), ldc_h=N)
     elif out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     ldc = N if out is None else out.stride(0)
@@ -124,14 +120,14 @@ def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, 
     if residual is not None:
         assert tuple(residual.shape) == (M, N) and residual.stride(1) == 1 and residual.stride(0) == ldc
     if isinstance(x, Split):
-        assert "B_hi" in wargs
-        _run(_desc(A_hi=_p(x.hi), A_lo=_p(x.lo), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual),
+        assert "B_hl" in wargs
+        _run(_desc(A_hl=_p(x.hl), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual),
                    M=M, N=N, K=K, lda=K, ldb=K, ldc=ldc, act=ACT[act], **wargs, **sargs))
         return ret
     assert x.stride(1) == 1
-    if "B_hi" in wargs and N > 64 and _can_presplit(x, K, K, x.stride(0)) and M * K < 2 ** 31:
-        hi, lo = split_activation(x, 1, M, K, 0, x.stride(0), relu=relu_in)      # every column tile reuses the split
-        _run(_desc(A_hi=_p(hi), A_lo=_p(lo), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual),
+    if "B_hl" in wargs and N > 64 and _can_presplit(x, K, K, x.stride(0)) and M * K < 2 ** 31:
+        hl = split_activation(x, 1, M, K, 0, x.stride(0), relu=relu_in)          # every column tile reuses the split
+        _run(_desc(A_hl=_p(hl), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual),
                    M=M, N=N, K=K, lda=K, ldb=K, ldc=ldc, act=ACT[act], **wargs, **sargs))
         return ret
     if sargs:  # the fp32-operand kernels write planes too, but keep this rare path simple: fp32 out + split pass
@@ -206,10 +202,10 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
         if r_ is not None:
             assert r_.stride() == out.stride()
     wargs = _weight_args(wp, ksize * ksize * cin)
-    if ("B_hi" in wargs and (Cout > 64 or ksize > 1) and _can_presplit(x, ksize * ksize * cin, cin, ld_in, x.stride(0))
+    if ("B_hl" in wargs and (Cout > 64 or ksize > 1) and _can_presplit(x, ksize * ksize * cin, cin, ld_in, x.stride(0))
             and B * H * W * cin < 2 ** 31):
-        hi, lo = split_activation(x, B, H * W, cin, x.stride(0), ld_in, relu=relu_in)  # once, not per tap / column tile
-        _run(_desc(A_hi=_p(hi), A_lo=_p(lo), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual),
+        hl = split_activation(x, B, H * W, cin, x.stride(0), ld_in, relu=relu_in)  # once, not per tap / column tile
+        _run(_desc(A_hl=_p(hl), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual),
                    residual2=_p(residual2), conv_bstride=H * W * cin, M=B * Ho * Wo, N=Cout, K=ksize * ksize * cin, lda=cin,
                    ldb=wp.shape[1], ldc=ldc, act=ACT[act], conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride,
                    conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo, **wargs))
@@ -229,9 +225,9 @@ def conv_transpose2d(x, wp, bias_tiled, r):
     Cout = wp.shape[0] // (r * r)
     out = torch.empty(B, H * r, W * r, Cout, dtype=torch.float32, device=x.device)
     wargs = _weight_args(wp, Cin)
-    if "B_hi" in wargs and _can_presplit(x, Cin, Cin) and x.numel() < 2 ** 31:
-        hi, lo = split_activation(x, 1, B * H * W, Cin, 0, Cin)
-        _run(_desc(A_hi=_p(hi), A_lo=_p(lo), B=_p(wp), C=_p(out), bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin,
+    if "B_hl" in wargs and _can_presplit(x, Cin, Cin) and x.numel() < 2 ** 31:
+        hl = split_activation(x, 1, B * H * W, Cin, 0, Cin)
+        _run(_desc(A_hl=_p(hl), B=_p(wp), C=_p(out), bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin,
                    lda=Cin, ldb=Cin, ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W, **wargs))
         return out
     _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin, lda=Cin, ldb=Cin,
@@ -249,7 +245,7 @@ def attention(qkv, B, T, heads, hd, out_split=False):
     else:
         out = torch.empty(B * T, heads * hd, dtype=torch.float32, device=qkv.device)
     _lib.check(_lib.lib().pp_attention_ex(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, _PREC[PRECISION], _p(out),
-                                          _p(sp.hi) if sp else None, _p(sp.lo) if sp else None, _lib.stream_ptr()),
+                                          _p(sp.hl) if sp else None, _lib.stream_ptr()),
                "pp_attention_ex")
     return sp if sp is not None else out
 
@@ -260,7 +256,7 @@ def layernorm(x, weight, bias, eps, out_split=False):
     assert x.is_contiguous()
     if out_split and _split_ok(C):
         sp = Split.empty(rows, C, x.device)
-        _lib.check(_lib.lib().pp_layernorm_split(_p(x), _p(weight), _p(bias), rows, C, float(eps), None, _p(sp.hi), _p(sp.lo),
+        _lib.check(_lib.lib().pp_layernorm_split(_p(x), _p(weight), _p(bias), rows, C, float(eps), None, _p(sp.hl),
                                                  _lib.stream_ptr()), "pp_layernorm_split")
         return sp
     y = torch.empty_like(x)
