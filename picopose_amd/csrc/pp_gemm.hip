@@ -750,7 +750,13 @@ constexpr int G_STAGE = G_A_H + G_B_H;                          // 24576 halfs =
 constexpr int G_STAGES = 3;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-__global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d, int gx, int gy) {
+}  // namespace
+
+// MODE 0: dense A; 1: convolution, channel-slice-major K order (Cin % 32 == 0); 2: convolution, natural K order
+// (external linkage: hipcc does not emit the host-side handle of this templated kernel from the unnamed namespace)
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void pp_gemm_f16x3g_kernel(const PpGemmDesc d, int gx, int gy) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (it cannot instantiate the LDS-DMA builtins)
     extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
             aoff[j] = abase[j] + (long long)(tky * d.conv_w + tkx) * d.lda + tci;
         }
     };
-    if (d.conv_kh != 0) {
+    if (MODE == 2) {
         const int tap = k8 / d.conv_cin;
         tci = k8 - tap * d.conv_cin;
         tky = tap / d.conv_kw;
@@ -818,10 +824,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
     }
     // channel-slice-major K order for convolutions with Cin % 32 == 0: per row a bit mask of the taps inside the image
     const int ntaps = d.conv_kh * d.conv_kw;
-    const bool cmajor = d.conv_kh != 0 && d.conv_cin % BK == 0 && ntaps <= 32;
     unsigned vmask[4] = {0u, 0u, 0u, 0u}, abyte[4] = {0u, 0u, 0u, 0u};
     const unsigned bbyte[2] = {boff[0], boff[1]};
-    if (cmajor) {
+    if (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             for (int t = 0; t < ntaps; ++t) {
@@ -842,48 +847,46 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     int kcur = k8;
-    // issue the 6 LDS-DMA loads of the next K tile into ring stage `stage` (wave-uniform)
-    auto fetch = [&](int stage) __attribute__((always_inline)) {
-        _Float16* st = glds + stage * G_STAGE;
-        if (cmajor) {
-            const bool kin = cci < d.conv_cin;
+    constexpr bool cmajor = MODE == 1;
+    // Offsets of the 6 LDS-DMA pieces of the next K tile (A rows j = 0..3, B rows j = 0, 1), then `advance`.  For
+    // MODE 0 / 1 everything here is straight-line code (selects, no branches), so the K loop body is one basic
+    // block and the pieces can be spread between the MFMAs (an LDS-DMA costs the wave ~60-180 issue cycles: six in
+    // a row right after the barrier stall the matrix pipe of both waves of a SIMD at once).
+    auto off_a = [&](int j) __attribute__((always_inline)) -> unsigned {
+        if (cmajor) {  // (bitwise, not &&: a short-circuit on the wave-uniform term would become a branch)
             const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned off = (((vmask[j] >> ctap) & 1u) && kin) ? abyte[j] + tapoff : 0xFFFFFFFFu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(st + ((j * 8 + w) * 8) * G_ROWH), 16, off, 0, 0, 0);
-            }
-            const unsigned koff = (unsigned)((ctap * d.conv_cin + cci) * 4);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const unsigned off = (kin && bbyte[j] != 0xFFFFFFFFu) ? bbyte[j] + koff : 0xFFFFFFFFu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(st + G_A_H + ((j * 8 + w) * 8) * G_ROWH), 16, off, 0, 0, 0);
-            }
-            ++ctap;
-            if (++ckx == d.conv_kw) {
-                ckx = 0;
-                if (++cky == d.conv_kh) {
-                    cky = 0;
-                    ctap = 0;
-                    cci += BK;
-                }
-            }
+            const unsigned ok = (vmask[j] >> ctap) & (cci < d.conv_cin ? 1u : 0u);
+            return (abyte[j] + tapoff) | (ok - 1u);  // ok = 0 -> 0xFFFFFFFF (plain ALU: `?:` here compiles to exec-masked blocks)
+        }
+        const unsigned ok = (aval[j] ? 1u : 0u) & (kcur < d.K ? 1u : 0u);
+        return ((unsigned)(aoff[j] * 4) + pbyte) | (ok - 1u);
+    };
+    auto off_b = [&](int j) __attribute__((always_inline)) -> unsigned {
+        if (cmajor) {
+            const unsigned ok = (cci < d.conv_cin ? 1u : 0u) & (bbyte[j] != 0xFFFFFFFFu ? 1u : 0u);
+            return (bbyte[j] + (unsigned)((ctap * d.conv_cin + cci) * 4)) | (ok - 1u);
+        }
+        return boff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+    };
+    auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * G_STAGE + ((j * 8 + w) * 8) * G_ROWH), 16, off_a(j), 0, 0, 0);
+    };
+    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * G_STAGE + G_A_H + ((j * 8 + w) * 8) * G_ROWH), 16, off_b(j), 0, 0, 0);
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (cmajor) {
+            const bool row_end = ckx + 1 == d.conv_kw, tap_end = row_end && cky + 1 == d.conv_kh;
+            ckx = row_end ? 0 : ckx + 1;
+            cky = tap_end ? 0 : (row_end ? cky + 1 : cky);
+            ctap = tap_end ? 0 : ctap + 1;
+            cci = tap_end ? cci + BK : cci;
             return;
         }
-        const bool kin = kcur < d.K;  // tiles past the end read zeros (never consumed)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned off = (aval[j] && kin) ? (unsigned)(aoff[j] * 4) + pbyte : 0xFFFFFFFFu;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(st + ((j * 8 + w) * 8) * G_ROWH), 16, off, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned off = kin ? boff[j] : 0xFFFFFFFFu;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(st + G_A_H + ((j * 8 + w) * 8) * G_ROWH), 16, off, 0, 0, 0);
-            boff[j] = boff[j] == 0xFFFFFFFFu ? boff[j] : boff[j] + 4 * BK;
-        }
+        for (int j = 0; j < 2; ++j) boff[j] = boff[j] == 0xFFFFFFFFu ? boff[j] : boff[j] + 4 * BK;
         kcur += BK;
-        if (d.conv_kh == 0) {
+        if (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) aoff[j] += BK;
         } else {
@@ -902,6 +905,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
                 for (int j = 0; j < 4; ++j) aoff[j] += BK;
             }
         }
+    };
+    auto fetch = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_a(stage, j);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma_b(stage, j);
+        advance();
     };
     const int sw = (l31 >> 1) & 7;  // read-side swizzle of this lane's rows (tile row offsets are multiples of 16)
     struct Frag {
@@ -942,14 +952,53 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
     Frag f0, f1;
     load_frag(f0, 0, 0);
     int cur = 0, nxt = 1;  // ring stage of tile kt / of tile kt + 1
+    // one accumulator tile (i, j): the three MFMAs of the f16x3 product
+    auto mma1 = [&](const Frag& f, int i, int j) __attribute__((always_inline)) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+    };
     for (int kt = 0; kt < nk; ++kt) {
         load_frag(f1, cur, 1);
         mma(f0);
         asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        fetch(cur);  // tile kt + 3 (tiles past the end: zeros, never used)
-        load_frag(f0, nxt, 0);
-        mma(f1);
+        if (MODE == 2) {
+            fetch(cur);  // tile kt + 3 (tiles past the end: zeros, never used)
+            load_frag(f0, nxt, 0);
+            mma(f1);
+        } else {
+            // The 6 DMA pieces of tile kt + 3 and the 8 fragment reads of the next half tile spread over the 12
+            // MFMAs of this half (order pinned: hipcc would issue all DMA pieces first)
+            const _Float16* st = glds + nxt * G_STAGE;
+            const int ch = ((lh * 2) ^ sw) * 8, cl = ((lh * 2 + 1) ^ sw) * 8;
+            const _Float16* ap = st + (wr * 64 + l31) * G_ROWH;
+            const _Float16* bp = st + G_A_H + (wc * 64 + l31) * G_ROWH;
+            dma_a(cur, 0);
+            f0.ah[0] = *(const h8*)(ap + ch);
+            f0.al[0] = *(const h8*)(ap + cl);
+            mma1(f1, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_a(cur, 1);
+            f0.bh[0] = *(const h8*)(bp + ch);
+            f0.bl[0] = *(const h8*)(bp + cl);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_a(cur, 2);
+            mma1(f1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_a(cur, 3);
+            f0.ah[1] = *(const h8*)(ap + 32 * G_ROWH + ch);
+            f0.al[1] = *(const h8*)(ap + 32 * G_ROWH + cl);
+            mma1(f1, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_b(cur, 0);
+            f0.bh[1] = *(const h8*)(bp + 32 * G_ROWH + ch);
+            f0.bl[1] = *(const h8*)(bp + 32 * G_ROWH + cl);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_b(cur, 1);
+            advance();
+            mma1(f1, 1, 1);
+        }
         cur = nxt;
         nxt = nxt == G_STAGES - 1 ? 0 : nxt + 1;
     }
@@ -975,7 +1024,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3g_kernel(const PpGemmDesc d,
                 epilogue_store(d, C, R, R2, m, n, v);
             }
     }
+#endif
 }
+
+namespace {
 
 // activation pre-split: x (B, P, C) fp32 with batch / row strides -> contiguous hl operand (B*P rows, ld = C):
 // one thread = 8 channels = 32 bytes in, 32 contiguous bytes (8 hi + 8 lo) out
@@ -1259,8 +1311,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     if (d.B_hl && (d.b_kn || d.ldb % 8 != 0 || d.K % 8 != 0 || z != 1 || !(d.b_scale > 0.f))) return PP_EINVAL;
     if (d.B_hl && !split) d.B_hl = nullptr;  // unaligned layer: the fp32 kernel reads d.B
     static const bool big_ok = [] {
-        return hipFuncSetAttribute((const void*)gemm_f16x3g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   G_STAGES * G_STAGE * 2) == hipSuccess;
+        const int lds = G_STAGES * G_STAGE * 2;
+        return hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     }();
     if (!big_ok) return PP_ELAUNCH;
     auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA
@@ -1268,7 +1322,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
         if (asplit && cfg == 3) {
             const int gx = (d.N + GBN - 1) / GBN, gy = (d.M + GBM - 1) / GBM;
-            hipLaunchKernelGGL(gemm_f16x3g_kernel, dim3(gx * gy), dim3(512), G_STAGES * G_STAGE * 2, st, d, gx, gy);
+            const int mode = d.conv_kh == 0 ? 0 : (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32 ? 1 : 2);
+            if (mode == 0) hipLaunchKernelGGL(pp_gemm_f16x3g_kernel<0>, dim3(gx * gy), dim3(512), G_STAGES * G_STAGE * 2, st, d, gx, gy);
+            else if (mode == 1) hipLaunchKernelGGL(pp_gemm_f16x3g_kernel<1>, dim3(gx * gy), dim3(512), G_STAGES * G_STAGE * 2, st, d, gx, gy);
+            else hipLaunchKernelGGL(pp_gemm_f16x3g_kernel<2>, dim3(gx * gy), dim3(512), G_STAGES * G_STAGE * 2, st, d, gx, gy);
         } else if (asplit) {
             if (narrow) hipLaunchKernelGGL((gemm_f16x3s_kernel<1, 3>), grid, dim3(256), 0, st, d);
             else hipLaunchKernelGGL((gemm_f16x3s_kernel<2, 2>), grid, dim3(256), 0, st, d);  // 64 KB LDS: 2 per CU
