@@ -185,6 +185,10 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # PP_BENCH_REHEARSE=1: rehearse the N > 1 code path on a ONE-GPU box (every rank on cuda:0, gloo instead of RCCL)
+    rehearse = os.environ.get("PP_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
@@ -192,7 +196,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from picopose_amd import _lib, ops
     from picopose_amd.dist import shard_bounds, sharded_forward, sharded_matching_templates
