@@ -66,8 +66,10 @@ class DPTHead(Packed):
 
     def _rcu(self, pk, key, x, extra=None):
         """ResidualConvUnit (dpt.py:72-95): bn2(conv2(relu(bn1(conv1(relu(x)))))) + x (+ extra)."""
-        h = ops.conv2d(x, pk[key + "_c1"], pk[key + "_b1"], 3, pad=1, relu_in=True)
-        return ops.conv2d(h, pk[key + "_c2"], pk[key + "_b2"], 3, pad=1, relu_in=True, residual=x, residual2=extra)
+        # conv1 hands relu(h) to conv2 as operand planes (out_split + split_relu): h itself is never stored
+        h = ops.conv2d(x, pk[key + "_c1"], pk[key + "_b1"], 3, pad=1, relu_in=True, out_split=True, split_relu=True)
+        return ops.conv2d(h, pk[key + "_c2"], pk[key + "_b2"], 3, pad=1, relu_in=not isinstance(h, ops.Split), residual=x,
+                          residual2=extra)
 
     def _fuse(self, pk, i, size, x0, x1=None):
         """FeatureFusionBlock (dpt.py:129-156)."""
@@ -161,22 +163,23 @@ class FlowDecoder(Packed):
             ncorr = (l + 1) * (2 * self.r + 1) ** 2
             corr = ops.corr_lookup(fr, fq, flow, l + 1, self.r, c_pad=-(-ncorr // 8) * 8)
             cf = torch.empty(B, H, W, 256, dtype=torch.float32, device=fr_in.device)  # [corr feat 192 | flow feat 64]
-            c1 = ops.conv2d(corr, pk[f"e{l}_corr0"], getattr(e.corr_net, "0").conv.bias, 1, act="relu")
+            c1 = ops.conv2d(corr, pk[f"e{l}_corr0"], getattr(e.corr_net, "0").conv.bias, 1, act="relu", out_split=True)
             ops.conv2d(c1, pk[f"e{l}_corr1"], getattr(e.corr_net, "1").conv.bias, 3, pad=1, act="relu", out=cf[..., 0:192])
             flow8 = torch.zeros(B, H, W, 8, dtype=torch.float32, device=fr_in.device)
             flow8[..., 0:2] = flow
-            f1 = ops.conv2d(flow8, pk[f"e{l}_flow0"], getattr(e.flow_net, "0").conv.bias, 7, pad=3, act="relu")
+            f1 = ops.conv2d(flow8, pk[f"e{l}_flow0"], getattr(e.flow_net, "0").conv.bias, 7, pad=3, act="relu", out_split=True)
             ops.conv2d(f1, pk[f"e{l}_flow1"], getattr(e.flow_net, "1").conv.bias, 3, pad=1, act="relu", out=cf[..., 192:256])
             ops.conv2d(cf, pk[f"e{l}_out0"], getattr(e.out_net, "0").conv.bias, 3, pad=1, act="relu", out=X[..., 512:638])
             X[..., 0:256] = fr
             X[..., 638:640] = flow                                  # cat([out, flow]) (raft_decoder.py:161)
             ops.warp(fq, flow, out=X[..., 256:512])                 # feature_sample (flow_decoder.py:49-56)
             fp, mp = self.flow_pred[l], self.mask_pred[l]
-            h = ops.conv2d(X, pk[f"fp{l}_0"], getattr(fp.layers, "0").conv.bias, 3, pad=1, act="relu")
-            h = ops.conv2d(h, pk[f"fp{l}_1"], getattr(fp.layers, "1").conv.bias, 3, pad=1, act="relu")
+            Xs = ops.split_image(X)        # both heads read the same operand: split once; hidden maps stay operand-only
+            h = ops.conv2d(Xs, pk[f"fp{l}_0"], getattr(fp.layers, "0").conv.bias, 3, pad=1, act="relu", out_split=True)
+            h = ops.conv2d(h, pk[f"fp{l}_1"], getattr(fp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True)
             flow = ops.conv2d(h, pk[f"fp{l}_p"], fp.predict_layer.bias, 3, pad=1, residual=flow)      # flow + delta
-            h = ops.conv2d(X, pk[f"mp{l}_0"], getattr(mp.layers, "0").conv.bias, 3, pad=1, act="relu")
-            h = ops.conv2d(h, pk[f"mp{l}_1"], getattr(mp.layers, "1").conv.bias, 3, pad=1, act="relu")
+            h = ops.conv2d(Xs, pk[f"mp{l}_0"], getattr(mp.layers, "0").conv.bias, 3, pad=1, act="relu", out_split=True)
+            h = ops.conv2d(h, pk[f"mp{l}_1"], getattr(mp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True)
             cert = ops.conv2d(h, pk[f"mp{l}_p"], mp.predict_layer.bias, 1, residual=cert)             # certainty + delta
             flows.append(flow)
             certs.append(cert)

@@ -40,10 +40,11 @@ class Split:
     """An activation that exists only as the f16x3 engine's "hl" operand: fp16 (rows, 2C), per 8 channels the 8 hi
     terms then the 8 lo terms (include/picopose_hip.h).  Producers (layernorm, attention, a GEMM epilogue) write it
     directly, so the consuming GEMM needs no split pass and the fp32 tensor is never stored."""
-    __slots__ = ("hl",)
+    __slots__ = ("hl", "image")
 
     def __init__(self, hl):
         self.hl = hl
+        self.image = None  # (B, H, W) when the rows are the pixels of NHWC images (operand of a convolution)
 
     @property
     def shape(self):
@@ -182,40 +183,73 @@ def pack_convT_weight(w, bias):
     return wp, (bias.repeat(r * r).contiguous() if bias is not None else None)
 
 
+def split_image(x, relu=False):
+    """NHWC image (B,H,W,C) (C % 8 == 0, channel-contiguous rows, free batch stride) -> Split with .image = (B,H,W):
+    the operand of several convolutions split once (f16x3 engine only; otherwise x itself)."""
+    B, H, W, C = x.shape
+    if not (_split_ok(C) and x.stride(3) == 1 and x.stride(1) == W * x.stride(2) and x.data_ptr() % 16 == 0
+            and x.stride(2) % 4 == 0 and x.stride(0) % 4 == 0 and B * H * W * C < 2 ** 30):
+        return x
+    sp = Split(split_activation(x, B, H * W, C, x.stride(0), x.stride(2), relu=relu))
+    sp.image = (B, H, W)
+    return sp
+
+
 def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residual=None, out=None, cin=None,
-           residual2=None):
-    """NHWC convolution. x (B,H,W,Cx) (channel-contiguous, may be a channel slice: cin <= Cx stride),
-    wp (Cout, k*k*cin) from pack_conv_weight.  out may be a channel slice of a wider NHWC buffer."""
-    B, H, W, Cx = x.shape
+           residual2=None, out_split=False, split_relu=False):
+    """NHWC convolution. x (B,H,W,Cx) (channel-contiguous, may be a channel slice: cin <= Cx stride) or a Split
+    carrying .image (a pre-split operand: no split pass, the producer has already applied any input ReLU),
+    wp (Cout, k*k*cin) from pack_conv_weight.  out may be a channel slice of a wider NHWC buffer.
+    out_split (f16x3 engine, no `out`): return the result as a Split (with split_relu: of max(result, 0), the next
+    layer's input ReLU folded in) instead of an fp32 tensor."""
+    xs = x if isinstance(x, Split) else None
+    if xs is not None:
+        (B, H, W), Cx = xs.image, xs.shape[1]
+        assert not relu_in and cin in (None, Cx)
+        ld_in = Cx
+    else:
+        B, H, W, Cx = x.shape
+        assert x.stride(3) == 1
+        ld_in = x.stride(2)
+        assert x.stride(1) == W * ld_in  # images may be spaced apart (tokens with a cls row): x.stride(0) is free
     cin = cin or Cx
     Cout = wp.shape[0]
-    assert wp.shape[1] == ksize * ksize * cin and x.stride(3) == 1
-    ld_in = x.stride(2)
-    assert x.stride(1) == W * ld_in  # images may be spaced apart (tokens with a cls row): x.stride(0) is free
+    assert wp.shape[1] == ksize * ksize * cin
     Ho = (H + 2 * pad - ksize) // stride + 1
     Wo = (W + 2 * pad - ksize) // stride + 1
-    if out is None:
-        out = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
-    ldc = out.stride(2)
-    assert out.stride(3) == 1 and out.stride(1) == Wo * ldc and out.stride(0) == Ho * Wo * ldc
+    wargs = _weight_args(wp, ksize * ksize * cin)
+    dev = xs.device if xs is not None else x.device
+    presplit = xs is not None or ("B_hl" in wargs and (Cout > 64 or ksize > 1)
+                                  and _can_presplit(x, ksize * ksize * cin, cin, ld_in, x.stride(0)) and B * H * W * cin < 2 ** 30)
+    sargs, ret = {}, None
+    if out_split and out is None and presplit and _split_ok(Cout) and residual is None and residual2 is None:
+        ret = Split.empty(B * Ho * Wo, Cout, dev)
+        ret.image = (B, Ho, Wo)
+        sargs = dict(C_hl=_p(ret.hl), ldc_h=Cout, c_relu=int(split_relu))
+        ldc = Cout
+    else:
+        if out is None:
+            out = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=dev)
+        ldc = out.stride(2)
+        assert out.stride(3) == 1 and out.stride(1) == Wo * ldc and out.stride(0) == Ho * Wo * ldc
+        ret = out
     for r_ in (residual, residual2):
         if r_ is not None:
             assert r_.stride() == out.stride()
-    wargs = _weight_args(wp, ksize * ksize * cin)
-    if ("B_hl" in wargs and (Cout > 64 or ksize > 1) and _can_presplit(x, ksize * ksize * cin, cin, ld_in, x.stride(0))
-            and B * H * W * cin < 2 ** 31):
-        hl = split_activation(x, B, H * W, cin, x.stride(0), ld_in, relu=relu_in)  # once, not per tap / column tile
+    if presplit:
+        assert "B_hl" in wargs
+        hl = xs.hl if xs is not None else split_activation(x, B, H * W, cin, x.stride(0), ld_in, relu=relu_in)  # once, not per tap / column tile
         _run(_desc(A_hl=_p(hl), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual),
                    residual2=_p(residual2), conv_bstride=H * W * cin, M=B * Ho * Wo, N=Cout, K=ksize * ksize * cin, lda=cin,
                    ldb=wp.shape[1], ldc=ldc, act=ACT[act], conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride,
-                   conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo, **wargs))
-        return out
+                   conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo, **wargs, **sargs))
+        return ret
     _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual), residual2=_p(residual2),
                conv_bstride=x.stride(0), M=B * Ho * Wo, N=Cout,
                K=ksize * ksize * cin, lda=ld_in, ldb=wp.shape[1], ldc=ldc, act=ACT[act], relu_in=int(relu_in),
                conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride, conv_pad=pad, conv_h=H, conv_w=W,
                conv_ho=Ho, conv_wo=Wo, **wargs))
-    return out
+    return ret
 
 
 def conv_transpose2d(x, wp, bias_tiled, r):
