@@ -129,6 +129,94 @@ __device__ __forceinline__ void epilogue_store(const PpGemmDesc& d, float* C, co
     }
 }
 
+// Epilogue of a wave's 64 x (32 NJ) accumulator block: out = residual + residual2 + gamma * act(descale * acc + bias).
+// The block leaves through a wave-private LDS patch (32 rows at a time) so that a lane owns 8 consecutive columns of a
+// row: 32-byte fp32 stores / residual loads and one 32-byte group of the hl operand, instead of 64 (or, for hl, 128)
+// scattered 4- and 2-byte accesses per lane.  Os: 32 x (32 NJ + 4) floats, free for this wave (no other wave touches it).
+// Pixel-shuffle stores (ConvTranspose2d), N % 8 != 0 and unaligned rows go element-wise from the accumulator layout.
+template <int NJ>
+__device__ __forceinline__ void epilogue_block(const PpGemmDesc& d, float descale, f32x16 (&acc)[2][NJ], float* Os, int mw, int nw,
+                                               int lane) {
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* C = d.C;
+    const float* R = d.residual;
+    const float* R2 = d.residual2;
+    if (d.shuffle_r != 0 || (d.N & 7) != 0 || (d.ldc & 3) != 0 || ((uintptr_t)C & 15) != 0 || (R && ((uintptr_t)R & 15) != 0) ||
+        (R2 && ((uintptr_t)R2 & 15) != 0)) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = nw + j * 32 + l31;
+            if (n >= d.N) continue;
+            const float bias = d.bias ? d.bias[n] : 0.f;
+            const float gamma = d.gamma ? d.gamma[n] : 1.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (m >= d.M) continue;
+                    float v = act_apply(acc[i][j][e] * descale + bias, d.act) * gamma;
+                    epilogue_store(d, C, R, R2, m, n, v);
+                }
+        }
+        return;
+    }
+    constexpr int OSLD = 32 * NJ + 4;     // floats per staged row
+    constexpr int LPR = 4 * NJ;           // lanes per row (8 columns each)
+    constexpr int RPP = 64 / LPR;         // rows per pass
+    const int rr = lane / LPR, c8 = (lane % LPR) * 8;
+    const int n = nw + c8;  // columns n .. n + 7 (N % 8 == 0: a group is in or out as a whole)
+    f4 bias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gam[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+    const bool ncol_ok = n < d.N;
+    if (ncol_ok) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (d.bias) bias[h][c] = d.bias[n + 4 * h + c];
+                if (d.gamma) gam[h][c] = d.gamma[n + 4 * h + c];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Os[((e & 3) + 8 * (e >> 2) + 4 * lh) * OSLD + j * 32 + l31] = acc[i][j][e];
+#pragma unroll
+        for (int it = 0; it < 32 / RPP; ++it) {
+            const int r = it * RPP + rr, m = mw + i * 32 + r;
+            f4 v[2];
+            v[0] = *(const f4*)(Os + r * OSLD + c8);
+            v[1] = *(const f4*)(Os + r * OSLD + c8 + 4);
+            if (m >= d.M || !ncol_ok) continue;
+            const size_t off = (size_t)m * d.ldc + n;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[h][c] = act_apply(v[h][c] * descale + bias[h][c], d.act) * gam[h][c];
+                if (R) v[h] += *(const f4*)(R + off + 4 * h);
+                if (R2) v[h] += *(const f4*)(R2 + off + 4 * h);
+                if (C) *(f4*)(C + off + 4 * h) = v[h];
+            }
+            if (d.C_hl) {
+                h8 hh, ll;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float x = v[c >> 2][c & 3];
+                    _Float16 a, b;
+                    pp_split_f16(d.c_relu ? fmaxf(x, 0.f) : x, a, b);
+                    hh[c] = a;
+                    ll[c] = b;
+                }
+                _Float16* hp = (_Float16*)d.C_hl + (size_t)m * 2 * d.ldc_h + 2 * n;
+                *(h8*)hp = hh;
+                *(h8*)(hp + 8) = ll;
+            }
+        }
+    }
+}
+
 template <bool VEC4, int NJ, int OCC>
 __global__ __launch_bounds__(256, OCC) void gemm_kernel(const PpGemmDesc d) {
     constexpr int BN = 64 * NJ;
@@ -699,27 +787,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
             __syncthreads();
         }
     }
-    float* C = d.C;
-    const float* R = d.residual;
-    const float* R2 = d.residual2;
-    const float descale = d.alpha / (A_SCALE * d.b_scale);
-    // ---- epilogue: out = residual + residual2 + gamma * act(alpha * acc + bias)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wc * 32 * NJ + j * 32 + l31;
-        if (n >= d.N) continue;
-        const float bias = d.bias ? d.bias[n] : 0.f;
-        const float gamma = d.gamma ? d.gamma[n] : 1.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m >= d.M) continue;
-                float v = act_apply(acc[i][j][e] * descale + bias, d.act) * gamma;
-                epilogue_store(d, C, R, R2, m, n, v);
-            }
-    }
+    // (the K loop ends with a barrier: the staging buffers are free; each wave uses a private patch)
+    epilogue_block<NJ>(d, d.alpha / (A_SCALE * d.b_scale), acc, (float*)lds + w * 32 * (32 * NJ + 4), m0 + wr * 64, n0 + wc * 32 * NJ,
+                       lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1004,89 +1074,9 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3g_kernel(const PpGemmDesc
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS at exit
 
-    float* C = d.C;
-    const float* R = d.residual;
-    const float* R2 = d.residual2;
-    const float descale = d.alpha / (A_SCALE * d.b_scale);
-    const int mw = m0 + wr * 64, nw = n0 + wc * 64;  // this wave's 64 x 64 output block
-    if (d.shuffle_r != 0 || (d.N & 7) != 0 || (d.ldc & 3) != 0 || ((uintptr_t)C & 15) != 0 || (R && ((uintptr_t)R & 15) != 0) ||
-        (R2 && ((uintptr_t)R2 & 15) != 0)) {
-        // pixel-shuffle store (ConvTranspose2d) / unaligned output rows: element-wise from the accumulator layout
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = nw + j * 32 + l31;
-            if (n >= d.N) continue;
-            const float bias = d.bias ? d.bias[n] : 0.f;
-            const float gamma = d.gamma ? d.gamma[n] : 1.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    if (m >= d.M) continue;
-                    float v = act_apply(acc[i][j][e] * descale + bias, d.act) * gamma;
-                    epilogue_store(d, C, R, R2, m, n, v);
-                }
-        }
-        return;
-    }
-    // The block leaves through LDS (the ring is free: all DMA landed, all fragment reads done) so that a lane owns 8
-    // consecutive columns of a row: 32-byte fp32 stores / residual loads and one 32-byte group of the hl operand
-    // instead of 64 (or, for hl, 128) scattered 4- and 2-byte accesses per lane.
+    // epilogue through LDS: the ring is free once every wave is past its last fragment read
     __builtin_amdgcn_s_barrier();
-    constexpr int OSLD = 68;  // floats per staged row
-    float* Os = (float*)glds + w * 64 * OSLD;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                Os[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * OSLD + j * 32 + l31] = acc[i][j][e];
-    const int rr = lane >> 3, c8 = (lane & 7) * 8;
-    const int n = nw + c8;  // columns n .. n + 7 (N % 8 == 0 on this path: whole groups are in or out)
-    f4 bias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gam[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
-    const bool ncol_ok = n < d.N;
-    if (ncol_ok) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (d.bias) bias[h][c] = d.bias[n + 4 * h + c];
-                if (d.gamma) gam[h][c] = d.gamma[n + 4 * h + c];
-            }
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int r = it * 8 + rr, m = mw + r;
-        f4 v[2];
-        v[0] = *(const f4*)(Os + r * OSLD + c8);
-        v[1] = *(const f4*)(Os + r * OSLD + c8 + 4);
-        if (m >= d.M || !ncol_ok) continue;
-        const size_t off = (size_t)m * d.ldc + n;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[h][c] = act_apply(v[h][c] * descale + bias[h][c], d.act) * gam[h][c];
-            if (R) v[h] += *(const f4*)(R + off + 4 * h);
-            if (R2) v[h] += *(const f4*)(R2 + off + 4 * h);
-            if (C) *(f4*)(C + off + 4 * h) = v[h];
-        }
-        if (d.C_hl) {
-            h8 hh, ll;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float x = v[c >> 2][c & 3];
-                _Float16 a, b;
-                pp_split_f16(d.c_relu ? fmaxf(x, 0.f) : x, a, b);
-                hh[c] = a;
-                ll[c] = b;
-            }
-            _Float16* hp = (_Float16*)d.C_hl + (size_t)m * 2 * d.ldc_h + 2 * n;
-            *(h8*)hp = hh;
-            *(h8*)(hp + 8) = ll;
-        }
-    }
+    epilogue_block<2>(d, d.alpha / (A_SCALE * d.b_scale), acc, (float*)glds + w * 32 * 68, m0 + wr * 64, n0 + wc * 64, lane);
 #endif
 }
 
