@@ -667,6 +667,26 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
         boff[j] = n < d.N ? (unsigned)(((long long)n * d.ldb + k8) * 4) : 0xFFFFFFFFu;
     }
 
+    // Convolutions with Cin % 32 == 0 walk K channel-slice-major, exactly like the LDS-DMA kernel (same summation
+    // order in every pre-split kernel: the result does not depend on the tile configuration the autotuner picks;
+    // the taps of a slice re-read L2-resident pixels).  Per row: a bit mask of the taps inside the image.
+    const int ntaps = d.conv_kh * d.conv_kw;
+    const bool cmajor = d.conv_kh != 0 && d.conv_cin % BK == 0 && ntaps <= 32;
+    unsigned vmask[2] = {0u, 0u}, abyte[2] = {0u, 0u}, bbyte[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bbyte[j] = boff[j];
+    if (cmajor) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            for (int t = 0; t < ntaps; ++t) {
+                const int iy = aoy[j] + t / d.conv_kw, ix = aox[j] + t % d.conv_kw;
+                if (arow_ok[j] && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) vmask[j] |= 1u << t;
+            }
+            abyte[j] = (unsigned)((abase[j] + k8) * 4);
+        }
+    }
+    int ctap = 0, cky = 0, ckx = 0, cci = 0;  // wave-uniform position of the next tile in channel-major order
+
     f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -682,6 +702,29 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
     Stage s0, s1, s2;
     int kcur = k8;  // k of this thread's slot in the tile being fetched
     auto fetch = [&](Stage& sg) __attribute__((always_inline)) {
+        if (cmajor) {
+            const unsigned kin = cci < d.conv_cin ? 1u : 0u;
+            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci) * 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned dead = ((vmask[j] >> ctap) & kin) - 1u;  // 0 or 0xFFFFFFFF (out of range: reads zeros)
+                sg.ah[j] = __builtin_amdgcn_raw_buffer_load_b128(Ar, (abyte[j] + tapoff) | dead, 0, 0);
+                sg.al[j] = __builtin_amdgcn_raw_buffer_load_b128(Ar, (abyte[j] + tapoff + 16) | dead, 0, 0);
+            }
+            const unsigned koff = (unsigned)((ctap * d.conv_cin + cci) * 4);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const unsigned dead = (kin & (bbyte[j] != 0xFFFFFFFFu ? 1u : 0u)) - 1u;
+                sg.bh[j] = __builtin_amdgcn_raw_buffer_load_b128(Br, (bbyte[j] + koff) | dead, 0, 0);
+                sg.bl[j] = __builtin_amdgcn_raw_buffer_load_b128(Br, (bbyte[j] + koff + 16) | dead, 0, 0);
+            }
+            const bool row_end = ckx + 1 == d.conv_kw, tap_end = row_end && cky + 1 == d.conv_kh;
+            ckx = row_end ? 0 : ckx + 1;
+            cky = tap_end ? 0 : (row_end ? cky + 1 : cky);
+            ctap = tap_end ? 0 : ctap + 1;
+            cci = tap_end ? cci + BK : cci;
+            return;
+        }
         const bool kin = kcur < d.K;  // tiles past the end read zeros (never consumed)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {

@@ -194,3 +194,25 @@ def test_fused_operand_planes_equal_separate_split(engine_precision):
 
     a, b = chain(True), chain(False)
     assert torch.equal(a, b)
+
+
+@gpu
+def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, engine_precision):
+    """The three pre-split kernels (128x128, 128x64, 256x128 LDS-DMA) walk K in the same order and accumulate the
+    same way, so the value of an output element does not depend on which one the autotuner picks for a shape —
+    which is what makes "all hypotheses as one batch" give exactly the per-hypothesis values."""
+    if engine_precision != "f16x3":
+        pytest.skip("pre-split operands exist in f16x3 mode only")
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    x, w, b = torch.randn(700, 768, generator=g).cuda(), (torch.randn(384, 768, generator=g) / 27).cuda(), torch.randn(384, generator=g).cuda()
+    xi = torch.randn(2, 24, 24, 64, generator=g).cuda()
+    wc = ops.pack_conv_weight((torch.randn(256, 64, 3, 3, generator=g) / 24).cuda())
+    outs = []
+    for cfg in ("0", "2", "3"):
+        monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
+        outs.append((ops.linear(x, w, b, act="gelu"), ops.conv2d(xi, wc, None, 3, pad=1, act="relu")))
+    for lin, conv in outs[1:]:
+        assert torch.equal(lin, outs[0][0])
+        assert torch.equal(conv, outs[0][1])
