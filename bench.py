@@ -48,6 +48,9 @@ WORKLOADS = {
     # name: (kind, crops per GPU-step, templates, vit, description)
     "full_b32_n162_vitb": ("full", 32, 162, "dinov2_vitb14", "configs[2]: batch 32, 162 templates, ViT-B/14, stage1+2+3 + PnP/RANSAC, hyp 5"),
     "full_b8_n42_vits": ("full", 8, 42, "dinov2_vits14", "batch 8, 42 templates, ViT-S/14, stage1+2+3 + PnP/RANSAC, hyp 5"),
+    # SURVEY.md §8(f) row 1 (NOT the headline: the reference recomputes the template ViT / DPT inside the step)
+    "full_cached_b32_n162_vitb": ("full_cached", 32, 162, "dinov2_vitb14",
+                                  "configs[2] with the EXTENDED template bank (template-side DPT maps precomputed too, SURVEY 8f row 1)"),
     "stage1_b32_n162_c768": ("stage1", 32, 162, "dinov2_vitb14", "configs[2] stage-1 shape: matching_templates only"),
     "stage1_b8_n42_c384": ("stage1", 8, 42, "dinov2_vits14", "configs[1]: batch 8, 42 templates, ViT-S/14, stage-1 matching only"),
     "stage1_b32_n162_c1024": ("stage1", 32, 162, "dinov2_vitl14", "base.yaml shape (ViT-L/14), stage-1 matching only"),
@@ -76,11 +79,13 @@ def stage1_bytes(B, N, C):
     return B * (N * C * 256 * 4 + C * 256 * 4 + 256 * 4 + 5 * 12)
 
 
-def full_gflop_per_crop(N, vit, hyp=5):
+def full_gflop_per_crop(N, vit, hyp=5, cached=False):
     C = VIT[vit][0]
     dpt = {"dinov2_vits14": 18.5, "dinov2_vitb14": 19.0, "dinov2_vitl14": 19.4}[vit]
-    # executed work: the query-side DPT head runs once per forward, not once per hypothesis (picopose_amd/picopose.py)
-    return (1 + hyp) * VIT[vit][3] + (1 + hyp) * dpt + hyp * 108.4 + hyp * 0.14 + N * 2 * 256 * 256 * C / 1e9
+    # executed work: the query-side DPT head runs once per forward, not once per hypothesis (picopose_amd/picopose.py);
+    # with the extended template bank the template-side ViT and DPT are not executed in the step at all
+    nvit = 1 if cached else 1 + hyp
+    return nvit * VIT[vit][3] + nvit * dpt + hyp * 108.4 + hyp * 0.14 + N * 2 * 256 * 256 * C / 1e9
 
 
 def make_cfg(vit):
@@ -214,6 +219,9 @@ def main():
     n_local = hi - lo
     sd = None
 
+    cached = kind == "full_cached"
+    if cached:
+        kind = "full"
     if kind == "stage1":
         g0 = torch.Generator(device=dev).manual_seed(0)
         query = torch.randn(B, C, 16, 16, device=dev, generator=g0)     # identical on every rank
@@ -237,8 +245,16 @@ def main():
         # feature bank (outside the timed region, run_test.py:120-134): this rank's template slice of ALL crops.
         # Synthetic stand-in for the other ranks' crops: features of this rank's own renders (same shapes/bytes).
         with torch.no_grad():
-            feats = torch.stack([torch.cat([fe(ep["tem_rgb"][b, s:min(s + 54, hi)])[-1] for s in range(lo, hi, 54)])
-                                 for b in range(Bl)])
+            if cached:   # extended bank (single GPU): last-level features + template-side DPT maps of every template
+                assert not distributed, "the extended-bank workload is single-GPU"
+                banks = [net.precompute_templates(ep["tem_rgb"][b]) for b in range(Bl)]
+                feats = torch.stack([bk["feature"] for bk in banks])
+                ep["template_cache"] = {"obj_index": torch.arange(Bl, device=dev),
+                                        "dpt": [torch.stack([bk["dpt"][k] for bk in banks]) for k in range(3)]}
+                del banks
+            else:
+                feats = torch.stack([torch.cat([fe(ep["tem_rgb"][b, s:min(s + 54, hi)])[-1] for s in range(lo, hi, 54)])
+                                     for b in range(Bl)])
         if distributed:
             bank = feats.repeat(world, 1, 1, 1, 1).contiguous()
         else:
@@ -296,7 +312,8 @@ def main():
         if world == 1 and a.mode == "fast" and (B, N, C) == (32, 162, 768) and os.path.exists(pmc):
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         line = {
-            "metric": "image-crops/sec (224x224, 162 templates)" + ("" if kind == "full" else ", stage-1 template matching only"),
+            "metric": "image-crops/sec (224x224, 162 templates)" + ("" if kind == "full" else ", stage-1 template matching only")
+                      + (", extended template bank (SURVEY 8f row 1: template ViT/DPT precomputed)" if cached else ""),
             "value": B / (dt / a.steps), "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 tensors; networks: f32 operands split into 2 f16 terms (22 bits) on f16 MFMA with f32 accumulate; stage-1 "
@@ -334,17 +351,17 @@ def main():
         if kind == "full":
             from picopose_amd import ops
 
-            tf = Bl * full_gflop_per_crop(N, vit) / (dt / a.steps) / 1e3   # useful (fp32-equivalent) TFLOP/s per GPU
+            tf = Bl * full_gflop_per_crop(N, vit, cached=cached) / (dt / a.steps) / 1e3   # useful (fp32-equivalent) TFLOP/s per GPU
             if ops.PRECISION == "f16x3":   # every product = 3 fp16 MFMA products
                 line["mfma"] = {"bound": "mfma", "scope": "whole step, all kernels (the GEMM/conv engine is >90 % of it)",
                                 "engine": "f16x3: operands split into 2 fp16 terms, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate",
                                 "useful_tflops": tf, "achieved": 3 * tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                                 "frac": 3 * tf / MFMA_F16_PEAK_TF, "frac_of_fp32_mfma_peak_equivalent": tf / MFMA_F32_PEAK_TF,
-                                "gflop_per_crop": full_gflop_per_crop(N, vit)}
+                                "gflop_per_crop": full_gflop_per_crop(N, vit, cached=cached)}
             else:
                 line["mfma"] = {"bound": "mfma", "scope": "whole step, all kernels (the GEMM/conv engine is >90 % of it)",
                                 "engine": "f32: v_mfma_f32_32x32x2_f32", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
-                                "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "gflop_per_crop": full_gflop_per_crop(N, vit)}
+                                "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "gflop_per_crop": full_gflop_per_crop(N, vit, cached=cached)}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_full(N, vit, sd) if kind == "full" else cpu_baseline_stage1(N, C)
         print(json.dumps(line), flush=True)

@@ -37,9 +37,28 @@ class Net(nn.Module):
             sel[key] = end_points[key]
         return sel
 
+    # ---- template bank extended to the template-side DPT outputs ---------------------------
+    def precompute_templates(self, tem_rgb, chunk=54):
+        """The bank precompute of run_test.py:120-134 for one object, extended: tem_rgb (N,3,224,224) ->
+        {"feature": (N,C,16,16) — what the reference keeps — and "dpt": [path_4 (N,16,16,256), path_3 (N,32,32,256),
+        path_2 (N,64,64,256)] NHWC}.  Eval mode is deterministic and every op is per sample, so a forward that reads
+        these maps (end_points["template_cache"]) returns exactly what recomputing the selected templates' ViT and DPT
+        head returns; it trades 5.5 MB of HBM per template for 5 of the 6 ViT forwards and 5 of the 6 DPT calls."""
+        fe, dpt = self.feature_extractor, self.offset_regressor.dpt_head
+        feats, maps = [], [[], [], []]
+        with torch.no_grad():
+            for s0 in range(0, tem_rgb.shape[0], chunk):
+                toks, (h0, w0) = fe.forward_tokens(tem_rgb[s0:s0 + chunk])
+                feats.append(ops.tokens_to_nchw(toks[-1], 1, h0, w0))
+                for k, m in enumerate(dpt.forward_nhwc([t[:, 1:].unflatten(1, (h0, w0)) for t in toks])):
+                    maps[k].append(m)
+        return {"feature": torch.cat(feats), "dpt": [torch.cat(m) for m in maps]}
+
     # model/picopose.py:72-95
-    def forward_test_hyp(self, end_points, real):
+    def forward_test_hyp(self, end_points, real, tem_cached=None):
         """`real` = (query token maps at the 4 taken blocks, (h0, w0), query-side DPT maps or None).
+        `tem_cached` = (selected templates' last-level features (B,C,16,16), their DPT maps) from the extended bank
+        instead of recomputing the template ViT + DPT head (precompute_templates).
 
         The reference recomputes dpt_head(features_real) for every hypothesis (offset_regressor.py:17 inside the
         loop of picopose.py:107); the query features do not depend on the hypothesis, so forward_test computes
@@ -51,10 +70,13 @@ class Net(nn.Module):
         output["tar_pts_2d"] = end_points["real_pts2d"].permute(0, 3, 2, 1)
         output["src_pts_3d"] = end_points["tem_pts3d"].permute(0, 3, 1, 2)
         # stage 1: template features
-        tem_tok, _ = fe.forward_tokens(end_points["tem_rgb"])
+        if tem_cached is None:
+            tem_tok, _ = fe.forward_tokens(end_points["tem_rgb"])
+            tem_last = ops.tokens_to_nchw(tem_tok[-1], 1, h0, w0)
+        else:
+            tem_last, tem_dpt = tem_cached
         # stage 2
-        sim = matching_features_similarity(ops.tokens_to_nchw(tem_tok[-1], 1, h0, w0),
-                                           ops.tokens_to_nchw(real_tok[-1], 1, h0, w0),
+        sim = matching_features_similarity(tem_last, ops.tokens_to_nchw(real_tok[-1], 1, h0, w0),
                                            end_points["tem_mask"], end_points["real_mask"])
         pred_translation, pred_scale, pred_inplane = self.affine_regressor(sim)
         pred_Ms = calc_pred_Ms(pred_scale, pred_inplane, pred_translation, end_points["tem_pose"], end_points["tem_K"],
@@ -67,8 +89,9 @@ class Net(nn.Module):
         orr = self.offset_regressor
         if real_dpt is None:
             real_dpt = orr.dpt_head.forward_nhwc([as_img(t) for t in real_tok])
-        flows, certs = orr.flow_decoder.forward_nhwc(orr.dpt_head.forward_nhwc([as_img(t) for t in tem_tok]), real_dpt,
-                                                     ops.to_nhwc(init_flow), ops.to_nhwc(init_certainty))
+        if tem_cached is None:
+            tem_dpt = orr.dpt_head.forward_nhwc([as_img(t) for t in tem_tok])
+        flows, certs = orr.flow_decoder.forward_nhwc(tem_dpt, real_dpt, ops.to_nhwc(init_flow), ops.to_nhwc(init_certainty))
         output["pred_tar_pts"], output["pred_src_pts"] = compute_stage3_correspondences(
             ops.to_nchw(flows[-1]), ops.to_nchw(certs[-1]), threshold=0.5)
         return output
@@ -76,8 +99,18 @@ class Net(nn.Module):
     def forward_hypotheses(self, end_points, pred_id_src, real):
         """The loop of model/picopose.py:106-108 over the top-k templates of every crop -> list of k output dicts."""
         hyp = pred_id_src.shape[1]
+        cache = end_points.get("template_cache")  # {"obj_index": (B,) long, "dpt": 3 x (O,N,h,w,256)} (precompute_templates)
+
+        def cached(rows, idx):
+            if cache is None:
+                return None
+            obj = cache["obj_index"][rows]
+            return end_points["template_feature"][rows, idx], [m[obj, idx] for m in cache["dpt"]]
+
         if not self.batch_hypotheses:
-            return [self.forward_test_hyp(self.select_template_data(end_points, pred_id_src, k), real) for k in range(hyp)]
+            rows = torch.arange(pred_id_src.shape[0], device=pred_id_src.device)
+            return [self.forward_test_hyp(self.select_template_data(end_points, pred_id_src, k), real,
+                                          cached(rows, pred_id_src[:, k])) for k in range(hyp)]
         # All hypotheses as ONE batch of hyp*B samples (hypothesis-major).  Every op on this path is per-sample
         # (eval-mode BatchNorm is folded, GroupNorm is per sample) and a GEMM row does not depend on the other
         # rows, so each hypothesis gets exactly the values the per-hypothesis loop gives it — with 5x larger
@@ -91,7 +124,8 @@ class Net(nn.Module):
         sel = {key: end_points[key][rows, idx] for key in ("tem_pose", "tem_K", "tem_M", "tem_mask", "tem_rgb", "tem_pts3d")}
         for key in ("real_pts2d", "real_K", "real_M", "real_mask", "real_pose"):
             sel[key] = rep(end_points[key])
-        out = self.forward_test_hyp(sel, ([rep(t) for t in real_tok], hw, None if real_dpt is None else [rep(t) for t in real_dpt]))
+        out = self.forward_test_hyp(sel, ([rep(t) for t in real_tok], hw, None if real_dpt is None else [rep(t) for t in real_dpt]),
+                                    cached(rows, idx))
         return [{key: v[k * B:(k + 1) * B] for key, v in out.items()} for k in range(hyp)]
 
     # model/picopose.py:97-112

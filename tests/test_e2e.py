@@ -92,3 +92,30 @@ def test_hip_forward_vs_reference(golden_dir, tag):
         total_bad += _keypoint_mismatch_is_explained(o["pred_tar_pts"], o["pred_src_pts"], ref[h]["pred_tar_pts"],
                                                      ref[h]["pred_src_pts"], aux["flow"][h].numpy(), aux["cert"][h].numpy())
     assert total_bad <= 0.002 * hyp * B * 4096
+
+
+@gpu
+@pytest.mark.parametrize("batched", [True, False])
+def test_extended_template_cache_gives_identical_outputs(batched):
+    """a forward that reads the precomputed template-side DPT maps (and the bank's last-level
+    features) returns bit-for-bit what recomputing the selected templates' ViT + DPT head returns."""
+    from picopose_amd.picopose import Net
+
+    B, N, hyp = 2, 5, 3
+    net = Net(small_cfg())
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 21))
+    net = net.cuda().eval()
+    net.batch_hypotheses = batched
+    dev = {k: v.cuda() for k, v in make_end_points(B, N, 33).items()}
+    banks = [net.precompute_templates(dev["tem_rgb"][b], chunk=3) for b in range(B)]   # one "object" per crop
+    dev["template_feature"] = torch.stack([bk["feature"] for bk in banks])
+    ref = net(dev, hyp)
+    dev["template_cache"] = {"obj_index": torch.arange(B, device="cuda"),
+                             "dpt": [torch.stack([bk["dpt"][k] for bk in banks]) for k in range(3)]}
+    got = net(dev, hyp)
+    for h in range(hyp):
+        assert set(got[h]) == set(ref[h])
+        for k in ref[h]:
+            assert torch.equal(got[h][k], ref[h][k]), (h, k)
+    # the bank feature of precompute_templates is the reference's bank (run_test.py:130-131)
+    assert torch.equal(banks[0]["feature"], net.feature_extractor(dev["tem_rgb"][0])[-1])
