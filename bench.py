@@ -333,12 +333,19 @@ def main():
             mult, peak = (3, MFMA_F16_PEAK_TF) if a.mode == "fast" else (1, MFMA_F32_PEAK_TF)
             n, msum, fl = gemm["launches"][k], gemm["ms"][k], gemm["flops"][k]
             ach = mult * fl / (msum * 1e-3) / 1e12
+            g_traffic = None   # HBM bytes of these kernels over one step, from the PMC passes (tools/pmc_step.sh)
+            pmc_step = os.path.join(ROOT, "profiles", "r01", "pmc_step.json")
+            if world == 1 and a.mode == "fast" and a.workload == "full_b32_n162_vitb" and os.path.exists(pmc_step):
+                g_traffic = json.load(open(pmc_step)).get("gemm_f16x3_hbm_bytes_per_step")
             line["roofline"] = {
                 "bound": "mfma",
                 "kernel": "gemm_f16x3s_kernel (GEMM / implicit-im2col conv, both operands pre-split into 2 fp16 planes; "
                           "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)" if a.mode == "fast" else
                           "gemm_kernel (v_mfma_f32_32x32x2_f32)",
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "traffic": None if g_traffic is None else g_traffic / n, "traffic_bytes_per_step": g_traffic,
+                "algorithmic_operand_bytes_note": "MFMA-bound kernels: HBM traffic (FETCH_SIZE x2 + WRITE_SIZE, PMC) is reported "
+                                                  "per average launch; it is 2-3 TB/s averaged over the step, far from the 8 TB/s roofline",
                 "launches_per_step": n, "kernel_ms_per_step": msum, "avg_launch_ms": msum / n,
                 "algorithmic_flops_per_step": fl, "mfma_flops_per_step": mult * fl,
                 "useful_tflops": fl / (msum * 1e-3) / 1e12, "share_of_step": msum / ms,
