@@ -85,7 +85,12 @@ def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=Non
         b_local = q_local.shape[0]
         q_all = q_local.new_empty((world * b_local,) + tuple(q_local.shape[1:]))
         dist.all_gather_into_tensor(q_all, q_local.contiguous(), group=group)
-        m_local = local_end_points["real_mask"].contiguous()
+        # stage 1 reads the query mask only at the nearest-sampled 16 x 16 patch grid (utils/matching.py:41-43,
+        # F.interpolate(mode="nearest") = rows/columns floor(i * H / 16)): exchange that kilobyte, not the full mask
+        m_full = local_end_points["real_mask"]
+        ih = (torch.arange(16, device=m_full.device) * m_full.shape[1]) // 16
+        iw = (torch.arange(16, device=m_full.device) * m_full.shape[2]) // 16
+        m_local = m_full[:, ih][:, :, iw].contiguous()
         m_all = m_local.new_empty((world * b_local,) + tuple(m_local.shape[1:]))
         dist.all_gather_into_tensor(m_all, m_local, group=group)
         lo, hi = shard_bounds(n_total, world, rank)
