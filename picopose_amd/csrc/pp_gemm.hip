@@ -134,7 +134,7 @@ __device__ __forceinline__ void epilogue_store(const PpGemmDesc& d, float* C, co
 // row: 32-byte fp32 stores / residual loads and one 32-byte group of the hl operand, instead of 64 (or, for hl, 128)
 // scattered 4- and 2-byte accesses per lane.  Os: 32 x (32 NJ + 4) floats, free for this wave (no other wave touches it).
 // Pixel-shuffle stores (ConvTranspose2d), N % 8 != 0 and unaligned rows go element-wise from the accumulator layout.
-template <int NJ>
+template <int NJ, int RP = 32>
 __device__ __forceinline__ void epilogue_block(const PpGemmDesc& d, float descale, f32x16 (&acc)[2][NJ], float* Os, int mw, int nw,
                                                int lane) {
     const int l31 = lane & 31, lh = lane >> 5;
@@ -161,9 +161,11 @@ __device__ __forceinline__ void epilogue_block(const PpGemmDesc& d, float descal
         }
         return;
     }
-    constexpr int OSLD = 32 * NJ + 4;     // floats per staged row
+    // RP = 32: a 32-row block per pass in a 32 x (32 NJ + 4) patch; RP = 8 (NJ = 2): 8-row groups in a 2 KB patch
+    constexpr int OSLD = RP == 32 ? 32 * NJ + 4 : 32 * NJ;  // floats per staged row
     constexpr int LPR = 4 * NJ;           // lanes per row (8 columns each)
-    constexpr int RPP = 64 / LPR;         // rows per pass
+    constexpr int RPP = 64 / LPR;         // rows per read pass
+    static_assert(RP == 32 || (RP == 8 && RPP == 8), "8-row groups need 8 lanes per row");
     const int rr = lane / LPR, c8 = (lane % LPR) * 8;
     const int n = nw + c8;  // columns n .. n + 7 (N % 8 == 0: a group is in or out as a whole)
     f4 bias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gam[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
@@ -177,41 +179,52 @@ __device__ __forceinline__ void epilogue_block(const PpGemmDesc& d, float descal
                 if (d.gamma) gam[h][c] = d.gamma[n + 4 * h + c];
             }
     }
+    auto emit_row = [&](int r, int m) __attribute__((always_inline)) {  // staged row r -> output row m
+        f4 v[2];
+        v[0] = *(const f4*)(Os + r * OSLD + c8);
+        v[1] = *(const f4*)(Os + r * OSLD + c8 + 4);
+        if (m >= d.M || !ncol_ok) return;
+        const size_t off = (size_t)m * d.ldc + n;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[h][c] = act_apply(v[h][c] * descale + bias[h][c], d.act) * gam[h][c];
+            if (R) v[h] += *(const f4*)(R + off + 4 * h);
+            if (R2) v[h] += *(const f4*)(R2 + off + 4 * h);
+            if (C) *(f4*)(C + off + 4 * h) = v[h];
+        }
+        if (d.C_hl) {
+            h8 hh, ll;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float x = v[c >> 2][c & 3];
+                _Float16 a, b;
+                pp_split_f16(d.c_relu ? fmaxf(x, 0.f) : x, a, b);
+                hh[c] = a;
+                ll[c] = b;
+            }
+            _Float16* hp = (_Float16*)d.C_hl + (size_t)m * 2 * d.ldc_h + 2 * n;
+            *(h8*)hp = hh;
+            *(h8*)(hp + 8) = ll;
+        }
+    };
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        if (RP == 32) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Os[((e & 3) + 8 * (e >> 2) + 4 * lh) * OSLD + j * 32 + l31] = acc[i][j][e];
+                for (int e = 0; e < 16; ++e) Os[((e & 3) + 8 * (e >> 2) + 4 * lh) * OSLD + j * 32 + l31] = acc[i][j][e];
 #pragma unroll
-        for (int it = 0; it < 32 / RPP; ++it) {
-            const int r = it * RPP + rr, m = mw + i * 32 + r;
-            f4 v[2];
-            v[0] = *(const f4*)(Os + r * OSLD + c8);
-            v[1] = *(const f4*)(Os + r * OSLD + c8 + 4);
-            if (m >= d.M || !ncol_ok) continue;
-            const size_t off = (size_t)m * d.ldc + n;
+            for (int it = 0; it < 32 / RPP; ++it) emit_row(it * RPP + rr, mw + i * 32 + it * RPP + rr);
+        } else {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int g = 0; g < 4; ++g) {  // rows 8 g .. 8 g + 7 of the block = accumulator registers 4 g .. 4 g + 3
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[h][c] = act_apply(v[h][c] * descale + bias[h][c], d.act) * gam[h][c];
-                if (R) v[h] += *(const f4*)(R + off + 4 * h);
-                if (R2) v[h] += *(const f4*)(R2 + off + 4 * h);
-                if (C) *(f4*)(C + off + 4 * h) = v[h];
-            }
-            if (d.C_hl) {
-                h8 hh, ll;
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float x = v[c >> 2][c & 3];
-                    _Float16 a, b;
-                    pp_split_f16(d.c_relu ? fmaxf(x, 0.f) : x, a, b);
-                    hh[c] = a;
-                    ll[c] = b;
-                }
-                _Float16* hp = (_Float16*)d.C_hl + (size_t)m * 2 * d.ldc_h + 2 * n;
-                *(h8*)hp = hh;
-                *(h8*)(hp + 8) = ll;
+                    for (int e = 0; e < 4; ++e) Os[(e + 4 * lh) * OSLD + j * 32 + l31] = acc[i][j][4 * g + e];
+                emit_row(rr, mw + i * 32 + 8 * g + rr);
             }
         }
     }
@@ -1123,6 +1136,226 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3g_kernel(const PpGemmDesc
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Persistent form of the LDS-DMA kernel (MODE 0 dense, 1 channel-slice-major convolution): one workgroup per CU
+// walks a sequence of 256x128 output tiles, and the DMA stream runs ahead ACROSS tile boundaries — while the last
+// K tiles of one output tile are being multiplied the first K tiles of the next are already landing in the ring, so
+// a new tile starts without the launch + first-tile latency and its epilogue overlaps the next tile's loads.  The
+// K loop, ring protocol and arithmetic (hence every result bit) are those of pp_gemm_f16x3g_kernel; the epilogue
+// stages through a separate 16 KB LDS patch (8-row groups) because the ring is never idle.
+//   vmcnt: the epilogue's stores / residual loads are younger than the DMA pieces in flight; `vmcnt(6)` after an
+//   epilogue therefore over-waits (at most six operations of any kind outstanding implies the older tile has
+//   landed: loads retire in order) — never under-waits.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void pp_gemm_f16x3p_kernel(const PpGemmDesc d, int gx, int gy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(MODE == 0 || MODE == 1, "natural-order convolutions use pp_gemm_f16x3g_kernel");
+    extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
+    // tiles of this workgroup: XCD x = id % 8 owns a contiguous chunk of the tile list; its workgroups interleave
+    // over it, so the tiles in flight on one XCD at any time are neighbours (shared A rows / halo / B columns in L2)
+    const int ntiles = gx * gy, nxw = (int)gridDim.x >> 3;  // gridDim.x is a multiple of 8
+    const int xcd = blockIdx.x & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int chunk1 = chunk0 + (xcd < r8 ? q8 + 1 : q8);
+    const int first = chunk0 + (int)(blockIdx.x >> 3);
+    if (first >= chunk1) return;
+    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
+    const int lr = lane >> 3;
+    const int sc = (lane & 7) ^ ((((w & 1) << 2) + (lr >> 1)) & 7);
+    const int k8 = (sc >> 1) * 8;
+    const unsigned pbyte = (unsigned)(sc & 1) * 16;
+    const int ntaps = d.conv_kh * d.conv_kw;
+    const int nk = (d.K + BK - 1) / BK;
+
+    // ---- fetch side: addressing state of the tile the DMA stream is in
+    unsigned abyte[4], amask[4], bbyte[2];   // A rows: byte offset of k = 0 (+ this lane's chunk); tap mask / row-valid bit
+    int ftile = first, fkt = 0;              // tile and K-tile index of the next DMA group (wave-uniform)
+    int ctap = 0, cky = 0, ckx = 0, cci = 0;
+    // (macros, not nested lambdas: state captured by reference stayed in scratch memory, and every scratch store /
+    // reload counts in vmcnt — hipcc then drained the DMA pipeline with vmcnt(0) inside the K loop)
+#define PP_P_SETUP(TILE)                                                                                             \
+    {                                                                                                                \
+        const int m0_ = ((TILE) / gx) * GBM, n0_ = ((TILE) % gx) * GBN;                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+            const int m = m0_ + (j * 8 + w) * 8 + lr;                                                                \
+            const bool ok = m < d.M;                                                                                 \
+            long long base = ok ? (long long)m * d.lda : 0;                                                          \
+            unsigned mask = ok ? 1u : 0u;                                                                            \
+            if (MODE == 1) {                                                                                         \
+                mask = 0u;                                                                                           \
+                if (ok) {                                                                                            \
+                    const int per = d.conv_ho * d.conv_wo;                                                           \
+                    const int bi = m / per, r = m - bi * per;                                                        \
+                    const int oy = (r / d.conv_wo) * d.conv_stride - d.conv_pad,                                     \
+                              ox = (r % d.conv_wo) * d.conv_stride - d.conv_pad;                                     \
+                    base = (long long)bi * d.conv_bstride + ((long long)oy * d.conv_w + ox) * d.lda;                 \
+                    for (int t = 0; t < ntaps; ++t) {                                                                \
+                        const int iy = oy + t / d.conv_kw, ix = ox + t % d.conv_kw;                                  \
+                        if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) mask |= 1u << t;                   \
+                    }                                                                                                \
+                }                                                                                                    \
+            }                                                                                                        \
+            abyte[j] = (unsigned)((base + k8) * 4) + pbyte;                                                          \
+            amask[j] = mask;                                                                                         \
+        }                                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
+            const int nb = n0_ + (j * 8 + w) * 8 + lr;                                                               \
+            bbyte[j] = nb < d.N ? (unsigned)(((long long)nb * d.ldb + k8) * 4) + pbyte : 0xFFFFFFFFu;                \
+        }                                                                                                            \
+        fkt = 0;                                                                                                     \
+        ctap = cky = ckx = cci = 0;                                                                                  \
+    }
+    // the DMA stream moves to the workgroup's next tile once a tile's nk K tiles have been issued
+#define PP_P_NEXT_TILE_IF_DONE()                                \
+    if (fkt == nk && ftile < chunk1) {                          \
+        ftile += nxw;                                           \
+        if (ftile < chunk1) PP_P_SETUP(ftile) else fkt = 0;     \
+    }
+    // byte offsets of the six pieces of K tile fkt of tile ftile (0xFFFFFFFF reads zeros: padding, tails, past the end)
+    auto off_a = [&](int j) __attribute__((always_inline)) -> unsigned {
+        if (MODE == 1) {
+            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci) * 4);
+            const unsigned ok = (amask[j] >> ctap) & (ftile < chunk1 ? 1u : 0u);
+            return (abyte[j] + tapoff) | (ok - 1u);
+        }
+        const unsigned ok = amask[j] & (ftile < chunk1 ? 1u : 0u) & (fkt * BK + k8 < d.K ? 1u : 0u);
+        return (abyte[j] + (unsigned)(fkt * BK * 4)) | (ok - 1u);
+    };
+    auto off_b = [&](int j) __attribute__((always_inline)) -> unsigned {
+        const unsigned live = (ftile < chunk1 ? 1u : 0u) & (bbyte[j] != 0xFFFFFFFFu ? 1u : 0u);
+        if (MODE == 1) return (bbyte[j] + (unsigned)((ctap * d.conv_cin + cci) * 4)) | (live - 1u);
+        return (bbyte[j] + (unsigned)(fkt * BK * 4)) | ((live & (fkt * BK + k8 < d.K ? 1u : 0u)) - 1u);
+    };
+    auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * G_STAGE + ((j * 8 + w) * 8) * G_ROWH), 16, off_a(j), 0, 0, 0);
+    };
+    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * G_STAGE + G_A_H + ((j * 8 + w) * 8) * G_ROWH), 16, off_b(j), 0, 0, 0);
+    };
+#define PP_P_ADVANCE() /* after the six pieces of a K tile */                                       \
+    {                                                                                              \
+        if (MODE == 1) {                                                                           \
+            const bool row_end = ckx + 1 == d.conv_kw, tap_end = row_end && cky + 1 == d.conv_kh;  \
+            ckx = row_end ? 0 : ckx + 1;                                                           \
+            cky = tap_end ? 0 : (row_end ? cky + 1 : cky);                                         \
+            ctap = tap_end ? 0 : ctap + 1;                                                         \
+            cci = tap_end ? cci + BK : cci;                                                        \
+        }                                                                                          \
+        ++fkt;                                                                                     \
+    }
+#define PP_P_FETCH(STAGE)                                               \
+    {                                                                   \
+        PP_P_NEXT_TILE_IF_DONE()                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) dma_a(STAGE, j);  \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) dma_b(STAGE, j);  \
+        PP_P_ADVANCE()                                                  \
+    }
+
+    const int sw = (l31 >> 1) & 7;
+    struct Frag {
+        h8 ah[2], al[2], bh[2], bl[2];
+    };
+    f32x16 acc[2][2];
+    auto load_frag = [&](Frag& f, int stage, int ks) __attribute__((always_inline)) {
+        const _Float16* st = glds + stage * G_STAGE;
+        const int ch = (((ks * 2 + lh) * 2) ^ sw) * 8, cl = (((ks * 2 + lh) * 2 + 1) ^ sw) * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * G_ROWH + ch);
+            f.al[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * G_ROWH + cl);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f.bh[j] = *(const h8*)(st + G_A_H + (wc * 64 + j * 32 + l31) * G_ROWH + ch);
+            f.bl[j] = *(const h8*)(st + G_A_H + (wc * 64 + j * 32 + l31) * G_ROWH + cl);
+        }
+    };
+    auto mma1 = [&](const Frag& f, int i, int j) __attribute__((always_inline)) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+    };
+    auto mma = [&](const Frag& f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma1(f, i, j);
+    };
+
+    PP_P_SETUP(first)
+    PP_P_FETCH(0)
+    PP_P_FETCH(1)
+    PP_P_FETCH(2)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frag f0, f1;
+    load_frag(f0, 0, 0);
+    int cur = 0, nxt = 1;
+    float* patch = (float*)(glds + G_STAGES * G_STAGE) + w * 512;  // 2 KB per wave behind the ring
+    const float descale = d.alpha / (A_SCALE * d.b_scale);
+    for (int tile = first; tile < chunk1; tile += nxw) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            load_frag(f1, cur, 1);
+            mma(f0);
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            PP_P_NEXT_TILE_IF_DONE()
+            const _Float16* st = glds + nxt * G_STAGE;
+            const int ch = ((lh * 2) ^ sw) * 8, cl = ((lh * 2 + 1) ^ sw) * 8;
+            const _Float16* ap = st + (wr * 64 + l31) * G_ROWH;
+            const _Float16* bp = st + G_A_H + (wc * 64 + l31) * G_ROWH;
+            dma_a(cur, 0);
+            f0.ah[0] = *(const h8*)(ap + ch);
+            f0.al[0] = *(const h8*)(ap + cl);
+            mma1(f1, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_a(cur, 1);
+            f0.bh[0] = *(const h8*)(bp + ch);
+            f0.bl[0] = *(const h8*)(bp + cl);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_a(cur, 2);
+            mma1(f1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_a(cur, 3);
+            f0.ah[1] = *(const h8*)(ap + 32 * G_ROWH + ch);
+            f0.al[1] = *(const h8*)(ap + 32 * G_ROWH + cl);
+            mma1(f1, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_b(cur, 0);
+            f0.bh[1] = *(const h8*)(bp + 32 * G_ROWH + ch);
+            f0.bl[1] = *(const h8*)(bp + 32 * G_ROWH + cl);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_b(cur, 1);
+            PP_P_ADVANCE()
+            mma1(f1, 1, 1);
+            cur = nxt;
+            nxt = nxt == G_STAGES - 1 ? 0 : nxt + 1;
+        }
+        // epilogue of this tile; the ring keeps receiving the next tile meanwhile (f0 already holds its first fragments)
+        epilogue_block<2, 8>(d, descale, acc, patch, (tile / gx) * GBM + wr * 64, (tile % gx) * GBN + wc * 64, lane);
+        // a compiler-visible full wait: with the epilogue's loads / stores pending at the loop header hipcc would put a
+        // vmcnt(0) in front of the fragment reads of EVERY K tile (the stores have to retire before the next counted
+        // wait anyway, and the two tiles in flight have landed during the epilogue)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS at exit
+#undef PP_P_SETUP
+#undef PP_P_NEXT_TILE_IF_DONE
+#undef PP_P_ADVANCE
+#undef PP_P_FETCH
+#endif
+}
+
 namespace {
 
 // activation pre-split: x (B, P, C) fp32 with batch / row strides -> contiguous hl operand (B*P rows, ld = C):
@@ -1410,13 +1643,21 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         const int lds = G_STAGES * G_STAGE * 2;
         return hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384) == hipSuccess &&
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384) == hipSuccess;
     }();
     if (!big_ok) return PP_ELAUNCH;
-    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA
+    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA, 4: persistent LDS-DMA
         const bool narrow = cfg == 2;
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
-        if (asplit && cfg == 3) {
+        if (asplit && cfg == 4) {  // persistent LDS-DMA kernel: one workgroup per CU (a multiple of 8), dense / channel-major conv
+            const int gx = (d.N + GBN - 1) / GBN, gy = (d.M + GBM - 1) / GBM;
+            const int nt = gx * gy, g = nt < cus ? (nt + 7) / 8 * 8 : cus / 8 * 8;
+            const int lds = G_STAGES * G_STAGE * 2 + 16384;
+            if (d.conv_kh == 0) hipLaunchKernelGGL(pp_gemm_f16x3p_kernel<0>, dim3(g), dim3(512), lds, st, d, gx, gy);
+            else hipLaunchKernelGGL(pp_gemm_f16x3p_kernel<1>, dim3(g), dim3(512), lds, st, d, gx, gy);
+        } else if (asplit && cfg == 3) {
             const int gx = (d.N + GBN - 1) / GBN, gy = (d.M + GBM - 1) / GBM;
             const int mode = d.conv_kh == 0 ? 0 : (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32 ? 1 : 2);
             if (mode == 0) hipLaunchKernelGGL(pp_gemm_f16x3g_kernel<0>, dim3(gx * gy), dim3(512), G_STAGES * G_STAGE * 2, st, d, gx, gy);
@@ -1452,8 +1693,9 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     int cfg = d.N <= 64 ? 2 : 0;
     if (const char* f = getenv("PP_GEMM_FORCE_CFG")) {  // tests: pin one kernel configuration (3 needs pre-split operands)
         const int fc = atoi(f);
-        if (fc >= 0 && fc <= 3 && (fc != 3 || asplit) && (fc != 1 || !asplit)) {
-            launch(fc);
+        const bool p_ok = asplit && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
+        if (fc >= 0 && fc <= 4 && (fc < 3 || asplit) && (fc != 1 || !asplit)) {
+            launch(fc == 4 && !p_ok ? 3 : fc);
             return pp_last_launch();
         }
     }
@@ -1475,9 +1717,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             int bc = 0;
             // pre-split operands: 128x128, 128x64 and (for problems that fill the chip with 256x128 tiles) the LDS-DMA kernel
             const bool big = asplit && (long long)((d.M + GBM - 1) / GBM) * ((d.N + GBN - 1) / GBN) >= cus / 2;
-            for (int c = 0; c < ((vec || big) ? 3 : 2); ++c) {
-                const int cand = asplit ? (c == 0 ? 0 : c == 1 ? 2 : 3) : (vec ? c : (c == 0 ? 0 : 2));
-                if (cand == 3 && !big) continue;
+            const bool p_ok = big && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
+            for (int c = 0; c < (asplit ? 4 : (vec ? 3 : 2)); ++c) {
+                const int cand = asplit ? (c == 0 ? 0 : c == 1 ? 2 : c == 2 ? 3 : 4) : (vec ? c : (c == 0 ? 0 : 2));
+                if ((cand == 3 && !big) || (cand == 4 && !p_ok)) continue;
                 launch(cand);  // warm
                 (void)hipEventRecord(e0, st);
                 launch(cand);

@@ -144,9 +144,23 @@ def test_lds_dma_kernel_pinned(monkeypatch, engine_precision):
         pytest.skip("pre-split operands exist in f16x3 mode only")
     from picopose_amd import ops
 
-    monkeypatch.setenv("PP_GEMM_FORCE_CFG", "3")
+    _pinned_big_kernel_cases(monkeypatch, "3")
+
+
+@gpu
+def test_persistent_lds_dma_kernel_pinned(monkeypatch, engine_precision):
+    """Same cases on the persistent form (configuration 4; shapes it does not cover fall back to configuration 3)."""
+    if engine_precision != "f16x3":
+        pytest.skip("pre-split operands exist in f16x3 mode only")
+    _pinned_big_kernel_cases(monkeypatch, "4")
+
+
+def _pinned_big_kernel_cases(monkeypatch, cfg):
+    from picopose_amd import ops
+
+    monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
     g = torch.Generator().manual_seed(77)
-    for M, K, N in [(257, 384, 1152), (1000, 768, 768), (300, 72, 130), (5, 4096, 64), (513, 32, 129)]:
+    for M, K, N in [(257, 384, 1152), (1000, 768, 768), (300, 72, 130), (5, 4096, 64), (513, 32, 129), (70000, 96, 256)]:
         x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
         _close(ops.linear(x.cuda(), w.cuda(), b.cuda(), act="gelu"), F.gelu(F.linear(x, w, b)))
     for cin, cout, k, s, p, hw in [(640, 512, 3, 1, 1, 32), (256, 256, 3, 2, 1, 16), (256, 256, 1, 1, 0, 16), (72, 136, 3, 1, 1, 20),
@@ -210,7 +224,7 @@ def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, 
     xi = torch.randn(2, 24, 24, 64, generator=g).cuda()
     wc = ops.pack_conv_weight((torch.randn(256, 64, 3, 3, generator=g) / 24).cuda())
     outs = []
-    for cfg in ("0", "2", "3"):
+    for cfg in ("0", "2", "3", "4"):
         monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
         outs.append((ops.linear(x, w, b, act="gelu"), ops.conv2d(xi, wc, None, 3, pad=1, act="relu")))
     for lin, conv in outs[1:]:
