@@ -10,7 +10,7 @@ for name, K, N, act in shapes:
     xs = ops.Split(ops.split_activation(x, 1, M, K, 0, K))
     for cfg in os.environ.get("CFGS", "0,2,3").split(","):
         os.environ["PP_GEMM_FORCE_CFG"] = cfg
-        for split_out in (False,):
+        for split_out in ((False, True) if os.environ.get("PLANES") else (False,)):
             for _ in range(3): y = ops.linear(xs, w, b, act=act, out_split=split_out)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
