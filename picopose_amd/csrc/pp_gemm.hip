@@ -1699,7 +1699,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             return pp_last_launch();
         }
     }
-    const bool alias = d.residual == d.C || d.residual2 == d.C;
+    const bool alias = d.C != nullptr && (d.residual == d.C || d.residual2 == d.C);  // (C is null for operand-only outputs)
     static const bool tune = [] { const char* e = getenv("PP_GEMM_AUTOTUNE"); return !(e && e[0] == '0'); }();
     if (tune && !alias && d.N > 64) {
         static std::mutex mu;
@@ -1732,6 +1732,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                     (void)hipEventElapsedTime(&t, e0, e1);
                     ms = t < ms ? t : ms;
                 }
+                if (dbg) fprintf(stderr, "[pp_gemm] autotune %s cfg %d: %.4f ms\n", key, cand, ms);
                 if (ms < bt) {
                     bt = ms;
                     bc = cand;
