@@ -36,3 +36,37 @@ def infer_batch(net, end_points, hyp=5):
         hyps.sort(key=lambda h: h["inliers_ratio"], reverse=True)                   # run_test.py:186
         results.append(hyps)
     return results
+
+
+def infer_image(net, data, templates_data, hyp=5, bs=16):
+    """One test image exactly as run_test.py:141-188 walks it: `data` holds the image's instances on dim 1
+    (data[key][0] = (n_instance, ...), plus 'obj_idx'), `templates_data[key]` the per-object template bank
+    ((n_objects, N, ...), including 'template_feature' and, optionally, an extended bank under 'template_cache').
+    Instances are processed in mini-batches of `bs`; returns preds_image: per instance the hypotheses sorted by
+    inlier ratio, each {'R_stage_3' (9,), 't_stage_3' (3,) in mm, 'inliers_ratio'} (run_test.py:181-186)."""
+    n_instance = data["score"].shape[1]
+    preds_image = []
+    for start in range(0, n_instance, bs):
+        end = min(start + bs, n_instance)
+        obj_idx = data["obj_idx"][0][start:end].reshape(-1)
+        inputs = {k: v[0][start:end].contiguous() for k, v in data.items()}
+        for k, v in templates_data.items():
+            if k == "template_cache":   # extended bank: maps stay per object, instances carry their object index
+                inputs[k] = {"obj_index": obj_idx, "dpt": v["dpt"]}
+            else:
+                inputs[k] = v[obj_idx].contiguous()
+        for hyps in infer_batch(net, inputs, hyp):
+            preds_image.append([{"R_stage_3": np.asarray(h["R"], dtype=np.float64).reshape(9),
+                                 "t_stage_3": np.asarray(h["t"], dtype=np.float64).reshape(3) * 1000,
+                                 "inliers_ratio": h["inliers_ratio"]} for h in hyps])
+    return preds_image
+
+
+def bop_csv_lines(scene_id, img_id, obj_ids, scores, preds_image, image_time):
+    """The BOP results rows of run_test.py:191-206: one line per instance, best hypothesis, t in millimetres."""
+    lines = []
+    for k, preds in enumerate(preds_image):
+        lines.append(",".join((str(scene_id), str(img_id), str(obj_ids[k]), str(scores[k]),
+                               " ".join(str(v) for v in preds[0]["R_stage_3"]),
+                               " ".join(str(v) for v in preds[0]["t_stage_3"]), f"{image_time}\n")))
+    return lines

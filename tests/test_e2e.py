@@ -119,3 +119,39 @@ def test_extended_template_cache_gives_identical_outputs(batched):
             assert torch.equal(got[h][k], ref[h][k]), (h, k)
     # the bank feature of precompute_templates is the reference's bank (run_test.py:130-131)
     assert torch.equal(banks[0]["feature"], net.feature_extractor(dev["tem_rgb"][0])[-1])
+
+
+@gpu
+def test_infer_image_walks_instances_like_run_test():
+    """pipeline.infer_image (run_test.py:141-188): instance mini-batches, templates gathered per object, hypotheses
+    sorted by inlier ratio, t in millimetres — with and without the extended template bank."""
+    from picopose_amd.picopose import Net
+    from picopose_amd.pipeline import infer_batch, infer_image
+
+    n_obj, N, n_inst, hyp = 2, 4, 3, 2
+    net = Net(small_cfg())
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 5))
+    net = net.cuda().eval()
+    tem = {k: v.cuda() for k, v in make_end_points(n_obj, N, 71).items() if k.startswith("tem_")}   # per-object banks
+    banks = [net.precompute_templates(tem["tem_rgb"][o]) for o in range(n_obj)]
+    tem["template_feature"] = torch.stack([b["feature"] for b in banks])
+    inst = {k: v.cuda() for k, v in make_end_points(n_inst, 1, 72).items() if k.startswith("real_")}
+    data = {k: v[None] for k, v in inst.items()}
+    data["obj_idx"] = torch.tensor([[1, 0, 1]], device="cuda")
+    data["score"] = torch.tensor([[0.9, 0.8, 0.7]], device="cuda")
+    preds = infer_image(net, data, tem, hyp=hyp, bs=2)
+    assert len(preds) == n_inst and all(len(p) == hyp for p in preds)
+    for p in preds:
+        assert p[0]["inliers_ratio"] >= p[1]["inliers_ratio"] and p[0]["R_stage_3"].shape == (9,) and p[0]["t_stage_3"].shape == (3,)
+    # same numbers as one batch over all instances
+    inputs = dict(inst)
+    inputs.update({k: v[data["obj_idx"][0]] for k, v in tem.items()})
+    for got, ref in zip(preds, infer_batch(net, inputs, hyp)):
+        for g, r in zip(got, ref):
+            assert np.allclose(g["R_stage_3"], np.asarray(r["R"]).reshape(9), atol=1e-6)
+            assert np.allclose(g["t_stage_3"], np.asarray(r["t"]).reshape(3) * 1000, atol=1e-3)
+    # extended bank: identical poses
+    tem["template_cache"] = {"dpt": [torch.stack([b["dpt"][k] for b in banks]) for k in range(3)]}
+    for got, ref in zip(infer_image(net, data, tem, hyp=hyp, bs=2), preds):
+        for g, r in zip(got, ref):
+            assert np.array_equal(g["R_stage_3"], r["R_stage_3"]) and np.array_equal(g["t_stage_3"], r["t_stage_3"])

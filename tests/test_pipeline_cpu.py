@@ -1,0 +1,15 @@
+"""CPU: evaluator-side formatting — no GPU, no library calls."""
+import numpy as np
+
+from picopose_amd.pipeline import bop_csv_lines
+
+
+def test_bop_csv_lines_format_matches_run_test():
+    # run_test.py:191-206: scene,img,obj,score,"R (9 values)","t in mm (3 values)",time\n — best hypothesis first
+    preds_image = [[{"R_stage_3": np.eye(3).reshape(9), "t_stage_3": np.array([0.01, -0.02, 0.8]) * 1000, "inliers_ratio": 0.9},
+                    {"R_stage_3": np.zeros(9), "t_stage_3": np.zeros(3), "inliers_ratio": 0.1}]]
+    (line,) = bop_csv_lines(3, 17, [5], [0.75], preds_image, 0.25)
+    f = line.split(",")
+    assert f[:4] == ["3", "17", "5", "0.75"] and line.endswith("0.25\n")
+    assert [float(v) for v in f[4].split(" ")] == list(np.eye(3).reshape(9))
+    assert np.allclose([float(v) for v in f[5].split(" ")], [10.0, -20.0, 800.0])
