@@ -1376,6 +1376,232 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3p_kernel(const PpGemmDesc
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Persistent LDS-DMA kernel with a 256x256 block tile (MODE 0 dense, 1 channel-slice-major convolution): 8 waves as
+// 2 x 4, each a 128x64 output block in 128 accumulator registers.  Per MFMA it needs 25 % fewer LDS fragment reads
+// and a third fewer L2 -> LDS bytes / DMA instructions than the 256x128 tile.  To fit 256 VGPRs the fragments are
+// handled in quarter-tile units (K half x pair of 32-row blocks: 12 MFMAs), the next unit's A fragments (and, at a K
+// half change, B fragments) are read while the current unit multiplies.  LDS: 2 stages x 64 KB + the 16 KB
+// epilogue patch; one tile in flight: the DMA of tile t+2 is issued (interleaved with the last unit's MFMAs) right
+// after the barrier that frees tile t's stage and has the three other units of tile t+1 to land.
+// Same summation order as every other pre-split kernel.
+// ---------------------------------------------------------------------------
+constexpr int QBM = 256, QBN = 256;
+constexpr int Q_A_H = QBM * G_ROWH, Q_B_H = QBN * G_ROWH;  // halfs per operand per stage
+constexpr int Q_STAGE = Q_A_H + Q_B_H;                      // 32768 halfs = 64 KB
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void pp_gemm_f16x3q_kernel(const PpGemmDesc d, int gx, int gy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(MODE == 0 || MODE == 1, "natural-order convolutions use pp_gemm_f16x3g_kernel");
+    extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3, l31 = lane & 31, lh = lane >> 5;
+    const int ntiles = gx * gy, nxw = (int)gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int chunk1 = chunk0 + (xcd < r8 ? q8 + 1 : q8);
+    const int first = chunk0 + (int)(blockIdx.x >> 3);
+    if (first >= chunk1) return;
+    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
+    const int lr = lane >> 3;
+    const int sc = (lane & 7) ^ ((((w & 1) << 2) + (lr >> 1)) & 7);
+    const int k8 = (sc >> 1) * 8;
+    const unsigned pbyte = (unsigned)(sc & 1) * 16;
+    const int ntaps = d.conv_kh * d.conv_kw;
+    const int nk = (d.K + BK - 1) / BK;
+
+    unsigned abyte[4], amask[4], bbyte[4];
+    int ftile = first, fkt = 0;
+    int ctap = 0, cky = 0, ckx = 0, cci = 0;
+#define PP_Q_SETUP(TILE)                                                                                             \
+    {                                                                                                                \
+        const int m0_ = ((TILE) / gx) * QBM, n0_ = ((TILE) % gx) * QBN;                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+            const int m = m0_ + (j * 8 + w) * 8 + lr;                                                                \
+            const bool ok = m < d.M;                                                                                 \
+            long long base = ok ? (long long)m * d.lda : 0;                                                          \
+            unsigned mask = ok ? 1u : 0u;                                                                            \
+            if (MODE == 1) {                                                                                         \
+                mask = 0u;                                                                                           \
+                if (ok) {                                                                                            \
+                    const int per = d.conv_ho * d.conv_wo;                                                           \
+                    const int bi = m / per, r = m - bi * per;                                                        \
+                    const int oy = (r / d.conv_wo) * d.conv_stride - d.conv_pad,                                     \
+                              ox = (r % d.conv_wo) * d.conv_stride - d.conv_pad;                                     \
+                    base = (long long)bi * d.conv_bstride + ((long long)oy * d.conv_w + ox) * d.lda;                 \
+                    for (int t = 0; t < ntaps; ++t) {                                                                \
+                        const int iy = oy + t / d.conv_kw, ix = ox + t % d.conv_kw;                                  \
+                        if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) mask |= 1u << t;                   \
+                    }                                                                                                \
+                }                                                                                                    \
+            }                                                                                                        \
+            abyte[j] = (unsigned)((base + k8) * 4) + pbyte;                                                          \
+            amask[j] = mask;                                                                                         \
+            const int nb = n0_ + (j * 8 + w) * 8 + lr;                                                               \
+            bbyte[j] = nb < d.N ? (unsigned)(((long long)nb * d.ldb + k8) * 4) + pbyte : 0xFFFFFFFFu;                \
+        }                                                                                                            \
+        fkt = 0;                                                                                                     \
+        ctap = cky = ckx = cci = 0;                                                                                  \
+    }
+#define PP_Q_NEXT_TILE_IF_DONE()                                \
+    if (fkt == nk && ftile < chunk1) {                          \
+        ftile += nxw;                                           \
+        if (ftile < chunk1) PP_Q_SETUP(ftile) else fkt = 0;     \
+    }
+    auto off_a = [&](int j) __attribute__((always_inline)) -> unsigned {
+        if (MODE == 1) {
+            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci) * 4);
+            const unsigned ok = (amask[j] >> ctap) & (ftile < chunk1 ? 1u : 0u);
+            return (abyte[j] + tapoff) | (ok - 1u);
+        }
+        const unsigned ok = amask[j] & (ftile < chunk1 ? 1u : 0u) & (fkt * BK + k8 < d.K ? 1u : 0u);
+        return (abyte[j] + (unsigned)(fkt * BK * 4)) | (ok - 1u);
+    };
+    auto off_b = [&](int j) __attribute__((always_inline)) -> unsigned {
+        const unsigned live = (ftile < chunk1 ? 1u : 0u) & (bbyte[j] != 0xFFFFFFFFu ? 1u : 0u);
+        if (MODE == 1) return (bbyte[j] + (unsigned)((ctap * d.conv_cin + cci) * 4)) | (live - 1u);
+        return (bbyte[j] + (unsigned)(fkt * BK * 4)) | ((live & (fkt * BK + k8 < d.K ? 1u : 0u)) - 1u);
+    };
+    auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * Q_STAGE + ((j * 8 + w) * 8) * G_ROWH), 16, off_a(j), 0, 0, 0);
+    };
+    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * Q_STAGE + Q_A_H + ((j * 8 + w) * 8) * G_ROWH), 16, off_b(j), 0, 0, 0);
+    };
+#define PP_Q_ADVANCE()                                                                             \
+    {                                                                                              \
+        if (MODE == 1) {                                                                           \
+            const bool row_end = ckx + 1 == d.conv_kw, tap_end = row_end && cky + 1 == d.conv_kh;  \
+            ckx = row_end ? 0 : ckx + 1;                                                           \
+            cky = tap_end ? 0 : (row_end ? cky + 1 : cky);                                         \
+            ctap = tap_end ? 0 : ctap + 1;                                                         \
+            cci = tap_end ? cci + BK : cci;                                                        \
+        }                                                                                          \
+        ++fkt;                                                                                     \
+    }
+
+    const int sw = (l31 >> 1) & 7;
+    struct AF {
+        h8 h[2], l[2];  // two 32-row blocks, hi / lo terms
+    };
+    f32x16 acc[4][2];
+    // A fragments of K half ks, row blocks 2 ip, 2 ip + 1; B fragments of K half ks (column blocks 0, 1)
+    auto load_a = [&](AF& f, int stage, int ks, int ip) __attribute__((always_inline)) {
+        const _Float16* st = glds + stage * Q_STAGE + (wr * 128 + ip * 64 + l31) * G_ROWH;
+        const int ch = (((ks * 2 + lh) * 2) ^ sw) * 8, cl = (((ks * 2 + lh) * 2 + 1) ^ sw) * 8;
+        f.h[0] = *(const h8*)(st + ch);
+        f.l[0] = *(const h8*)(st + cl);
+        f.h[1] = *(const h8*)(st + 32 * G_ROWH + ch);
+        f.l[1] = *(const h8*)(st + 32 * G_ROWH + cl);
+    };
+    auto load_b = [&](AF& f, int stage, int ks) __attribute__((always_inline)) {
+        const _Float16* st = glds + stage * Q_STAGE + Q_A_H + (wc * 64 + l31) * G_ROWH;
+        const int ch = (((ks * 2 + lh) * 2) ^ sw) * 8, cl = (((ks * 2 + lh) * 2 + 1) ^ sw) * 8;
+        f.h[0] = *(const h8*)(st + ch);
+        f.l[0] = *(const h8*)(st + cl);
+        f.h[1] = *(const h8*)(st + 32 * G_ROWH + ch);
+        f.l[1] = *(const h8*)(st + 32 * G_ROWH + cl);
+    };
+    auto mma1 = [&](const AF& a, const AF& b, int ip, int i, int j) __attribute__((always_inline)) {
+        acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l[i], b.h[j], acc[2 * ip + i][j], 0, 0, 0);
+        acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[i], b.l[j], acc[2 * ip + i][j], 0, 0, 0);
+        acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[i], b.h[j], acc[2 * ip + i][j], 0, 0, 0);
+    };
+    auto mma_unit = [&](const AF& a, const AF& b, int ip) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma1(a, b, ip, i, j);
+    };
+
+    PP_Q_SETUP(first)
+    {
+        PP_Q_NEXT_TILE_IF_DONE()
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_a(0, j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_b(0, j);
+        PP_Q_ADVANCE()
+        PP_Q_NEXT_TILE_IF_DONE()
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_a(1, j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_b(1, j);
+        PP_Q_ADVANCE()
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    AF a0, a1, b0, b1;
+    load_a(a0, 0, 0, 0);
+    load_b(b0, 0, 0);
+    int cur = 0;
+    float* patch = (float*)(glds + 2 * Q_STAGE) + w * 512;
+    const float descale = d.alpha / (A_SCALE * d.b_scale);
+    for (int tile = first; tile < chunk1; tile += nxw) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            // unit 0: (ks 0, rows 0-63)   | reads A(ks 0, rows 64-127)
+            load_a(a1, cur, 0, 1);
+            mma_unit(a0, b0, 0);
+            // unit 1: (ks 0, rows 64-127) | reads A(ks 1, rows 0-63), B(ks 1)
+            load_a(a0, cur, 1, 0);
+            load_b(b1, cur, 1);
+            mma_unit(a1, b0, 1);
+            // unit 2: (ks 1, rows 0-63)   | reads A(ks 1, rows 64-127)
+            load_a(a1, cur, 1, 1);
+            mma_unit(a0, b1, 0);
+            // tile kt+1 has landed (its DMA was issued one iteration ago), all fragment reads of tile kt are done
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // unit 3: (ks 1, rows 64-127) | DMA of tile kt+2 into the stage just freed, reads A(ks 0, rows 0-63), B(ks 0)
+            // of tile kt+1
+            PP_Q_NEXT_TILE_IF_DONE()
+            const int nst = cur ^ 1;
+            dma_a(cur, 0);
+            load_a(a0, nst, 0, 0);
+            mma1(a1, b1, 1, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_a(cur, 1);
+            dma_a(cur, 2);
+            load_b(b0, nst, 0);
+            mma1(a1, b1, 1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_a(cur, 3);
+            dma_b(cur, 0);
+            mma1(a1, b1, 1, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_b(cur, 1);
+            dma_b(cur, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_b(cur, 3);
+            PP_Q_ADVANCE()
+            mma1(a1, b1, 1, 1, 1);
+            cur = nst;
+        }
+        // epilogue: the wave's 128 x 64 block as two 64-row halves through the 2 KB patch
+        {
+            const int mw = (tile / gx) * QBM + wr * 128, nw = (tile % gx) * QBN + wc * 64;
+            f32x16(&lo)[2][2] = *reinterpret_cast<f32x16(*)[2][2]>(&acc[0]);
+            f32x16(&hi)[2][2] = *reinterpret_cast<f32x16(*)[2][2]>(&acc[2]);
+            epilogue_block<2, 8>(d, descale, lo, patch, mw, nw, lane);
+            epilogue_block<2, 8>(d, descale, hi, patch, mw + 64, nw, lane);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), visible to hipcc (see pp_gemm_f16x3p_kernel)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef PP_Q_SETUP
+#undef PP_Q_NEXT_TILE_IF_DONE
+#undef PP_Q_ADVANCE
+#endif
+}
+
 namespace {
 
 // activation pre-split: x (B, P, C) fp32 with batch / row strides -> contiguous hl operand (B*P rows, ld = C):
@@ -1665,13 +1891,21 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384) == hipSuccess;
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384) == hipSuccess &&
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess &&
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess;
     }();
     if (!big_ok) return PP_ELAUNCH;
-    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA, 4: persistent LDS-DMA
+    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA, 4: persistent LDS-DMA, 5: persistent LDS-DMA with 256x256 tiles
         const bool narrow = cfg == 2;
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
-        if (asplit && cfg == 4) {  // persistent LDS-DMA kernel: one workgroup per CU (a multiple of 8), dense / channel-major conv
+        if (asplit && cfg == 5) {  // persistent LDS-DMA kernel, 256x256 tiles
+            const int gx = (d.N + QBN - 1) / QBN, gy = (d.M + QBM - 1) / QBM;
+            const int nt = gx * gy, g = nt < cus ? (nt + 7) / 8 * 8 : cus / 8 * 8;
+            const int lds = 2 * Q_STAGE * 2 + 16384;
+            if (d.conv_kh == 0) hipLaunchKernelGGL(pp_gemm_f16x3q_kernel<0>, dim3(g), dim3(512), lds, st, d, gx, gy);
+            else hipLaunchKernelGGL(pp_gemm_f16x3q_kernel<1>, dim3(g), dim3(512), lds, st, d, gx, gy);
+        } else if (asplit && cfg == 4) {  // persistent LDS-DMA kernel: one workgroup per CU (a multiple of 8), dense / channel-major conv
             const int gx = (d.N + GBN - 1) / GBN, gy = (d.M + GBM - 1) / GBM;
             const int nt = gx * gy, g = nt < cus ? (nt + 7) / 8 * 8 : cus / 8 * 8;
             const int lds = G_STAGES * G_STAGE * 2 + 16384;
@@ -1714,8 +1948,8 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     if (const char* f = getenv("PP_GEMM_FORCE_CFG")) {  // tests: pin one kernel configuration (3 needs pre-split operands)
         const int fc = atoi(f);
         const bool p_ok = asplit && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
-        if (fc >= 0 && fc <= 4 && (fc < 3 || asplit) && (fc != 1 || !asplit)) {
-            launch(fc == 4 && !p_ok ? 3 : fc);
+        if (fc >= 0 && fc <= 5 && (fc < 3 || asplit) && (fc != 1 || !asplit)) {
+            launch(fc >= 4 && !(p_ok && (fc == 4 || d.N > 128)) ? 3 : fc);
             return pp_last_launch();
         }
     }
@@ -1738,9 +1972,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             // pre-split operands: 128x128, 128x64 and (for problems that fill the chip with 256x128 tiles) the LDS-DMA kernel
             const bool big = asplit && (long long)((d.M + GBM - 1) / GBM) * ((d.N + GBN - 1) / GBN) >= cus / 2;
             const bool p_ok = big && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
-            for (int c = 0; c < (asplit ? 4 : (vec ? 3 : 2)); ++c) {
-                const int cand = asplit ? (c == 0 ? 0 : c == 1 ? 2 : c == 2 ? 3 : 4) : (vec ? c : (c == 0 ? 0 : 2));
-                if ((cand == 3 && !big) || (cand == 4 && !p_ok)) continue;
+            const bool q_ok = p_ok && d.N > 128 && (long long)((d.M + QBM - 1) / QBM) * ((d.N + QBN - 1) / QBN) >= cus / 2;
+            for (int c = 0; c < (asplit ? 5 : (vec ? 3 : 2)); ++c) {
+                const int cand = asplit ? (c == 0 ? 0 : c == 1 ? 2 : c + 1) : (vec ? c : (c == 0 ? 0 : 2));
+                if ((cand == 3 && !big) || (cand == 4 && !p_ok) || (cand == 5 && !q_ok)) continue;
                 launch(cand);  // warm
                 float ms = 1e30f;
                 for (int rep = 0; rep < 2; ++rep) {  // best of two: single samples mis-rank configurations within ~5 %

@@ -155,6 +155,14 @@ def test_persistent_lds_dma_kernel_pinned(monkeypatch, engine_precision):
     _pinned_big_kernel_cases(monkeypatch, "4")
 
 
+@gpu
+def test_persistent_256x256_kernel_pinned(monkeypatch, engine_precision):
+    """Same cases on the 256x256-tile persistent kernel (configuration 5; falls back where it does not apply)."""
+    if engine_precision != "f16x3":
+        pytest.skip("pre-split operands exist in f16x3 mode only")
+    _pinned_big_kernel_cases(monkeypatch, "5")
+
+
 def _pinned_big_kernel_cases(monkeypatch, cfg):
     from picopose_amd import ops
 
@@ -224,7 +232,7 @@ def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, 
     xi = torch.randn(2, 24, 24, 64, generator=g).cuda()
     wc = ops.pack_conv_weight((torch.randn(256, 64, 3, 3, generator=g) / 24).cuda())
     outs = []
-    for cfg in ("0", "2", "3", "4"):
+    for cfg in ("0", "2", "3", "4", "5"):
         monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
         outs.append((ops.linear(x, w, b, act="gelu"), ops.conv2d(xi, wc, None, 3, pad=1, act="relu")))
     for lin, conv in outs[1:]:
