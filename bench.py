@@ -96,8 +96,8 @@ def make_cfg(vit):
 
 
 def seeded_weights(net, seed):
-    """Random-init weights of the architecture (no network for checkpoints): oracle/weights.py recipe."""
-    from oracle.weights import seeded_state_dict
+    """Random-init weights of the architecture (no network for checkpoints)."""
+    from picopose_amd.utils.seeding import seeded_state_dict
 
     sd = seeded_state_dict(net.state_dict(), seed)
     net.load_state_dict(sd)

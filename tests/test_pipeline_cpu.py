@@ -13,3 +13,16 @@ def test_bop_csv_lines_format_matches_run_test():
     assert f[:4] == ["3", "17", "5", "0.75"] and line.endswith("0.25\n")
     assert [float(v) for v in f[4].split(" ")] == list(np.eye(3).reshape(9))
     assert np.allclose([float(v) for v in f[5].split(" ")], [10.0, -20.0, 800.0])
+
+
+def test_package_seeding_recipe_equals_the_fixture_recipe():
+    import torch
+
+    from oracle.weights import seeded_state_dict as ref
+    from picopose_amd.utils.seeding import seeded_state_dict as got
+
+    tmpl = {"a.weight": torch.zeros(4, 3, 2, 2), "a.bias": torch.zeros(4), "bn.running_var": torch.zeros(4),
+            "bn.running_mean": torch.zeros(4), "bn.num_batches_tracked": torch.zeros((), dtype=torch.long),
+            "ls1.gamma": torch.zeros(4), "cls_token": torch.zeros(1, 1, 4), "n.weight": torch.zeros(4)}
+    a, b = ref(tmpl, 7), got(tmpl, 7)
+    assert all(torch.equal(a[k], b[k]) for k in tmpl)
