@@ -149,7 +149,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
 // ---------------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr int KHLD = 72;   // halfs per K row in LDS (64 + 8 pad: 144-byte stride, conflict-free ds_read_b128)
-constexpr int VTLD = 40;   // halfs per V^T row (32 key slots + 8 pad: 80-byte stride)
+constexpr int VLD = 96;    // halfs per V row in LDS (64 d + 32 pad: 192-byte stride = 48 banks: the four rows a
+                           // ds_read_b64_tr_b16 half-wave touches sit on disjoint bank quarters)
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 constexpr int OLD = 68;    // floats per staged output row
 constexpr float P_SCALE = 1024.f;
 
@@ -163,8 +166,8 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Kh = (_Float16*)smem;            // [KC][KHLD]
     _Float16* Kl = Kh + KC * KHLD;
-    _Float16* Vh = Kl + KC * KHLD;             // [HD][VTLD]  (V^T, permuted key slots)
-    _Float16* Vl = Vh + HD * VTLD;
+    _Float16* Vh = Kl + KC * KHLD;             // [KC key slots][VLD]: row = k-slot of the key, d contiguous
+    _Float16* Vl = Vh + KC * VLD;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int b = blockIdx.y / heads, h = blockIdx.y % heads;
     const int C3 = 3 * heads * HD;
@@ -202,24 +205,29 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
 
     for (int k0 = 0; k0 < T; k0 += KC) {
         __syncthreads();
-        for (int idx = tid; idx < KC * (HD / 4); idx += nthr) {  // 512 float4 per tensor
+        for (int idx = tid; idx < KC * (HD / 4); idx += nthr) {  // 512 float4 per tensor; 8-byte LDS writes
             const int row = idx >> 4, c4 = (idx & 15) * 4;
             f4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
             if (k0 + row < T) {
                 kv = *(const f4*)(kp + (size_t)(k0 + row) * C3 + c4);
                 vv = *(const f4*)(vp + (size_t)(k0 + row) * C3 + c4);
             }
-            const int slot = vt_slot(row);
+            h4 khh, kll, vhh, vll;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 _Float16 hh, ll;
                 pp_split_f16(kv[i], hh, ll);
-                Kh[row * KHLD + c4 + i] = hh;
-                Kl[row * KHLD + c4 + i] = ll;
+                khh[i] = hh;
+                kll[i] = ll;
                 pp_split_f16(vv[i], hh, ll);
-                Vh[(c4 + i) * VTLD + slot] = hh;
-                Vl[(c4 + i) * VTLD + slot] = ll;
+                vhh[i] = hh;
+                vll[i] = ll;
             }
+            *(h4*)(Kh + row * KHLD + c4) = khh;
+            *(h4*)(Kl + row * KHLD + c4) = kll;
+            const int slot = vt_slot(row);   // K [key][d], V [slot(key)][d]
+            *(h4*)(Vh + slot * VLD + c4) = vhh;
+            *(h4*)(Vl + slot * VLD + c4) = vll;
         }
         __syncthreads();
         f32x16 sacc;
@@ -262,12 +270,24 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
             o0[e] *= alpha;
             o1[e] *= alpha;
         }
+        // V^T fragments by transposing reads from the [slot][d] tile: lane (d = l31 [+32], lh) gets slots 16 s + 8 lh .. + 7
+        auto vfrag = [&](const _Float16* V, int s, int dhalf) __attribute__((always_inline)) -> h8 {
+            const int col = 32 * dhalf + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            const int row = 16 * s + 8 * lh + ((lane & 15) >> 2);
+            const _Float16* p = V + row * VLD + col;
+            const fp16x4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p);
+            const fp16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(p + 4 * VLD));
+            h8 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r[e] = (_Float16)lo4[e];
+                r[4 + e] = (_Float16)hi4[e];
+            }
+            return r;
+        };
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const h8 v0h = *(const h8*)(Vh + l31 * VTLD + 16 * s + 8 * lh);
-            const h8 v0l = *(const h8*)(Vl + l31 * VTLD + 16 * s + 8 * lh);
-            const h8 v1h = *(const h8*)(Vh + (32 + l31) * VTLD + 16 * s + 8 * lh);
-            const h8 v1l = *(const h8*)(Vl + (32 + l31) * VTLD + 16 * s + 8 * lh);
+            const h8 v0h = vfrag(Vh, s, 0), v0l = vfrag(Vl, s, 0), v1h = vfrag(Vh, s, 1), v1l = vfrag(Vl, s, 1);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph[s], o0, 0, 0, 0);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl[s], o0, 0, 0, 0);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph[s], o0, 0, 0, 0);
@@ -338,7 +358,7 @@ static int attention_launch(const float* qkv, int B, int T, int heads, int head_
                 wpb = c;
             }
         }
-        const size_t kv = (size_t)(2 * KC * KHLD + 2 * HD * VTLD) * sizeof(_Float16), os = (size_t)wpb * 32 * OLD * sizeof(float);
+        const size_t kv = (size_t)(2 * KC * KHLD + 2 * KC * VLD) * sizeof(_Float16), os = (size_t)wpb * 32 * OLD * sizeof(float);
         hipLaunchKernelGGL(attn_f16x3_kernel, dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
                            (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl);
     } else {
