@@ -208,6 +208,10 @@ int pp_attention_split(const float* qkv, int B, int T, int heads, int head_dim, 
  * out and/or the hl operand out_hl. */
 int pp_attention_ex(const float* qkv, int B, int T, int heads, int head_dim, float scale, int prec, float* out, void* out_hl,
                     void* stream);
+/* PP_PREC_F16X3 attention whose input is already the hl operand (B*T rows, ld = 3*heads*head_dim) that the qkv GEMM
+ * wrote (PpGemmDesc.C_hl): no split work inside the kernel; bit-identical to pp_attention_ex on the fp32 qkv. */
+int pp_attention_hl(const void* qkv_hl, int B, int T, int heads, int head_dim, float scale, float* out, void* out_hl,
+                    void* stream);
 
 /* nn.LayerNorm(C, eps) over rows of a [rows][C] matrix. */
 int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps,

@@ -161,7 +161,10 @@ __device__ __forceinline__ int vt_slot(int key) {  // key (0..31) of a chunk -> 
     return s * 16 + ((r >> 2) & 1) * 8 + (r & 3) + 4 * (r >> 3);
 }
 
-__global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict__ qkv, int T, int heads, float scale,
+// HLIN: q, k, v arrive as the hl operand the qkv GEMM epilogue wrote (no split work here at all: fragments and the
+// K / V chunks are 16-byte copies); otherwise fp32 qkv, split while staging.  Both give the same bits.
+template <bool HLIN>
+__global__ __launch_bounds__(256) void attn_f16x3_kernel(const void* __restrict__ qkv_any, int T, int heads, float scale,
                                                          float* __restrict__ out, _Float16* __restrict__ out_hl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Kh = (_Float16*)smem;            // [KC][KHLD]
@@ -171,13 +174,21 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int b = blockIdx.y / heads, h = blockIdx.y % heads;
     const int C3 = 3 * heads * HD;
-    const float* base = qkv + (size_t)b * T * C3 + h * HD;
+    const float* base = (const float*)qkv_any + (size_t)b * T * C3 + h * HD;            // fp32 input
+    const _Float16* hbase = (const _Float16*)qkv_any + ((size_t)b * T * C3 + h * HD) * 2;  // hl input (h*HD % 8 == 0)
     const int q = (blockIdx.x * (nthr >> 6) + w) * 32 + l31;
     const int qc = q < T ? q : T - 1;
 
-    // Q fragments: step s holds d = 16 s + 8 lh .. + 7 of query l31, pre-scaled, split
+    // Q fragments: step s holds d = 16 s + 8 lh .. + 7 of query l31 (unscaled: the scores are scaled after the MFMAs)
     h8 qh[4], ql[4];
-    {
+    if (HLIN) {
+        const _Float16* qp = hbase + (size_t)qc * C3 * 2;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qh[s] = *(const h8*)(qp + 2 * (16 * s + 8 * lh));
+            ql[s] = *(const h8*)(qp + 2 * (16 * s + 8 * lh) + 8);
+        }
+    } else {
         const float* qp = base + (size_t)qc * C3;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -185,10 +196,10 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 _Float16 hh, ll;
-                pp_split_f16(a[i] * scale, hh, ll);
+                pp_split_f16(a[i], hh, ll);
                 qh[s][i] = hh;
                 ql[s][i] = ll;
-                pp_split_f16(c[i] * scale, hh, ll);
+                pp_split_f16(c[i], hh, ll);
                 qh[s][4 + i] = hh;
                 ql[s][4 + i] = ll;
             }
@@ -200,11 +211,30 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
     float mrun = -INFINITY, lrun = 0.f;
     const float* kp = base + heads * HD;
     const float* vp = base + 2 * heads * HD;
-    constexpr float S_DESCALE = 1.0f / (PP_A_SCALE * PP_A_SCALE);
+    const float S_DESCALE = scale / (PP_A_SCALE * PP_A_SCALE);
     constexpr float O_RESCALE = 1.0f / (PP_A_SCALE * P_SCALE);
 
     for (int k0 = 0; k0 < T; k0 += KC) {
         __syncthreads();
+        if (HLIN) {
+            for (int idx = tid; idx < KC * (HD / 8); idx += nthr) {  // 256 (hi, lo) 16-byte pairs per tensor: plain copies
+                const int row = idx >> 3, g = idx & 7;
+                h8 kh8 = {0, 0, 0, 0, 0, 0, 0, 0}, kl8 = kh8, vh8 = kh8, vl8 = kh8;
+                if (k0 + row < T) {
+                    const _Float16* kp2 = hbase + ((size_t)(k0 + row) * C3 + heads * HD + 8 * g) * 2;
+                    const _Float16* vp2 = hbase + ((size_t)(k0 + row) * C3 + 2 * heads * HD + 8 * g) * 2;
+                    kh8 = *(const h8*)kp2;
+                    kl8 = *(const h8*)(kp2 + 8);
+                    vh8 = *(const h8*)vp2;
+                    vl8 = *(const h8*)(vp2 + 8);
+                }
+                *(h8*)(Kh + row * KHLD + 8 * g) = kh8;
+                *(h8*)(Kl + row * KHLD + 8 * g) = kl8;
+                const int slot = vt_slot(row);
+                *(h8*)(Vh + slot * VLD + 8 * g) = vh8;
+                *(h8*)(Vl + slot * VLD + 8 * g) = vl8;
+            }
+        } else
         for (int idx = tid; idx < KC * (HD / 4); idx += nthr) {  // 512 float4 per tensor; 8-byte LDS writes
             const int row = idx >> 4, c4 = (idx & 15) * 4;
             f4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
@@ -343,9 +373,9 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(const float* __restrict
 
 extern "C" {
 
-static int attention_launch(const float* qkv, int B, int T, int heads, int head_dim, float scale, int prec, float* out,
+static int attention_launch(const void* qkv, bool hl_in, int B, int T, int heads, int head_dim, float scale, int prec, float* out,
                             void* out_hl, void* stream) {
-    if (!qkv || (!out && !out_hl) || B <= 0 || T <= 0 || heads <= 0) return PP_EINVAL;
+    if (!qkv || (!out && !out_hl) || B <= 0 || T <= 0 || heads <= 0 || (hl_in && prec != PP_PREC_F16X3)) return PP_EINVAL;
     if (head_dim != HD || ((uintptr_t)qkv % 16) != 0) return PP_EINVAL;
     if (prec == PP_PREC_F16X3) {
         // waves per workgroup: the split of the ceil(T/32) query tiles that wastes the fewest wave slots
@@ -359,10 +389,14 @@ static int attention_launch(const float* qkv, int B, int T, int heads, int head_
             }
         }
         const size_t kv = (size_t)(2 * KC * KHLD + 2 * KC * VLD) * sizeof(_Float16), os = (size_t)wpb * 32 * OLD * sizeof(float);
-        hipLaunchKernelGGL(attn_f16x3_kernel, dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
-                           (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl);
+        if (hl_in)
+            hipLaunchKernelGGL(attn_f16x3_kernel<true>, dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
+                               (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl);
+        else
+            hipLaunchKernelGGL(attn_f16x3_kernel<false>, dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
+                               (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl);
     } else {
-        hipLaunchKernelGGL(attn_kernel, dim3((T + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, qkv, T, heads,
+        hipLaunchKernelGGL(attn_kernel, dim3((T + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, (const float*)qkv, T, heads,
                            scale, out, (_Float16*)out_hl);
     }
     return pp_last_launch();
@@ -370,19 +404,25 @@ static int attention_launch(const float* qkv, int B, int T, int heads, int head_
 
 int pp_attention(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* stream) {
     if (!out) return PP_EINVAL;
-    return attention_launch(qkv, B, T, heads, head_dim, scale, PP_PREC_F32, out, nullptr, stream);
+    return attention_launch(qkv, false, B, T, heads, head_dim, scale, PP_PREC_F32, out, nullptr, stream);
 }
 
 int pp_attention_split(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* out_hl,
                        void* stream) {
     if (!out_hl) return PP_EINVAL;
-    return attention_launch(qkv, B, T, heads, head_dim, scale, PP_PREC_F32, out, out_hl, stream);
+    return attention_launch(qkv, false, B, T, heads, head_dim, scale, PP_PREC_F32, out, out_hl, stream);
 }
 
 int pp_attention_ex(const float* qkv, int B, int T, int heads, int head_dim, float scale, int prec, float* out, void* out_hl,
                     void* stream) {
     if (prec != PP_PREC_F32 && prec != PP_PREC_F16X3) return PP_EINVAL;
-    return attention_launch(qkv, B, T, heads, head_dim, scale, prec, out, out_hl, stream);
+    return attention_launch(qkv, false, B, T, heads, head_dim, scale, prec, out, out_hl, stream);
+}
+
+int pp_attention_hl(const void* qkv_hl, int B, int T, int heads, int head_dim, float scale, float* out, void* out_hl,
+                    void* stream) {
+    if (((uintptr_t)qkv_hl % 16) != 0) return PP_EINVAL;
+    return attention_launch(qkv_hl, true, B, T, heads, head_dim, scale, PP_PREC_F16X3, out, out_hl, stream);
 }
 
 }  // extern "C"

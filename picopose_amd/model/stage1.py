@@ -123,7 +123,7 @@ class FeatureExtractor(Packed):
         for i, blk in enumerate(v.blocks):
             # out_split: on the f16x3 engine each producer writes the next linear's operand planes directly
             h = ops.layernorm(xs, blk.norm1.weight, blk.norm1.bias, 1e-6, out_split=True)
-            qkv = ops.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias)                       # (B*T, 3*heads*hd)
+            qkv = ops.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias, out_split=True)       # (B*T, 3*heads*hd)
             o = ops.attention(qkv, B, T, heads, hd, out_split=True)                           # fused QK^T/softmax/PV
             xs = ops.linear(o, blk.attn.proj.weight, blk.attn.proj.bias, gamma=blk.ls1.gamma, residual=xs)
             h = ops.layernorm(xs, blk.norm2.weight, blk.norm2.bias, 1e-6, out_split=True)

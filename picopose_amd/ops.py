@@ -270,17 +270,22 @@ def conv_transpose2d(x, wp, bias_tiled, r):
 
 
 def attention(qkv, B, T, heads, hd, out_split=False):
-    """qkv (B*T, 3*heads*hd) from the qkv linear -> (B*T, heads*hd): softmax((q hd^-1/2) k^T) v per head, fused,
-    in the engine's current arithmetic.  out_split: return the result as a Split (f16x3 engine only)."""
-    assert qkv.is_contiguous()
+    """qkv (B*T, 3*heads*hd) from the qkv linear (fp32, or a Split written by its epilogue) -> (B*T, heads*hd):
+    softmax((q hd^-1/2) k^T) v per head, fused, in the engine's current arithmetic.  out_split: return the result as
+    a Split (f16x3 engine only)."""
     sp = out = None
+    dev = qkv.device
     if out_split and _split_ok(heads * hd):
-        sp = Split.empty(B * T, heads * hd, qkv.device)
+        sp = Split.empty(B * T, heads * hd, dev)
     else:
-        out = torch.empty(B * T, heads * hd, dtype=torch.float32, device=qkv.device)
-    _lib.check(_lib.lib().pp_attention_ex(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, _PREC[PRECISION], _p(out),
-                                          _p(sp.hl) if sp else None, _lib.stream_ptr()),
-               "pp_attention_ex")
+        out = torch.empty(B * T, heads * hd, dtype=torch.float32, device=dev)
+    if isinstance(qkv, Split):
+        _lib.check(_lib.lib().pp_attention_hl(_p(qkv.hl), B, T, heads, hd, float(hd) ** -0.5, _p(out),
+                                              _p(sp.hl) if sp else None, _lib.stream_ptr()), "pp_attention_hl")
+    else:
+        assert qkv.is_contiguous()
+        _lib.check(_lib.lib().pp_attention_ex(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, _PREC[PRECISION], _p(out),
+                                              _p(sp.hl) if sp else None, _lib.stream_ptr()), "pp_attention_ex")
     return sp if sp is not None else out
 
 

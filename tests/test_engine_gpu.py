@@ -207,7 +207,7 @@ def test_fused_operand_planes_equal_separate_split(engine_precision):
     def chain(fused):
         h = ops.layernorm(x, lw, lb, 1e-6, out_split=fused)
         assert isinstance(h, ops.Split) == fused
-        qkv = ops.linear(h, wqkv, bqkv)
+        qkv = ops.linear(h, wqkv, bqkv, out_split=fused)
         o = ops.attention(qkv, B, T, heads, hd, out_split=fused)
         y = ops.linear(o, wp, None, residual=x)
         f = ops.linear(ops.layernorm(y, lw, lb, 1e-6, out_split=fused), w1, b1, act="gelu", out_split=fused)
