@@ -64,16 +64,19 @@ class DPTHead(Packed):
                     pk[f"f{i}_u{j}_c{c}"], pk[f"f{i}_u{j}_b{c}"] = ops.pack_conv_weight(w), b.contiguous()
         return pk
 
-    def _rcu(self, pk, key, x, extra=None):
+    def _rcu(self, pk, key, x, extra=None, more=False):
         """ResidualConvUnit (dpt.py:72-95): bn2(conv2(relu(bn1(conv1(relu(x)))))) + x (+ extra)."""
-        # conv1 hands relu(h) to conv2 as operand planes (out_split + split_relu): h itself is never stored
-        h = ops.conv2d(x, pk[key + "_c1"], pk[key + "_b1"], 3, pad=1, relu_in=True, out_split=True, split_relu=True)
+        # conv1 hands relu(h) to conv2 as operand planes (out_split + split_relu): h itself is never stored.  The
+        # unit's fp32 output also carries its relu'd operand form (also_split) for the next unit's conv1.
+        xin = getattr(x, "_hl_relu", None)
+        h = ops.conv2d(x if xin is None else xin, pk[key + "_c1"], pk[key + "_b1"], 3, pad=1, relu_in=xin is None,
+                       out_split=True, split_relu=True)
         return ops.conv2d(h, pk[key + "_c2"], pk[key + "_b2"], 3, pad=1, relu_in=not isinstance(h, ops.Split), residual=x,
-                          residual2=extra)
+                          residual2=extra, also_split="relu" if more else None)
 
     def _fuse(self, pk, i, size, x0, x1=None):
         """FeatureFusionBlock (dpt.py:129-156)."""
-        out = x0 if x1 is None else self._rcu(pk, f"f{i}_u1", x1, extra=x0)
+        out = x0 if x1 is None else self._rcu(pk, f"f{i}_u1", x1, extra=x0, more=True)   # feeds resConfUnit2
         out = self._rcu(pk, f"f{i}_u2", out)
         out = ops.resize_bilinear(out, size[0], size[1])
         return ops.conv2d(out, pk[f"f{i}_out"], getattr(self.scratch, f"refinenet{i}").out_conv.bias, 1)
@@ -86,7 +89,8 @@ class DPTHead(Packed):
         l2 = ops.conv_transpose2d(x[1], pk["up1"], pk["up1_b"], 2)
         l3 = x[2]
         l4 = ops.conv2d(x[3], pk["down3"], getattr(r, "3").bias, 3, stride=2, pad=1)
-        rn = [ops.conv2d(l, pk[f"rn{i + 1}"], None, 3, pad=1) for i, l in enumerate((l1, l2, l3, l4))]
+        # every layerK_rn output is the input of a ResidualConvUnit (fp32 for its skip, relu'd operand for its conv1)
+        rn = [ops.conv2d(l, pk[f"rn{i + 1}"], None, 3, pad=1, also_split="relu") for i, l in enumerate((l1, l2, l3, l4))]
         p4 = self._fuse(pk, 4, rn[2].shape[1:3], rn[3])
         p3 = self._fuse(pk, 3, rn[1].shape[1:3], p4, rn[2])
         p2 = self._fuse(pk, 2, rn[0].shape[1:3], p3, rn[1])
@@ -162,13 +166,21 @@ class FlowDecoder(Packed):
             fr = ops.conv2d(fr_in, pk[f"proj{l}"], pk[f"proj{l}_b"], 1)   # contiguous copy for the lookup
             ncorr = (l + 1) * (2 * self.r + 1) ** 2
             corr = ops.corr_lookup(fr, fq, flow, l + 1, self.r, c_pad=-(-ncorr // 8) * 8)
-            cf = torch.empty(B, H, W, 256, dtype=torch.float32, device=fr_in.device)  # [corr feat 192 | flow feat 64]
+            # [corr feat 192 | flow feat 64]: on the f16x3 engine the concat exists only as the operand of out_net
+            hl_cat = ops.PRECISION == "f16x3"
+            if hl_cat:
+                cf = ops.Split.empty(B * H * W, 256, fr_in.device)
+                cf.image = (B, H, W)
+            else:
+                cf = torch.empty(B, H, W, 256, dtype=torch.float32, device=fr_in.device)
             c1 = ops.conv2d(corr, pk[f"e{l}_corr0"], getattr(e.corr_net, "0").conv.bias, 1, act="relu", out_split=True)
-            ops.conv2d(c1, pk[f"e{l}_corr1"], getattr(e.corr_net, "1").conv.bias, 3, pad=1, act="relu", out=cf[..., 0:192])
+            ops.conv2d(c1, pk[f"e{l}_corr1"], getattr(e.corr_net, "1").conv.bias, 3, pad=1, act="relu",
+                       **(dict(hl_into=(cf, 0)) if hl_cat else dict(out=cf[..., 0:192])))
             flow8 = torch.zeros(B, H, W, 8, dtype=torch.float32, device=fr_in.device)
             flow8[..., 0:2] = flow
             f1 = ops.conv2d(flow8, pk[f"e{l}_flow0"], getattr(e.flow_net, "0").conv.bias, 7, pad=3, act="relu", out_split=True)
-            ops.conv2d(f1, pk[f"e{l}_flow1"], getattr(e.flow_net, "1").conv.bias, 3, pad=1, act="relu", out=cf[..., 192:256])
+            ops.conv2d(f1, pk[f"e{l}_flow1"], getattr(e.flow_net, "1").conv.bias, 3, pad=1, act="relu",
+                       **(dict(hl_into=(cf, 192)) if hl_cat else dict(out=cf[..., 192:256])))
             ops.conv2d(cf, pk[f"e{l}_out0"], getattr(e.out_net, "0").conv.bias, 3, pad=1, act="relu", out=X[..., 512:638])
             X[..., 0:256] = fr
             X[..., 638:640] = flow                                  # cat([out, flow]) (raft_decoder.py:161)

@@ -196,12 +196,16 @@ def split_image(x, relu=False):
 
 
 def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residual=None, out=None, cin=None,
-           residual2=None, out_split=False, split_relu=False):
+           residual2=None, out_split=False, split_relu=False, also_split=None, hl_into=None):
     """NHWC convolution. x (B,H,W,Cx) (channel-contiguous, may be a channel slice: cin <= Cx stride) or a Split
     carrying .image (a pre-split operand: no split pass, the producer has already applied any input ReLU),
     wp (Cout, k*k*cin) from pack_conv_weight.  out may be a channel slice of a wider NHWC buffer.
     out_split (f16x3 engine, no `out`): return the result as a Split (with split_relu: of max(result, 0), the next
-    layer's input ReLU folded in) instead of an fp32 tensor."""
+    layer's input ReLU folded in) instead of an fp32 tensor.
+    also_split ("relu" | "plain"; f16x3 engine): return the fp32 tensor AND attach its operand form as `._hl` /
+    `._hl_relu` (a Split) for a following convolution, both written by this epilogue.
+    hl_into = (Split over (B*Ho*Wo, Ctot), col0): write the result ONLY as operand columns col0.. of that shared
+    Split (channel concatenation of operands; Cout % 8 == 0, col0 % 8 == 0) — returns None."""
     xs = x if isinstance(x, Split) else None
     if xs is not None:
         (B, H, W), Cx = xs.image, xs.shape[1]
@@ -222,6 +226,17 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     presplit = xs is not None or ("B_hl" in wargs and (Cout > 64 or ksize > 1)
                                   and _can_presplit(x, ksize * ksize * cin, cin, ld_in, x.stride(0)) and B * H * W * cin < 2 ** 30)
     sargs, ret = {}, None
+    if hl_into is not None:
+        tgt, col0 = hl_into
+        assert presplit and out is None and Cout % 8 == 0 and col0 % 8 == 0 and residual is None and residual2 is None
+        ctot = tgt.shape[1]
+        assert tgt.shape[0] == B * Ho * Wo and col0 + Cout <= ctot
+        hl = xs.hl if xs is not None else split_activation(x, B, H * W, cin, x.stride(0), ld_in, relu=relu_in)
+        _run(_desc(A_hl=_p(hl), B=_p(wp), C=None, bias=_p(bias), conv_bstride=H * W * cin, M=B * Ho * Wo, N=Cout,
+                   K=ksize * ksize * cin, lda=cin, ldb=wp.shape[1], ldc=Cout, act=ACT[act], conv_kh=ksize, conv_kw=ksize,
+                   conv_cin=cin, conv_stride=stride, conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo,
+                   C_hl=tgt.hl.data_ptr() + 4 * col0, ldc_h=ctot, c_relu=int(split_relu), **wargs))
+        return None
     if out_split and out is None and presplit and _split_ok(Cout) and residual is None and residual2 is None:
         ret = Split.empty(B * Ho * Wo, Cout, dev)
         ret.image = (B, Ho, Wo)
@@ -236,6 +251,12 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     for r_ in (residual, residual2):
         if r_ is not None:
             assert r_.stride() == out.stride()
+    extra = None
+    if also_split is not None and presplit and _split_ok(Cout) and not sargs and out.is_contiguous():
+        extra = Split.empty(B * Ho * Wo, Cout, dev)
+        extra.image = (B, Ho, Wo)
+        sargs = dict(C_hl=_p(extra.hl), ldc_h=Cout, c_relu=int(also_split == "relu"))
+        setattr(out, "_hl_relu" if also_split == "relu" else "_hl", extra)
     if presplit:
         assert "B_hl" in wargs
         hl = xs.hl if xs is not None else split_activation(x, B, H * W, cin, x.stride(0), ld_in, relu=relu_in)  # once, not per tap / column tile
