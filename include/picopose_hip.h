@@ -247,6 +247,11 @@ int pp_warp_nhwc(const float* feat, const float* flow, int B, int H, int W, int 
                  float* out, int ld_out, void* stream);
 /* nn.AvgPool2d(2,2) on NHWC. */
 int pp_avgpool2_nhwc(const float* in, int B, int H, int W, int C, float* out, void* stream);
+/* dst[i] = src[index[i]] for i < n: rows of row_floats fp32 (a multiple of 4; both buffers 16-byte aligned), index int64
+ * into the n_src_rows rows of src — the selection of the top-k templates' rgb / mask / pts3d / pose / K / M rows
+ * (model/picopose.py:55-62). */
+int pp_gather_rows(const float* src, const long long* index, long long n_src_rows, long long row_floats, int n, float* dst,
+                   void* stream);
 /* CorrelationPyramid (raft_decoder.py:30-53) + CorrLookup (corr_lookup.py:100-134) without the
  * (B*HW, HW) volume: f1 (B,H,W,C), f2_l{0,1,2} = f2 and its 2x2 average pools, flow (B,H,W,ld_flow);
  * out (B,H,W,ld_out) with channel l*(2r+1)^2 + a*(2r+1) + b = corr_l sampled at x offset a-r,

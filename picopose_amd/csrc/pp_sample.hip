@@ -164,6 +164,18 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
     }
 }
 
+// Row gather: dst[i] = src[index[i]] for rows of `row` floats (row % 4 == 0, 16-byte aligned): the selection of the
+// top-k templates' data (model/picopose.py:55-62 — torch.gather with an expanded index over (B,N,3,224,224) etc.)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ index,
+                                                          long long row, long long nsrc, float* __restrict__ dst) {
+    const long long r = index[blockIdx.y];
+    if (r < 0 || r >= nsrc) return;  // (validated on the host side of the mirrors; never expected)
+    const f4* s4 = (const f4*)(src + r * row);
+    f4* d4 = (f4*)(dst + (long long)blockIdx.y * row);
+    const long long n4 = row >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) d4[i] = s4[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -208,6 +220,18 @@ int pp_corr_lookup_nhwc(const float* f1, const float* f2_l0, const float* f2_l1,
     hipLaunchKernelGGL(corr_lookup_kernel, dim3((H * W + 3) / 4, B), dim3(256), smem, (hipStream_t)stream, f1,
                        f2_l0, f2_l1, f2_l2, flow, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out,
                        ld_out);
+    return pp_last_launch();
+}
+
+int pp_gather_rows(const float* src, const long long* index, long long n_src_rows, long long row_floats, int n, float* dst,
+                   void* stream) {
+    if (!src || !index || !dst || n <= 0 || n_src_rows <= 0 || row_floats <= 0 || row_floats % 4 != 0 ||
+        ((uintptr_t)src % 16) != 0 || ((uintptr_t)dst % 16) != 0)
+        return PP_EINVAL;
+    const long long n4 = row_floats / 4;
+    const int gx = (int)((n4 + 255) / 256 < 64 ? (n4 + 255) / 256 : 64);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, src, index, row_floats, n_src_rows,
+                       dst);
     return pp_last_launch();
 }
 

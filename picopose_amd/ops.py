@@ -436,3 +436,17 @@ def normalize_rows(x, eps=1e-12):
     y = torch.empty_like(x)
     _lib.check(_lib.lib().pp_normalize_rows(_p(x), rows, n, float(eps), _p(y), _lib.stream_ptr()), "pp_normalize_rows")
     return y
+
+
+def gather_rows(src, index):
+    """dst[i] = src.flatten(0, k)[index[i]]: src (R, ...) contiguous fp32 with rows of a multiple of 4 floats, index (n,)
+    int64 -> (n, ...).  Small rows (poses, intrinsics) that are not a multiple of 4 floats fall to torch indexing."""
+    R = src.shape[0]
+    row = src[0].numel()
+    if row % 4 != 0 or not src.is_contiguous() or src.dtype != torch.float32 or src.data_ptr() % 16 != 0:
+        return src[index]
+    index = index.contiguous()
+    dst = torch.empty((index.numel(),) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.lib().pp_gather_rows(_p(src), _p(index), R, row, index.numel(), _p(dst), _lib.stream_ptr()),
+               "pp_gather_rows")
+    return dst

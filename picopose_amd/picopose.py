@@ -121,7 +121,11 @@ class Net(nn.Module):
         idx = pred_id_src.t().reshape(-1)
         rows = torch.arange(B, device=idx.device).repeat(hyp)
         rep = lambda t: t.repeat(hyp, *([1] * (t.dim() - 1)))  # noqa: E731
-        sel = {key: end_points[key][rows, idx] for key in ("tem_pose", "tem_K", "tem_M", "tem_mask", "tem_rgb", "tem_pts3d")}
+        N = end_points["tem_pose"].shape[1]
+        flat = rows * N + idx                                            # row of (b, template) in the (B*N, ...) view
+        sel = {key: (ops.gather_rows(end_points[key].flatten(0, 1), flat) if end_points[key].is_contiguous()
+                     else end_points[key][rows, idx])
+               for key in ("tem_pose", "tem_K", "tem_M", "tem_mask", "tem_rgb", "tem_pts3d")}
         for key in ("real_pts2d", "real_K", "real_M", "real_mask", "real_pose"):
             sel[key] = rep(end_points[key])
         out = self.forward_test_hyp(sel, ([rep(t) for t in real_tok], hw, None if real_dpt is None else [rep(t) for t in real_dpt]),

@@ -94,3 +94,15 @@ def test_similarity_volume(golden_dir):
         ref = om.matching_features_similarity(src, tar, m, None)
         got = matching_features_similarity(src.cuda(), tar.cuda(), m.cuda(), None).cpu()
         assert (got - ref).abs().max().item() <= 2e-6
+
+
+@gpu
+def test_gather_rows_equals_indexing():
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(6, 5, 3, 8, 4, generator=g).cuda()          # (B, N, ...) -> rows of 96 floats
+    idx = torch.tensor([29, 0, 7, 7, 13], device="cuda")
+    assert torch.equal(ops.gather_rows(src.flatten(0, 1), idx), src.flatten(0, 1)[idx])
+    small = torch.randn(30, 3, 3, generator=g).cuda()              # 9 floats per row: torch indexing path
+    assert torch.equal(ops.gather_rows(small, idx), small[idx])
