@@ -57,14 +57,15 @@ def sharded_matching_templates(local_bank, tar_feat, tar_mask, n_total, topk=5, 
 
 
 def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=None, features_fn=None, scores_fn=None,
-                    topk_fn=None, tail_fn=None):
+                    topk_fn=None, tail_fn=None, overlap_fn=None):
     """Net.forward (eval) with the template FEATURE bank sharded over the ranks and the crops data-parallel.
 
     Every rank owns `b_local` crops (`local_end_points`, with the raw template data of ITS crops) and the slice
     [shard_bounds) of the feature bank of ALL crops: local_bank (world*b_local, n_local, C, 16, 16), crops ordered
     rank-major.  Exchange steps: all-gather of the query features and masks (every rank scores its template slice
     against all crops) and the all-gather of the (B_total, n_local) score slices; stages 2-3 run on the rank's own
-    crops.  *_fn default to the HIP model; tests inject CPU stand-ins to run under gloo.
+    crops.  The query-side DPT head (overlap_fn: state -> state) does not feed stage 1, so it runs while the all-gathers
+    of the query features are in flight.  *_fn default to the HIP model; tests inject CPU stand-ins to run under gloo.
     Returns the list (hyp) of output dicts for the rank's own crops."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if features_fn is None:
@@ -74,8 +75,11 @@ def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=Non
 
         def features_fn(x):
             toks, (h0, w0) = net.feature_extractor.forward_tokens(x)
-            dpt = net.offset_regressor.dpt_head.forward_nhwc([t[:, 1:].unflatten(1, (h0, w0)) for t in toks])
-            return (toks, (h0, w0), dpt), ops.tokens_to_nchw(toks[-1], 1, h0, w0)
+            return (toks, (h0, w0), None), ops.tokens_to_nchw(toks[-1], 1, h0, w0)
+
+        def overlap_fn(real):   # query-side DPT maps, computed once for all hypotheses (picopose.py forward_test)
+            toks, (h0, w0), _ = real
+            return toks, (h0, w0), net.offset_regressor.dpt_head.forward_nhwc([t[:, 1:].unflatten(1, (h0, w0)) for t in toks])
 
         scores_fn = lambda b, q, m: hm.template_scores(b, q, m, mode=net.match_mode)  # noqa: E731
         topk_fn = hm.topk_templates
@@ -84,7 +88,7 @@ def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=Non
         real, q_local = features_fn(local_end_points["real_rgb"])          # (state for stages 2-3, (b,C,16,16))
         b_local = q_local.shape[0]
         q_all = q_local.new_empty((world * b_local,) + tuple(q_local.shape[1:]))
-        dist.all_gather_into_tensor(q_all, q_local.contiguous(), group=group)
+        pending = [dist.all_gather_into_tensor(q_all, q_local.contiguous(), group=group, async_op=True)]
         # stage 1 reads the query mask only at the nearest-sampled 16 x 16 patch grid (utils/matching.py:41-43,
         # F.interpolate(mode="nearest") = rows/columns floor(i * H / 16)): exchange that kilobyte, not the full mask
         m_full = local_end_points["real_mask"]
@@ -92,7 +96,11 @@ def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=Non
         iw = (torch.arange(16, device=m_full.device) * m_full.shape[2]) // 16
         m_local = m_full[:, ih][:, :, iw].contiguous()
         m_all = m_local.new_empty((world * b_local,) + tuple(m_local.shape[1:]))
-        dist.all_gather_into_tensor(m_all, m_local, group=group)
+        pending.append(dist.all_gather_into_tensor(m_all, m_local, group=group, async_op=True))
+        if overlap_fn is not None:
+            real = overlap_fn(real)
+        for wk in pending:
+            wk.wait()
         lo, hi = shard_bounds(n_total, world, rank)
         assert local_bank.shape[0] == world * b_local and local_bank.shape[1] == hi - lo
         full = gather_scores(scores_fn(local_bank, q_all, m_all), n_total, group=group)      # (B_total, N)
