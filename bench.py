@@ -51,6 +51,7 @@ WORKLOADS = {
     # SURVEY.md §8(f) row 1 (NOT the headline: the reference recomputes the template ViT / DPT inside the step)
     "full_cached_b32_n162_vitb": ("full_cached", 32, 162, "dinov2_vitb14",
                                   "configs[2] with the EXTENDED template bank (template-side DPT maps precomputed too, SURVEY 8f row 1)"),
+    "full_b8_n42_vitl": ("full", 8, 42, "dinov2_vitl14", "batch 8, 42 templates, ViT-L/14 (config/base.yaml backbone), stage1+2+3 + PnP/RANSAC, hyp 5"),
     "stage1_b32_n162_c768": ("stage1", 32, 162, "dinov2_vitb14", "configs[2] stage-1 shape: matching_templates only"),
     "stage1_b8_n42_c384": ("stage1", 8, 42, "dinov2_vits14", "configs[1]: batch 8, 42 templates, ViT-S/14, stage-1 matching only"),
     "stage1_b32_n162_c1024": ("stage1", 32, 162, "dinov2_vitl14", "base.yaml shape (ViT-L/14), stage-1 matching only"),
@@ -312,7 +313,7 @@ def main():
         if world == 1 and a.mode == "fast" and (B, N, C) == (32, 162, 768) and os.path.exists(pmc):
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         line = {
-            "metric": "image-crops/sec (224x224, 162 templates)" + ("" if kind == "full" else ", stage-1 template matching only")
+            "metric": f"image-crops/sec (224x224, {N} templates)" + ("" if kind == "full" else ", stage-1 template matching only")
                       + (", extended template bank (SURVEY 8f row 1: template ViT/DPT precomputed)" if cached else ""),
             "value": B / (dt / a.steps), "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
