@@ -250,3 +250,24 @@ def test_gelu_epilogue_accuracy():
     got = ops.linear(x.cuda(), eye.cuda(), None, act="gelu").cpu()
     ref = F.gelu(x.double()).float()
     assert (got - ref).abs().max().item() <= 2e-6 + 2e-7 * 10   # + the f16x3 operand rounding of x (2^-22 relative)
+
+
+@gpu
+@pytest.mark.parametrize("B,T,heads", [(1, 1, 1), (2, 33, 2), (3, 100, 6), (2, 257, 12), (1, 300, 3), (1, 1025, 2)])
+def test_attention_shapes_and_operand_input(B, T, heads, engine_precision):
+    """Fused attention for ragged sequence lengths (query tiles / key chunks with tails), from the fp32 qkv tensor
+    and — f16x3 engine — from the hl operand the qkv GEMM epilogue writes (same bits)."""
+    from picopose_amd import ops
+
+    hd = 64
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = torch.randn(B * T, 3 * heads * hd, generator=g)
+    q, k, v = qkv.view(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).permute(0, 2, 1, 3).reshape(B * T, heads * hd).float()
+    got = ops.attention(qkv.cuda(), B, T, heads, hd)
+    _close(got, ref, 2e-5)
+    if engine_precision == "f16x3":
+        sp = ops.Split(ops.split_activation(qkv.cuda(), 1, B * T, 3 * heads * hd, 0, 3 * heads * hd))
+        assert torch.equal(ops.attention(sp, B, T, heads, hd), got)
+        out_sp = ops.attention(sp, B, T, heads, hd, out_split=True)
+        assert torch.equal(out_sp.hl, ops.split_activation(got, 1, B * T, heads * hd, 0, heads * hd))
