@@ -1156,6 +1156,32 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3g_kernel(const PpGemmDesc
 #endif
 }
 
+// Order in which the persistent kernels walk the output tiles: bands of 4 tile rows, inside a band column groups of
+// <= 8 tile columns, inside a group row-major.  The 32 workgroups of an XCD work on 32 consecutive tiles, i.e. on
+// ~4 tile rows x 8 tile columns: each A row slice and each B column slice missed in L2 serves 8 resp. 4 tiles (row-major
+// order over a wide N would be 1.3 rows x 24 columns: the B operand streams from the Infinity Cache all the time —
+// 29 % L2 misses on the fc1 GEMM).  For gx <= 8 this is plain row-major.  A bijection of [0, gx*gy).
+__device__ __forceinline__ void tile_rc(int t, int gx, int gy, int& r, int& c) {
+    const int ncg = (gx + 7) >> 3, band = 4 * gx;
+    const int rg = t / band;
+    int u = t - rg * band;
+    int br = gy - 4 * rg;
+    br = br > 4 ? 4 : br;  // (the last band may be short; the bands before it are full, so rg is right)
+    const int wq = gx / ncg, wrem = gx - wq * ncg;  // the first wrem groups have wq + 1 columns
+    int c0 = 0;
+    r = c = 0;
+    for (int g = 0; g < ncg; ++g) {
+        const int wg = wq + (g < wrem ? 1 : 0), cnt = br * wg;
+        if (u < cnt) {
+            r = 4 * rg + u / wg;
+            c = c0 + u % wg;
+            return;
+        }
+        u -= cnt;
+        c0 += wg;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Persistent form of the LDS-DMA kernel (MODE 0 dense, 1 channel-slice-major convolution): one workgroup per CU
 // walks a sequence of 256x128 output tiles, and the DMA stream runs ahead ACROSS tile boundaries — while the last
@@ -1199,7 +1225,9 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3p_kernel(const PpGemmDesc
     // reload counts in vmcnt — hipcc then drained the DMA pipeline with vmcnt(0) inside the K loop)
 #define PP_P_SETUP(TILE)                                                                                             \
     {                                                                                                                \
-        const int m0_ = ((TILE) / gx) * GBM, n0_ = ((TILE) % gx) * GBN;                                              \
+        int tr_, tc_;                                                                                                \
+        tile_rc((TILE), gx, gy, tr_, tc_);                                                                           \
+        const int m0_ = tr_ * GBM, n0_ = tc_ * GBN;                                                                  \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
             const int m = m0_ + (j * 8 + w) * 8 + lr;                                                                \
             const bool ok = m < d.M;                                                                                 \
@@ -1362,7 +1390,9 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3p_kernel(const PpGemmDesc
             nxt = nxt == G_STAGES - 1 ? 0 : nxt + 1;
         }
         // epilogue of this tile; the ring keeps receiving the next tile meanwhile (f0 already holds its first fragments)
-        epilogue_block<2, 8>(d, descale, acc, patch, (tile / gx) * GBM + wr * 64, (tile % gx) * GBN + wc * 64, lane);
+        int tr, tc;
+        tile_rc(tile, gx, gy, tr, tc);
+        epilogue_block<2, 8>(d, descale, acc, patch, tr * GBM + wr * 64, tc * GBN + wc * 64, lane);
         // a compiler-visible full wait: with the epilogue's loads / stores pending at the loop header hipcc would put a
         // vmcnt(0) in front of the fragment reads of EVERY K tile (the stores have to retire before the next counted
         // wait anyway, and the two tiles in flight have landed during the epilogue)
@@ -1417,7 +1447,9 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3q_kernel(const PpGemmDesc
     int ctap = 0, cky = 0, ckx = 0, cci = 0;
 #define PP_Q_SETUP(TILE)                                                                                             \
     {                                                                                                                \
-        const int m0_ = ((TILE) / gx) * QBM, n0_ = ((TILE) % gx) * QBN;                                              \
+        int tr_, tc_;                                                                                                \
+        tile_rc((TILE), gx, gy, tr_, tc_);                                                                           \
+        const int m0_ = tr_ * QBM, n0_ = tc_ * QBN;                                                                  \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
             const int m = m0_ + (j * 8 + w) * 8 + lr;                                                                \
             const bool ok = m < d.M;                                                                                 \
@@ -1587,7 +1619,9 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3q_kernel(const PpGemmDesc
         }
         // epilogue: the wave's 128 x 64 block as two 64-row halves through the 2 KB patch
         {
-            const int mw = (tile / gx) * QBM + wr * 128, nw = (tile % gx) * QBN + wc * 64;
+            int tr, tc;
+            tile_rc(tile, gx, gy, tr, tc);
+            const int mw = tr * QBM + wr * 128, nw = tc * QBN + wc * 64;
             f32x16(&lo)[2][2] = *reinterpret_cast<f32x16(*)[2][2]>(&acc[0]);
             f32x16(&hi)[2][2] = *reinterpret_cast<f32x16(*)[2][2]>(&acc[2]);
             epilogue_block<2, 8>(d, descale, lo, patch, mw, nw, lane);
