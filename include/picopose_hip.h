@@ -241,6 +241,9 @@ int pp_normalize_rows(const float* x, int rows, int n, float eps, float* y, void
  * result is multiplied by `mul` (the 2x of the flow up-sampling). */
 int pp_resize_bilinear_nhwc(const float* in, int B, int H, int W, int C, int Ho, int Wo, float mul,
                             float* out, void* stream);
+/* Same, writing the result only as an hl operand (B*Ho*Wo rows, ld = C, C % 8 == 0) for the convolution that follows. */
+int pp_resize_bilinear_nhwc_hl(const float* in, int B, int H, int W, int C, int Ho, int Wo, float mul, void* out_hl,
+                               void* stream);
 /* FlowDecoder.feature_sample (flow_decoder.py:49-56): out[b,p,:] = bilinear(feat[b], p + flow[b,p]),
  * zeros padding, align_corners=True.  flow rows have ld_flow floats (x, y first), out rows ld_out. */
 int pp_warp_nhwc(const float* feat, const float* flow, int B, int H, int W, int C, int ld_flow,

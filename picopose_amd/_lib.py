@@ -94,6 +94,7 @@ def lib():
         L.pp_assemble_tokens.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
         L.pp_normalize_rows.argtypes = [vp, i32, i32, f32, vp, vp]
         L.pp_resize_bilinear_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp]
+        L.pp_resize_bilinear_nhwc_hl.argtypes = [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp]
         L.pp_warp_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]
         L.pp_avgpool2_nhwc.argtypes = [vp, i32, i32, i32, i32, vp, vp]
         L.pp_gather_rows.argtypes = [vp, vp, c.c_longlong, c.c_longlong, i32, vp, vp]

@@ -14,7 +14,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // F.interpolate(mode="bilinear", align_corners=True) — dpt.py:150-152, flow_decoder.py:88-92.
 // ATen: src = dst * (in-1)/(out-1); i0 = floor, i1 = min(i0+1, in-1), lambda = src - i0.
 __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ in, int H, int W, int C,
-                                                     int Ho, int Wo, float mul, float* __restrict__ out) {
+                                                     int Ho, int Wo, float mul, float* __restrict__ out,
+                                                     _Float16* __restrict__ out_hl) {
     const int b = blockIdx.z, oy = blockIdx.y, tid = threadIdx.x;
     const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
@@ -22,6 +23,35 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
     const int y0 = (int)fy, y1 = y0 + (y0 < H - 1 ? 1 : 0);
     const float ly = fy - (float)y0, hy = 1.f - ly;
     const float* ib = in + (size_t)b * H * W * C;
+    if (out_hl) {  // the result only as the f16x3 operand of the following 1x1 convolution: 8 channels per thread
+        _Float16* oh = out_hl + ((size_t)b * Ho + oy) * Wo * 2 * C;
+        const int C8 = C >> 3;
+        for (int i = blockIdx.x * 256 + tid; i < Wo * C8; i += gridDim.x * 256) {
+            const int ox = i / C8, c = (i - ox * C8) * 8;
+            const float fx = sx * (float)ox;
+            const int x0 = (int)fx, x1 = x0 + (x0 < W - 1 ? 1 : 0);
+            const float lx = fx - (float)x0, hx = 1.f - lx;
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            h8 hh, ll;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int cc = c + 4 * q;
+                const f4 a = *(const f4*)(ib + ((size_t)y0 * W + x0) * C + cc), bq = *(const f4*)(ib + ((size_t)y0 * W + x1) * C + cc);
+                const f4 cq = *(const f4*)(ib + ((size_t)y1 * W + x0) * C + cc), dq = *(const f4*)(ib + ((size_t)y1 * W + x1) * C + cc);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = (hy * (hx * a[k] + lx * bq[k]) + ly * (hx * cq[k] + lx * dq[k])) * mul;
+                    _Float16 h, l;
+                    pp_split_f16(v, h, l);
+                    hh[4 * q + k] = h;
+                    ll[4 * q + k] = l;
+                }
+            }
+            *(h8*)(oh + (size_t)ox * 2 * C + 2 * c) = hh;
+            *(h8*)(oh + (size_t)ox * 2 * C + 2 * c + 8) = ll;
+        }
+        return;
+    }
     float* ob = out + ((size_t)b * Ho + oy) * Wo * C;
     if ((C & 3) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {  // 4 channels per thread: same arithmetic per element
         const int C4 = C >> 2;
@@ -203,7 +233,18 @@ int pp_resize_bilinear_nhwc(const float* in, int B, int H, int W, int C, int Ho,
     const int work = vec ? Wo * (C / 4) : Wo * C;
     const int gx = (work + 1023) / 1024;  // four items per thread: one workgroup per output row for 64 x 256 channels
     hipLaunchKernelGGL(resize_kernel, dim3(gx < 64 ? gx : 64, Ho, B), dim3(256), 0, (hipStream_t)stream, in, H, W,
-                       C, Ho, Wo, mul, out);
+                       C, Ho, Wo, mul, out, (_Float16*)nullptr);
+    return pp_last_launch();
+}
+
+int pp_resize_bilinear_nhwc_hl(const float* in, int B, int H, int W, int C, int Ho, int Wo, float mul, void* out_hl,
+                               void* stream) {
+    if (!in || !out_hl || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || Ho <= 0 || Wo <= 0 ||
+        (((uintptr_t)in | (uintptr_t)out_hl) & 15) != 0)
+        return PP_EINVAL;
+    const int gx = (Wo * (C / 8) + 1023) / 1024;
+    hipLaunchKernelGGL(resize_kernel, dim3(gx < 64 ? gx : 64, Ho, B), dim3(256), 0, (hipStream_t)stream, in, H, W,
+                       C, Ho, Wo, mul, (float*)nullptr, (_Float16*)out_hl);
     return pp_last_launch();
 }
 

@@ -78,7 +78,7 @@ class DPTHead(Packed):
         """FeatureFusionBlock (dpt.py:129-156)."""
         out = x0 if x1 is None else self._rcu(pk, f"f{i}_u1", x1, extra=x0, more=True)   # feeds resConfUnit2
         out = self._rcu(pk, f"f{i}_u2", out)
-        out = ops.resize_bilinear(out, size[0], size[1])
+        out = ops.resize_bilinear(out, size[0], size[1], out_split=True)   # feeds only the 1x1 out_conv
         return ops.conv2d(out, pk[f"f{i}_out"], getattr(self.scratch, f"refinenet{i}").out_conv.bias, 1)
 
     def forward_nhwc(self, feats):

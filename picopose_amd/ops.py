@@ -363,10 +363,17 @@ def to_nchw(x):
     return out
 
 
-def resize_bilinear(x, Ho, Wo, mul=1.0):
-    """F.interpolate(bilinear, align_corners=True) on NHWC, result times `mul`."""
+def resize_bilinear(x, Ho, Wo, mul=1.0, out_split=False):
+    """F.interpolate(bilinear, align_corners=True) on NHWC, result times `mul`.  out_split (f16x3 engine): return the
+    result as a Split with .image for the convolution that follows, instead of an fp32 tensor."""
     B, H, W, C = x.shape
     assert x.is_contiguous()
+    if out_split and _split_ok(C) and x.data_ptr() % 16 == 0:
+        sp = Split.empty(B * Ho * Wo, C, x.device)
+        sp.image = (B, Ho, Wo)
+        _lib.check(_lib.lib().pp_resize_bilinear_nhwc_hl(_p(x), B, H, W, C, Ho, Wo, float(mul), _p(sp.hl), _lib.stream_ptr()),
+                   "pp_resize_bilinear_nhwc_hl")
+        return sp
     out = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().pp_resize_bilinear_nhwc(_p(x), B, H, W, C, Ho, Wo, float(mul), _p(out), _lib.stream_ptr()),
                "pp_resize_bilinear_nhwc")
