@@ -2012,7 +2012,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                 if ((cand == 3 && !big) || (cand == 4 && !p_ok) || (cand == 5 && !q_ok)) continue;
                 launch(cand);  // warm
                 float ms = 1e30f;
-                for (int rep = 0; rep < 2; ++rep) {  // best of two: single samples mis-rank configurations within ~5 %
+                for (int rep = 0; rep < 3; ++rep) {  // best of three: single samples mis-rank configurations within ~5 %
                     (void)hipEventRecord(e0, st);
                     launch(cand);
                     (void)hipEventRecord(e1, st);
