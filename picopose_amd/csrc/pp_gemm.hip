@@ -161,8 +161,10 @@ __device__ __forceinline__ void epilogue_block(const PpGemmDesc& d, float descal
     float* C = d.C;
     const float* R = d.residual;
     const float* R2 = d.residual2;
-    if (d.shuffle_r != 0 || (d.N & 7) != 0 || (d.ldc & 3) != 0 || ((uintptr_t)C & 15) != 0 || (R && ((uintptr_t)R & 15) != 0) ||
-        (R2 && ((uintptr_t)R2 & 15) != 0)) {
+    // (pixel-shuffle stores stay vectorised when the 8 columns of a lane are 8 channels of one output pixel)
+    const bool shuffle_vec = d.shuffle_r == 0 || ((d.N / (d.shuffle_r * d.shuffle_r)) & 7) == 0;
+    if (!shuffle_vec || (d.shuffle_r != 0 && d.C_hl) || (d.N & 7) != 0 || (d.ldc & 3) != 0 || ((uintptr_t)C & 15) != 0 ||
+        (R && ((uintptr_t)R & 15) != 0) || (R2 && ((uintptr_t)R2 & 15) != 0)) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = nw + j * 32 + l31;
@@ -204,7 +206,16 @@ __device__ __forceinline__ void epilogue_block(const PpGemmDesc& d, float descal
         v[0] = *(const f4*)(Os + r * OSLD + c8);
         v[1] = *(const f4*)(Os + r * OSLD + c8 + 4);
         if (m >= d.M || !ncol_ok) return;
-        const size_t off = (size_t)m * d.ldc + n;
+        size_t off;
+        if (d.shuffle_r == 0) {
+            off = (size_t)m * d.ldc + n;
+        } else {  // ConvTranspose2d(kernel = stride = r): columns n .. n + 7 = channels co .. co + 7 of sub-pixel (dy, dx)
+            const int rr_ = d.shuffle_r, cout = d.N / (rr_ * rr_);
+            const int sub = n / cout, co = n - sub * cout, dy = sub / rr_, dx = sub - dy * rr_;
+            const int per = d.shuffle_h * d.shuffle_w;
+            const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
+            off = (((size_t)b * d.shuffle_h * rr_ + y * rr_ + dy) * (d.shuffle_w * rr_) + x * rr_ + dx) * d.ldc + co;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
