@@ -26,3 +26,22 @@ def test_package_seeding_recipe_equals_the_fixture_recipe():
             "ls1.gamma": torch.zeros(4), "cls_token": torch.zeros(1, 1, 4), "n.weight": torch.zeros(4)}
     a, b = ref(tmpl, 7), got(tmpl, 7)
     assert all(torch.equal(a[k], b[k]) for k in tmpl)
+
+
+def test_compat_module_name_resolves_like_the_reference_loader():
+    """run_test.py:17-20,234-235: `sys.path.append(<model dir>); MODEL = importlib.import_module("picopose")`."""
+    import importlib
+    import os
+    import sys
+
+    import picopose_amd
+
+    sys.path.insert(0, os.path.join(os.path.dirname(picopose_amd.__file__), "compat"))
+    try:
+        mod = importlib.import_module("picopose")
+        from picopose_amd.picopose import Net
+
+        assert mod.Net is Net
+    finally:
+        sys.path.pop(0)
+        sys.modules.pop("picopose", None)
