@@ -255,6 +255,18 @@ int pp_avgpool2_nhwc(const float* in, int B, int H, int W, int C, float* out, vo
  * (model/picopose.py:55-62). */
 int pp_gather_rows(const float* src, const long long* index, long long n_src_rows, long long row_floats, int n, float* dst,
                    void* stream);
+
+/* -------------------------------------------------------------------------
+ * Crop preprocessing of one detection (provider/bop_test_dataset.py:162-177, utils/data_utils.py:231-250):
+ * image (H, W, 3) uint8 as loaded, optional full-frame binary mask (H, W) uint8 (device pointers); crop rows [y1, y2),
+ * columns [x1, x2); out_rgb (3, S, S) fp32 = (cv2-style INTER_LINEAR resize of the channel-flipped crop / 255
+ * [* (mask > 0) if rgb_mask_flag] - mean) / std (mean3 / std3: host pointers to 3 doubles, in output-channel order);
+ * out_mask (S, S) fp32 = INTER_NEAREST resize of the cropped mask (may be NULL).  cv2 is not available to pin the
+ * interpolation bit-for-bit: it follows OpenCV's published definition (oracle/preprocess.py).
+ * ------------------------------------------------------------------------- */
+int pp_crop_resize_normalize(const unsigned char* image, int H, int W, const unsigned char* mask, int y1, int y2, int x1,
+                             int x2, int S, int rgb_mask_flag, const double* mean3, const double* std3, float* out_rgb,
+                             float* out_mask, void* stream);
 /* CorrelationPyramid (raft_decoder.py:30-53) + CorrLookup (corr_lookup.py:100-134) without the
  * (B*HW, HW) volume: f1 (B,H,W,C), f2_l{0,1,2} = f2 and its 2x2 average pools, flow (B,H,W,ld_flow);
  * out (B,H,W,ld_out) with channel l*(2r+1)^2 + a*(2r+1) + b = corr_l sampled at x offset a-r,

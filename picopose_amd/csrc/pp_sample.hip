@@ -222,6 +222,57 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) d4[i] = s4[i];
 }
 
+// Crop + resize + normalise of one detection (provider/bop_test_dataset.py:162-177 with utils/data_utils.py:231-250):
+// out_rgb[c] = (resize_linear(image[y1:y2, x1:x2, 2-c] / 255 [* (mask > 0)]) - mean[c]) / std[c], out_mask =
+// resize_nearest(mask[y1:y2, x1:x2]).  cv2.resize semantics on a float image (pixel centres, edge clamp), in double
+// like OpenCV's CV_64F path and torchvision's Normalize on the float64 tensor.  One thread per output pixel.
+__global__ __launch_bounds__(256) void crop_resize_kernel(const unsigned char* __restrict__ img, int W,
+                                                          const unsigned char* __restrict__ mask, int y1, int y2, int x1,
+                                                          int x2, int S, int mask_rgb, double m0, double m1, double m2,
+                                                          double s0, double s1, double s2, float* __restrict__ out_rgb,
+                                                          float* __restrict__ out_mask) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S * S) return;
+    const int oy = i / S, ox = i - oy * S, h = y2 - y1, w = x2 - x1;
+    auto taps = [](int o, int n, int S_, int& i0, int& i1, double& fr) {
+        const double f = ((double)o + 0.5) * ((double)n / (double)S_) - 0.5;
+        i0 = (int)floor(f);
+        fr = f - (double)i0;
+        if (i0 < 0) {
+            i0 = 0;
+            fr = 0.0;
+        }
+        if (i0 >= n - 1) {
+            i0 = n - 1;
+            fr = 0.0;
+        }
+        i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+    };
+    int ya, yb, xa, xb;
+    double fy, fx;
+    taps(oy, h, S, ya, yb, fy);
+    taps(ox, w, S, xa, xb, fx);
+    const double mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    auto px = [&](int yy, int xx, int c) -> double {  // channel c of the flipped ([..., ::-1]) crop, / 255, optionally masked
+        const size_t p = (size_t)(y1 + yy) * W + (x1 + xx);
+        double v = (double)img[p * 3 + (2 - c)] / 255.0;
+        if (mask_rgb && mask && mask[p] == 0) v = 0.0;
+        return v;
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double top = px(ya, xa, c) * (1.0 - fx) + px(ya, xb, c) * fx;
+        const double bot = px(yb, xa, c) * (1.0 - fx) + px(yb, xb, c) * fx;
+        out_rgb[(size_t)c * S * S + i] = (float)(((top * (1.0 - fy) + bot * fy) - mean[c]) / stdv[c]);
+    }
+    if (out_mask) {
+        int yi = (int)floor((double)oy * ((double)h / (double)S)), xi = (int)floor((double)ox * ((double)w / (double)S));
+        yi = yi < h - 1 ? yi : h - 1;
+        xi = xi < w - 1 ? xi : w - 1;
+        out_mask[i] = mask ? (float)mask[(size_t)(y1 + yi) * W + (x1 + xi)] : 1.f;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -291,6 +342,17 @@ int pp_gather_rows(const float* src, const long long* index, long long n_src_row
     const int gx = (int)((n4 + 255) / 256 < 64 ? (n4 + 255) / 256 : 64);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, src, index, row_floats, n_src_rows,
                        dst);
+    return pp_last_launch();
+}
+
+int pp_crop_resize_normalize(const unsigned char* image, int H, int W, const unsigned char* mask, int y1, int y2, int x1,
+                             int x2, int S, int rgb_mask_flag, const double* mean3, const double* std3, float* out_rgb,
+                             float* out_mask, void* stream) {
+    if (!image || !out_rgb || !mean3 || !std3 || H <= 0 || W <= 0 || S <= 0 || y1 < 0 || x1 < 0 || y2 > H || x2 > W ||
+        y2 <= y1 || x2 <= x1)
+        return PP_EINVAL;
+    hipLaunchKernelGGL(crop_resize_kernel, dim3((S * S + 255) / 256), dim3(256), 0, (hipStream_t)stream, image, W, mask, y1, y2,
+                       x1, x2, S, rgb_mask_flag, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out_rgb, out_mask);
     return pp_last_launch();
 }
 

@@ -1,0 +1,86 @@
+"""Crop preprocessing of a detection — mirror of provider/bop_test_dataset.py:146-207 (`BOPTestset.get_instance`) and
+utils/data_utils.py:131-196, 231-250 on the device.
+
+The bounding-box arithmetic, the crop affine `M`, the 64x64 lookup grid `pts2d`, the channel flip and the CLIP
+normalisation follow the reference line by line; the two `cv2.resize` calls run in `pp_crop_resize_normalize`
+(OpenCV's published INTER_LINEAR / INTER_NEAREST definitions; cv2 is not available here to pin them bit-for-bit).
+File IO (image / RLE decoding) stays with the caller."""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)       # bop_test_dataset.py:40
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)       # bop_test_dataset.py:41
+
+
+def _square(rmin, rmax, cmin, cmax, img_width, img_length, size_ratio=1.0):
+    r_b, c_b = rmax - rmin, cmax - cmin
+    b = min(max(r_b, c_b), min(img_width, img_length)) * size_ratio
+    center = [int((rmin + rmax) / 2), int((cmin + cmax) / 2)]
+    rmin, rmax = center[0] - int(b / 2), center[0] + int(b / 2)
+    cmin, cmax = center[1] - int(b / 2), center[1] + int(b / 2)
+    if rmin < 0:
+        rmax += -rmin
+        rmin = 0
+    if cmin < 0:
+        cmax += -cmin
+        cmin = 0
+    if rmax > img_width:
+        rmin -= rmax - img_width
+        rmax = img_width
+    if cmax > img_length:
+        cmin -= cmax - img_length
+        cmax = img_length
+    return [int(rmin), int(rmax), int(cmin), int(cmax)]
+
+
+def get_bbox(label, size_ratio=1.0):
+    """utils/data_utils.py:131-165: square box around the non-zero pixels of a (H, W) mask -> [rmin, rmax, cmin, cmax]."""
+    label = np.asarray(label)
+    rows, cols = np.any(label, axis=1), np.any(label, axis=0)
+    rmin, rmax = np.where(rows)[0][[0, -1]]
+    cmin, cmax = np.where(cols)[0][[0, -1]]
+    return _square(int(rmin), int(rmax) + 1, int(cmin), int(cmax) + 1, label.shape[0], label.shape[1], size_ratio)
+
+
+def get_square_bbox(bbox, img_size, size_ratio=1.0):
+    """utils/data_utils.py:167-196."""
+    return _square(bbox[0], bbox[1], bbox[2], bbox[3], img_size[0], img_size[1], size_ratio)
+
+
+def crop_instance(image_u8, mask_u8, det_bbox_xywh, img_size=224, pts_size=64, minimum_n_point=8, rgb_mask_flag=False,
+                  device="cuda"):
+    """One detection (bop_test_dataset.py:162-207): image (H,W,3) uint8 ndarray as loaded, full-frame binary mask (H,W)
+    ndarray, detection box [x, y, w, h] -> dict(rgb (3,S,S) f32 cuda, mask (S,S) f32 cuda, bbox, M (3,3) f32 tensor,
+    pts2d (P,P,2) f64 tensor) — the per-instance entries `real_rgb`, `real_mask`, `real_M`, `real_pts2d` of end_points."""
+    mask_u8 = np.ascontiguousarray(mask_u8, dtype=np.uint8)
+    image_u8 = np.ascontiguousarray(np.asarray(image_u8)[..., :3], dtype=np.uint8)
+    h, w = mask_u8.shape
+    assert image_u8.shape[:2] == (h, w)
+    if np.sum(mask_u8) > minimum_n_point:
+        y1, y2, x1, x2 = get_bbox(mask_u8)
+    else:
+        b = det_bbox_xywh
+        y1, y2, x1, x2 = get_square_bbox([b[1], b[1] + b[3], b[0], b[0] + b[2]], (h, w))
+    bbox = [y1, y2, x1, x2]
+    img_d = torch.from_numpy(image_u8).to(device)
+    msk_d = torch.from_numpy(mask_u8).to(device)
+    rgb = torch.empty(3, img_size, img_size, dtype=torch.float32, device=device)
+    mask = torch.empty(img_size, img_size, dtype=torch.float32, device=device)
+    mean, std = (ctypes.c_double * 3)(*CLIP_MEAN), (ctypes.c_double * 3)(*CLIP_STD)
+    _lib.check(_lib.lib().pp_crop_resize_normalize(img_d.data_ptr(), h, w, msk_d.data_ptr(), y1, y2, x1, x2, img_size,
+                                                   int(rgb_mask_flag), mean, std, rgb.data_ptr(), mask.data_ptr(),
+                                                   _lib.stream_ptr()), "pp_crop_resize_normalize")
+    M_crop = np.array([[1, 0, -bbox[2]], [0, 1, -bbox[0]], [0, 0, 1]], dtype=np.float32)
+    M_resize = np.array([[img_size / (y2 - y1), 0, 0], [0, img_size / (x2 - x1), 0], [0, 0, 1]], dtype=np.float32)
+    M = M_resize @ M_crop
+    patch = img_size / pts_size                                  # utils/torch_utils.py:287-295 (y first, as there)
+    x = np.arange(0, img_size, patch, dtype=np.float32) + patch / 2
+    yy, xx = np.meshgrid(x, x, indexing="ij")
+    pts = np.concatenate((np.stack([yy, xx], axis=2), np.ones((pts_size, pts_size, 1))), axis=2)
+    p = np.linalg.inv(M) @ pts.reshape(-1, 3).transpose(1, 0)
+    pts2d = (p[:2] / p[2:]).transpose(1, 0).reshape(pts_size, pts_size, 2)
+    return {"rgb": rgb, "mask": mask, "bbox": bbox, "M": torch.from_numpy(M), "pts2d": torch.from_numpy(pts2d)}

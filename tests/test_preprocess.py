@@ -1,0 +1,61 @@
+"""Crop preprocessing: host bounding-box / affine logic against the oracle restatement of
+utils/data_utils.py and provider/bop_test_dataset.py on CPU; the device resize against the oracle on GPU.
+cv2 itself is not available: the interpolation parity with OpenCV is unpinned (oracle/preprocess.py header)."""
+import numpy as np
+import pytest
+
+from oracle import preprocess as op
+
+gpu = pytest.mark.gpu
+
+
+def _case(seed, H=480, W=640):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    mask = np.zeros((H, W), np.uint8)
+    y, x = int(rng.integers(0, H - 60)), int(rng.integers(0, W - 90))
+    hh, ww = int(rng.integers(20, H - y)), int(rng.integers(20, W - x))
+    mask[y:y + hh, x:x + ww] = rng.random((hh, ww)) < 0.8
+    return img, mask, [x, y, ww, hh]
+
+
+def test_bbox_logic_matches_oracle_and_known_answers():
+    from picopose_amd.utils import preprocess as hp
+
+    m = np.zeros((480, 640), np.uint8)
+    m[100:220, 300:380] = 1
+    assert hp.get_bbox(m) == op.get_bbox(m) == [100, 220, 280, 400]           # 120 x 80 box -> 120 x 120 around its centre
+    m2 = np.zeros((480, 640), np.uint8)
+    m2[0:50, 600:640] = 1                                                        # touches two borders: shifted back inside
+    assert hp.get_bbox(m2) == op.get_bbox(m2) == [0, 50, 590, 640]
+    assert hp.get_square_bbox([10, 400, 5, 30], (480, 640)) == op.get_square_bbox([10, 400, 5, 30], (480, 640))
+    for s in range(5):
+        _, mk, _ = _case(s)
+        assert hp.get_bbox(mk) == op.get_bbox(mk)
+
+
+def test_oracle_resize_known_answers():
+    ramp = np.arange(8, dtype=np.float64)[None, :, None].repeat(4, 0)
+    up = op.resize_linear(ramp, 16)[0, :, 0]                                      # 2x upsampling of a ramp: pixel-centre alignment
+    assert np.allclose(up[:4], [0.0, 0.25, 0.75, 1.25]) and up[-1] == 7.0
+    assert np.array_equal(op.resize_nearest(np.arange(6)[None].repeat(6, 0), 3)[0], [0, 2, 4])
+    assert np.allclose(op.resize_linear(np.full((5, 7, 3), 0.3), 224), 0.3)
+
+
+@gpu
+@pytest.mark.parametrize("seed,flag", [(0, False), (1, True), (2, False), (3, True)])
+def test_crop_instance_device_vs_oracle(seed, flag):
+    import torch
+
+    from picopose_amd.utils import preprocess as hp
+
+    img, mask, det = _case(seed)
+    if seed == 2:
+        mask[:] = 0
+        mask[5, 5] = 1                                                            # too few points: detection-box fallback
+    ref = op.crop_instance(img, mask, det, rgb_mask_flag=flag)
+    got = hp.crop_instance(img, mask, det, rgb_mask_flag=flag)
+    assert got["bbox"] == ref["bbox"]
+    assert np.array_equal(got["M"].numpy(), ref["M"]) and np.array_equal(got["pts2d"].numpy(), ref["pts2d"])
+    assert torch.equal(got["mask"].cpu(), torch.from_numpy(ref["mask"]))
+    assert np.abs(got["rgb"].cpu().numpy() - ref["rgb"]).max() <= 1e-6            # double arithmetic on both sides
