@@ -267,6 +267,10 @@ int pp_gather_rows(const float* src, const long long* index, long long n_src_row
 int pp_crop_resize_normalize(const unsigned char* image, int H, int W, const unsigned char* mask, int y1, int y2, int x1,
                              int x2, int S, int rgb_mask_flag, const double* mean3, const double* std3, float* out_rgb,
                              float* out_mask, void* stream);
+/* Template lookup points (bop_test_dataset.py:233-235, data_utils.py:97-115): depth (H, W) fp32 metres -> out (P, P, 3):
+ * the back-projection ((x-cx) z/fx, (y-cy) z/fy, z) of the crop rows [y1,y2) x columns [x1,x2), INTER_NEAREST-resized. */
+int pp_depth_points_nearest(const float* depth_m, int H, int W, int y1, int y2, int x1, int x2, int P, float fx, float fy,
+                            float cx, float cy, float* out_pts, void* stream);
 /* CorrelationPyramid (raft_decoder.py:30-53) + CorrLookup (corr_lookup.py:100-134) without the
  * (B*HW, HW) volume: f1 (B,H,W,C), f2_l{0,1,2} = f2 and its 2x2 average pools, flow (B,H,W,ld_flow);
  * out (B,H,W,ld_out) with channel l*(2r+1)^2 + a*(2r+1) + b = corr_l sampled at x offset a-r,

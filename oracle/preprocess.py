@@ -107,3 +107,31 @@ def crop_instance(image_rgb_u8, mask_u8, det_bbox_xywh, img_size=224, pts_size=6
     p = np.linalg.inv(M) @ pts.reshape(-1, 3).transpose(1, 0)
     pts2d = (p[:2] / p[2:]).transpose(1, 0).reshape(pts_size, pts_size, 2)
     return {"rgb": rgb, "mask": mask.astype(np.float32), "bbox": bbox, "M": M, "pts2d": pts2d}
+
+
+def crop_template(rgba_u8, depth_mm, K, object_pose_mm, img_size=224, pts_size=64, rgb_mask_flag=False):
+    """bop_test_dataset.py:210-264 (`_get_template`) for one rendered view; file loading left to the caller."""
+    rgb = rgba_u8[..., :3]
+    mask = (rgba_u8[..., 3] / 255).astype(np.float32)
+    y1, y2, x1, x2 = bbox = get_bbox(mask)
+    mask = mask[y1:y2, x1:x2]
+    depth = depth_mm / 1000.0
+    # data_utils.py:97-115 on the crop
+    ys, xs = np.mgrid[y1:y2, x1:x2]
+    pt2 = depth[y1:y2, x1:x2].astype(np.float32)
+    pt0 = (xs.astype(np.float32) - np.float32(K[0, 2])) * pt2 / np.float32(K[0, 0])
+    pt1 = (ys.astype(np.float32) - np.float32(K[1, 2])) * pt2 / np.float32(K[1, 1])
+    cloud = np.stack([pt0, pt1, pt2]).transpose((1, 2, 0))
+    pts = resize_nearest(cloud, pts_size)
+    rgbf = rgb[..., ::-1][y1:y2, x1:x2, :] / 255.0
+    if rgb_mask_flag:
+        rgbf = rgbf * (mask[:, :, None] > 0).astype(np.uint8)
+    rgbf = resize_linear(rgbf, img_size)
+    mask_r = resize_nearest(mask.astype(int), img_size)
+    rgbn = ((rgbf.transpose(2, 0, 1) - CLIP_MEAN[:, None, None]) / CLIP_STD[:, None, None]).astype(np.float32)
+    pose = np.array(object_pose_mm, dtype=np.float64)
+    pose[:3, 3] = pose[:3, 3] / 1000.0
+    M_crop = np.array([[1, 0, -bbox[2]], [0, 1, -bbox[0]], [0, 0, 1]], dtype=np.float32)
+    M_resize = np.array([[img_size / (y2 - y1), 0, 0], [0, img_size / (x2 - x1), 0], [0, 0, 1]], dtype=np.float32)
+    return {"rgb": rgbn, "mask": mask_r.astype(np.float32), "pts3d": pts.astype(np.float32), "bbox": bbox,
+            "M": M_resize @ M_crop, "pose": pose.astype(np.float32)}

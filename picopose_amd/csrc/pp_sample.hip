@@ -273,6 +273,24 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const unsigned char* _
     }
 }
 
+// Template lookup points (provider/bop_test_dataset.py:233-235 with utils/data_utils.py:97-115): the back-projected depth
+// crop, INTER_NEAREST-resized to P x P: out[i, j] = ((x - cx) z / fx, (y - cy) z / fy, z) at the sampled crop pixel.
+__global__ __launch_bounds__(256) void depth_points_kernel(const float* __restrict__ depth, int W, int y1, int y2, int x1,
+                                                           int x2, int P, float fx, float fy, float cx, float cy,
+                                                           float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P * P) return;
+    const int oy = i / P, ox = i - oy * P, h = y2 - y1, w = x2 - x1;
+    int yi = (int)floor((double)oy * ((double)h / (double)P)), xi = (int)floor((double)ox * ((double)w / (double)P));
+    yi = yi < h - 1 ? yi : h - 1;
+    xi = xi < w - 1 ? xi : w - 1;
+    const int y = y1 + yi, x = x1 + xi;
+    const float z = depth[(size_t)y * W + x];
+    out[3 * i + 0] = ((float)x - cx) * z / fx;
+    out[3 * i + 1] = ((float)y - cy) * z / fy;
+    out[3 * i + 2] = z;
+}
+
 }  // namespace
 
 extern "C" {
@@ -353,6 +371,16 @@ int pp_crop_resize_normalize(const unsigned char* image, int H, int W, const uns
         return PP_EINVAL;
     hipLaunchKernelGGL(crop_resize_kernel, dim3((S * S + 255) / 256), dim3(256), 0, (hipStream_t)stream, image, W, mask, y1, y2,
                        x1, x2, S, rgb_mask_flag, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out_rgb, out_mask);
+    return pp_last_launch();
+}
+
+int pp_depth_points_nearest(const float* depth_m, int H, int W, int y1, int y2, int x1, int x2, int P, float fx, float fy,
+                            float cx, float cy, float* out_pts, void* stream) {
+    if (!depth_m || !out_pts || H <= 0 || W <= 0 || P <= 0 || y1 < 0 || x1 < 0 || y2 > H || x2 > W || y2 <= y1 || x2 <= x1 ||
+        fx == 0.f || fy == 0.f)
+        return PP_EINVAL;
+    hipLaunchKernelGGL(depth_points_kernel, dim3((P * P + 255) / 256), dim3(256), 0, (hipStream_t)stream, depth_m, W, y1, y2, x1,
+                       x2, P, fx, fy, cx, cy, out_pts);
     return pp_last_launch();
 }
 

@@ -84,3 +84,39 @@ def crop_instance(image_u8, mask_u8, det_bbox_xywh, img_size=224, pts_size=64, m
     p = np.linalg.inv(M) @ pts.reshape(-1, 3).transpose(1, 0)
     pts2d = (p[:2] / p[2:]).transpose(1, 0).reshape(pts_size, pts_size, 2)
     return {"rgb": rgb, "mask": mask, "bbox": bbox, "M": torch.from_numpy(M), "pts2d": torch.from_numpy(pts2d)}
+
+
+def crop_template(rgba_u8, depth_mm, K, object_pose_mm, img_size=224, pts_size=64, rgb_mask_flag=False, device="cuda"):
+    """One template view (bop_test_dataset.py:210-264, `_get_template`): rendered RGBA (H,W,4) uint8, depth (H,W) in mm,
+    template intrinsics K (3,3), object pose (4,4) with t in mm -> dict(rgb (3,S,S), mask (S,S), pts3d (P,P,3) metres
+    [cuda f32], bbox, M (3,3) f32, K, pose (t in metres)) — the per-template entries `tem_*` of end_points."""
+    rgba_u8 = np.asarray(rgba_u8)
+    mask = (rgba_u8[..., 3] / 255).astype(np.float32)                   # :222
+    y1, y2, x1, x2 = bbox = get_bbox(mask)                              # :223
+    mask_int = np.ascontiguousarray(mask.astype(int).astype(np.uint8))  # :242 `.astype(int)`: only alpha == 255 survives
+    rgb_u8 = np.ascontiguousarray(rgba_u8[..., :3], dtype=np.uint8)
+    h, w = mask.shape
+    img_d, msk_d = torch.from_numpy(rgb_u8).to(device), torch.from_numpy(mask_int).to(device)
+    # (the reference masks the colours with `mask > 0`, i.e. alpha > 0, not with the integer mask: data for that test)
+    msk_rgb_d = torch.from_numpy(np.ascontiguousarray((mask > 0).astype(np.uint8))).to(device) if rgb_mask_flag else msk_d
+    rgb = torch.empty(3, img_size, img_size, dtype=torch.float32, device=device)
+    mout = torch.empty(img_size, img_size, dtype=torch.float32, device=device)
+    mean, std = (ctypes.c_double * 3)(*CLIP_MEAN), (ctypes.c_double * 3)(*CLIP_STD)
+    L = _lib.lib()
+    _lib.check(L.pp_crop_resize_normalize(img_d.data_ptr(), h, w, msk_rgb_d.data_ptr(), y1, y2, x1, x2, img_size, int(rgb_mask_flag),
+                                          mean, std, rgb.data_ptr(), None, _lib.stream_ptr()), "pp_crop_resize_normalize")
+    dummy = torch.empty(3, img_size, img_size, dtype=torch.float32, device=device)
+    _lib.check(L.pp_crop_resize_normalize(img_d.data_ptr(), h, w, msk_d.data_ptr(), y1, y2, x1, x2, img_size, 0, mean, std,
+                                          dummy.data_ptr(), mout.data_ptr(), _lib.stream_ptr()), "pp_crop_resize_normalize")
+    depth_d = torch.from_numpy(np.ascontiguousarray(np.asarray(depth_mm) / 1000.0, dtype=np.float32)).to(device)   # :227
+    pts = torch.empty(pts_size, pts_size, 3, dtype=torch.float32, device=device)
+    K = np.asarray(K, dtype=np.float64)
+    _lib.check(L.pp_depth_points_nearest(depth_d.data_ptr(), h, w, y1, y2, x1, x2, pts_size, float(K[0, 0]), float(K[1, 1]),
+                                         float(K[0, 2]), float(K[1, 2]), pts.data_ptr(), _lib.stream_ptr()),
+               "pp_depth_points_nearest")
+    pose = np.array(object_pose_mm, dtype=np.float64)
+    pose[:3, 3] = pose[:3, 3] / 1000.0                                  # :246
+    M_crop = np.array([[1, 0, -bbox[2]], [0, 1, -bbox[0]], [0, 0, 1]], dtype=np.float32)
+    M_resize = np.array([[img_size / (y2 - y1), 0, 0], [0, img_size / (x2 - x1), 0], [0, 0, 1]], dtype=np.float32)
+    return {"rgb": rgb, "mask": mout, "pts3d": pts, "bbox": bbox, "M": torch.from_numpy(M_resize @ M_crop),
+            "K": torch.from_numpy(K.astype(np.float32)), "pose": torch.from_numpy(pose.astype(np.float32))}

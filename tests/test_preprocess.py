@@ -59,3 +59,28 @@ def test_crop_instance_device_vs_oracle(seed, flag):
     assert np.array_equal(got["M"].numpy(), ref["M"]) and np.array_equal(got["pts2d"].numpy(), ref["pts2d"])
     assert torch.equal(got["mask"].cpu(), torch.from_numpy(ref["mask"]))
     assert np.abs(got["rgb"].cpu().numpy() - ref["rgb"]).max() <= 1e-6            # double arithmetic on both sides
+
+
+@gpu
+@pytest.mark.parametrize("flag", [False, True])
+def test_crop_template_device_vs_oracle(flag):
+    from picopose_amd.utils import preprocess as hp
+
+    rng = np.random.default_rng(11)
+    H, W = 480, 640
+    rgba = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    alpha = np.zeros((H, W), np.uint8)
+    alpha[120:300, 200:330] = 255
+    alpha[110:120, 200:330] = 128                                   # anti-aliased rim: in the bbox / colour mask, not in the int mask
+    rgba[..., 3] = alpha
+    depth = (rng.random((H, W)) * 400 + 600).astype(np.float64) * (alpha > 0)
+    K = np.array([[572.4114, 0, 320], [0, 573.57043, 240], [0, 0, 1.0]])
+    pose = np.eye(4)
+    pose[:3, 3] = [10.0, -20.0, 800.0]
+    ref = op.crop_template(rgba, depth, K, pose, rgb_mask_flag=flag)
+    got = hp.crop_template(rgba, depth, K, pose, rgb_mask_flag=flag)
+    assert got["bbox"] == ref["bbox"] and np.array_equal(got["M"].numpy(), ref["M"])
+    assert np.array_equal(got["mask"].cpu().numpy(), ref["mask"])
+    assert np.abs(got["rgb"].cpu().numpy() - ref["rgb"]).max() <= 1e-6
+    assert np.abs(got["pts3d"].cpu().numpy() - ref["pts3d"]).max() <= 1e-6
+    assert np.allclose(got["pose"].numpy()[:3, 3], [0.01, -0.02, 0.8])
