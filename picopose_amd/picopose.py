@@ -128,7 +128,9 @@ class Net(nn.Module):
                for key in ("tem_pose", "tem_K", "tem_M", "tem_mask", "tem_rgb", "tem_pts3d")}
         for key in ("real_pts2d", "real_K", "real_M", "real_mask", "real_pose"):
             sel[key] = rep(end_points[key])
-        out = self.forward_test_hyp(sel, ([rep(t) for t in real_tok], hw, None if real_dpt is None else [rep(t) for t in real_dpt]),
+        # (with the query-side DPT maps at hand only the last token level is read again: for the stage-2 similarity)
+        toks = [rep(t) for t in real_tok] if real_dpt is None else [None] * (len(real_tok) - 1) + [rep(real_tok[-1])]
+        out = self.forward_test_hyp(sel, (toks, hw, None if real_dpt is None else [rep(t) for t in real_dpt]),
                                     cached(rows, idx))
         return [{key: v[k * B:(k + 1) * B] for key, v in out.items()} for k in range(hyp)]
 
