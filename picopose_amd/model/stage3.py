@@ -162,6 +162,8 @@ class FlowDecoder(Packed):
             B, H, W, _ = fr_in.shape
             X = torch.empty(B, H, W, 640, dtype=torch.float32, device=fr_in.device)  # [render | warped real | motion]
             fq = ops.conv2d(fq_in, pk[f"proj{l}"], pk[f"proj{l}_b"], 1)
+            if fq.shape[0] != B:   # query maps given once for all hypotheses (hypothesis-major batch): project once, tile
+                fq = fq.repeat(B // fq.shape[0], 1, 1, 1)
             e = self.encoder[l]
             fr = ops.conv2d(fr_in, pk[f"proj{l}"], pk[f"proj{l}_b"], 1)   # contiguous copy for the lookup
             ncorr = (l + 1) * (2 * self.r + 1) ** 2

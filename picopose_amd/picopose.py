@@ -130,7 +130,8 @@ class Net(nn.Module):
             sel[key] = rep(end_points[key])
         # (with the query-side DPT maps at hand only the last token level is read again: for the stage-2 similarity)
         toks = [rep(t) for t in real_tok] if real_dpt is None else [None] * (len(real_tok) - 1) + [rep(real_tok[-1])]
-        out = self.forward_test_hyp(sel, (toks, hw, None if real_dpt is None else [rep(t) for t in real_dpt]),
+        # (the query-side DPT maps go in un-repeated: the flow decoder projects them once and tiles the projection)
+        out = self.forward_test_hyp(sel, (toks, hw, real_dpt),
                                     cached(rows, idx))
         return [{key: v[k * B:(k + 1) * B] for key, v in out.items()} for k in range(hyp)]
 
