@@ -164,7 +164,7 @@ __device__ __forceinline__ int vt_slot(int key) {  // key (0..31) of a chunk -> 
 // HLIN: q, k, v arrive as the hl operand the qkv GEMM epilogue wrote (no split work here at all: fragments and the
 // K / V chunks are 16-byte copies); otherwise fp32 qkv, split while staging.  Both give the same bits.
 template <bool HLIN>
-__global__ __launch_bounds__(256) void attn_f16x3_kernel(const void* __restrict__ qkv_any, int T, int heads, float scale,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_f16x3_kernel(const void* __restrict__ qkv_any, int T, int heads, float scale,
                                                          float* __restrict__ out, _Float16* __restrict__ out_hl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Kh = (_Float16*)smem;            // [KC][KHLD]
