@@ -268,6 +268,12 @@ def main():
                 outs = net(ep, 5)
             return outs, pnp_for_outputs(outs, ep["real_K"])            # PnP/RANSAC + D2H of the poses
 
+    if kind == "stage1":   # a step is ~1 ms: without ~0.3 s of load first, the timed steps run while the clocks still ramp
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < 0.3:
+            for _ in range(20):
+                out = step()
+            torch.cuda.synchronize()
     for _ in range(a.warmup):
         out = step()
     torch.cuda.synchronize()
