@@ -51,6 +51,15 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #ifndef PP_S1_NT
 #define PP_S1_NT 0
 #endif
+#ifndef PP_S1_DIAG
+#define PP_S1_DIAG 0  // tuning builds (wrong results): 1 = re-read one query tile, 2 = no MFMA phase
+#endif
+#ifndef PP_S1_MAP
+#define PP_S1_MAP 0  // 1: linear workgroup -> (crop, template, half) order instead of one crop per XCD
+#endif
+#ifndef PP_S1_QDMA
+#define PP_S1_QDMA 1  // 1: query tiles by LDS-DMA (3-buffer ring), bank tiles three K-steps ahead in registers
+#endif
 #if PP_S1_NT
 #define PP_S1_LDX(p) __builtin_nontemporal_load(p)  // bank tiles are read once: keep them out of L2
 #else
@@ -193,10 +202,17 @@ constexpr int EPI_COLP = EPI_RS + 128 * 4;        // float[2][128]
 constexpr int EPI_SIM0 = EPI_COLP + 2 * 128 * 4;  // float[128]
 constexpr int EPI_ST0 = EPI_SIM0 + 128 * 4;       // float[256]
 constexpr int EPI_BYTES = EPI_ST0 + 256 * 4;
+#if PP_S1_QDMA
+constexpr int Q_RING = 3;
+constexpr int SMEM_BYTES = 2 * 10240 + Q_RING * 16384;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#else
+constexpr int Q_RING = 2;
 constexpr int SMEM_BYTES = 53248;
+#endif
 static_assert(EPI_BYTES <= SMEM_BYTES, "epilogue LDS overflow");
-static_assert(2 * Cfg<PP_MATCH_FAST>::XS_BYTES + 2 * Cfg<PP_MATCH_FAST>::QS_BYTES <= SMEM_BYTES, "");
-static_assert(2 * Cfg<PP_MATCH_EXACT>::XS_BYTES + 2 * Cfg<PP_MATCH_EXACT>::QS_BYTES <= SMEM_BYTES, "");
+static_assert(2 * Cfg<PP_MATCH_FAST>::XS_BYTES + Q_RING * Cfg<PP_MATCH_FAST>::QS_BYTES <= SMEM_BYTES, "");
+static_assert(2 * Cfg<PP_MATCH_EXACT>::XS_BYTES + Q_RING * Cfg<PP_MATCH_EXACT>::QS_BYTES <= SMEM_BYTES, "");
 
 // max with the value of lane^1 / lane^2 (DPP quad permutes, no LDS traffic)
 __device__ __forceinline__ float dpp_xor1(float v) {
@@ -225,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
     {
         const int bid = blockIdx.x;
         const int per_crop = 2 * N;
-        if (B >= 8) {
+        if (B >= 8 && PP_S1_MAP == 0) {
             const int x = bid & 7, j = bid >> 3;
             b = x + 8 * (j / per_crop);
             const int r = j % per_crop;
@@ -237,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
             const int r = bid % per_crop;
             n = r >> 1;
             half = r & 1;
+            if (b >= B) return;
         }
     }
     const int tid = threadIdx.x;
@@ -269,10 +286,31 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
     const u4* qptr = (MODE == PP_MATCH_FAST ? (const u4*)(qh + (size_t)b * C * P)
                                             : (const u4*)(qf + (size_t)b * C * P)) + tid;
 
+#if PP_S1_QDMA
+    f4 x0[K::XL], x1[K::XL], x2[K::XL];  // X tiles of the next three K-steps, in flight
+    // query tiles: linear 16 KB copies global -> LDS ring by LDS-DMA (1 KB per wave instruction)
+    const __amdgpu_buffer_rsrc_t Qr = __builtin_amdgcn_make_buffer_rsrc(
+        MODE == PP_MATCH_FAST ? (void*)(qh + (size_t)b * C * P) : (void*)(qf + (size_t)b * C * P), 0,
+        C * P * (MODE == PP_MATCH_FAST ? 2 : 4), 0x00020000);
+    const unsigned qvoff = tid * 16;
+    char* Qring = smem + 2 * K::XS_BYTES;
+    // bank tiles by buffer loads bounded to this template's slice: K-steps past the end read zeros without
+    // memory traffic, so every step issues the same loads and the counted waits below are exact
+    const __amdgpu_buffer_rsrc_t Xr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(bank + bn * (size_t)C * P), 0, C * P * 4, 0x00020000);
+    const unsigned xvoff = (half * 128 + (2 * w + lh) * P + 4 * l31) * 4;
+#define LOAD_XB(ks_, x_)                                                              \
+    do {                                                                              \
+        _Pragma("unroll") for (int j = 0; j < K::XL; ++j) x_[j] = __builtin_bit_cast( \
+            f4, __builtin_amdgcn_raw_buffer_load_b128(Xr, xvoff, ((ks_) * K::KS + 8 * j) * P * 4, 0)); \
+    } while (0)
+#else
     f4 x0[K::XL], x1[K::XL];  // X tiles of the next two K-steps, in flight
     u4 q0[4];                 // query tile(s) of the next K-step(s) (L2 / Infinity Cache)
 #if PP_S1_QDEPTH == 2
     u4 q1[4];
+#endif
+
 #endif
 
 #define LOAD_X(ks_, x_)                                                               \
@@ -285,6 +323,56 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
         _Pragma("unroll") for (int j = 0; j < 4; ++j) q_[j] =                         \
             qptr[(size_t)(ks_) * 1024 + j * 256];                                     \
     } while (0)
+#if PP_S1_QDMA
+#define DMA_Q(ks_, buf_)                                                              \
+    do {                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                 \
+                Qr, (lds_ptr_t)(Qring + (buf_) * 16384 + (j * 256 + w * 64) * 16), 16, qvoff, \
+                ((ks_) * 1024 + j * 256) * 16, 0, 0);                                 \
+    } while (0)
+#define STORE_X(Xs_, x_)                                                              \
+    do {                                                                              \
+        if (MODE == PP_MATCH_FAST) {                                                  \
+            _Pragma("unroll") for (int j = 0; j < K::XL; ++j) {                       \
+                const f4 v = x_[j];                                                   \
+                ssq0 = fmaf(v.x, v.x, ssq0);                                          \
+                ssq1 = fmaf(v.y, v.y, ssq1);                                          \
+                ssq2 = fmaf(v.z, v.z, ssq2);                                          \
+                ssq3 = fmaf(v.w, v.w, ssq3);                                          \
+                h4 hv;                                                                \
+                hv[0] = (_Float16)v.x;                                                \
+                hv[1] = (_Float16)v.y;                                                \
+                hv[2] = (_Float16)v.z;                                                \
+                hv[3] = (_Float16)v.w;                                                \
+                *(h4*)((Xs_) + (8 * j + 2 * w + lh) * XROW_F16 + 8 * l31) = hv;       \
+            }                                                                         \
+        } else {                                                                      \
+            _Pragma("unroll") for (int j = 0; j < K::XL; ++j)                         \
+                *(f4*)((Xs_) + ((8 * j + 2 * w + lh) * 128 + 4 * l31) * 4) = x_[j];   \
+        }                                                                             \
+    } while (0)
+// one K-step.  VMEM issue order is X(0) Q(0) X(1) Q(1) X(2) | Q(ks+2) X(ks+3) per step, so when step ks
+// starts, X(ks+1), Q(ks+1), X(ks+2) may still be in flight: a counted vmcnt retires this wave's share of
+// Q(ks) (and X(ks)); the barrier then publishes Q(ks) of all waves together with the X tile.
+#define STEP(ks_, x_, qcur_, qnxt_)                                                   \
+    do {                                                                              \
+        char* Xs_ = smem + (((ks_)&1) ? K::XS_BYTES : 0);                             \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        if ((ks_) >= 0) {                                                             \
+            if (MODE == PP_MATCH_FAST) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                     \
+            STORE_X(Xs_, x_);                                                         \
+            __builtin_amdgcn_sched_barrier(0); /* x_ consumed before it is reloaded */ \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
+            __builtin_amdgcn_s_barrier();                                             \
+        }                                                                             \
+        if (PP_S1_DIAG != 1) DMA_Q((ks_) + 2, qnxt_);                                 \
+        else DMA_Q(0, qnxt_);                                                         \
+        LOAD_XB((ks_) + 3, x_);                                                       \
+        if ((ks_) >= 0 && PP_S1_DIAG != 2) mfma_step(Xs_, Qring + (qcur_) * 16384);   \
+    } while (0)
+#else
 #define STORE_STEP(Xs_, Qs_, x_, q_)                                                    \
     do {                                                                              \
         if (MODE == PP_MATCH_FAST) {                                                  \
@@ -332,7 +420,50 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
     } while (0)
 #endif
 
+#endif
+
     auto mfma_step = [&](const char* Xs, const char* Qs) __attribute__((always_inline)) {
+#if PP_S1_QDMA
+        if (MODE == PP_MATCH_FAST) {
+            // The transposing reads are inline asm: as builtins hipcc orders them after every pending LDS-DMA
+            // (s_waitcnt vmcnt(0) in the K loop).  Their results are retired by the explicit lgkmcnt(0).
+            h8 a[2][4];
+            fp16x4_t lo[2][2], hi[2][2];
+            const int col = wc * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            const int row = 8 * lh + ((lane & 15) >> 2);
+            const unsigned xaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(Xs + row * XROW_F16 + col * 2);
+#define S1_READ(kh_)                                                                          \
+    do {                                                                                      \
+        _Pragma("unroll") for (int tb = 0; tb < 4; ++tb) a[kh_][tb] =                         \
+            *(const h8*)(Qs + ((kh_) * 8 + wr * 4 + tb) * 1024 + lane * 16);                  \
+        asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%5\n\tds_read_b64_tr_b16 %1, %4 offset:%6\n\t" \
+                     "ds_read_b64_tr_b16 %2, %4 offset:%7\n\tds_read_b64_tr_b16 %3, %4 offset:%8"     \
+                     : "=&v"(lo[kh_][0]), "=&v"(hi[kh_][0]), "=&v"(lo[kh_][1]), "=&v"(hi[kh_][1])      \
+                     : "v"(xaddr), "n"((kh_) * 16 * XROW_F16), "n"((kh_) * 16 * XROW_F16 + 4 * XROW_F16), \
+                       "n"((kh_) * 16 * XROW_F16 + 64), "n"((kh_) * 16 * XROW_F16 + 4 * XROW_F16 + 64)  \
+                     : "memory");                                                             \
+    } while (0)
+#define S1_MMA(kh_)                                                                           \
+    do {                                                                                      \
+        h8 bf[2];                                                                             \
+        _Pragma("unroll") for (int sb = 0; sb < 2; ++sb)                                      \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                   \
+                bf[sb][e] = (_Float16)lo[kh_][sb][e];                                         \
+                bf[sb][4 + e] = (_Float16)hi[kh_][sb][e];                                     \
+            }                                                                                 \
+        _Pragma("unroll") for (int tb = 0; tb < 4; ++tb)                                      \
+            _Pragma("unroll") for (int sb = 0; sb < 2; ++sb) acc[tb][sb] =                    \
+                __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kh_][tb], bf[sb], acc[tb][sb], 0, 0, 0); \
+    } while (0)
+            S1_READ(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            S1_READ(1);
+            S1_MMA(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            S1_MMA(1);
+#undef S1_READ
+#undef S1_MMA
+#else
         if (MODE == PP_MATCH_FAST) {
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
@@ -362,6 +493,7 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
                         acc[tb][sb] =
                             __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tb], bf[sb], acc[tb][sb], 0, 0, 0);
             }
+#endif
         } else {
             const float* Xf = (const float*)Xs;
             const float* Qf = (const float*)Qs;
@@ -387,6 +519,23 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
 
     // ---- K loop: both operands prefetched two K-steps ahead in registers, LDS double buffer,
     //      one barrier per K-step.  KT is even (C % 64 == 0).
+#if PP_S1_QDMA
+    // The first iteration (ks = -3) only issues loads — Q(-1) (out of bounds: zeros), X(0), Q(0), X(1), Q(1), X(2)
+    // — so each tile register has ONE defining load (no copies of in-flight registers at the back edge) and
+    // the issue order is the steady state's from the start.  Steps past KT multiply zero tiles.
+    int ks_first = -3;
+    asm volatile("" : "+s"(ks_first));  // opaque: hipcc must not peel the load-only iteration
+#pragma clang loop unroll(disable)
+    for (int ks = ks_first; ks < KT; ks += 3) {
+        STEP(ks, x0, 0, 2);
+        STEP(ks + 1, x1, 1, 0);
+        STEP(ks + 2, x2, 2, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS
+#undef LOAD_XB
+#undef DMA_Q
+#undef STORE_X
+#else
     LOAD_X(0, x0);
     LOAD_Q(0, q0);
     LOAD_X(1, x1);
@@ -397,10 +546,13 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
         STEP(ks, x0, q0, Xs0, Qs0);
         STEP(ks + 1, x1, q1, Xs1, Qs1);
     }
+#endif
 #undef STEP
 #undef LOAD_X
+#if !PP_S1_QDMA
 #undef LOAD_Q
 #undef STORE_STEP
+#endif
     __syncthreads();
 #if PP_S1_EPI == 1
     {
@@ -806,6 +958,15 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask, i
     hipLaunchKernelGGL(s1_qpack, dim3(B, C / 32), dim3(256), 0, stream, query, w.denom, w.m16, C,
                        w.qh, w.qf);
     const int grid = (B >= 8) ? 8 * ((B + 7) / 8) * 2 * N : B * 2 * N;
+#if PP_S1_QDMA
+    static const bool lds_ok = [] {  // > 64 KB of dynamic LDS needs the opt-in
+        return hipFuncSetAttribute((const void*)s1_main<PP_MATCH_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   SMEM_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)s1_main<PP_MATCH_EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   SMEM_BYTES) == hipSuccess;
+    }();
+    if (!lds_ok) return PP_ELAUNCH;
+#endif
     {
         PpProfScope prof(stream);  // roofline kernel of stage 1 (bench.py)
         if (mode == PP_MATCH_FAST)

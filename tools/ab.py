@@ -8,6 +8,8 @@ variants = [v if v != "default" else "" for v in sys.argv[4:]] or [""]
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(1)
 bank = torch.randn(B, N, C, 16, 16, device=dev, generator=g)
+if os.environ.get('AB_CONST') == '1':
+    bank.fill_(0.1234)  # data-dependence check: constant bank
 q = torch.randn(B, C, 16, 16, device=dev, generator=g)
 yy, xx = torch.meshgrid(torch.arange(224.0), torch.arange(224.0), indexing="ij")
 m = (((yy - 111.5) ** 2 + (xx - 111.5) ** 2) < (0.4 * 224) ** 2).float()[None].repeat(B, 1, 1).to(dev)
