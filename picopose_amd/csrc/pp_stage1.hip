@@ -13,13 +13,15 @@
 // registers/LDS:  i1[t] != 0  <=>  max_s sim[t,s] > sim[t,0]   (first max wins
 // ties in torch.max, so a tie with column 0 yields index 0), same for i2.
 //
-// Work decomposition: one 256-thread workgroup (4 waves, 2x2) owns all 256
-// query patches x 128 template patches (one half) of one template; each wave
-// holds a 128x64 fp32 tile in 128 accumulator registers.  The bank is read
-// exactly once (coalesced 16 B/lane, 512 B row segments); the pre-normalised,
-// pre-masked query operand is re-read from L2 (workgroups of one crop are
-// placed on one XCD).  Two workgroups per CU overlap one's epilogue with the
-// other's stream.
+// Work decomposition: a work item is all 256 query patches x 128 template patches
+// (one half) of one template; a 256-thread workgroup (4 waves, 2x2) processes it with
+// a 128x64 fp32 tile per wave in 128 accumulator registers.  Workgroups are persistent
+// (two per CU) and walk the items in bank order.  The bank is read exactly once
+// (coalesced 16 B/lane, 512 B row segments, three K-steps ahead in registers, bounded
+// buffer loads); the pre-normalised, pre-masked query operand comes from L2 by LDS-DMA
+// into a 3-slot ring.  The tile stream rolls from one item into the next, so the next
+// item's first tiles are in flight during the epilogue, and the co-resident workgroup
+// overlaps its K loop with it.
 //
 // Two arithmetic modes share the skeleton:
 //   EXACT  v_mfma_f32_32x32x2_f32 — bit-for-bit an fp32 fma chain over c.
@@ -41,30 +43,6 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
-
-#ifndef PP_S1_QDEPTH
-#define PP_S1_QDEPTH 1
-#endif
-#ifndef PP_S1_EPI
-#define PP_S1_EPI 0  // 1: tuning build that skips the epilogue (wrong results, K-loop ceiling)
-#endif
-#ifndef PP_S1_NT
-#define PP_S1_NT 0
-#endif
-#ifndef PP_S1_DIAG
-#define PP_S1_DIAG 0  // tuning builds (wrong results): 1 = re-read one query tile, 2 = no MFMA phase
-#endif
-#ifndef PP_S1_MAP
-#define PP_S1_MAP 0  // 1: linear workgroup -> (crop, template, half) order instead of one crop per XCD
-#endif
-#ifndef PP_S1_QDMA
-#define PP_S1_QDMA 1  // 1: query tiles by LDS-DMA (3-buffer ring), bank tiles three K-steps ahead in registers
-#endif
-#if PP_S1_NT
-#define PP_S1_LDX(p) __builtin_nontemporal_load(p)  // bank tiles are read once: keep them out of L2
-#else
-#define PP_S1_LDX(p) (*(p))
-#endif
 
 constexpr int P = 256;           // patches per image (16x16), fixed by the reference
 constexpr int XROW_F16 = 320;    // bytes per k-row of the fp16 X tile (256 + 64 pad:
@@ -185,34 +163,34 @@ struct Cfg<PP_MATCH_EXACT> {
     static constexpr int KS = 16;                 // channels per K-step
     static constexpr int XL = 2;                  // 16-byte X loads per thread per step
     static constexpr int XS_BYTES = 16 * 128 * 4; // [16][128] fp32
-    static constexpr int QS_BYTES = 16 * 256 * 4; // [16][256] fp32
 };
 template <>
 struct Cfg<PP_MATCH_FAST> {
     static constexpr int KS = 32;
     static constexpr int XL = 4;
     static constexpr int XS_BYTES = 32 * XROW_F16;  // [32][160 halfs] (128 used)
-    static constexpr int QS_BYTES = 16 * 1024;      // 16 fragment chunks of 1 KB
 };
 
-constexpr int EPI_T_BYTES = 4 * 128 * TROW * 4;   // float[4 waves][128 rows][TROW]
-constexpr int EPI_RED = EPI_T_BYTES;              // float[8][128]
-constexpr int EPI_RS = EPI_RED + 8 * 128 * 4;     // float[128]
-constexpr int EPI_COLP = EPI_RS + 128 * 4;        // float[2][128]
+// LDS: [query ring: 3 slots of 16 KB][X tile buffer 1][X tile buffer 0][small epilogue arrays].
+// The epilogue's transpose tile T lives in ring slot 2 + X buffer 1: slots 0/1 receive the NEXT item's first
+// query tiles while the epilogue runs, and X buffer 0 (written by the next item's step 0) stays untouched, so
+// the step's own barrier is the only one needed between an epilogue and the following K loop.
+constexpr int QS = 16384;                         // one query tile: 16 fragment chunks of 1 KB (fast) / [16][256] fp32
+constexpr int Q_RING = 3;
+constexpr int XS_MAX = Cfg<PP_MATCH_FAST>::XS_BYTES;
+constexpr int XS1_OFF = Q_RING * QS;              // K-steps of odd parity
+constexpr int XS0_OFF = XS1_OFF + XS_MAX;         // K-steps of even parity
+constexpr int EPI_T = 2 * QS;                     // float[4 waves][128 rows][TROW]
+constexpr int EPI_T_BYTES = 4 * 128 * TROW * 4;
+constexpr int EPI_RED = XS0_OFF + XS_MAX;         // float[8][128]
+constexpr int EPI_COLP = EPI_RED + 8 * 128 * 4;   // float[2][128]
 constexpr int EPI_SIM0 = EPI_COLP + 2 * 128 * 4;  // float[128]
 constexpr int EPI_ST0 = EPI_SIM0 + 128 * 4;       // float[256]
-constexpr int EPI_BYTES = EPI_ST0 + 256 * 4;
-#if PP_S1_QDMA
-constexpr int Q_RING = 3;
-constexpr int SMEM_BYTES = 2 * 10240 + Q_RING * 16384;
+constexpr int SMEM_BYTES = EPI_ST0 + 256 * 4;
+static_assert(EPI_T + EPI_T_BYTES <= XS0_OFF, "epilogue transpose tile overlaps X buffer 0");
+static_assert(Cfg<PP_MATCH_EXACT>::XS_BYTES <= XS_MAX, "");
+static_assert(2 * SMEM_BYTES <= 160 * 1024, "two workgroups per CU");
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-#else
-constexpr int Q_RING = 2;
-constexpr int SMEM_BYTES = 53248;
-#endif
-static_assert(EPI_BYTES <= SMEM_BYTES, "epilogue LDS overflow");
-static_assert(2 * Cfg<PP_MATCH_FAST>::XS_BYTES + Q_RING * Cfg<PP_MATCH_FAST>::QS_BYTES <= SMEM_BYTES, "");
-static_assert(2 * Cfg<PP_MATCH_EXACT>::XS_BYTES + Q_RING * Cfg<PP_MATCH_EXACT>::QS_BYTES <= SMEM_BYTES, "");
 
 // max with the value of lane^1 / lane^2 (DPP quad permutes, no LDS traffic)
 __device__ __forceinline__ float dpp_xor1(float v) {
@@ -222,53 +200,75 @@ __device__ __forceinline__ float dpp_xor2(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
 }
 
-// One 256-thread workgroup (4 waves, 2x2) = (crop b, template n, half): all 256 query patches
-// x 128 template patches; each wave holds a 128x64 fp32 tile in 128 accumulator registers.
+// Work item v -> (crop, template, half), in bank order: the workgroups resident at any time stream one
+// contiguous window of the bank (measured 4 % faster than keeping each crop on one XCD; the query operand is
+// then cached by every XCD's L2, 393 KB per crop and XCD against 127 MB of bank per crop).
+__device__ __forceinline__ void s1_item(int v, int N, int& b, int& n, int& half) {
+    const int per_crop = 2 * N;
+    b = v / per_crop;
+    const int r = v % per_crop;
+    n = r >> 1;
+    half = r & 1;
+}
+
+// Persistent 256-thread workgroups (4 waves, 2x2), two per CU.  A work item = (crop b, template n, half):
+// all 256 query patches x 128 template patches; each wave holds a 128x64 fp32 tile in 128 accumulator
+// registers.  The K loop runs over a tile stream that rolls from one item into the next, so the next
+// item's first tiles are in flight while the epilogue of the current one runs.
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank,
                                                   const _Float16* __restrict__ qh,
-                                                  const float* __restrict__ qf, int B, int N, int C,
+                                                  const float* __restrict__ qf, int N, int C, int total,
                                                   float4* __restrict__ rowrec,
                                                   float* __restrict__ simt0,
                                                   float* __restrict__ colmax,
                                                   float* __restrict__ sim0s) {
     using K = Cfg<MODE>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int QELT = MODE == PP_MATCH_FAST ? 2 : 4;
 
-    // ---- workgroup -> (crop, template, half); crops of one XCD label (blockIdx % 8) stay
-    //      together so the crop's query operand is served by that XCD's L2
-    int b, n, half;
-    {
-        const int bid = blockIdx.x;
-        const int per_crop = 2 * N;
-        if (B >= 8 && PP_S1_MAP == 0) {
-            const int x = bid & 7, j = bid >> 3;
-            b = x + 8 * (j / per_crop);
-            const int r = j % per_crop;
-            n = r >> 1;
-            half = r & 1;
-            if (b >= B) return;
-        } else {
-            b = bid / per_crop;
-            const int r = bid % per_crop;
-            n = r >> 1;
-            half = r & 1;
-            if (b >= B) return;
-        }
-    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 1, wc = w & 1;
     const int l31 = lane & 31, lh = lane >> 5;
-
-    const size_t bn = (size_t)b * N + n;
     const int KT = C / K::KS;
+    const int KT3 = (KT + 2) / 3 * 3;  // K-steps per item; steps past KT multiply zero tiles
+    const int G = gridDim.x;
 
-    char* Xs0 = smem;
-    char* Xs1 = smem + K::XS_BYTES;
-    char* Qs0 = smem + 2 * K::XS_BYTES;
-    char* Qs1 = Qs0 + K::QS_BYTES;
+    // ---- first item of this workgroup, and the one after it
+    int b, n, half;
+    int v_cur = blockIdx.x;
+    if (v_cur >= total) return;
+    s1_item(v_cur, N, b, n, half);
+    int v_nxt = v_cur + G;
+
+    char* Qring = smem;
+
+    // Tile stream.  Bank tiles: buffer loads bounded to the item's slice (base = its first row at this half's
+    // column offset), query tiles: linear 16 KB copies global -> LDS by LDS-DMA (1 KB per wave instruction).
+    // Tiles past the end of a slice read zeros without memory traffic, so every step issues the same loads and
+    // the counted waits below are exact.  After an item's last tile the descriptors switch to the next item's
+    // (an empty slice when there is none).
+#define X_DESC(b_, n_, half_, ok_)                                                                         \
+    __builtin_amdgcn_make_buffer_rsrc((void*)(bank + ((size_t)(b_) * N + (n_)) * (size_t)C * P + (half_) * 128), 0, \
+                                      (ok_) ? C * P * 4 - (half_) * 512 : 0, 0x00020000)
+#define Q_DESC(b_, ok_)                                                                                     \
+    __builtin_amdgcn_make_buffer_rsrc(MODE == PP_MATCH_FAST ? (void*)(qh + (size_t)(b_) * C * P)           \
+                                                            : (void*)(qf + (size_t)(b_) * C * P),          \
+                                      0, (ok_) ? C * P * QELT : 0, 0x00020000)
+    __amdgpu_buffer_rsrc_t Xd = X_DESC(b, n, half, true), Qd = Q_DESC(b, true);
+    __amdgpu_buffer_rsrc_t XdN, QdN;
+    {
+        int b2, n2, h2;
+        const bool ok = v_nxt < total;
+        s1_item(ok ? v_nxt : v_cur, N, b2, n2, h2);
+        XdN = X_DESC(b2, n2, h2, ok);
+        QdN = Q_DESC(b2, ok);
+    }
+    int xt = 0, qt = -1;  // next tile of the stream; the very first query copy is a dummy (out of bounds: zeros)
+    const unsigned xvoff = ((2 * w + lh) * P + 4 * l31) * 4;
+    const unsigned qvoff = tid * 16;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -277,59 +277,29 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     // FAST: sum of squares of this thread's 4 columns; EXACT: ssq0/ssq1 = column blocks sb 0/1
     float ssq0 = 0.f, ssq1 = 0.f, ssq2 = 0.f, ssq3 = 0.f;
-
-    // per-thread global pointers of the K-step loads
-    const float* xptr = bank + bn * (size_t)C * P + half * 128 + (size_t)(2 * w + lh) * P + 4 * l31;
-    const u4* qptr = (MODE == PP_MATCH_FAST ? (const u4*)(qh + (size_t)b * C * P)
-                                            : (const u4*)(qf + (size_t)b * C * P)) + tid;
-
-#if PP_S1_QDMA
     f4 x0[K::XL], x1[K::XL], x2[K::XL];  // X tiles of the next three K-steps, in flight
-    // query tiles: linear 16 KB copies global -> LDS ring by LDS-DMA (1 KB per wave instruction)
-    const __amdgpu_buffer_rsrc_t Qr = __builtin_amdgcn_make_buffer_rsrc(
-        MODE == PP_MATCH_FAST ? (void*)(qh + (size_t)b * C * P) : (void*)(qf + (size_t)b * C * P), 0,
-        C * P * (MODE == PP_MATCH_FAST ? 2 : 4), 0x00020000);
-    const unsigned qvoff = tid * 16;
-    char* Qring = smem + 2 * K::XS_BYTES;
-    // bank tiles by buffer loads bounded to this template's slice: K-steps past the end read zeros without
-    // memory traffic, so every step issues the same loads and the counted waits below are exact
-    const __amdgpu_buffer_rsrc_t Xr =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(bank + bn * (size_t)C * P), 0, C * P * 4, 0x00020000);
-    const unsigned xvoff = (half * 128 + (2 * w + lh) * P + 4 * l31) * 4;
-#define LOAD_XB(ks_, x_)                                                              \
-    do {                                                                              \
-        _Pragma("unroll") for (int j = 0; j < K::XL; ++j) x_[j] = __builtin_bit_cast( \
-            f4, __builtin_amdgcn_raw_buffer_load_b128(Xr, xvoff, ((ks_) * K::KS + 8 * j) * P * 4, 0)); \
-    } while (0)
-#else
-    f4 x0[K::XL], x1[K::XL];  // X tiles of the next two K-steps, in flight
-    u4 q0[4];                 // query tile(s) of the next K-step(s) (L2 / Infinity Cache)
-#if PP_S1_QDEPTH == 2
-    u4 q1[4];
-#endif
 
-#endif
-
-#define LOAD_X(ks_, x_)                                                               \
-    do {                                                                              \
-        _Pragma("unroll") for (int j = 0; j < K::XL; ++j) x_[j] =                     \
-            PP_S1_LDX((const f4*)(xptr + (size_t)((ks_) * K::KS + 8 * j) * P));       \
+#define LOAD_XB(x_)                                                                               \
+    do {                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < K::XL; ++j) x_[j] = __builtin_bit_cast(             \
+            f4, __builtin_amdgcn_raw_buffer_load_b128(Xd, xvoff, (xt * K::KS + 8 * j) * P * 4, 0)); \
+        if (++xt == KT3) {                                                                        \
+            xt = 0;                                                                               \
+            Xd = XdN;                                                                             \
+        }                                                                                         \
     } while (0)
-#define LOAD_Q(ks_, q_)                                                               \
-    do {                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) q_[j] =                         \
-            qptr[(size_t)(ks_) * 1024 + j * 256];                                     \
-    } while (0)
-#if PP_S1_QDMA
-#define DMA_Q(ks_, buf_)                                                              \
-    do {                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                 \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                 \
-                Qr, (lds_ptr_t)(Qring + (buf_) * 16384 + (j * 256 + w * 64) * 16), 16, qvoff, \
-                ((ks_) * 1024 + j * 256) * 16, 0, 0);                                 \
+#define DMA_Q(slot_)                                                                              \
+    do {                                                                                          \
+        const int qtile = qt < 0 ? KT3 : qt; /* the dummy: a tile past the end */                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(   \
+            Qd, (lds_ptr_t)(Qring + (slot_) * QS + (j * 256 + w * 64) * 16), 16, qvoff,           \
+            (qtile * 1024 + j * 256) * 16, 0, 0);                                                 \
+        if (++qt == KT3) {                                                                        \
+            qt = 0;                                                                               \
+            Qd = QdN;                                                                             \
+        }                                                                                         \
     } while (0)
 #define STORE_X(Xs_, x_)                                                              \
     do {                                                                              \
@@ -352,78 +322,33 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
                 *(f4*)((Xs_) + ((8 * j + 2 * w + lh) * 128 + 4 * l31) * 4) = x_[j];   \
         }                                                                             \
     } while (0)
-// one K-step.  VMEM issue order is X(0) Q(0) X(1) Q(1) X(2) | Q(ks+2) X(ks+3) per step, so when step ks
-// starts, X(ks+1), Q(ks+1), X(ks+2) may still be in flight: a counted vmcnt retires this wave's share of
-// Q(ks) (and X(ks)); the barrier then publishes Q(ks) of all waves together with the X tile.
-#define STEP(ks_, x_, qcur_, qnxt_)                                                   \
+#define LDS_BARRIER()                                          \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                          \
+    } while (0)
+// One K-step (ct = K-step of the current item, < 0 while the stream warms up).  VMEM issue order per step is
+// Q(ct+2) X(ct+3), so when step ct starts X(ct+1), Q(ct+1), X(ct+2) may still be in flight: a counted vmcnt
+// retires this wave's share of Q(ct) (and X(ct)); the barrier then publishes Q(ct) of all waves together
+// with the X tile.  Each tile register has ONE defining load (no copies of in-flight registers at the back
+// edge), which is why the warm-up runs through the same code with the compute parts switched off.
+#define STEP(ct_, x_, qcur_, qnxt_)                                                   \
     do {                                                                              \
-        char* Xs_ = smem + (((ks_)&1) ? K::XS_BYTES : 0);                             \
+        char* Xs_ = smem + (((ct_)&1) ? XS1_OFF : XS0_OFF);                           \
         __builtin_amdgcn_sched_barrier(0);                                            \
-        if ((ks_) >= 0) {                                                             \
+        if ((ct_) >= 0) {                                                             \
             if (MODE == PP_MATCH_FAST) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                     \
             STORE_X(Xs_, x_);                                                         \
             __builtin_amdgcn_sched_barrier(0); /* x_ consumed before it is reloaded */ \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
-            __builtin_amdgcn_s_barrier();                                             \
+            LDS_BARRIER();                                                            \
         }                                                                             \
-        if (PP_S1_DIAG != 1) DMA_Q((ks_) + 2, qnxt_);                                 \
-        else DMA_Q(0, qnxt_);                                                         \
-        LOAD_XB((ks_) + 3, x_);                                                       \
-        if ((ks_) >= 0 && PP_S1_DIAG != 2) mfma_step(Xs_, Qring + (qcur_) * 16384);   \
+        DMA_Q(qnxt_);                                                                 \
+        LOAD_XB(x_);                                                                  \
+        if ((ct_) >= 0) mfma_step(Xs_, Qring + (qcur_) * QS);                         \
     } while (0)
-#else
-#define STORE_STEP(Xs_, Qs_, x_, q_)                                                    \
-    do {                                                                              \
-        if (MODE == PP_MATCH_FAST) {                                                  \
-            _Pragma("unroll") for (int j = 0; j < K::XL; ++j) {                       \
-                const f4 v = x_[j];                                                   \
-                ssq0 = fmaf(v.x, v.x, ssq0);                                          \
-                ssq1 = fmaf(v.y, v.y, ssq1);                                          \
-                ssq2 = fmaf(v.z, v.z, ssq2);                                          \
-                ssq3 = fmaf(v.w, v.w, ssq3);                                          \
-                h4 hv;                                                                \
-                hv[0] = (_Float16)v.x;                                                \
-                hv[1] = (_Float16)v.y;                                                \
-                hv[2] = (_Float16)v.z;                                                \
-                hv[3] = (_Float16)v.w;                                                \
-                *(h4*)((Xs_) + (8 * j + 2 * w + lh) * XROW_F16 + 8 * l31) = hv;       \
-            }                                                                         \
-        } else {                                                                      \
-            _Pragma("unroll") for (int j = 0; j < K::XL; ++j)                         \
-                *(f4*)((Xs_) + ((8 * j + 2 * w + lh) * 128 + 4 * l31) * 4) = x_[j];   \
-        }                                                                             \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                 \
-            *(u4*)((Qs_) + (j * 256 + tid) * 16) = q_[j];                             \
-    } while (0)
-// one K-step: publish tile ks (registers -> LDS buffer ks&1), refill the registers with
-// tiles ks+2 (X) and ks+PP_S1_QDEPTH (Q), one barrier, MFMAs on the published tile
-#if PP_S1_QDEPTH == 2
-#define STEP(ks_, x_, q_, Xs_, Qs_)                                                   \
-    do {                                                                              \
-        STORE_STEP(Xs_, Qs_, x_, q_);                                                 \
-        if ((ks_) + 2 < KT) {                                                         \
-            LOAD_X((ks_) + 2, x_);                                                    \
-            LOAD_Q((ks_) + 2, q_);                                                    \
-        }                                                                             \
-        __syncthreads();                                                              \
-        mfma_step(Xs_, Qs_);                                                          \
-    } while (0)
-#else
-#define STEP(ks_, x_, q_, Xs_, Qs_)                                                   \
-    do {                                                                              \
-        STORE_STEP(Xs_, Qs_, x_, q0);                                                 \
-        if ((ks_) + 2 < KT) LOAD_X((ks_) + 2, x_);                                    \
-        if ((ks_) + 1 < KT) LOAD_Q((ks_) + 1, q0);                                    \
-        __syncthreads();                                                              \
-        mfma_step(Xs_, Qs_);                                                          \
-    } while (0)
-#endif
-
-#endif
 
     auto mfma_step = [&](const char* Xs, const char* Qs) __attribute__((always_inline)) {
-#if PP_S1_QDMA
         if (MODE == PP_MATCH_FAST) {
             // The transposing reads are inline asm: as builtins hipcc orders them after every pending LDS-DMA
             // (s_waitcnt vmcnt(0) in the K loop).  Their results are retired by the explicit lgkmcnt(0).
@@ -431,7 +356,8 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
             fp16x4_t lo[2][2], hi[2][2];
             const int col = wc * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
             const int row = 8 * lh + ((lane & 15) >> 2);
-            const unsigned xaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(Xs + row * XROW_F16 + col * 2);
+            const unsigned xaddr =
+                (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(Xs + row * XROW_F16 + col * 2);
 #define S1_READ(kh_)                                                                          \
     do {                                                                                      \
         _Pragma("unroll") for (int tb = 0; tb < 4; ++tb) a[kh_][tb] =                         \
@@ -463,37 +389,6 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
             S1_MMA(1);
 #undef S1_READ
 #undef S1_MMA
-#else
-        if (MODE == PP_MATCH_FAST) {
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                h8 a[4], bf[2];
-#pragma unroll
-                for (int tb = 0; tb < 4; ++tb)
-                    a[tb] = *(const h8*)(Qs + (kh * 8 + wr * 4 + tb) * 1024 + lane * 16);
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb) {
-                    const int col = wc * 64 + sb * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-                    const int row = kh * 16 + 8 * lh + ((lane & 15) >> 2);
-                    const char* p = Xs + row * XROW_F16 + col * 2;
-                    fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                        (__attribute__((address_space(3))) fp16x4_t*)(p));
-                    fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                        (__attribute__((address_space(3))) fp16x4_t*)(p + 4 * XROW_F16));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        bf[sb][e] = (_Float16)lo[e];
-                        bf[sb][4 + e] = (_Float16)hi[e];
-                    }
-                }
-#pragma unroll
-                for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-                    for (int sb = 0; sb < 2; ++sb)
-                        acc[tb][sb] =
-                            __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tb], bf[sb], acc[tb][sb], 0, 0, 0);
-            }
-#endif
         } else {
             const float* Xf = (const float*)Xs;
             const float* Qf = (const float*)Qs;
@@ -517,177 +412,179 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
         }
     };
 
-    // ---- K loop: both operands prefetched two K-steps ahead in registers, LDS double buffer,
-    //      one barrier per K-step.  KT is even (C % 64 == 0).
-#if PP_S1_QDMA
-    // The first iteration (ks = -3) only issues loads — Q(-1) (out of bounds: zeros), X(0), Q(0), X(1), Q(1), X(2)
-    // — so each tile register has ONE defining load (no copies of in-flight registers at the back edge) and
-    // the issue order is the steady state's from the start.  Steps past KT multiply zero tiles.
-    int ks_first = -3;
-    asm volatile("" : "+s"(ks_first));  // opaque: hipcc must not peel the load-only iteration
+    int ct = -3;
+    asm volatile("" : "+s"(ct));  // opaque: hipcc must not peel the load-only iteration
 #pragma clang loop unroll(disable)
-    for (int ks = ks_first; ks < KT; ks += 3) {
-        STEP(ks, x0, 0, 2);
-        STEP(ks + 1, x1, 1, 0);
-        STEP(ks + 2, x2, 2, 1);
+    for (;;) {
+        if (ct == KT3) {
+            // ------------------------------------------------------------ epilogue of item (b, n, half)
+            const size_t bn = (size_t)b * N + n;
+            float* T = (float*)(smem + EPI_T);
+            float* red = (float*)(smem + EPI_RED);
+            float* colp = (float*)(smem + EPI_COLP);
+            float* sim0 = (float*)(smem + EPI_SIM0);
+            float* st0 = (float*)(smem + EPI_ST0);
+
+            // 1. column norms -> 1/max(||x_s||, 1e-12)   (F.normalize, matching.py:43): partial sums through
+            //    LDS (the barrier also tells that every wave is past its last tile reads), then every thread
+            //    adds up the partials of its own two columns in a fixed order
+            if (MODE == PP_MATCH_FAST) {
+                *(f4*)(red + (2 * w + lh) * 128 + 4 * l31) = f4{ssq0, ssq1, ssq2, ssq3};
+            } else {
+                const float s0 = ssq0 + __shfl_xor(ssq0, 32);
+                const float s1 = ssq1 + __shfl_xor(ssq1, 32);
+                if (wr == 0 && lh == 0) {
+                    red[wc * 64 + l31] = s0;
+                    red[wc * 64 + 32 + l31] = s1;
+                }
+            }
+            LDS_BARRIER();
+
+            // 2. scale columns, 3. column maxima over this wave's 128 rows, row t = 0 excluded
+            //    (i2[s] != 0  <=>  max_{t>0} sim[t,s] > sim[0,s]); row 0 is tb 0, register 0, lanes 0..31
+            float cm[2];
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                const int col = wc * 64 + sb * 32 + l31;
+                float ss;
+                if (MODE == PP_MATCH_FAST) {
+                    ss = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ss += red[i * 128 + col];
+                } else {
+                    ss = red[col];
+                }
+                const float r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+                float m = -INFINITY;
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        acc[tb][sb][e] *= r;
+                        if (tb != 0 || e != 0) m = fmaxf(m, acc[tb][sb][e]);
+                    }
+                if (!(wr == 0 && lh == 0)) m = fmaxf(m, acc[0][sb][0]);
+                cm[sb] = fmaxf(m, __shfl_xor(m, 32));
+            }
+            if (lh == 0) {
+                colp[wr * 128 + wc * 64 + l31] = cm[0];
+                colp[wr * 128 + wc * 64 + 32 + l31] = cm[1];
+                if (wr == 0) {
+                    sim0[wc * 64 + l31] = acc[0][0][0];
+                    sim0[wc * 64 + 32 + l31] = acc[0][1][0];
+                }
+            }
+
+            // 4. row maxima over this workgroup's 128 columns, column s = 0 excluded
+            //    (i1[t] != 0  <=>  max_{s>0} sim[t,s] > sim[t,0]).
+            //    In registers: max over the two column blocks, then a two-step reduce-scatter over
+            //    the lane quad (DPP): afterwards lane q of a quad owns rows 4i+q and each value is the
+            //    max of 8 columns {c..c+3, c+32..c+35}, c = 4*(lane column / 4).  The 16 "entries" of
+            //    a row (8 per wave column) are transposed through LDS and scanned by one thread.
+            //    The waves holding template patch 0 (half 0, wave column 0: lanes 0 and 32, sb 0) first save
+            //    that column (sim[t,0]) and then take it out of the maxima.
+            if (half == 0 && wc == 0) {
+                if (l31 == 0) {
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4)  // rows tb*32 + 8*e4 + 4*lh + (0..3)
+                            *(f4*)(st0 + wr * 128 + tb * 32 + 8 * e4 + 4 * lh) =
+                                f4{acc[tb][0][4 * e4], acc[tb][0][4 * e4 + 1], acc[tb][0][4 * e4 + 2],
+                                   acc[tb][0][4 * e4 + 3]};
+                }
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[tb][0][e] = l31 == 0 ? -INFINITY : acc[tb][0][e];
+            }
+            {
+                const bool odd = lane & 1, bit1 = (lane >> 1) & 1;
+                const int q = lane & 3;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {  // rows r = 4i..4i+3  (r = tb*16 + e)
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = 4 * i + k, tb = r >> 4, e = r & 15;
+                        v[k] = fmaxf(acc[tb][0][e], acc[tb][1][e]);
+                    }
+                    const float u0 = fmaxf(odd ? v[1] : v[0], dpp_xor1(odd ? v[0] : v[1]));  // row 4i + odd
+                    const float u1 = fmaxf(odd ? v[3] : v[2], dpp_xor1(odd ? v[2] : v[3]));  // row 4i+2+odd
+                    const float wv = fmaxf(bit1 ? u1 : u0, dpp_xor2(bit1 ? u0 : u1));        // row 4i + q
+                    // row r = 4i+q: tb = i>>2, e = 4*(i&3)+q -> t_local = tb*32 + (e&3) + 8*(e>>2) + 4*lh
+                    const int tl = (i >> 2) * 32 + q + 8 * (i & 3) + 4 * lh;
+                    T[(w * 128 + tl) * TROW + (l31 >> 2)] = wv;
+                }
+            }
+            LDS_BARRIER();
+            {
+                // Row record over this half's 16 entries:
+                //   .x best entry   .y second best entry   .z first column of the best entry (int bits)
+                const int wrr = tid >> 7, tl = tid & 127;
+                const float* r0 = T + ((2 * wrr) * 128 + tl) * TROW;
+                const float* r1 = T + ((2 * wrr + 1) * 128 + tl) * TROW;
+                float a1 = -INFINITY, a2 = -INFINITY;
+                int p1 = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f4 u = *(const f4*)((i < 2 ? r0 : r1) + 4 * (i & 1));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float val = u[e];
+                        a2 = fmaxf(a2, fminf(a1, val));
+                        p1 = val > a1 ? 4 * i + e : p1;
+                        a1 = fmaxf(a1, val);
+                    }
+                }
+                const int scol = half * 128 + (p1 >> 3) * 64 + 4 * (p1 & 7);
+                rowrec[(bn * 2 + half) * P + tid] = make_float4(a1, a2, __int_as_float(scol), 0.f);
+            }
+            if (tid < 128) {
+                colmax[bn * P + half * 128 + tid] = fmaxf(colp[tid], colp[128 + tid]);
+                sim0s[bn * P + half * 128 + tid] = sim0[tid];
+            }
+            if (half == 0) simt0[bn * P + tid] = st0[tid];
+
+            // ---- next item (its first tiles are already in flight)
+            v_cur = v_nxt;
+            if (v_cur >= total) break;
+            s1_item(v_cur, N, b, n, half);
+            v_nxt = v_cur + G;
+            {
+                int b2, n2, h2;
+                const bool ok = v_nxt < total;
+                s1_item(ok ? v_nxt : v_cur, N, b2, n2, h2);
+                XdN = X_DESC(b2, n2, h2, ok);
+                QdN = Q_DESC(b2, ok);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            ssq0 = ssq1 = ssq2 = ssq3 = 0.f;
+            ct = 0;
+            // Stores and loads retire in no fixed order relative to each other, so the counted waits of the
+            // K loop need the epilogue's stores out of the way (the builtin keeps hipcc's own count in step).
+            // No barrier here: the next step writes X buffer 0 only, and its own barrier comes before anything
+            // touches ring slot 2 / X buffer 1 (the transpose tile) or the small arrays again.
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        }
+        STEP(ct, x0, 0, 2);
+        STEP(ct + 1, x1, 1, 0);
+        STEP(ct + 2, x2, 2, 1);
+        ct += 3;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS
-#undef LOAD_XB
-#undef DMA_Q
-#undef STORE_X
-#else
-    LOAD_X(0, x0);
-    LOAD_Q(0, q0);
-    LOAD_X(1, x1);
-#if PP_S1_QDEPTH == 2
-    LOAD_Q(1, q1);
-#endif
-    for (int ks = 0; ks < KT; ks += 2) {
-        STEP(ks, x0, q0, Xs0, Qs0);
-        STEP(ks + 1, x1, q1, Xs1, Qs1);
-    }
-#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS at exit
 #undef STEP
-#undef LOAD_X
-#if !PP_S1_QDMA
-#undef LOAD_Q
-#undef STORE_STEP
-#endif
-    __syncthreads();
-#if PP_S1_EPI == 1
-    {
-        float tsum = ssq0 + ssq1 + ssq2 + ssq3;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tsum += acc[i][j][r];
-        simt0[bn * P + tid] = tsum;
-        return;
-    }
-#endif
-
-    // ---------------------------------------------------------------- epilogue
-    float* T = (float*)smem;
-    float* red = (float*)(smem + EPI_RED);
-    float* rs = (float*)(smem + EPI_RS);
-    float* colp = (float*)(smem + EPI_COLP);
-    float* sim0 = (float*)(smem + EPI_SIM0);
-    float* st0 = (float*)(smem + EPI_ST0);
-
-    // 1. column norms -> 1/max(||x_s||, 1e-12)   (F.normalize, matching.py:43)
-    if (MODE == PP_MATCH_FAST) {
-        *(f4*)(red + (2 * w + lh) * 128 + 4 * l31) = f4{ssq0, ssq1, ssq2, ssq3};
-    } else {
-        const float s0 = ssq0 + __shfl_xor(ssq0, 32);
-        const float s1 = ssq1 + __shfl_xor(ssq1, 32);
-        if (wr == 0 && lh == 0) {
-            red[wc * 64 + l31] = s0;
-            red[wc * 64 + 32 + l31] = s1;
-        }
-    }
-    __syncthreads();
-    if (tid < 128) {
-        float s;
-        if (MODE == PP_MATCH_FAST) {
-            s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s += red[i * 128 + tid];
-        } else {
-            s = red[tid];
-        }
-        rs[tid] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
-    }
-    __syncthreads();
-
-    // 2. scale columns, 3. column maxima over this wave's 128 rows, row t = 0 excluded
-    //    (i2[s] != 0  <=>  max_{t>0} sim[t,s] > sim[0,s]); row 0 is tb 0, register 0, lanes 0..31
-    float cm[2];
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-        const float r = rs[wc * 64 + sb * 32 + l31];
-        float m = -INFINITY;
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                acc[tb][sb][e] *= r;
-                if (tb != 0 || e != 0) m = fmaxf(m, acc[tb][sb][e]);
-            }
-        if (!(wr == 0 && lh == 0)) m = fmaxf(m, acc[0][sb][0]);
-        cm[sb] = fmaxf(m, __shfl_xor(m, 32));
-    }
-    if (lh == 0) {
-        colp[wr * 128 + wc * 64 + l31] = cm[0];
-        colp[wr * 128 + wc * 64 + 32 + l31] = cm[1];
-        if (wr == 0) {
-            sim0[wc * 64 + l31] = acc[0][0][0];
-            sim0[wc * 64 + 32 + l31] = acc[0][1][0];
-        }
-    }
-
-    // 4. row maxima over this workgroup's 128 columns, column s = 0 excluded
-    //    (i1[t] != 0  <=>  max_{s>0} sim[t,s] > sim[t,0]).
-    //    In registers: max over the two column blocks, then a two-step reduce-scatter over
-    //    the lane quad (DPP): afterwards lane q of a quad owns rows 4i+q and each value is the
-    //    max of 8 columns {c..c+3, c+32..c+35}, c = 4*(lane column / 4).  The 16 "entries" of
-    //    a row (8 per wave column) are transposed through LDS and scanned by one thread.
-    const bool zlane = (half == 0 && wc == 0 && l31 == 0);  // holds column s = 0 in sb 0
-    if (wc == 0 && l31 == 0) {
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                st0[wr * 128 + tb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh] = acc[tb][0][e];
-    }
-    {
-        const bool odd = lane & 1, bit1 = (lane >> 1) & 1;
-        const int q = lane & 3;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {  // rows r = 4i..4i+3  (r = tb*16 + e)
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = 4 * i + k, tb = r >> 4, e = r & 15;
-                v[k] = zlane ? acc[tb][1][e] : fmaxf(acc[tb][0][e], acc[tb][1][e]);
-            }
-            const float u0 = fmaxf(odd ? v[1] : v[0], dpp_xor1(odd ? v[0] : v[1]));  // row 4i + odd
-            const float u1 = fmaxf(odd ? v[3] : v[2], dpp_xor1(odd ? v[2] : v[3]));  // row 4i+2+odd
-            const float wv = fmaxf(bit1 ? u1 : u0, dpp_xor2(bit1 ? u0 : u1));        // row 4i + q
-            // row r = 4i+q: tb = i>>2, e = 4*(i&3)+q -> t_local = tb*32 + (e&3) + 8*(e>>2) + 4*lh
-            const int tl = (i >> 2) * 32 + q + 8 * (i & 3) + 4 * lh;
-            T[(w * 128 + tl) * TROW + (l31 >> 2)] = wv;
-        }
-    }
-    __syncthreads();
-    {
-        // Row record over this half's 16 entries:
-        //   .x best entry   .y second best entry   .z first column of the best entry (int bits)
-        const int wrr = tid >> 7, tl = tid & 127;
-        const float* r0 = T + ((2 * wrr) * 128 + tl) * TROW;
-        const float* r1 = T + ((2 * wrr + 1) * 128 + tl) * TROW;
-        float a1 = -INFINITY, a2 = -INFINITY;
-        int p1 = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f4 u = *(const f4*)((i < 2 ? r0 : r1) + 4 * (i & 1));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float val = u[e];
-                a2 = fmaxf(a2, fminf(a1, val));
-                p1 = val > a1 ? 4 * i + e : p1;
-                a1 = fmaxf(a1, val);
-            }
-        }
-        const int scol = half * 128 + (p1 >> 3) * 64 + 4 * (p1 & 7);
-        rowrec[(bn * 2 + half) * P + tid] = make_float4(a1, a2, __int_as_float(scol), 0.f);
-    }
-    if (tid < 128) {
-        colmax[bn * P + half * 128 + tid] = fmaxf(colp[tid], colp[128 + tid]);
-        sim0s[bn * P + half * 128 + tid] = sim0[tid];
-    }
-    if (half == 0) simt0[bn * P + tid] = st0[tid];
+#undef LDS_BARRIER
+#undef STORE_X
+#undef DMA_Q
+#undef LOAD_XB
+#undef X_DESC
+#undef Q_DESC
 }
 
 // ---------------------------------------------------------------------------
@@ -957,8 +854,14 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask, i
                        w.denom, w.m16);
     hipLaunchKernelGGL(s1_qpack, dim3(B, C / 32), dim3(256), 0, stream, query, w.denom, w.m16, C,
                        w.qh, w.qf);
-    const int grid = (B >= 8) ? 8 * ((B + 7) / 8) * 2 * N : B * 2 * N;
-#if PP_S1_QDMA
+    // persistent workgroups, two per CU
+    const int total = B * 2 * N;
+    static const int slots = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 2 * cus;
+    }();
+    const int grid = total < slots ? total : slots;
     static const bool lds_ok = [] {  // > 64 KB of dynamic LDS needs the opt-in
         return hipFuncSetAttribute((const void*)s1_main<PP_MATCH_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    SMEM_BYTES) == hipSuccess &&
@@ -966,15 +869,14 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask, i
                                    SMEM_BYTES) == hipSuccess;
     }();
     if (!lds_ok) return PP_ELAUNCH;
-#endif
     {
         PpProfScope prof(stream);  // roofline kernel of stage 1 (bench.py)
         if (mode == PP_MATCH_FAST)
             hipLaunchKernelGGL(s1_main<PP_MATCH_FAST>, dim3(grid), dim3(256), SMEM_BYTES, stream,
-                               bank, w.qh, w.qf, B, N, C, w.rowrec, w.simt0, w.colmax, w.sim0s);
+                               bank, w.qh, w.qf, N, C, total, w.rowrec, w.simt0, w.colmax, w.sim0s);
         else
             hipLaunchKernelGGL(s1_main<PP_MATCH_EXACT>, dim3(grid), dim3(256), SMEM_BYTES, stream,
-                               bank, w.qh, w.qf, B, N, C, w.rowrec, w.simt0, w.colmax, w.sim0s);
+                               bank, w.qh, w.qf, N, C, total, w.rowrec, w.simt0, w.colmax, w.sim0s);
     }
     if (stats) PP_CHECK_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(int32_t), stream));
     hipLaunchKernelGGL(s1_resolve, dim3(B * N), dim3(256), (size_t)10 * C * sizeof(float), stream,

@@ -2,6 +2,7 @@
 // parallelism: NB 16-byte loads per thread per batch, DEPTH batches in flight, WGs/CU capped by LDS.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f4 __attribute__((ext_vector_type(4)));
 template <int NB, int DEPTH>
 __global__ __launch_bounds__(256) void probe(const float* __restrict__ bank, int C, float* out) {
@@ -30,7 +31,45 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ bank, int
     }
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = smem[0];
 }
-int main() {
+// the same stream with the stage-1 kernel's per-step synchronisation: optional barrier per batch (all 4 waves
+// advance together) and optional fp16 conversion + LDS write of the batch
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+template <int NB, int DEPTH, bool BAR, bool LDSW>
+__global__ __launch_bounds__(256) void probe2(const float* __restrict__ bank, int C, float* out) {
+    extern __shared__ char smem[];
+    const int item = blockIdx.x, half = item & 1;
+    const size_t bn = item >> 1;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    const float* xp = bank + bn * (size_t)C * 256 + half * 128 + (size_t)(2 * w + lh) * 256 + 4 * l31;
+    f4 acc = {0, 0, 0, 0};
+    f4 v[DEPTH][NB];
+    const int steps = C / (8 * NB);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) v[d][j] = *(const f4*)(xp + (size_t)((d * NB + j) * 8) * 256);
+    for (int s = 0; s < steps; s += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                acc += v[d][j];
+                if (LDSW) {
+                    h4 hv = {(_Float16)v[d][j].x, (_Float16)v[d][j].y, (_Float16)v[d][j].z, (_Float16)v[d][j].w};
+                    *(h4*)(smem + ((s + d) & 1) * 10240 + (8 * j + 2 * w + lh) * 320 + 8 * l31) = hv;
+                }
+            }
+            if (BAR) __syncthreads();
+            const int ns = s + d + DEPTH;
+            const int cs = ns < steps ? ns : 0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) v[d][j] = *(const f4*)(xp + (size_t)((cs * NB + j) * 8) * 256);
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = smem[0];
+}
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 10;  // e.g. 5000: sustained (power-limited) rate
     const int BN = 32 * 162, C = 768;
     const size_t n = (size_t)BN * C * 256;
     float *bank, *out;
@@ -44,7 +83,7 @@ int main() {
         for (int i = 0; i < 3; ++i) launch();
         (void)hipDeviceSynchronize();
         float tot = 0;
-        for (int r = 0; r < 10; ++r) {
+        for (int r = 0; r < reps; ++r) {
             (void)hipEventRecord(e0);
             launch();
             (void)hipEventRecord(e1);
@@ -53,7 +92,7 @@ int main() {
             (void)hipEventElapsedTime(&ms, e0, e1);
             tot += ms;
         }
-        printf("%-44s avg %.3f ms -> %.0f GB/s\n", name, tot / 10, n * 4 / (tot / 10) / 1e6);
+        printf("%-44s avg %.3f ms -> %.0f GB/s\n", name, tot / reps, n * 4 / (tot / reps) / 1e6);
     };
 #define RUN(NB, D, LDS, label) time(label, [&] { hipLaunchKernelGGL((probe<NB, D>), dim3(BN * 2), dim3(256), LDS, 0, bank, C, out); })
     // 2 WGs/CU (LDS 70 KB each), as the stage-1 kernel
@@ -65,5 +104,10 @@ int main() {
     RUN(4, 2, 50 * 1024, "3 WG/CU, 16 KB x2 per WG (96 KB/CU)");
     RUN(4, 2, 36 * 1024, "4 WG/CU, 16 KB x2 per WG (128 KB/CU)");
     RUN(4, 2, 0, "8 WG/CU, 16 KB x2 per WG (256 KB/CU)");
+#define RUN2(D, BAR, LDSW, label) time(label, [&] { hipLaunchKernelGGL((probe2<4, D, BAR, LDSW>), dim3(BN * 2), dim3(256), 70 * 1024, 0, bank, C, out); })
+    RUN2(3, true, false, "2 WG/CU, 16 KB x3, barrier per step");
+    RUN2(3, false, true, "2 WG/CU, 16 KB x3, f16 LDS write");
+    RUN2(3, true, true, "2 WG/CU, 16 KB x3, barrier + LDS write");
+    RUN2(2, true, true, "2 WG/CU, 16 KB x2, barrier + LDS write");
     return 0;
 }
