@@ -135,3 +135,47 @@ def test_golden_fixtures_from_the_reference(mode, golden_dir):
             assert np.count_nonzero(gs) == 0
             continue  # all scores tie at 0: torch's tie order is unspecified, ours is lowest-id-first
         assert np.array_equal(gi, c["index"]), name
+
+
+@gpu
+def test_full_size_b32_n162_c768_properties():
+    """BASELINE configs[2] stage-1 shape (4.1 GB bank, 10368 work items over 512 persistent workgroups):
+    oracle on a sample of crops, fast == exact decisions, and two size-independent properties —
+    template permutation equivariance and invariance to positive per-column scaling of the bank
+    (matching.py:43 normalises every template patch)."""
+    from picopose_amd.utils import matching as hm
+
+    B, N, C = 32, 162, 768
+    g = torch.Generator(device="cuda").manual_seed(5)
+    bank = torch.randn(B, N, C, 16, 16, device="cuda", generator=g)
+    query = torch.randn(B, C, 16, 16, device="cuda", generator=g)
+    yy, xx = torch.meshgrid(torch.arange(224.0), torch.arange(224.0), indexing="ij")
+    disk = (((yy - 111.5) ** 2 + (xx - 111.5) ** 2) < (0.4 * 224) ** 2).float()
+    m = disk[None].repeat(B, 1, 1).cuda()
+
+    fast = hm.template_scores(bank, query, m, mode="fast")
+    exact = hm.template_scores(bank, query, m, mode="exact")
+    # exact mode vs the CPU oracle on three crops (first, middle, last: every region of the item walk)
+    for b in (0, 17, 31):
+        ref = om.template_scores(bank[b:b + 1].cpu(), query[b:b + 1].cpu(), m[b:b + 1].cpu())
+        margin = om.decision_margins(bank[b:b + 1].cpu(), query[b:b + 1].cpu(), m[b:b + 1].cpu())
+        safe = margin > 1e-5
+        assert safe.float().mean() > 0.9
+        assert (exact[b:b + 1].cpu() - ref).abs()[safe].max().item() <= 2e-6
+        assert (fast[b:b + 1].cpu() - ref).abs()[safe].max().item() <= 1e-5
+    # fast mode takes the same discrete decisions as exact mode: scores differ by rounding only
+    assert (fast - exact).abs().max().item() <= 1e-5
+    # (on random features the 162 scores of a crop lie within ~1e-3 of each other, so the top-5 ORDER may differ
+    # between the modes where two scores are within the rounding error; the top-5 score values may not)
+    assert (hm.topk_templates(fast, 5)[0] - hm.topk_templates(exact, 5)[0]).abs().max().item() <= 1e-5
+
+    # permutation of the template axis permutes the scores (bit-exact: same per-template arithmetic)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(6)).cuda()
+    fast_p = hm.template_scores(bank[:, perm].contiguous(), query, m, mode="fast")
+    assert torch.equal(fast_p, fast[:, perm])
+    del fast_p
+    # positive per-patch scaling by powers of two leaves every normalised column unchanged
+    scale = torch.tensor([0.5, 1.0, 2.0, 4.0], device="cuda")[torch.randint(0, 4, (B, N, 1, 16, 16), device="cuda", generator=g)]
+    bank.mul_(scale)
+    exact_s = hm.template_scores(bank, query, m, mode="exact")
+    assert (exact_s - exact).abs().max().item() <= 2e-6
