@@ -346,7 +346,7 @@ def main():
                 g_traffic = json.load(open(pmc_step)).get("gemm_f16x3_hbm_bytes_per_step")
             line["roofline"] = {
                 "bound": "mfma",
-                "kernel": "gemm_f16x3s_kernel (GEMM / implicit-im2col conv, both operands pre-split into 2 fp16 planes; "
+                "kernel": "pp_gemm f16x3 family: pp_gemm_f16x3{q,p,g}_kernel + gemm_f16x3s_kernel (GEMM / implicit-im2col conv, both operands pre-split into 2 fp16 planes; "
                           "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)" if a.mode == "fast" else
                           "gemm_kernel (v_mfma_f32_32x32x2_f32)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
