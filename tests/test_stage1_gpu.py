@@ -179,3 +179,36 @@ def test_full_size_b32_n162_c768_properties():
     bank.mul_(scale)
     exact_s = hm.template_scores(bank, query, m, mode="exact")
     assert (exact_s - exact).abs().max().item() <= 2e-6
+
+
+@gpu
+def test_max_size_b64_n512_c1024_indexing():
+    """BASELINE configs[4] stage-1 shape on one GPU (34 GB bank, 65536 work items): byte offsets beyond 32 bits.
+    The score of a (crop, template) pair depends on that pair only, so the oracle runs on a sample of pairs
+    taken from the corners of the bank."""
+    from picopose_amd.utils import matching as hm
+
+    B, N, C = 64, 512, 1024
+    free, _ = torch.cuda.mem_get_info()
+    if free < 48 << 30:
+        pytest.skip("needs 48 GB of free HBM")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    bank = torch.empty(B, N, C, 16, 16, device="cuda")
+    for b in range(B):  # fill crop by crop: a one-shot randn of 34 GB would need a second 34 GB of temporaries
+        bank[b].normal_(generator=g)
+    query = torch.randn(B, C, 16, 16, device="cuda", generator=g)
+    m = (torch.rand(B, 224, 224, device="cuda", generator=g) < 0.7).float()
+    fast = hm.template_scores(bank, query, m, mode="fast")
+    assert torch.isfinite(fast).all()
+    for b in (0, 33, 63):
+        for n0 in (0, 255, 508):
+            sl = slice(n0, n0 + 4)
+            args = (bank[b:b + 1, sl].cpu(), query[b:b + 1].cpu(), m[b:b + 1].cpu())
+            ref = om.template_scores(*args)
+            safe = om.decision_margins(*args) > 1e-5
+            err = (fast[b:b + 1, sl].cpu() - ref).abs()
+            assert err[safe].max().item() <= 1e-5 if safe.any() else True
+            assert err.max().item() <= 1.0 / 256 + 1e-5
+    score, index = hm.topk_templates(fast, 5)
+    ts, ti = torch.topk(fast, 5, dim=1)
+    assert torch.equal(score, ts)
