@@ -13,15 +13,16 @@
 // registers/LDS:  i1[t] != 0  <=>  max_s sim[t,s] > sim[t,0]   (first max wins
 // ties in torch.max, so a tie with column 0 yields index 0), same for i2.
 //
-// Work decomposition: a work item is all 256 query patches x 128 template patches
-// (one half) of one template; a 256-thread workgroup (4 waves, 2x2) processes it with
-// a 128x64 fp32 tile per wave in 128 accumulator registers.  Workgroups are persistent
-// (two per CU) and walk the items in bank order.  The bank is read exactly once
-// (coalesced 16 B/lane, 512 B row segments, three K-steps ahead in registers, bounded
-// buffer loads); the pre-normalised, pre-masked query operand comes from L2 by LDS-DMA
-// into a 3-slot ring.  The tile stream rolls from one item into the next, so the next
-// item's first tiles are in flight during the epilogue, and the co-resident workgroup
-// overlaps its K loop with it.
+// Work decomposition: a work item is one template against all 256 query patches; a
+// 512-thread workgroup (8 waves: 2 template halves x 2 x 2) processes it with a 128x64
+// fp32 tile per wave in 128 accumulator registers.  Workgroups are persistent (one per
+// CU) and walk the items in bank order.  The bank is read exactly once (coalesced
+// 16 B/lane, 512 B row segments, three K-steps ahead in registers, bounded buffer loads,
+// nt policy); the pre-normalised, pre-masked query operand comes from L2 by LDS-DMA into
+// a 3-slot ring shared by both halves (the copy instructions, not their bytes, are what
+// costs: with 4-wave workgroups on template halves — PP_S1_WAVES=4, two per CU — the
+// kernel issues twice as many and runs 9 % slower).  The tile stream rolls from one item
+// into the next, so the next item's first tiles are in flight during the epilogue.
 //
 // Two arithmetic modes share the skeleton:
 //   EXACT  v_mfma_f32_32x32x2_f32 — bit-for-bit an fp32 fma chain over c.
@@ -32,6 +33,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/picopose_hip.h"
 #include "pp_common.h"
 
@@ -183,18 +185,25 @@ struct Cfg<PP_MATCH_FAST> {
 constexpr int QS = 16384;                         // one query tile: 16 fragment chunks of 1 KB (fast) / [16][256] fp32
 constexpr int Q_RING = 3;
 constexpr int XS_MAX = Cfg<PP_MATCH_FAST>::XS_BYTES;
-constexpr int XS1_OFF = Q_RING * QS;              // K-steps of odd parity
-constexpr int XS0_OFF = XS1_OFF + XS_MAX;         // K-steps of even parity
-constexpr int EPI_T = 2 * QS;                     // float[4 waves][128 rows][TROW]
-constexpr int EPI_T_BYTES = 4 * 128 * TROW * 4;
-constexpr int EPI_RED = XS0_OFF + XS_MAX;         // float[8][128]
-constexpr int EPI_COLP = EPI_RED + 8 * 128 * 4;   // float[2][128]
-constexpr int EPI_SIM0 = EPI_COLP + 2 * 128 * 4;  // float[128]
-constexpr int EPI_ST0 = EPI_SIM0 + 128 * 4;       // float[256]
-constexpr int SMEM_BYTES = EPI_ST0 + 256 * 4;
-static_assert(EPI_T + EPI_T_BYTES <= XS0_OFF, "epilogue transpose tile overlaps X buffer 0");
+// NW = waves per workgroup: 4 (a work item is one half of a template, two workgroups per CU) or 8 (a work item
+// is a whole template — both halves share every query tile, which halves the LDS-DMA copies — one per CU).
+template <int NW>
+struct Lay {
+    static constexpr int HV = NW / 4;                    // template halves per workgroup
+    static constexpr int XS1_OFF = Q_RING * QS;          // X buffers of odd K-steps, one per half
+    static constexpr int T_BYTES = NW * 128 * TROW * 4;  // float[NW waves][128 rows][TROW]
+    static constexpr int T_PAD = T_BYTES > QS + HV * XS_MAX ? T_BYTES - QS - HV * XS_MAX : 0;
+    static constexpr int XS0_OFF = XS1_OFF + HV * XS_MAX + T_PAD;  // X buffers of even K-steps
+    static constexpr int EPI_T = 2 * QS;                 // ring slot 2 + X buffers 1 (+ pad)
+    static constexpr int EPI_RED = XS0_OFF + HV * XS_MAX;          // float[HV][8][128]
+    static constexpr int EPI_COLP = EPI_RED + HV * 8 * 128 * 4;    // float[HV][2][128]
+    static constexpr int EPI_SIM0 = EPI_COLP + HV * 2 * 128 * 4;   // float[HV][128]
+    static constexpr int EPI_ST0 = EPI_SIM0 + HV * 128 * 4;        // float[256]
+    static constexpr int SMEM_BYTES = EPI_ST0 + 256 * 4;
+    static_assert(EPI_T + T_BYTES <= XS0_OFF, "epilogue transpose tile overlaps X buffer 0");
+    static_assert((NW == 4 ? 2 : 1) * SMEM_BYTES <= 160 * 1024, "workgroups per CU");
+};
 static_assert(Cfg<PP_MATCH_EXACT>::XS_BYTES <= XS_MAX, "");
-static_assert(2 * SMEM_BYTES <= 160 * 1024, "two workgroups per CU");
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // max with the value of lane^1 / lane^2 (DPP quad permutes, no LDS traffic)
@@ -208,7 +217,14 @@ __device__ __forceinline__ float dpp_xor2(float v) {
 // Work item v -> (crop, template, half), in bank order: the workgroups resident at any time stream one
 // contiguous window of the bank (measured 4 % faster than keeping each crop on one XCD; the query operand is
 // then cached by every XCD's L2, 393 KB per crop and XCD against 127 MB of bank per crop).
+template <int NW>
 __device__ __forceinline__ void s1_item(int v, int N, int& b, int& n, int& half) {
+    if (NW == 8) {  // whole templates
+        b = v / N;
+        n = v % N;
+        half = 0;
+        return;
+    }
     const int per_crop = 2 * N;
     b = v / per_crop;
     const int r = v % per_crop;
@@ -216,12 +232,13 @@ __device__ __forceinline__ void s1_item(int v, int N, int& b, int& n, int& half)
     half = r & 1;
 }
 
-// Persistent 256-thread workgroups (4 waves, 2x2), two per CU.  A work item = (crop b, template n, half):
-// all 256 query patches x 128 template patches; each wave holds a 128x64 fp32 tile in 128 accumulator
-// registers.  The K loop runs over a tile stream that rolls from one item into the next, so the next
+// Persistent workgroups of NW waves.  NW = 8 (default): a work item = (crop b, template n), waves 0-3 own
+// template patches 0..127 and waves 4-7 patches 128..255, one workgroup per CU.  NW = 4: a work item =
+// (crop, template, half), two workgroups per CU.  Within a half the 4 waves are 2 x 2 over (128 query patches,
+// 64 template patches): each holds a 128x64 fp32 tile in 128 accumulator registers.  The K loop runs over a tile stream that rolls from one item into the next, so the next
 // item's first tiles are in flight while the epilogue of the current one runs.
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank,
+template <int MODE, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float* __restrict__ bank,
                                                   const _Float16* __restrict__ qh,
                                                   const float* __restrict__ qf, int N, int C, int total,
                                                   float4* __restrict__ rowrec,
@@ -229,13 +246,17 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
                                                   float* __restrict__ colmax,
                                                   float* __restrict__ sim0s) {
     using K = Cfg<MODE>;
+    using L = Lay<NW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QELT = MODE == PP_MATCH_FAST ? 2 : 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = NW == 8 ? w8 >> 2 : 0;  // NW == 8: waves 0-3 own template half 0, waves 4-7 half 1
+    const int w = w8 & 3;                  // wave within its half: 2 x 2 over (128 query rows, 64 columns)
     const int wr = w >> 1, wc = w & 1;
+    const int th = tid & 255;              // thread within its half
     const int l31 = lane & 31, lh = lane >> 5;
     const int KT = C / K::KS;
     const int KT3 = (KT + 2) / 3 * 3;  // K-steps per item; steps past KT multiply zero tiles
@@ -245,7 +266,8 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
     int b, n, half;
     int v_cur = blockIdx.x;
     if (v_cur >= total) return;
-    s1_item(v_cur, N, b, n, half);
+    s1_item<NW>(v_cur, N, b, n, half);
+    if (NW == 8) half = hw;
     int v_nxt = v_cur + G;
 
     char* Qring = smem;
@@ -262,17 +284,17 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
     __builtin_amdgcn_make_buffer_rsrc(MODE == PP_MATCH_FAST ? (void*)(qh + (size_t)(b_) * C * P)           \
                                                             : (void*)(qf + (size_t)(b_) * C * P),          \
                                       0, (ok_) ? C * P * QELT : 0, 0x00020000)
-    __amdgpu_buffer_rsrc_t Xd = X_DESC(b, n, half, true), Qd = Q_DESC(b, true);
+    __amdgpu_buffer_rsrc_t Xd = X_DESC(b, n, NW == 8 ? 0 : half, true), Qd = Q_DESC(b, true);
     __amdgpu_buffer_rsrc_t XdN, QdN;
     {
         int b2, n2, h2;
         const bool ok = v_nxt < total;
-        s1_item(ok ? v_nxt : v_cur, N, b2, n2, h2);
+        s1_item<NW>(ok ? v_nxt : v_cur, N, b2, n2, h2);
         XdN = X_DESC(b2, n2, h2, ok);
         QdN = Q_DESC(b2, ok);
     }
     int xt = 0, qt = -1;  // next tile of the stream; the very first query copy is a dummy (out of bounds: zeros)
-    const unsigned xvoff = ((2 * w + lh) * P + 4 * l31) * 4;
+    const unsigned xvoff = ((NW == 8 ? hw * 128 : 0) + (2 * w + lh) * P + 4 * l31) * 4;
     const unsigned qvoff = tid * 16;
 
     f32x16 acc[4][2];
@@ -298,9 +320,9 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
 #define DMA_Q(slot_)                                                                              \
     do {                                                                                          \
         const int qtile = qt < 0 ? KT3 : qt; /* the dummy: a tile past the end */                 \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(   \
-            Qd, (lds_ptr_t)(Qring + (slot_) * QS + (j * 256 + w * 64) * 16), 16, qvoff,           \
-            (qtile * 1024 + j * 256) * 16, 0, 0);                                                 \
+        _Pragma("unroll") for (int j = 0; j < 16 / NW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds( \
+            Qd, (lds_ptr_t)(Qring + (slot_) * QS + (j * NW + w8) * 1024), 16, qvoff,              \
+            (qtile * 1024 + j * NW * 64) * 16, 0, 0);                                             \
         if (++qt == KT3) {                                                                        \
             qt = 0;                                                                               \
             Qd = QdN;                                                                             \
@@ -339,11 +361,14 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
 // edge), which is why the warm-up runs through the same code with the compute parts switched off.
 #define STEP(ct_, x_, qcur_, qnxt_)                                                   \
     do {                                                                              \
-        char* Xs_ = smem + (((ct_)&1) ? XS1_OFF : XS0_OFF);                           \
+        char* Xs_ = smem + (((ct_)&1) ? L::XS1_OFF : L::XS0_OFF) + hw * XS_MAX;       \
         __builtin_amdgcn_sched_barrier(0);                                            \
         if ((ct_) >= 0) {                                                             \
-            if (MODE == PP_MATCH_FAST) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                     \
+            /* 2 X tiles + 1 query tile of this wave may stay in flight */            \
+            if (MODE == PP_MATCH_FAST && NW == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
+            else if (MODE == PP_MATCH_FAST) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); \
+            else if (NW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        \
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                     \
             STORE_X(Xs_, x_);                                                         \
             __builtin_amdgcn_sched_barrier(0); /* x_ consumed before it is reloaded */ \
             LDS_BARRIER();                                                            \
@@ -424,11 +449,11 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
         if (ct == KT3) {
             // ------------------------------------------------------------ epilogue of item (b, n, half)
             const size_t bn = (size_t)b * N + n;
-            float* T = (float*)(smem + EPI_T);
-            float* red = (float*)(smem + EPI_RED);
-            float* colp = (float*)(smem + EPI_COLP);
-            float* sim0 = (float*)(smem + EPI_SIM0);
-            float* st0 = (float*)(smem + EPI_ST0);
+            float* T = (float*)(smem + L::EPI_T);
+            float* red = (float*)(smem + L::EPI_RED) + hw * 8 * 128;
+            float* colp = (float*)(smem + L::EPI_COLP) + hw * 2 * 128;
+            float* sim0 = (float*)(smem + L::EPI_SIM0) + hw * 128;
+            float* st0 = (float*)(smem + L::EPI_ST0);
 
             // 1. column norms -> 1/max(||x_s||, 1e-12)   (F.normalize, matching.py:43): partial sums through
             //    LDS (the barrier also tells that every wave is past its last tile reads), then every thread
@@ -519,16 +544,16 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
                     const float wv = fmaxf(bit1 ? u1 : u0, dpp_xor2(bit1 ? u0 : u1));        // row 4i + q
                     // row r = 4i+q: tb = i>>2, e = 4*(i&3)+q -> t_local = tb*32 + (e&3) + 8*(e>>2) + 4*lh
                     const int tl = (i >> 2) * 32 + q + 8 * (i & 3) + 4 * lh;
-                    T[(w * 128 + tl) * TROW + (l31 >> 2)] = wv;
+                    T[(w8 * 128 + tl) * TROW + (l31 >> 2)] = wv;
                 }
             }
             LDS_BARRIER();
             {
                 // Row record over this half's 16 entries:
                 //   .x best entry   .y second best entry   .z first column of the best entry (int bits)
-                const int wrr = tid >> 7, tl = tid & 127;
-                const float* r0 = T + ((2 * wrr) * 128 + tl) * TROW;
-                const float* r1 = T + ((2 * wrr + 1) * 128 + tl) * TROW;
+                const int wrr = th >> 7, tl = th & 127;
+                const float* r0 = T + ((4 * hw + 2 * wrr) * 128 + tl) * TROW;
+                const float* r1 = T + ((4 * hw + 2 * wrr + 1) * 128 + tl) * TROW;
                 float a1 = -INFINITY, a2 = -INFINITY;
                 int p1 = 0;
 #pragma unroll
@@ -543,23 +568,24 @@ __global__ __launch_bounds__(256, 2) void s1_main(const float* __restrict__ bank
                     }
                 }
                 const int scol = half * 128 + (p1 >> 3) * 64 + 4 * (p1 & 7);
-                rowrec[(bn * 2 + half) * P + tid] = make_float4(a1, a2, __int_as_float(scol), 0.f);
+                rowrec[(bn * 2 + half) * P + th] = make_float4(a1, a2, __int_as_float(scol), 0.f);
             }
-            if (tid < 128) {
-                colmax[bn * P + half * 128 + tid] = fmaxf(colp[tid], colp[128 + tid]);
-                sim0s[bn * P + half * 128 + tid] = sim0[tid];
+            if (th < 128) {
+                colmax[bn * P + half * 128 + th] = fmaxf(colp[th], colp[128 + th]);
+                sim0s[bn * P + half * 128 + th] = sim0[th];
             }
-            if (half == 0) simt0[bn * P + tid] = st0[tid];
+            if (half == 0) simt0[bn * P + th] = st0[th];
 
             // ---- next item (its first tiles are already in flight)
             v_cur = v_nxt;
             if (v_cur >= total) break;
-            s1_item(v_cur, N, b, n, half);
+            s1_item<NW>(v_cur, N, b, n, half);
+            if (NW == 8) half = hw;
             v_nxt = v_cur + G;
             {
                 int b2, n2, h2;
                 const bool ok = v_nxt < total;
-                s1_item(ok ? v_nxt : v_cur, N, b2, n2, h2);
+                s1_item<NW>(ok ? v_nxt : v_cur, N, b2, n2, h2);
                 XdN = X_DESC(b2, n2, h2, ok);
                 QdN = Q_DESC(b2, ok);
             }
@@ -859,29 +885,42 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask, i
                        w.denom, w.m16);
     hipLaunchKernelGGL(s1_qpack, dim3(B, C / 32), dim3(256), 0, stream, query, w.denom, w.m16, C,
                        w.qh, w.qf);
-    // persistent workgroups, two per CU
-    const int total = B * 2 * N;
-    static const int slots = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return 2 * cus;
+    // persistent workgroups: 8 waves / whole templates / one per CU, or (PP_S1_WAVES=4) 4 waves / template
+    // halves / two per CU
+    static const int nw = [] {
+        const char* e = getenv("PP_S1_WAVES");
+        return e && atoi(e) == 4 ? 4 : 8;
     }();
-    const int grid = total < slots ? total : slots;
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
     static const bool lds_ok = [] {  // > 64 KB of dynamic LDS needs the opt-in
-        return hipFuncSetAttribute((const void*)s1_main<PP_MATCH_FAST>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   SMEM_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)s1_main<PP_MATCH_EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   SMEM_BYTES) == hipSuccess;
+        auto set = [](const void* f, int bytes) {
+            return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        };
+        return set((const void*)s1_main<PP_MATCH_FAST, 4>, Lay<4>::SMEM_BYTES) &&
+               set((const void*)s1_main<PP_MATCH_EXACT, 4>, Lay<4>::SMEM_BYTES) &&
+               set((const void*)s1_main<PP_MATCH_FAST, 8>, Lay<8>::SMEM_BYTES) &&
+               set((const void*)s1_main<PP_MATCH_EXACT, 8>, Lay<8>::SMEM_BYTES);
     }();
     if (!lds_ok) return PP_ELAUNCH;
     {
         PpProfScope prof(stream);  // roofline kernel of stage 1 (bench.py)
-        if (mode == PP_MATCH_FAST)
-            hipLaunchKernelGGL(s1_main<PP_MATCH_FAST>, dim3(grid), dim3(256), SMEM_BYTES, stream,
-                               bank, w.qh, w.qf, N, C, total, w.rowrec, w.simt0, w.colmax, w.sim0s);
-        else
-            hipLaunchKernelGGL(s1_main<PP_MATCH_EXACT>, dim3(grid), dim3(256), SMEM_BYTES, stream,
-                               bank, w.qh, w.qf, N, C, total, w.rowrec, w.simt0, w.colmax, w.sim0s);
+        const int total = nw == 8 ? B * N : B * 2 * N, slots = nw == 8 ? cus : 2 * cus;
+        const int grid = total < slots ? total : slots;
+#define S1_LAUNCH(MODE_, NW_)                                                                                  \
+    hipLaunchKernelGGL((s1_main<MODE_, NW_>), dim3(grid), dim3(64 * NW_), Lay<NW_>::SMEM_BYTES, stream, bank, w.qh, \
+                       w.qf, N, C, total, w.rowrec, w.simt0, w.colmax, w.sim0s)
+        if (mode == PP_MATCH_FAST) {
+            if (nw == 8) S1_LAUNCH(PP_MATCH_FAST, 8);
+            else S1_LAUNCH(PP_MATCH_FAST, 4);
+        } else {
+            if (nw == 8) S1_LAUNCH(PP_MATCH_EXACT, 8);
+            else S1_LAUNCH(PP_MATCH_EXACT, 4);
+        }
+#undef S1_LAUNCH
     }
     if (stats) PP_CHECK_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(int32_t), stream));
     hipLaunchKernelGGL(s1_resolve, dim3(B * N), dim3(256), (size_t)10 * C * sizeof(float), stream,
