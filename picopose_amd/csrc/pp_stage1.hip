@@ -887,10 +887,8 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask, i
                        w.qh, w.qf);
     // persistent workgroups: 8 waves / whole templates / one per CU, or (PP_S1_WAVES=4) 4 waves / template
     // halves / two per CU
-    static const int nw = [] {
-        const char* e = getenv("PP_S1_WAVES");
-        return e && atoi(e) == 4 ? 4 : 8;
-    }();
+    const char* nw_env = getenv("PP_S1_WAVES");  // read per call: the tests run both shapes in one process
+    const int nw = nw_env && atoi(nw_env) == 4 ? 4 : 8;
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);

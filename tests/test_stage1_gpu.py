@@ -212,3 +212,20 @@ def test_max_size_b64_n512_c1024_indexing():
     score, index = hm.topk_templates(fast, 5)
     ts, ti = torch.topk(fast, 5, dim=1)
     assert torch.equal(score, ts)
+
+
+@gpu
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_four_wave_workgroup_shape(mode, monkeypatch):
+    """PP_S1_WAVES=4: the half-template work items (two 256-thread workgroups per CU) give the same scores as the
+    default 8-wave workgroups — bit for bit, the per-wave arithmetic is identical — and match the oracle."""
+    from picopose_amd.utils import matching as hm
+
+    for B, N, C in ((9, 40, 768), (3, 7, 1024)):    # 720 half-items > 512 workgroups: the item walk rolls over
+        bank, query, m = _inputs(B, N, C, 31)
+        ref8 = hm.template_scores(bank.cuda(), query.cuda(), m.cuda(), mode=mode)
+        monkeypatch.setenv("PP_S1_WAVES", "4")
+        got4 = hm.template_scores(bank.cuda(), query.cuda(), m.cuda(), mode=mode)
+        monkeypatch.delenv("PP_S1_WAVES")
+        assert torch.equal(got4, ref8)
+    _check(2, 6, 64, seed=5, mode=mode)
