@@ -199,19 +199,47 @@ struct Lay {
     static constexpr int EPI_COLP = EPI_RED + HV * 8 * 128 * 4;    // float[HV][2][128]
     static constexpr int EPI_SIM0 = EPI_COLP + HV * 2 * 128 * 4;   // float[HV][128]
     static constexpr int EPI_ST0 = EPI_SIM0 + HV * 128 * 4;        // float[256]
-    static constexpr int SMEM_BYTES = EPI_ST0 + 256 * 4;
+    // results of up to PARK items wait here and leave in one burst (NW == 8: LDS to spare; NW == 4: registers)
+    static constexpr int PARK = NW == 8 ? 4 : 0;
+    static constexpr int PARK_OFF = EPI_ST0 + 256 * 4;   // per item: float4[HV][256], float[HV][128] x 2, float[256]
+    static constexpr int PARK_ITEM = HV * 256 * 16 + 2 * HV * 128 * 4 + 256 * 4;
+    static constexpr int SMEM_BYTES = PARK_OFF + PARK * PARK_ITEM;
     static_assert(EPI_T + T_BYTES <= XS0_OFF, "epilogue transpose tile overlaps X buffer 0");
     static_assert((NW == 4 ? 2 : 1) * SMEM_BYTES <= 160 * 1024, "workgroups per CU");
 };
 static_assert(Cfg<PP_MATCH_EXACT>::XS_BYTES <= XS_MAX, "");
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// max with the value of lane^1 / lane^2 (DPP quad permutes, no LDS traffic)
-__device__ __forceinline__ float dpp_xor1(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+// Epilogue arithmetic as single instructions.  fmaxf() through hipcc costs up to three (it canonicalises both
+// inputs with v_max x,x first), and update_dpp + fmaxf costs four (zero the destination, v_mov_dpp, canonicalise,
+// max): the epilogue is VALU-bound, so these are inline asm.  NaN handling is v_max_f32's (IEEE mode: a quiet NaN
+// input loses), as before.
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
-__device__ __forceinline__ float dpp_xor2(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// max(own, partner's `src`) with the partner = lane^1 / lane^2 of the quad (DPP, no LDS traffic).  The s_nop
+// covers the 2 wait states a DPP read needs after a VALU write of the same register.
+__device__ __forceinline__ float vmax_xor1(float own, float src) {
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "v"(own));
+    return r;
+}
+__device__ __forceinline__ float vmax_xor2(float own, float src) {
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "v"(own));
+    return r;
 }
 
 // Work item v -> (crop, template, half), in bank order: the workgroups resident at any time stream one
@@ -442,6 +470,45 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
         }
     };
 
+    // Results leave at the START of a later epilogue, not at the end of their own: vmcnt retires in order, a store
+    // is acknowledged only after microseconds under the read stream, and the K loop's counted waits sit behind it.
+    // Issued at the start they retire during the epilogue's arithmetic.  With 8 waves the results of 4 items are
+    // parked in LDS (each thread re-reads only what it wrote) and leave in one burst — the stall is per episode,
+    // not per byte: 791 -> 737 us — with 4 waves (no LDS to spare) one item waits in registers.
+    float4 p_rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    float p_cm = 0.f, p_s0 = 0.f, p_st0 = 0.f;
+    int p_idx = -1;   // NW == 4: (crop * N + template) * 2 + half of the pending results, -1 = none
+    int p_cnt = 0;    // NW == 8: parked items
+    int p_bn0 = 0, p_bn1 = 0, p_bn2 = 0, p_bn3 = 0;  // their crop * N + template
+    char* park = smem + L::PARK_OFF;
+#define PARK_REC(k_) ((float4*)(park + (k_) * L::PARK_ITEM) + hw * 256 + th)
+#define PARK_CM(k_) ((float*)(park + (k_) * L::PARK_ITEM + L::HV * 4096) + hw * 128 + th)
+#define PARK_S0(k_) ((float*)(park + (k_) * L::PARK_ITEM + L::HV * 4096 + L::HV * 512) + hw * 128 + th)
+#define PARK_ST0(k_) ((float*)(park + (k_) * L::PARK_ITEM + L::HV * 4096 + L::HV * 1024) + th)
+#define STORE_ONE(bn_, half_, rec_, cm_, s0_, st0_)                                           \
+    do {                                                                                       \
+        rowrec[((size_t)(bn_) * 2 + (half_)) * P + th] = (rec_);                               \
+        if (th < 128) {                                                                        \
+            colmax[(size_t)(bn_) * P + (half_) * 128 + th] = (cm_);                            \
+            sim0s[(size_t)(bn_) * P + (half_) * 128 + th] = (s0_);                             \
+        }                                                                                      \
+        if ((half_) == 0) simt0[(size_t)(bn_) * P + th] = (st0_);                              \
+    } while (0)
+#define STORE_PENDING(all_)                                                                    \
+    do {                                                                                       \
+        if (NW == 8) {                                                                         \
+            if (p_cnt == L::PARK || ((all_) && p_cnt > 0)) {                                   \
+                _Pragma("unroll") for (int k = 0; k < L::PARK; ++k) if (k < p_cnt) {           \
+                    const int pbn = k == 0 ? p_bn0 : k == 1 ? p_bn1 : k == 2 ? p_bn2 : p_bn3;  \
+                    STORE_ONE(pbn, hw, *PARK_REC(k), *PARK_CM(k), *PARK_S0(k), *PARK_ST0(k));  \
+                }                                                                              \
+                p_cnt = 0;                                                                     \
+            }                                                                                  \
+        } else if (p_idx >= 0) {                                                               \
+            STORE_ONE(p_idx >> 1, p_idx & 1, p_rec, p_cm, p_s0, p_st0);                        \
+        }                                                                                      \
+    } while (0)
+
     int ct = -3;
     asm volatile("" : "+s"(ct));  // opaque: hipcc must not peel the load-only iteration
 #pragma clang loop unroll(disable)
@@ -454,6 +521,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
             float* colp = (float*)(smem + L::EPI_COLP) + hw * 2 * 128;
             float* sim0 = (float*)(smem + L::EPI_SIM0) + hw * 128;
             float* st0 = (float*)(smem + L::EPI_ST0);
+            STORE_PENDING(false);
 
             // 1. column norms -> 1/max(||x_s||, 1e-12)   (F.normalize, matching.py:43): partial sums through
             //    LDS (the barrier also tells that every wave is past its last tile reads), then every thread
@@ -485,16 +553,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
                     ss = red[col];
                 }
                 const float r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-                float m = -INFINITY;
 #pragma unroll
                 for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        acc[tb][sb][e] *= r;
-                        if (tb != 0 || e != 0) m = fmaxf(m, acc[tb][sb][e]);
-                    }
-                if (!(wr == 0 && lh == 0)) m = fmaxf(m, acc[0][sb][0]);
-                cm[sb] = fmaxf(m, __shfl_xor(m, 32));
+                    for (int e = 0; e < 16; ++e) acc[tb][sb][e] *= r;
+                float m = acc[0][sb][1];  // elements (tb, e) != (0, 0), two per v_max3
+#pragma unroll
+                for (int k = 2; k < 64; k += 2) m = vmax3(m, acc[k >> 4][sb][k & 15], acc[(k + 1) >> 4][sb][(k + 1) & 15]);
+                if (!(wr == 0 && lh == 0)) m = vmax(m, acc[0][sb][0]);
+                cm[sb] = vmax(m, __shfl_xor(m, 32));
             }
             if (lh == 0) {
                 colp[wr * 128 + wc * 64 + l31] = cm[0];
@@ -537,11 +604,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int r = 4 * i + k, tb = r >> 4, e = r & 15;
-                        v[k] = fmaxf(acc[tb][0][e], acc[tb][1][e]);
+                        v[k] = vmax(acc[tb][0][e], acc[tb][1][e]);
                     }
-                    const float u0 = fmaxf(odd ? v[1] : v[0], dpp_xor1(odd ? v[0] : v[1]));  // row 4i + odd
-                    const float u1 = fmaxf(odd ? v[3] : v[2], dpp_xor1(odd ? v[2] : v[3]));  // row 4i+2+odd
-                    const float wv = fmaxf(bit1 ? u1 : u0, dpp_xor2(bit1 ? u0 : u1));        // row 4i + q
+                    const float u0 = vmax_xor1(odd ? v[1] : v[0], odd ? v[0] : v[1]);  // row 4i + odd
+                    const float u1 = vmax_xor1(odd ? v[3] : v[2], odd ? v[2] : v[3]);  // row 4i+2+odd
+                    const float wv = vmax_xor2(bit1 ? u1 : u0, bit1 ? u0 : u1);        // row 4i + q
                     // row r = 4i+q: tb = i>>2, e = 4*(i&3)+q -> t_local = tb*32 + (e&3) + 8*(e>>2) + 4*lh
                     const int tl = (i >> 2) * 32 + q + 8 * (i & 3) + 4 * lh;
                     T[(w8 * 128 + tl) * TROW + (l31 >> 2)] = wv;
@@ -562,19 +629,38 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float val = u[e];
-                        a2 = fmaxf(a2, fminf(a1, val));
+                        a2 = vmax(a2, vmin(a1, val));
                         p1 = val > a1 ? 4 * i + e : p1;
-                        a1 = fmaxf(a1, val);
+                        a1 = vmax(a1, val);
                     }
                 }
                 const int scol = half * 128 + (p1 >> 3) * 64 + 4 * (p1 & 7);
-                rowrec[(bn * 2 + half) * P + th] = make_float4(a1, a2, __int_as_float(scol), 0.f);
+                p_rec = make_float4(a1, a2, __int_as_float(scol), 0.f);
             }
             if (th < 128) {
-                colmax[bn * P + half * 128 + th] = fmaxf(colp[th], colp[128 + th]);
-                sim0s[bn * P + half * 128 + th] = sim0[th];
+                p_cm = vmax(colp[th], colp[128 + th]);
+                p_s0 = sim0[th];
             }
-            if (half == 0) simt0[bn * P + th] = st0[th];
+            if (half == 0) p_st0 = st0[th];
+            if (NW == 8) {  // park (thread-private slots: no barrier between these writes and the burst's reads)
+#pragma unroll
+                for (int k = 0; k < L::PARK; ++k)
+                    if (k == p_cnt) {
+                        *PARK_REC(k) = p_rec;
+                        if (th < 128) {
+                            *PARK_CM(k) = p_cm;
+                            *PARK_S0(k) = p_s0;
+                        }
+                        if (half == 0) *PARK_ST0(k) = p_st0;
+                    }
+                p_bn0 = p_cnt == 0 ? (int)bn : p_bn0;
+                p_bn1 = p_cnt == 1 ? (int)bn : p_bn1;
+                p_bn2 = p_cnt == 2 ? (int)bn : p_bn2;
+                p_bn3 = p_cnt == 3 ? (int)bn : p_bn3;
+                ++p_cnt;
+            } else {
+                p_idx = (int)(bn * 2 + half);
+            }
 
             // ---- next item (its first tiles are already in flight)
             v_cur = v_nxt;
@@ -608,7 +694,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
         STEP(ct + 2, x2, 2, 1);
         ct += 3;
     }
+    STORE_PENDING(true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS at exit
+#undef STORE_PENDING
+#undef STORE_ONE
+#undef PARK_REC
+#undef PARK_CM
+#undef PARK_S0
+#undef PARK_ST0
 #undef STEP
 #undef LDS_BARRIER
 #undef STORE_X
