@@ -244,9 +244,10 @@ int pp_resize_bilinear_nhwc(const float* in, int B, int H, int W, int C, int Ho,
 /* Same, writing the result only as an hl operand (B*Ho*Wo rows, ld = C, C % 8 == 0) for the convolution that follows. */
 int pp_resize_bilinear_nhwc_hl(const float* in, int B, int H, int W, int C, int Ho, int Wo, float mul, void* out_hl,
                                void* stream);
-/* FlowDecoder.feature_sample (flow_decoder.py:49-56): out[b,p,:] = bilinear(feat[b], p + flow[b,p]),
- * zeros padding, align_corners=True.  flow rows have ld_flow floats (x, y first), out rows ld_out. */
-int pp_warp_nhwc(const float* feat, const float* flow, int B, int H, int W, int C, int ld_flow,
+/* FlowDecoder.feature_sample (flow_decoder.py:49-56): out[b,p,:] = bilinear(feat[b % feat_batch], p + flow[b,p]),
+ * zeros padding, align_corners=True.  flow rows have ld_flow floats (x, y first), out rows ld_out.  feat holds
+ * feat_batch images (= B, or the query maps given once for the B / feat_batch hypotheses of a hypothesis-major batch). */
+int pp_warp_nhwc(const float* feat, int feat_batch, const float* flow, int B, int H, int W, int C, int ld_flow,
                  float* out, int ld_out, void* stream);
 /* nn.AvgPool2d(2,2) on NHWC. */
 int pp_avgpool2_nhwc(const float* in, int B, int H, int W, int C, float* out, void* stream);
@@ -272,11 +273,12 @@ int pp_crop_resize_normalize(const unsigned char* image, int H, int W, const uns
 int pp_depth_points_nearest(const float* depth_m, int H, int W, int y1, int y2, int x1, int x2, int P, float fx, float fy,
                             float cx, float cy, float* out_pts, void* stream);
 /* CorrelationPyramid (raft_decoder.py:30-53) + CorrLookup (corr_lookup.py:100-134) without the
- * (B*HW, HW) volume: f1 (B,H,W,C), f2_l{0,1,2} = f2 and its 2x2 average pools, flow (B,H,W,ld_flow);
+ * (B*HW, HW) volume: f1 (B,H,W,C) with rows of ld_f1 floats, f2_l{0,1,2} = f2 and its 2x2 average pools holding
+ * f2_batch images (image b reads f2[b % f2_batch]), flow (B,H,W,ld_flow);
  * out (B,H,W,ld_out) with channel l*(2r+1)^2 + a*(2r+1) + b = corr_l sampled at x offset a-r,
  * y offset b-r around (p + flow)/2^l. */
-int pp_corr_lookup_nhwc(const float* f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
-                        const float* flow, int B, int H, int W, int C, int levels, int radius,
+int pp_corr_lookup_nhwc(const float* f1, int ld_f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
+                        int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius,
                         int ld_flow, float* out, int ld_out, void* stream);
 
 /* ------------------------------------------------------------------------- *

@@ -95,13 +95,13 @@ def lib():
         L.pp_normalize_rows.argtypes = [vp, i32, i32, f32, vp, vp]
         L.pp_resize_bilinear_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp]
         L.pp_resize_bilinear_nhwc_hl.argtypes = [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp]
-        L.pp_warp_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]
+        L.pp_warp_nhwc.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]
         L.pp_avgpool2_nhwc.argtypes = [vp, i32, i32, i32, i32, vp, vp]
         L.pp_gather_rows.argtypes = [vp, vp, c.c_longlong, c.c_longlong, i32, vp, vp]
         L.pp_depth_points_nearest.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, f32, f32, vp, vp]
         L.pp_crop_resize_normalize.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, c.POINTER(c.c_double),
                                                c.POINTER(c.c_double), vp, vp, vp]
-        L.pp_corr_lookup_nhwc.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
+        L.pp_corr_lookup_nhwc.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
         L.pp_pnp_ransac.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib

@@ -89,9 +89,9 @@ __device__ __forceinline__ float roundtrip(float x, int size) {
 
 // FlowDecoder.feature_sample — flow_decoder.py:49-56: out[p] = bilinear(feat, p + flow[p]), zeros padding.
 // One wave per pixel, lanes over channels (float4).
-__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ feat, const float* __restrict__ flow,
-                                                   int H, int W, int C, int ld_flow, float* __restrict__ out,
-                                                   int ld_out) {
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ feat, int feat_batch,
+                                                   const float* __restrict__ flow, int H, int W, int C, int ld_flow,
+                                                   float* __restrict__ out, int ld_out) {
     const int b = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= H * W) return;
     const int y = p / W, x = p - y * W;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
     const float x0f = floorf(ix), y0f = floorf(iy);
     const int x0 = (int)x0f, y0 = (int)y0f;
     const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix, wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
-    const float* fb = feat + (size_t)b * H * W * C;
+    const float* fb = feat + (size_t)(b % feat_batch) * H * W * C;  // feat given once for several hypotheses
     float* o = out + ((size_t)b * H * W + p) * ld_out;
     const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
     const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__
 // window order).  One wave per pixel: the (2r+2)^2 integer neighbours per level are dotted by
 // one lane each (C sequential fmas, f1[p] broadcast from LDS), then lanes blend the 4 corners.
 constexpr int MAXR = 2, TW = 2 * MAXR + 2, MAXL = 3;
-__global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ f1,
-                                                          const float* __restrict__ f2l0,
+__global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ f1, int ld_f1,
+                                                          int f2_batch, const float* __restrict__ f2l0,
                                                           const float* __restrict__ f2l1,
                                                           const float* __restrict__ f2l2,
                                                           const float* __restrict__ flow, int H, int W, int C,
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
     const int y = live ? p / W : 0, x = live ? p - y * W : 0;
     const int tw = 2 * r + 2, win = 2 * r + 1;
     if (live) {
-        const float* src = f1 + ((size_t)b * H * W + p) * C;
+        const float* src = f1 + ((size_t)b * H * W + p) * ld_f1;
         for (int c = lane * 4; c < C; c += 256) *(f4*)(a + c) = *(const f4*)(src + c);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
             float dot = 0.f;
             if (qx >= 0 && qx < Wl && qy >= 0 && qy < Hl) {
                 const float* f2 = l == 0 ? f2l0 : (l == 1 ? f2l1 : f2l2);
-                const float* q = f2 + (((size_t)b * Hl + qy) * Wl + qx) * C;
+                const float* q = f2 + (((size_t)(b % f2_batch) * Hl + qy) * Wl + qx) * C;
                 for (int c = 0; c < C; c += 4) {
                     const f4 u = *(const f4*)(a + c), v = *(const f4*)(q + c);
                     dot = fmaf(u.x, v.x, dot);
@@ -317,13 +317,13 @@ int pp_resize_bilinear_nhwc_hl(const float* in, int B, int H, int W, int C, int 
     return pp_last_launch();
 }
 
-int pp_warp_nhwc(const float* feat, const float* flow, int B, int H, int W, int C, int ld_flow, float* out,
-                 int ld_out, void* stream) {
-    if (!feat || !flow || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || ld_flow < 2 ||
+int pp_warp_nhwc(const float* feat, int feat_batch, const float* flow, int B, int H, int W, int C, int ld_flow,
+                 float* out, int ld_out, void* stream) {
+    if (!feat || !flow || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || ld_flow < 2 || feat_batch <= 0 ||
         ld_out < C || ld_out % 4 != 0 || ((uintptr_t)out % 16) != 0)
         return PP_EINVAL;
-    hipLaunchKernelGGL(warp_kernel, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, flow, H, W,
-                       C, ld_flow, out, ld_out);
+    hipLaunchKernelGGL(warp_kernel, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, feat_batch, flow,
+                       H, W, C, ld_flow, out, ld_out);
     return pp_last_launch();
 }
 
@@ -335,18 +335,19 @@ int pp_avgpool2_nhwc(const float* in, int B, int H, int W, int C, float* out, vo
     return pp_last_launch();
 }
 
-int pp_corr_lookup_nhwc(const float* f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
-                        const float* flow, int B, int H, int W, int C, int levels, int radius, int ld_flow,
-                        float* out, int ld_out, void* stream) {
+int pp_corr_lookup_nhwc(const float* f1, int ld_f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
+                        int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius,
+                        int ld_flow, float* out, int ld_out, void* stream) {
     if (!f1 || !f2_l0 || !flow || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return PP_EINVAL;
+    if (ld_f1 < C || ld_f1 % 4 != 0 || ((uintptr_t)f1 % 16) != 0 || f2_batch <= 0) return PP_EINVAL;
     if (levels < 1 || levels > MAXL || radius < 1 || radius > MAXR) return PP_EINVAL;
     if ((levels > 1 && !f2_l1) || (levels > 2 && !f2_l2)) return PP_EINVAL;
     if ((H >> (levels - 1)) < 1 || (W >> (levels - 1)) < 1 || ld_flow < 2) return PP_EINVAL;
     const int win = 2 * radius + 1;
     if (ld_out < levels * win * win) return PP_EINVAL;
     const size_t smem = (size_t)4 * (C + MAXL * TW * TW) * sizeof(float);
-    hipLaunchKernelGGL(corr_lookup_kernel, dim3((H * W + 3) / 4, B), dim3(256), smem, (hipStream_t)stream, f1,
-                       f2_l0, f2_l1, f2_l2, flow, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out,
+    hipLaunchKernelGGL(corr_lookup_kernel, dim3((H * W + 3) / 4, B), dim3(256), smem, (hipStream_t)stream, f1, ld_f1,
+                       f2_batch, f2_l0, f2_l1, f2_l2, flow, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out,
                        ld_out);
     return pp_last_launch();
 }

@@ -161,11 +161,11 @@ class FlowDecoder(Packed):
             fr_in, fq_in = feat_render_list[l], feat_real_list[l]
             B, H, W, _ = fr_in.shape
             X = torch.empty(B, H, W, 640, dtype=torch.float32, device=fr_in.device)  # [render | warped real | motion]
+            # query maps given once for all hypotheses (hypothesis-major batch): projected once; the lookup and the
+            # warp read image b % (B / hyp) of them
             fq = ops.conv2d(fq_in, pk[f"proj{l}"], pk[f"proj{l}_b"], 1)
-            if fq.shape[0] != B:   # query maps given once for all hypotheses (hypothesis-major batch): project once, tile
-                fq = fq.repeat(B // fq.shape[0], 1, 1, 1)
             e = self.encoder[l]
-            fr = ops.conv2d(fr_in, pk[f"proj{l}"], pk[f"proj{l}_b"], 1)   # contiguous copy for the lookup
+            fr = ops.conv2d(fr_in, pk[f"proj{l}"], pk[f"proj{l}_b"], 1, out=X[..., 0:256])   # straight into its slice of X
             ncorr = (l + 1) * (2 * self.r + 1) ** 2
             corr = ops.corr_lookup(fr, fq, flow, l + 1, self.r, c_pad=-(-ncorr // 8) * 8)
             # [corr feat 192 | flow feat 64]: on the f16x3 engine the concat exists only as the operand of out_net
@@ -184,7 +184,6 @@ class FlowDecoder(Packed):
             ops.conv2d(f1, pk[f"e{l}_flow1"], getattr(e.flow_net, "1").conv.bias, 3, pad=1, act="relu",
                        **(dict(hl_into=(cf, 192)) if hl_cat else dict(out=cf[..., 192:256])))
             ops.conv2d(cf, pk[f"e{l}_out0"], getattr(e.out_net, "0").conv.bias, 3, pad=1, act="relu", out=X[..., 512:638])
-            X[..., 0:256] = fr
             X[..., 638:640] = flow                                  # cat([out, flow]) (raft_decoder.py:161)
             ops.warp(fq, flow, out=X[..., 256:512])                 # feature_sample (flow_decoder.py:49-56)
             fp, mp = self.flow_pred[l], self.mask_pred[l]

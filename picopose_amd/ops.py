@@ -381,12 +381,15 @@ def resize_bilinear(x, Ho, Wo, mul=1.0, out_split=False):
 
 
 def warp(feat, flow, out=None):
-    """grid_sample warp of NHWC `feat` by NHWC `flow` (B,H,W,>=2 with x,y first); out may be a channel slice."""
-    B, H, W, C = feat.shape
+    """grid_sample warp of NHWC `feat` by NHWC `flow` (B,H,W,>=2 with x,y first); out may be a channel slice.
+    feat may hold B / k images: image b of the (hypothesis-major) batch then samples feat[b % (B / k)]."""
+    B, H, W = flow.shape[:3]
+    Bf, Hf, Wf, C = feat.shape
+    assert (Hf, Wf) == (H, W) and B % Bf == 0
     assert feat.is_contiguous() and flow.stride(3) == 1 and flow.stride(2) * W == flow.stride(1)
     if out is None:
-        out = torch.empty_like(feat)
-    _lib.check(_lib.lib().pp_warp_nhwc(_p(feat), _p(flow), B, H, W, C, flow.stride(2), _p(out), out.stride(2),
+        out = torch.empty(B, H, W, C, dtype=torch.float32, device=feat.device)
+    _lib.check(_lib.lib().pp_warp_nhwc(_p(feat), Bf, _p(flow), B, H, W, C, flow.stride(2), _p(out), out.stride(2),
                                        _lib.stream_ptr()), "pp_warp_nhwc")
     return out
 
@@ -401,18 +404,21 @@ def avgpool2(x):
 
 def corr_lookup(f1, f2, flow, levels, radius, c_pad=None):
     """Correlation pyramid + lookup, NHWC: (B,H,W,C) x2, flow (B,H,W,>=2) -> (B,H,W,levels*(2r+1)^2)
-    (c_pad: channel count of the result, zero-filled beyond the levels*(2r+1)^2 real channels)."""
+    (c_pad: channel count of the result, zero-filled beyond the levels*(2r+1)^2 real channels).
+    f1 may be a channel slice of a wider buffer; f2 may hold B / k images (image b reads f2[b % (B / k)])."""
     B, H, W, C = f1.shape
-    assert f1.is_contiguous() and f2.is_contiguous() and flow.stride(3) == 1
+    assert f2.is_contiguous() and flow.stride(3) == 1 and B % f2.shape[0] == 0 and tuple(f2.shape[1:]) == (H, W, C)
+    assert f1.stride(3) == 1 and f1.stride(1) == W * f1.stride(2) and f1.stride(0) == H * f1.stride(1)
     pyr = [f2]
     for _ in range(levels - 1):
         pyr.append(avgpool2(pyr[-1]))
     n = levels * (2 * radius + 1) ** 2
     np_ = c_pad if c_pad and c_pad > n else n
     out = (torch.zeros if np_ > n else torch.empty)(B, H, W, np_, dtype=torch.float32, device=f1.device)
-    _lib.check(_lib.lib().pp_corr_lookup_nhwc(_p(f1), _p(pyr[0]), _p(pyr[1]) if levels > 1 else None,
-                                              _p(pyr[2]) if levels > 2 else None, _p(flow), B, H, W, C, levels, radius,
-                                              flow.stride(2), _p(out), np_, _lib.stream_ptr()), "pp_corr_lookup_nhwc")
+    _lib.check(_lib.lib().pp_corr_lookup_nhwc(_p(f1), f1.stride(2), _p(pyr[0]), _p(pyr[1]) if levels > 1 else None,
+                                              _p(pyr[2]) if levels > 2 else None, f2.shape[0], _p(flow), B, H, W, C,
+                                              levels, radius, flow.stride(2), _p(out), np_, _lib.stream_ptr()),
+               "pp_corr_lookup_nhwc")
     return out
 
 
