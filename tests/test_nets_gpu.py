@@ -87,6 +87,28 @@ def test_corr_lookup_vs_reference_golden(golden_dir):
 
 
 @gpu
+def test_lookup_and_warp_with_shared_query_maps_and_strided_input():
+    """The hypothesis-major batch keeps the query maps un-tiled (image b reads map b % Bq) and the template map
+    is a channel slice of the decoder input buffer: bit-identical to the tiled / contiguous call."""
+    from picopose_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Bq, hyp, H, W, C = 3, 4, 16, 16, 64
+    B = Bq * hyp
+    f1 = torch.randn(B, H, W, C, device="cuda", generator=g)
+    fq = torch.randn(Bq, H, W, C, device="cuda", generator=g)
+    flow = torch.randn(B, H, W, 2, device="cuda", generator=g) * 3
+    wide = torch.zeros(B, H, W, 160, device="cuda")
+    wide[..., 32:96] = f1
+    ref = ops.corr_lookup(f1, fq.repeat(hyp, 1, 1, 1), flow, 2, 2, c_pad=56)
+    assert torch.equal(ops.corr_lookup(wide[..., 32:96], fq, flow, 2, 2, c_pad=56), ref)
+    assert torch.equal(ops.warp(fq, flow), ops.warp(fq.repeat(hyp, 1, 1, 1), flow))
+    out = torch.zeros(B, H, W, 160, device="cuda")
+    ops.warp(fq, flow, out=out[..., 96:160])
+    assert torch.equal(out[..., 96:160], ops.warp(fq.repeat(hyp, 1, 1, 1), flow)) and not out[..., :96].any()
+
+
+@gpu
 def test_offset_regressor_vs_reference_golden(golden_dir):
     from picopose_amd.model.stage3 import OffsetRegressor
 
