@@ -1,0 +1,29 @@
+#!/bin/bash
+# usage: tools/pmc_mfma_step.sh <tag> — MFMA pipe utilisation per kernel over the steps of the default bench
+# (counters only, one group per run, no tracing); profiles/r01/pmc_mfma_step.txt is the same data cut to ONE step
+# (the dispatches between the last two stage-1 launches).  busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs).
+tag=$1
+root=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d $root/gpurun_out/pmc_mfma_${tag} -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $root/gpurun_out/pmc_mfma_${tag}.log 2>&1
+cd $root
+python3 - "$root/gpurun_out/pmc_mfma_${tag}" <<'PY'
+import csv, glob, sys, collections, re
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.Counter()
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        n = re.sub(r"\(.*", "", n.replace("void ", "").replace("(anonymous namespace)::", ""))[:44]
+        agg[n][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE": cnt[n] += 1
+print(f"{'kernel':46s} {'launches':>8s} {'MFMA busy':>10s} {'share of GPU-active cycles':>27s}")
+tot = sum(v["GRBM_GUI_ACTIVE"] for v in agg.values())
+tb = 0.0
+for n, v in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])[:16]:
+    act = v["GRBM_GUI_ACTIVE"] / 8 * 1024
+    busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / act if act else 0.0
+    tb += v["SQ_VALU_MFMA_BUSY_CYCLES"]
+    print(f"{n:46s} {cnt[n]:8d} {busy:10.3f} {v['GRBM_GUI_ACTIVE'] / tot:27.3f}")
+print(f"all kernels of the run: MFMA busy {tb / (tot / 8 * 1024):.3f} of the SIMD cycles while a kernel is active")
+PY
