@@ -12,7 +12,12 @@ bank are resident in HBM before the timed region (the bank is precomputed as run
 `stage1_*` workloads time reference utils/matching.py:29-69 alone (configs[1] and the stage-1 shape of
 configs[2]).
 
-N > 1 (torch.distributed.run, one rank per GPU, RCCL): weak scaling — every rank owns 32 crops (global
+`python bench.py --gpus N` (N > 1) from a plain shell starts its own ranks: before anything touches the GPU it
+spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process and relays its output
+and return code (a process that has initialised the GPU is never re-exec'ed).  Under torch.distributed.run
+(WORLD_SIZE set) it is a rank.
+
+N > 1 (one rank per GPU, RCCL): weak scaling — every rank owns 32 crops (global
 batch 32*N); the template FEATURE bank is sharded over the ranks along N (each rank scores its slice of all
 crops), exchanged with all-gathers of the query features/masks and of the (B, N/G) score slices; stages 2-3
 and PnP run data-parallel on the rank's own crops.
@@ -56,6 +61,7 @@ WORKLOADS = {
     "stage1_b8_n42_c384": ("stage1", 8, 42, "dinov2_vits14", "configs[1]: batch 8, 42 templates, ViT-S/14, stage-1 matching only"),
     "stage1_b32_n162_c1024": ("stage1", 32, 162, "dinov2_vitl14", "base.yaml shape (ViT-L/14), stage-1 matching only"),
 }
+FP16_BANK = set()           # workloads whose template feature bank is stored fp16 (configs[4] groundwork)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a read-only probe reaches 6.2-6.4 TB/s
 MFMA_F32_PEAK_TF = 157.3   # dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16 MFMA peak (v_mfma_f32_32x32x16_f16), MI355X_MICROARCH.md
@@ -75,9 +81,10 @@ def cpu_cores():
     return max(1, min(n, 16))  # one GPU's job owns a 16-core share of the host
 
 
-def stage1_bytes(B, N, C):
-    # per crop N*C*256*4 (bank, read once) + C*256*4 (query) + 256*4 (mask) + k*12
-    return B * (N * C * 256 * 4 + C * 256 * 4 + 256 * 4 + 5 * 12)
+def stage1_bytes(B, N, C, bank_elem_bytes=4):
+    # per crop N*C*256*4 (bank, read once; 2 B/elem when the bank is stored fp16) + C*256*4 (query)
+    # + 256*4 (mask) + k*12
+    return B * (N * C * 256 * bank_elem_bytes + C * 256 * 4 + 256 * 4 + 5 * 12)
 
 
 def full_gflop_per_crop(N, vit, hyp=5, cached=False):
@@ -96,19 +103,36 @@ def make_cfg(vit):
               stage3=ns(nclass=1, in_channels=C, use_bn=True, out_channels=[256, 512, 1024, 1024], num_levels=3, radius=4))
 
 
-def seeded_weights(net, seed):
-    """Random-init weights of the architecture (no network for checkpoints)."""
-    from picopose_amd.utils.seeding import seeded_state_dict
+def seeded_weights(net, seed, vit):
+    """Random-init weights of the architecture (no network for checkpoints) with the last layer of every prediction
+    head calibrated (picopose_amd/utils/seeding.py) so that ~half of the 4096 key-point slots survive stage 3 and
+    PnP/RANSAC receives thousands of correspondences per problem, as with a trained network."""
+    from picopose_amd.utils.seeding import calibrated_state_dict
 
-    sd = seeded_state_dict(net.state_dict(), seed)
+    sd = calibrated_state_dict(net.state_dict(), seed, vit)
     net.load_state_dict(sd)
     return sd
 
 
+def dome_points(K, M, device, size=64, crop=224, z0=0.8, relief=0.05, radius=0.4):
+    """(size,size,3) template-camera-frame points of a shallow dome seen through crop affine M with intrinsics K: a
+    geometrically consistent synthetic object, so that the key-points of stage 3 describe a pose PnP/RANSAC can find
+    (a crop-to-crop similarity of a near-planar object is a rigid motion).  Same construction as tests/netcfg.py."""
+    c = torch.arange(size, dtype=torch.float32, device=device) * (crop / size) + crop / (2 * size)
+    cy, cx = torch.meshgrid(c, c, indexing="ij")
+    u, v = (cx - M[0, 2]) / M[0, 0], (cy - M[1, 2]) / M[1, 1]
+    r2 = ((cx - (crop - 1) / 2) ** 2 + (cy - (crop - 1) / 2) ** 2) / (radius * crop) ** 2
+    z = z0 - relief * (1 - r2).clamp_min(0)
+    return torch.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z], dim=-1)
+
+
 def make_end_points(B, N, device, seed):
-    """Synthetic eval inputs of SURVEY.md §8(d), generated on the device (N(0,1) crops/templates, disk masks, BOP K)."""
+    """Synthetic eval inputs of SURVEY.md §8(d), generated on the device (N(0,1) crops/templates, disk masks, BOP K).
+    One deviation from §8(d): `tem_pts3d` is the dome of dome_points() instead of U(-0.1, 0.1) noise — random 3-D
+    points admit no pose, and the PnP/RANSAC leg of the step must do the work it does on real data."""
     g = torch.Generator(device=device).manual_seed(seed)
     K = torch.tensor([[572.4114, 0, 320], [0, 573.57043, 240], [0, 0, 1.0]], device=device)
+    tem_M = torch.tensor([[1.5, 0, -300.0], [0, 1.5, -200.0], [0, 0, 1.0]], device=device)
     c = torch.arange(64, device=device).float() * 3.5 + 1.75
     gy, gx = torch.meshgrid(c, c, indexing="ij")
     pts = (torch.stack([gx, gy], dim=-1) - torch.tensor([-100.0, -80.0], device=device)) / 2.0
@@ -123,9 +147,8 @@ def make_end_points(B, N, device, seed):
         "real_pose": torch.eye(4, device=device)[None].repeat(B, 1, 1), "real_pts2d": pts[None].repeat(B, 1, 1, 1),
         "tem_rgb": torch.randn(B, N, 3, 224, 224, device=device, generator=g),
         "tem_mask": disk_mask(1, device)[None].repeat(B, N, 1, 1),
-        "tem_pts3d": (torch.rand(B, N, 64, 64, 3, device=device, generator=g) - 0.5) * 0.2, "tem_pose": pose,
-        "tem_K": K[None, None].repeat(B, N, 1, 1),
-        "tem_M": torch.tensor([[1.5, 0, -300.0], [0, 1.5, -200.0], [0, 0, 1.0]], device=device)[None, None].repeat(B, N, 1, 1),
+        "tem_pts3d": dome_points(K, tem_M, device)[None, None].repeat(B, N, 1, 1, 1), "tem_pose": pose,
+        "tem_K": K[None, None].repeat(B, N, 1, 1), "tem_M": tem_M[None, None].repeat(B, N, 1, 1),
     }
 
 
@@ -173,15 +196,36 @@ def cpu_baseline_full(N, vit, sd, budget=25.0):
         # the PnP/RANSAC oracle is numpy restating OpenCV's C++ solver: timed beside the forward, not inside `value`
         # (it would make the reference's CPU path look slower than it is)
         t1 = time.perf_counter()
+        npts = []
         for k, o in enumerate(outs):      # run_test.py:168-184: one PnP problem per (instance, hypothesis)
             opnp.pose_recovery_ransac_pnp(o["tar_pts_2d"][0].numpy(), o["src_pts_3d"][0].numpy(), ep["real_K"][0].numpy(),
                                           o["tem_pose"][0].numpy(), o["pred_tar_pts"][0].numpy(),
                                           o["pred_src_pts"][0].numpy(), prob=k)
+            npts.append(int((o["pred_tar_pts"][0, :, 0] >= 0).sum()))
         pnp_s = time.perf_counter() - t1
     return {"value": reps / dt, "unit": "crops/s", "cores": cores, "kind": "port",
             "sample": f"{reps} x oracle Net.forward (stage1->stage3, hyp 5) on 1 crop x {N} templates, {vit}, torch CPU fp32, "
                       f"{cores} threads (feature bank precomputed, as on the GPU); PnP/RANSAC not in `value`: cv2 is absent and "
-                      f"the numpy oracle of it took {pnp_s:.2f} s for the crop's 5 problems (1 thread)"}
+                      f"the numpy oracle of it took {pnp_s:.2f} s for the crop's 5 problems ({sum(npts) // 5} correspondences "
+                      f"each on average, 1 thread)"}
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` from a plain shell: run the N ranks as a child torch.distributed.run job (nothing in
+    this process has touched the GPU) and hand back its return code; rank 0 of the child prints the JSON line."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, cpu_cores() // n)))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -192,15 +236,19 @@ def main():
     ap.add_argument("--workload", default="full_b32_n162_vitb", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the untimed --mode exact comparison leg")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))      # child job; this process never touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start the ranks with torch.distributed.run --nproc-per-node {a.gpus} "
+                         f"(or run plain `python bench.py --gpus {a.gpus}`, which does that itself)")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        raise SystemExit(f"bench.py needs an MI355X (rank {rank} of {world}): the HIP path has no CPU fallback")
     # PP_BENCH_REHEARSE=1: rehearse the N > 1 code path on a ONE-GPU box (every rank on cuda:0, gloo instead of RCCL)
     rehearse = os.environ.get("PP_BENCH_REHEARSE") == "1"
     if rehearse:
@@ -208,6 +256,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
+    backend = "none"
     if distributed:
         import torch.distributed as dist
 
@@ -216,6 +265,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        backend = f"{dist.get_backend()} ({'gloo rehearsal on one GPU' if rehearse else 'RCCL over xGMI'}), world_size {dist.get_world_size()}"
 
     from picopose_amd import _lib, ops
     from picopose_amd.dist import shard_bounds, sharded_forward, sharded_matching_templates
@@ -229,6 +279,7 @@ def main():
     lo, hi = shard_bounds(N, world, rank)
     n_local = hi - lo
     sd = None
+    bank_dtype = torch.float16 if a.workload in FP16_BANK else torch.float32
 
     cached = kind == "full_cached"
     if cached:
@@ -237,7 +288,7 @@ def main():
         g0 = torch.Generator(device=dev).manual_seed(0)
         query = torch.randn(B, C, 16, 16, device=dev, generator=g0)     # identical on every rank
         mask = disk_mask(B, dev)
-        bank = torch.randn(B, n_local, C, 16, 16, device=dev, generator=torch.Generator(device=dev).manual_seed(1 + rank))
+        bank = torch.randn(B, n_local, C, 16, 16, device=dev, generator=torch.Generator(device=dev).manual_seed(1 + rank)).to(bank_dtype)
 
         def step():
             if distributed:
@@ -245,10 +296,11 @@ def main():
             return hm.matching_templates(bank, query, None, mask, topk=5, mode=a.mode)
     else:
         from picopose_amd.picopose import Net
-        from picopose_amd.pipeline import pnp_for_outputs
+        from picopose_amd.pipeline import pnp_for_outputs, pnp_inputs
+        from picopose_amd.utils.pose_recovery import pnp_launch
 
         net = Net(make_cfg(vit))
-        sd = seeded_weights(net, 4)
+        sd = seeded_weights(net, 4, vit)
         net = net.to(dev).eval()
         net.match_mode = a.mode
         ep = make_end_points(Bl, N, dev, 100 + rank)                     # this rank's crops + their raw templates
@@ -266,16 +318,17 @@ def main():
             else:
                 feats = torch.stack([torch.cat([fe(ep["tem_rgb"][b, s:min(s + 54, hi)])[-1] for s in range(lo, hi, 54)])
                                      for b in range(Bl)])
+        feats = feats.to(bank_dtype)
         if distributed:
             bank = feats.repeat(world, 1, 1, 1, 1).contiguous()
         else:
             ep["template_feature"] = feats
 
+        def forward():
+            return sharded_forward(net, ep, bank, N, hyp=5) if distributed else net(ep, 5)
+
         def step():
-            if distributed:
-                outs = sharded_forward(net, ep, bank, N, hyp=5)
-            else:
-                outs = net(ep, 5)
+            outs = forward()
             return outs, pnp_for_outputs(outs, ep["real_K"])            # PnP/RANSAC + D2H of the poses
 
     if kind == "stage1":   # a step is ~1 ms: without ~0.3 s of load first, the timed steps run while the clocks still ramp
@@ -288,32 +341,100 @@ def main():
         out = step()
     torch.cuda.synchronize()
     L = _lib.lib()
-    _lib.check(L.pp_prof_enable(a.steps), "pp_prof_enable")
+    # stage-1 workloads: the roofline kernel IS the step, so its launch is bracketed by HIP events inside the timed steps
+    # (on the launch stream); full path: the event brackets go into extra, untimed steps after the timed region
+    if kind == "stage1":
+        _lib.check(L.pp_prof_enable(a.steps), "pp_prof_enable")
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         out = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    buf = (ctypes.c_float * a.steps)()
-    cnt = ctypes.c_int()
-    _lib.check(L.pp_prof_collect(buf, a.steps, ctypes.byref(cnt)), "pp_prof_collect")
-    _lib.check(L.pp_prof_enable(0), "pp_prof_enable")
-    kern_ms = sum(buf[i] for i in range(cnt.value)) / max(cnt.value, 1)
-    gemm = None
-    if kind == "full":   # one more (untimed) step with an event pair around every GEMM launch
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+
+    def collect_stage1(n):
+        buf, cnt = (ctypes.c_float * n)(), ctypes.c_int()
+        _lib.check(L.pp_prof_collect(buf, n, ctypes.byref(cnt)), "pp_prof_collect")
+        _lib.check(L.pp_prof_enable(0), "pp_prof_enable")
+        return sum(buf[i] for i in range(cnt.value)) / max(cnt.value, 1)
+
+    gemm = pnp = exact = None
+    if kind == "stage1":
+        kern_ms = collect_stage1(a.steps)
+    else:
+        _lib.check(L.pp_prof_enable(3), "pp_prof_enable")       # 3 untimed steps with events around the stage-1 launch
+        for _ in range(3):
+            out = step()
+        torch.cuda.synchronize()
+        kern_ms = collect_stage1(3)
+        # one more untimed step with an event pair around every GEMM launch, and around the PnP launch
         _lib.check(L.pp_prof_gemm_enable(8192), "pp_prof_gemm_enable")
-        out = step()
+        net.keep_stage3 = True
+        outs = forward()
+        net.keep_stage3 = False
         torch.cuda.synchronize()
         g_ms, g_fl, g_n = (ctypes.c_double * 2)(), (ctypes.c_double * 2)(), (ctypes.c_int * 2)()
         _lib.check(L.pp_prof_gemm_collect(g_ms, g_fl, g_n), "pp_prof_gemm_collect")
         _lib.check(L.pp_prof_gemm_enable(0), "pp_prof_gemm_enable")
         gemm = {"ms": list(g_ms), "flops": list(g_fl), "launches": list(g_n)}
+        args = pnp_inputs(outs, ep["real_K"])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pnp_launch(*args)
+        torch.cuda.synchronize()
+        e0.record()
+        pnp_launch(*args)
+        e1.record()
+        torch.cuda.synchronize()
+        rot, tvec, ratio, ok, npts = pnp_for_outputs(outs, ep["real_K"], return_npts=True)
+        pnp = {"problems": int(npts.size), "valid_points_mean": float(npts.mean()), "valid_points_min": int(npts.min()),
+               "valid_points_max": int(npts.max()), "kernel_ms": e0.elapsed_time(e1), "success_rate": float(ok.mean()),
+               "inliers_ratio_mean": float(ratio.mean()), "iterations": 150, "reprojection_px": 2.0,
+               "note": "batched EPnP-RANSAC of all (crop, hypothesis) problems in one launch (csrc/pp_pnp.hip), inside every timed step"}
+        if npts.min() < 5:
+            raise SystemExit(f"bench: a PnP problem received {int(npts.min())} correspondences (< the 5-point sample): "
+                             "the key-point -> PnP chain is not loaded")
+        if a.mode == "fast" and world == 1 and not a.no_exact_leg:
+            # the same step in --mode exact (fp32 MFMA everywhere, exact-fp32 stage 1), untimed leg: its rate and the
+            # deviation of the default (f16x3) arithmetic from it on these very inputs
+            fast = {"poses": torch.stack([o["pred_poses"] for o in outs]), "tar": torch.stack([o["pred_tar_pts"] for o in outs]),
+                    "ids": torch.stack([o["tem_pose"] for o in outs]), "flow": net.last_stage3[0].clone(),
+                    "cert": net.last_stage3[1].clone(), "tvec": tvec, "rot": rot}
+            ops.PRECISION, net.match_mode = "f32", "exact"
+            net.keep_stage3 = True
+            for _ in range(2):
+                xo = step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                xo = step()
+            torch.cuda.synchronize()
+            x_dt = (time.perf_counter() - t1) / 2
+            net.keep_stage3 = False
+            ops.PRECISION, net.match_mode = "f16x3", a.mode
+            xouts, (xrot, xtvec, _, xok) = xo
+            same_t = torch.stack([o["tem_pose"] for o in xouts]) == fast["ids"]
+            xtar = torch.stack([o["pred_tar_pts"] for o in xouts])
+            both = ok & xok
+            exact = {"value": Bl / x_dt, "unit": "crops/s", "ms_per_step": x_dt * 1e3,
+                     "dtype": "f32 (v_mfma_f32_32x32x2_f32 in every kernel, exact-fp32 stage 1; PnP f64)",
+                     "f16x3_vs_exact": {
+                         "same_templates": bool(same_t.all()),
+                         "pred_poses_max_abs": float((torch.stack([o["pred_poses"] for o in xouts]) - fast["poses"]).abs().max()),
+                         "flow_max_abs_px": float((net.last_stage3[0] - fast["flow"]).abs().max()),
+                         "flow_max_abs_value": float(fast["flow"].abs().max()),
+                         "certainty_logit_max_abs": float((net.last_stage3[1] - fast["cert"]).abs().max()),
+                         "keypoint_slots_equal": float((xtar == fast["tar"]).all(-1).float().mean()),
+                         "pnp_translation_max_abs_m": float(abs(xtvec - tvec)[both].max()) if both.any() else None,
+                         "pnp_translation_median_abs_m": float(__import__("numpy").median(abs(xtvec - tvec)[both])) if both.any() else None}}
 
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -322,70 +443,79 @@ def main():
 
     if rank == 0:
         ms = dt / a.steps * 1e3
-        kbytes = stage1_bytes(B, n_local, C)        # bytes one launch of the stage-1 kernel streams on this rank
+        bpe = 2 if bank_dtype == torch.float16 else 4
+        kbytes = stage1_bytes(B, n_local, C, bpe)   # bytes one launch of the stage-1 kernel streams on this rank
         achieved = kbytes / (kern_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from the PMC passes (profiles/, tools/pmc.sh): same kernel, same shape
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_stage1.json")
-        if world == 1 and a.mode == "fast" and (B, N, C) == (32, 162, 768) and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+        prof_dir = next((d for d in ("r02", "r01") if os.path.isdir(os.path.join(ROOT, "profiles", d))), "r01")
+        traffic = traffic_src = None  # HBM bytes per launch from a separate PMC pass (tools/pmc.sh): same kernel, same shape
+        pmc = os.path.join(ROOT, "profiles", prof_dir, "pmc_traffic_stage1.json")
+        if world == 1 and a.mode == "fast" and (B, N, C, bpe) == (32, 162, 768, 4) and os.path.exists(pmc):
+            traffic, traffic_src = json.load(open(pmc))["hbm_bytes_per_launch"], os.path.relpath(pmc, ROOT)
         line = {
             "metric": f"image-crops/sec (224x224, {N} templates)" + ("" if kind == "full" else ", stage-1 template matching only")
                       + (", extended template bank (SURVEY 8f row 1: template ViT/DPT precomputed)" if cached else ""),
             "value": B / (dt / a.steps), "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms, "ms_per_step_median_hip_events": step_ms[len(step_ms) // 2],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 tensors; networks: f32 operands split into 2 f16 terms (22 bits) on f16 MFMA with f32 accumulate; stage-1 "
                      "contraction: f16 MFMA operands, f32 accumulate, exact f32 re-evaluation of near-ties; PnP f64"
                      if a.mode == "fast" else "f32 (fp32 MFMA everywhere; PnP f64)",
             "data": "synthetic",
             "config": {"workload": f"{a.workload}: {desc}", "global_batch": B, "templates": N, "backbone": vit, "channels": C,
-                       "hypotheses": 5, "mode": a.mode, "weights": "seeded random init",
+                       "hypotheses": 5, "mode": a.mode, "bank_dtype": "f16" if bpe == 2 else "f32",
+                       "weights": "seeded random init, prediction heads calibrated (picopose_amd/utils/seeding.py)",
                        "parallelism": "single GPU" if world == 1 else
-                       f"crops data-parallel x{world}; feature bank template-sharded x{world} + RCCL all-gathers (query features, scores)"},
+                       f"crops data-parallel x{world}; feature bank template-sharded x{world} + all-gathers (packed query operand, scores); {backend}"},
         }
         s1_roof = {"bound": "hbm", "kernel": f"s1_main<{a.mode}> (stage-1 fused similarity)", "achieved": achieved,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                   "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kbytes}
+                   "traffic_source": traffic_src, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kbytes,
+                   "timing": "HIP events on the launch stream around this launch, " +
+                             ("inside the timed steps" if kind == "stage1" else "3 extra untimed steps after the timed region")}
         if kind == "full" and gemm and gemm["launches"][0] > 0:
             k = 0 if a.mode == "fast" else 1     # fast: pre-split f16x3 kernel; exact: the fp32-MFMA kernel
             mult, peak = (3, MFMA_F16_PEAK_TF) if a.mode == "fast" else (1, MFMA_F32_PEAK_TF)
             n, msum, fl = gemm["launches"][k], gemm["ms"][k], gemm["flops"][k]
             ach = mult * fl / (msum * 1e-3) / 1e12
-            g_traffic = None   # HBM bytes of these kernels over one step, from the PMC passes (tools/pmc_step.sh)
-            pmc_step = os.path.join(ROOT, "profiles", "r01", "pmc_step.json")
+            g_traffic = g_src = None   # HBM bytes of these kernels over one step, from separate PMC passes (tools/pmc_step.sh)
+            pmc_step = os.path.join(ROOT, "profiles", prof_dir, "pmc_step.json")
             if world == 1 and a.mode == "fast" and a.workload == "full_b32_n162_vitb" and os.path.exists(pmc_step):
-                g_traffic = json.load(open(pmc_step)).get("gemm_f16x3_hbm_bytes_per_step")
+                g_traffic, g_src = json.load(open(pmc_step)).get("gemm_f16x3_hbm_bytes_per_step"), os.path.relpath(pmc_step, ROOT)
             line["roofline"] = {
                 "bound": "mfma",
                 "kernel": "pp_gemm f16x3 family: pp_gemm_f16x3{q,p,g}_kernel + gemm_f16x3s_kernel (GEMM / implicit-im2col conv, both operands pre-split into 2 fp16 planes; "
                           "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)" if a.mode == "fast" else
                           "gemm_kernel (v_mfma_f32_32x32x2_f32)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": None if g_traffic is None else g_traffic / n, "traffic_bytes_per_step": g_traffic,
-                "algorithmic_operand_bytes_note": "MFMA-bound kernels: HBM traffic (FETCH_SIZE x2 + WRITE_SIZE, PMC) is reported "
-                                                  "per average launch; it is 2-3 TB/s averaged over the step, far from the 8 TB/s roofline",
+                "frac_algorithmic": fl / (msum * 1e-3) / 1e12 / peak,
+                "frac_note": "frac = EXECUTED MFMA flops (3 fp16 MFMA products per fp32-grade product) / time / fp16 dense peak; "
+                             "frac_algorithmic = 2MNK / time / the same peak (ceiling 1/3 under the 3-term scheme)"
+                             if a.mode == "fast" else "fp32 MFMA: executed = algorithmic",
+                "traffic": None if g_traffic is None else g_traffic / n, "traffic_bytes_per_step": g_traffic, "traffic_source": g_src,
                 "launches_per_step": n, "kernel_ms_per_step": msum, "avg_launch_ms": msum / n,
                 "algorithmic_flops_per_step": fl, "mfma_flops_per_step": mult * fl,
                 "useful_tflops": fl / (msum * 1e-3) / 1e12, "share_of_step": msum / ms,
-                "note": "achieved = MFMA flops executed (3 fp16 MFMA products per fp32-equivalent product) / summed launch "
-                        "durations, HIP events around every launch of one step; useful_tflops = 2MNK / time",
+                "timing": "HIP events on the launch stream around every launch of one extra, untimed step",
             }
             line["roofline_stage1"] = s1_roof
         else:
             line["roofline"] = s1_roof
         if kind == "full":
-            from picopose_amd import ops
-
             tf = Bl * full_gflop_per_crop(N, vit, cached=cached) / (dt / a.steps) / 1e3   # useful (fp32-equivalent) TFLOP/s per GPU
-            if ops.PRECISION == "f16x3":   # every product = 3 fp16 MFMA products
-                line["mfma"] = {"bound": "mfma", "scope": "whole step, all kernels (the GEMM/conv engine is >90 % of it)",
+            if a.mode == "fast":   # every product = 3 fp16 MFMA products
+                line["mfma"] = {"bound": "mfma", "scope": "whole step, all kernels (the GEMM/conv engine is >85 % of it)",
                                 "engine": "f16x3: operands split into 2 fp16 terms, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate",
                                 "useful_tflops": tf, "achieved": 3 * tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
-                                "frac": 3 * tf / MFMA_F16_PEAK_TF, "frac_of_fp32_mfma_peak_equivalent": tf / MFMA_F32_PEAK_TF,
+                                "frac": 3 * tf / MFMA_F16_PEAK_TF, "frac_algorithmic": tf / MFMA_F16_PEAK_TF,
+                                "frac_of_fp32_mfma_peak_equivalent": tf / MFMA_F32_PEAK_TF,
                                 "gflop_per_crop": full_gflop_per_crop(N, vit, cached=cached)}
             else:
-                line["mfma"] = {"bound": "mfma", "scope": "whole step, all kernels (the GEMM/conv engine is >90 % of it)",
+                line["mfma"] = {"bound": "mfma", "scope": "whole step, all kernels (the GEMM/conv engine is >85 % of it)",
                                 "engine": "f32: v_mfma_f32_32x32x2_f32", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
                                 "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "gflop_per_crop": full_gflop_per_crop(N, vit, cached=cached)}
+            line["pnp"] = pnp
+            if exact is not None:
+                line["exact_mode"] = exact
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_full(N, vit, sd) if kind == "full" else cpu_baseline_stage1(N, C)
         print(json.dumps(line), flush=True)

@@ -1,0 +1,70 @@
+"""Measure the head calibration of the seeded random weights (TEST INFRASTRUCTURE; runs the CPU oracle).
+
+With plain seeded random weights the stage-3 heads emit flows of +-1000 px and certainty logits of +-100, so no
+key-point survives compute_stage3_correspondences (utils/correspondence.py:28-59) and the PnP step receives nothing
+(VERDICT r01, weak #1).  The calibration rescales ONLY the last layer of each prediction head (affine heads of
+stage 2; flow_pred.l.predict_layer / mask_pred.l.predict_layer of stage 3) so that, on the synthetic inputs, the
+per-level flow updates have a std of a fraction of a pixel and the certainty updates a std of ~1 around 0: about
+half of the 4096 entries then survive, like a trained network's output.  Every other weight keeps its draw.
+
+    python oracle/calibrate_heads.py            # prints the table committed in oracle/weights.py and
+                                                # picopose_amd/utils/seeding.py (HEAD_CALIBRATION)
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLOW_STD = (0.15, 0.2, 0.4)     # target std of the flow update of level l (grid pixels of that level)
+CERT_STD = (1.0, 1.0, 1.0)      # target std of the certainty-logit update of level l
+
+
+def measure(sd_raw, ep, heads, take, template=0):
+    """-> calibration dict {"flow": [(gain, shift)]*3, "cert": [(gain, shift)]*3} for apply_head_calibration."""
+    from oracle import geometry as og
+    from oracle import matching as om
+    from oracle import nets as on
+    from oracle.weights import AFFINE_CALIBRATION, apply_head_calibration
+
+    cal = {"flow": [(1.0, 0.0)] * 3, "cert": [(1.0, 0.0)] * 3}
+    with torch.no_grad():
+        sd = apply_head_calibration(sd_raw, dict(cal, affine=AFFINE_CALIBRATION))
+        fr = on.vit_features(sd, ep["real_rgb"], heads, take)
+        ft = on.vit_features(sd, ep["tem_rgb"][:, template], heads, take)
+        sim = om.matching_features_similarity(ft[-1], fr[-1], ep["tem_mask"][:, template], None)
+        t, s, ip = on.affine_regressor(sd, sim)
+        Ms = og.calc_pred_Ms(s, ip, t, ep["tem_pose"][:, template], ep["tem_K"][:, template], ep["tem_M"][:, template])
+        f0, c0 = og.compute_init_correspondences(Ms, ep["tem_mask"][:, template])
+        dt, dr = on.dpt_head(sd, ft), on.dpt_head(sd, fr)
+        up = lambda x: torch.nn.functional.interpolate(x, scale_factor=(2, 2), mode="bilinear", align_corners=True)  # noqa: E731
+        for l in range(3):
+            sd = apply_head_calibration(sd_raw, dict(cal, affine=AFFINE_CALIBRATION))
+            fl, ce = on.flow_decoder(sd, dt, dr, f0, c0)
+            prev_f = f0 if l == 0 else 2 * up(fl[l - 1])
+            prev_c = c0 if l == 0 else up(ce[l - 1])
+            df, dc = fl[l] - prev_f, ce[l] - prev_c
+            for key, d, target in (("flow", df, FLOW_STD[l]), ("cert", dc, CERT_STD[l])):
+                gain = target / float(d.std())
+                shift = -gain * float(d.mean())          # added to the (scaled) bias: zero-mean update
+                cal[key] = list(cal[key])
+                cal[key][l] = (gain, shift)
+    return cal, (t, s, ip)
+
+
+if __name__ == "__main__":
+    import bench
+    from oracle.weights import seeded_state_dict
+    from picopose_amd.picopose import Net
+
+    torch.set_num_threads(8)
+    for vit in ("dinov2_vits14", "dinov2_vitb14", "dinov2_vitl14"):
+        C, heads, idx, _ = bench.VIT[vit]
+        sd = seeded_state_dict(Net(bench.make_cfg(vit)).state_dict(), 4)
+        ep = {k: v.cpu() for k, v in bench.make_end_points(2, 2, "cpu", 100).items()}
+        cal, _ = measure(sd, ep, heads, [b[-1] for b in idx])
+        print(f'    "{vit}": {{"flow": {[(float("%.4g" % g), float("%.4g" % s)) for g, s in cal["flow"]]},')
+        print(f'                     "cert": {[(float("%.4g" % g), float("%.4g" % s)) for g, s in cal["cert"]]}}},', flush=True)

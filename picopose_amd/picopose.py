@@ -27,6 +27,10 @@ class Net(nn.Module):
         self.offset_regressor = OffsetRegressor(cfg.stage3)
         self.match_mode = None  # None -> picopose_amd.utils.matching.DEFAULT_MODE ("fast")
         self.batch_hypotheses = True  # run the hyp candidates of all crops as one batch (same values, larger launches)
+        # measurement aid (bench.py's f16x3-vs-exact deviation, tests): keep the last level's flow / certainty maps
+        # (NHWC, hypothesis-major when batched) of the latest forward in self.last_stage3
+        self.keep_stage3 = False
+        self.last_stage3 = None
 
     # model/picopose.py:52-70 — pick hypothesis k's template for every crop (pure indexing)
     def select_template_data(self, end_points, pred_id_src, k):
@@ -92,6 +96,8 @@ class Net(nn.Module):
         if tem_cached is None:
             tem_dpt = orr.dpt_head.forward_nhwc([as_img(t) for t in tem_tok])
         flows, certs = orr.flow_decoder.forward_nhwc(tem_dpt, real_dpt, ops.to_nhwc(init_flow), ops.to_nhwc(init_certainty))
+        if self.keep_stage3:
+            self.last_stage3 = (flows[-1], certs[-1])
         output["pred_tar_pts"], output["pred_src_pts"] = compute_stage3_correspondences(
             ops.to_nchw(flows[-1]), ops.to_nchw(certs[-1]), threshold=0.5)
         return output

@@ -8,13 +8,22 @@ import torch
 from .utils.pose_recovery import pose_recovery_ransac_pnp_batched
 
 
-def pnp_for_outputs(outputs, real_K):
-    """outputs: list (hyp) of Net.forward dicts; real_K (B,3,3) -> rot (hyp,B,3,3), tvec (hyp,B,3,1), ratio, ok."""
-    hyp, B = len(outputs), outputs[0]["pred_poses"].shape[0]
+def pnp_inputs(outputs, real_K):
+    """The (hyp*B) PnP problems of a forward, hypothesis-major: arguments of pose_recovery_ransac_pnp_batched."""
+    hyp = len(outputs)
     cat = lambda k: torch.cat([o[k] for o in outputs], dim=0)  # noqa: E731
-    rot, tvec, ratio, ok = pose_recovery_ransac_pnp_batched(cat("tar_pts_2d"), cat("src_pts_3d"), real_K.repeat(hyp, 1, 1),
-                                                           cat("tem_pose"), cat("pred_tar_pts"), cat("pred_src_pts"))
-    return (rot.reshape(hyp, B, 3, 3), tvec.reshape(hyp, B, 3, 1), ratio.reshape(hyp, B), ok.reshape(hyp, B))
+    return (cat("tar_pts_2d"), cat("src_pts_3d"), real_K.repeat(hyp, 1, 1), cat("tem_pose"), cat("pred_tar_pts"),
+            cat("pred_src_pts"))
+
+
+def pnp_for_outputs(outputs, real_K, return_npts=False):
+    """outputs: list (hyp) of Net.forward dicts; real_K (B,3,3) -> rot (hyp,B,3,3), tvec (hyp,B,3,1), ratio, ok
+    [+ npts (hyp,B): correspondences each problem received]."""
+    hyp, B = len(outputs), outputs[0]["pred_poses"].shape[0]
+    res = pose_recovery_ransac_pnp_batched(*pnp_inputs(outputs, real_K), return_npts=return_npts)
+    rot, tvec, ratio, ok = res[:4]
+    out = (rot.reshape(hyp, B, 3, 3), tvec.reshape(hyp, B, 3, 1), ratio.reshape(hyp, B), ok.reshape(hyp, B))
+    return out + (res[4].reshape(hyp, B),) if return_npts else out
 
 
 def infer_batch(net, end_points, hyp=5):

@@ -18,13 +18,9 @@ def pose_recovery_2d_prediction(query_M, query_K, pred_Ms, template_K, template_
     return out
 
 
-def pose_recovery_ransac_pnp_batched(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations=150,
-                                     reproj_error=2.0):
-    """All (instance, hypothesis) problems of a batch in ONE launch and ONE device->host copy
-    (the reference loops over them on the host with a sync each, run_test.py:168-184).
-
-    tar_pts_2d (P,2,H,W), src_pts_3d (P,3,H,W), K (P,3,3), tem_pose (P,4,4), tar_pts/src_pts (P,N,2) int64
-    -> rot (P,3,3) f64, tvec (P,3,1) f64, inliers_ratio (P) f64, success (P) bool   (numpy arrays)."""
+def pnp_launch(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations=150, reproj_error=2.0):
+    """Enqueue the batched PnP/RANSAC kernel; returns DEVICE tensors (rot (P,3,3) f64, tvec (P,3) f64, ratio (P) f64,
+    ok (P) i32, npts (P) i32 = correspondences each problem received) without synchronising."""
     t2, s3, Kd, pose = _lib.dev_f32(tar_pts_2d, src_pts_3d, K, tem_pose)
     tp, sp = tar_pts.contiguous().long(), src_pts.contiguous().long()
     P, _, H, W = t2.shape
@@ -39,7 +35,23 @@ def pose_recovery_ransac_pnp_batched(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pt
                                   P, H, W, N, int(iterations), float(reproj_error), rot.data_ptr(), tvec.data_ptr(),
                                   ratio.data_ptr(), ok.data_ptr(), npts.data_ptr(), _lib.stream_ptr())
     _lib.check(rc, "pp_pnp_ransac")
-    return (rot.cpu().numpy(), tvec.cpu().numpy().reshape(P, 3, 1), ratio.cpu().numpy(), ok.cpu().numpy().astype(bool))
+    return rot, tvec, ratio, ok, npts
+
+
+def pose_recovery_ransac_pnp_batched(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations=150,
+                                     reproj_error=2.0, return_npts=False):
+    """All (instance, hypothesis) problems of a batch in ONE launch and ONE device->host copy
+    (the reference loops over them on the host with a sync each, run_test.py:168-184).
+
+    tar_pts_2d (P,2,H,W), src_pts_3d (P,3,H,W), K (P,3,3), tem_pose (P,4,4), tar_pts/src_pts (P,N,2) int64
+    -> rot (P,3,3) f64, tvec (P,3,1) f64, inliers_ratio (P) f64, success (P) bool   (numpy arrays)
+    [+ npts (P) int32 with return_npts]."""
+    rot, tvec, ratio, ok, npts = pnp_launch(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations, reproj_error)
+    P = rot.shape[0]
+    # one packed device->host copy (P x 14 doubles) instead of four
+    host = torch.cat([rot.reshape(P, 9), tvec, ratio[:, None], ok.double()[:, None], npts.double()[:, None]], dim=1).cpu().numpy()
+    res = (host[:, :9].reshape(P, 3, 3).copy(), host[:, 9:12].reshape(P, 3, 1).copy(), host[:, 12].copy(), host[:, 13] != 0)
+    return res + (host[:, 14].astype("int32"),) if return_npts else res
 
 
 def pose_recovery_ransac_pnp(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts):

@@ -17,7 +17,22 @@ HEADS = 6
 TAKE = [2, 5, 8, 11]
 
 
-def make_end_points(B, N, seed, feature_fn=None, tem_pose=None):
+def dome_points(K, M, size=64, crop=224, z0=0.8, relief=0.05, radius=0.4):
+    """Template-camera-frame 3-D points of a shallow dome seen through the crop affine M (crop px = M . image px) with
+    intrinsics K: the 64x64 lookup map `tem_pts3d` of a geometrically consistent synthetic object.  A similarity
+    between template crop and query crop is then (up to the dome's small parallax) a rigid motion, so the key-point
+    lists of stage 3 give PnP/RANSAC a pose to find.  K, M: (3,3) tensors -> (size, size, 3)."""
+    import torch
+
+    c = torch.arange(size, dtype=torch.float32) * (crop / size) + crop / (2 * size)
+    cy, cx = torch.meshgrid(c, c, indexing="ij")
+    u, v = (cx - M[0, 2]) / M[0, 0], (cy - M[1, 2]) / M[1, 1]
+    r2 = ((cx - (crop - 1) / 2) ** 2 + (cy - (crop - 1) / 2) ** 2) / (radius * crop) ** 2
+    z = z0 - relief * (1 - r2).clamp_min(0)
+    return torch.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z], dim=-1)
+
+
+def make_end_points(B, N, seed, feature_fn=None, tem_pose=None, dome=False):
     """Synthetic eval `end_points`: N(0,1) crops and template renders, disk masks, BOP
     intrinsics, random template rotations at z = 0.8 m, crop affines that satisfy inverse_affine's asserts.
     `template_feature` = feature_fn(tem_rgb)[-1] per template (as run_test.py:120-134 precomputes it)."""
@@ -40,6 +55,9 @@ def make_end_points(B, N, seed, feature_fn=None, tem_pose=None):
     ep["tem_rgb"] = torch.randn(B, N, 3, 224, 224, generator=g)
     ep["tem_mask"] = disk[None, None].repeat(B, N, 1, 1)
     ep["tem_pts3d"] = (torch.rand(B, N, 64, 64, 3, generator=g) - 0.5) * 0.2
+    if dome:   # (the random map above is still drawn, so both variants share every other tensor of a seed)
+        tem_M = torch.tensor([[1.5, 0, -300.0], [0, 1.5, -200.0], [0, 0, 1.0]])
+        ep["tem_pts3d"] = dome_points(K, tem_M)[None, None].repeat(B, N, 1, 1, 1)
     q, _ = torch.linalg.qr(torch.randn(B, N, 3, 3, generator=g))
     q = q * torch.sign(torch.det(q))[..., None, None]
     pose = torch.eye(4)[None, None].repeat(B, N, 1, 1)

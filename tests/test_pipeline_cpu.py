@@ -26,6 +26,22 @@ def test_package_seeding_recipe_equals_the_fixture_recipe():
             "ls1.gamma": torch.zeros(4), "cls_token": torch.zeros(1, 1, 4), "n.weight": torch.zeros(4)}
     a, b = ref(tmpl, 7), got(tmpl, 7)
     assert all(torch.equal(a[k], b[k]) for k in tmpl)
+    # ... and the head calibration (table + application) is the same text on both sides
+    from oracle import weights as ow
+    from picopose_amd.utils import seeding as ps
+
+    assert ow.HEAD_CALIBRATION == ps.HEAD_CALIBRATION and ow.AFFINE_CALIBRATION == ps.AFFINE_CALIBRATION
+    heads = {f"affine_regressor.{h}_predictor.4.{k}": torch.randn(n, 8) if k == "weight" else torch.randn(n)
+             for h, n in (("translation", 2), ("scale", 1), ("inplane", 2)) for k in ("weight", "bias")}
+    for name in ("flow_pred", "mask_pred"):
+        for l in range(3):
+            c = 2 if name == "flow_pred" else 1
+            heads[f"offset_regressor.flow_decoder.{name}.{l}.predict_layer.weight"] = torch.randn(c, 8, 3, 3)
+            heads[f"offset_regressor.flow_decoder.{name}.{l}.predict_layer.bias"] = torch.randn(c)
+    cal = dict(ow.HEAD_CALIBRATION["dinov2_vitb14"], affine=ow.AFFINE_CALIBRATION)
+    x, y = ow.apply_head_calibration(heads, cal), ps.apply_head_calibration(heads, cal)
+    assert all(torch.equal(x[k], y[k]) for k in heads)
+    assert not any(torch.equal(x[k], heads[k]) for k in heads if "translation" not in k)
 
 
 def test_compat_module_name_resolves_like_the_reference_loader():
@@ -45,3 +61,26 @@ def test_compat_module_name_resolves_like_the_reference_loader():
     finally:
         sys.path.pop(0)
         sys.modules.pop("picopose", None)
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain shell (no WORLD_SIZE) must start two ranks itself (a child
+    torch.distributed.run job) — here, without a GPU, both ranks stop at the no-GPU check and say who they are."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode()
+    import torch
+
+    if not torch.cuda.is_available():
+        assert r.returncode != 0
+        assert "rank 0 of 2" in out and "rank 1 of 2" in out, out[-1500:]
+    # a rank count that contradicts the launcher is refused before any GPU call
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stdout.decode()

@@ -5,7 +5,7 @@ from picopose_amd.picopose import Net
 from picopose_amd.pipeline import pnp_for_outputs
 dev = torch.device("cuda", 0)
 vit = "dinov2_vitb14"; Bl, N = 32, 162
-net = Net(bench.make_cfg(vit)); bench.seeded_weights(net, 4); net = net.to(dev).eval()
+net = Net(bench.make_cfg(vit)); bench.seeded_weights(net, 4, vit); net = net.to(dev).eval()
 ep = bench.make_end_points(Bl, N, dev, 100)
 fe = net.feature_extractor
 with torch.no_grad():

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from picopose_amd.picopose import Net
 vit = "dinov2_vitb14"; B, N = 32, 162
-net = Net(bench.make_cfg(vit)); bench.seeded_weights(net, 4); net = net.cuda().eval()
+net = Net(bench.make_cfg(vit)); bench.seeded_weights(net, 4, vit); net = net.cuda().eval()
 ep = bench.make_end_points(B, N, torch.device("cuda"), 100)
 ep["template_feature"] = torch.randn(B, N, 768, 16, 16, device="cuda")
 for _ in range(2): net(ep, 5)

@@ -5,7 +5,7 @@ from picopose_amd import ops
 from picopose_amd.picopose import Net
 from picopose_amd.pipeline import pnp_for_outputs
 vit="dinov2_vitb14"
-net=Net(bench.make_cfg(vit)); bench.seeded_weights(net,4); net=net.cuda().eval()
+net=Net(bench.make_cfg(vit)); bench.seeded_weights(net, 4, vit); net=net.cuda().eval()
 ep=bench.make_end_points(32,162,"cuda",100)
 with torch.no_grad():
     fe=net.feature_extractor
