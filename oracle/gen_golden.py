@@ -263,7 +263,159 @@ def gen_e2e():
     print("e2e fixtures written")
 
 
-GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry, "nets": gen_nets, "e2e": gen_e2e}
+def _cfg(vit):
+    import types
+
+    ns = types.SimpleNamespace
+    C, idx = {"dinov2_vits14": (384, [[0, 2], [3, 5], [6, 8], [9, 11]]), "dinov2_vitb14": (768, [[0, 2], [3, 5], [6, 8], [9, 11]]),
+              "dinov2_vitl14": (1024, [[0, 5], [6, 11], [12, 17], [18, 23]])}[vit]
+    return ns(hypothesis=5, stage1=ns(vit_type=vit, pretrained=False, interaction_indexes=idx),
+              stage2=ns(in_channel=256, hidden_dim=256),
+              stage3=ns(nclass=1, in_channels=C, use_bn=True, out_channels=[256, 512, 1024, 1024], num_levels=3, radius=4))
+
+
+def _cal_arrays(cal):
+    """calibration dict -> arrays stored in a fixture (tests rebuild the weights from them, not from the table)."""
+    return {"cal_flow": np.array(cal["flow"], np.float64), "cal_cert": np.array(cal["cert"], np.float64),
+            **{f"cal_affine_{h}": np.array([g, *shift], np.float64) for h, (g, shift) in cal["affine"].items()}}
+
+
+def gen_e2e_calibrated():
+    """Reference Net.forward (eval) with CALIBRATED heads and the dome geometry (tests/netcfg.dome_points): about half of
+    the 4096 key-point slots are valid per hypothesis, so the network -> key-points -> PnP chain is compared on realistic
+    occupancy.  ViT-S (B=2, N=4, hyp 3) and ViT-B (B=1, N=3, hyp 2: the 12-head / K=768/3072 shapes of
+    BASELINE configs[2] inside a net-vs-reference comparison).  Weights = oracle.weights.seeded_state_dict(seed 4) with
+    the stored calibration applied; mmcv.cnn.ConvModule is the stand-in of oracle/ref_shims.py (mmcv 2.0.0 arithmetic
+    for norm_cfg=None: Conv2d + bias, ReLU)."""
+    _ref()
+    sys.path.insert(0, os.path.join(REF, "model"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import ref_shims
+
+    ref_shims.install()
+    import picopose as ref_picopose
+
+    from oracle.weights import AFFINE_CALIBRATION, HEAD_CALIBRATION, apply_head_calibration, seeded_state_dict
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from netcfg import make_end_points
+
+    out = {}
+    with torch.no_grad():
+        for tag, (vit, B, N, hyp, seed) in {"vits_b2n4": ("dinov2_vits14", 2, 4, 3, 41), "vitb_b1n3": ("dinov2_vitb14", 1, 3, 2, 42)}.items():
+            net = ref_picopose.Net(_cfg(vit)).eval()
+            cal = dict(HEAD_CALIBRATION[vit], affine=AFFINE_CALIBRATION)
+            net.load_state_dict(apply_head_calibration(seeded_state_dict(net.state_dict(), 4), cal))
+            ep = make_end_points(B, N, seed, feature_fn=net.feature_extractor, dome=True)
+            res = net({k: v.clone() for k, v in ep.items()}, hyp)
+            out[f"{tag}/meta"] = np.array([B, N, hyp, seed, 4], dtype=np.int64)
+            out[f"{tag}/vit"] = np.array(vit)
+            for k, v in _cal_arrays(cal).items():
+                out[f"{tag}/{k}"] = v
+            out[f"{tag}/template_feature_probe"] = ep["template_feature"][:, :, ::16, 3, 5].numpy()
+            out[f"{tag}/tem_pose_all"] = ep["tem_pose"].numpy()
+            for k, o in enumerate(res):
+                print(tag, "hyp", k, "valid key-points", (o["pred_tar_pts"][..., 0] >= 0).sum(1).tolist())
+                for key, val in o.items():
+                    if key in ("tar_pts_2d", "src_pts_3d"):   # pure functions of the inputs (a permute of real_pts2d / the
+                        continue                              # selected template's dome): rebuilt by the test, not stored
+                    out[f"{tag}/h{k}/{key}"] = val.numpy()
+    np.savez_compressed(os.path.join(OUT, "e2e_calibrated.npz"), **out)
+    print("calibrated e2e fixtures written")
+
+
+def gen_vit_wide():
+    """FeatureExtractor of the reference at ViT-B/14 and ViT-L/14 (configs[2] / config/base.yaml widths): B=1, the input is
+    regenerated from its seed, only probes of the 4 returned levels are stored."""
+    _ref()
+    sys.path.insert(0, os.path.join(REF, "model"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from model.stage1.feature_extractor import FeatureExtractor
+
+    from oracle.weights import seeded_state_dict
+
+    out = {}
+    with torch.no_grad():
+        for vit, wseed, xseed in (("dinov2_vitb14", 51, 52), ("dinov2_vitl14", 53, 54)):
+            fe = FeatureExtractor(_cfg(vit).stage1).eval()
+            fe.load_state_dict(seeded_state_dict(fe.state_dict(), wseed))
+            x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(xseed))
+            feats = fe(x)
+            out[f"{vit}/seeds"] = np.array([wseed, xseed], dtype=np.int64)
+            out[f"{vit}/pixel_probe"] = torch.stack([f[0, :, 3, 5] for f in feats]).numpy()          # (4, C)
+            out[f"{vit}/channel_probe"] = torch.stack([f[0, ::32] for f in feats]).numpy()           # (4, C/32, 16, 16)
+            out[f"{vit}/absmax"] = np.array([float(f.abs().max()) for f in feats])
+    np.savez_compressed(os.path.join(OUT, "vit_wide.npz"), **out)
+    print("ViT-B / ViT-L fixtures written")
+
+
+def gen_state_dict():
+    """Names, shapes and dtypes of the reference Net's state_dict for ViT-S/B/L (the authors' checkpoint must load)."""
+    import json
+
+    _ref()
+    sys.path.insert(0, os.path.join(REF, "model"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import ref_shims
+
+    ref_shims.install()
+    import picopose as ref_picopose
+
+    table = {}
+    for vit in ("dinov2_vits14", "dinov2_vitb14", "dinov2_vitl14"):
+        sd = ref_picopose.Net(_cfg(vit)).state_dict()
+        table[vit] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
+        print(vit, len(sd), "tensors")
+    with open(os.path.join(OUT, "state_dict_names.json"), "w") as f:
+        json.dump(table, f, separators=(",", ":"))
+
+
+def gen_preprocess():
+    """get_bbox / get_square_bbox of the reference (utils/data_utils.py:131-196) on seeded masks and boxes, including the
+    clamped-at-every-border cases.  data_utils imports cv2 / imageio at module level: empty in-memory modules stand in
+    (neither function touches them)."""
+    import types
+
+    _ref()
+    for name in ("cv2", "imageio"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    from utils.data_utils import get_bbox, get_square_bbox
+
+    rng = np.random.RandomState(77)
+    masks, boxes_in, sizes, ratios, out_mask, out_sq = [], [], [], [], [], []
+    H, W = 48, 64
+    for i in range(40):
+        m = np.zeros((H, W), np.uint8)
+        r0, c0 = rng.randint(0, H - 2), rng.randint(0, W - 2)
+        r1, c1 = rng.randint(r0 + 1, H + 1), rng.randint(c0 + 1, W + 1)
+        if i % 5 == 0:                       # thin / border-hugging / full-frame shapes
+            r0, r1 = (0, H) if i % 10 == 0 else (H - 3, H)
+        if i % 7 == 0:
+            c0, c1 = 0, 2
+        m[r0:r1, c0:c1] = rng.rand(r1 - r0, c1 - c0) < 0.8
+        if not m.any():
+            m[r0, c0] = 1
+        ratio = [1.0, 1.2, 1.5][i % 3]
+        masks.append(m)
+        ratios.append(ratio)
+        out_mask.append(get_bbox(m, ratio))
+    for i in range(60):
+        ih, iw = [(480, 640), (540, 720), (1080, 1920), (300, 200)][i % 4]
+        r0, c0 = rng.randint(-20, ih), rng.randint(-20, iw)
+        r1, c1 = r0 + rng.randint(1, ih), c0 + rng.randint(1, iw)
+        ratio = [1.0, 1.2, 1.5][i % 3]
+        boxes_in.append([r0, r1, c0, c1])
+        sizes.append([ih, iw])
+        out_sq.append(get_square_bbox([r0, r1, c0, c1], (ih, iw), ratio))
+    np.savez_compressed(os.path.join(OUT, "preprocess_boxes.npz"), masks=np.stack(masks), mask_ratio=np.array(ratios),
+                        mask_boxes=np.array(out_mask, np.int64), boxes=np.array(boxes_in, np.int64), sizes=np.array(sizes, np.int64),
+                        box_ratio=np.array([[1.0, 1.2, 1.5][i % 3] for i in range(60)]), square_boxes=np.array(out_sq, np.int64))
+    print("bbox fixtures written")
+
+
+GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry, "nets": gen_nets, "e2e": gen_e2e,
+              "e2e_calibrated": gen_e2e_calibrated, "vit_wide": gen_vit_wide, "state_dict": gen_state_dict,
+              "preprocess": gen_preprocess}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

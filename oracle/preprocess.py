@@ -85,11 +85,11 @@ def crop_instance(image_rgb_u8, mask_u8, det_bbox_xywh, img_size=224, pts_size=6
     mask (H, W), detection box [x, y, w, h] -> dict(rgb (3,S,S) f32, mask (S,S) f32, bbox, M (3,3) f32, pts2d (P,P,2) f64)."""
     h, w = mask_u8.shape
     if np.sum(mask_u8) > minimum_n_point:
-        y1, y2, x1, x2 = get_bbox(mask_u8)
-    else:
-        b = det_bbox_xywh
+        bbox = get_bbox(mask_u8)                                                        # :170-171
+        y1, y2, x1, x2 = bbox
+    else:   # :172-173 — `bbox` is NOT reassigned here: it stays the detection's [x, y, w, h] and feeds M_crop below
+        b = bbox = list(det_bbox_xywh)
         y1, y2, x1, x2 = get_square_bbox([b[1], b[1] + b[3], b[0], b[0] + b[2]], (h, w))
-    bbox = [y1, y2, x1, x2]
     m = mask_u8[y1:y2, x1:x2]
     rgb = image_rgb_u8.astype(np.uint8)[..., ::-1][y1:y2, x1:x2, :3] / 255.0         # data_utils.py:245 (channel flip)
     if rgb_mask_flag:

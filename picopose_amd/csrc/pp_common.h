@@ -20,6 +20,26 @@ __device__ __forceinline__ void pp_split_f16(float v, _Float16& hi, _Float16& lo
 // "hl" operand format (include/picopose_hip.h): half index of element (k, term p) inside a row
 __device__ __forceinline__ int pp_hl_col(int k, int p) { return ((k >> 3) << 4) + (p << 3) + (k & 7); }
 
+// One-time per-DEVICE initialisation (kernel attributes such as the > 64 KB dynamic-LDS opt-in are per device, and a
+// process may drive several GPUs): `state[pp_cur_device()]` is 0 until initialised, then 1 (ok) or -1 (failed).
+// Re-running an initialiser is harmless, so no lock is needed.
+#define PP_MAX_DEVICES 64
+static inline int pp_cur_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= PP_MAX_DEVICES) d = 0;
+    return d;
+}
+static inline int pp_cu_count() {
+    static int cus[PP_MAX_DEVICES];
+    const int d = pp_cur_device();
+    if (cus[d] == 0) {
+        int n = 256;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d);
+        cus[d] = n > 0 ? n : 256;
+    }
+    return cus[d];
+}
+
 static inline int pp_last_launch() { return hipGetLastError() == hipSuccess ? PP_OK : PP_ELAUNCH; }
 
 

@@ -1904,9 +1904,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                 d.ldb, d.conv_kh, d.conv_kw, d.conv_cin, d.b_kn, d.batch0 * d.batch1, (int)((uintptr_t)d.A % 16), (int)((uintptr_t)d.B % 16));
     // block tile 128x128 (3 workgroups/CU) or 128x64 (4/CU): take the one with the shorter makespan
     // rounds(tiles / resident slots) x relative tile time — fixes the wave-quantisation tail of mid-size GEMMs
-    int dev = 0, cus = 256;
-    PP_CHECK_HIP(hipGetDevice(&dev));
-    PP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int cus = pp_cu_count();   // cached per device (two runtime calls per GEMM launch otherwise)
     const long long rows = (d.M + BM - 1) / BM, z = (long long)d.batch0 * d.batch1;
     hipStream_t st = (hipStream_t)stream;
     const bool split = d.prec == PP_PREC_F16X3 && vec;  // unaligned (tiny) layers stay on the fp32 kernel
@@ -1930,17 +1928,20 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     }
     if (d.B_hl && (d.b_kn || d.ldb % 8 != 0 || d.K % 8 != 0 || z != 1 || !(d.b_scale > 0.f))) return PP_EINVAL;
     if (d.B_hl && !split) d.B_hl = nullptr;  // unaligned layer: the fp32 kernel reads d.B
-    static const bool big_ok = [] {
+    static signed char big_state[PP_MAX_DEVICES];   // the > 64 KB dynamic-LDS opt-in is per device
+    signed char& big_ok = big_state[pp_cur_device()];
+    if (big_ok == 0) {
         const int lds = G_STAGES * G_STAGE * 2;
-        return hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
+        big_ok = (hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess;
-    }();
-    if (!big_ok) return PP_ELAUNCH;
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess)
+                     ? 1 : -1;
+    }
+    if (big_ok < 0) return PP_ELAUNCH;
     auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA, 4: persistent LDS-DMA, 5: persistent LDS-DMA with 256x256 tiles
         const bool narrow = cfg == 2;
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);

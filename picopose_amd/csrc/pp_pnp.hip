@@ -542,10 +542,10 @@ int pp_pnp_ransac(const float* tar_pts_2d, const float* src_pts_3d, const float*
     if (P <= 0 || H <= 0 || W <= 0 || N <= 0 || N > MAXP || iterations <= 0 || reproj_threshold <= 0.f) return PP_EINVAL;
     const size_t smem = (size_t)MAXP * (3 + 2) * sizeof(float) + MAXP + NT * sizeof(double) + (size_t)NT * 12 * sizeof(double) +
                         NT * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[PP_MAX_DEVICES];   // the dynamic-LDS opt-in is per device
+    if (!attr_set[pp_cur_device()]) {
         PP_CHECK_HIP(hipFuncSetAttribute((const void*)pnp_ransac_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
+        attr_set[pp_cur_device()] = true;
     }
     hipLaunchKernelGGL(pnp_ransac_kernel, dim3(P), dim3(NT), smem, (hipStream_t)stream, tar_pts_2d, src_pts_3d, K,
                        tem_pose, tar_pts, src_pts, H, W, N, iterations, reproj_threshold, rot, tvec, inlier_ratio,

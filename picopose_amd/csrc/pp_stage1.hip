@@ -985,21 +985,21 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask, i
     // halves / two per CU
     const char* nw_env = getenv("PP_S1_WAVES");  // read per call: the tests run both shapes in one process
     const int nw = nw_env && atoi(nw_env) == 4 ? 4 : 8;
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n;
-    }();
-    static const bool lds_ok = [] {  // > 64 KB of dynamic LDS needs the opt-in
+    const int cus = pp_cu_count();
+    static signed char lds_state[PP_MAX_DEVICES];   // > 64 KB of dynamic LDS needs the opt-in, per device
+    signed char& lds_ok = lds_state[pp_cur_device()];
+    if (lds_ok == 0) {
         auto set = [](const void* f, int bytes) {
             return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
         };
-        return set((const void*)s1_main<PP_MATCH_FAST, 4>, Lay<4>::SMEM_BYTES) &&
-               set((const void*)s1_main<PP_MATCH_EXACT, 4>, Lay<4>::SMEM_BYTES) &&
-               set((const void*)s1_main<PP_MATCH_FAST, 8>, Lay<8>::SMEM_BYTES) &&
-               set((const void*)s1_main<PP_MATCH_EXACT, 8>, Lay<8>::SMEM_BYTES);
-    }();
-    if (!lds_ok) return PP_ELAUNCH;
+        lds_ok = set((const void*)s1_main<PP_MATCH_FAST, 4>, Lay<4>::SMEM_BYTES) &&
+                 set((const void*)s1_main<PP_MATCH_EXACT, 4>, Lay<4>::SMEM_BYTES) &&
+                 set((const void*)s1_main<PP_MATCH_FAST, 8>, Lay<8>::SMEM_BYTES) &&
+                 set((const void*)s1_main<PP_MATCH_EXACT, 8>, Lay<8>::SMEM_BYTES) &&
+                 set((const void*)s1_resolve, 10 * 2048 * (int)sizeof(float))   // 10 * C floats, C <= 2048
+                     ? 1 : -1;
+    }
+    if (lds_ok < 0) return PP_ELAUNCH;
     {
         PpProfScope prof(stream);  // roofline kernel of stage 1 (bench.py)
         const int total = nw == 8 ? B * N : B * 2 * N, slots = nw == 8 ? cus : 2 * cus;

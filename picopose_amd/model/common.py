@@ -78,12 +78,12 @@ class Packed(nn.Module):
         self._pack_cache = None
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, *a, **k):
+        # nn.Module.load_state_dict recurses through `_load_from_state_dict` of EVERY module of the tree — this hook
+        # fires when a checkpoint is loaded through any ancestor (Net.load_state_dict, Lite.load_from_checkpoint),
+        # whereas an override of load_state_dict only sees loads that start at this very module
         self._pack_cache = None
-        for m in self.modules():
-            if isinstance(m, Packed):
-                m._pack_cache = None
-        return super().load_state_dict(*a, **k)
+        return super()._load_from_state_dict(*a, **k)
 
     def packed(self):
         if self._pack_cache is None:

@@ -2,7 +2,7 @@
 utils/data_utils.py:131-196, 231-250 on the device.
 
 The bounding-box arithmetic, the crop affine `M`, the 64x64 lookup grid `pts2d`, the channel flip and the CLIP
-normalisation follow the reference line by line; the two `cv2.resize` calls run in `pp_crop_resize_normalize`
+normalisation give the reference's values (boxes pinned by reference-generated fixtures, tests/golden/preprocess_boxes.npz); the two `cv2.resize` calls run in `pp_crop_resize_normalize`
 (OpenCV's published INTER_LINEAR / INTER_NEAREST definitions; cv2 is not available here to pin them bit-for-bit).
 File IO (image / RLE decoding) stays with the caller."""
 import ctypes
@@ -16,25 +16,24 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)       # bop_test_dataset.py:40
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)       # bop_test_dataset.py:41
 
 
+def _fit_axis(lo, hi, side, limit):
+    """A window of `side` (truncated to an even number of pixels) centred on the integer midpoint of [lo, hi), pushed back
+    inside [0, limit]: first off the low border, then off the high one (it may then stick out below 0 again, as upstream)."""
+    mid, half = int((lo + hi) / 2), int(side / 2)
+    a, b = mid - half, mid + half
+    if a < 0:
+        a, b = 0, b - a
+    if b > limit:
+        a, b = a - (b - limit), limit
+    return int(a), int(b)
+
+
 def _square(rmin, rmax, cmin, cmax, img_width, img_length, size_ratio=1.0):
-    r_b, c_b = rmax - rmin, cmax - cmin
-    b = min(max(r_b, c_b), min(img_width, img_length)) * size_ratio
-    center = [int((rmin + rmax) / 2), int((cmin + cmax) / 2)]
-    rmin, rmax = center[0] - int(b / 2), center[0] + int(b / 2)
-    cmin, cmax = center[1] - int(b / 2), center[1] + int(b / 2)
-    if rmin < 0:
-        rmax += -rmin
-        rmin = 0
-    if cmin < 0:
-        cmax += -cmin
-        cmin = 0
-    if rmax > img_width:
-        rmin -= rmax - img_width
-        rmax = img_width
-    if cmax > img_length:
-        cmin -= cmax - img_length
-        cmax = img_length
-    return [int(rmin), int(rmax), int(cmin), int(cmax)]
+    """Square window of utils/data_utils.py:139-165 (= :170-196): side = the larger extent, capped by the smaller image
+    dimension, times size_ratio; rows and columns are fitted independently.  Pinned by tests/golden/preprocess_boxes.npz
+    (outputs of the reference functions)."""
+    side = min(max(rmax - rmin, cmax - cmin), min(img_width, img_length)) * size_ratio
+    return [*_fit_axis(rmin, rmax, side, img_width), *_fit_axis(cmin, cmax, side, img_length)]
 
 
 def get_bbox(label, size_ratio=1.0):
@@ -61,11 +60,14 @@ def crop_instance(image_u8, mask_u8, det_bbox_xywh, img_size=224, pts_size=64, m
     h, w = mask_u8.shape
     assert image_u8.shape[:2] == (h, w)
     if np.sum(mask_u8) > minimum_n_point:
-        y1, y2, x1, x2 = get_bbox(mask_u8)
+        bbox = get_bbox(mask_u8)
+        y1, y2, x1, x2 = bbox
     else:
-        b = det_bbox_xywh
+        # bop_test_dataset.py:172-173: the crop window comes from the detection box, but `bbox` — which feeds M_crop and
+        # is returned — stays the detection's [x, y, w, h] (an upstream quirk: M then translates by (-w, -x)); kept for
+        # parity with the reference's outputs on such instances
+        b = bbox = list(det_bbox_xywh)
         y1, y2, x1, x2 = get_square_bbox([b[1], b[1] + b[3], b[0], b[0] + b[2]], (h, w))
-    bbox = [y1, y2, x1, x2]
     img_d = torch.from_numpy(image_u8).to(device)
     msk_d = torch.from_numpy(mask_u8).to(device)
     rgb = torch.empty(3, img_size, img_size, dtype=torch.float32, device=device)

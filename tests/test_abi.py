@@ -32,3 +32,60 @@ def test_argument_validation_needs_no_gpu():
     # null pointers / unsupported channel count are rejected before any HIP call
     assert L.pp_stage1_scores(None, None, None, 224, 224, 1, 1, 64, 1, 0.0, None, 0, None, None, None) == -1
     assert L.pp_topk(None, 1, 4, 2, None, None, None) == -1
+
+
+def test_state_dict_names_shapes_equal_the_reference(golden_dir):
+    """`Net(cfg).state_dict()` must carry the reference Net's tensors — same names, same ORDER, same shapes and
+    dtypes — for ViT-S/B/L, so that Lite.load_from_checkpoint(..., network=model) loads the authors' checkpoint
+    (run_test.py:272).  Fixture: tests/golden/state_dict_names.json, dumped from the reference (oracle/gen_golden.py)."""
+    import json
+    import os
+    import types
+
+    from picopose_amd.picopose import Net
+
+    ns = types.SimpleNamespace
+    table = json.load(open(os.path.join(golden_dir, "state_dict_names.json")))
+    widths = {"dinov2_vits14": (384, [[0, 2], [3, 5], [6, 8], [9, 11]]), "dinov2_vitb14": (768, [[0, 2], [3, 5], [6, 8], [9, 11]]),
+              "dinov2_vitl14": (1024, [[0, 5], [6, 11], [12, 17], [18, 23]])}
+    assert set(table) == set(widths)
+    for vit, (C, idx) in widths.items():
+        cfg = ns(hypothesis=5, stage1=ns(vit_type=vit, pretrained=False, interaction_indexes=idx), stage2=ns(in_channel=256, hidden_dim=256),
+                 stage3=ns(nclass=1, in_channels=C, use_bn=True, out_channels=[256, 512, 1024, 1024], num_levels=3, radius=4))
+        got = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in Net(cfg).state_dict().items()]
+        assert got == table[vit], next((a, b) for a, b in zip(got, table[vit]) if a != b)
+    assert len(table["dinov2_vitl14"]) == 603
+
+
+def test_pack_cache_is_dropped_when_a_checkpoint_loads_through_the_top_level_net():
+    """nn.Module.load_state_dict never calls a child's load_state_dict, so a pack-once cache keyed on
+    nothing survived `Net.load_state_dict` and later forwards mixed old packed conv weights with new linears."""
+    import sys
+    import os
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from netcfg import small_cfg
+
+    from picopose_amd.model.common import Packed
+    from picopose_amd.picopose import Net
+    from picopose_amd.utils.seeding import seeded_state_dict
+
+    net = Net(small_cfg())
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 1))
+    packed = [m for m in net.modules() if isinstance(m, Packed)]
+    assert len(packed) >= 4
+    fd = net.offset_regressor.flow_decoder
+    old = fd.packed()["fp0_p"].clone()                       # packs on first use (pure re-layout: runs on the CPU too)
+    for m in packed:
+        m._pack_cache = m._pack_cache or {"stale": True}
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 2))
+    assert all(m._pack_cache is None for m in packed)
+    assert not torch.equal(fd.packed()["fp0_p"], old)
+    # loading through a wrapper one level further up (Lightning's `network.` prefix) drops it as well
+    wrapper = torch.nn.Module()
+    wrapper.network = net
+    fd.packed()
+    wrapper.load_state_dict({"network." + k: v for k, v in seeded_state_dict(net.state_dict(), 3).items()})
+    assert fd._pack_cache is None

@@ -155,3 +155,130 @@ def test_infer_image_walks_instances_like_run_test():
     for got, ref in zip(infer_image(net, data, tem, hyp=hyp, bs=2), preds):
         for g, r in zip(got, ref):
             assert np.array_equal(g["R_stage_3"], r["R_stage_3"]) and np.array_equal(g["t_stage_3"], r["t_stage_3"])
+
+
+# ---- calibrated heads + dome geometry: the network -> key-points -> PnP chain on realistic occupancy ---------------------
+CAL_CASES = ["vits_b2n4", "vitb_b1n3"]
+VIT_CFG = {"dinov2_vits14": (384, 6, [[0, 2], [3, 5], [6, 8], [9, 11]]), "dinov2_vitb14": (768, 12, [[0, 2], [3, 5], [6, 8], [9, 11]])}
+
+
+def _vit_cfg(vit):
+    import types
+
+    ns = types.SimpleNamespace
+    C, _, idx = VIT_CFG[vit]
+    return ns(hypothesis=5, stage1=ns(vit_type=vit, pretrained=False, interaction_indexes=idx), stage2=ns(in_channel=256, hidden_dim=256),
+              stage3=ns(nclass=1, in_channels=C, use_bn=True, out_channels=[256, 512, 1024, 1024], num_levels=3, radius=4))
+
+
+def _load_cal(golden_dir, tag):
+    from oracle.weights import apply_head_calibration
+
+    z = np.load(os.path.join(golden_dir, "e2e_calibrated.npz"))
+    B, N, hyp, seed, wseed = (int(v) for v in z[f"{tag}/meta"])
+    vit = str(z[f"{tag}/vit"])
+    cal = {"flow": [tuple(r) for r in z[f"{tag}/cal_flow"]], "cert": [tuple(r) for r in z[f"{tag}/cal_cert"]],
+           "affine": {h: (float(z[f"{tag}/cal_affine_{h}"][0]), tuple(z[f"{tag}/cal_affine_{h}"][1:]))
+                      for h in ("translation", "scale", "inplane")}}
+    ref = [{k.split("/", 2)[2]: z[k] for k in z.files if k.startswith(f"{tag}/h{h}/")} for h in range(hyp)]
+    weights = lambda template: apply_head_calibration(seeded_state_dict(template, wseed), cal)  # noqa: E731
+    return z, B, N, hyp, seed, vit, ref, weights
+
+
+def _valid(pts):
+    return (pts[..., 0] >= 0).sum(-1)
+
+
+@pytest.mark.parametrize("tag", CAL_CASES)
+def test_oracle_forward_vs_reference_calibrated(golden_dir, tag):
+    from picopose_amd.picopose import Net
+
+    torch.set_num_threads(8)
+    z, B, N, hyp, seed, vit, ref, weights = _load_cal(golden_dir, tag)
+    _, heads, idx = VIT_CFG[vit]
+    take = [b[-1] for b in idx]
+    sd = weights(Net(_vit_cfg(vit)).state_dict())
+    fe = lambda x: on.vit_features(sd, x, heads, take)  # noqa: E731
+    ep = make_end_points(B, N, seed, feature_fn=fe, tem_pose=torch.from_numpy(z[f"{tag}/tem_pose_all"]), dome=True)
+    assert np.abs(ep["template_feature"][:, :, ::16, 3, 5].numpy() - z[f"{tag}/template_feature_probe"]).max() < 1e-4
+    outs, aux = on.net_forward_test(sd, ep, hyp, heads, take)
+    for h in range(hyp):
+        assert _valid(ref[h]["pred_tar_pts"]).min() >= 1000                           # the fixture carries data
+        assert np.array_equal(outs[h]["tem_pose"].numpy(), ref[h]["tem_pose"])        # same templates picked
+        assert np.abs(outs[h]["pred_poses"].numpy() - ref[h]["pred_poses"]).max() <= 1e-4
+        bad = _keypoint_mismatch_is_explained(outs[h]["pred_tar_pts"].numpy(), outs[h]["pred_src_pts"].numpy(),
+                                              ref[h]["pred_tar_pts"], ref[h]["pred_src_pts"], aux["flow"][h].numpy(),
+                                              aux["cert"][h].numpy(), rel=2e-5)
+        assert bad <= 4 * B
+
+
+def _hip_calibrated_forward(golden_dir, tag):
+    from picopose_amd.picopose import Net
+
+    z, B, N, hyp, seed, vit, ref, weights = _load_cal(golden_dir, tag)
+    _, heads, idx = VIT_CFG[vit]
+    net = Net(_vit_cfg(vit))
+    sd = weights(net.state_dict())
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    ep = make_end_points(B, N, seed, tem_pose=torch.from_numpy(z[f"{tag}/tem_pose_all"]), dome=True)
+    dev = {k: v.cuda() for k, v in ep.items()}
+    dev["template_feature"] = torch.stack([net.feature_extractor(dev["tem_rgb"][b])[-1] for b in range(B)])
+    net.keep_stage3 = True
+    outs = net(dev, hyp)
+    fl, ce = net.last_stage3                              # NHWC, hypothesis-major (hyp*B, 64, 64, c)
+    flow = fl.permute(0, 3, 1, 2).reshape(hyp, B, 2, 64, 64).cpu().numpy()
+    cert = ce.permute(0, 3, 1, 2).reshape(hyp, B, 1, 64, 64).cpu().numpy()
+    return z, B, N, hyp, ref, ep, dev, outs, flow, cert
+
+
+def _check_hip_vs_reference(z, tag, B, hyp, ref, outs, flow, cert):
+    total_bad = 0
+    for h in range(hyp):
+        o = {k: v.cpu().numpy() for k, v in outs[h].items()}
+        assert np.array_equal(o["tem_pose"], ref[h]["tem_pose"])                        # template ids: exact
+        assert np.abs(o["pred_poses"] - ref[h]["pred_poses"]).max() <= 1e-4             # north_star tolerance
+        assert o["pred_tar_pts"].dtype == np.int64 and o["pred_tar_pts"].shape == ref[h]["pred_tar_pts"].shape
+        # every slot that differs from the REFERENCE's list lies on a threshold of OUR flow / certainty maps within the
+        # float tolerance stated for the offset tensors (5e-4 * max|tensor|): logit ~ 0, coordinate ~ integer
+        total_bad += _keypoint_mismatch_is_explained(o["pred_tar_pts"], o["pred_src_pts"], ref[h]["pred_tar_pts"],
+                                                     ref[h]["pred_src_pts"], flow[h], cert[h])
+        assert _valid(o["pred_tar_pts"]).min() >= 1000
+    assert total_bad <= 0.002 * hyp * B * 4096, total_bad
+    return total_bad
+
+
+@gpu
+@pytest.mark.parametrize("tag", CAL_CASES)
+def test_hip_forward_vs_reference_calibrated(golden_dir, tag):
+    """~2500-3200 valid key-points per hypothesis (fixture from the reference Net): template ids exact, stage-2 poses
+    1e-4, key-point lists bit-equal except threshold cases; then PnP/RANSAC on them."""
+    from picopose_amd.pipeline import pnp_for_outputs
+    from oracle import pnp as opnp
+
+    z, B, N, hyp, ref, ep, dev, outs, flow, cert = _hip_calibrated_forward(golden_dir, tag)
+    _check_hip_vs_reference(z, tag, B, hyp, ref, outs, flow, cert)
+    rot, tvec, ratio, ok, npts = pnp_for_outputs(outs, dev["real_K"], return_npts=True)
+    assert npts.min() >= 1000 and ok.all()
+    for h in range(hyp):
+        for b in range(B):
+            # CPU oracle of PnP/RANSAC on the REFERENCE's key-point lists (same sampling sequence: problem id h*B+b)
+            t2 = ep["real_pts2d"][b].permute(2, 1, 0).numpy()
+            sel = int(np.argmax([np.array_equal(ep["tem_pose"][b, n].numpy(), ref[h]["tem_pose"][b]) for n in range(N)]))
+            s3 = ep["tem_pts3d"][b, sel].permute(2, 0, 1).numpy()
+            orot, otvec, oratio, ook = opnp.pose_recovery_ransac_pnp(t2, s3, ep["real_K"][b].numpy(), ref[h]["tem_pose"][b],
+                                                                     ref[h]["pred_tar_pts"][b], ref[h]["pred_src_pts"][b], prob=h * B + b)
+            assert ook and abs(oratio - ratio[h, b]) < 0.03, (h, b, oratio, ratio[h, b])
+            assert np.abs(otvec - tvec[h, b]).max() < 0.01 and np.abs(orot - rot[h, b]).max() < 0.03, (h, b, otvec.ravel(), tvec[h, b].ravel())
+            # and the pose is the one stage 2 predicted, refined (the dome is consistent with the affine): same ballpark
+            assert np.abs(tvec[h, b, :, 0] - ref[h]["pred_poses"][b, :3, 3]).max() < 0.15
+
+
+@gpu
+@pytest.mark.parametrize("cfg", ["4", "5"])
+def test_hip_forward_vitb_with_pinned_persistent_kernels(golden_dir, monkeypatch, cfg):
+    """The ViT-B net-vs-reference comparison with every pre-split GEMM / conv forced onto the persistent 256x128 (cfg 4)
+    and 256x256 (cfg 5) kernels — the kernels the headline bench runs — instead of the autotuner's pick."""
+    monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
+    z, B, N, hyp, ref, ep, dev, outs, flow, cert = _hip_calibrated_forward(golden_dir, "vitb_b1n3")
+    _check_hip_vs_reference(z, "vitb_b1n3", B, hyp, ref, outs, flow, cert)

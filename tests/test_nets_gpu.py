@@ -128,3 +128,32 @@ def test_offset_regressor_vs_reference_golden(golden_dir):
         # offsets in pixels / certainty logits: stated tolerance 5e-4 relative to the tensor's max (fp32 both sides)
         _close(fl[i], z[f"s3/flow{i}"], 5e-4)
         _close(ce[i], z[f"s3/cert{i}"], 5e-4)
+
+
+@gpu
+@pytest.mark.parametrize("vit", ["dinov2_vitb14", "dinov2_vitl14"])
+@pytest.mark.parametrize("force", [None, "4", "5"])
+def test_feature_extractor_vs_reference_golden_vitb_vitl(golden_dir, monkeypatch, vit, force):
+    """FeatureExtractor at the widths of BASELINE configs[2] (ViT-B/14) and config/base.yaml (ViT-L/14) against the
+    reference's outputs (tests/golden/vit_wide.npz) — with the autotuner's kernels, and with every pre-split GEMM pinned
+    to the persistent 256x128 (4) / 256x256 (5) kernels the headline bench runs."""
+    import numpy as np
+    import types
+
+    from picopose_amd.model.stage1 import FeatureExtractor
+
+    if force is not None:
+        monkeypatch.setenv("PP_GEMM_FORCE_CFG", force)
+    C, idx = {"dinov2_vitb14": (768, [[0, 2], [3, 5], [6, 8], [9, 11]]), "dinov2_vitl14": (1024, [[0, 5], [6, 11], [12, 17], [18, 23]])}[vit]
+    z = np.load(os.path.join(golden_dir, "vit_wide.npz"))
+    wseed, xseed = (int(v) for v in z[f"{vit}/seeds"])
+    fe = FeatureExtractor(types.SimpleNamespace(vit_type=vit, pretrained=False, interaction_indexes=idx))
+    fe.load_state_dict(seeded_state_dict(fe.state_dict(), wseed))
+    fe = fe.cuda().eval()
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(xseed))
+    feats = fe(x.cuda())
+    assert len(feats) == 4 and feats[0].shape == (1, C, 16, 16)
+    for l, f in enumerate(feats):          # tolerance: 2e-4 * max|level| as for ViT-S (24 blocks of fp32 reassociation at ViT-L)
+        amax = float(z[f"{vit}/absmax"][l])
+        assert float(np.abs(f[0, :, 3, 5].cpu().numpy() - z[f"{vit}/pixel_probe"][l]).max()) <= 2e-4 * amax
+        assert float(np.abs(f[0, ::32].cpu().numpy() - z[f"{vit}/channel_probe"][l]).max()) <= 2e-4 * amax

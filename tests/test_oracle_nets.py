@@ -68,3 +68,27 @@ def test_corr_lookup_oracle_vs_reference(golden_dir):
     out = on.corr_lookup(t["corr/f1"], t["corr/f2"], t["corr/flow"], 3, 2)
     assert out.shape == (2, 75, 16, 16)
     _close(out, z["corr/out"], 1e-6)
+
+
+def _wide_cfg(vit):
+    import types
+
+    C, heads, idx = {"dinov2_vitb14": (768, 12, [[0, 2], [3, 5], [6, 8], [9, 11]]),
+                     "dinov2_vitl14": (1024, 16, [[0, 5], [6, 11], [12, 17], [18, 23]])}[vit]
+    return types.SimpleNamespace(vit_type=vit, pretrained=False, interaction_indexes=idx), heads, [b[-1] for b in idx]
+
+
+def test_vit_oracle_vs_reference_at_vitb_and_vitl(golden_dir):
+    """The widths the bench and config/base.yaml run (ViT-B/14: 12 heads, K = 768/3072; ViT-L/14: 24 blocks, 16 heads)."""
+    from picopose_amd.model.stage1 import FeatureExtractor
+
+    z = np.load(os.path.join(golden_dir, "vit_wide.npz"))
+    torch.set_num_threads(8)
+    for vit in ("dinov2_vitb14", "dinov2_vitl14"):
+        s1, heads, take = _wide_cfg(vit)
+        wseed, xseed = (int(v) for v in z[f"{vit}/seeds"])
+        sd = seeded_state_dict(FeatureExtractor(s1).state_dict(), wseed)
+        x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(xseed))
+        feats = on.vit_features({"feature_extractor." + k: v for k, v in sd.items()}, x, heads, take)
+        _close(torch.stack([f[0, :, 3, 5] for f in feats]), z[f"{vit}/pixel_probe"], 1e-5)
+        _close(torch.stack([f[0, ::32] for f in feats]), z[f"{vit}/channel_probe"], 1e-5)

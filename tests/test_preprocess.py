@@ -34,6 +34,35 @@ def test_bbox_logic_matches_oracle_and_known_answers():
         assert hp.get_bbox(mk) == op.get_bbox(mk)
 
 
+def test_boxes_equal_the_reference_functions_outputs(golden_dir):
+    """Product AND oracle against tests/golden/preprocess_boxes.npz = outputs of the reference's own get_bbox /
+    get_square_bbox (utils/data_utils.py:131-196; oracle/gen_golden.py gen_preprocess), incl. boxes clamped at every border."""
+    import os
+
+    from picopose_amd.utils import preprocess as hp
+
+    z = np.load(os.path.join(golden_dir, "preprocess_boxes.npz"))
+    for m, ratio, want in zip(z["masks"], z["mask_ratio"], z["mask_boxes"]):
+        assert hp.get_bbox(m, float(ratio)) == op.get_bbox(m, float(ratio)) == want.tolist()
+    for box, size, ratio, want in zip(z["boxes"], z["sizes"], z["box_ratio"], z["square_boxes"]):
+        args = ([int(v) for v in box], (int(size[0]), int(size[1])), float(ratio))
+        assert hp.get_square_bbox(*args) == op.get_square_bbox(*args) == want.tolist()
+
+
+def test_small_mask_branch_keeps_the_detection_box_like_the_reference():
+    # bop_test_dataset.py:170-185: with <= minimum_n_point mask pixels the crop WINDOW comes from the detection box but
+    # `bbox` (returned, and used by M_crop as [-bbox[2], -bbox[0]]) stays the detection's [x, y, w, h]
+    img, mask, det = _case(2)
+    mask[:] = 0
+    mask[5, 5] = 1
+    ref = op.crop_instance(img, mask, det)
+    x, y, w, h = det
+    y1, y2, x1, x2 = op.get_square_bbox([y, y + h, x, x + w], mask.shape)
+    assert ref["bbox"] == det
+    assert np.allclose(ref["M"], np.array([[224 / (y2 - y1), 0, -w * 224 / (y2 - y1)], [0, 224 / (x2 - x1), -x * 224 / (x2 - x1)],
+                                           [0, 0, 1]], np.float32))
+
+
 def test_oracle_resize_known_answers():
     ramp = np.arange(8, dtype=np.float64)[None, :, None].repeat(4, 0)
     up = op.resize_linear(ramp, 16)[0, :, 0]                                      # 2x upsampling of a ramp: pixel-centre alignment
