@@ -386,6 +386,11 @@ def main():
         _lib.check(L.pp_prof_gemm_collect(g_ms, g_fl, g_n), "pp_prof_gemm_collect")
         _lib.check(L.pp_prof_gemm_enable(0), "pp_prof_gemm_enable")
         gemm = {"ms": list(g_ms), "flops": list(g_fl), "launches": list(g_n)}
+        sat_checked = None
+        if a.mode == "fast":    # one more untimed forward that verifies every f16x3 operand buffer it produces (raises on saturation)
+            n0, ops.CHECK_SATURATION = ops.saturation_checks, True
+            forward()
+            ops.CHECK_SATURATION, sat_checked = False, ops.saturation_checks - n0
         args = pnp_inputs(outs, ep["real_K"])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         pnp_launch(*args)
@@ -421,20 +426,29 @@ def main():
             net.keep_stage3 = False
             ops.PRECISION, net.match_mode = "f16x3", a.mode
             xouts, (xrot, xtvec, _, xok) = xo
-            same_t = torch.stack([o["tem_pose"] for o in xouts]) == fast["ids"]
+            import numpy as np
+
+            # stage 1 ranks 162 random templates whose scores differ in the 4th digit: the two arithmetic modes may order a
+            # near-tie differently, and a different template is a different problem — compare the (crop, hypothesis) pairs
+            # that chose the same template, and report how many did
+            same = (torch.stack([o["tem_pose"] for o in xouts]) == fast["ids"]).flatten(2).all(-1)          # (hyp, B)
             xtar = torch.stack([o["pred_tar_pts"] for o in xouts])
-            both = ok & xok
+            sm = same.cpu().numpy()
+            flat = same.reshape(-1)
+            both = ok & xok & sm
+            dpose = (torch.stack([o["pred_poses"] for o in xouts]) - fast["poses"]).abs()[same]
             exact = {"value": Bl / x_dt, "unit": "crops/s", "ms_per_step": x_dt * 1e3,
                      "dtype": "f32 (v_mfma_f32_32x32x2_f32 in every kernel, exact-fp32 stage 1; PnP f64)",
                      "f16x3_vs_exact": {
-                         "same_templates": bool(same_t.all()),
-                         "pred_poses_max_abs": float((torch.stack([o["pred_poses"] for o in xouts]) - fast["poses"]).abs().max()),
-                         "flow_max_abs_px": float((net.last_stage3[0] - fast["flow"]).abs().max()),
+                         "pairs": int(same.numel()), "pairs_with_same_template": int(same.sum()),
+                         "pred_poses_max_abs": float(dpose.max()),
+                         "flow_max_abs_px": float((net.last_stage3[0] - fast["flow"]).abs()[flat].max()),
                          "flow_max_abs_value": float(fast["flow"].abs().max()),
-                         "certainty_logit_max_abs": float((net.last_stage3[1] - fast["cert"]).abs().max()),
-                         "keypoint_slots_equal": float((xtar == fast["tar"]).all(-1).float().mean()),
+                         "certainty_logit_max_abs": float((net.last_stage3[1] - fast["cert"]).abs()[flat].max()),
+                         "keypoint_slots_equal": float((xtar == fast["tar"]).all(-1)[same].float().mean()),
                          "pnp_translation_max_abs_m": float(abs(xtvec - tvec)[both].max()) if both.any() else None,
-                         "pnp_translation_median_abs_m": float(__import__("numpy").median(abs(xtvec - tvec)[both])) if both.any() else None}}
+                         "pnp_translation_median_abs_m": float(np.median(abs(xtvec - tvec)[both])) if both.any() else None,
+                         "note": "compared on the (crop, hypothesis) pairs for which both modes picked the same template"}}
 
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -514,6 +528,10 @@ def main():
                                 "engine": "f32: v_mfma_f32_32x32x2_f32", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
                                 "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "gflop_per_crop": full_gflop_per_crop(N, vit, cached=cached)}
             line["pnp"] = pnp
+            if sat_checked is not None:
+                line["f16x3_operand_range"] = {"operands_verified": sat_checked, "saturated": 0,
+                                               "note": "every operand buffer of one untimed forward checked against the fp16 clamp "
+                                                       "(|activation| < 16376, picopose_amd/ops.py CHECK_SATURATION); a hit aborts the bench"}
             if exact is not None:
                 line["exact_mode"] = exact
         if world == 1 and not a.no_cpu_baseline:

@@ -28,11 +28,11 @@ def measure(sd_raw, ep, heads, take, template=0):
     from oracle import geometry as og
     from oracle import matching as om
     from oracle import nets as on
-    from oracle.weights import AFFINE_CALIBRATION, apply_head_calibration
+    from oracle.weights import AFFINE_CALIBRATION, PROJ_BN_GAIN, apply_head_calibration
 
     cal = {"flow": [(1.0, 0.0)] * 3, "cert": [(1.0, 0.0)] * 3}
     with torch.no_grad():
-        sd = apply_head_calibration(sd_raw, dict(cal, affine=AFFINE_CALIBRATION))
+        sd = apply_head_calibration(sd_raw, dict(cal, affine=AFFINE_CALIBRATION, proj_bn=PROJ_BN_GAIN))
         fr = on.vit_features(sd, ep["real_rgb"], heads, take)
         ft = on.vit_features(sd, ep["tem_rgb"][:, template], heads, take)
         sim = om.matching_features_similarity(ft[-1], fr[-1], ep["tem_mask"][:, template], None)
@@ -42,7 +42,7 @@ def measure(sd_raw, ep, heads, take, template=0):
         dt, dr = on.dpt_head(sd, ft), on.dpt_head(sd, fr)
         up = lambda x: torch.nn.functional.interpolate(x, scale_factor=(2, 2), mode="bilinear", align_corners=True)  # noqa: E731
         for l in range(3):
-            sd = apply_head_calibration(sd_raw, dict(cal, affine=AFFINE_CALIBRATION))
+            sd = apply_head_calibration(sd_raw, dict(cal, affine=AFFINE_CALIBRATION, proj_bn=PROJ_BN_GAIN))
             fl, ce = on.flow_decoder(sd, dt, dr, f0, c0)
             prev_f = f0 if l == 0 else 2 * up(fl[l - 1])
             prev_c = c0 if l == 0 else up(ce[l - 1])
@@ -52,7 +52,20 @@ def measure(sd_raw, ep, heads, take, template=0):
                 shift = -gain * float(d.mean())          # added to the (scaled) bias: zero-mean update
                 cal[key] = list(cal[key])
                 cal[key][l] = (gain, shift)
-    return cal, (t, s, ip)
+    # largest activation the flow decoder sees with the final calibration (the f16x3 engine needs < 16376)
+    seen = [0.0]
+    relu = torch.nn.functional.relu
+
+    def spy(x, *a, **k):
+        seen[0] = max(seen[0], float(x.abs().max()))
+        return relu(x, *a, **k)
+
+    torch.nn.functional.relu, on.F.relu = spy, spy
+    try:
+        on.flow_decoder(apply_head_calibration(sd_raw, dict(cal, affine=AFFINE_CALIBRATION, proj_bn=PROJ_BN_GAIN)), dt, dr, f0, c0)
+    finally:
+        torch.nn.functional.relu, on.F.relu = relu, relu
+    return cal, (t, s, ip, seen[0], max(float(d.abs().max()) for d in dt + dr))
 
 
 if __name__ == "__main__":
@@ -65,6 +78,7 @@ if __name__ == "__main__":
         C, heads, idx, _ = bench.VIT[vit]
         sd = seeded_state_dict(Net(bench.make_cfg(vit)).state_dict(), 4)
         ep = {k: v.cpu() for k, v in bench.make_end_points(2, 2, "cpu", 100).items()}
-        cal, _ = measure(sd, ep, heads, [b[-1] for b in idx])
+        cal, info = measure(sd, ep, heads, [b[-1] for b in idx])
+        print(f"    # {vit}: max |pre-ReLU activation| in the flow decoder {info[3]:.0f}, max |DPT map| {info[4]:.0f}")
         print(f'    "{vit}": {{"flow": {[(float("%.4g" % g), float("%.4g" % s)) for g, s in cal["flow"]]},')
         print(f'                     "cert": {[(float("%.4g" % g), float("%.4g" % s)) for g, s in cal["cert"]]}}},', flush=True)

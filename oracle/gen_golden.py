@@ -277,6 +277,7 @@ def _cfg(vit):
 def _cal_arrays(cal):
     """calibration dict -> arrays stored in a fixture (tests rebuild the weights from them, not from the table)."""
     return {"cal_flow": np.array(cal["flow"], np.float64), "cal_cert": np.array(cal["cert"], np.float64),
+            "cal_proj_bn": np.float64(cal["proj_bn"]),
             **{f"cal_affine_{h}": np.array([g, *shift], np.float64) for h, (g, shift) in cal["affine"].items()}}
 
 
@@ -295,7 +296,7 @@ def gen_e2e_calibrated():
     ref_shims.install()
     import picopose as ref_picopose
 
-    from oracle.weights import AFFINE_CALIBRATION, HEAD_CALIBRATION, apply_head_calibration, seeded_state_dict
+    from oracle.weights import AFFINE_CALIBRATION, HEAD_CALIBRATION, PROJ_BN_GAIN, apply_head_calibration, seeded_state_dict
 
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
     from netcfg import make_end_points
@@ -304,7 +305,7 @@ def gen_e2e_calibrated():
     with torch.no_grad():
         for tag, (vit, B, N, hyp, seed) in {"vits_b2n4": ("dinov2_vits14", 2, 4, 3, 41), "vitb_b1n3": ("dinov2_vitb14", 1, 3, 2, 42)}.items():
             net = ref_picopose.Net(_cfg(vit)).eval()
-            cal = dict(HEAD_CALIBRATION[vit], affine=AFFINE_CALIBRATION)
+            cal = dict(HEAD_CALIBRATION[vit], affine=AFFINE_CALIBRATION, proj_bn=PROJ_BN_GAIN)
             net.load_state_dict(apply_head_calibration(seeded_state_dict(net.state_dict(), 4), cal))
             ep = make_end_points(B, N, seed, feature_fn=net.feature_extractor, dome=True)
             res = net({k: v.clone() for k, v in ep.items()}, hyp)

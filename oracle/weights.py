@@ -37,20 +37,24 @@ def seeded_state_dict(template, seed):
 # ---- head calibration: realistic key-point occupancy from random weights (oracle/calibrate_heads.py) ---------------
 # last layer of each stage-2 head: (gain on weight and bias, value added to the bias)
 AFFINE_CALIBRATION = {"translation": (1.0, (0.0, 0.0)), "scale": (0.2, (1.0,)), "inplane": (0.3, (1.0, 0.0))}
-# last layer of the stage-3 heads per level, measured with weight seed 4 on the synthetic inputs: (gain, bias shift)
+# eval BatchNorm of the flow decoder's feature projections (proj.l.1): scale and shift times this.  With the plain draw
+# the projected maps have std ~20, their correlation ~400 and the decoder's hidden maps reach 5e4 — a trained decoder
+# works on O(1) maps, and 5e4 is outside the f16x3 engine's operand range (|x| < 16376, picopose_amd/ops.py)
+PROJ_BN_GAIN = 0.05
+# last layer of the stage-3 heads per level, measured with weight seed 4 and PROJ_BN_GAIN on the synthetic inputs: (gain, bias shift)
 HEAD_CALIBRATION = {
-    "dinov2_vits14": {"flow": [(0.0008216, 0.06904), (0.0002099, 0.03091), (0.0001567, -0.5886)],
-                      "cert": [(0.01325, -0.4792), (0.003205, -1.727), (0.0006062, -1.996)]},
-    "dinov2_vitb14": {"flow": [(0.0006585, 0.1665), (0.0003779, 0.07594), (0.0006391, 0.313)],
-                      "cert": [(0.00871, -1.248), (0.003779, 1.673), (0.0009429, 2.101)]},
-    "dinov2_vitl14": {"flow": [(0.0003526, 0.05194), (0.0001661, 0.2838), (9.149e-05, 0.3788)],
-                      "cert": [(0.003864, -1.477), (0.0007211, 1.431), (0.0002781, -1.573)]},
+    "dinov2_vits14": {"flow": [(0.2184, 0.08754), (0.05955, 0.03011), (0.06486, -0.6083)],
+                      "cert": [(1.701, -0.6621), (0.7953, -1.931), (0.2702, -2.5)]},
+    "dinov2_vitb14": {"flow": [(0.1671, 0.1216), (0.1069, -0.04104), (0.1318, 0.2138)],
+                      "cert": [(1.952, -1.574), (0.883, 0.5047), (0.3407, 2.576)]},
+    "dinov2_vitl14": {"flow": [(0.1285, 0.02845), (0.04446, 0.2571), (0.03843, 0.5124)],
+                      "cert": [(1.155, -2.277), (0.2594, 1.235), (0.1157, -1.861)]},
 }
 
 
 def apply_head_calibration(sd, cal):
     """-> copy of `sd` with the LAST layer of every prediction head rescaled: w' = g*w, b' = g*b + shift.
-    cal = {"affine": AFFINE_CALIBRATION-like, "flow": [(g, shift)]*levels, "cert": [(g, shift)]*levels}."""
+    cal = {"affine": AFFINE_CALIBRATION-like, "proj_bn": gain, "flow": [(g, shift)]*levels, "cert": [(g, shift)]*levels}."""
     out = dict(sd)
 
     def rescale(prefix, g, shift):
@@ -59,6 +63,9 @@ def apply_head_calibration(sd, cal):
 
     for head, (g, shift) in cal.get("affine", {}).items():
         rescale(f"affine_regressor.{head}_predictor.4.", g, shift)
+    if "proj_bn" in cal:
+        for l in range(len(cal.get("flow", ()))):
+            rescale(f"offset_regressor.flow_decoder.proj.{l}.1.", cal["proj_bn"], 0.0)
     for key, name in (("flow", "flow_pred"), ("cert", "mask_pred")):
         for l, (g, shift) in enumerate(cal.get(key, ())):
             rescale(f"offset_regressor.flow_decoder.{name}.{l}.predict_layer.", g, shift)
@@ -67,4 +74,4 @@ def apply_head_calibration(sd, cal):
 
 def calibrated_state_dict(template, seed, vit_type):
     """Seeded weights with the committed head calibration of the architecture."""
-    return apply_head_calibration(seeded_state_dict(template, seed), dict(HEAD_CALIBRATION[vit_type], affine=AFFINE_CALIBRATION))
+    return apply_head_calibration(seeded_state_dict(template, seed), dict(HEAD_CALIBRATION[vit_type], affine=AFFINE_CALIBRATION, proj_bn=PROJ_BN_GAIN))

@@ -19,6 +19,27 @@ PRECISION = "f16x3"
 _PREC = {"f32": 0, "f16x3": 1}
 _split_cache = {}
 
+# The f16x3 engine stores an activation operand as hi = f16(4 x), lo = f16(4 x - hi): |x| must stay below
+# 65504 / 4 = 16376, beyond which the split SATURATES (finite, but wrong) — fp32 has no such limit.  Trained networks
+# stay orders of magnitude below it; badly scaled random weights need not.  CHECK_SATURATION = True makes every producer
+# of an operand verify its buffer (a host sync per operand: a debugging / test / bench-verification mode, never on in a
+# timed region) and raise instead of returning silently clipped values.
+CHECK_SATURATION = False
+saturation_checks = 0        # operands verified since import (bench.py reports it)
+
+
+def _chk(hl, what):
+    """hl: fp16 operand buffer (or None).  Raises if any element sits at the fp16 clamp (|v| >= 65504) or is not finite."""
+    global saturation_checks
+    if CHECK_SATURATION and hl is not None:
+        saturation_checks += 1
+        bad = (hl.view(torch.int16) & 0x7FFF) >= 0x7BFF
+        if bool(bad.any()):
+            raise _lib.PicoPoseHipError(
+                f"f16x3 operand saturated in {what}: {int(bad.sum())} of {hl.numel()} fp16 terms at the clamp "
+                "(|activation| >= 16376); run with ops.PRECISION = 'f32' (bench.py --mode exact) for this network")
+    return hl
+
 
 def split_weight(w):
     """(hl, scale) — the f16x3 "hl" operand (fp16 (N, 2K): per 8 k the hi then the lo terms) and power-of-two scale
@@ -68,7 +89,7 @@ def split_activation(x, B, P, C, batch_stride, row_stride, relu=False):
     hl = torch.empty(B * P, 2 * C, dtype=torch.float16, device=x.device)
     _lib.check(_lib.lib().pp_split_activation(_p(x), batch_stride, B, P, row_stride, C, int(relu), _p(hl),
                                               _lib.stream_ptr()), "pp_split_activation")
-    return hl
+    return _chk(hl, "pp_split_activation")
 
 
 def _can_presplit(x, K, C, *strides):
@@ -88,8 +109,11 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
-def _run(d, what="pp_gemm"):
+def _run(d, what="pp_gemm", written=None):
+    """written: the Split this launch writes operand columns of (verified under CHECK_SATURATION)."""
     _lib.check(_lib.lib().pp_gemm(ctypes.byref(d), _lib.stream_ptr()), what)
+    if written is not None:
+        _chk(written.hl, f"{what} epilogue (M={d.M}, N={d.N}, K={d.K})")
 
 
 def _desc(**kw):
@@ -123,13 +147,13 @@ def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, 
     if isinstance(x, Split):
         assert "B_hl" in wargs
         _run(_desc(A_hl=_p(x.hl), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual),
-                   M=M, N=N, K=K, lda=K, ldb=K, ldc=ldc, act=ACT[act], **wargs, **sargs))
+                   M=M, N=N, K=K, lda=K, ldb=K, ldc=ldc, act=ACT[act], **wargs, **sargs), written=ret if sargs else None)
         return ret
     assert x.stride(1) == 1
     if "B_hl" in wargs and N > 64 and _can_presplit(x, K, K, x.stride(0)) and M * K < 2 ** 31:
         hl = split_activation(x, 1, M, K, 0, x.stride(0), relu=relu_in)          # every column tile reuses the split
         _run(_desc(A_hl=_p(hl), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual),
-                   M=M, N=N, K=K, lda=K, ldb=K, ldc=ldc, act=ACT[act], **wargs, **sargs))
+                   M=M, N=N, K=K, lda=K, ldb=K, ldc=ldc, act=ACT[act], **wargs, **sargs), written=ret if sargs else None)
         return ret
     if sargs:  # the fp32-operand kernels write planes too, but keep this rare path simple: fp32 out + split pass
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
@@ -235,7 +259,8 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
         _run(_desc(A_hl=_p(hl), B=_p(wp), C=None, bias=_p(bias), conv_bstride=H * W * cin, M=B * Ho * Wo, N=Cout,
                    K=ksize * ksize * cin, lda=cin, ldb=wp.shape[1], ldc=Cout, act=ACT[act], conv_kh=ksize, conv_kw=ksize,
                    conv_cin=cin, conv_stride=stride, conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo,
-                   C_hl=tgt.hl.data_ptr() + 4 * col0, ldc_h=ctot, c_relu=int(split_relu), **wargs))
+                   C_hl=tgt.hl.data_ptr() + 4 * col0, ldc_h=ctot, c_relu=int(split_relu), **wargs),
+             written=Split(tgt.hl[:, 2 * col0:2 * (col0 + Cout)]) if CHECK_SATURATION else None)
         return None
     if out_split and out is None and presplit and _split_ok(Cout) and residual is None and residual2 is None:
         ret = Split.empty(B * Ho * Wo, Cout, dev)
@@ -263,7 +288,8 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
         _run(_desc(A_hl=_p(hl), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual),
                    residual2=_p(residual2), conv_bstride=H * W * cin, M=B * Ho * Wo, N=Cout, K=ksize * ksize * cin, lda=cin,
                    ldb=wp.shape[1], ldc=ldc, act=ACT[act], conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride,
-                   conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo, **wargs, **sargs))
+                   conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo, **wargs, **sargs),
+             written=(extra if extra is not None else ret) if sargs else None)
         return ret
     _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual), residual2=_p(residual2),
                conv_bstride=x.stride(0), M=B * Ho * Wo, N=Cout,
@@ -307,6 +333,8 @@ def attention(qkv, B, T, heads, hd, out_split=False):
         assert qkv.is_contiguous()
         _lib.check(_lib.lib().pp_attention_ex(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, _PREC[PRECISION], _p(out),
                                               _p(sp.hl) if sp else None, _lib.stream_ptr()), "pp_attention_ex")
+    if sp is not None:
+        _chk(sp.hl, "pp_attention")
     return sp if sp is not None else out
 
 
@@ -318,6 +346,7 @@ def layernorm(x, weight, bias, eps, out_split=False):
         sp = Split.empty(rows, C, x.device)
         _lib.check(_lib.lib().pp_layernorm_split(_p(x), _p(weight), _p(bias), rows, C, float(eps), None, _p(sp.hl),
                                                  _lib.stream_ptr()), "pp_layernorm_split")
+        _chk(sp.hl, "pp_layernorm_split")
         return sp
     y = torch.empty_like(x)
     _lib.check(_lib.lib().pp_layernorm(_p(x), _p(weight), _p(bias), rows, C, float(eps), _p(y), _lib.stream_ptr()),
@@ -373,6 +402,7 @@ def resize_bilinear(x, Ho, Wo, mul=1.0, out_split=False):
         sp.image = (B, Ho, Wo)
         _lib.check(_lib.lib().pp_resize_bilinear_nhwc_hl(_p(x), B, H, W, C, Ho, Wo, float(mul), _p(sp.hl), _lib.stream_ptr()),
                    "pp_resize_bilinear_nhwc_hl")
+        _chk(sp.hl, "pp_resize_bilinear_nhwc_hl")
         return sp
     out = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().pp_resize_bilinear_nhwc(_p(x), B, H, W, C, Ho, Wo, float(mul), _p(out), _lib.stream_ptr()),

@@ -178,6 +178,7 @@ def _load_cal(golden_dir, tag):
     B, N, hyp, seed, wseed = (int(v) for v in z[f"{tag}/meta"])
     vit = str(z[f"{tag}/vit"])
     cal = {"flow": [tuple(r) for r in z[f"{tag}/cal_flow"]], "cert": [tuple(r) for r in z[f"{tag}/cal_cert"]],
+           "proj_bn": float(z[f"{tag}/cal_proj_bn"]),
            "affine": {h: (float(z[f"{tag}/cal_affine_{h}"][0]), tuple(z[f"{tag}/cal_affine_{h}"][1:]))
                       for h in ("translation", "scale", "inplane")}}
     ref = [{k.split("/", 2)[2]: z[k] for k in z.files if k.startswith(f"{tag}/h{h}/")} for h in range(hyp)]
@@ -225,7 +226,13 @@ def _hip_calibrated_forward(golden_dir, tag):
     dev = {k: v.cuda() for k, v in ep.items()}
     dev["template_feature"] = torch.stack([net.feature_extractor(dev["tem_rgb"][b])[-1] for b in range(B)])
     net.keep_stage3 = True
-    outs = net(dev, hyp)
+    from picopose_amd import ops
+
+    ops.CHECK_SATURATION = True       # every f16x3 operand buffer is verified against the fp16 clamp (raises on a hit)
+    try:
+        outs = net(dev, hyp)
+    finally:
+        ops.CHECK_SATURATION = False
     fl, ce = net.last_stage3                              # NHWC, hypothesis-major (hyp*B, 64, 64, c)
     flow = fl.permute(0, 3, 1, 2).reshape(hyp, B, 2, 64, 64).cpu().numpy()
     cert = ce.permute(0, 3, 1, 2).reshape(hyp, B, 1, 64, 64).cpu().numpy()
@@ -260,17 +267,29 @@ def test_hip_forward_vs_reference_calibrated(golden_dir, tag):
     _check_hip_vs_reference(z, tag, B, hyp, ref, outs, flow, cert)
     rot, tvec, ratio, ok, npts = pnp_for_outputs(outs, dev["real_K"], return_npts=True)
     assert npts.min() >= 1000 and ok.all()
+    # (a) like for like: the HIP PnP kernel fed with the REFERENCE's key-point lists against the CPU oracle of PnP/RANSAC
+    # on the same lists (same sampling sequence, problem id h*B+b) — consensus within 2 points, pose to solver tolerance
+    # scaled by the 1.75 px grid noise of these correspondences;
+    # (b) the chain: PnP on the HIP net's own lists (a few threshold slots differ, so RANSAC may settle on another of its
+    # 150 hypotheses) finds the same pose within the scatter of such hypotheses.
+    from picopose_amd.utils.pose_recovery import pose_recovery_ransac_pnp_batched
+
+    ref_outs = [dict(outs[h], pred_tar_pts=torch.from_numpy(ref[h]["pred_tar_pts"]).cuda(),
+                     pred_src_pts=torch.from_numpy(ref[h]["pred_src_pts"]).cuda()) for h in range(hyp)]
+    rrot, rtvec, rratio, rok, rnpts = pnp_for_outputs(ref_outs, dev["real_K"], return_npts=True)
     for h in range(hyp):
         for b in range(B):
-            # CPU oracle of PnP/RANSAC on the REFERENCE's key-point lists (same sampling sequence: problem id h*B+b)
             t2 = ep["real_pts2d"][b].permute(2, 1, 0).numpy()
             sel = int(np.argmax([np.array_equal(ep["tem_pose"][b, n].numpy(), ref[h]["tem_pose"][b]) for n in range(N)]))
             s3 = ep["tem_pts3d"][b, sel].permute(2, 0, 1).numpy()
             orot, otvec, oratio, ook = opnp.pose_recovery_ransac_pnp(t2, s3, ep["real_K"][b].numpy(), ref[h]["tem_pose"][b],
                                                                      ref[h]["pred_tar_pts"][b], ref[h]["pred_src_pts"][b], prob=h * B + b)
-            assert ook and abs(oratio - ratio[h, b]) < 0.03, (h, b, oratio, ratio[h, b])
-            assert np.abs(otvec - tvec[h, b]).max() < 0.01 and np.abs(orot - rot[h, b]).max() < 0.03, (h, b, otvec.ravel(), tvec[h, b].ravel())
-            # and the pose is the one stage 2 predicted, refined (the dome is consistent with the affine): same ballpark
+            n = int(rnpts[h, b])
+            assert ook and rok[h, b] and n == int(_valid(ref[h]["pred_tar_pts"][b:b + 1])[0])
+            assert abs(oratio - rratio[h, b]) * n <= 2, (h, b, oratio * n, rratio[h, b] * n)
+            assert np.abs(otvec - rtvec[h, b]).max() < 2e-3 and np.abs(orot - rrot[h, b]).max() < 2e-3, (h, b, otvec.ravel(), rtvec[h, b].ravel())
+            assert abs(ratio[h, b] - rratio[h, b]) < 0.1 and np.abs(tvec[h, b] - rtvec[h, b]).max() < 0.06
+            # and it is the pose stage 2 predicted, refined (the dome is consistent with the affine): same ballpark
             assert np.abs(tvec[h, b, :, 0] - ref[h]["pred_poses"][b, :3, 3]).max() < 0.15
 
 

@@ -271,3 +271,25 @@ def test_attention_shapes_and_operand_input(B, T, heads, engine_precision):
         assert torch.equal(ops.attention(sp, B, T, heads, hd), got)
         out_sp = ops.attention(sp, B, T, heads, hd, out_split=True)
         assert torch.equal(out_sp.hl, ops.split_activation(got, 1, B * T, heads * hd, 0, heads * hd))
+
+
+@gpu
+def test_saturation_check_raises_instead_of_returning_clipped_operands():
+    """The f16x3 operand format holds |x| < 16376; ops.CHECK_SATURATION turns a silent clip into an error."""
+    from picopose_amd import _lib, ops
+
+    if ops.PRECISION != "f16x3":
+        pytest.skip("f16x3 engine only")
+    x = torch.randn(64, 256, device="cuda")
+    w = torch.randn(128, 256, device="cuda") * 0.05
+    ops.CHECK_SATURATION = True
+    try:
+        ops.linear(x, w, out_split=True)                           # in range: fine
+        x[3, 7] = 4.0e4
+        with pytest.raises(_lib.PicoPoseHipError, match="saturated"):
+            ops.linear(x, w)                                       # the pre-split of the activation clips
+        big = torch.full((128, 256), 30.0, device="cuda")
+        with pytest.raises(_lib.PicoPoseHipError, match="saturated"):
+            ops.linear(torch.full((64, 256), 30.0, device="cuda"), big, out_split=True)   # 256 * 900 = 230400 in the epilogue
+    finally:
+        ops.CHECK_SATURATION = False

@@ -1,0 +1,98 @@
+"""Statistical characterisation of the GPU PnP/RANSAC (cv2 cannot be pinned here): seeded problems per
+regime (pixel noise x outlier fraction x number of correspondences) -> success rate and rotation / translation error
+quantiles against the planted ground truth for pp_pnp_ransac, and (on a sub-sample) for the CPU oracle oracle/pnp.py.
+
+    python tools/pnp_stats.py [--problems 1000] [--oracle 6] [--out gpurun_out/pnp_stats.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+NOISE = (0.0, 0.3, 1.0)
+OUTLIERS = (0.0, 0.3, 0.6)
+NPTS = (8, 64, 512, 4096)
+
+
+def good_pose(ang, dt, noise, n_in):
+    """A pose counts as found when it is within the error a least-squares fit of n_in noisy points can have, with slack:
+    rotation < 0.05 deg + 60 deg * noise / sqrt(n_in) (px noise over a ~0.2 m object at 0.9 m, f = 572), |dt|/|t| < 1e-4 + 0.1 * noise / sqrt(n_in)."""
+    s = noise / np.sqrt(max(n_in, 1))
+    return (ang < 0.05 + 60.0 * s) & (dt < 1e-4 + 0.1 * s)
+
+
+def run(problems=1000, n_oracle=6, seed=2024, log=print):
+    from pnp_problems import make_batch, pose_errors
+
+    from oracle import pnp as op
+    from picopose_amd.utils.pose_recovery import pose_recovery_ransac_pnp_batched
+
+    rng = np.random.default_rng(seed)
+    table = []
+    for n in NPTS:
+        for out in OUTLIERS:
+            for noise in NOISE:
+                b = make_batch(rng, problems, n, out, noise)
+                dev = {k: torch.from_numpy(b[k]).cuda() for k in ("tar2d", "src3d", "K", "pose", "tar_pts", "src_pts")}
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rot, tvec, ratio, ok = pose_recovery_ransac_pnp_batched(dev["tar2d"], dev["src3d"], dev["K"], dev["pose"],
+                                                                        dev["tar_pts"], dev["src_pts"])
+                ms = (time.perf_counter() - t0) * 1e3
+                ang, dt = pose_errors(rot, tvec, b["R"], b["t"])
+                good = ok & good_pose(ang, dt, noise, b["n_in"])
+                q = lambda v, p: float(np.quantile(v[ok], p)) if ok.any() else None   # noqa: E731
+                row = {"n": n, "outliers": out, "noise_px": noise, "n_inliers": b["n_in"], "problems": problems,
+                       "returned_success": float(ok.mean()), "pose_found": float(good.mean()),
+                       "rot_deg_p50": q(ang, 0.5), "rot_deg_p95": q(ang, 0.95), "trans_rel_p50": q(dt, 0.5), "trans_rel_p95": q(dt, 0.95),
+                       "inlier_ratio_mean": float(ratio[ok].mean()) if ok.any() else None, "gpu_ms_batch": ms}
+                # the CPU oracle on the first few problems: same sampling sequence -> same decisions, solver-level differences
+                m = min(n_oracle, problems)
+                o_ok, o_ang, o_dt, o_dratio, o_dpose = [], [], [], [], []
+                for i in range(m):
+                    r, t, ra, su = op.pose_recovery_ransac_pnp(b["tar2d"][i], b["src3d"][i], b["K"][i], b["pose"][i], b["tar_pts"][i],
+                                                               b["src_pts"][i], prob=i)
+                    o_ok.append(su)
+                    a, d = pose_errors(r[None], t[None], b["R"][i:i + 1], b["t"][i:i + 1])
+                    o_ang.append(float(a[0]))
+                    o_dt.append(float(d[0]))
+                    o_dratio.append(abs(ra - ratio[i]) * n)
+                    o_dpose.append(float(np.abs(r - rot[i]).max()) if su and ok[i] else 0.0)
+                row.update({"oracle_problems": m, "oracle_success_agrees": float(np.mean(np.array(o_ok) == ok[:m])),
+                            "oracle_pose_found": float(np.mean(np.array(o_ok) & good_pose(np.array(o_ang), np.array(o_dt), noise, b["n_in"]))),
+                            "oracle_vs_gpu_inlier_count_maxdiff": float(max(o_dratio)), "oracle_vs_gpu_rot_maxdiff": float(max(o_dpose))})
+                table.append(row)
+                log(json.dumps(row))
+    return table
+
+
+def markdown(table):
+    f = lambda v, fmt="%.3g": "—" if v is None else fmt % v  # noqa: E731
+    lines = ["| n | outliers | noise px | success | pose found | rot° p50 / p95 | Δt/t p50 / p95 | oracle pose found (sub-sample) | oracle vs GPU Δinliers |",
+             "|---|---|---|---|---|---|---|---|---|"]
+    for r in table:
+        lines.append(f"| {r['n']} | {int(r['outliers'] * 100)} % | {r['noise_px']} | {r['returned_success']:.3f} | {r['pose_found']:.3f} | "
+                     f"{f(r['rot_deg_p50'])} / {f(r['rot_deg_p95'])} | {f(r['trans_rel_p50'])} / {f(r['trans_rel_p95'])} | "
+                     f"{r['oracle_pose_found']:.2f} ({r['oracle_problems']}) | {r['oracle_vs_gpu_inlier_count_maxdiff']:.0f} |")
+    return "\n".join(lines)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--problems", type=int, default=1000)
+    ap.add_argument("--oracle", type=int, default=6)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pnp_stats.json"))
+    a = ap.parse_args()
+    t = run(a.problems, a.oracle)
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(t, open(a.out, "w"), indent=1)
+    open(a.out.replace(".json", ".md"), "w").write(markdown(t) + "\n")
+    print(markdown(t))
