@@ -19,141 +19,235 @@
 
 namespace {
 
-constexpr int NT = 256;
+#ifndef PP_PNP_NT
+#define PP_PNP_NT 512
+#endif
+constexpr int NT = PP_PNP_NT;     // 8 waves, one workgroup per CU (the correspondences of a problem fill most of the LDS)
+constexpr int NW = NT / 64;
+constexpr int GL = 16;            // lanes of a solver group (12 of them own a column of the 12x12 system)
+constexpr int NG = NT / GL;       // solver groups per workgroup: RANSAC hypotheses are solved NG at a time
 constexpr int MAXP = 4096;
-constexpr int SAMPLE = 5;  // minimal sample size of solvePnPRansac for EPNP
+constexpr int MAXH = 256;         // RANSAC hypotheses kept per problem
+constexpr int SAMPLE = 5;         // minimal sample size of solvePnPRansac for EPNP
 
 // ------------------------------------------------------------------ small dense helpers (double)
-// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 12): a is destroyed,
-// w = eigenvalues, v[k*n + i] = component i of eigenvector k; then sorted ascending.
-template <int N>
-__device__ void jacobi_eig(double* a, double* w, double* v) {
-    for (int i = 0; i < N; ++i)
-        for (int j = 0; j < N; ++j) v[i * N + j] = i == j ? 1.0 : 0.0;
+// Everything below keeps its operands in registers: every array index is a compile-time constant after unrolling
+// (a per-lane matrix with run-time indices lives in scratch memory, whose latency made the first version of this kernel
+// spend 9 ms on 160 problems).
+
+#define PP_JROT3(A, V, p, q)                                                                   \
+    {                                                                                          \
+        const double apq = A[p][q];                                                            \
+        if (fabs(apq) >= 1e-300) {                                                             \
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);                            \
+            const double t_ = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
+            const double c_ = 1.0 / sqrt(t_ * t_ + 1.0), s_ = t_ * c_;                         \
+            _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                 \
+                const double akp = A[k_][p], akq = A[k_][q];                                   \
+                A[k_][p] = c_ * akp - s_ * akq;                                                \
+                A[k_][q] = s_ * akp + c_ * akq;                                                \
+            }                                                                                  \
+            _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                 \
+                const double apk = A[p][k_], aqk = A[q][k_];                                   \
+                A[p][k_] = c_ * apk - s_ * aqk;                                                \
+                A[q][k_] = s_ * apk + c_ * aqk;                                                \
+            }                                                                                  \
+            _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                 \
+                const double vpk = V[p][k_], vqk = V[q][k_];                                   \
+                V[p][k_] = c_ * vpk - s_ * vqk;                                                \
+                V[q][k_] = s_ * vpk + c_ * vqk;                                                \
+            }                                                                                  \
+        }                                                                                      \
+    }
+
+#define PP_CSWAP3(w, V, i, j)                                   \
+    if (w[j] < w[i]) {                                          \
+        const double tw_ = w[i]; w[i] = w[j]; w[j] = tw_;       \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {      \
+            const double tv_ = V[i][k_]; V[i][k_] = V[j][k_]; V[j][k_] = tv_; \
+        }                                                       \
+    }
+
+// cyclic Jacobi eigen-decomposition of a symmetric 3x3 matrix: w ascending, V[k] = eigenvector k (rows)
+__device__ inline void eig3_sym(double (&A)[3][3], double (&w)[3], double (&V)[3][3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < N; ++p)
-            for (int q = p + 1; q < N; ++q) off += a[p * N + q] * a[p * N + q];
-        double diag = 0.0;
-        for (int p = 0; p < N; ++p) diag += a[p * N + p] * a[p * N + p];
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
         if (off <= 1e-30 * (diag + 1e-300)) break;
-        for (int p = 0; p < N; ++p)
-            for (int q = p + 1; q < N; ++q) {
-                const double apq = a[p * N + q];
-                if (fabs(apq) < 1e-300) continue;
-                const double theta = (a[q * N + q] - a[p * N + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < N; ++k) {  // A <- A J
-                    const double akp = a[k * N + p], akq = a[k * N + q];
-                    a[k * N + p] = c * akp - s * akq;
-                    a[k * N + q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < N; ++k) {  // A <- J^T A
-                    const double apk = a[p * N + k], aqk = a[q * N + k];
-                    a[p * N + k] = c * apk - s * aqk;
-                    a[q * N + k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < N; ++k) {  // eigenvectors as rows of v
-                    const double vpk = v[p * N + k], vqk = v[q * N + k];
-                    v[p * N + k] = c * vpk - s * vqk;
-                    v[q * N + k] = s * vpk + c * vqk;
-                }
-            }
+        PP_JROT3(A, V, 0, 1)
+        PP_JROT3(A, V, 0, 2)
+        PP_JROT3(A, V, 1, 2)
     }
-    for (int i = 0; i < N; ++i) w[i] = a[i * N + i];
-    for (int i = 0; i < N - 1; ++i) {  // selection sort, ascending
-        int m = i;
-        for (int j = i + 1; j < N; ++j)
-            if (w[j] < w[m]) m = j;
-        if (m != i) {
-            const double tw = w[i];
-            w[i] = w[m];
-            w[m] = tw;
-            for (int k = 0; k < N; ++k) {
-                const double tv = v[i * N + k];
-                v[i * N + k] = v[m * N + k];
-                v[m * N + k] = tv;
-            }
-        }
-    }
+    w[0] = A[0][0]; w[1] = A[1][1]; w[2] = A[2][2];
+    // selection sort order of the first version (min to slot 0, then min of the rest to slot 1)
+    if (w[1] < w[0] && w[1] <= w[2]) { PP_CSWAP3(w, V, 0, 1) } else if (w[2] < w[0] && w[2] < w[1]) { PP_CSWAP3(w, V, 0, 2) }
+    PP_CSWAP3(w, V, 1, 2)
 }
 
-// least squares  min |A x - b|  for A (6 x C), via normal equations + Gaussian elimination
+// least squares  min |A x - b|  for A (6 x C), via normal equations + Gaussian elimination with partial pivoting
+// (the pivot row is brought up by predicated swaps, so that no run-time row index appears)
 template <int C>
-__device__ void lstsq6(const double (*A)[C], const double* b, double* x) {
+__device__ inline void lstsq6(const double (&A)[6][C], const double (&b)[6], double (&x)[C]) {
     double n[C][C + 1];
+#pragma unroll
     for (int i = 0; i < C; ++i) {
+#pragma unroll
         for (int j = 0; j < C; ++j) {
             double s = 0.0;
+#pragma unroll
             for (int r = 0; r < 6; ++r) s += A[r][i] * A[r][j];
             n[i][j] = s;
         }
         double s = 0.0;
+#pragma unroll
         for (int r = 0; r < 6; ++r) s += A[r][i] * b[r];
         n[i][C] = s;
     }
+#pragma unroll
     for (int i = 0; i < C; ++i) {
         int p = i;
+        double pv = fabs(n[i][i]);
+#pragma unroll
         for (int r = i + 1; r < C; ++r)
-            if (fabs(n[r][i]) > fabs(n[p][i])) p = r;
-        if (p != i)
-            for (int c = 0; c <= C; ++c) {
-                const double t = n[i][c];
-                n[i][c] = n[p][c];
-                n[p][c] = t;
+            if (fabs(n[r][i]) > pv) { pv = fabs(n[r][i]); p = r; }
+#pragma unroll
+        for (int r = i + 1; r < C; ++r)
+            if (r == p) {
+#pragma unroll
+                for (int c = 0; c <= C; ++c) {
+                    const double t = n[i][c];
+                    n[i][c] = n[r][c];
+                    n[r][c] = t;
+                }
             }
         const double d = fabs(n[i][i]) > 1e-300 ? n[i][i] : 1e-300;
+#pragma unroll
         for (int r = i + 1; r < C; ++r) {
             const double f = n[r][i] / d;
+#pragma unroll
             for (int c = i; c <= C; ++c) n[r][c] -= f * n[i][c];
         }
     }
+#pragma unroll
     for (int i = C - 1; i >= 0; --i) {
         double s = n[i][C];
+#pragma unroll
         for (int c = i + 1; c < C; ++c) s -= n[i][c] * x[c];
         x[i] = s / (fabs(n[i][i]) > 1e-300 ? n[i][i] : 1e-300);
     }
 }
 
-__device__ inline double det3(const double* m) {
+__device__ inline double det3(const double (&m)[9]) {
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
 }
 
 // rotation of the Horn alignment: the proper rotation closest to U V^T of the SVD of the 3x3
 // cross-covariance H = sum (pc)(pw)^T (Kabsch: when det(U V^T) < 0 the direction of the smallest
 // singular value flips, which is what completing both bases to right-handed triads does)
-__device__ void horn_rotation(const double* H, double* R) {
-    double hth[9], w[3], v[9];
+__device__ inline void horn_rotation(const double (&H)[9], double (&R)[9]) {
+    double hth[3][3], w[3], v[3][3];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) hth[i * 3 + j] = H[0 * 3 + i] * H[0 * 3 + j] + H[1 * 3 + i] * H[1 * 3 + j] + H[2 * 3 + i] * H[2 * 3 + j];
-    jacobi_eig<3>(hth, w, v);  // ascending; rows of v = right singular vectors
-    double u[9];               // columns u_k = H v_k / sigma_k for the two largest, third by cross product
+#pragma unroll
+        for (int j = 0; j < 3; ++j) hth[i][j] = H[0 * 3 + i] * H[0 * 3 + j] + H[1 * 3 + i] * H[1 * 3 + j] + H[2 * 3 + i] * H[2 * 3 + j];
+    eig3_sym(hth, w, v);  // ascending; rows of v = right singular vectors
+    double u[3][3];       // u_k = H v_k / sigma_k for the two largest, third by cross product
+#pragma unroll
     for (int k = 2; k >= 1; --k) {
         double x[3];
-        for (int i = 0; i < 3; ++i) x[i] = H[i * 3 + 0] * v[k * 3 + 0] + H[i * 3 + 1] * v[k * 3 + 1] + H[i * 3 + 2] * v[k * 3 + 2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) x[i] = H[i * 3 + 0] * v[k][0] + H[i * 3 + 1] * v[k][1] + H[i * 3 + 2] * v[k][2];
         const double nn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-        for (int i = 0; i < 3; ++i) u[k * 3 + i] = nn > 1e-300 ? x[i] / nn : (i == k ? 1.0 : 0.0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) u[k][i] = nn > 1e-300 ? x[i] / nn : (i == k ? 1.0 : 0.0);
     }
     // make u1 orthogonal to u2 (guards a tiny sigma_1), u0 = u1 x u2 ; same for v0 = v1 x v2
-    const double d12 = u[3] * u[6] + u[4] * u[7] + u[5] * u[8];
-    for (int i = 0; i < 3; ++i) u[3 + i] -= d12 * u[6 + i];
-    const double n1 = sqrt(u[3] * u[3] + u[4] * u[4] + u[5] * u[5]);
-    for (int i = 0; i < 3; ++i) u[3 + i] /= (n1 > 1e-300 ? n1 : 1.0);
-    u[0] = u[4] * u[8] - u[5] * u[7];
-    u[1] = u[5] * u[6] - u[3] * u[8];
-    u[2] = u[3] * u[7] - u[4] * u[6];
-    double v0[3] = {v[4] * v[8] - v[5] * v[7], v[5] * v[6] - v[3] * v[8], v[3] * v[7] - v[4] * v[6]};
-    // R = sum_k u_k v_k^T with (u0, v0) completing right-handed triads: det(R) = +1 ...
+    const double d12 = u[1][0] * u[2][0] + u[1][1] * u[2][1] + u[1][2] * u[2][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u[1][i] -= d12 * u[2][i];
+    const double n1 = sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u[1][i] /= (n1 > 1e-300 ? n1 : 1.0);
+    u[0][0] = u[1][1] * u[2][2] - u[1][2] * u[2][1];
+    u[0][1] = u[1][2] * u[2][0] - u[1][0] * u[2][2];
+    u[0][2] = u[1][0] * u[2][1] - u[1][1] * u[2][0];
+    const double v0[3] = {v[1][1] * v[2][2] - v[1][2] * v[2][1], v[1][2] * v[2][0] - v[1][0] * v[2][2], v[1][0] * v[2][1] - v[1][1] * v[2][0]};
+    // R = sum_k u_k v_k^T with (u0, v0) completing right-handed triads: det(R) = +1 — the det-corrected U V^T
+#pragma unroll
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) R[i * 3 + j] = u[0 + i] * v0[j] + u[3 + i] * v[3 + j] + u[6 + i] * v[6 + j];
-    // ... which is the det-corrected U V^T (the smallest singular direction is the one that flips)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[i * 3 + j] = u[0][i] * v0[j] + u[1][i] * v[1][j] + u[2][i] * v[2][j];
+}
+
+// ------------------------------------------------------------------ 12x12 symmetric eigenproblem, cooperative
+// One-sided (Hestenes) Jacobi on the columns of the symmetric positive semi-definite G = M^T M, a 16-lane group per
+// matrix: lane k < 12 holds column k of G (g) and of the accumulated rotations (v) in registers.  The 66 column pairs
+// of a sweep are visited as 11 rounds of 6 disjoint pairs (round-robin tournament); the two lanes of a pair fetch each
+// other's columns with ds_bpermute, compute the same rotation bit for bit and apply their half of it.  At convergence
+// G V = [g_1 .. g_12] has orthogonal columns: g_k = lambda_k v_k, so |g_k| is the eigenvalue of the lane's vector v.
+__device__ inline void hestenes12(double (&g)[12], double (&v)[12], int k) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = i == k ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 14; ++sweep) {
+        // A column carries absolute rounding noise of ~eps * lambda_max per component from its rotations against the
+        // large columns, so g_p . g_q cannot be driven below ~eps * lambda_max * (|g_p| + |g_q|): pairs under that
+        // floor are converged (the absolute criterion of the symmetric eigensolvers, LAPACK's included).
+        double amax2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) amax2 += g[i] * g[i];
+#pragma unroll
+        for (int o = 1; o < GL; o <<= 1) amax2 = fmax(amax2, __shfl_xor(amax2, o, GL));
+        const double floor2 = 2.5e-29 * amax2;                  // (16 eps)^2 * 2 * lambda_max^2
+        int rotated = 0;
+        double alpha = 0.0;                                     // |g_k|^2, recomputed once per sweep, then updated
+#pragma unroll
+        for (int i = 0; i < 12; ++i) alpha += g[i] * g[i];
+        for (int s = 0; s < 11; ++s) {
+            int partner = k;                                    // lanes 12..15 pair with themselves: no-op
+            if (k == 11) partner = s;
+            else if (k == s) partner = 11;
+            else if (k < 11) { partner = 2 * s - k; partner += partner < 0 ? 11 : 0; partner -= partner >= 11 ? 11 : 0; }
+            double og[12], ov[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { og[i] = __shfl(g[i], partner, GL); ov[i] = __shfl(v[i], partner, GL); }
+            const double beta = __shfl(alpha, partner, GL);
+            double gamma = 0.0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) gamma += g[i] * og[i];
+            const bool low = k < partner;                        // this lane owns column p (the lower index) of the pair
+            const double ap = low ? alpha : beta, aq = low ? beta : alpha;
+            if (partner != k && gamma * gamma > floor2 * (ap + aq)) {
+                rotated = 1;
+                // The rotation must be orthogonal to fp64 accuracy (c^2 + s^2 = 1), its ANGLE need not be exact: tan is
+                // evaluated in fp32 (single-instruction rcp / sqrt; an fp64 division or square root costs ~35 instructions,
+                // and three of them were half of a Jacobi step).  An angle good to 1e-7 leaves g_p . g_q reduced by that
+                // factor instead of annihilated, which the next sweep finishes — the sweep count does not change.
+                const float zf = (float)(aq - ap) * __builtin_amdgcn_rcpf((float)(2.0 * gamma));
+                const float tf = copysignf(1.0f, zf) * __builtin_amdgcn_rcpf(fabsf(zf) + __builtin_amdgcn_sqrtf(1.0f + zf * zf));
+                const double t = (tf == tf && fabsf(tf) <= 1.0f) ? (double)tf : 0.0;
+                const double c = rsqrt(1.0 + t * t), sn = c * t;
+                const double so = low ? -sn : sn;                // p: c g_p - s g_q ; q: s g_p + c g_q
+#pragma unroll
+                for (int i = 0; i < 12; ++i) { g[i] = c * g[i] + so * og[i]; v[i] = c * v[i] + so * ov[i]; }
+                // |g_p'|^2 = c^2 a_p - 2 c s gamma + s^2 a_q ; |g_q'|^2 = s^2 a_p + 2 c s gamma + c^2 a_q
+                alpha = low ? c * c * ap - 2.0 * c * sn * gamma + sn * sn * aq : sn * sn * ap + 2.0 * c * sn * gamma + c * c * aq;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < GL; o <<= 1) rotated |= __shfl_xor(rotated, o, GL);
+        if (!rotated) break;
+    }
 }
 
 // ------------------------------------------------------------------ EPnP
-// MODE 0: one thread solves alone over `n` sampled points (idx[0..n)).
-// MODE 1: the whole workgroup solves over the points with use[i] != 0; every thread runs the small
-//         algebra redundantly, point loops are strided and block-reduced through `red`.
+// MODE 0: a 16-lane group solves over `n` sampled points (idx[0..n)); every lane runs the small algebra, lane k owns
+//         column k of the 12x12 system.
+// MODE 1: the whole workgroup solves over the points with use[i] != 0; every thread runs the small algebra
+//         redundantly, point loops are strided over the workgroup and block-reduced through `red`.
 struct Cam {
     double fu, fv, uc, vc;
 };
@@ -165,23 +259,34 @@ struct PointSet {
     const int* idx;   // MODE 0: sample indices
     const unsigned char* use;  // MODE 1: inlier mask
     int n;            // MODE 0: sample size, MODE 1: total points
-    double* red;      // MODE 1: LDS scratch [NT]
+    double* red;      // MODE 1: LDS scratch [NW][144]
 };
 
-template <int MODE>
-__device__ inline void block_sum(const PointSet<MODE>& ps, double* vals, int cnt) {
+// sum of vals[0..CNT) over the workgroup, result in every thread (MODE 0: every lane already holds the full sums)
+template <int MODE, int CNT>
+__device__ inline void block_sum(const PointSet<MODE>& ps, double (&vals)[CNT]) {
     if (MODE == 0) return;
-    for (int c = 0; c < cnt; ++c) {
-        __syncthreads();
-        ps.red[threadIdx.x] = vals[c];
-        __syncthreads();
-        for (int s = NT / 2; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) ps.red[threadIdx.x] += ps.red[threadIdx.x + s];
-            __syncthreads();
-        }
-        vals[c] = ps.red[0];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        double x = vals[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        vals[c] = x;
+    }
+    __syncthreads();   // (the previous use of `red` has been read by everyone)
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) ps.red[wv * CNT + c] = vals[c];
     }
     __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        double x = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) x += ps.red[w * CNT + c];
+        vals[c] = x;
+    }
 }
 
 #define PP_FOR_POINTS(ps, i, ...)                                                          \
@@ -199,32 +304,37 @@ __device__ inline void block_sum(const PointSet<MODE>& ps, double* vals, int cnt
 
 // returns the mean reprojection error of the chosen solution; R (row-major) and t
 template <int MODE>
-__device__ double epnp(const PointSet<MODE>& ps, const Cam& cam, double* R, double* t) {
+__device__ double epnp(const PointSet<MODE>& ps, const Cam& cam, double (&R)[9], double (&t)[3]) {
+    const int gk = threadIdx.x & (GL - 1);   // lane of the solver group
     // ---- control points: centroid + principal directions
-    double acc[16];
-    for (int k = 0; k < 4; ++k) acc[k] = 0.0;
-    PP_FOR_POINTS(ps, i, { acc[0] += ps.p3[3 * i]; acc[1] += ps.p3[3 * i + 1]; acc[2] += ps.p3[3 * i + 2]; acc[3] += 1.0; })
-    block_sum(ps, acc, 4);
-    const double n = acc[3];
+    double a4[4] = {0.0, 0.0, 0.0, 0.0};
+    PP_FOR_POINTS(ps, i, { a4[0] += ps.p3[3 * i]; a4[1] += ps.p3[3 * i + 1]; a4[2] += ps.p3[3 * i + 2]; a4[3] += 1.0; })
+    block_sum<MODE, 4>(ps, a4);
+    const double n = a4[3];
     double cws[4][3];
-    for (int k = 0; k < 3; ++k) cws[0][k] = acc[k] / n;
-    for (int k = 0; k < 6; ++k) acc[k] = 0.0;
+_Pragma("unroll")
+    for (int k = 0; k < 3; ++k) cws[0][k] = a4[k] / n;
+    double a6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     PP_FOR_POINTS(ps, i, {
         const double x = ps.p3[3 * i] - cws[0][0], y = ps.p3[3 * i + 1] - cws[0][1], z = ps.p3[3 * i + 2] - cws[0][2];
-        acc[0] += x * x; acc[1] += x * y; acc[2] += x * z; acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
+        a6[0] += x * x; a6[1] += x * y; a6[2] += x * z; a6[3] += y * y; a6[4] += y * z; a6[5] += z * z;
     })
-    block_sum(ps, acc, 6);
+    block_sum<MODE, 6>(ps, a6);
     {
-        double c3[9] = {acc[0], acc[1], acc[2], acc[1], acc[3], acc[4], acc[2], acc[4], acc[5]}, w[3], v[9];
-        jacobi_eig<3>(c3, w, v);
+        double c3[3][3] = {{a6[0], a6[1], a6[2]}, {a6[1], a6[3], a6[4]}, {a6[2], a6[4], a6[5]}}, w[3], v[3][3];
+        eig3_sym(c3, w, v);
+#pragma unroll
         for (int k = 0; k < 3; ++k) {  // largest first, as the SVD ordering of OpenCV's EPnP
             const double kk = sqrt(fmax(w[2 - k], 0.0) / n);
-            for (int c = 0; c < 3; ++c) cws[k + 1][c] = cws[0][c] + kk * v[(2 - k) * 3 + c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cws[k + 1][c] = cws[0][c] + kk * v[2 - k][c];
         }
     }
     // ---- barycentric coordinates: alpha_{1..3} = CC^-1 (p - c0)
     double cc[9], cci[9];
+#pragma unroll
     for (int r = 0; r < 3; ++r)
+#pragma unroll
         for (int c = 0; c < 3; ++c) cc[r * 3 + c] = cws[c + 1][r] - cws[0][r];
     {
         const double d = det3(cc);
@@ -233,58 +343,107 @@ __device__ double epnp(const PointSet<MODE>& ps, const Cam& cam, double* R, doub
         cci[3] = (cc[5] * cc[6] - cc[3] * cc[8]) * id; cci[4] = (cc[0] * cc[8] - cc[2] * cc[6]) * id; cci[5] = (cc[2] * cc[3] - cc[0] * cc[5]) * id;
         cci[6] = (cc[3] * cc[7] - cc[4] * cc[6]) * id; cci[7] = (cc[1] * cc[6] - cc[0] * cc[7]) * id; cci[8] = (cc[0] * cc[4] - cc[1] * cc[3]) * id;
     }
-    auto alphas = [&](int i, double* a) {
+    auto alphas = [&](int i, double (&a)[4]) {
         const double x = ps.p3[3 * i] - cws[0][0], y = ps.p3[3 * i + 1] - cws[0][1], z = ps.p3[3 * i + 2] - cws[0][2];
         a[1] = cci[0] * x + cci[1] * y + cci[2] * z;
         a[2] = cci[3] * x + cci[4] * y + cci[5] * z;
         a[3] = cci[6] * x + cci[7] * y + cci[8] * z;
         a[0] = 1.0 - a[1] - a[2] - a[3];
     };
-    // ---- M^T M (12 x 12, upper triangle accumulated)
-    double mtm[144];
+    // ---- M^T M (12 x 12): lane gk of a solver group accumulates column gk.  MODE 1: group g takes the points
+    // g, g + NG, ..., then the columns are summed over the groups (wave shuffles, then `red`)
+    double g12[12], v12[12];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) g12[r] = 0.0;
     {
-        double up[78];
-        for (int k = 0; k < 78; ++k) up[k] = 0.0;
-        PP_FOR_POINTS(ps, i, {
-            double a[4], r1[12], r2[12];
+        const int kj = gk / 3, kc = gk - 3 * kj;   // column gk = (control point kj, coordinate kc); kj == 4 for the idle lanes
+        auto add_point = [&](int i) {
+            double a[4];
             alphas(i, a);
-            const double u = ps.p2[2 * i], vv = ps.p2[2 * i + 1];
+            const double du = cam.uc - ps.p2[2 * i], dv = cam.vc - ps.p2[2 * i + 1];
+            const double ak = kj == 0 ? a[0] : kj == 1 ? a[1] : kj == 2 ? a[2] : kj == 3 ? a[3] : 0.0;
+            // row 1 of the point: (a_j fu, 0, a_j du), row 2: (0, a_j fv, a_j dv)
+            const double r1k = kc == 0 ? ak * cam.fu : kc == 2 ? ak * du : 0.0;
+            const double r2k = kc == 1 ? ak * cam.fv : kc == 2 ? ak * dv : 0.0;
+#pragma unroll
             for (int j = 0; j < 4; ++j) {
-                r1[3 * j] = a[j] * cam.fu; r1[3 * j + 1] = 0.0; r1[3 * j + 2] = a[j] * (cam.uc - u);
-                r2[3 * j] = 0.0; r2[3 * j + 1] = a[j] * cam.fv; r2[3 * j + 2] = a[j] * (cam.vc - vv);
+                g12[3 * j] += (a[j] * cam.fu) * r1k;
+                g12[3 * j + 1] += (a[j] * cam.fv) * r2k;
+                g12[3 * j + 2] += (a[j] * du) * r1k + (a[j] * dv) * r2k;
             }
-            int k = 0;
-            for (int r = 0; r < 12; ++r)
-                for (int c = r; c < 12; ++c) up[k++] += r1[r] * r1[c] + r2[r] * r2[c];
-        })
-        block_sum(ps, up, 78);
-        int k = 0;
-        for (int r = 0; r < 12; ++r)
-            for (int c = r; c < 12; ++c) {
-                mtm[r * 12 + c] = up[k];
-                mtm[c * 12 + r] = up[k++];
+        };
+        if (MODE == 0) {
+            for (int ii = 0; ii < ps.n; ++ii) add_point(ps.idx[ii]);
+        } else {
+            for (int i = threadIdx.x / GL; i < ps.n; i += NG)
+                if (ps.use[i]) add_point(i);
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+            for (int r = 0; r < 12; ++r) { g12[r] += __shfl_xor(g12[r], 16); g12[r] += __shfl_xor(g12[r], 32); }
+            __syncthreads();
+            if (lane < 12) {
+#pragma unroll
+                for (int r = 0; r < 12; ++r) ps.red[(wv * 12 + lane) * 12 + r] = g12[r];
             }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                double x = 0.0;
+                if (gk < 12)
+                    for (int w = 0; w < NW; ++w) x += ps.red[(w * 12 + gk) * 12 + r];
+                g12[r] = x;
+            }
+        }
     }
-    double ew[12], ev[144];
-    jacobi_eig<12>(mtm, ew, ev);  // ascending: ev rows 0..3 span the (approximate) null space
-    const double* vn[4] = {ev, ev + 12, ev + 24, ev + 36};
+    hestenes12(g12, v12, gk);
+    // the four eigenvectors of the smallest eigenvalues, ascending, into every lane: vn[i][0..12)
+    double vn[4][12];
+    {
+        double lam = 0.0;
+#pragma unroll
+        for (int r = 0; r < 12; ++r) lam += g12[r] * g12[r];   // |g_k|^2 = lambda_k^2: same order
+        if (gk >= 12) lam = 1e300;
+        int rank = 0;
+#pragma unroll
+        for (int o = 0; o < 12; ++o) {
+            const double lo = __shfl(lam, o, GL);
+            rank += (lo < lam || (lo == lam && o < gk)) ? 1 : 0;
+        }
+        int src[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int o = 0; o < 12; ++o) {
+            const int ro = __shfl(rank, o, GL);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) src[q] = ro == q ? o : src[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 12; ++r) vn[q][r] = __shfl(v12[r], src[q], GL);
+    }
     // ---- L (6 x 10) and rho
     double L[6][10], rho[6];
     {
-        const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+        constexpr int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
         double dv[4][6][3];
+#pragma unroll
         for (int i = 0; i < 4; ++i)
+#pragma unroll
             for (int p = 0; p < 6; ++p)
+#pragma unroll
                 for (int c = 0; c < 3; ++c) dv[i][p][c] = vn[i][3 * pa[p] + c] - vn[i][3 * pb[p] + c];
-        auto dot = [&](int i, int j, int p) { return dv[i][p][0] * dv[j][p][0] + dv[i][p][1] * dv[j][p][1] + dv[i][p][2] * dv[j][p][2]; };
+#define PP_DOT(i, j, p) (dv[i][p][0] * dv[j][p][0] + dv[i][p][1] * dv[j][p][1] + dv[i][p][2] * dv[j][p][2])
+#pragma unroll
         for (int p = 0; p < 6; ++p) {
-            L[p][0] = dot(0, 0, p); L[p][1] = 2 * dot(0, 1, p); L[p][2] = dot(1, 1, p); L[p][3] = 2 * dot(0, 2, p);
-            L[p][4] = 2 * dot(1, 2, p); L[p][5] = dot(2, 2, p); L[p][6] = 2 * dot(0, 3, p); L[p][7] = 2 * dot(1, 3, p);
-            L[p][8] = 2 * dot(2, 3, p); L[p][9] = dot(3, 3, p);
+            L[p][0] = PP_DOT(0, 0, p); L[p][1] = 2 * PP_DOT(0, 1, p); L[p][2] = PP_DOT(1, 1, p); L[p][3] = 2 * PP_DOT(0, 2, p);
+            L[p][4] = 2 * PP_DOT(1, 2, p); L[p][5] = PP_DOT(2, 2, p); L[p][6] = 2 * PP_DOT(0, 3, p); L[p][7] = 2 * PP_DOT(1, 3, p);
+            L[p][8] = 2 * PP_DOT(2, 3, p); L[p][9] = PP_DOT(3, 3, p);
             double s = 0.0;
+#pragma unroll
             for (int c = 0; c < 3; ++c) s += (cws[pa[p]][c] - cws[pb[p]][c]) * (cws[pa[p]][c] - cws[pb[p]][c]);
             rho[p] = s;
         }
+#undef PP_DOT
     }
     // ---- three beta initialisations, Gauss-Newton, pose, keep the least reprojection error
     double best_err = 1e300;
@@ -292,12 +451,14 @@ __device__ double epnp(const PointSet<MODE>& ps, const Cam& cam, double* R, doub
         double b[4] = {0, 0, 0, 0};
         if (approx == 0) {  // betas10 columns B11 B12 B13 B14
             double A4[6][4], x[4];
+#pragma unroll
             for (int p = 0; p < 6; ++p) { A4[p][0] = L[p][0]; A4[p][1] = L[p][1]; A4[p][2] = L[p][3]; A4[p][3] = L[p][6]; }
             lstsq6<4>(A4, rho, x);
             if (x[0] < 0) { b[0] = sqrt(-x[0]); b[1] = -x[1] / b[0]; b[2] = -x[2] / b[0]; b[3] = -x[3] / b[0]; }
             else { b[0] = sqrt(x[0]); b[1] = x[1] / b[0]; b[2] = x[2] / b[0]; b[3] = x[3] / b[0]; }
         } else if (approx == 1) {  // B11 B12 B22
             double A3[6][3], x[3];
+#pragma unroll
             for (int p = 0; p < 6; ++p) { A3[p][0] = L[p][0]; A3[p][1] = L[p][1]; A3[p][2] = L[p][2]; }
             lstsq6<3>(A3, rho, x);
             if (x[0] < 0) { b[0] = sqrt(-x[0]); b[1] = x[2] < 0 ? sqrt(-x[2]) : 0.0; }
@@ -305,7 +466,9 @@ __device__ double epnp(const PointSet<MODE>& ps, const Cam& cam, double* R, doub
             if (x[1] < 0) b[0] = -b[0];
         } else {  // B11 B12 B22 B13 B23
             double A5[6][5], x[5];
+#pragma unroll
             for (int p = 0; p < 6; ++p)
+#pragma unroll
                 for (int c = 0; c < 5; ++c) A5[p][c] = L[p][c];
             lstsq6<5>(A5, rho, x);
             if (x[0] < 0) { b[0] = sqrt(-x[0]); b[1] = x[2] < 0 ? sqrt(-x[2]) : 0.0; }
@@ -313,9 +476,11 @@ __device__ double epnp(const PointSet<MODE>& ps, const Cam& cam, double* R, doub
             if (x[1] < 0) b[0] = -b[0];
             b[2] = fabs(b[0]) > 1e-300 ? x[3] / b[0] : 0.0;
         }
+        // (MODE 1: b is the same in every thread, so this branch is uniform and the block sums below stay aligned)
         if (!(b[0] == b[0]) || !(b[1] == b[1]) || !(b[2] == b[2]) || !(b[3] == b[3])) continue;
         for (int it = 0; it < 5; ++it) {  // Gauss-Newton on the 6 distance constraints
             double A[6][4], rb[6], dx[4];
+#pragma unroll
             for (int p = 0; p < 6; ++p) {
                 const double* l = L[p];
                 A[p][0] = 2 * l[0] * b[0] + l[1] * b[1] + l[3] * b[2] + l[6] * b[3];
@@ -327,42 +492,51 @@ __device__ double epnp(const PointSet<MODE>& ps, const Cam& cam, double* R, doub
                                   l[8] * b[2] * b[3] + l[9] * b[3] * b[3]);
             }
             lstsq6<4>(A, rb, dx);
+#pragma unroll
             for (int k = 0; k < 4; ++k) b[k] += dx[k];
         }
         // control points in the camera frame, sign from the depth of the points
         double ccs[4][3];
+#pragma unroll
         for (int j = 0; j < 4; ++j)
+#pragma unroll
             for (int c = 0; c < 3; ++c) ccs[j][c] = b[0] * vn[0][3 * j + c] + b[1] * vn[1][3 * j + c] + b[2] * vn[2][3 * j + c] + b[3] * vn[3][3 * j + c];
-        double s8[16];
-        for (int k = 0; k < 7; ++k) s8[k] = 0.0;
+        double s6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         PP_FOR_POINTS(ps, i, {
             double a[4];
             alphas(i, a);
-            for (int c = 0; c < 3; ++c) s8[c] += a[0] * ccs[0][c] + a[1] * ccs[1][c] + a[2] * ccs[2][c] + a[3] * ccs[3][c];
-            s8[3] += ps.p3[3 * i]; s8[4] += ps.p3[3 * i + 1]; s8[5] += ps.p3[3 * i + 2];
+_Pragma("unroll")
+            for (int c = 0; c < 3; ++c) s6[c] += a[0] * ccs[0][c] + a[1] * ccs[1][c] + a[2] * ccs[2][c] + a[3] * ccs[3][c];
+            s6[3] += ps.p3[3 * i]; s6[4] += ps.p3[3 * i + 1]; s6[5] += ps.p3[3 * i + 2];
         })
-        block_sum(ps, s8, 6);
-        if (s8[2] < 0) {  // solve_for_sign (mean depth must be positive)
+        block_sum<MODE, 6>(ps, s6);
+        if (s6[2] < 0) {  // solve_for_sign (mean depth must be positive)
+#pragma unroll
             for (int j = 0; j < 4; ++j)
+#pragma unroll
                 for (int c = 0; c < 3; ++c) ccs[j][c] = -ccs[j][c];
-            for (int c = 0; c < 3; ++c) s8[c] = -s8[c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s6[c] = -s6[c];
         }
         double pc0[3], pw0[3];
-        for (int c = 0; c < 3; ++c) { pc0[c] = s8[c] / n; pw0[c] = s8[3 + c] / n; }
-        double H[9];
-        for (int k = 0; k < 9; ++k) H[k] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pc0[c] = s6[c] / n; pw0[c] = s6[3 + c] / n; }
+        double H[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         PP_FOR_POINTS(ps, i, {
             double a[4], pc[3];
             alphas(i, a);
+_Pragma("unroll")
             for (int c = 0; c < 3; ++c) pc[c] = a[0] * ccs[0][c] + a[1] * ccs[1][c] + a[2] * ccs[2][c] + a[3] * ccs[3][c] - pc0[c];
             const double w0 = ps.p3[3 * i] - pw0[0], w1 = ps.p3[3 * i + 1] - pw0[1], w2 = ps.p3[3 * i + 2] - pw0[2];
+_Pragma("unroll")
             for (int r = 0; r < 3; ++r) { H[r * 3] += pc[r] * w0; H[r * 3 + 1] += pc[r] * w1; H[r * 3 + 2] += pc[r] * w2; }
         })
-        block_sum(ps, H, 9);
+        block_sum<MODE, 9>(ps, H);
         double Rc[9], tc[3];
         horn_rotation(H, Rc);
+#pragma unroll
         for (int r = 0; r < 3; ++r) tc[r] = pc0[r] - (Rc[r * 3] * pw0[0] + Rc[r * 3 + 1] * pw0[1] + Rc[r * 3 + 2] * pw0[2]);
-        double er[2] = {0.0, 0.0};
+        double er[1] = {0.0};
         PP_FOR_POINTS(ps, i, {
             const double X = ps.p3[3 * i], Y = ps.p3[3 * i + 1], Z = ps.p3[3 * i + 2];
             const double xc = Rc[0] * X + Rc[1] * Y + Rc[2] * Z + tc[0], yc = Rc[3] * X + Rc[4] * Y + Rc[5] * Z + tc[1];
@@ -371,11 +545,13 @@ __device__ double epnp(const PointSet<MODE>& ps, const Cam& cam, double* R, doub
             const double du = cam.uc + cam.fu * xc * iz - ps.p2[2 * i], dvv = cam.vc + cam.fv * yc * iz - ps.p2[2 * i + 1];
             er[0] += sqrt(du * du + dvv * dvv);
         })
-        block_sum(ps, er, 1);
+        block_sum<MODE, 1>(ps, er);
         const double err = er[0] / n;
         if (err == err && err < best_err) {
             best_err = err;
+#pragma unroll
             for (int k = 0; k < 9; ++k) R[k] = Rc[k];
+#pragma unroll
             for (int k = 0; k < 3; ++k) t[k] = tc[k];
         }
     }
@@ -400,10 +576,10 @@ __global__ __launch_bounds__(NT) void pnp_ransac_kernel(const float* __restrict_
     float* p3 = (float*)smem;                      // [MAXP][3]
     float* p2 = p3 + 3 * MAXP;                     // [MAXP][2]
     unsigned char* use = (unsigned char*)(p2 + 2 * MAXP);  // [MAXP]
-    double* red = (double*)(use + MAXP);           // [NT]
-    double* hyp = red + NT;                        // [NT][12]  R, t of every hypothesis
-    int* cnt = (int*)(hyp + NT * 12);              // [NT]
-    __shared__ int wsum[4], base, best_h, best_c;
+    double* red = (double*)(use + MAXP);           // [NW][144]
+    double* hyp = red + NW * 144;                  // [MAXH][12]  R, t of every hypothesis
+    int* cnt = (int*)(hyp + MAXH * 12);            // [MAXH]
+    __shared__ int wsum[NW], base, best_h, best_c;
     const int prob = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t* tp = tar_pts + (size_t)prob * N * 2;
     const int64_t* sp = src_pts + (size_t)prob * N * 2;
@@ -415,6 +591,7 @@ __global__ __launch_bounds__(NT) void pnp_ransac_kernel(const float* __restrict_
 
     // ---- gather the valid correspondences in list order (utils/torch_utils.py:257-284), object frame
     if (tid == 0) base = 0;
+    if (tid < MAXH) cnt[tid] = 0;
     __syncthreads();
     for (int n0 = 0; n0 < N; n0 += NT) {
         const int n = n0 + tid;
@@ -424,8 +601,8 @@ __global__ __launch_bounds__(NT) void pnp_ransac_kernel(const float* __restrict_
         const unsigned long long bal = __ballot(v);
         if (lane == 0) wsum[wv] = __popcll(bal);
         __syncthreads();
-        int off = base;
-        for (int i = 0; i < wv; ++i) off += wsum[i];
+        int off = base, tot = 0;
+        for (int i = 0; i < NW; ++i) { off += i < wv ? wsum[i] : 0; tot += wsum[i]; }
         if (v) {
             const int r = off + __popcll(bal & ((1ull << lane) - 1ull));
             if (r < MAXP) {
@@ -439,7 +616,7 @@ __global__ __launch_bounds__(NT) void pnp_ransac_kernel(const float* __restrict_
             }
         }
         __syncthreads();
-        if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (tid == 0) base += tot;
         __syncthreads();
     }
     const int np = base < MAXP ? base : MAXP;
@@ -454,52 +631,80 @@ __global__ __launch_bounds__(NT) void pnp_ransac_kernel(const float* __restrict_
     };
     if (np < SAMPLE) { fail(); return; }
 
-    // ---- RANSAC hypotheses: thread h solves EPnP on its own 5-point sample
-    const int nh = iters < NT ? iters : NT;
-    if (tid < nh) {
-        int idx[SAMPLE];
-        unsigned s = hash32(0x9E3779B9u * (unsigned)(prob + 1) ^ (unsigned)(tid * 7919 + 17));
-        for (int k = 0; k < SAMPLE; ++k) {
-            for (;;) {
-                s = hash32(s + 0x6D2B79F5u);
-                const int c = (int)(s % (unsigned)np);
-                bool dup = false;
-                for (int j = 0; j < k; ++j) dup |= idx[j] == c;
-                if (!dup) { idx[k] = c; break; }
+    // ---- RANSAC hypotheses: solver group g (16 lanes) solves EPnP on the 5-point samples of hypotheses g, g + NG, ...
+    const int nh = iters < MAXH ? iters : MAXH;
+    for (int h0 = 0; h0 < nh; h0 += NG) {
+        const int h = h0 + tid / GL;
+        if (h < nh) {      // (uniform over the 16 lanes of a group; the shuffles inside stay within the group)
+            int idx[SAMPLE];
+            unsigned s = hash32(0x9E3779B9u * (unsigned)(prob + 1) ^ (unsigned)(h * 7919 + 17));
+#pragma unroll
+            for (int k = 0; k < SAMPLE; ++k) {
+                for (;;) {
+                    s = hash32(s + 0x6D2B79F5u);
+                    const int c = (int)(s % (unsigned)np);
+                    bool dup = false;
+#pragma unroll
+                    for (int j = 0; j < SAMPLE; ++j) dup |= j < k && idx[j] == c;
+                    if (!dup) { idx[k] = c; break; }
+                }
+            }
+            PointSet<0> ps = {p3, p2, idx, nullptr, SAMPLE, nullptr};
+            double R[9], t[3];
+            const double e = epnp<0>(ps, cam, R, t);
+            if ((tid & (GL - 1)) == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) hyp[h * 12 + k] = e < 1e299 ? R[k] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) hyp[h * 12 + 9 + k] = e < 1e299 ? t[k] : 0.0;
             }
         }
-        PointSet<0> ps = {p3, p2, idx, nullptr, SAMPLE, nullptr};
-        double R[9], t[3];
-        const double e = epnp<0>(ps, cam, R, t);
-        for (int k = 0; k < 9; ++k) hyp[tid * 12 + k] = e < 1e299 ? R[k] : 0.0;
-        for (int k = 0; k < 3; ++k) hyp[tid * 12 + 9 + k] = e < 1e299 ? t[k] : 0.0;
     }
     __syncthreads();
-    // ---- score every hypothesis on every point (squared reprojection error <= thresh^2)
+    // ---- score every hypothesis on every point (squared reprojection error <= thresh^2): a thread keeps its (up to 8)
+    // points in registers and walks the hypotheses (the 12 doubles of a model are an LDS broadcast); counts are summed
+    // per wave and added to cnt[h] with one LDS atomic per wave — no barrier inside the loop
     const double th2 = (double)thresh * (double)thresh;
-    for (int h = 0; h < nh; ++h) {
-        const double* M = hyp + h * 12;
-        int c = 0;
-        for (int i = tid; i < np; i += NT) {
-            const double X = p3[3 * i], Y = p3[3 * i + 1], Z = p3[3 * i + 2];
-            const double zc = M[6] * X + M[7] * Y + M[8] * Z + M[11];
-            const double iz = 1.0 / zc;
-            const double du = cam.uc + cam.fu * (M[0] * X + M[1] * Y + M[2] * Z + M[9]) * iz - p2[2 * i];
-            const double dv = cam.vc + cam.fv * (M[3] * X + M[4] * Y + M[5] * Z + M[10]) * iz - p2[2 * i + 1];
-            c += (du * du + dv * dv <= th2) ? 1 : 0;  // NaN (degenerate hypothesis) is never an inlier
+    {
+        constexpr int PPT = MAXP / NT;
+        double X[PPT], Y[PPT], Z[PPT], U[PPT], V[PPT];
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int i = tid + q * NT;
+            const bool in = i < np;
+            X[q] = in ? p3[3 * i] : 0.0; Y[q] = in ? p3[3 * i + 1] : 0.0; Z[q] = in ? p3[3 * i + 2] : 0.0;
+            U[q] = in ? p2[2 * i] : 1e30; V[q] = in ? p2[2 * i + 1] : 1e30;      // a padding slot is never an inlier
         }
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (lane == 0) wsum[wv] = c;
-        __syncthreads();
-        if (tid == 0) cnt[h] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
+        for (int h = 0; h < nh; ++h) {
+            const double* M = hyp + h * 12;
+            const double m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3], m4 = M[4], m5 = M[5], m6 = M[6], m7 = M[7], m8 = M[8];
+            const double t0 = M[9], t1 = M[10], t2 = M[11];
+            int c = 0;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                if (q * NT >= np) break;   // uniform
+                const double zc = m6 * X[q] + m7 * Y[q] + m8 * Z[q] + t2;
+                const double iz = 1.0 / zc;
+                const double du = cam.uc + cam.fu * (m0 * X[q] + m1 * Y[q] + m2 * Z[q] + t0) * iz - U[q];
+                const double dv = cam.vc + cam.fv * (m3 * X[q] + m4 * Y[q] + m5 * Z[q] + t1) * iz - V[q];
+                c += (du * du + dv * dv <= th2) ? 1 : 0;  // NaN (degenerate hypothesis) is never an inlier
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            if (lane == 0 && c) atomicAdd(&cnt[h], c);
+        }
     }
-    if (tid == 0) {
-        int bh = 0, bc = -1;
-        for (int h = 0; h < nh; ++h)
+    __syncthreads();
+    if (tid < 64) {   // arg-max of the consensus, lowest hypothesis index among equals
+        int bc = -1, bh = 0;
+        for (int h = tid; h < nh; h += 64)
             if (cnt[h] > bc) { bc = cnt[h]; bh = h; }
-        best_h = bh;
-        best_c = bc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int oc = __shfl_xor(bc, o), oh = __shfl_xor(bh, o);
+            if (oc > bc || (oc == bc && oh < bh)) { bc = oc; bh = oh; }
+        }
+        if (tid == 0) { best_h = bh; best_c = bc; }
     }
     __syncthreads();
     if (best_c < SAMPLE) { fail(); return; }
@@ -540,8 +745,8 @@ int pp_pnp_ransac(const float* tar_pts_2d, const float* src_pts_3d, const float*
         !success || !num_points)
         return PP_EINVAL;
     if (P <= 0 || H <= 0 || W <= 0 || N <= 0 || N > MAXP || iterations <= 0 || reproj_threshold <= 0.f) return PP_EINVAL;
-    const size_t smem = (size_t)MAXP * (3 + 2) * sizeof(float) + MAXP + NT * sizeof(double) + (size_t)NT * 12 * sizeof(double) +
-                        NT * sizeof(int);
+    const size_t smem = (size_t)MAXP * (3 + 2) * sizeof(float) + MAXP + (size_t)NW * 144 * sizeof(double) +
+                        (size_t)MAXH * 12 * sizeof(double) + MAXH * sizeof(int);
     static bool attr_set[PP_MAX_DEVICES];   // the dynamic-LDS opt-in is per device
     if (!attr_set[pp_cur_device()]) {
         PP_CHECK_HIP(hipFuncSetAttribute((const void*)pnp_ransac_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

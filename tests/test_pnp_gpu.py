@@ -1,50 +1,22 @@
 """Known-answer tests of the GPU PnP/RANSAC (utils/pose_recovery.py:68-105).  cv2 is not available, so
 parity with OpenCV is unpinned: correctness is defined on synthetic correspondences."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 gpu = pytest.mark.gpu
-K0 = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1.0]])
-
-
-def _rot(rng):
-    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
-    return q * np.sign(np.linalg.det(q))
 
 
 def _problem(rng, n_pts, n_out=0, noise=0.0):
-    """Build the function's inputs for one problem: template-frame 3-D map, original-image 2-D map, index lists."""
-    R_tem, t_tem = _rot(rng), np.array([0.02, -0.01, 0.8])
-    R_gt, t_gt = _rot(rng), np.array([0.05, -0.03, 0.9]) + 0.05 * rng.standard_normal(3)
-    H = W = 64
-    src3d = np.zeros((3, H, W), np.float32)
-    tar2d = np.zeros((2, H, W), np.float32)
-    tar_pts = -np.ones((H * W, 2), np.int64)
-    src_pts = -np.ones((H * W, 2), np.int64)
-    cells = rng.permutation(H * W)[:n_pts]
-    tcells = rng.permutation(H * W)[:n_pts]
-    slots = np.sort(rng.permutation(H * W)[:n_pts])
-    obj = (rng.random((n_pts, 3)) - 0.5) * 0.2
-    cam_tem = obj @ R_tem.T + t_tem
-    cam_gt = obj @ R_gt.T + t_gt
-    uv = (cam_gt / cam_gt[:, 2:]) @ K0.T
-    uv = uv[:, :2] + noise * rng.standard_normal((n_pts, 2))
-    outl = rng.permutation(n_pts)[:n_out]
-    uv[outl] = rng.random((n_out, 2)) * np.array([640, 480])
-    for i in range(n_pts):
-        sy, sx = divmod(int(cells[i]), W)
-        ty, tx = divmod(int(tcells[i]), W)
-        src3d[:, sy, sx] = cam_tem[i]
-        tar2d[:, ty, tx] = uv[i]
-        src_pts[slots[i]] = (sx, sy)
-        tar_pts[slots[i]] = (tx, ty)
-    pose = np.eye(4, dtype=np.float32)
-    pose[:3, :3], pose[:3, 3] = R_tem, t_tem
-    inl = np.ones(n_pts, bool)
-    inl[outl] = False
-    return dict(tar2d=tar2d, src3d=src3d, K=K0.astype(np.float32), pose=pose, tar_pts=tar_pts, src_pts=src_pts,
-                R=R_gt, t=t_gt, n_in=int(inl.sum()))
+    """One problem in the function's input layout (tests/pnp_problems.py), as a dict of per-problem arrays."""
+    from pnp_problems import make_batch
+
+    b = make_batch(rng, 1, n_pts, (n_out / n_pts) if n_pts else 0.0, noise)
+    return {k: (v[0] if isinstance(v, np.ndarray) else v) for k, v in b.items()}
 
 
 def _run(problems):
@@ -117,9 +89,44 @@ def test_hip_kernel_agrees_with_the_cpu_oracle():
             assert np.array_equal(rot[i], r) and np.array_equal(tvec[i], t) and ratio[i] == ra
             continue
         n = int((p["tar_pts"][:, 0] != -1).sum())
-        # stated tolerance: the winning hypothesis may differ where two 5-point models tie within a point or two
-        assert abs(ratio[i] - ra) * n <= 2, (i, ratio[i] * n, ra * n)
+        # stated tolerance: a 5-point sample leaves M^T M with a 2-dimensional null space, whose basis is the eigensolver's
+        # choice (one-sided Jacobi here, LAPACK there): some of the 150 hypotheses differ, and on noisy data the winner
+        # may be another model of nearly the same consensus
+        assert abs(ratio[i] - ra) * n <= max(2, 0.02 * n), (i, ratio[i] * n, ra * n)
         # clean data: solver tolerance.  Noisy data: the two refits run on inlier sets that may differ by a point
         # or two, which moves the pose by about noise / (f * sqrt(n)) * depth — loosest for the 64-point case
         tol = (1e-6, 2e-3, 1e-2, 2e-3, 1e-6)[i]
         assert np.abs(rot[i] - r).max() < tol and np.abs(tvec[i] - t).max() < tol, (i, np.abs(rot[i] - r).max())
+
+
+@gpu
+def test_statistical_characterisation_against_ground_truth_and_oracle():
+    """cv2.solvePnPRansac cannot be pinned here, so the kernel is characterised statistically: 200 seeded
+    problems per regime (noise 0 / 0.3 / 1 px x outliers 0 / 30 / 60 % x n = 8 / 64 / 512 / 4096), success rate and
+    error quantiles against the planted pose, the CPU oracle on a sub-sample.  Thresholds: the 1000-problem table of
+    profiles/r02/pnp_stats.md with a margin, and what RANSAC theory allows — 150 five-point samples contain an
+    all-inlier one with probability 1 - (1 - w^5)^150 = 0.786 at inlier fraction w = 0.4 (1.0 at w >= 0.7)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import pnp_stats
+
+    table = pnp_stats.run(problems=200, n_oracle=3, log=lambda s: None)
+    assert len(table) == 36
+    for r in table:
+        n, out, noise, tag = r["n"], r["outliers"], r["noise_px"], (r["n"], r["outliers"], r["noise_px"])
+        if r["n_inliers"] < 5:                                   # n = 8 with 60 % outliers: 3 true correspondences
+            assert r["returned_success"] <= 0.02, tag            # (5 uniform outliers agreeing within 2 px: never, in practice)
+            continue
+        if out <= 0.3:
+            assert r["returned_success"] >= 0.99, (tag, r)
+            assert r["pose_found"] >= (0.95 if n == 8 or noise == 1.0 else 0.99), (tag, r)
+            if noise == 0.0:
+                assert r["rot_deg_p95"] < 1e-3 and r["trans_rel_p95"] < 1e-5, (tag, r)
+                # exact data: kernel and oracle find the same consensus and the same pose
+                assert r["oracle_vs_gpu_inlier_count_maxdiff"] == 0 and r["oracle_vs_gpu_rot_maxdiff"] < 1e-6, (tag, r)
+            else:
+                assert r["rot_deg_p95"] < 4.0 * noise / np.sqrt(r["n_inliers"]) * 3.2 + 0.3 * noise, (tag, r)
+        else:                                                    # 60 % outliers: bounded by the sampling probability
+            assert 0.55 <= r["returned_success"] <= 1.0, (tag, r)
+            if noise <= 0.3:
+                assert r["pose_found"] >= 0.55 and r["rot_deg_p50"] < 0.3, (tag, r)
+        assert r["oracle_success_agrees"] >= 0.66, (tag, r)
