@@ -80,15 +80,93 @@ def _horn(H):
     return U @ D @ Vt
 
 
-def epnp(p3, p2, cam):
-    """EPnP on the given points: returns (mean reprojection error, R (3,3), t (3,)); error = inf if no solution."""
+def _eig3_jacobi(A):
+    """Cyclic Jacobi on a symmetric 3x3 matrix in the kernel's rotation order (csrc/pp_pnp.hip eig3_sym): eigenvalues
+    ascending, eigenvectors as rows.  Used with solver="kernel" so that eigenvector SIGNS (which fix the control points'
+    parametrisation) are the kernel's, not LAPACK's."""
+    A = np.array(A, np.float64)
+    V = np.eye(3)
+    for _ in range(30):
+        off = A[0, 1] ** 2 + A[0, 2] ** 2 + A[1, 2] ** 2
+        diag = A[0, 0] ** 2 + A[1, 1] ** 2 + A[2, 2] ** 2
+        if off <= 1e-30 * (diag + 1e-300):
+            break
+        for p, q in ((0, 1), (0, 2), (1, 2)):
+            apq = A[p, q]
+            if abs(apq) < 1e-300:
+                continue
+            theta = (A[q, q] - A[p, p]) / (2.0 * apq)
+            t = (1.0 if theta >= 0 else -1.0) / (abs(theta) + np.sqrt(theta * theta + 1.0))
+            c = 1.0 / np.sqrt(t * t + 1.0)
+            sn = t * c
+            J = np.eye(3)
+            J[p, p] = J[q, q] = c
+            J[p, q], J[q, p] = sn, -sn
+            A = J.T @ A @ J
+            V = J.T @ V                                   # rows p, q of V: c v_p - s v_q, s v_p + c v_q
+    w = np.diag(A).copy()
+    order = sorted(range(3), key=lambda k: (w[k], k))
+    return w[order], V[order]
+
+
+def _round_robin(s):
+    """The 6 disjoint column pairs (p < q) of round s of the kernel's 12-player tournament."""
+    pairs = [(s, 11)]
+    for k in range(11):
+        if k != s:
+            q = (2 * s - k) % 11
+            if k < q:
+                pairs.append((k, q))
+    return pairs
+
+
+def _hestenes12(G):
+    """One-sided Jacobi on the columns of the symmetric PSD 12x12 G, restating csrc/pp_pnp.hip hestenes12 (same pair
+    order, same convergence floor, incremental column norms; the kernel evaluates the rotation tangent in fp32, this
+    restatement in fp64 — an angle difference of 1e-7).  Returns (lambda^2 per column, V) with V[:, k] the eigenvector."""
+    g = np.array(G, np.float64)
+    v = np.eye(12)
+    for _ in range(14):
+        alpha = (g * g).sum(axis=0)
+        floor2 = 2.5e-29 * alpha.max()
+        rotated = False
+        for s in range(11):
+            for p, q in _round_robin(s):
+                gamma = float(g[:, p] @ g[:, q])
+                ap, aq = alpha[p], alpha[q]
+                if gamma * gamma > floor2 * (ap + aq):
+                    rotated = True
+                    zeta = (aq - ap) / (2.0 * gamma)
+                    t = (1.0 if zeta >= 0 else -1.0) / (abs(zeta) + np.sqrt(1.0 + zeta * zeta))
+                    if not (abs(t) <= 1.0):
+                        t = 0.0
+                    c = 1.0 / np.sqrt(1.0 + t * t)
+                    sn = c * t
+                    gp, gq, vp, vq = g[:, p].copy(), g[:, q].copy(), v[:, p].copy(), v[:, q].copy()
+                    g[:, p], g[:, q] = c * gp - sn * gq, sn * gp + c * gq
+                    v[:, p], v[:, q] = c * vp - sn * vq, sn * vp + c * vq
+                    alpha[p] = c * c * ap - 2.0 * c * sn * gamma + sn * sn * aq
+                    alpha[q] = sn * sn * ap + 2.0 * c * sn * gamma + c * c * aq
+        if not rotated:
+            break
+    return (g * g).sum(axis=0), v
+
+
+def epnp(p3, p2, cam, solver="lapack"):
+    """EPnP on the given points: returns (mean reprojection error, R (3,3), t (3,)); error = inf if no solution.
+    solver="lapack": numpy eigh (independent of the kernel); solver="kernel": the kernel's own eigen-solvers restated
+    (_eig3_jacobi, _hestenes12), which fixes the basis of the degenerate null space of a minimal sample the same way."""
     fu, fv, uc, vc = cam
     p3 = np.asarray(p3, np.float64)
     p2 = np.asarray(p2, np.float64)
     n = len(p3)
     c0 = p3.mean(axis=0)
     q = p3 - c0
-    w, v = np.linalg.eigh(q.T @ q)                          # ascending
+    if solver == "kernel":
+        w, vr = _eig3_jacobi(q.T @ q)
+        v = vr.T
+    else:
+        w, v = np.linalg.eigh(q.T @ q)                      # ascending
     cws = [c0]
     for k in range(3):                                       # largest first
         cws.append(c0 + np.sqrt(max(w[2 - k], 0.0) / n) * v[:, 2 - k])
@@ -104,8 +182,13 @@ def epnp(p3, p2, cam):
         M[0::2, 3 * j + 2] = al[:, j] * (uc - p2[:, 0])
         M[1::2, 3 * j + 1] = al[:, j] * fv
         M[1::2, 3 * j + 2] = al[:, j] * (vc - p2[:, 1])
-    _, ev = np.linalg.eigh(M.T @ M)
-    vn = [ev[:, k] for k in range(4)]                        # null-space basis, smallest eigenvalue first
+    if solver == "kernel":
+        lam2, ev = _hestenes12(M.T @ M)
+        order = sorted(range(12), key=lambda k: (lam2[k], k))
+        vn = [ev[:, order[k]] for k in range(4)]
+    else:
+        _, ev = np.linalg.eigh(M.T @ M)
+        vn = [ev[:, k] for k in range(4)]                    # null-space basis, smallest eigenvalue first
     pa, pb = [0, 0, 0, 1, 1, 2], [1, 2, 3, 2, 3, 3]
     dv = np.array([[vn[i][3 * pa[p]:3 * pa[p] + 3] - vn[i][3 * pb[p]:3 * pb[p] + 3] for p in range(6)] for i in range(4)])
     dot = lambda i, j: (dv[i] * dv[j]).sum(axis=1)           # noqa: E731  (6,)
@@ -166,7 +249,7 @@ def _inliers(p3, p2, cam, R, t, th2):
 
 
 def pose_recovery_ransac_pnp(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, prob=0, iterations=150,
-                             reproj_error=2.0):
+                             reproj_error=2.0, solver="lapack"):
     """utils/pose_recovery.py:68-105 -> (rot (3,3) f64, tvecs (3,1) f64, inliers_ratio float, success bool).
     `prob` is the problem's index in its batch (it seeds the sampling sequence, as in the batched HIP launch)."""
     fail = (np.eye(3), np.array([[0.0], [0.0], [1.0]]), 0.0, False)
@@ -180,7 +263,7 @@ def pose_recovery_ransac_pnp(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_p
     best_c, best = -1, None
     for h in range(min(iterations, 256)):                    # one hypothesis per thread of the 256-thread workgroup
         idx = sample_indices(prob, h, n)
-        err, R, t = epnp(p3[idx], p2[idx], cam)
+        err, R, t = epnp(p3[idx], p2[idx], cam, solver)
         if not np.isfinite(err):
             R, t = np.zeros((3, 3)), np.zeros(3)
         c = int(_inliers(p3, p2, cam, R, t, th2).sum())
@@ -189,7 +272,20 @@ def pose_recovery_ransac_pnp(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_p
     if best_c < SAMPLE:
         return fail
     use = _inliers(p3, p2, cam, best[0], best[1], th2)
-    err, R, t = epnp(p3[use], p2[use], cam)
+    err, R, t = epnp(p3[use], p2[use], cam, solver)
     if not np.isfinite(err):
         R, t = best
     return R, t.reshape(3, 1), best_c / n, True
+
+
+def reprojection_gap(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, pose_a, pose_b):
+    """Median pixel distance between the projections of the problem's 3-D points under two poses (R, t) — the well-posed
+    way to compare two PnP answers when the scene leaves part of the pose weakly constrained (a shallow object)."""
+    p3, _ = gather_valid(tar_pts_2d, src_pts_3d, tem_pose, tar_pts, src_pts)
+    K = np.asarray(K, np.float64)
+
+    def proj(R, t):
+        c = p3.astype(np.float64) @ np.asarray(R, np.float64).T + np.asarray(t, np.float64).reshape(1, 3)
+        return np.stack([K[0, 2] + K[0, 0] * c[:, 0] / c[:, 2], K[1, 2] + K[1, 1] * c[:, 1] / c[:, 2]], axis=1)
+
+    return float(np.median(np.linalg.norm(proj(*pose_a) - proj(*pose_b), axis=1)))

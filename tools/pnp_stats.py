@@ -25,9 +25,10 @@ NPTS = (8, 64, 512, 4096)
 def good_pose(ang, dt, noise, n_in):
     """A pose counts as found when it is within the error a least-squares fit of n_in noisy points can have, with slack:
     rotation < 0.05 deg + 60 deg * noise / sqrt(n_in) (px noise over a ~0.2 m object at 0.9 m, f = 572),
-    |dt|/|t| < 1e-4 + 0.01 * noise (the depth of a 2 px consensus set is biased by its truncated noise, whatever n is)."""
+    |dt|/|t| < 1e-4 + 0.1 * noise / sqrt(n_in) + 0.01 * noise (the depth of a 2 px consensus set is biased by its
+    truncated noise, whatever n is)."""
     s = noise / np.sqrt(max(n_in, 1))
-    return (ang < 0.05 + 60.0 * s) & (dt < 1e-4 + 0.01 * noise)
+    return (ang < 0.05 + 60.0 * s) & (dt < 1e-4 + 0.1 * s + 0.01 * noise)
 
 
 def run(problems=1000, n_oracle=6, seed=2024, log=print):
