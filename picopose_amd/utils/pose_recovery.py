@@ -1,4 +1,6 @@
 """Host mirror of reference utils/pose_recovery.py (HIP through the C ABI)."""
+import os
+
 import torch
 
 from .. import _lib
@@ -7,9 +9,13 @@ from .. import _lib
 def pose_recovery_2d_prediction(query_M, query_K, pred_Ms, template_K, template_Ms, template_poses):
     """Drop-in for reference utils/pose_recovery.py:9-65 -> pred_poses (B,4,4).
 
-    The reference asserts (with a host sync) that query_M is a crop affine (M01 = M10 = 0,
-    M00 = M11, torch_utils.py:100-101); here that is the caller's contract."""
+    The reference asserts, with two host syncs per call, that query_M is a crop affine (M01 = M10 = 0, M00 = M11:
+    `inverse_affine`, torch_utils.py:100-101).  Here that is the caller's contract by default — the path stays
+    sync-free — and PP_CHECK_CONTRACTS=1 in the environment restores the two asserts (same AssertionError)."""
     qM, qK, pM, tK, tM, tp = _lib.dev_f32(query_M, query_K, pred_Ms, template_K, template_Ms, template_poses)
+    if os.environ.get("PP_CHECK_CONTRACTS") == "1":
+        assert torch.all(qM[:, 0, 1] == 0) and torch.all(qM[:, 1, 0] == 0)          # torch_utils.py:100
+        assert torch.all(qM[:, 0, 0] == qM[:, 1, 1])                                 # torch_utils.py:101
     B = qM.shape[0]
     out = torch.empty(B, 4, 4, dtype=torch.float32, device=qM.device)
     rc = _lib.lib().pp_pose_recovery_2d(qM.data_ptr(), qK.data_ptr(), pM.data_ptr(), tK.data_ptr(), tM.data_ptr(),

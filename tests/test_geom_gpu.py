@@ -33,6 +33,27 @@ def test_calc_pred_Ms_and_pose_recovery(geo):
 
 
 @gpu
+def test_contract_check_opt_in(geo, monkeypatch):
+    """The reference's inverse_affine asserts a crop affine (torch_utils.py:100-101).  Default here: the caller's contract
+    (no host sync); PP_CHECK_CONTRACTS=1 restores the AssertionError."""
+    from picopose_amd.utils.pose_recovery import pose_recovery_2d_prediction
+
+    z, t = geo
+    bad = t["query_M"].clone()
+    bad[0, 0, 1] = 0.5                                           # a shear: not a crop affine
+    args = lambda qM: (qM, t["K"], t["pred_Ms"], t["K"], t["tem_M"], t["tem_pose"])  # noqa: E731
+    pose_recovery_2d_prediction(*args(bad))                      # default: not checked
+    monkeypatch.setenv("PP_CHECK_CONTRACTS", "1")
+    pose_recovery_2d_prediction(*args(t["query_M"]))             # a valid crop affine passes
+    with pytest.raises(AssertionError):
+        pose_recovery_2d_prediction(*args(bad))
+    uneven = t["query_M"].clone()
+    uneven[1, 1, 1] *= 1.5
+    with pytest.raises(AssertionError):
+        pose_recovery_2d_prediction(*args(uneven))
+
+
+@gpu
 def test_init_correspondences(geo):
     from picopose_amd.utils.correspondence import compute_init_correspondences
 

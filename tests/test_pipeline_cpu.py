@@ -84,3 +84,40 @@ def test_bench_gpus_n_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1"),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stdout.decode()
+
+
+def test_compat_import_installs_the_pnp_drop_in(tmp_path):
+    """run_test.py:26 does `from utils.pose_recovery import pose_recovery_ransac_pnp` at start-up and imports the model
+    module by name only at :234.  With picopose_amd/compat on sys.path that import must re-bind the evaluator's PnP to the
+    HIP drop-in — in `utils.pose_recovery` and in the module that already holds the reference function — so that
+    run_test.py needs no edit.  Stub `utils` package and stub evaluator module; no GPU."""
+    import importlib
+    import os
+    import sys
+    import types
+
+    import picopose_amd
+    from picopose_amd.utils.pose_recovery import pose_recovery_ransac_pnp as ours
+
+    pkg = tmp_path / "utils"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text("")
+    (pkg / "pose_recovery.py").write_text("def pose_recovery_ransac_pnp(*a):\n    return 'reference'\n")
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "utils" or k.startswith("utils.") or k == "picopose"}
+    sys.path.insert(0, str(tmp_path))
+    sys.path.insert(0, os.path.join(os.path.dirname(picopose_amd.__file__), "compat"))
+    try:
+        evaluator = types.ModuleType("fake_run_test")                 # what run_test.py:26 leaves behind
+        exec("from utils.pose_recovery import pose_recovery_ransac_pnp", evaluator.__dict__)
+        sys.modules["fake_run_test"] = evaluator
+        assert evaluator.pose_recovery_ransac_pnp() == "reference"
+        mod = importlib.import_module("picopose")                     # run_test.py:234
+        assert evaluator.pose_recovery_ransac_pnp is ours
+        assert sys.modules["utils.pose_recovery"].pose_recovery_ransac_pnp is ours
+        assert set(mod.installed_in) >= {"utils.pose_recovery", "fake_run_test"}
+    finally:
+        sys.path.remove(str(tmp_path))
+        sys.path.pop(0)
+        for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.") or k in ("picopose", "fake_run_test")]:
+            sys.modules.pop(k)
+        sys.modules.update(saved)
