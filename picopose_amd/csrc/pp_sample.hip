@@ -3,6 +3,7 @@
 // reference's materialised correlation pyramid.
 
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "../../include/picopose_hip.h"
 #include "pp_common.h"
@@ -210,6 +211,189 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
     }
 }
 
+// ---- the same lookup, tiled on the matrix cores --------------------------------------------------------------
+// With one lane per neighbour position the kernel above streams 108 separate 1 KB rows of f2 per pixel through the
+// texture path (64 distinct cache lines per load instruction): 9.4 ms per step once the flows are realistic.  Here a
+// workgroup takes an 8 x 8 tile of source pixels.  Their targets lie close together (a flow field is smooth), so the
+// 6 x 6 neighbourhoods of all 64 pixels fall into one 16 x 16 REGION of the (pooled) f2 map: the workgroup computes the
+// local correlation S[64 pixels][256 region positions] = F1_tile . F2_region^T on the matrix cores — in the engine's
+// f16x3 arithmetic: every fp32 value is split into two fp16 terms as it is staged into LDS (hi = f16(4x), lo = f16(4x -
+// hi)) and a product is hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (22 operand bits; 5x
+// the rate of the fp32 MFMA, which made this kernel matrix-bound).  K = C in chunks of 32 channels, coalesced 128-byte
+// row segments.  S stays in LDS, and every pixel then blends its 25 bilinear samples per level out of S.  Pixels whose
+// neighbourhood does not fit the region are served by further passes with a new region (a pixel with the smallest
+// origin is always covered, so the loop ends; smooth flows need one pass), neighbourhoods entirely outside the image
+// are zeros without any work.  f2 rows outside the image enter as zero rows (grid_sample's zeros padding).
+constexpr int CT = 8, CM = CT * CT;            // source-pixel tile
+constexpr int CRW = 16, CN = CRW * CRW;        // region of f2 positions
+constexpr int CK = 32, CKP = CK + 4;           // channels per chunk; LDS row = 32 hi + 32 lo halfs + pad = 36 dwords
+                                               // (144 B: conflict-free b128 reads)
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+constexpr int CSP = CN + 4;                    // row pitch of S
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const float* __restrict__ f1, int ld_f1, int f2_batch,
+                                                                  const float* __restrict__ f2l0, const float* __restrict__ f2l1,
+                                                                  const float* __restrict__ f2l2, const float* __restrict__ flow,
+                                                                  int B, int H, int W, int C, int L, int r, int ld_flow,
+                                                                  float inv_sqrt_c, float* __restrict__ out, int ld_out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* As = sm;                        // [CM][CKP]
+    float* Bs = sm + CM * CKP;             // [CN][CKP]
+    float* S = sm;                         // [CM][CSP], aliases As/Bs once the K loop is over
+    __shared__ float s_cx[CM], s_cy[CM];
+    __shared__ int s_bx[CM], s_by[CM], s_state[CM], s_ox, s_oy, s_todo;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int tiles_x = W / CT, tiles = tiles_x * (H / CT), total = tiles * B;
+    // workgroups are dealt round-robin to the 8 XCDs: make consecutive tiles (same image, overlapping regions) share an L2
+    int g = blockIdx.x;
+    if (total % 8 == 0) g = (g % 8) * (total / 8) + g / 8;
+    const int b = g / tiles, tile = g - b * tiles;
+    const int y0 = (tile / tiles_x) * CT, x0 = (tile % tiles_x) * CT;
+    const int tw = 2 * r + 2, win = 2 * r + 1, fit = CRW - tw;
+    const int my = tid >> 3, mx = tid & 7;                  // tid < 64: the pixel this thread describes
+    float gx = 0.f, gy = 0.f;
+    if (tid < CM) {
+        const float* fl = flow + ((size_t)b * H * W + (size_t)(y0 + my) * W + x0 + mx) * ld_flow;
+        gx = (float)(x0 + mx) + fl[0];
+        gy = (float)(y0 + my) + fl[1];
+    }
+    for (int l = 0; l < L; ++l) {
+        const int Hl = H >> l, Wl = W >> l;
+        const float* f2 = (l == 0 ? f2l0 : (l == 1 ? f2l1 : f2l2)) + (size_t)(b % f2_batch) * Hl * Wl * C;
+        if (tid == 0) s_todo = 0;
+        __syncthreads();
+        if (tid < CM) {
+            const float sc = (float)(1 << l);
+            // centre sample (offset 0): its integer corner anchors the neighbourhood (clamped far outside: no overflow)
+            const float cx = fminf(fmaxf(roundtrip(gx / sc, Wl), -1.0e6f), 1.0e6f);
+            const float cy = fminf(fmaxf(roundtrip(gy / sc, Hl), -1.0e6f), 1.0e6f);
+            const int bx = (int)floorf(cx) - r, by = (int)floorf(cy) - r;
+            s_cx[tid] = cx; s_cy[tid] = cy; s_bx[tid] = bx; s_by[tid] = by;
+            const bool outside = bx >= Wl || by >= Hl || bx + tw <= 0 || by + tw <= 0;
+            s_state[tid] = outside ? 2 : 0;                // 0 = to do, 1 = done, 2 = all zeros
+            if (!outside) atomicAdd(&s_todo, 1);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < CM * win * win; idx += 256) {   // neighbourhoods outside the image: zeros
+            const int m = idx / (win * win), o = idx - m * (win * win);
+            if (s_state[m] == 2)
+                out[((size_t)b * H * W + (size_t)(y0 + (m >> 3)) * W + x0 + (m & 7)) * ld_out + l * win * win + o] = 0.f;
+        }
+        while (s_todo > 0) {                                // (uniform: read after a barrier, written before the next)
+            // ---- region of this pass: origin = smallest bx still to do, then the smallest by among its column band
+            if (tid == 0) { s_ox = 0x7fffffff; s_oy = 0x7fffffff; }
+            __syncthreads();
+            if (tid < CM && s_state[tid] == 0) atomicMin(&s_ox, s_bx[tid]);
+            __syncthreads();
+            if (tid < CM && s_state[tid] == 0 && s_bx[tid] - s_ox <= fit) atomicMin(&s_oy, s_by[tid]);
+            __syncthreads();
+            const int ox = s_ox, oy = s_oy;
+            // ---- S = F1_tile . F2_region^T
+            f32x16_t acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            f4 ra[2], rb[8];
+            const int part = tid & 7, row0 = tid >> 3;
+            auto load_chunk = [&](int kc) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int m = row0 + 32 * i;
+                    ra[i] = *(const f4*)(f1 + ((size_t)b * H * W + (size_t)(y0 + (m >> 3)) * W + x0 + (m & 7)) * ld_f1 + kc * CK + 4 * part);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int n = row0 + 32 * i, qy = oy + (n >> 4), qx = ox + (n & 15);
+                    const bool in = qx >= 0 && qx < Wl && qy >= 0 && qy < Hl;
+                    rb[i] = in ? *(const f4*)(f2 + ((size_t)qy * Wl + qx) * C + kc * CK + 4 * part) : f4{0.f, 0.f, 0.f, 0.f};
+                }
+            };
+            load_chunk(0);
+            const int nk = C / CK;
+            for (int kc = 0; kc < nk; ++kc) {
+                __syncthreads();                            // the previous chunk (or the previous pass's S) has been read
+                // split into the two fp16 planes of the row: halfs [0,32) = hi, [32,64) = lo
+                auto put = [&](float* rowp, f4 v) {
+                    _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
+                    pp_split_f16(v.x, h0, l0);
+                    pp_split_f16(v.y, h1, l1);
+                    pp_split_f16(v.z, h2, l2);
+                    pp_split_f16(v.w, h3, l3);
+                    const h4_t hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
+                    *(h4_t*)((_Float16*)rowp + 4 * part) = hi;
+                    *(h4_t*)((_Float16*)rowp + 32 + 4 * part) = lo;
+                };
+#pragma unroll
+                for (int i = 0; i < 2; ++i) put(As + (row0 + 32 * i) * CKP, ra[i]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) put(Bs + (row0 + 32 * i) * CKP, rb[i]);
+                __syncthreads();
+                if (kc + 1 < nk) load_chunk(kc + 1);        // in flight under the MFMAs
+                // lane (l31, lh) feeds row / column l31 with channels 16 s + 8 lh .. + 7 of the chunk in k-step s
+                h8_t ah[2][2], al[2][2], bh[2][2], bl[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const _Float16* ar = (const _Float16*)(As + (i * 32 + l31) * CKP) + 16 * q + 8 * lh;
+                        const _Float16* br = (const _Float16*)(Bs + (wv * 64 + i * 32 + l31) * CKP) + 16 * q + 8 * lh;
+                        ah[i][q] = *(const h8_t*)ar;
+                        al[i][q] = *(const h8_t*)(ar + 32);
+                        bh[i][q] = *(const h8_t*)br;
+                        bl[i][q] = *(const h8_t*)(br + 32);
+                    }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i][q], bh[j][q], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i][q], bl[j][q], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i][q], bh[j][q], acc[i][j], 0, 0, 0);
+                        }
+            }
+            __syncthreads();                                // every wave is done reading As/Bs: S may overwrite them
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)            // accumulator (e, lane): row (e/4)*8 + lh*4 + e%4, column l31
+                        S[(i * 32 + (e >> 2) * 8 + lh * 4 + (e & 3)) * CSP + wv * 64 + j * 32 + l31] =
+                            acc[i][j][e] * (inv_sqrt_c / (PP_A_SCALE * PP_A_SCALE));
+            __syncthreads();
+            // ---- blend the 25 samples of every pixel whose neighbourhood lies in the region
+            for (int idx = tid; idx < CM * win * win; idx += 256) {
+                const int m = idx / (win * win), o = idx - m * (win * win), ai = o / win, bi = o - ai * win;
+                const int dx = s_bx[m] - ox, dy = s_by[m] - oy;
+                if (s_state[m] == 0 && dx >= 0 && dx <= fit && dy >= 0 && dy <= fit) {
+                    const float cx = s_cx[m], cy = s_cy[m];
+                    const float wx1 = cx - floorf(cx), wy1 = cy - floorf(cy), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                    const float* t = S + m * CSP + (dy + bi) * CRW + dx + ai;   // x offset a-r -> +ai, y offset b-r -> +bi
+                    out[((size_t)b * H * W + (size_t)(y0 + (m >> 3)) * W + x0 + (m & 7)) * ld_out + l * win * win + o] =
+                        t[0] * (wx0 * wy0) + t[1] * (wx1 * wy0) + t[CRW] * (wx0 * wy1) + t[CRW + 1] * (wx1 * wy1);
+                }
+            }
+            __syncthreads();
+            if (tid < CM && s_state[tid] == 0) {
+                const int dx = s_bx[tid] - ox, dy = s_by[tid] - oy;
+                if (dx >= 0 && dx <= fit && dy >= 0 && dy <= fit) {
+                    s_state[tid] = 1;
+                    atomicSub(&s_todo, 1);
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
 // Row gather: dst[i] = src[index[i]] for rows of `row` floats (row % 4 == 0, 16-byte aligned): the selection of the
 // top-k templates' data (model/picopose.py:55-62 — torch.gather with an expanded index over (B,N,3,224,224) etc.)
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ index,
@@ -345,6 +529,20 @@ int pp_corr_lookup_nhwc(const float* f1, int ld_f1, const float* f2_l0, const fl
     if ((H >> (levels - 1)) < 1 || (W >> (levels - 1)) < 1 || ld_flow < 2) return PP_EINVAL;
     const int win = 2 * radius + 1;
     if (ld_out < levels * win * win) return PP_EINVAL;
+    static const bool tiled = [] { const char* e = getenv("PP_CORR_TILED"); return !(e && e[0] == '0'); }();
+    if (tiled && H % CT == 0 && W % CT == 0 && C % CK == 0 && ((uintptr_t)f2_l0 % 16) == 0) {
+        // matrix-core version: one workgroup per 8 x 8 pixel tile (PP_CORR_TILED=0 keeps the lane-per-position kernel)
+        const size_t lds = (size_t)(CM * CSP > (CM + CN) * CKP ? CM * CSP : (CM + CN) * CKP) * sizeof(float);
+        static signed char attr[PP_MAX_DEVICES];
+        signed char& ok = attr[pp_cur_device()];
+        if (ok == 0)
+            ok = hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
+        if (ok < 0) return PP_ELAUNCH;
+        hipLaunchKernelGGL(corr_lookup_mfma_kernel, dim3((unsigned)((H / CT) * (W / CT) * B)), dim3(256), lds, (hipStream_t)stream,
+                           f1, ld_f1, f2_batch, f2_l0, f2_l1, f2_l2, flow, B, H, W, C, levels, radius, ld_flow,
+                           1.0f / sqrtf((float)C), out, ld_out);
+        return pp_last_launch();
+    }
     const size_t smem = (size_t)4 * (C + MAXL * TW * TW) * sizeof(float);
     hipLaunchKernelGGL(corr_lookup_kernel, dim3((H * W + 3) / 4, B), dim3(256), smem, (hipStream_t)stream, f1, ld_f1,
                        f2_batch, f2_l0, f2_l1, f2_l2, flow, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out,

@@ -1,5 +1,7 @@
-"""Per-step kernel breakdown from a rocprofv3 kernel trace of bench.py: the dispatches between the last two
-stage-1 launches (s1_main) are exactly one timed step.  usage: step_breakdown.py <kernel_trace.csv>"""
+"""Per-step kernel breakdown from a rocprofv3 kernel trace of bench.py: the dispatches between two consecutive
+stage-1 launches (s1_main) are exactly one step.  usage: step_breakdown.py <kernel_trace.csv> [step index, default 2]
+(with --warmup 1 --steps 3 the s1_main launches 1..3 open the timed steps; later ones belong to the untimed
+event / verification legs of bench.py)."""
 import collections
 import csv
 import re
@@ -8,7 +10,8 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "s1_main" in r["Kernel_Name"]]
-lo, hi = marks[-2], marks[-1]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+lo, hi = marks[k], marks[k + 1]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in rows[lo:hi]:
     n = r["Kernel_Name"]
