@@ -11,10 +11,17 @@
 
 // f16x3 activation operand: v -> hi = f16(4 v), lo = f16(4 v - hi) (saturated); the same split in every producer
 #define PP_A_SCALE 4.f
+// (precision study builds only — tools/precision_study.py: -DPP_STUDY_ACT_LO_ZERO drops the lo term of every ACTIVATION
+// operand, -DPP_STUDY_W_LO_ZERO that of every weight: the engine then evaluates the 2-term "weights split only" and the
+// 1-term plain-fp16 products bit for bit, at the 3-term kernels' speed.  Never defined in the product build.)
 __device__ __forceinline__ void pp_split_f16(float v, _Float16& hi, _Float16& lo) {
     const float x = v * PP_A_SCALE;
     hi = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+#ifdef PP_STUDY_ACT_LO_ZERO
+    lo = (_Float16)0.f;
+#else
     lo = (_Float16)fminf(fmaxf(x - (float)hi, -65504.f), 65504.f);
+#endif
 }
 
 // "hl" operand format (include/picopose_hip.h): half index of element (k, term p) inside a row

@@ -431,6 +431,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(const PpGemmDesc d) {
 // ---------------------------------------------------------------------------
 constexpr float A_SCALE = PP_A_SCALE;  // activation operand scale of the f16x3 engine
 
+template <bool WEIGHT = false>
 __device__ __forceinline__ void split_f16x4(const f4 v, float s, h4& hi, h4& lo) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -438,6 +439,12 @@ __device__ __forceinline__ void split_f16x4(const f4 v, float s, h4& hi, h4& lo)
         const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
         hi[i] = h;
         lo[i] = (_Float16)fminf(fmaxf(x - (float)h, -65504.f), 65504.f);
+#ifdef PP_STUDY_ACT_LO_ZERO   // (precision study builds, pp_common.h)
+        if (!WEIGHT) lo[i] = (_Float16)0.f;
+#endif
+#ifdef PP_STUDY_W_LO_ZERO
+        if (WEIGHT) lo[i] = (_Float16)0.f;
+#endif
     }
 }
 
@@ -581,7 +588,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const PpGemmDesc d
                     hh = rbh[BSPLIT ? j : 0];
                     ll = rbl[BSPLIT ? j : 0];
                 } else {
-                    split_f16x4(rb[BSPLIT ? 0 : j], A_SCALE, hh, ll);
+                    split_f16x4<true>(rb[BSPLIT ? 0 : j], A_SCALE, hh, ll);
                 }
                 *(h4*)(Bh + AROW(j) * LDH + kq) = hh;
                 *(h4*)(Bl + AROW(j) * LDH + kq) = ll;
@@ -1647,6 +1654,261 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3q_kernel(const PpGemmDesc
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolutions (Cin % 32 == 0, W a power of two in [16, 256]) on the persistent 256x256 kernel
+// with ROW-SHARED A delivery.  pp_gemm_f16x3q_kernel<1> copies the 256-pixel A tile into LDS once per TAP — nine
+// LDS-DMA tiles per 32-channel slice although the three taps of a filter row read the same pixels shifted by one.
+// Here the A buffer is filled once per (slice, filter row dy) and the three taps read it at row offsets dx: A copies
+// / 3, all LDS-DMA instructions of the K loop - 30 % (the copies, not the MFMAs, set this kernel's pace).  For the shift
+// to be exact at the image's left / right edge the buffer holds the tile's 256 / W image rows with an explicit ZERO
+// pixel before and after each of them (LDS row pitch W + 2 pixels): those rows are out-of-range DMA offsets — written
+// as zeros without traffic, like the rows y + dy outside the image.  W divides the tile and tiles start at multiples
+// of 256, so the LDS row of a tile row is the same for every tile and every lane keeps it in four registers.  Two A
+// buffers alternate per filter row; the weight tiles keep their per-tap ring.  K order, MFMA order and hence every
+// result bit are those of pp_gemm_f16x3q_kernel<1>.
+// ---------------------------------------------------------------------------
+constexpr int H_A_ROWS = 288;                       // 256 + 2 * 256 / W rows used (W >= 16), 36 LDS-DMA instructions
+constexpr int H_A_H = H_A_ROWS * G_ROWH;            // halfs per A buffer (36 KB)
+constexpr int H_LDS_BYTES = (2 * H_A_H + 2 * Q_B_H) * 2 + 16384;
+
+__global__ __launch_bounds__(512, 1) void pp_gemm_f16x3h_kernel(const PpGemmDesc d, int gx, int gy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3, l31 = lane & 31, lh = lane >> 5;
+    const int ntiles = gx * gy, nxw = (int)gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int chunk1 = chunk0 + (xcd < r8 ? q8 + 1 : q8);
+    const int first = chunk0 + (int)(blockIdx.x >> 3);
+    if (first >= chunk1) return;
+    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
+    const int lr = lane >> 3;
+    const int sc = (lane & 7) ^ ((((w & 1) << 2) + (lr >> 1)) & 7);
+    const int k8 = (sc >> 1) * 8;
+    const unsigned pbyte = (unsigned)(sc & 1) * 16;
+    const int nk = (d.K + BK - 1) / BK;       // 9 * Cin / 32
+    const int W = d.conv_w, WP = W + 2, nrows = (QBM / W) * WP;
+    _Float16* const Bbase = glds + 2 * H_A_H;
+
+    // Per lane, constant over the tiles: its (up to five) A rows rho = (j * 8 + w) * 8 + lr of the padded buffer ->
+    // tile pixel mu (or a zero pixel), as a byte offset relative to the tile's first pixel; its four weight rows.
+    unsigned arel[5];
+    auto a_pixel = [&](int j, int& mu) __attribute__((always_inline)) -> bool {   // row j is a pixel (not a pad / unused row)
+        const int rho = (j * 8 + w) * 8 + lr, ir = rho / WP, c = rho - ir * WP;
+        mu = ir * W + c - 1;
+        return rho < nrows && c >= 1 && c <= W;
+    };
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        int mu;
+        const bool pix = a_pixel(j, mu);
+        arel[j] = (unsigned)(((long long)(pix ? mu : 0) * d.lda + k8) * 4) + pbyte;
+    }
+    const unsigned brel = (unsigned)(((long long)(w * 8 + lr) * d.ldb + k8) * 4) + pbyte;
+    const unsigned bstep = (unsigned)(64 * d.ldb * 4);
+    unsigned amask = 0u, bmask = 0u;          // per tile: bit 3 j + dy = source row y + dy - 1 of A row j exists; bit j = column in range
+    unsigned abase = 0u, bbase = 0u;          // per tile (scalar): byte offset of the tile's first pixel / first weight row
+    int ftile = first, fkt = 0, fab = 0;      // fetch cursor: tile, K step, A buffer of the filter row being fetched
+    int cky = 0, ckx = 0, cci = 0;
+#define PP_H_SETUP(TILE)                                                                                             \
+    {                                                                                                                \
+        int tr_, tc_;                                                                                                \
+        tile_rc((TILE), gx, gy, tr_, tc_);                                                                           \
+        const int m0_ = tr_ * QBM, n0_ = tc_ * QBN;                                                                  \
+        abase = (unsigned)((long long)m0_ * d.lda * 4);                                                              \
+        bbase = (unsigned)((long long)n0_ * d.ldb * 4);                                                              \
+        amask = bmask = 0u;                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                              \
+            int mu_;                                                                                                 \
+            const bool pix_ = a_pixel(j, mu_);                                                                       \
+            const int m = m0_ + mu_;                                                                                 \
+            if (pix_ && m < d.M) {                                                                                   \
+                const int y = (m % (d.conv_h * W)) / W;                                                              \
+                _Pragma("unroll") for (int t = 0; t < 3; ++t) if (y + t - 1 >= 0 && y + t - 1 < d.conv_h) amask |= 1u << (3 * j + t); \
+            }                                                                                                        \
+            if (j < 4 && n0_ + w * 8 + lr + 64 * j < d.N) bmask |= 1u << j;                                          \
+        }                                                                                                            \
+        fkt = 0;                                                                                                     \
+        cky = ckx = cci = 0;                                                                                         \
+    }
+#define PP_H_NEXT_TILE_IF_DONE()                                \
+    if (fkt == nk && ftile < chunk1) {                          \
+        ftile += nxw;                                           \
+        if (ftile < chunk1) PP_H_SETUP(ftile) else fkt = 0;     \
+    }
+    auto off_a = [&](int j) __attribute__((always_inline)) -> unsigned {
+        const unsigned tapoff = abase + (unsigned)((((cky - 1) * W) * d.lda + cci) * 4);
+        const unsigned ok = (amask >> (3 * j + cky)) & (ftile < chunk1 ? 1u : 0u);
+        return (arel[j] + tapoff) | ((ok & 1u) - 1u);
+    };
+    auto off_b = [&](int j) __attribute__((always_inline)) -> unsigned {
+        const unsigned live = (ftile < chunk1 ? 1u : 0u) & (bmask >> j);
+        return (brel + bbase + (unsigned)(((cky * 3 + ckx) * d.conv_cin + cci) * 4) + (unsigned)j * bstep) | ((live & 1u) - 1u);
+    };
+    auto dma_a = [&](int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + fab * H_A_H + ((j * 8 + w) * 8) * G_ROWH), 16, off_a(j), 0, 0, 0);
+    };
+    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(Bbase + stage * Q_B_H + ((j * 8 + w) * 8) * G_ROWH), 16, off_b(j), 0, 0, 0);
+    };
+#define PP_H_ADVANCE()                                                                   \
+    {                                                                                    \
+        const bool row_end = ckx == 2, tap_end = row_end && cky == 2;                    \
+        fab = row_end ? fab ^ 1 : fab;    /* the next filter row goes to the other buffer */ \
+        ckx = row_end ? 0 : ckx + 1;                                                     \
+        cky = tap_end ? 0 : (row_end ? cky + 1 : cky);                                   \
+        cci = tap_end ? cci + BK : cci;                                                  \
+        ++fkt;                                                                           \
+    }
+
+    // LDS row (at dx = 0) of this lane's row in the wave's 32-row block q: rowlane + srow(q), the second term uniform
+    // (tile row base_q + l31 with base_q a multiple of 32: for W >= 32 the block lies inside one image row)
+    const int rowlane = (l31 / W) * WP + (l31 & (W - 1)) + 1;
+    auto srow = [&](int q) __attribute__((always_inline)) -> int {
+        const int bq = wr * 128 + q * 32;
+        return W >= 32 ? (bq / W) * WP + (bq & (W - 1)) : (bq / W) * WP;
+    };
+    struct AF {
+        h8 h[2], l[2];  // two 32-row blocks, hi / lo terms
+    };
+    f32x16 acc[4][2];
+    // A fragments of K half ks, row blocks 2 ip, 2 ip + 1 of tap column dx (a compile-time constant at every call site:
+    // the K loop is unrolled over the three taps of a filter row) from A buffer ab
+    // The address of a fragment = row * 128 B + ((k chunk) ^ key(row)) * 16 B with key = (row >> 1) & 7 depends on the
+    // lane AND on dx: it is recomputed at every read from ONE per-lane register (5 VALU operations per row) — left to
+    // itself hipcc hoists the 48 distinct addresses out of the K loop and then spills them (20 scratch reloads per K step).
+    int rl = rowlane;
+    auto load_a = [&](AF& f, int ab, const int dx, int ks, int ip) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(rl));      // opaque: nothing derived from it is loop-invariant
+        const char* base = (const char*)(glds + ab * H_A_H);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = rl + (srow(2 * ip + i) + dx);
+            const int key = (r >> 1) & 7;
+            const int chunk = ((ks * 2 + lh) * 2) ^ key;
+            const char* st = base + r * (G_ROWH * 2) + chunk * 16;
+            f.h[i] = *(const h8*)st;
+            f.l[i] = *(const h8*)(base + r * (G_ROWH * 2) + (chunk ^ 1) * 16);
+        }
+    };
+    auto load_b = [&](AF& f, int stage, int ks) __attribute__((always_inline)) {
+        const _Float16* st = Bbase + stage * Q_B_H + (wc * 64 + l31) * G_ROWH;
+        const int sw = (l31 >> 1) & 7;
+        const int ch = (((ks * 2 + lh) * 2) ^ sw) * 8, cl = (((ks * 2 + lh) * 2 + 1) ^ sw) * 8;
+        f.h[0] = *(const h8*)(st + ch);
+        f.l[0] = *(const h8*)(st + cl);
+        f.h[1] = *(const h8*)(st + 32 * G_ROWH + ch);
+        f.l[1] = *(const h8*)(st + 32 * G_ROWH + cl);
+    };
+    auto mma1 = [&](const AF& a, const AF& b, int ip, int i, int j) __attribute__((always_inline)) {
+        acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l[i], b.h[j], acc[2 * ip + i][j], 0, 0, 0);
+        acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[i], b.l[j], acc[2 * ip + i][j], 0, 0, 0);
+        acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[i], b.h[j], acc[2 * ip + i][j], 0, 0, 0);
+    };
+    auto mma_unit = [&](const AF& a, const AF& b, int ip) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma1(a, b, ip, i, j);
+    };
+    const bool five = w < 4;    // rows 256 .. 287 of an A buffer belong to the fifth instruction of waves 0-3
+
+    PP_H_SETUP(first)
+    {   // K steps 0 (filter row 0: A buffer 0 + weights of tap 0) and 1 (weights of tap 1)
+        PP_H_NEXT_TILE_IF_DONE()
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_a(j);
+        if (five) dma_a(4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_b(0, j);
+        PP_H_ADVANCE()
+        PP_H_NEXT_TILE_IF_DONE()
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_b(1, j);
+        PP_H_ADVANCE()
+    }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // K step 0 has landed (the 4 weight pieces of step 1 may fly)
+    __builtin_amdgcn_s_barrier();
+    AF a0, a1, b0, b1;
+    int cab = 0;                 // compute cursor: A buffer of the current filter row
+    load_a(a0, 0, -1, 0, 0);
+    load_b(b0, 0, 0);
+    int cur = 0;
+    float* patch = (float*)(Bbase + 2 * Q_B_H) + w * 512;
+    const float descale = d.alpha / (A_SCALE * d.b_scale);
+    for (int tile = first; tile < chunk1; tile += nxw) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // One K step with the tap column DX a compile-time constant; NDX / NAB: the next step's.
+#define PP_H_STEP(DX, NDX, NAB)                                                                                       \
+        {                                                                                                             \
+            load_a(a1, cab, DX, 0, 1);                                                                                \
+            mma_unit(a0, b0, 0);                                                                                      \
+            load_a(a0, cab, DX, 1, 0);                                                                                \
+            load_b(b1, cur, 1);                                                                                       \
+            mma_unit(a1, b0, 1);                                                                                      \
+            load_a(a1, cab, DX, 1, 1);                                                                                \
+            mma_unit(a0, b1, 0);                                                                                      \
+            /* the next K step has landed, every fragment read of this one is done */                                \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
+            __builtin_amdgcn_s_barrier();                                                                             \
+            /* unit 3 | DMA of the step after next: its weights into the stage just freed and, when it opens a filter \
+               row (every third step: DX == 0 here), that row's pixels into the A buffer the row before last used */ \
+            PP_H_NEXT_TILE_IF_DONE()                                                                                  \
+            const int nst = cur ^ 1;                                                                                  \
+            if (DX == 0) dma_a(0);                                                                                    \
+            load_a(a0, NAB, NDX, 0, 0);                                                                               \
+            mma1(a1, b1, 1, 0, 0);                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            if (DX == 0) { dma_a(1); dma_a(2); }                                                                      \
+            load_b(b0, nst, 0);                                                                                       \
+            mma1(a1, b1, 1, 0, 1);                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            if (DX == 0) { dma_a(3); if (five) dma_a(4); }                                                            \
+            dma_b(cur, 0);                                                                                            \
+            mma1(a1, b1, 1, 1, 0);                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            dma_b(cur, 1);                                                                                            \
+            dma_b(cur, 2);                                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            dma_b(cur, 3);                                                                                            \
+            PP_H_ADVANCE()                                                                                            \
+            mma1(a1, b1, 1, 1, 1);                                                                                    \
+            cur = nst;                                                                                                \
+        }
+        // (the fetch cursor runs two steps ahead: while tap dx = 0 of a filter row computes, the step being fetched is
+        // tap dx = -1 of the NEXT filter row — the one that opens it)
+        for (int kt = 0; kt < nk; kt += 3) {
+            PP_H_STEP(-1, 0, cab)
+            PP_H_STEP(0, 1, cab)
+            PP_H_STEP(1, -1, cab ^ 1)
+            cab ^= 1;
+        }
+#undef PP_H_STEP
+        {
+            int tr, tc;
+            tile_rc(tile, gx, gy, tr, tc);
+            const int mw = tr * QBM + wr * 128, nw = tc * QBN + wc * 64;
+            f32x16(&lo)[2][2] = *reinterpret_cast<f32x16(*)[2][2]>(&acc[0]);
+            f32x16(&hi)[2][2] = *reinterpret_cast<f32x16(*)[2][2]>(&acc[2]);
+            epilogue_block<2, 8>(d, descale, lo, patch, mw, nw, lane);
+            epilogue_block<2, 8>(d, descale, hi, patch, mw + 64, nw, lane);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), visible to hipcc (see pp_gemm_f16x3p_kernel)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef PP_H_SETUP
+#undef PP_H_NEXT_TILE_IF_DONE
+#undef PP_H_ADVANCE
+#endif
+}
+
 namespace {
 
 // activation pre-split: x (B, P, C) fp32 with batch / row strides -> contiguous hl operand (B*P rows, ld = C):
@@ -1846,7 +2108,11 @@ __global__ void split_f16x3_kernel(const float* __restrict__ w, long long n, con
         const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
         _Float16* p = hl + ((i >> 3) << 4) + (i & 7);  // rows are multiples of 8 long: groups never straddle rows
         p[0] = h;
+#ifdef PP_STUDY_W_LO_ZERO   // (precision study builds, pp_common.h)
+        p[8] = (_Float16)0.f;
+#else
         p[8] = (_Float16)(x - (float)h);
+#endif
     }
 }
 
@@ -1938,14 +2204,23 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                hipFuncSetAttribute((const void*)pp_gemm_f16x3p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess)
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess &&
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES) == hipSuccess)
                      ? 1 : -1;
     }
     if (big_ok < 0) return PP_ELAUNCH;
-    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA, 4: persistent LDS-DMA, 5: persistent LDS-DMA with 256x256 tiles
+    // row-shared 3x3 kernel (cfg 6): 3x3 / stride 1 / pad 1, Cin % 32 == 0, W a power of two dividing the 256-row tile
+    const bool h_shape = asplit && d.conv_kh == 3 && d.conv_kw == 3 && d.conv_stride == 1 && d.conv_pad == 1 && d.conv_cin % BK == 0 &&
+                         d.conv_ho == d.conv_h && d.conv_wo == d.conv_w && d.conv_w >= 16 && d.conv_w <= QBM && (d.conv_w & (d.conv_w - 1)) == 0 &&
+                         d.lda == d.conv_cin && d.K == 9 * d.conv_cin && d.conv_bstride == (long long)d.conv_h * d.conv_w * d.lda;
+    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA, 4: persistent LDS-DMA, 5: persistent LDS-DMA with 256x256 tiles, 6: 5 with row-shared A delivery (3x3 convolutions)
         const bool narrow = cfg == 2;
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
-        if (asplit && cfg == 5) {  // persistent LDS-DMA kernel, 256x256 tiles
+        if (asplit && cfg == 6) {
+            const int gx = (d.N + QBN - 1) / QBN, gy = (d.M + QBM - 1) / QBM;
+            const int nt = gx * gy, g = nt < cus ? (nt + 7) / 8 * 8 : cus / 8 * 8;
+            hipLaunchKernelGGL(pp_gemm_f16x3h_kernel, dim3(g), dim3(512), H_LDS_BYTES, st, d, gx, gy);
+        } else if (asplit && cfg == 5) {  // persistent LDS-DMA kernel, 256x256 tiles
             const int gx = (d.N + QBN - 1) / QBN, gy = (d.M + QBM - 1) / QBM;
             const int nt = gx * gy, g = nt < cus ? (nt + 7) / 8 * 8 : cus / 8 * 8;
             const int lds = 2 * Q_STAGE * 2 + 16384;
@@ -1994,6 +2269,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     if (const char* f = getenv("PP_GEMM_FORCE_CFG")) {  // tests: pin one kernel configuration (3 needs pre-split operands)
         const int fc = atoi(f);
         const bool p_ok = asplit && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
+        if (fc == 6 && asplit) {   // the row-shared kernel where the shape allows it, else the 256x256 / 256x128 persistent ones
+            launch(h_shape && d.N > 128 ? 6 : (p_ok ? (d.N > 128 ? 5 : 4) : 3));
+            return pp_last_launch();
+        }
         if (fc >= 0 && fc <= 5 && (fc < 3 || asplit) && (fc != 1 || !asplit)) {
             launch(fc >= 4 && !(p_ok && (fc == 4 || d.N > 128)) ? 3 : fc);
             return pp_last_launch();
@@ -2019,14 +2298,16 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             const bool big = asplit && (long long)((d.M + GBM - 1) / GBM) * ((d.N + GBN - 1) / GBN) >= cus / 2;
             const bool p_ok = big && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
             const bool q_ok = p_ok && d.N > 128 && (long long)((d.M + QBM - 1) / QBM) * ((d.N + QBN - 1) / QBN) >= cus / 2;
-            for (int c = 0; c < (asplit ? 5 : (vec ? 3 : 2)); ++c) {
+            for (int c = 0; c < (asplit ? 6 : (vec ? 3 : 2)); ++c) {
                 const int cand = asplit ? (c == 0 ? 0 : c == 1 ? 2 : c + 1) : (vec ? c : (c == 0 ? 0 : 2));
-                if ((cand == 3 && !big) || (cand == 4 && !p_ok) || (cand == 5 && !q_ok)) continue;
+                if ((cand == 3 && !big) || (cand == 4 && !p_ok) || (cand == 5 && !q_ok) || (cand == 6 && !(q_ok && h_shape))) continue;
                 launch(cand);  // warm
                 float ms = 1e30f;
-                for (int rep = 0; rep < 3; ++rep) {  // best of three: single samples mis-rank configurations within ~5 %
+                // best of three bursts of four back-to-back launches: single synchronised launches run on a GPU that idles
+                // (and re-clocks) between samples and mis-ranked configurations within ~5-10 % from run to run
+                for (int rep = 0; rep < 3; ++rep) {
                     (void)hipEventRecord(e0, st);
-                    launch(cand);
+                    for (int k = 0; k < 4; ++k) launch(cand);
                     (void)hipEventRecord(e1, st);
                     (void)hipEventSynchronize(e1);
                     float t = 0.f;

@@ -163,6 +163,32 @@ def test_persistent_256x256_kernel_pinned(monkeypatch, engine_precision):
     _pinned_big_kernel_cases(monkeypatch, "5")
 
 
+@gpu
+def test_row_shared_conv3x3_kernel_pinned(monkeypatch, engine_precision):
+    """Configuration 6: 3x3 / stride 1 / pad 1 convolutions on the persistent 256x256 kernel with row-shared A delivery
+    (one LDS copy of the pixels per filter ROW, the three taps read it at shifted rows, edge lanes zeroed).  Against
+    torch's conv2d for W = 64 / 32 / 16 / 8, batches that leave a partial last tile, Cout with a column tail; and
+    bit-identical to configuration 5 (same K order, same MFMA order)."""
+    if engine_precision != "f16x3":
+        pytest.skip("pre-split operands exist in f16x3 mode only")
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(78)
+    for B, cin, cout, hw in [(2, 64, 256, 64), (3, 640, 512, 32), (5, 256, 192, 16), (1, 32, 520, 64), (7, 96, 256, 8), (1, 128, 256, 16)]:
+        x = torch.randn(B, cin, hw, hw, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        b = torch.randn(cout, generator=g)
+        ref = F.relu(F.conv2d(x, w, b, padding=1))
+        xn, wp = ops.to_nhwc(x.cuda()), ops.pack_conv_weight(w.cuda())
+        monkeypatch.setenv("PP_GEMM_FORCE_CFG", "6")
+        out6 = ops.conv2d(xn, wp, b.cuda(), 3, 1, 1, act="relu")
+        monkeypatch.setenv("PP_GEMM_FORCE_CFG", "5")
+        out5 = ops.conv2d(xn, wp, b.cuda(), 3, 1, 1, act="relu")
+        _close(ops.to_nchw(out6), ref)
+        assert torch.equal(out6, out5), (B, cin, cout, hw, float((out6 - out5).abs().max()))
+    _pinned_big_kernel_cases(monkeypatch, "6")     # shapes it does not apply to fall back to the other kernels
+
+
 def _pinned_big_kernel_cases(monkeypatch, cfg):
     from picopose_amd import ops
 
@@ -232,7 +258,7 @@ def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, 
     xi = torch.randn(2, 24, 24, 64, generator=g).cuda()
     wc = ops.pack_conv_weight((torch.randn(256, 64, 3, 3, generator=g) / 24).cuda())
     outs = []
-    for cfg in ("0", "2", "3", "4", "5"):
+    for cfg in ("0", "2", "3", "4", "5", "6"):
         monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
         outs.append((ops.linear(x, w, b, act="gelu"), ops.conv2d(xi, wc, None, 3, pad=1, act="relu")))
     for lin, conv in outs[1:]:
