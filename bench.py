@@ -60,8 +60,15 @@ WORKLOADS = {
     "stage1_b32_n162_c768": ("stage1", 32, 162, "dinov2_vitb14", "configs[2] stage-1 shape: matching_templates only"),
     "stage1_b8_n42_c384": ("stage1", 8, 42, "dinov2_vits14", "configs[1]: batch 8, 42 templates, ViT-S/14, stage-1 matching only"),
     "stage1_b32_n162_c1024": ("stage1", 32, 162, "dinov2_vitl14", "base.yaml shape (ViT-L/14), stage-1 matching only"),
+    # BASELINE configs[4] groundwork (batch 64 / 512 templates / ViT-L / fp16 on 8 GPUs): what ONE rank of that job runs —
+    # its 64-template slice of the fp16-stored feature bank for all 64 crops, and stages 2-3 + PnP on its own crops
+    "stage1_b64_n64_c1024_f16bank": ("stage1", 64, 64, "dinov2_vitl14",
+                                     "one rank's share of configs[4], stage 1 only: 64 crops x 64 of the 512 templates, ViT-L/14 width, bank stored fp16"),
+    "full_b64_n64_vitl": ("full", 64, 64, "dinov2_vitl14",
+                          "one rank's share of configs[4]: batch 64, 64 of the 512 templates (fp16 bank), ViT-L/14, stage1+2+3 + PnP/RANSAC, hyp 5, 224x224 "
+                          "(256x256 is not a multiple of the 14-pixel patch: the reference asserts, patch_embed.py:73-74)"),
 }
-FP16_BANK = set()           # workloads whose template feature bank is stored fp16 (configs[4] groundwork)
+FP16_BANK = {"stage1_b64_n64_c1024_f16bank", "full_b64_n64_vitl"}   # workloads whose template feature bank is stored fp16
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a read-only probe reaches 6.2-6.4 TB/s
 MFMA_F32_PEAK_TF = 157.3   # dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16 MFMA peak (v_mfma_f32_32x32x16_f16), MI355X_MICROARCH.md

@@ -80,6 +80,17 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask,
                      float eps, void* workspace, size_t workspace_bytes,
                      float* sim_avg, int32_t* stats, void* stream);
 
+/* The same with the bank's storage type as an argument (BASELINE configs[4]: a template bank kept in half precision —
+ * half the HBM bytes per template).  bank_dtype = PP_BANK_F32: bank is float (B,N,C,16,16), exactly pp_stage1_scores;
+ * PP_BANK_F16: bank is IEEE half (B,N,C,16,16) and the result is what pp_stage1_scores returns on those values
+ * widened to float (the rounding to half happened when the bank was stored, outside this library). */
+#define PP_BANK_F32 0
+#define PP_BANK_F16 1
+int pp_stage1_scores_ex(const void* bank, int bank_dtype, const float* query, const float* mask,
+                        int mask_h, int mask_w, int B, int N, int C, int mode,
+                        float eps, void* workspace, size_t workspace_bytes,
+                        float* sim_avg, int32_t* stats, void* stream);
+
 int pp_topk(const float* scores, int B, int N, int k, float* out_score,
             int64_t* out_index, void* stream);
 

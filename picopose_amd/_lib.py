@@ -14,6 +14,8 @@ _HEADER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "includ
 PP_OK = 0
 PP_MATCH_EXACT = 0
 PP_MATCH_FAST = 1
+PP_BANK_F32 = 0
+PP_BANK_F16 = 1
 
 _lib = None
 
@@ -70,6 +72,7 @@ def lib():
         L.pp_prof_gemm_collect.argtypes = [c.POINTER(c.c_double), c.POINTER(c.c_double), c.POINTER(i32)]
         L.pp_stage1_workspace_bytes.argtypes = [i32, i32, i32, c.POINTER(sz)]
         L.pp_stage1_scores.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, vp, vp]
+        L.pp_stage1_scores_ex.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, vp, vp]
         L.pp_topk.argtypes = [vp, i32, i32, i32, vp, vp, vp]
         L.pp_stage1_match.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz,
                                       vp, vp, vp, vp, vp]

@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/picopose_hip.h"
 #include "pp_common.h"
 
@@ -44,6 +45,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 // cache policy of the bank loads: 2 = nt (streamed once: keeps the query operand resident in L2;
@@ -265,8 +267,10 @@ __device__ __forceinline__ void s1_item(int v, int N, int& b, int& n, int& half)
 // (crop, template, half), two workgroups per CU.  Within a half the 4 waves are 2 x 2 over (128 query patches,
 // 64 template patches): each holds a 128x64 fp32 tile in 128 accumulator registers.  The K loop runs over a tile stream that rolls from one item into the next, so the next
 // item's first tiles are in flight while the epilogue of the current one runs.
-template <int MODE, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float* __restrict__ bank,
+// XT = element type of the bank in HBM: float (the reference's layout) or _Float16 (a bank stored in half precision —
+// BASELINE configs[4]: half the bytes per template; the values ARE the fp16-rounded features, all arithmetic as before).
+template <int MODE, int NW, typename XT = float>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const XT* __restrict__ bank,
                                                   const _Float16* __restrict__ qh,
                                                   const float* __restrict__ qf, int N, int C, int total,
                                                   float4* __restrict__ rowrec,
@@ -277,6 +281,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
     using L = Lay<NW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QELT = MODE == PP_MATCH_FAST ? 2 : 4;
+    constexpr int ES = (int)sizeof(XT);      // bytes per bank element
+    typedef typename std::conditional<ES == 4, f4, u2>::type xreg_t;   // 4 bank elements of one thread
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
     // (an empty slice when there is none).
 #define X_DESC(b_, n_, half_, ok_)                                                                         \
     __builtin_amdgcn_make_buffer_rsrc((void*)(bank + ((size_t)(b_) * N + (n_)) * (size_t)C * P + (half_) * 128), 0, \
-                                      (ok_) ? C * P * 4 - (half_) * 512 : 0, 0x00020000)
+                                      (ok_) ? C * P * ES - (half_) * 128 * ES : 0, 0x00020000)
 #define Q_DESC(b_, ok_)                                                                                     \
     __builtin_amdgcn_make_buffer_rsrc(MODE == PP_MATCH_FAST ? (void*)(qh + (size_t)(b_) * C * P)           \
                                                             : (void*)(qf + (size_t)(b_) * C * P),          \
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
         QdN = Q_DESC(b2, ok);
     }
     int xt = 0, qt = -1;  // next tile of the stream; the very first query copy is a dummy (out of bounds: zeros)
-    const unsigned xvoff = ((NW == 8 ? hw * 128 : 0) + (2 * w + lh) * P + 4 * l31) * 4;
+    const unsigned xvoff = ((NW == 8 ? hw * 128 : 0) + (2 * w + lh) * P + 4 * l31) * ES;
     const unsigned qvoff = tid * 16;
 
     f32x16 acc[4][2];
@@ -334,12 +340,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // FAST: sum of squares of this thread's 4 columns; EXACT: ssq0/ssq1 = column blocks sb 0/1
     float ssq0 = 0.f, ssq1 = 0.f, ssq2 = 0.f, ssq3 = 0.f;
-    f4 x0[K::XL], x1[K::XL], x2[K::XL];  // X tiles of the next three K-steps, in flight
+    xreg_t x0[K::XL], x1[K::XL], x2[K::XL];  // X tiles of the next three K-steps, in flight
 
 #define LOAD_XB(x_)                                                                               \
     do {                                                                                          \
-        _Pragma("unroll") for (int j = 0; j < K::XL; ++j) x_[j] = __builtin_bit_cast(             \
-            f4, __builtin_amdgcn_raw_buffer_load_b128(Xd, xvoff, (xt * K::KS + 8 * j) * P * 4, PP_S1_XAUX)); \
+        _Pragma("unroll") for (int j = 0; j < K::XL; ++j) {                                       \
+            if constexpr (ES == 4)                                                                \
+                x_[j] = __builtin_bit_cast(xreg_t, __builtin_amdgcn_raw_buffer_load_b128(Xd, xvoff, (xt * K::KS + 8 * j) * P * 4, PP_S1_XAUX)); \
+            else                                                                                  \
+                x_[j] = __builtin_bit_cast(xreg_t, __builtin_amdgcn_raw_buffer_load_b64(Xd, xvoff, (xt * K::KS + 8 * j) * P * 2, PP_S1_XAUX)); \
+        }                                                                                         \
         if (++xt == KT3) {                                                                        \
             xt = 0;                                                                               \
             Xd = XdN;                                                                             \
@@ -360,21 +370,34 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
     do {                                                                              \
         if (MODE == PP_MATCH_FAST) {                                                  \
             _Pragma("unroll") for (int j = 0; j < K::XL; ++j) {                       \
-                const f4 v = x_[j];                                                   \
+                f4 v;                                                                 \
+                h4 hv;                                                                \
+                if constexpr (ES == 4) {                                              \
+                    v = __builtin_bit_cast(f4, x_[j]);                                \
+                    hv[0] = (_Float16)v.x;                                            \
+                    hv[1] = (_Float16)v.y;                                            \
+                    hv[2] = (_Float16)v.z;                                            \
+                    hv[3] = (_Float16)v.w;                                            \
+                } else {   /* the bank already is fp16: the MFMA operand as stored */ \
+                    hv = __builtin_bit_cast(h4, x_[j]);                               \
+                    v = f4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};   \
+                }                                                                     \
                 ssq0 = fmaf(v.x, v.x, ssq0);                                          \
                 ssq1 = fmaf(v.y, v.y, ssq1);                                          \
                 ssq2 = fmaf(v.z, v.z, ssq2);                                          \
                 ssq3 = fmaf(v.w, v.w, ssq3);                                          \
-                h4 hv;                                                                \
-                hv[0] = (_Float16)v.x;                                                \
-                hv[1] = (_Float16)v.y;                                                \
-                hv[2] = (_Float16)v.z;                                                \
-                hv[3] = (_Float16)v.w;                                                \
                 *(h4*)((Xs_) + (8 * j + 2 * w + lh) * XROW_F16 + 8 * l31) = hv;       \
             }                                                                         \
         } else {                                                                      \
-            _Pragma("unroll") for (int j = 0; j < K::XL; ++j)                         \
-                *(f4*)((Xs_) + ((8 * j + 2 * w + lh) * 128 + 4 * l31) * 4) = x_[j];   \
+            _Pragma("unroll") for (int j = 0; j < K::XL; ++j) {                       \
+                f4 v;                                                                 \
+                if constexpr (ES == 4) v = __builtin_bit_cast(f4, x_[j]);             \
+                else {                                                                \
+                    const h4 hv = __builtin_bit_cast(h4, x_[j]);                      \
+                    v = f4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};   \
+                }                                                                     \
+                *(f4*)((Xs_) + ((8 * j + 2 * w + lh) * 128 + 4 * l31) * 4) = v;       \
+            }                                                                         \
         }                                                                             \
     } while (0)
 #define LDS_BARRIER()                                          \
@@ -727,7 +750,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const float*
 // v_mfma_f32_32x32x2_f32, the column norm is the sum of an even-channel and an odd-channel
 // fma chain, sim = dot * (1 / max(sqrt(ss), 1e-12)) — so the decisions equal EXACT mode's.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void s1_resolve(const float* __restrict__ bank,
+template <typename XT>
+__global__ __launch_bounds__(256) void s1_resolve(const XT* __restrict__ bank,
                                                   const float* __restrict__ qf,
                                                   const float* __restrict__ m16, int N, int C,
                                                   int fast, float eps,
@@ -768,7 +792,7 @@ __global__ __launch_bounds__(256) void s1_resolve(const float* __restrict__ bank
         }
         __syncthreads();
         const int ne = nent;
-        const float* X = bank + bn * (size_t)C * P;
+        const XT* X = bank + bn * (size_t)C * P;
         const float* Q = qf + (size_t)b * C * P;
         for (int e = 0; e < ne; ++e) {
             const unsigned f = ent[e];
@@ -827,7 +851,7 @@ __global__ __launch_bounds__(256) void s1_resolve(const float* __restrict__ bank
                 // thread o = i: row entry: a = q[:,idx] (uniform), x = X[:,o];
                 //               column entry: a = q[:,o], x = X[:,idx]
                 const float* ap = Q + (kind == 1 ? idx : i);
-                const float* xp = X + (kind == 1 ? i : idx);
+                const XT* xp = X + (kind == 1 ? i : idx);
                 float dot = 0.f, se = 0.f, so = 0.f;
                 for (int c0 = 0; c0 < C; c0 += 32) {
                     float a[32], x[32];
@@ -960,16 +984,20 @@ int pp_stage1_workspace_bytes(int B, int N, int C, size_t* bytes) {
     return PP_OK;
 }
 
-int pp_stage1_scores(const float* bank, const float* query, const float* mask, int mask_h,
-                     int mask_w, int B, int N, int C, int mode, float eps, void* workspace,
-                     size_t workspace_bytes, float* sim_avg, int32_t* stats, void* stream_) {
+int pp_stage1_scores_ex(const void* bank_, int bank_dtype, const float* query, const float* mask, int mask_h,
+                        int mask_w, int B, int N, int C, int mode, float eps, void* workspace,
+                        size_t workspace_bytes, float* sim_avg, int32_t* stats, void* stream_) {
+    const float* bank = (const float*)bank_;
+    const _Float16* bank16 = (const _Float16*)bank_;
+    const bool f16 = bank_dtype == PP_BANK_F16;
+    if (bank_dtype != PP_BANK_F32 && bank_dtype != PP_BANK_F16) return PP_EINVAL;
     if (!bank || !query || !mask || !sim_avg || !workspace) return PP_EINVAL;
     if (B <= 0 || N <= 0 || C <= 0 || mask_h <= 0 || mask_w <= 0) return PP_EINVAL;
     if (mode != PP_MATCH_EXACT && mode != PP_MATCH_FAST) return PP_EINVAL;
     if (C % 64 != 0 || C > 2048) return PP_EINVAL;
     if ((size_t)B * N >= (1u << 23)) return PP_EINVAL;
     if (((uintptr_t)workspace & 255) != 0) return PP_EWORKSPACE;
-    if (((uintptr_t)bank & 15) != 0) return PP_EINVAL;
+    if (((uintptr_t)bank & 15) != 0) return PP_EINVAL;   // (fp16: 8-byte loads of 16-byte aligned rows)
     S1Ws w = carve(workspace, B, N, C);
     if (workspace_bytes < w.total) return PP_EWORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
@@ -984,7 +1012,7 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask, i
     // persistent workgroups: 8 waves / whole templates / one per CU, or (PP_S1_WAVES=4) 4 waves / template
     // halves / two per CU
     const char* nw_env = getenv("PP_S1_WAVES");  // read per call: the tests run both shapes in one process
-    const int nw = nw_env && atoi(nw_env) == 4 ? 4 : 8;
+    const int nw = !f16 && nw_env && atoi(nw_env) == 4 ? 4 : 8;   // (the fp16 bank runs the 8-wave shape only)
     const int cus = pp_cu_count();
     static signed char lds_state[PP_MAX_DEVICES];   // > 64 KB of dynamic LDS needs the opt-in, per device
     signed char& lds_ok = lds_state[pp_cur_device()];
@@ -996,7 +1024,10 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask, i
                  set((const void*)s1_main<PP_MATCH_EXACT, 4>, Lay<4>::SMEM_BYTES) &&
                  set((const void*)s1_main<PP_MATCH_FAST, 8>, Lay<8>::SMEM_BYTES) &&
                  set((const void*)s1_main<PP_MATCH_EXACT, 8>, Lay<8>::SMEM_BYTES) &&
-                 set((const void*)s1_resolve, 10 * 2048 * (int)sizeof(float))   // 10 * C floats, C <= 2048
+                 set((const void*)s1_main<PP_MATCH_FAST, 8, _Float16>, Lay<8>::SMEM_BYTES) &&
+                 set((const void*)s1_main<PP_MATCH_EXACT, 8, _Float16>, Lay<8>::SMEM_BYTES) &&
+                 set((const void*)s1_resolve<_Float16>, 10 * 2048 * (int)sizeof(float)) &&
+                 set((const void*)s1_resolve<float>, 10 * 2048 * (int)sizeof(float))   // 10 * C floats, C <= 2048
                      ? 1 : -1;
     }
     if (lds_ok < 0) return PP_ELAUNCH;
@@ -1007,7 +1038,13 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask, i
 #define S1_LAUNCH(MODE_, NW_)                                                                                  \
     hipLaunchKernelGGL((s1_main<MODE_, NW_>), dim3(grid), dim3(64 * NW_), Lay<NW_>::SMEM_BYTES, stream, bank, w.qh, \
                        w.qf, N, C, total, w.rowrec, w.simt0, w.colmax, w.sim0s)
-        if (mode == PP_MATCH_FAST) {
+#define S1_LAUNCH16(MODE_)                                                                                     \
+    hipLaunchKernelGGL((s1_main<MODE_, 8, _Float16>), dim3(grid), dim3(512), Lay<8>::SMEM_BYTES, stream, bank16, w.qh, \
+                       w.qf, N, C, total, w.rowrec, w.simt0, w.colmax, w.sim0s)
+        if (f16) {
+            if (mode == PP_MATCH_FAST) S1_LAUNCH16(PP_MATCH_FAST);
+            else S1_LAUNCH16(PP_MATCH_EXACT);
+        } else if (mode == PP_MATCH_FAST) {
             if (nw == 8) S1_LAUNCH(PP_MATCH_FAST, 8);
             else S1_LAUNCH(PP_MATCH_FAST, 4);
         } else {
@@ -1015,12 +1052,25 @@ int pp_stage1_scores(const float* bank, const float* query, const float* mask, i
             else S1_LAUNCH(PP_MATCH_EXACT, 4);
         }
 #undef S1_LAUNCH
+#undef S1_LAUNCH16
     }
     if (stats) PP_CHECK_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(int32_t), stream));
-    hipLaunchKernelGGL(s1_resolve, dim3(B * N), dim3(256), (size_t)10 * C * sizeof(float), stream,
-                       bank, w.qf, w.m16, N, C, mode == PP_MATCH_FAST ? 1 : 0, eps, w.rowrec,
-                       w.simt0, w.colmax, w.sim0s, sim_avg, stats);
+    if (f16)
+        hipLaunchKernelGGL(s1_resolve<_Float16>, dim3(B * N), dim3(256), (size_t)10 * C * sizeof(float), stream,
+                           bank16, w.qf, w.m16, N, C, mode == PP_MATCH_FAST ? 1 : 0, eps, w.rowrec,
+                           w.simt0, w.colmax, w.sim0s, sim_avg, stats);
+    else
+        hipLaunchKernelGGL(s1_resolve<float>, dim3(B * N), dim3(256), (size_t)10 * C * sizeof(float), stream,
+                           bank, w.qf, w.m16, N, C, mode == PP_MATCH_FAST ? 1 : 0, eps, w.rowrec,
+                           w.simt0, w.colmax, w.sim0s, sim_avg, stats);
     return pp_last_launch();
+}
+
+int pp_stage1_scores(const float* bank, const float* query, const float* mask, int mask_h,
+                     int mask_w, int B, int N, int C, int mode, float eps, void* workspace,
+                     size_t workspace_bytes, float* sim_avg, int32_t* stats, void* stream) {
+    return pp_stage1_scores_ex(bank, PP_BANK_F32, query, mask, mask_h, mask_w, B, N, C, mode, eps, workspace,
+                               workspace_bytes, sim_avg, stats, stream);
 }
 
 int pp_topk(const float* scores, int B, int N, int k, float* out_score, int64_t* out_index,

@@ -47,20 +47,23 @@ def _check_inputs(src_feats, tar_feat, tar_mask):
 
 
 def template_scores(src_feats, tar_feat, tar_mask, mode=None, eps=0.0, return_stats=False):
-    """sim_avg (B,N) of utils/matching.py:38-66 for a (B,N,C,16,16) bank."""
+    """sim_avg (B,N) of utils/matching.py:38-66 for a (B,N,C,16,16) bank.  A bank handed over as torch.float16 is read
+    as stored (2 bytes per element in HBM — BASELINE configs[4]); the result is what the fp32 path returns on those
+    values widened to float."""
     B, N, C = _check_inputs(src_feats, tar_feat, tar_mask)
     mode_id = _MODES[mode or DEFAULT_MODE]
-    bank = src_feats.contiguous().float()
+    half = src_feats.dtype == torch.float16
+    bank = src_feats.contiguous() if half else src_feats.contiguous().float()
     query = tar_feat.contiguous().float()
     mask = tar_mask.contiguous().float()
     ws, nbytes = _workspace(B, N, C, bank.device)
     sim_avg = torch.empty(B, N, dtype=torch.float32, device=bank.device)
     stats = torch.zeros(4, dtype=torch.int32, device=bank.device) if return_stats else None
-    rc = _lib.lib().pp_stage1_scores(
-        bank.data_ptr(), query.data_ptr(), mask.data_ptr(), mask.shape[1], mask.shape[2],
-        B, N, C, mode_id, float(eps), ws.data_ptr(), nbytes, sim_avg.data_ptr(),
+    rc = _lib.lib().pp_stage1_scores_ex(
+        bank.data_ptr(), _lib.PP_BANK_F16 if half else _lib.PP_BANK_F32, query.data_ptr(), mask.data_ptr(), mask.shape[1],
+        mask.shape[2], B, N, C, mode_id, float(eps), ws.data_ptr(), nbytes, sim_avg.data_ptr(),
         stats.data_ptr() if stats is not None else None, _stream_ptr())
-    _lib.check(rc, "pp_stage1_scores")
+    _lib.check(rc, "pp_stage1_scores_ex")
     return (sim_avg, stats) if return_stats else sim_avg
 
 

@@ -229,3 +229,64 @@ def test_four_wave_workgroup_shape(mode, monkeypatch):
         monkeypatch.delenv("PP_S1_WAVES")
         assert torch.equal(got4, ref8)
     _check(2, 6, 64, seed=5, mode=mode)
+
+
+@gpu
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("B,N,C", [(1, 4, 384), (2, 6, 64), (8, 42, 384), (5, 9, 768), (3, 7, 1024)])
+def test_half_precision_bank_equals_fp32_path_on_the_rounded_values(B, N, C, mode):
+    """BASELINE configs[4] stores the template bank as fp16 (2 B/elem in HBM).  The fp16-bank path must return what the
+    reference arithmetic gives on those stored values: (a) the CPU oracle on bank.half().float() within the same
+    tolerances as the fp32 path, (b) in exact mode BIT-equal to the HIP fp32-bank path fed with the widened values
+    (same kernel arithmetic, only the load differs), (c) top-k ids equal."""
+    from picopose_amd.utils import matching as hm
+
+    bank, query, m = _inputs(B, N, C, seed=7 * B + N)
+    bank16 = bank.half()
+    wide = bank16.float()
+    ref = om.template_scores(wide, query, m)
+    margin = om.decision_margins(wide, query, m)
+    got = hm.template_scores(bank16.cuda(), query.cuda(), m.cuda(), mode=mode)
+    same = hm.template_scores(wide.cuda(), query.cuda(), m.cuda(), mode=mode)
+    if mode == "exact":
+        assert torch.equal(got, same)
+    safe = margin > 1e-5
+    err = (got.cpu() - ref).abs()
+    assert err[safe].max().item() <= (2e-6 if mode == "exact" else 1e-5)
+    assert err.max().item() <= 1.0 / 256 + 1e-5
+    k = min(5, N)
+    gs, gi = hm.matching_templates(bank16.cuda(), query.cuda(), None, m.cuda(), topk=k, mode=mode)
+    ss, si = hm.matching_templates(wide.cuda(), query.cuda(), None, m.cuda(), topk=k, mode=mode)
+    assert torch.equal(gi, si) or torch.equal(gs, ss)
+
+
+@gpu
+def test_half_precision_bank_full_size_and_golden(golden_dir):
+    """The configs[2] stage-1 shape with an fp16 bank (2.04 GB instead of 4.08 GB): fast == exact decisions, and the
+    reference-generated golden cases with their banks rounded to fp16 against the oracle on the rounded values."""
+    import os
+
+    import numpy as np
+
+    from picopose_amd.utils import matching as hm
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    bank = torch.randn(32, 162, 768, 16, 16, device="cuda", generator=g).half()
+    query = torch.randn(32, 768, 16, 16, device="cuda", generator=g)
+    yy, xx = torch.meshgrid(torch.arange(224.0), torch.arange(224.0), indexing="ij")
+    m = (((yy - 111.5) ** 2 + (xx - 111.5) ** 2) < (0.4 * 224) ** 2).float()[None].repeat(32, 1, 1).cuda()
+    fast = hm.template_scores(bank, query, m, mode="fast")
+    exact = hm.template_scores(bank, query, m, mode="exact")
+    assert (fast - exact).abs().max().item() <= 1e-5
+    assert torch.equal(torch.topk(fast, 5, dim=1).indices, torch.topk(exact, 5, dim=1).indices) or (fast - exact).abs().max().item() < 2e-6
+    z = np.load(os.path.join(golden_dir, "stage1_matching_templates.npz"))
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        bank = torch.from_numpy(z[f"{name}/bank"]).half()
+        if not torch.isfinite(bank).all():
+            continue
+        query, mask = torch.from_numpy(z[f"{name}/query"]), torch.from_numpy(z[f"{name}/mask"])
+        ref = om.template_scores(bank.float(), query, mask)
+        got = hm.template_scores(bank.cuda(), query.cuda(), mask.cuda(), mode="fast").cpu()
+        margin = om.decision_margins(bank.float(), query, mask)
+        safe = margin > 1e-5
+        assert (got - ref).abs()[safe].max().item() <= 1e-5 if safe.any() else True
