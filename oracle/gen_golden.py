@@ -414,9 +414,123 @@ def gen_preprocess():
     print("bbox fixtures written")
 
 
+def synthetic_eval_case(seed=5, n_images=3, hyp=3):
+    """Canned evaluator inputs shared by gen_run_test (which feeds them to the REFERENCE run_test.run_test) and by
+    tests/test_pipeline_cpu.py (which feeds them to picopose_amd.pipeline): per image a few instances, per (instance,
+    hypothesis) a canned PnP answer (R, t, inlier ratio, success) and a canned stage-2 pose.  The network outputs carry
+    only an id that selects the canned answer — the loop semantics are what is under test, not the arithmetic."""
+    rng = np.random.RandomState(seed)
+    images = []
+    uid = 0
+    for i in range(n_images):
+        n_inst = [3, 1, 5][i % 3]
+        inst = []
+        for k in range(n_inst):
+            hyps = []
+            for h in range(hyp):
+                q, _ = np.linalg.qr(rng.randn(3, 3))
+                ok = bool(rng.rand() > 0.35)
+                hyps.append({"uid": uid, "R": q.tolist(), "t": (rng.randn(3) * 0.1 + [0, 0, 0.8]).tolist(),
+                             "ratio": float(np.round(rng.rand(), 3)) if ok else 0.0, "ok": ok,
+                             "stage2": np.vstack([np.hstack([np.linalg.qr(rng.randn(3, 3))[0], rng.randn(3, 1) * 0.1 + [[0], [0], [0.9]]]),
+                                                  [[0, 0, 0, 1]]]).astype(np.float32).tolist()})
+                uid += 1
+            inst.append({"obj_id": int(rng.randint(1, 4)), "score": float(np.round(rng.rand(), 4)), "hyps": hyps})
+        images.append({"scene_id": 10 + i, "img_id": 100 + 7 * i, "seg_time": 0.0, "instances": inst})
+    return {"hyp": hyp, "bs": 2, "n_obj": 3, "images": images}
+
+
+def gen_run_test():
+    """The REFERENCE evaluator loop itself — run_test.run_test (run_test.py:100-221) — on the canned case above: instance
+    mini-batches, PnP per (instance, hypothesis), stage-2 fallback, ranking by inlier ratio, the BOP csv rows.  It runs on
+    the CPU with: a stub model and a stub dataset module (ours: they only carry ids), `pose_recovery_ransac_pnp` replaced
+    by the canned table, `Tensor.cuda` / `torch.cuda.synchronize` neutralised, and empty in-memory modules for the
+    third-party imports of run_test.py that this image lacks (omegaconf, pytorch_lightning, timm, cv2 — none is touched
+    by the loop).  Stored: the case and the csv rows (without their last column, which is wall-clock time)."""
+    import json
+    import tempfile
+    import types
+
+    _ref()
+    for name in ("omegaconf", "pytorch_lightning", "timm", "timm.scheduler", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["omegaconf"].OmegaConf = object
+    sys.modules["pytorch_lightning"].LightningModule = torch.nn.Module
+    sys.modules["timm"].scheduler = sys.modules["timm.scheduler"]
+    import run_test as rt
+
+    case = synthetic_eval_case()
+    hyp = case["hyp"]
+    table = {h["uid"]: h for im in case["images"] for inst in im["instances"] for h in inst["hyps"]}
+
+    def fake_pnp(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts):
+        h = table[int(tar_pts[0, 0])]
+        return np.array(h["R"]), np.array(h["t"]).reshape(3, 1), h["ratio"], h["ok"]
+
+    class Model(torch.nn.Module):
+        def feature_extractor(self, x):
+            return [torch.zeros(x.shape[0], 4, 16, 16)]
+
+        def forward(self, inputs, hyp_):
+            outs = []
+            for tk in range(hyp_):
+                uid = inputs["uid"][:, tk]
+                outs.append({"tar_pts_2d": torch.zeros(len(uid), 2, 4, 4), "src_pts_3d": torch.zeros(len(uid), 3, 4, 4),
+                             "tem_pose": torch.eye(4).repeat(len(uid), 1, 1), "pred_tar_pts": uid[:, None, None].repeat(1, 16, 2),
+                             "pred_src_pts": uid[:, None, None].repeat(1, 16, 2),
+                             "pred_poses": torch.tensor([table[int(u)]["stage2"] for u in uid], dtype=torch.float32)})
+            return outs
+
+    class BOPTestset(torch.utils.data.Dataset):
+        def __init__(self, cfg, name, det):
+            self.obj_idxs = {1: 0, 2: 1, 3: 2}
+            self.n_template_view = 5
+
+        def __len__(self):
+            return len(case["images"])
+
+        def __getitem__(self, i):
+            im = case["images"][i]
+            n = len(im["instances"])
+            # tensor kinds and shapes of BOPTestset.__getitem__ (provider/bop_test_dataset.py:120-143)
+            return {"scene_id": torch.IntTensor([im["scene_id"]]), "img_id": torch.IntTensor([im["img_id"]]),
+                    "seg_time": torch.FloatTensor([im["seg_time"]]),
+                    "score": torch.FloatTensor([[x["score"]] for x in im["instances"]]),
+                    "obj_id": torch.IntTensor([[x["obj_id"]] for x in im["instances"]]),
+                    "obj_idx": torch.IntTensor([[x["obj_id"] - 1] for x in im["instances"]]),
+                    "real_K": torch.eye(3).repeat(n, 1, 1),
+                    "uid": torch.tensor([[h["uid"] for h in x["hyps"]] for x in im["instances"]])}
+
+        def get_templates(self, device):
+            return {"tem_rgb": torch.zeros(case["n_obj"], self.n_template_view, 3, 14, 14)}
+
+    mod = types.ModuleType("pp_fake_dataset")
+    mod.BOPTestset = BOPTestset
+    sys.modules["pp_fake_dataset"] = mod
+    ns = types.SimpleNamespace
+    cfg = ns(test_dataloader=ns(bs=case["bs"], num_workers=0, shuffle=False, drop_last=False, pin_memory=False),
+             test_dataset=ns(name="pp_fake_dataset"), model=ns(hypothesis=hyp))
+    rt.pose_recovery_ransac_pnp = fake_pnp
+    saved = torch.Tensor.cuda, torch.cuda.synchronize
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            rt.run_test(Model(), cfg, tmp, "synthetic", None)
+            (name,) = os.listdir(tmp)
+            lines = open(os.path.join(tmp, name)).read().splitlines()
+    finally:
+        torch.Tensor.cuda, torch.cuda.synchronize = saved
+    assert name == f"picopose-stage3-{hyp}hyp_synthetic-test.csv", name
+    rows = [ln.rsplit(",", 1)[0] for ln in lines]            # drop the wall-clock column
+    with open(os.path.join(OUT, "run_test_rows.json"), "w") as f:
+        json.dump({"case": case, "csv_name": name, "rows": rows}, f, separators=(",", ":"))
+    print(f"run_test fixture written: {len(rows)} rows")
+
+
 GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry, "nets": gen_nets, "e2e": gen_e2e,
               "e2e_calibrated": gen_e2e_calibrated, "vit_wide": gen_vit_wide, "state_dict": gen_state_dict,
-              "preprocess": gen_preprocess}
+              "preprocess": gen_preprocess, "run_test": gen_run_test}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

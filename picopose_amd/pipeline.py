@@ -26,12 +26,14 @@ def pnp_for_outputs(outputs, real_K, return_npts=False):
     return out + (res[4].reshape(hyp, B),) if return_npts else out
 
 
-def infer_batch(net, end_points, hyp=5):
+def infer_batch(net, end_points, hyp=5, pnp_fn=None):
     """-> per-instance pose hypotheses sorted by inlier ratio (run_test.py:168-186):
-    list over instances of list over hypotheses of dict(R (3,3), t (3,), inliers_ratio, pnp_success)."""
+    list over instances of list over hypotheses of dict(R (3,3), t (3,), inliers_ratio, pnp_success).
+    pnp_fn(outputs, real_K) -> (rot (hyp,B,3,3), tvec (hyp,B,3,1), ratio (hyp,B), ok (hyp,B)) replaces the batched HIP
+    PnP (tests of the loop semantics inject canned answers)."""
     outputs = net(end_points, hyp)
-    rot, tvec, ratio, ok = pnp_for_outputs(outputs, end_points["real_K"])
-    stage2 = np.stack([o["pred_poses"].cpu().numpy() for o in outputs])            # (hyp,B,4,4)
+    rot, tvec, ratio, ok = (pnp_fn or pnp_for_outputs)(outputs, end_points["real_K"])
+    stage2 = np.stack([o["pred_poses"].cpu().numpy() for o in outputs])            # (hyp,B,4,4) float32
     B = stage2.shape[1]
     results = []
     for b in range(B):
@@ -39,15 +41,15 @@ def infer_batch(net, end_points, hyp=5):
         for k in range(hyp):
             if ok[k, b]:
                 hyps.append(dict(R=rot[k, b], t=tvec[k, b, :, 0], inliers_ratio=float(ratio[k, b]), pnp_success=True))
-            else:  # run_test.py:177-179: fall back to the stage-2 pose
-                hyps.append(dict(R=stage2[k, b, :3, :3].astype(np.float64), t=stage2[k, b, :3, 3].astype(np.float64),
-                                 inliers_ratio=0.0, pnp_success=False))
-        hyps.sort(key=lambda h: h["inliers_ratio"], reverse=True)                   # run_test.py:186
+            else:  # run_test.py:177-179: fall back to the stage-2 pose — float32 as the network returned it (the csv row of
+                # such an instance prints float32 values), with the inlier ratio PnP reported
+                hyps.append(dict(R=stage2[k, b, :3, :3], t=stage2[k, b, :3, 3], inliers_ratio=float(ratio[k, b]), pnp_success=False))
+        hyps.sort(key=lambda h: h["inliers_ratio"], reverse=True)                   # run_test.py:186 (stable, like sorted())
         results.append(hyps)
     return results
 
 
-def infer_image(net, data, templates_data, hyp=5, bs=16):
+def infer_image(net, data, templates_data, hyp=5, bs=16, pnp_fn=None):
     """One test image exactly as run_test.py:141-188 walks it: `data` holds the image's instances on dim 1
     (data[key][0] = (n_instance, ...), plus 'obj_idx'), `templates_data[key]` the per-object template bank
     ((n_objects, N, ...), including 'template_feature' and, optionally, an extended bank under 'template_cache').
@@ -58,15 +60,14 @@ def infer_image(net, data, templates_data, hyp=5, bs=16):
     for start in range(0, n_instance, bs):
         end = min(start + bs, n_instance)
         obj_idx = data["obj_idx"][0][start:end].reshape(-1)
-        inputs = {k: v[0][start:end].contiguous() for k, v in data.items()}
+        inputs = {k: v[0][start:end].contiguous() for k, v in data.items() if v[0].dim() > 0}
         for k, v in templates_data.items():
             if k == "template_cache":   # extended bank: maps stay per object, instances carry their object index
                 inputs[k] = {"obj_index": obj_idx, "dpt": v["dpt"]}
             else:
                 inputs[k] = v[obj_idx].contiguous()
-        for hyps in infer_batch(net, inputs, hyp):
-            preds_image.append([{"R_stage_3": np.asarray(h["R"], dtype=np.float64).reshape(9),
-                                 "t_stage_3": np.asarray(h["t"], dtype=np.float64).reshape(3) * 1000,
+        for hyps in infer_batch(net, inputs, hyp, pnp_fn=pnp_fn):
+            preds_image.append([{"R_stage_3": np.asarray(h["R"]).reshape(9), "t_stage_3": np.asarray(h["t"]).reshape(3) * 1000,
                                  "inliers_ratio": h["inliers_ratio"]} for h in hyps])
     return preds_image
 

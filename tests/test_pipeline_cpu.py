@@ -121,3 +121,49 @@ def test_compat_import_installs_the_pnp_drop_in(tmp_path):
         for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.") or k in ("picopose", "fake_run_test")]:
             sys.modules.pop(k)
         sys.modules.update(saved)
+
+
+def test_evaluator_loop_reproduces_the_reference_run_test_rows(golden_dir):
+    """pipeline.infer_image + bop_csv_lines against tests/golden/run_test_rows.json — the csv rows the
+    REFERENCE's own run_test.run_test (run_test.py:100-221) wrote for the same canned case (oracle/gen_golden.py
+    gen_run_test): instance mini-batches of `bs`, PnP per (instance, hypothesis), stage-2 fallback (float32, as printed by
+    the reference), stable ranking by inlier ratio, best hypothesis per instance, t in millimetres, str() formatting."""
+    import json
+    import os
+
+    import torch
+
+    from picopose_amd.pipeline import infer_image
+
+    d = json.load(open(os.path.join(golden_dir, "run_test_rows.json")))
+    case, hyp = d["case"], d["case"]["hyp"]
+    table = {h["uid"]: h for im in case["images"] for inst in im["instances"] for h in inst["hyps"]}
+
+    def net(inputs, hyp_):          # the stub model of the generator: outputs carry only the id of the canned answer
+        outs = []
+        for tk in range(hyp_):
+            uid = inputs["uid"][:, tk]
+            outs.append({"pred_tar_pts": uid[:, None, None].repeat(1, 16, 2),
+                         "pred_poses": torch.tensor([table[int(u)]["stage2"] for u in uid], dtype=torch.float32)})
+        return outs
+
+    def pnp_fn(outputs, real_K):
+        H, B = len(outputs), outputs[0]["pred_poses"].shape[0]
+        rot, tvec, ratio, ok = np.zeros((H, B, 3, 3)), np.zeros((H, B, 3, 1)), np.zeros((H, B)), np.zeros((H, B), bool)
+        for h in range(H):
+            for b in range(B):
+                e = table[int(outputs[h]["pred_tar_pts"][b, 0, 0])]
+                rot[h, b], tvec[h, b, :, 0], ratio[h, b], ok[h, b] = np.array(e["R"]), np.array(e["t"]), e["ratio"], e["ok"]
+        return rot, tvec, ratio, ok
+
+    rows = []
+    for im in case["images"]:
+        inst = im["instances"]
+        data = {"score": torch.FloatTensor([[x["score"]] for x in inst])[None], "obj_id": torch.IntTensor([[x["obj_id"]] for x in inst])[None],
+                "obj_idx": torch.IntTensor([[x["obj_id"] - 1] for x in inst])[None], "real_K": torch.eye(3).repeat(len(inst), 1, 1)[None],
+                "uid": torch.tensor([[h["uid"] for h in x["hyps"]] for x in inst])[None]}
+        preds = infer_image(net, data, {}, hyp=hyp, bs=case["bs"], pnp_fn=pnp_fn)
+        lines = bop_csv_lines(im["scene_id"], im["img_id"], [data["obj_id"][0][k].item() for k in range(len(inst))],
+                              [data["score"][0][k].item() for k in range(len(inst))], preds, 0.0)
+        rows += [ln.rsplit(",", 1)[0] for ln in lines]
+    assert rows == d["rows"], next((a, b) for a, b in zip(rows, d["rows"]) if a != b)

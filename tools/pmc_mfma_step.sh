@@ -5,25 +5,34 @@
 tag=$1
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d $root/gpurun_out/pmc_mfma_${tag} -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $root/gpurun_out/pmc_mfma_${tag}.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d $root/gpurun_out/pmc_mfma_${tag} -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-exact-leg > $root/gpurun_out/pmc_mfma_${tag}.log 2>&1
 cd $root
 python3 - "$root/gpurun_out/pmc_mfma_${tag}" <<'PY'
 import csv, glob, sys, collections, re
+rows = []
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    rows += list(csv.DictReader(open(f)))
+ids = sorted({int(r["Dispatch_Id"]) for r in rows if "s1_main" in r["Kernel_Name"]})
+lo, hi = ids[1], ids[2]      # --warmup 1 --steps 1: the timed step = dispatches [s1_main #1, s1_main #2)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
-for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        n = r["Kernel_Name"]
-        n = re.sub(r"\(.*", "", n.replace("void ", "").replace("(anonymous namespace)::", ""))[:44]
-        agg[n][r["Counter_Name"]] += float(r["Counter_Value"])
-        if r["Counter_Name"] == "GRBM_GUI_ACTIVE": cnt[n] += 1
+for r in rows:
+    if not (lo <= int(r["Dispatch_Id"]) < hi):
+        continue
+    n = r["Kernel_Name"]
+    n = re.sub(r"\(.*", "", n.replace("void ", "").replace("(anonymous namespace)::", ""))[:44]
+    agg[n][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Counter_Name"] == "GRBM_GUI_ACTIVE": cnt[n] += 1
+print(f"ONE timed step of bench.py (default workload), dispatches {lo}..{hi - 1}")
 print(f"{'kernel':46s} {'launches':>8s} {'MFMA busy':>10s} {'share of GPU-active cycles':>27s}")
 tot = sum(v["GRBM_GUI_ACTIVE"] for v in agg.values())
 tb = 0.0
-for n, v in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])[:16]:
+vit = [0.0, 0.0]
+for n, v in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"]):
+    tb += v["SQ_VALU_MFMA_BUSY_CYCLES"]
+for n, v in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])[:18]:
     act = v["GRBM_GUI_ACTIVE"] / 8 * 1024
     busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / act if act else 0.0
-    tb += v["SQ_VALU_MFMA_BUSY_CYCLES"]
     print(f"{n:46s} {cnt[n]:8d} {busy:10.3f} {v['GRBM_GUI_ACTIVE'] / tot:27.3f}")
-print(f"all kernels of the run: MFMA busy {tb / (tot / 8 * 1024):.3f} of the SIMD cycles while a kernel is active")
+print(f"whole step: MFMA busy {tb / (tot / 8 * 1024):.3f} of the SIMD cycles while a kernel is active")
 PY

@@ -1,5 +1,5 @@
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --warmup 1` into HBM bytes per
-kernel for ONE step (the dispatches between the last two stage-1 launches).  FETCH_SIZE is doubled (gfx950 reports
+kernel for ONE step (the dispatches between the stage-1 launches that open the timed step and the leg after it).  FETCH_SIZE is doubled (gfx950 reports
 half the bytes of wide coalesced reads, MI355X_MICROARCH.md); both counters are in KiB."""
 import collections
 import csv
@@ -15,7 +15,7 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == cname]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     marks = [i for i, r in enumerate(rows) if "s1_main" in r["Kernel_Name"]]
-    lo, hi = marks[-2], marks[-1]
+    lo, hi = marks[1], marks[2]   # --warmup 1 --steps 1: launch 1 opens the timed step, launch 2 the first untimed leg
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows[lo:hi]:
         n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
