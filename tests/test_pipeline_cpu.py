@@ -79,7 +79,9 @@ def test_bench_gpus_n_launches_its_own_ranks():
 
     if not torch.cuda.is_available():
         assert r.returncode != 0
-        assert "rank 0 of 2" in out and "rank 1 of 2" in out, out[-1500:]
+        # (the elastic agent stops the surviving rank as soon as the first one has failed, so only one of them is sure
+        # to get its message out)
+        assert "rank 0 of 2" in out or "rank 1 of 2" in out, out[-1500:]
     # a rank count that contradicts the launcher is refused before any GPU call
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1"),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
