@@ -486,7 +486,7 @@ def main():
                        "hypotheses": 5, "mode": a.mode, "bank_dtype": "f16" if bpe == 2 else "f32",
                        "weights": "seeded random init, prediction heads calibrated (picopose_amd/utils/seeding.py)",
                        "parallelism": "single GPU" if world == 1 else
-                       f"crops data-parallel x{world}; feature bank template-sharded x{world} + all-gathers (packed query operand, scores); {backend}"},
+                       f"crops data-parallel x{world}; feature bank template-sharded x{world} + all-gathers (query features, sampled masks, scores); {backend}"},
         }
         s1_roof = {"bound": "hbm", "kernel": f"s1_main<{a.mode}> (stage-1 fused similarity)", "achieved": achieved,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
