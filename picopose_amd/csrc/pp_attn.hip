@@ -164,7 +164,7 @@ __device__ __forceinline__ int vt_slot(int key) {  // key (0..31) of a chunk -> 
 // HLIN: q, k, v arrive as the hl operand the qkv GEMM epilogue wrote (no split work here at all: fragments and the
 // K / V chunks are 16-byte copies); otherwise fp32 qkv, split while staging.  Both give the same bits.
 template <bool HLIN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_f16x3_kernel(const void* __restrict__ qkv_any, int T, int heads, float scale,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_f16x3_kernel(const void* __restrict__ qkv_any, int T, int heads, float scale,
                                                          float* __restrict__ out, _Float16* __restrict__ out_hl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Kh = (_Float16*)smem;            // [KC][KHLD]
@@ -214,52 +214,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const float S_DESCALE = scale / (PP_A_SCALE * PP_A_SCALE);
     constexpr float O_RESCALE = 1.0f / (PP_A_SCALE * P_SCALE);
 
-    for (int k0 = 0; k0 < T; k0 += KC) {
-        __syncthreads();
-        if (HLIN) {
-            for (int idx = tid; idx < KC * (HD / 8); idx += nthr) {  // 256 (hi, lo) 16-byte pairs per tensor: plain copies
+    // Keys are consumed in chunks of KC = 32 through LDS; a tail of up to TAILMAX keys (T = 257 = 8 x 32 + 1: the chunk
+    // loop would spend a ninth pass, 11 % of the kernel, on ONE key) is folded in afterwards on the VALU.
+    constexpr int TAILMAX = 4;
+    const int ntail = (T % KC) <= TAILMAX ? T % KC : 0, Tm = T - ntail;
+    // The chunk after the current one is fetched into registers while the current one is multiplied (the global -> LDS
+    // staging used to sit, latency exposed, between two barriers of every chunk).
+    constexpr int NIT = HLIN ? 2 : 4;            // items per thread: 256 (hi, lo) pairs / 512 float4 per tensor, >= 128 threads
+    h8 pk[HLIN ? 2 * NIT : 1], pv[HLIN ? 2 * NIT : 1];
+    f4 fk[HLIN ? 1 : NIT], fv[HLIN ? 1 : NIT];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * nthr;
+            if (HLIN) {
                 const int row = idx >> 3, g = idx & 7;
-                h8 kh8 = {0, 0, 0, 0, 0, 0, 0, 0}, kl8 = kh8, vh8 = kh8, vl8 = kh8;
-                if (k0 + row < T) {
+                h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                pk[2 * it] = pk[2 * it + 1] = pv[2 * it] = pv[2 * it + 1] = z;
+                if (idx < KC * (HD / 8) && k0 + row < Tm) {
                     const _Float16* kp2 = hbase + ((size_t)(k0 + row) * C3 + heads * HD + 8 * g) * 2;
                     const _Float16* vp2 = hbase + ((size_t)(k0 + row) * C3 + 2 * heads * HD + 8 * g) * 2;
-                    kh8 = *(const h8*)kp2;
-                    kl8 = *(const h8*)(kp2 + 8);
-                    vh8 = *(const h8*)vp2;
-                    vl8 = *(const h8*)(vp2 + 8);
+                    pk[2 * it] = *(const h8*)kp2;
+                    pk[2 * it + 1] = *(const h8*)(kp2 + 8);
+                    pv[2 * it] = *(const h8*)vp2;
+                    pv[2 * it + 1] = *(const h8*)(vp2 + 8);
                 }
-                *(h8*)(Kh + row * KHLD + 8 * g) = kh8;
-                *(h8*)(Kl + row * KHLD + 8 * g) = kl8;
-                const int slot = vt_slot(row);
-                *(h8*)(Vh + slot * VLD + 8 * g) = vh8;
-                *(h8*)(Vl + slot * VLD + 8 * g) = vl8;
+            } else {
+                const int row = idx >> 4, c4 = (idx & 15) * 4;
+                fk[it] = fv[it] = f4{0.f, 0.f, 0.f, 0.f};
+                if (idx < KC * (HD / 4) && k0 + row < Tm) {
+                    fk[it] = *(const f4*)(kp + (size_t)(k0 + row) * C3 + c4);
+                    fv[it] = *(const f4*)(vp + (size_t)(k0 + row) * C3 + c4);
+                }
             }
-        } else
-        for (int idx = tid; idx < KC * (HD / 4); idx += nthr) {  // 512 float4 per tensor; 8-byte LDS writes
-            const int row = idx >> 4, c4 = (idx & 15) * 4;
-            f4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (k0 + row < T) {
-                kv = *(const f4*)(kp + (size_t)(k0 + row) * C3 + c4);
-                vv = *(const f4*)(vp + (size_t)(k0 + row) * C3 + c4);
-            }
-            h4 khh, kll, vhh, vll;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                _Float16 hh, ll;
-                pp_split_f16(kv[i], hh, ll);
-                khh[i] = hh;
-                kll[i] = ll;
-                pp_split_f16(vv[i], hh, ll);
-                vhh[i] = hh;
-                vll[i] = ll;
-            }
-            *(h4*)(Kh + row * KHLD + c4) = khh;
-            *(h4*)(Kl + row * KHLD + c4) = kll;
-            const int slot = vt_slot(row);   // K [key][d], V [slot(key)][d]
-            *(h4*)(Vh + slot * VLD + c4) = vhh;
-            *(h4*)(Vl + slot * VLD + c4) = vll;
         }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * nthr;
+            if (HLIN) {
+                if (idx >= KC * (HD / 8)) continue;
+                const int row = idx >> 3, g = idx & 7, slot = vt_slot(row);   // K [key][d], V [slot(key)][d]
+                *(h8*)(Kh + row * KHLD + 8 * g) = pk[2 * it];
+                *(h8*)(Kl + row * KHLD + 8 * g) = pk[2 * it + 1];
+                *(h8*)(Vh + slot * VLD + 8 * g) = pv[2 * it];
+                *(h8*)(Vl + slot * VLD + 8 * g) = pv[2 * it + 1];
+            } else {
+                if (idx >= KC * (HD / 4)) continue;
+                const int row = idx >> 4, c4 = (idx & 15) * 4, slot = vt_slot(row);
+                h4 khh, kll, vhh, vll;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    _Float16 hh, ll;
+                    pp_split_f16(fk[it][i], hh, ll);
+                    khh[i] = hh;
+                    kll[i] = ll;
+                    pp_split_f16(fv[it][i], hh, ll);
+                    vhh[i] = hh;
+                    vll[i] = ll;
+                }
+                *(h4*)(Kh + row * KHLD + c4) = khh;
+                *(h4*)(Kl + row * KHLD + c4) = kll;
+                *(h4*)(Vh + slot * VLD + c4) = vhh;
+                *(h4*)(Vl + slot * VLD + c4) = vll;
+            }
+        }
+    };
+    if (Tm > 0) fetch(0);
+    for (int k0 = 0; k0 < Tm; k0 += KC) {
+        __syncthreads();                       // the previous chunk has been read by every wave
+        commit();
         __syncthreads();
+        if (k0 + KC < Tm) fetch(k0 + KC);      // in flight under this chunk's MFMAs and soft-max
         f32x16 sacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
@@ -275,7 +302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            sacc[e] = key < T ? sacc[e] * S_DESCALE : -INFINITY;
+            sacc[e] = key < Tm ? sacc[e] * S_DESCALE : -INFINITY;
             mx = fmaxf(mx, sacc[e]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -324,6 +351,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph[s], o1, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl[s], o1, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph[s], o1, 0, 0, 0);
+        }
+    }
+    // ---- tail keys on the VALU: one online-soft-max step per key with exact fp32 products of the operands' values
+    // (hi + lo is exact in fp32).  Lane (l31, lh) holds dims 16 s + 8 lh + i of its query; its accumulator register e
+    // holds O^T[d = (e & 3) + 8 (e >> 2) + 4 lh (+ 32)][query l31].
+    if (ntail > 0) {
+        __syncthreads();                       // every wave is done with the chunk buffers
+        float* tk = (float*)smem;              // [TAILMAX][64] values of 4 k, then [TAILMAX][64] of 4 v
+        float* tv = tk + TAILMAX * HD;
+        for (int idx = tid; idx < ntail * HD; idx += nthr) {
+            const int r = idx / HD, dd = idx - r * HD;
+            float kf, vf;
+            if (HLIN) {
+                const _Float16* kp2 = hbase + ((size_t)(Tm + r) * C3 + heads * HD) * 2 + pp_hl_col(dd, 0);
+                const _Float16* vp2 = hbase + ((size_t)(Tm + r) * C3 + 2 * heads * HD) * 2 + pp_hl_col(dd, 0);
+                kf = (float)kp2[0] + (float)kp2[8];
+                vf = (float)vp2[0] + (float)vp2[8];
+            } else {
+                _Float16 hh, ll;
+                pp_split_f16(kp[(size_t)(Tm + r) * C3 + dd], hh, ll);
+                kf = (float)hh + (float)ll;
+                pp_split_f16(vp[(size_t)(Tm + r) * C3 + dd], hh, ll);
+                vf = (float)hh + (float)ll;
+            }
+            tk[idx] = kf;
+            tv[idx] = vf;
+        }
+        __syncthreads();
+        for (int r = 0; r < ntail; ++r) {
+            float dot = 0.f;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    dot = fmaf((float)qh[s4][i] + (float)ql[s4][i], tk[r * HD + 16 * s4 + 8 * lh + i], dot);
+            dot += __shfl_xor(dot, 32);
+            const float sv = dot * S_DESCALE;
+            const float mnew = fmaxf(mrun, sv);
+            const float alpha = expf(mrun - mnew), pe = expf(sv - mnew);
+            lrun = lrun * alpha + pe;
+            mrun = mnew;
+            const float pw = pe * P_SCALE;     // the units of the MFMA path: (4 v) (1024 p)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int dd = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                o0[e] = fmaf(tv[r * HD + dd], pw, o0[e] * alpha);
+                o1[e] = fmaf(tv[r * HD + 32 + dd], pw, o1[e] * alpha);
+            }
         }
     }
     // output through LDS: O^T registers (lane = query) -> rows of 64 floats per query, written as full lines
