@@ -287,7 +287,11 @@ int pp_depth_points_nearest(const float* depth_m, int H, int W, int y1, int y2, 
  * (B*HW, HW) volume: f1 (B,H,W,C) with rows of ld_f1 floats, f2_l{0,1,2} = f2 and its 2x2 average pools holding
  * f2_batch images (image b reads f2[b % f2_batch]), flow (B,H,W,ld_flow);
  * out (B,H,W,ld_out) with channel l*(2r+1)^2 + a*(2r+1) + b = corr_l sampled at x offset a-r,
- * y offset b-r around (p + flow)/2^l. */
+ * y offset b-r around (p + flow)/2^l.
+ * When H, W are multiples of 8 and C of 32 the local correlations of an 8x8 pixel tile against a 16x16 region of f2
+ * are computed on the matrix cores in the engine's f16x3 arithmetic (22 operand bits, fp32 accumulation; values with
+ * |x| >= 16376 saturate); otherwise (and with PP_CORR_TILED=0 in the environment) by exact fp32 fmas, one lane per
+ * neighbour position. */
 int pp_corr_lookup_nhwc(const float* f1, int ld_f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
                         int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius,
                         int ld_flow, float* out, int ld_out, void* stream);
@@ -296,7 +300,9 @@ int pp_corr_lookup_nhwc(const float* f1, int ld_f1, const float* f2_l0, const fl
  * utils/pose_recovery.py:68-105 pose_recovery_ransac_pnp, batched over P = instances x hypotheses
  * (run_test.py:168-184 calls it once per pair): gather of the valid 2D/3D correspondences, object-frame
  * transform, RANSAC (5-point samples, `iterations`, squared reprojection error <= threshold^2) with EPnP
- * as the model solver and an EPnP refit on the inliers (picopose_amd/csrc/pp_pnp.hip).
+ * as the model solver and an EPnP refit on the inliers (picopose_amd/csrc/pp_pnp.hip).  One 512-thread workgroup per
+ * problem, fp64; hypothesis h of problem p draws its sample from a counter-based hash of (p, h), so a problem's result
+ * depends on its index in the batch (as OpenCV's depends on its RNG state), not on the launch configuration.
  *   tar_pts_2d (P,2,H,W), src_pts_3d (P,3,H,W), K (P,3,3), tem_pose (P,4,4) fp32;
  *   tar_pts, src_pts (P,N,2) int64 (x,y) with -1 padding, N <= 4096;
  *   out: rot (P,3,3) f64, tvec (P,3) f64, inlier_ratio (P) f64, success (P) int32 (0: the reference's
