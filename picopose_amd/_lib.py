@@ -60,6 +60,11 @@ def lib():
                 f"{LIB} not found: build it with `python -m picopose_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback."
             )
+        # torch first: PyTorch-ROCm bundles its own libamdhip64, and this library must bind to THAT runtime (it launches on
+        # torch's streams and takes torch's device pointers).  Loaded before torch, it would pull in /opt/rocm's copy — two
+        # HIP runtimes in one process, and every launch fails (seen on the GPU box with build() followed by smoke()).
+        import torch  # noqa: F401
+
         L = ctypes.CDLL(LIB)
         c = ctypes
         vp, i32, f32, sz = c.c_void_p, c.c_int, c.c_float, c.c_size_t

@@ -2,6 +2,8 @@
 No compute calls here (no GPU)."""
 import ctypes
 
+import pytest
+
 from picopose_amd import _lib
 from picopose_amd.build import LIB, build_lib
 
@@ -89,3 +91,22 @@ def test_pack_cache_is_dropped_when_a_checkpoint_loads_through_the_top_level_net
     fd.packed()
     wrapper.load_state_dict({"network." + k: v for k, v in seeded_state_dict(net.state_dict(), 3).items()})
     assert fd._pack_cache is None
+
+
+@pytest.mark.gpu
+def test_library_loaded_before_torch_still_launches():
+    """`__graft_entry__.build()` opens the library before anything has imported torch.  PyTorch-ROCm bundles its own HIP
+    runtime; if the library bound to /opt/rocm's copy instead, the process would hold two runtimes and every launch on a
+    torch stream would fail (seen on the GPU box: build() followed by smoke() in one process).  _lib.lib() therefore
+    imports torch first — checked here in a fresh interpreter."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import __graft_entry__ as g; g.build(); import torch; from picopose_amd.utils import matching as hm; "
+            "g0 = torch.Generator().manual_seed(0); bank = torch.randn(1, 4, 384, 16, 16, generator=g0).cuda(); "
+            "q = torch.randn(1, 384, 16, 16, generator=g0).cuda(); s, i = hm.matching_templates(bank, q, None, torch.ones(1, 224, 224).cuda(), topk=4); "
+            "torch.cuda.synchronize(); print('LAUNCH OK', i.tolist())")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and "LAUNCH OK" in r.stdout.decode(), r.stdout.decode()[-2000:]
