@@ -213,7 +213,7 @@ def test_oracle_forward_vs_reference_calibrated(golden_dir, tag):
         assert bad <= 4 * B
 
 
-def _hip_calibrated_forward(golden_dir, tag):
+def _hip_calibrated_forward(golden_dir, tag, match_mode=None):
     from picopose_amd.picopose import Net
 
     z, B, N, hyp, seed, vit, ref, weights = _load_cal(golden_dir, tag)
@@ -222,6 +222,7 @@ def _hip_calibrated_forward(golden_dir, tag):
     sd = weights(net.state_dict())
     net.load_state_dict(sd)
     net = net.cuda().eval()
+    net.match_mode = match_mode
     ep = make_end_points(B, N, seed, tem_pose=torch.from_numpy(z[f"{tag}/tem_pose_all"]), dome=True)
     dev = {k: v.cuda() for k, v in ep.items()}
     dev["template_feature"] = torch.stack([net.feature_extractor(dev["tem_rgb"][b])[-1] for b in range(B)])
@@ -297,10 +298,26 @@ def test_hip_forward_vs_reference_calibrated(golden_dir, tag):
 
 
 @gpu
-@pytest.mark.parametrize("cfg", ["4", "5"])
+@pytest.mark.parametrize("tag", CAL_CASES)
+def test_hip_forward_vs_reference_calibrated_exact_mode(golden_dir, tag):
+    """The same comparison in `--mode exact`: fp32 MFMA in every kernel (ops.PRECISION = "f32") and the exact-fp32 stage 1."""
+    from picopose_amd import ops
+
+    old = ops.PRECISION
+    ops.PRECISION = "f32"
+    try:
+        z, B, N, hyp, ref, ep, dev, outs, flow, cert = _hip_calibrated_forward(golden_dir, tag, match_mode="exact")
+        _check_hip_vs_reference(z, tag, B, hyp, ref, outs, flow, cert)
+    finally:
+        ops.PRECISION = old
+
+
+@gpu
+@pytest.mark.parametrize("cfg", ["4", "5", "6"])
 def test_hip_forward_vitb_with_pinned_persistent_kernels(golden_dir, monkeypatch, cfg):
-    """The ViT-B net-vs-reference comparison with every pre-split GEMM / conv forced onto the persistent 256x128 (cfg 4)
-    and 256x256 (cfg 5) kernels — the kernels the headline bench runs — instead of the autotuner's pick."""
+    """The ViT-B net-vs-reference comparison with every pre-split GEMM / conv forced onto the persistent 256x128 (cfg 4),
+    256x256 (cfg 5) and row-shared 3x3 (cfg 6) kernels — the kernels the headline bench runs — instead of the
+    autotuner's pick."""
     monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
     z, B, N, hyp, ref, ep, dev, outs, flow, cert = _hip_calibrated_forward(golden_dir, "vitb_b1n3")
     _check_hip_vs_reference(z, "vitb_b1n3", B, hyp, ref, outs, flow, cert)
