@@ -529,7 +529,8 @@ int pp_corr_lookup_nhwc(const float* f1, int ld_f1, const float* f2_l0, const fl
     if ((H >> (levels - 1)) < 1 || (W >> (levels - 1)) < 1 || ld_flow < 2) return PP_EINVAL;
     const int win = 2 * radius + 1;
     if (ld_out < levels * win * win) return PP_EINVAL;
-    static const bool tiled = [] { const char* e = getenv("PP_CORR_TILED"); return !(e && e[0] == '0'); }();
+    const char* te = getenv("PP_CORR_TILED");   // read per call: the tests run both kernels in one process
+    const bool tiled = !(te && te[0] == '0');
     if (tiled && H % CT == 0 && W % CT == 0 && C % CK == 0 && ((uintptr_t)f2_l0 % 16) == 0) {
         // matrix-core version: one workgroup per 8 x 8 pixel tile (PP_CORR_TILED=0 keeps the lane-per-position kernel)
         const size_t lds = (size_t)(CM * CSP > (CM + CN) * CKP ? CM * CSP : (CM + CN) * CKP) * sizeof(float);

@@ -157,3 +157,32 @@ def test_feature_extractor_vs_reference_golden_vitb_vitl(golden_dir, monkeypatch
         amax = float(z[f"{vit}/absmax"][l])
         assert float(np.abs(f[0, :, 3, 5].cpu().numpy() - z[f"{vit}/pixel_probe"][l]).max()) <= 2e-4 * amax
         assert float(np.abs(f[0, ::32].cpu().numpy() - z[f"{vit}/channel_probe"][l]).max()) <= 2e-4 * amax
+
+
+@gpu
+@pytest.mark.parametrize("H,levels,scale", [(16, 1, 1.0), (32, 2, 3.0), (64, 3, 0.7), (64, 3, 40.0), (24, 2, 2.0)])
+def test_tiled_corr_lookup_equals_the_lane_per_position_kernel(monkeypatch, H, levels, scale):
+    """The matrix-core correlation lookup (8x8 pixel tiles x 16x16 regions, f16x3) against the exact-fp32
+    lane-per-position kernel it replaced (PP_CORR_TILED=0) and against the CPU oracle: smooth flows (one region pass),
+    noisy flows (several passes per tile), flows far outside the image (no pass at all), a query map shared by several
+    images of the batch, an output with padded channels."""
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(H * 10 + levels)
+    B, C = 4, 64
+    f1 = torch.randn(B, H, H, C, generator=g).cuda()
+    f2 = torch.randn(2, H, H, C, generator=g).cuda()                     # image b reads f2[b % 2]
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(H, dtype=torch.float32), indexing="ij")
+    smooth = torch.stack([0.15 * xx - 0.1 * yy + 1.3, 0.1 * xx + 0.2 * yy - 2.1], dim=-1)[None].repeat(B, 1, 1, 1)
+    flow = (smooth + scale * torch.randn(B, H, H, 2, generator=g)).cuda()
+    pad = -(-(levels * 25) // 8) * 8
+    tiled = ops.corr_lookup(f1, f2, flow, levels, 2, c_pad=pad)
+    monkeypatch.setenv("PP_CORR_TILED", "0")
+    exact = ops.corr_lookup(f1, f2, flow, levels, 2, c_pad=pad)
+    monkeypatch.delenv("PP_CORR_TILED")
+    ref = on.corr_lookup(f1.cpu().permute(0, 3, 1, 2), f2.cpu().repeat(2, 1, 1, 1).permute(0, 3, 1, 2), flow.cpu().permute(0, 3, 1, 2), levels, 2)
+    ref = ref.permute(0, 2, 3, 1)
+    n = levels * 25
+    assert float((exact[..., :n].cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((tiled[..., :n].cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(tiled[..., n:], torch.zeros_like(tiled[..., n:]))
