@@ -28,6 +28,7 @@ constexpr int GL = 16;            // lanes of a solver group (12 of them own a c
 constexpr int NG = NT / GL;       // solver groups per workgroup: RANSAC hypotheses are solved NG at a time
 constexpr int MAXP = 4096;
 constexpr int MAXH = 256;         // RANSAC hypotheses kept per problem
+constexpr int HB = 128;           // hypotheses per batch (their null-space vectors wait in LDS between the two phases)
 constexpr int SAMPLE = 5;         // minimal sample size of solvePnPRansac for EPNP
 
 // ------------------------------------------------------------------ small dense helpers (double)
@@ -260,6 +261,7 @@ struct PointSet {
     const unsigned char* use;  // MODE 1: inlier mask
     int n;            // MODE 0: sample size, MODE 1: total points
     double* red;      // MODE 1: LDS scratch [NW][144]
+    double* vn;       // MODE 0, PHASE 1 / 2: the hypothesis' four null-space vectors [4][12] in LDS
 };
 
 // sum of vals[0..CNT) over the workgroup, result in every thread (MODE 0: every lane already holds the full sums)
@@ -302,8 +304,13 @@ __device__ inline void block_sum(const PointSet<MODE>& ps, double (&vals)[CNT]) 
         }                                                                                  \
     }
 
-// returns the mean reprojection error of the chosen solution; R (row-major) and t
-template <int MODE>
+// returns the mean reprojection error of the chosen solution; R (row-major) and t.
+// PHASE 0: the whole solve.  A RANSAC hypothesis (MODE 0) is solved in two phases so that only the 12x12 eigenproblem
+// pays for a 16-lane group: PHASE 1 (a group per hypothesis) stops after the eigen-solve and leaves the four null-space
+// vectors in LDS; PHASE 2 (ONE THREAD per hypothesis, 64 per wave) repeats the cheap preparation — bit for bit the same
+// control points — picks the vectors up and does the scalar algebra (three beta initialisations, Gauss-Newton, Horn
+// alignment), which a group would execute sixteen times over.
+template <int MODE, int PHASE = 0>
 __device__ double epnp(const PointSet<MODE>& ps, const Cam& cam, double (&R)[9], double (&t)[3]) {
     const int gk = threadIdx.x & (GL - 1);   // lane of the solver group
     // ---- control points: centroid + principal directions
@@ -352,6 +359,8 @@ _Pragma("unroll")
     };
     // ---- M^T M (12 x 12): lane gk of a solver group accumulates column gk.  MODE 1: group g takes the points
     // g, g + NG, ..., then the columns are summed over the groups (wave shuffles, then `red`)
+    double vn[4][12];
+    if (PHASE != 2) {
     double g12[12], v12[12];
 #pragma unroll
     for (int r = 0; r < 12; ++r) g12[r] = 0.0;
@@ -397,7 +406,6 @@ _Pragma("unroll")
     }
     hestenes12(g12, v12, gk);
     // the four eigenvectors of the smallest eigenvalues, ascending, into every lane: vn[i][0..12)
-    double vn[4][12];
     {
         double lam = 0.0;
 #pragma unroll
@@ -416,10 +424,23 @@ _Pragma("unroll")
 #pragma unroll
             for (int q = 0; q < 4; ++q) src[q] = ro == q ? o : src[q];
         }
+        if (PHASE == 1) {          // hand the vectors over through LDS: the lane ranked q < 4 owns vector q
+            if (gk < 12 && rank < 4) {
+#pragma unroll
+                for (int r = 0; r < 12; ++r) ps.vn[rank * 12 + r] = v12[r];
+            }
+            return 0.0;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 12; ++r) vn[q][r] = __shfl(v12[r], src[q], GL);
+    }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 12; ++r) vn[q][r] = ps.vn[q * 12 + r];
     }
     // ---- L (6 x 10) and rho
     double L[6][10], rho[6];
@@ -576,8 +597,9 @@ __global__ __launch_bounds__(NT) void pnp_ransac_kernel(const float* __restrict_
     float* p3 = (float*)smem;                      // [MAXP][3]
     float* p2 = p3 + 3 * MAXP;                     // [MAXP][2]
     unsigned char* use = (unsigned char*)(p2 + 2 * MAXP);  // [MAXP]
-    double* red = (double*)(use + MAXP);           // [NW][144]
-    double* hyp = red + NW * 144;                  // [MAXH][12]  R, t of every hypothesis
+    double* vnb = (double*)(use + MAXP);           // [HB][4][12] null-space vectors of a batch of hypotheses
+    double* red = vnb;                             // [NW][144] (the refit's reduction scratch, after the hypotheses)
+    double* hyp = vnb + HB * 48;                   // [MAXH][12]  R, t of every hypothesis
     int* cnt = (int*)(hyp + MAXH * 12);            // [MAXH]
     __shared__ int wsum[NW], base, best_h, best_c;
     const int prob = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -631,36 +653,51 @@ __global__ __launch_bounds__(NT) void pnp_ransac_kernel(const float* __restrict_
     };
     if (np < SAMPLE) { fail(); return; }
 
-    // ---- RANSAC hypotheses: solver group g (16 lanes) solves EPnP on the 5-point samples of hypotheses g, g + NG, ...
+    // ---- RANSAC hypotheses on 5-point samples, HB at a time: phase 1 — solver group g (16 lanes) runs the 12x12
+    // eigen-solve of hypotheses g, g + NG, ... and leaves their null-space vectors in LDS; phase 2 — thread h finishes
+    // hypothesis h (64 hypotheses per wave instead of 4)
     const int nh = iters < MAXH ? iters : MAXH;
-    for (int h0 = 0; h0 < nh; h0 += NG) {
-        const int h = h0 + tid / GL;
-        if (h < nh) {      // (uniform over the 16 lanes of a group; the shuffles inside stay within the group)
-            int idx[SAMPLE];
-            unsigned s = hash32(0x9E3779B9u * (unsigned)(prob + 1) ^ (unsigned)(h * 7919 + 17));
+    auto sample = [&](int h, int (&idx)[SAMPLE]) __attribute__((always_inline)) {
+        unsigned s = hash32(0x9E3779B9u * (unsigned)(prob + 1) ^ (unsigned)(h * 7919 + 17));
 #pragma unroll
-            for (int k = 0; k < SAMPLE; ++k) {
-                for (;;) {
-                    s = hash32(s + 0x6D2B79F5u);
-                    const int c = (int)(s % (unsigned)np);
-                    bool dup = false;
+        for (int k = 0; k < SAMPLE; ++k) {
+            for (;;) {
+                s = hash32(s + 0x6D2B79F5u);
+                const int c = (int)(s % (unsigned)np);
+                bool dup = false;
 #pragma unroll
-                    for (int j = 0; j < SAMPLE; ++j) dup |= j < k && idx[j] == c;
-                    if (!dup) { idx[k] = c; break; }
-                }
-            }
-            PointSet<0> ps = {p3, p2, idx, nullptr, SAMPLE, nullptr};
-            double R[9], t[3];
-            const double e = epnp<0>(ps, cam, R, t);
-            if ((tid & (GL - 1)) == 0) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) hyp[h * 12 + k] = e < 1e299 ? R[k] : 0.0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) hyp[h * 12 + 9 + k] = e < 1e299 ? t[k] : 0.0;
+                for (int j = 0; j < SAMPLE; ++j) dup |= j < k && idx[j] == c;
+                if (!dup) { idx[k] = c; break; }
             }
         }
+    };
+    for (int hb = 0; hb < nh; hb += HB) {
+        const int hend = hb + HB < nh ? hb + HB : nh;
+        for (int h0 = hb; h0 < hend; h0 += NG) {
+            const int h = h0 + tid / GL;
+            if (h < hend) {      // (uniform over the 16 lanes of a group; the shuffles inside stay within the group)
+                int idx[SAMPLE];
+                sample(h, idx);
+                PointSet<0> ps = {p3, p2, idx, nullptr, SAMPLE, nullptr, vnb + (h - hb) * 48};
+                double R[9], t[3];
+                (void)epnp<0, 1>(ps, cam, R, t);
+            }
+        }
+        __syncthreads();
+        if (tid < HB && hb + tid < hend) {
+            const int h = hb + tid;
+            int idx[SAMPLE];
+            sample(h, idx);
+            PointSet<0> ps = {p3, p2, idx, nullptr, SAMPLE, nullptr, vnb + tid * 48};
+            double R[9], t[3];
+            const double e = epnp<0, 2>(ps, cam, R, t);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) hyp[h * 12 + k] = e < 1e299 ? R[k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) hyp[h * 12 + 9 + k] = e < 1e299 ? t[k] : 0.0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // ---- score every hypothesis on every point (squared reprojection error <= thresh^2): a thread keeps its (up to 8)
     // points in registers and walks the hypotheses (the 12 doubles of a model are an LDS broadcast); counts are summed
     // per wave and added to cnt[h] with one LDS atomic per wave — no barrier inside the loop
@@ -720,7 +757,7 @@ __global__ __launch_bounds__(NT) void pnp_ransac_kernel(const float* __restrict_
     }
     __syncthreads();
     // ---- refit on the inlier set (all threads cooperate, identical small algebra in every thread)
-    PointSet<1> ps = {p3, p2, nullptr, use, np, red};
+    PointSet<1> ps = {p3, p2, nullptr, use, np, red, nullptr};
     double R[9], t[3];
     const double e = epnp<1>(ps, cam, R, t);
     if (tid == 0) {
@@ -745,7 +782,8 @@ int pp_pnp_ransac(const float* tar_pts_2d, const float* src_pts_3d, const float*
         !success || !num_points)
         return PP_EINVAL;
     if (P <= 0 || H <= 0 || W <= 0 || N <= 0 || N > MAXP || iterations <= 0 || reproj_threshold <= 0.f) return PP_EINVAL;
-    const size_t smem = (size_t)MAXP * (3 + 2) * sizeof(float) + MAXP + (size_t)NW * 144 * sizeof(double) +
+    static_assert(HB * 48 >= NW * 144, "the refit's reduction scratch aliases the null-space vector buffer");
+    const size_t smem = (size_t)MAXP * (3 + 2) * sizeof(float) + MAXP + (size_t)HB * 48 * sizeof(double) +
                         (size_t)MAXH * 12 * sizeof(double) + MAXH * sizeof(int);
     static bool attr_set[PP_MAX_DEVICES];   // the dynamic-LDS opt-in is per device
     if (!attr_set[pp_cur_device()]) {
