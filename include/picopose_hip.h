@@ -206,6 +206,10 @@ int pp_split_f16x3(const float* w, long long n, void* hl, float* scale, void* st
  * once into a contiguous hl buffer (B*P rows, ld = C) for PP_PREC_F16X3 (activation scale 4; optional ReLU first). */
 int pp_split_activation(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu,
                         void* hl, void* stream);
+/* The same into C columns of a wider hl operand whose rows hold ld_h elements (hl = address of the first column's
+ * group: a multiple of 8 columns into the row): the channel concatenation of operands without an fp32 concat buffer. */
+int pp_split_activation_ld(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu,
+                           void* hl, int ld_h, void* stream);
 
 /* Fused multi-head self-attention (model/stage1/layers/attention.py:49-62): qkv (B,T,3,heads,64) as the qkv
  * linear produces it -> out (B,T,heads*64) = softmax((q*scale) k^T) v per head; exact fp32 MFMA, flash style. */
@@ -260,6 +264,9 @@ int pp_resize_bilinear_nhwc_hl(const float* in, int B, int H, int W, int C, int 
  * feat_batch images (= B, or the query maps given once for the B / feat_batch hypotheses of a hypothesis-major batch). */
 int pp_warp_nhwc(const float* feat, int feat_batch, const float* flow, int B, int H, int W, int C, int ld_flow,
                  float* out, int ld_out, void* stream);
+/* Same, writing the result only as C columns of an hl operand with rows of ld_h elements (C % 8 == 0). */
+int pp_warp_nhwc_hl(const float* feat, int feat_batch, const float* flow, int B, int H, int W, int C, int ld_flow,
+                    void* out_hl, int ld_h, void* stream);
 /* nn.AvgPool2d(2,2) on NHWC. */
 int pp_avgpool2_nhwc(const float* in, int B, int H, int W, int C, float* out, void* stream);
 /* dst[i] = src[index[i]] for i < n: rows of row_floats fp32 (a multiple of 4; both buffers 16-byte aligned), index int64

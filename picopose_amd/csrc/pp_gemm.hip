@@ -1914,7 +1914,8 @@ namespace {
 // activation pre-split: x (B, P, C) fp32 with batch / row strides -> contiguous hl operand (B*P rows, ld = C):
 // one thread = 8 channels = 32 bytes in, 32 contiguous bytes (8 hi + 8 lo) out
 __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict__ x, long long bstride, int P, int ld,
-                                                        int C, long long total8, int relu, _Float16* __restrict__ hl) {
+                                                        int C, long long total8, int relu, _Float16* __restrict__ hl,
+                                                        int ldh) {
     const int c8n = C >> 3;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
         const long long row = i / c8n;
@@ -1932,7 +1933,7 @@ __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict_
         h4 h0, l0, h1, l1;
         split_f16x4(v0, A_SCALE, h0, l0);
         split_f16x4(v1, A_SCALE, h1, l1);
-        _Float16* o = hl + row * 2 * C + 2 * c;
+        _Float16* o = hl + row * ldh + 2 * c;
         *(h4*)o = h0;
         *(h4*)(o + 4) = h1;
         *(h4*)(o + 8) = l0;
@@ -2128,16 +2129,21 @@ int pp_split_f16x3(const float* w, long long n, void* hl, float* scale, void* st
     return pp_last_launch();
 }
 
-int pp_split_activation(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu, void* hl,
-                        void* stream) {
+int pp_split_activation_ld(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu, void* hl,
+                           int ld_h, void* stream) {
     if (!x || !hl || B <= 0 || P <= 0 || C <= 0 || C % 8 != 0 || row_stride % 4 != 0 || batch_stride % 4 != 0 ||
-        ((uintptr_t)x % 16) != 0 || ((uintptr_t)hl % 16) != 0)
+        ((uintptr_t)x % 16) != 0 || ((uintptr_t)hl % 16) != 0 || ld_h < C || ld_h % 8 != 0)
         return PP_EINVAL;
     const long long total8 = (long long)B * P * (C / 8);
     const int grid = (int)((total8 + 255) / 256 < 8192 ? (total8 + 255) / 256 : 8192);
     hipLaunchKernelGGL(split_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, batch_stride, P, row_stride, C,
-                       total8, relu, (_Float16*)hl);
+                       total8, relu, (_Float16*)hl, 2 * ld_h);
     return pp_last_launch();
+}
+
+int pp_split_activation(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu, void* hl,
+                        void* stream) {
+    return pp_split_activation_ld(x, batch_stride, B, P, row_stride, C, relu, hl, C, stream);
 }
 
 int pp_gemm(const PpGemmDesc* desc, void* stream) {

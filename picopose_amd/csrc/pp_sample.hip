@@ -90,6 +90,9 @@ __device__ __forceinline__ float roundtrip(float x, int size) {
 
 // FlowDecoder.feature_sample — flow_decoder.py:49-56: out[p] = bilinear(feat, p + flow[p]), zeros padding.
 // One wave per pixel, lanes over channels (float4).
+// HL: the result leaves only as columns of an hl operand (rows of ld_out ELEMENTS = 2 ld_out halfs): a lane's 4 channels
+// are half of a group of 8 — 4 hi terms and 4 lo terms, 8 bytes each.
+template <bool HL>
 __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ feat, int feat_batch,
                                                    const float* __restrict__ flow, int H, int W, int C, int ld_flow,
                                                    float* __restrict__ out, int ld_out) {
@@ -102,7 +105,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
     const int x0 = (int)x0f, y0 = (int)y0f;
     const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix, wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
     const float* fb = feat + (size_t)(b % feat_batch) * H * W * C;  // feat given once for several hypotheses
-    float* o = out + ((size_t)b * H * W + p) * ld_out;
+    float* o = HL ? nullptr : out + ((size_t)b * H * W + p) * ld_out;
+    _Float16* oh = HL ? (_Float16*)out + ((size_t)b * H * W + p) * 2 * ld_out : nullptr;
     const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
     const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
     for (int c = lane * 4; c < C; c += 256) {
@@ -111,7 +115,19 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
         if (vy0 && vx1) acc += *(const f4*)(fb + ((size_t)y0 * W + x0 + 1) * C + c) * (wx1 * wy0);
         if (vy1 && vx0) acc += *(const f4*)(fb + ((size_t)(y0 + 1) * W + x0) * C + c) * (wx0 * wy1);
         if (vy1 && vx1) acc += *(const f4*)(fb + ((size_t)(y0 + 1) * W + x0 + 1) * C + c) * (wx1 * wy1);
-        *(f4*)(o + c) = acc;
+        if (HL) {
+            typedef _Float16 h4w __attribute__((ext_vector_type(4)));
+            _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
+            pp_split_f16(acc.x, h0, l0);
+            pp_split_f16(acc.y, h1, l1);
+            pp_split_f16(acc.z, h2, l2);
+            pp_split_f16(acc.w, h3, l3);
+            _Float16* q = oh + pp_hl_col(c, 0);
+            *(h4w*)q = h4w{h0, h1, h2, h3};
+            *(h4w*)(q + 8) = h4w{l0, l1, l2, l3};
+        } else {
+            *(f4*)(o + c) = acc;
+        }
     }
 }
 
@@ -506,8 +522,18 @@ int pp_warp_nhwc(const float* feat, int feat_batch, const float* flow, int B, in
     if (!feat || !flow || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || ld_flow < 2 || feat_batch <= 0 ||
         ld_out < C || ld_out % 4 != 0 || ((uintptr_t)out % 16) != 0)
         return PP_EINVAL;
-    hipLaunchKernelGGL(warp_kernel, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, feat_batch, flow,
+    hipLaunchKernelGGL(warp_kernel<false>, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, feat_batch, flow,
                        H, W, C, ld_flow, out, ld_out);
+    return pp_last_launch();
+}
+
+int pp_warp_nhwc_hl(const float* feat, int feat_batch, const float* flow, int B, int H, int W, int C, int ld_flow,
+                    void* out_hl, int ld_h, void* stream) {
+    if (!feat || !flow || !out_hl || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || ld_flow < 2 || feat_batch <= 0 ||
+        ld_h < C || ld_h % 8 != 0 || ((uintptr_t)out_hl % 16) != 0)
+        return PP_EINVAL;
+    hipLaunchKernelGGL(warp_kernel<true>, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, feat_batch, flow,
+                       H, W, C, ld_flow, (float*)out_hl, ld_h);
     return pp_last_launch();
 }
 

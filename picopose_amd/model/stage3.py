@@ -79,7 +79,8 @@ class DPTHead(Packed):
         out = x0 if x1 is None else self._rcu(pk, f"f{i}_u1", x1, extra=x0, more=True)   # feeds resConfUnit2
         out = self._rcu(pk, f"f{i}_u2", out)
         out = ops.resize_bilinear(out, size[0], size[1], out_split=True)   # feeds only the 1x1 out_conv
-        return ops.conv2d(out, pk[f"f{i}_out"], getattr(self.scratch, f"refinenet{i}").out_conv.bias, 1)
+        # the path map is an output (fp32) AND the input of the flow decoder's 1x1 projection: its operand form rides along
+        return ops.conv2d(out, pk[f"f{i}_out"], getattr(self.scratch, f"refinenet{i}").out_conv.bias, 1, also_split="plain")
 
     def forward_nhwc(self, feats):
         """feats: 4 NHWC maps (B,16,16,C) (may be views with a free batch stride) -> [path_4, path_3, path_2] NHWC."""
@@ -160,34 +161,58 @@ class FlowDecoder(Packed):
         for l in range(self.num_levels):
             fr_in, fq_in = feat_render_list[l], feat_real_list[l]
             B, H, W, _ = fr_in.shape
-            X = torch.empty(B, H, W, 640, dtype=torch.float32, device=fr_in.device)  # [render | warped real | motion]
+            # decoder input [render | warped real | motion] (640 channels).  f32 engine: an fp32 NHWC buffer X the producers
+            # write their slices of.  f16x3 engine: X never exists — the producers write their columns of the OPERAND Xs the
+            # two heads read (the 1x1 projection also keeps its fp32 map for the correlation lookup), which removes the
+            # read + write of the whole concat by a separate split pass.
+            opcat = ops.PRECISION == "f16x3"
+            dev = fr_in.device
+            if opcat:
+                Xs = ops.Split.empty(B * H * W, 640, dev)
+                Xs.image = (B, H, W)
+                X = None
+            else:
+                X = torch.empty(B, H, W, 640, dtype=torch.float32, device=dev)   # [render | warped real | motion]
             # query maps given once for all hypotheses (hypothesis-major batch): projected once; the lookup and the
             # warp read image b % (B / hyp) of them
-            fq = ops.conv2d(fq_in, pk[f"proj{l}"], pk[f"proj{l}_b"], 1)
+            fq = ops.conv2d(getattr(fq_in, "_hl", fq_in), pk[f"proj{l}"], pk[f"proj{l}_b"], 1)
             e = self.encoder[l]
-            fr = ops.conv2d(fr_in, pk[f"proj{l}"], pk[f"proj{l}_b"], 1, out=X[..., 0:256])   # straight into its slice of X
+            fr_src = getattr(fr_in, "_hl", fr_in)
+            if opcat:
+                fr = ops.conv2d(fr_src, pk[f"proj{l}"], pk[f"proj{l}_b"], 1, hl_into=(Xs, 0),
+                                out=torch.empty(B, H, W, 256, dtype=torch.float32, device=dev))
+            else:
+                fr = ops.conv2d(fr_src, pk[f"proj{l}"], pk[f"proj{l}_b"], 1, out=X[..., 0:256])   # straight into its slice of X
             ncorr = (l + 1) * (2 * self.r + 1) ** 2
             corr = ops.corr_lookup(fr, fq, flow, l + 1, self.r, c_pad=-(-ncorr // 8) * 8)
             # [corr feat 192 | flow feat 64]: on the f16x3 engine the concat exists only as the operand of out_net
-            hl_cat = ops.PRECISION == "f16x3"
+            hl_cat = opcat
             if hl_cat:
-                cf = ops.Split.empty(B * H * W, 256, fr_in.device)
+                cf = ops.Split.empty(B * H * W, 256, dev)
                 cf.image = (B, H, W)
             else:
-                cf = torch.empty(B, H, W, 256, dtype=torch.float32, device=fr_in.device)
+                cf = torch.empty(B, H, W, 256, dtype=torch.float32, device=dev)
             c1 = ops.conv2d(corr, pk[f"e{l}_corr0"], getattr(e.corr_net, "0").conv.bias, 1, act="relu", out_split=True)
             ops.conv2d(c1, pk[f"e{l}_corr1"], getattr(e.corr_net, "1").conv.bias, 3, pad=1, act="relu",
                        **(dict(hl_into=(cf, 0)) if hl_cat else dict(out=cf[..., 0:192])))
-            flow8 = torch.zeros(B, H, W, 8, dtype=torch.float32, device=fr_in.device)
+            flow8 = torch.zeros(B, H, W, 8, dtype=torch.float32, device=dev)
             flow8[..., 0:2] = flow
             f1 = ops.conv2d(flow8, pk[f"e{l}_flow0"], getattr(e.flow_net, "0").conv.bias, 7, pad=3, act="relu", out_split=True)
             ops.conv2d(f1, pk[f"e{l}_flow1"], getattr(e.flow_net, "1").conv.bias, 3, pad=1, act="relu",
                        **(dict(hl_into=(cf, 192)) if hl_cat else dict(out=cf[..., 192:256])))
-            ops.conv2d(cf, pk[f"e{l}_out0"], getattr(e.out_net, "0").conv.bias, 3, pad=1, act="relu", out=X[..., 512:638])
-            X[..., 638:640] = flow                                  # cat([out, flow]) (raft_decoder.py:161)
-            ops.warp(fq, flow, out=X[..., 256:512])                 # feature_sample (flow_decoder.py:49-56)
+            if opcat:
+                # motion = cat([out_net (126), flow (2)]) (raft_decoder.py:161): a 128-channel fp32 map, split into its columns
+                mo = torch.empty(B, H, W, 128, dtype=torch.float32, device=dev)
+                ops.conv2d(cf, pk[f"e{l}_out0"], getattr(e.out_net, "0").conv.bias, 3, pad=1, act="relu", out=mo[..., 0:126])
+                mo[..., 126:128] = flow
+                ops.split_activation(mo, B, H * W, 128, H * W * 128, 128, into=(Xs, 512))
+                ops.warp(fq, flow, hl_into=(Xs, 256))               # feature_sample (flow_decoder.py:49-56)
+            else:
+                ops.conv2d(cf, pk[f"e{l}_out0"], getattr(e.out_net, "0").conv.bias, 3, pad=1, act="relu", out=X[..., 512:638])
+                X[..., 638:640] = flow                                  # cat([out, flow]) (raft_decoder.py:161)
+                ops.warp(fq, flow, out=X[..., 256:512])                 # feature_sample (flow_decoder.py:49-56)
+                Xs = ops.split_image(X)    # both heads read the same operand: split once; hidden maps stay operand-only
             fp, mp = self.flow_pred[l], self.mask_pred[l]
-            Xs = ops.split_image(X)        # both heads read the same operand: split once; hidden maps stay operand-only
             h = ops.conv2d(Xs, pk[f"fp{l}_0"], getattr(fp.layers, "0").conv.bias, 3, pad=1, act="relu", out_split=True)
             h = ops.conv2d(h, pk[f"fp{l}_1"], getattr(fp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True)
             flow = ops.conv2d(h, pk[f"fp{l}_p"], fp.predict_layer.bias, 3, pad=1, residual=flow)      # flow + delta

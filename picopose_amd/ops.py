@@ -84,8 +84,17 @@ def _split_ok(C):
     return PRECISION == "f16x3" and C % 8 == 0
 
 
-def split_activation(x, B, P, C, batch_stride, row_stride, relu=False):
-    """Pre-split an activation operand (B, P, C) into a contiguous hl buffer (B*P, 2C) for the f16x3 engine."""
+def split_activation(x, B, P, C, batch_stride, row_stride, relu=False, into=None):
+    """Pre-split an activation operand (B, P, C) into a contiguous hl buffer (B*P, 2C) for the f16x3 engine.
+    into = (Split over (B*P, Ctot), col0): write columns col0 .. col0 + C of that wider operand instead (col0 % 8 == 0)."""
+    if into is not None:
+        tgt, col0 = into
+        ctot = tgt.shape[1]
+        assert tgt.shape[0] == B * P and col0 % 8 == 0 and col0 + C <= ctot
+        _lib.check(_lib.lib().pp_split_activation_ld(_p(x), batch_stride, B, P, row_stride, C, int(relu),
+                                                     tgt.hl.data_ptr() + 4 * col0, ctot, _lib.stream_ptr()), "pp_split_activation_ld")
+        _chk(tgt.hl[:, 2 * col0:2 * (col0 + C)], "pp_split_activation_ld")
+        return None
     hl = torch.empty(B * P, 2 * C, dtype=torch.float16, device=x.device)
     _lib.check(_lib.lib().pp_split_activation(_p(x), batch_stride, B, P, row_stride, C, int(relu), _p(hl),
                                               _lib.stream_ptr()), "pp_split_activation")
@@ -228,8 +237,9 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     layer's input ReLU folded in) instead of an fp32 tensor.
     also_split ("relu" | "plain"; f16x3 engine): return the fp32 tensor AND attach its operand form as `._hl` /
     `._hl_relu` (a Split) for a following convolution, both written by this epilogue.
-    hl_into = (Split over (B*Ho*Wo, Ctot), col0): write the result ONLY as operand columns col0.. of that shared
-    Split (channel concatenation of operands; Cout % 8 == 0, col0 % 8 == 0) — returns None."""
+    hl_into = (Split over (B*Ho*Wo, Ctot), col0): write the result as operand columns col0.. of that shared Split
+    (channel concatenation of operands; Cout % 8 == 0, col0 % 8 == 0) — and, if `out` is given, as fp32 there too;
+    returns `out` (None without it)."""
     xs = x if isinstance(x, Split) else None
     if xs is not None:
         (B, H, W), Cx = xs.image, xs.shape[1]
@@ -252,16 +262,20 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     sargs, ret = {}, None
     if hl_into is not None:
         tgt, col0 = hl_into
-        assert presplit and out is None and Cout % 8 == 0 and col0 % 8 == 0 and residual is None and residual2 is None
+        assert presplit and Cout % 8 == 0 and col0 % 8 == 0 and residual is None and residual2 is None
         ctot = tgt.shape[1]
         assert tgt.shape[0] == B * Ho * Wo and col0 + Cout <= ctot
+        ldc = Cout
+        if out is not None:
+            ldc = out.stride(2)
+            assert out.stride(3) == 1 and out.stride(1) == Wo * ldc and out.stride(0) == Ho * Wo * ldc
         hl = xs.hl if xs is not None else split_activation(x, B, H * W, cin, x.stride(0), ld_in, relu=relu_in)
-        _run(_desc(A_hl=_p(hl), B=_p(wp), C=None, bias=_p(bias), conv_bstride=H * W * cin, M=B * Ho * Wo, N=Cout,
-                   K=ksize * ksize * cin, lda=cin, ldb=wp.shape[1], ldc=Cout, act=ACT[act], conv_kh=ksize, conv_kw=ksize,
+        _run(_desc(A_hl=_p(hl), B=_p(wp), C=_p(out), bias=_p(bias), conv_bstride=H * W * cin, M=B * Ho * Wo, N=Cout,
+                   K=ksize * ksize * cin, lda=cin, ldb=wp.shape[1], ldc=ldc, act=ACT[act], conv_kh=ksize, conv_kw=ksize,
                    conv_cin=cin, conv_stride=stride, conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo,
                    C_hl=tgt.hl.data_ptr() + 4 * col0, ldc_h=ctot, c_relu=int(split_relu), **wargs),
              written=Split(tgt.hl[:, 2 * col0:2 * (col0 + Cout)]) if CHECK_SATURATION else None)
-        return None
+        return out
     if out_split and out is None and presplit and _split_ok(Cout) and residual is None and residual2 is None:
         ret = Split.empty(B * Ho * Wo, Cout, dev)
         ret.image = (B, Ho, Wo)
@@ -410,13 +424,22 @@ def resize_bilinear(x, Ho, Wo, mul=1.0, out_split=False):
     return out
 
 
-def warp(feat, flow, out=None):
+def warp(feat, flow, out=None, hl_into=None):
     """grid_sample warp of NHWC `feat` by NHWC `flow` (B,H,W,>=2 with x,y first); out may be a channel slice.
-    feat may hold B / k images: image b of the (hypothesis-major) batch then samples feat[b % (B / k)]."""
+    feat may hold B / k images: image b of the (hypothesis-major) batch then samples feat[b % (B / k)].
+    hl_into = (Split over (B*H*W, Ctot), col0): write the result only as operand columns of that Split (f16x3 engine)."""
     B, H, W = flow.shape[:3]
     Bf, Hf, Wf, C = feat.shape
     assert (Hf, Wf) == (H, W) and B % Bf == 0
     assert feat.is_contiguous() and flow.stride(3) == 1 and flow.stride(2) * W == flow.stride(1)
+    if hl_into is not None:
+        tgt, col0 = hl_into
+        ctot = tgt.shape[1]
+        assert tgt.shape[0] == B * H * W and col0 % 8 == 0 and col0 + C <= ctot and C % 8 == 0
+        _lib.check(_lib.lib().pp_warp_nhwc_hl(_p(feat), Bf, _p(flow), B, H, W, C, flow.stride(2), tgt.hl.data_ptr() + 4 * col0,
+                                              ctot, _lib.stream_ptr()), "pp_warp_nhwc_hl")
+        _chk(tgt.hl[:, 2 * col0:2 * (col0 + C)], "pp_warp_nhwc_hl")
+        return None
     if out is None:
         out = torch.empty(B, H, W, C, dtype=torch.float32, device=feat.device)
     _lib.check(_lib.lib().pp_warp_nhwc(_p(feat), Bf, _p(flow), B, H, W, C, flow.stride(2), _p(out), out.stride(2),
