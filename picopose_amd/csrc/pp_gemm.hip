@@ -126,7 +126,8 @@ __device__ __forceinline__ f4 load_a(const PpGemmDesc& d, const float* __restric
 // consumer's input ReLU folded in) so the next GEMM needs no separate split pass.
 __device__ __forceinline__ void epilogue_store(const PpGemmDesc& d, float* C, const float* R, const float* R2, int m, int n,
                                                float v) {
-    size_t off;
+    size_t off, orow = (size_t)m;
+    int ocol = n;
     if (d.shuffle_r == 0) {
         off = (size_t)m * d.ldc + n;
     } else {
@@ -135,7 +136,9 @@ __device__ __forceinline__ void epilogue_store(const PpGemmDesc& d, float* C, co
         const int sub = n / cout, co = n - sub * cout, dy = sub / r, dx = sub - dy * r;
         const int per = d.shuffle_h * d.shuffle_w;
         const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
-        off = (((size_t)b * d.shuffle_h * r + y * r + dy) * (d.shuffle_w * r) + x * r + dx) * d.ldc + co;
+        orow = ((size_t)b * d.shuffle_h * r + y * r + dy) * (d.shuffle_w * r) + x * r + dx;   // output pixel
+        ocol = co;
+        off = orow * d.ldc + co;
     }
     if (R) v += R[off];
     if (R2) v += R2[off];
@@ -143,7 +146,7 @@ __device__ __forceinline__ void epilogue_store(const PpGemmDesc& d, float* C, co
     if (d.C_hl) {
         _Float16 h, l;
         pp_split_f16(d.c_relu ? fmaxf(v, 0.f) : v, h, l);
-        _Float16* hp = (_Float16*)d.C_hl + (size_t)m * 2 * d.ldc_h + pp_hl_col(n, 0);
+        _Float16* hp = (_Float16*)d.C_hl + orow * 2 * d.ldc_h + pp_hl_col(ocol, 0);
         hp[0] = h;
         hp[8] = l;
     }
@@ -163,7 +166,7 @@ __device__ __forceinline__ void epilogue_block(const PpGemmDesc& d, float descal
     const float* R2 = d.residual2;
     // (pixel-shuffle stores stay vectorised when the 8 columns of a lane are 8 channels of one output pixel)
     const bool shuffle_vec = d.shuffle_r == 0 || ((d.N / (d.shuffle_r * d.shuffle_r)) & 7) == 0;
-    if (!shuffle_vec || (d.shuffle_r != 0 && d.C_hl) || (d.N & 7) != 0 || (d.ldc & 3) != 0 || ((uintptr_t)C & 15) != 0 ||
+    if (!shuffle_vec || (d.N & 7) != 0 || (d.ldc & 3) != 0 || ((uintptr_t)C & 15) != 0 ||
         (R && ((uintptr_t)R & 15) != 0) || (R2 && ((uintptr_t)R2 & 15) != 0)) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -206,7 +209,8 @@ __device__ __forceinline__ void epilogue_block(const PpGemmDesc& d, float descal
         v[0] = *(const f4*)(Os + r * OSLD + c8);
         v[1] = *(const f4*)(Os + r * OSLD + c8 + 4);
         if (m >= d.M || !ncol_ok) return;
-        size_t off;
+        size_t off, orow = (size_t)m;     // output row / first column of this lane's 8 values (fp32 and hl alike)
+        int ocol = n;
         if (d.shuffle_r == 0) {
             off = (size_t)m * d.ldc + n;
         } else {  // ConvTranspose2d(kernel = stride = r): columns n .. n + 7 = channels co .. co + 7 of sub-pixel (dy, dx)
@@ -214,7 +218,9 @@ __device__ __forceinline__ void epilogue_block(const PpGemmDesc& d, float descal
             const int sub = n / cout, co = n - sub * cout, dy = sub / rr_, dx = sub - dy * rr_;
             const int per = d.shuffle_h * d.shuffle_w;
             const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
-            off = (((size_t)b * d.shuffle_h * rr_ + y * rr_ + dy) * (d.shuffle_w * rr_) + x * rr_ + dx) * d.ldc + co;
+            orow = ((size_t)b * d.shuffle_h * rr_ + y * rr_ + dy) * (d.shuffle_w * rr_) + x * rr_ + dx;
+            ocol = co;
+            off = orow * d.ldc + co;
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -234,7 +240,7 @@ __device__ __forceinline__ void epilogue_block(const PpGemmDesc& d, float descal
                 hh[c] = a;
                 ll[c] = b;
             }
-            _Float16* hp = (_Float16*)d.C_hl + (size_t)m * 2 * d.ldc_h + 2 * n;
+            _Float16* hp = (_Float16*)d.C_hl + orow * 2 * d.ldc_h + 2 * ocol;
             *(h8*)hp = hh;
             *(h8*)(hp + 8) = ll;
         }
@@ -2148,8 +2154,12 @@ int pp_split_activation(const float* x, long long batch_stride, int B, int P, in
 
 int pp_gemm(const PpGemmDesc* desc, void* stream) {
     if (!desc || (!desc->A && !desc->A_hl) || !desc->B || (!desc->C && !desc->C_hl)) return PP_EINVAL;
-    if (desc->C_hl && (desc->shuffle_r != 0 || desc->ldc_h < desc->N || desc->ldc_h % 8 != 0 || desc->batch0 * desc->batch1 != 1))
-        return PP_EINVAL;
+    {   // operand output: rows of ldc_h elements holding the N columns (pixel-shuffle stores: the N / r^2 channels of a pixel)
+        const int r2 = desc->shuffle_r > 0 ? desc->shuffle_r * desc->shuffle_r : 1;
+        if (desc->C_hl && (desc->ldc_h < desc->N / r2 || desc->ldc_h % 8 != 0 || desc->batch0 * desc->batch1 != 1 ||
+                           (desc->shuffle_r != 0 && (desc->N / r2) % 8 != 0)))
+            return PP_EINVAL;
+    }
     PpGemmDesc d = *desc;
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch0 <= 0 || d.batch1 <= 0) return PP_EINVAL;
     if (d.act < 0 || d.act > PP_ACT_TANH) return PP_EINVAL;

@@ -86,8 +86,9 @@ class DPTHead(Packed):
         """feats: 4 NHWC maps (B,16,16,C) (may be views with a free batch stride) -> [path_4, path_3, path_2] NHWC."""
         pk, r = self.packed(), self.resize_layers
         x = [ops.conv2d(f, pk[f"proj{i}"], self.projects[i].bias, 1) for i, f in enumerate(feats)]
-        l1 = ops.conv_transpose2d(x[0], pk["up0"], pk["up0_b"], 4)
-        l2 = ops.conv_transpose2d(x[1], pk["up1"], pk["up1_b"], 2)
+        # (the up-sampled maps feed only their layerK_rn convolution: operand-only outputs on the f16x3 engine)
+        l1 = ops.conv_transpose2d(x[0], pk["up0"], pk["up0_b"], 4, out_split=True)
+        l2 = ops.conv_transpose2d(x[1], pk["up1"], pk["up1_b"], 2, out_split=True)
         l3 = x[2]
         l4 = ops.conv2d(x[3], pk["down3"], getattr(r, "3").bias, 3, stride=2, pad=1)
         # every layerK_rn output is the input of a ResidualConvUnit (fp32 for its skip, relu'd operand for its conv1)

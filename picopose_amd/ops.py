@@ -313,18 +313,28 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     return ret
 
 
-def conv_transpose2d(x, wp, bias_tiled, r):
-    """ConvTranspose2d(kernel = stride = r, padding 0) on NHWC: (B,H,W,Cin) -> (B,H*r,W*r,Cout)."""
+def conv_transpose2d(x, wp, bias_tiled, r, out_split=False):
+    """ConvTranspose2d(kernel = stride = r, padding 0) on NHWC: (B,H,W,Cin) -> (B,H*r,W*r,Cout).
+    out_split (f16x3 engine): return the result only as a Split with .image (the pixel-shuffle store of the epilogue
+    writes operand groups) for the convolution that follows — the fp32 map is never stored."""
     B, H, W, Cin = x.shape
     assert x.is_contiguous()
     Cout = wp.shape[0] // (r * r)
-    out = torch.empty(B, H * r, W * r, Cout, dtype=torch.float32, device=x.device)
     wargs = _weight_args(wp, Cin)
     if "B_hl" in wargs and _can_presplit(x, Cin, Cin) and x.numel() < 2 ** 31:
         hl = split_activation(x, 1, B * H * W, Cin, 0, Cin)
+        if out_split and _split_ok(Cout):
+            sp = Split.empty(B * H * r * W * r, Cout, x.device)
+            sp.image = (B, H * r, W * r)
+            _run(_desc(A_hl=_p(hl), B=_p(wp), C=None, bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin,
+                       lda=Cin, ldb=Cin, ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W, C_hl=_p(sp.hl), ldc_h=Cout, **wargs),
+                 written=sp)
+            return sp
+        out = torch.empty(B, H * r, W * r, Cout, dtype=torch.float32, device=x.device)
         _run(_desc(A_hl=_p(hl), B=_p(wp), C=_p(out), bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin,
                    lda=Cin, ldb=Cin, ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W, **wargs))
         return out
+    out = torch.empty(B, H * r, W * r, Cout, dtype=torch.float32, device=x.device)
     _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin, lda=Cin, ldb=Cin,
                ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W, **wargs))
     return out

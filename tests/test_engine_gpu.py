@@ -319,3 +319,25 @@ def test_saturation_check_raises_instead_of_returning_clipped_operands():
             ops.linear(torch.full((64, 256), 30.0, device="cuda"), big, out_split=True)   # 256 * 900 = 230400 in the epilogue
     finally:
         ops.CHECK_SATURATION = False
+
+
+@gpu
+@pytest.mark.parametrize("r,cin,cout,hw", [(4, 256, 256, 16), (2, 512, 512, 16), (2, 64, 96, 12)])
+def test_conv_transpose_operand_output_equals_split_of_the_fp32_result(r, cin, cout, hw, engine_precision):
+    """ConvTranspose2d(kernel = stride = r) whose pixel-shuffle epilogue writes the NEXT convolution's operand directly
+    (no fp32 map): bit-identical to splitting the fp32 result, and correct against torch."""
+    if engine_precision != "f16x3":
+        pytest.skip("operand outputs exist in f16x3 mode only")
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(r * 100 + cin)
+    x = torch.randn(3, cin, hw, hw, generator=g)
+    w, b = torch.randn(cin, cout, r, r, generator=g) / cin ** 0.5, torch.randn(cout, generator=g)
+    wp, bp = ops.pack_convT_weight(w.cuda(), b.cuda())
+    xn = ops.to_nhwc(x.cuda())
+    full = ops.conv_transpose2d(xn, wp, bp, r)
+    _close(ops.to_nchw(full), F.conv_transpose2d(x, w, b, stride=r))
+    sp = ops.conv_transpose2d(xn, wp, bp, r, out_split=True)
+    assert isinstance(sp, ops.Split) and sp.image == (3, hw * r, hw * r)
+    want = ops.split_image(full)
+    assert torch.equal(sp.hl, want.hl)
