@@ -1,7 +1,7 @@
 // PnP / RANSAC pose recovery on the GPU — the host step of the reference
 // (utils/pose_recovery.py:68-105: gather 2D/3D coordinates, bring the 3-D points to the object
 // frame, cv2.solvePnPRansac(EPNP, 150 iterations, 2 px), Rodrigues) as ONE batched launch:
-// one 256-thread workgroup per (instance, hypothesis) problem, no per-problem host sync.
+// one 512-thread workgroup per (instance, hypothesis) problem, no per-problem host sync.
 //
 // OpenCV (opencv-python 4.9, requirements.txt:3) is not vendored in the reference and is absent
 // from the build image, so this is a from-scratch restatement of the published algorithm with
@@ -19,10 +19,7 @@
 
 namespace {
 
-#ifndef PP_PNP_NT
-#define PP_PNP_NT 512
-#endif
-constexpr int NT = PP_PNP_NT;     // 8 waves, one workgroup per CU (the correspondences of a problem fill most of the LDS)
+constexpr int NT = 512;           // 8 waves, one workgroup per CU (the correspondences of a problem fill most of the LDS)
 constexpr int NW = NT / 64;
 constexpr int GL = 16;            // lanes of a solver group (12 of them own a column of the 12x12 system)
 constexpr int NG = NT / GL;       // solver groups per workgroup: RANSAC hypotheses are solved NG at a time
