@@ -112,6 +112,7 @@ def lib():
         L.pp_crop_resize_normalize.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, c.POINTER(c.c_double),
                                                c.POINTER(c.c_double), vp, vp, vp]
         L.pp_corr_lookup_nhwc.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
+        L.pp_corr_lookup_nhwc_ex.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
         L.pp_pnp_ransac.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib

@@ -545,9 +545,10 @@ int pp_avgpool2_nhwc(const float* in, int B, int H, int W, int C, float* out, vo
     return pp_last_launch();
 }
 
-int pp_corr_lookup_nhwc(const float* f1, int ld_f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
-                        int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius,
-                        int ld_flow, float* out, int ld_out, void* stream) {
+int pp_corr_lookup_nhwc_ex(const float* f1, int ld_f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
+                           int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius,
+                           int ld_flow, int prec, float* out, int ld_out, void* stream) {
+    if (prec != PP_PREC_F32 && prec != PP_PREC_F16X3) return PP_EINVAL;
     if (!f1 || !f2_l0 || !flow || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return PP_EINVAL;
     if (ld_f1 < C || ld_f1 % 4 != 0 || ((uintptr_t)f1 % 16) != 0 || f2_batch <= 0) return PP_EINVAL;
     if (levels < 1 || levels > MAXL || radius < 1 || radius > MAXR) return PP_EINVAL;
@@ -556,7 +557,7 @@ int pp_corr_lookup_nhwc(const float* f1, int ld_f1, const float* f2_l0, const fl
     const int win = 2 * radius + 1;
     if (ld_out < levels * win * win) return PP_EINVAL;
     const char* te = getenv("PP_CORR_TILED");   // read per call: the tests run both kernels in one process
-    const bool tiled = !(te && te[0] == '0');
+    const bool tiled = prec == PP_PREC_F16X3 && !(te && te[0] == '0');   // PP_PREC_F32: exact fp32 fmas, always
     if (tiled && H % CT == 0 && W % CT == 0 && C % CK == 0 && ((uintptr_t)f2_l0 % 16) == 0) {
         // matrix-core version: one workgroup per 8 x 8 pixel tile (PP_CORR_TILED=0 keeps the lane-per-position kernel)
         const size_t lds = (size_t)(CM * CSP > (CM + CN) * CKP ? CM * CSP : (CM + CN) * CKP) * sizeof(float);
@@ -575,6 +576,13 @@ int pp_corr_lookup_nhwc(const float* f1, int ld_f1, const float* f2_l0, const fl
                        f2_batch, f2_l0, f2_l1, f2_l2, flow, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out,
                        ld_out);
     return pp_last_launch();
+}
+
+int pp_corr_lookup_nhwc(const float* f1, int ld_f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
+                        int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius,
+                        int ld_flow, float* out, int ld_out, void* stream) {
+    return pp_corr_lookup_nhwc_ex(f1, ld_f1, f2_l0, f2_l1, f2_l2, f2_batch, flow, B, H, W, C, levels, radius, ld_flow,
+                                  PP_PREC_F16X3, out, ld_out, stream);
 }
 
 int pp_gather_rows(const float* src, const long long* index, long long n_src_rows, long long row_floats, int n, float* dst,

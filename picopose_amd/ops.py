@@ -480,10 +480,10 @@ def corr_lookup(f1, f2, flow, levels, radius, c_pad=None):
     n = levels * (2 * radius + 1) ** 2
     np_ = c_pad if c_pad and c_pad > n else n
     out = (torch.zeros if np_ > n else torch.empty)(B, H, W, np_, dtype=torch.float32, device=f1.device)
-    _lib.check(_lib.lib().pp_corr_lookup_nhwc(_p(f1), f1.stride(2), _p(pyr[0]), _p(pyr[1]) if levels > 1 else None,
-                                              _p(pyr[2]) if levels > 2 else None, f2.shape[0], _p(flow), B, H, W, C,
-                                              levels, radius, flow.stride(2), _p(out), np_, _lib.stream_ptr()),
-               "pp_corr_lookup_nhwc")
+    _lib.check(_lib.lib().pp_corr_lookup_nhwc_ex(_p(f1), f1.stride(2), _p(pyr[0]), _p(pyr[1]) if levels > 1 else None,
+                                                 _p(pyr[2]) if levels > 2 else None, f2.shape[0], _p(flow), B, H, W, C,
+                                                 levels, radius, flow.stride(2), _PREC[PRECISION], _p(out), np_,
+                                                 _lib.stream_ptr()), "pp_corr_lookup_nhwc_ex")
     return out
 
 
