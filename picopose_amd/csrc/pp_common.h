@@ -11,7 +11,7 @@
 
 // f16x3 activation operand: v -> hi = f16(4 v), lo = f16(4 v - hi) (saturated); the same split in every producer
 #define PP_A_SCALE 4.f
-// (precision study builds only — tools/precision_study.py: -DPP_STUDY_ACT_LO_ZERO drops the lo term of every ACTIVATION
+// (precision study builds only — tests/precision_study.py: -DPP_STUDY_ACT_LO_ZERO drops the lo term of every ACTIVATION
 // operand, -DPP_STUDY_W_LO_ZERO that of every weight: the engine then evaluates the 2-term "weights split only" and the
 // 1-term plain-fp16 products bit for bit, at the 3-term kernels' speed.  Never defined in the product build.)
 __device__ __forceinline__ void pp_split_f16(float v, _Float16& hi, _Float16& lo) {

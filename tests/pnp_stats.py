@@ -2,7 +2,7 @@
 regime (pixel noise x outlier fraction x number of correspondences) -> success rate and rotation / translation error
 quantiles against the planted ground truth for pp_pnp_ransac, and (on a sub-sample) for the CPU oracle oracle/pnp.py.
 
-    python tools/pnp_stats.py [--problems 1000] [--oracle 6] [--out gpurun_out/pnp_stats.json]
+    python tests/pnp_stats.py [--problems 1000] [--oracle 6] [--out gpurun_out/pnp_stats.json]
 """
 import argparse
 import json

@@ -112,8 +112,7 @@ def test_statistical_characterisation_against_ground_truth_and_oracle():
     error quantiles against the planted pose, the CPU oracle on a sub-sample.  Thresholds: the 1000-problem table of
     profiles/r02/pnp_stats.md with a margin, and what RANSAC theory allows — 150 five-point samples contain an
     all-inlier one with probability 1 - (1 - w^5)^150 = 0.786 at inlier fraction w = 0.4 (1.0 at w >= 0.7)."""
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
-    import pnp_stats
+    import pnp_stats          # tests/pnp_stats.py (it runs the CPU oracle beside the kernel: test infrastructure)
 
     table = pnp_stats.run(problems=200, n_oracle=3, log=lambda s: None)
     assert len(table) == 36

@@ -1,4 +1,4 @@
-"""Merge the PRECISION_STUDY lines of tools/precision_study.py runs (one per library build) into a markdown table."""
+"""Merge the PRECISION_STUDY lines of tests/precision_study.py runs (one per library build) into a markdown table."""
 import json
 import sys
 
