@@ -1,5 +1,5 @@
 """Synthetic PnP problems in the layout utils/pose_recovery.py:68-105 consumes (shared by tests/test_pnp_gpu.py and
-tools/pnp_stats.py): a template-camera-frame 3-D map (3,64,64), an original-image 2-D map (2,64,64) and the two
+tests/pnp_stats.py): a template-camera-frame 3-D map (3,64,64), an original-image 2-D map (2,64,64) and the two
 -1-padded (4096,2) int64 [x, y] key-point lists of compute_stage3_correspondences, plus the planted ground truth."""
 import numpy as np
 
