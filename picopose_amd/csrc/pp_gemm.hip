@@ -1951,37 +1951,118 @@ __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict_
 // Row-wise kernels around the GEMMs
 // ---------------------------------------------------------------------------
 
-// nn.LayerNorm(eps) over the last dimension: one wave per row (model/stage1 block.py:56,68)
+// nn.LayerNorm(eps) over the last dimension: one wave per row (model/stage1 block.py:56,68).  A lane owns NG groups of 8
+// consecutive channels (two 16-byte loads; the row is read once and stays in registers), mean and variance are the
+// two-pass forms over the registers, and the f16x3 operand of the following linear layer leaves as one 32-byte
+// [8 hi | 8 lo] group per store.  NG = 0: any C, the row is re-read from cache (not used by the ViT widths).
+template <int NG>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ b, int rows, int C, float eps,
                                                         float* __restrict__ y, _Float16* __restrict__ hl) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (size_t)row * C;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += xr[c];
+    if constexpr (NG > 0) {
+        const int ngrp = C >> 3;
+        f4 v[NG][2];
+        float s = 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s / (float)C;
-    float v = 0.f;
-    for (int c = lane; c < C; c += 64) {
-        const float dlt = xr[c] - mean;
-        v = fmaf(dlt, dlt, v);
-    }
+        for (int j = 0; j < NG; ++j) {
+            const int gi = lane + 64 * j;
+            if (gi < ngrp) {
+                v[j][0] = *(const f4*)(xr + gi * 8);
+                v[j][1] = *(const f4*)(xr + gi * 8 + 4);
+            } else {
+                v[j][0] = f4{0.f, 0.f, 0.f, 0.f};
+                v[j][1] = v[j][0];
+            }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    const float rstd = 1.0f / sqrtf(v / (float)C + eps);
-    for (int c = lane; c < C; c += 64) {
-        const float o = (xr[c] - mean) * rstd * g[c] + b[c];
-        if (y) y[(size_t)row * C + c] = o;
-        if (hl) {  // f16x3 operand of the following linear layer
-            _Float16 h, l;
-            pp_split_f16(o, h, l);
-            _Float16* hp = hl + (size_t)row * 2 * C + pp_hl_col(c, 0);
-            hp[0] = h;
-            hp[8] = l;
+            for (int k = 0; k < 4; ++k) s += v[j][0][k] + v[j][1][k];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            if (lane + 64 * j < ngrp) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dlt = v[j][h][k] - mean;
+                        q = fmaf(dlt, dlt, q);
+                    }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int gi = lane + 64 * j;
+            if (gi >= ngrp) continue;
+            f4 o[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f4 gg = *(const f4*)(g + gi * 8 + 4 * h), bb = *(const f4*)(b + gi * 8 + 4 * h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[h][k] = (v[j][h][k] - mean) * rstd * gg[k] + bb[k];
+            }
+            if (y) {
+                *(f4*)(y + (size_t)row * C + gi * 8) = o[0];
+                *(f4*)(y + (size_t)row * C + gi * 8 + 4) = o[1];
+            }
+            if (hl) {
+                h4 h0, l0, h1, l1;
+                split_f16x4(o[0], A_SCALE, h0, l0);
+                split_f16x4(o[1], A_SCALE, h1, l1);
+                _Float16* hp = hl + (size_t)row * 2 * C + gi * 16;
+                *(h4*)hp = h0;
+                *(h4*)(hp + 4) = h1;
+                *(h4*)(hp + 8) = l0;
+                *(h4*)(hp + 12) = l1;
+            }
+        }
+    } else {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += xr[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)C;
+        float v = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float dlt = xr[c] - mean;
+            v = fmaf(dlt, dlt, v);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const float rstd = 1.0f / sqrtf(v / (float)C + eps);
+        for (int c = lane; c < C; c += 64) {
+            const float o = (xr[c] - mean) * rstd * g[c] + b[c];
+            if (y) y[(size_t)row * C + c] = o;
+            if (hl) {  // f16x3 operand of the following linear layer
+                _Float16 h, l;
+                pp_split_f16(o, h, l);
+                _Float16* hp = hl + (size_t)row * 2 * C + pp_hl_col(c, 0);
+                hp[0] = h;
+                hp[8] = l;
+            }
         }
     }
+}
+
+static void launch_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
+                             _Float16* hl, hipStream_t st) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    const bool vec = C % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
+                     ((uintptr_t)beta % 16 == 0) && (!y || (uintptr_t)y % 16 == 0) && (!hl || (uintptr_t)hl % 16 == 0);
+    if (vec && C <= 512)
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, rows, C, eps, y, hl);
+    else if (vec && C <= 1024)
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, gamma, beta, rows, C, eps, y, hl);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, st, x, gamma, beta, rows, C, eps, y, hl);
 }
 
 // softmax over the last dimension, in place: one wave per row (layers/attention.py:57)
@@ -2364,16 +2445,14 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
 int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
                  void* stream) {
     if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0) return PP_EINVAL;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                       rows, C, eps, y, (_Float16*)nullptr);
+    launch_layernorm(x, gamma, beta, rows, C, eps, y, nullptr, (hipStream_t)stream);
     return pp_last_launch();
 }
 
 int pp_layernorm_split(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
                        void* hl, void* stream) {
     if (!x || !gamma || !beta || !hl || rows <= 0 || C <= 0 || C % 8 != 0) return PP_EINVAL;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                       rows, C, eps, y, (_Float16*)hl);
+    launch_layernorm(x, gamma, beta, rows, C, eps, y, (_Float16*)hl, (hipStream_t)stream);
     return pp_last_launch();
 }
 

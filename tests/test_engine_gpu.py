@@ -213,6 +213,23 @@ def _pinned_big_kernel_cases(monkeypatch, cfg):
 
 
 @gpu
+@pytest.mark.parametrize("rows,C", [(501, 384), (1030, 768), (257, 1024), (7, 40), (66, 100), (9, 2048)])
+def test_layernorm_widths_and_operand_output(rows, C, engine_precision):
+    """Register-resident rows (C a multiple of 8 up to 1024: partial and full lane groups) and the any-width path;
+    the operand written by the kernel equals the split of its own fp32 output."""
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 3 + 1.5
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    y = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6)
+    _close(y, F.layer_norm(x, (C,), w, b, 1e-6), 1e-5)
+    if engine_precision == "f16x3" and C % 8 == 0:
+        sp = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6, out_split=True)
+        assert torch.equal(sp.hl, ops.split_activation(y, 1, rows, C, 0, C))
+
+
+@gpu
 def test_fused_operand_planes_equal_separate_split(engine_precision):
     """layernorm / attention / GEMM epilogues that write the next GEMM's f16x3 operand planes directly give
     bit-identical results to the fp32 tensor + separate split pass."""
