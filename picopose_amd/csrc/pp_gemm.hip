@@ -37,6 +37,22 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
+// One f16x3 term: D = A(32 x 16) * B(16 x 32) + C on the matrix cores.  (-DPP_STUDY_MFMA16: timing-only study build that
+// issues the same flops as two 16x16x32 instructions on quarter accumulators — results are NOT valid.)
+__device__ __forceinline__ f32x16 pp_mfma(const h8 a, const h8 b, f32x16 c) {
+#ifdef PP_STUDY_MFMA16
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x4_ c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[8], c[9], c[10], c[11]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
+    c[8] = c1[0]; c[9] = c1[1]; c[10] = c1[2]; c[11] = c1[3];
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
 constexpr int BM = 128, BK = 32, LDT = 36;  // BN = 64 * NJ (template): 128x128 or 128x64 block tiles
 
 // erf(z) = z P(z^2) / Q(z^2) on |z| <= 3.925 (clamped beyond: erf = +-1 to fp32 precision), a least-squares
@@ -619,9 +635,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const PpGemmDesc d
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = pp_mfma(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = pp_mfma(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = pp_mfma(ah[i], bh[j], acc[i][j]);
                 }
         }
     }
@@ -855,9 +871,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc 
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = pp_mfma(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = pp_mfma(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = pp_mfma(ah[i], bh[j], acc[i][j]);
                 }
         }
     };
@@ -1107,9 +1123,9 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3g_kernel(const PpGemmDesc
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = pp_mfma(f.al[i], f.bh[j], acc[i][j]);
+                acc[i][j] = pp_mfma(f.ah[i], f.bl[j], acc[i][j]);
+                acc[i][j] = pp_mfma(f.ah[i], f.bh[j], acc[i][j]);
             }
     };
     // Ring: tile t lives in stage t % 3.  Iteration t holds tile t (being read), t+1 and t+2 (DMA in flight).
@@ -1124,9 +1140,9 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3g_kernel(const PpGemmDesc
     int cur = 0, nxt = 1;  // ring stage of tile kt / of tile kt + 1
     // one accumulator tile (i, j): the three MFMAs of the f16x3 product
     auto mma1 = [&](const Frag& f, int i, int j) __attribute__((always_inline)) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = pp_mfma(f.al[i], f.bh[j], acc[i][j]);
+        acc[i][j] = pp_mfma(f.ah[i], f.bl[j], acc[i][j]);
+        acc[i][j] = pp_mfma(f.ah[i], f.bh[j], acc[i][j]);
     };
     for (int kt = 0; kt < nk; ++kt) {
         load_frag(f1, cur, 1);
@@ -1177,6 +1193,166 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3g_kernel(const PpGemmDesc
     // epilogue through LDS: the ring is free once every wave is past its last fragment read
     __builtin_amdgcn_s_barrier();
     epilogue_block<2>(d, d.alpha / (A_SCALE * d.b_scale), acc, (float*)glds + w * 32 * 68, m0 + wr * 64, n0 + wc * 64, lane);
+#endif
+}
+
+// Two workgroups per CU ("d", cfg 7): the 256x128 tile of the kernel above with 4 waves (2 x 2, 128x64 each) and K tiles
+// of 16 (one MFMA step; 64-byte row segments) in a ring of 3 x 24 KB, so two workgroups share a CU and the epilogue of
+// one (20-25 % of a K = 768 tile, during which the matrix pipe of a one-workgroup CU idles) runs under the K loop of the
+// other; a wave's 128x64 block also needs 0.5 fragment reads per MFMA instead of 0.67.  Dense A only.  LDS row r holds
+// its four 16-byte chunks at positions c ^ ((r >> 2) & 3) (conflict-free ds_read_b128, applied to the DMA source side).
+// Same K order and accumulation as every other pre-split kernel.
+constexpr int D_KT = 16, D_ROWH = 32;                          // halfs per LDS row: 16 k x (hi, lo) = 64 bytes
+constexpr int D_A_H = GBM * D_ROWH, D_B_H = GBN * D_ROWH;
+constexpr int D_STAGE = D_A_H + D_B_H;                         // 12288 halfs = 24 KB
+constexpr int D_STAGES = 3;
+constexpr int D_LDS_BYTES = D_STAGES * D_STAGE * 2;            // 72 KB: two workgroups in the 160 KB of a CU
+
+__global__ __launch_bounds__(256, 2) void pp_gemm_f16x3d_kernel(const PpGemmDesc d, int gx, int gy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
+    const int nwg = gx * gy, orig = blockIdx.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int m0 = (wg / gx) * GBM, n0 = (wg % gx) * GBN;
+    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
+
+    // DMA slots: instruction q of wave w fills rows (q*4 + w)*16 + (lane >> 2) (A: q = 0..3, B: q = 0, 1); LDS chunk
+    // position lane & 3 holds source chunk sc = term (sc & 1) of the 8 k starting at 8 (sc >> 1)
+    const int lr = lane >> 2;
+    const int sc = (lane & 3) ^ ((lr >> 2) & 3);
+    int kcur = (sc >> 1) * 8;
+    unsigned aoff[4], boff[2];  // byte offsets of this lane's chunks (0xFFFFFFFF: row past M / N -> zeros)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + (j * 4 + w) * 16 + lr;
+        aoff[j] = m < d.M ? (unsigned)((long long)m * d.lda * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nb = n0 + (j * 4 + w) * 16 + lr;
+        boff[j] = nb < d.N ? (unsigned)((long long)nb * d.ldb * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
+    }
+    auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
+        const unsigned off = aoff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * D_STAGE + ((j * 4 + w) * 16) * D_ROWH), 16, off, 0, 0, 0);
+    };
+    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
+        const unsigned off = boff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * D_STAGE + D_A_H + ((j * 4 + w) * 16) * D_ROWH), 16, off, 0, 0, 0);
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aoff[j] = aoff[j] == 0xFFFFFFFFu ? aoff[j] : aoff[j] + 4 * D_KT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) boff[j] = boff[j] == 0xFFFFFFFFu ? boff[j] : boff[j] + 4 * D_KT;
+        kcur += D_KT;
+    };
+    auto fetch = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_a(stage, j);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma_b(stage, j);
+        advance();
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int sw = (l31 >> 2) & 3;
+    const int ch = ((lh * 2) ^ sw) * 8, cl = ((lh * 2 + 1) ^ sw) * 8;   // hi / lo chunk of this lane's 8 k
+    const int arow = (wr * 128 + l31) * D_ROWH, brow = D_A_H + (wc * 64 + l31) * D_ROWH;
+    struct Frag {
+        h8 ah[4], al[4], bh[2], bl[2];
+    };
+    auto mma1 = [&](const Frag& f, int i, int j) __attribute__((always_inline)) {
+        acc[i][j] = pp_mfma(f.al[i], f.bh[j], acc[i][j]);
+        acc[i][j] = pp_mfma(f.ah[i], f.bl[j], acc[i][j]);
+        acc[i][j] = pp_mfma(f.ah[i], f.bh[j], acc[i][j]);
+    };
+    const int nk = (d.K + D_KT - 1) / D_KT;
+    fetch(0);
+    fetch(1);
+    fetch(2);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frag fa, fb;
+    {
+        const _Float16* st = glds;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa.ah[i] = *(const h8*)(st + arow + i * 32 * D_ROWH + ch);
+            fa.al[i] = *(const h8*)(st + arow + i * 32 * D_ROWH + cl);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fa.bh[j] = *(const h8*)(st + brow + j * 32 * D_ROWH + ch);
+            fa.bl[j] = *(const h8*)(st + brow + j * 32 * D_ROWH + cl);
+        }
+    }
+    int cur = 0, nxt = 1;
+    // One K tile: first half of the MFMAs of tile kt (fragments F, complete), then the barrier that publishes tile kt + 1
+    // and frees tile kt's stage, then the 6 DMA pieces of tile kt + 3 and the 12 fragment reads of tile kt + 1 (into G)
+    // spread over the second half of the MFMAs.
+#define PP_D_TILE(F, G)                                                                      \
+    {                                                                                        \
+        mma1(F, 0, 0);                                                                       \
+        mma1(F, 0, 1);                                                                       \
+        mma1(F, 1, 0);                                                                       \
+        mma1(F, 1, 1);                                                                       \
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                          \
+        __builtin_amdgcn_s_barrier();                                                        \
+        const _Float16* st = glds + nxt * D_STAGE;                                           \
+        dma_a(cur, 0);                                                                       \
+        G.ah[0] = *(const h8*)(st + arow + ch);                                              \
+        G.al[0] = *(const h8*)(st + arow + cl);                                              \
+        mma1(F, 2, 0);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        dma_a(cur, 1);                                                                       \
+        G.bh[0] = *(const h8*)(st + brow + ch);                                              \
+        G.bl[0] = *(const h8*)(st + brow + cl);                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        dma_a(cur, 2);                                                                       \
+        G.ah[1] = *(const h8*)(st + arow + 32 * D_ROWH + ch);                                \
+        G.al[1] = *(const h8*)(st + arow + 32 * D_ROWH + cl);                                \
+        mma1(F, 2, 1);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        dma_a(cur, 3);                                                                       \
+        G.bh[1] = *(const h8*)(st + brow + 32 * D_ROWH + ch);                                \
+        G.bl[1] = *(const h8*)(st + brow + 32 * D_ROWH + cl);                                \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        dma_b(cur, 0);                                                                       \
+        G.ah[2] = *(const h8*)(st + arow + 64 * D_ROWH + ch);                                \
+        G.al[2] = *(const h8*)(st + arow + 64 * D_ROWH + cl);                                \
+        mma1(F, 3, 0);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        dma_b(cur, 1);                                                                       \
+        advance();                                                                           \
+        G.ah[3] = *(const h8*)(st + arow + 96 * D_ROWH + ch);                                \
+        G.al[3] = *(const h8*)(st + arow + 96 * D_ROWH + cl);                                \
+        mma1(F, 3, 1);                                                                       \
+        cur = nxt;                                                                           \
+        nxt = nxt == D_STAGES - 1 ? 0 : nxt + 1;                                             \
+    }
+    for (int kt = 0; kt < nk; kt += 2) {
+        PP_D_TILE(fa, fb)
+        if (kt + 1 < nk) PP_D_TILE(fb, fa)
+    }
+#undef PP_D_TILE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS at exit
+    __builtin_amdgcn_s_barrier();
+    const float descale = d.alpha / (A_SCALE * d.b_scale);
+    float* Os = (float*)glds + w * 32 * 68;
+    epilogue_block<2>(d, descale, reinterpret_cast<f32x16(&)[2][2]>(acc[0]), Os, m0 + wr * 128, n0 + wc * 64, lane);
+    epilogue_block<2>(d, descale, reinterpret_cast<f32x16(&)[2][2]>(acc[2]), Os, m0 + wr * 128 + 64, n0 + wc * 64, lane);
 #endif
 }
 
@@ -1347,9 +1523,9 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3p_kernel(const PpGemmDesc
         }
     };
     auto mma1 = [&](const Frag& f, int i, int j) __attribute__((always_inline)) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = pp_mfma(f.al[i], f.bh[j], acc[i][j]);
+        acc[i][j] = pp_mfma(f.ah[i], f.bl[j], acc[i][j]);
+        acc[i][j] = pp_mfma(f.ah[i], f.bh[j], acc[i][j]);
     };
     auto mma = [&](const Frag& f) __attribute__((always_inline)) {
 #pragma unroll
@@ -1561,9 +1737,9 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3q_kernel(const PpGemmDesc
         f.l[1] = *(const h8*)(st + 32 * G_ROWH + cl);
     };
     auto mma1 = [&](const AF& a, const AF& b, int ip, int i, int j) __attribute__((always_inline)) {
-        acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l[i], b.h[j], acc[2 * ip + i][j], 0, 0, 0);
-        acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[i], b.l[j], acc[2 * ip + i][j], 0, 0, 0);
-        acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[i], b.h[j], acc[2 * ip + i][j], 0, 0, 0);
+        acc[2 * ip + i][j] = pp_mfma(a.l[i], b.h[j], acc[2 * ip + i][j]);
+        acc[2 * ip + i][j] = pp_mfma(a.h[i], b.l[j], acc[2 * ip + i][j]);
+        acc[2 * ip + i][j] = pp_mfma(a.h[i], b.h[j], acc[2 * ip + i][j]);
     };
     auto mma_unit = [&](const AF& a, const AF& b, int ip) __attribute__((always_inline)) {
 #pragma unroll
@@ -1809,9 +1985,9 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3h_kernel(const PpGemmDesc
         f.l[1] = *(const h8*)(st + 32 * G_ROWH + cl);
     };
     auto mma1 = [&](const AF& a, const AF& b, int ip, int i, int j) __attribute__((always_inline)) {
-        acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l[i], b.h[j], acc[2 * ip + i][j], 0, 0, 0);
-        acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[i], b.l[j], acc[2 * ip + i][j], 0, 0, 0);
-        acc[2 * ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[i], b.h[j], acc[2 * ip + i][j], 0, 0, 0);
+        acc[2 * ip + i][j] = pp_mfma(a.l[i], b.h[j], acc[2 * ip + i][j]);
+        acc[2 * ip + i][j] = pp_mfma(a.h[i], b.l[j], acc[2 * ip + i][j]);
+        acc[2 * ip + i][j] = pp_mfma(a.h[i], b.h[j], acc[2 * ip + i][j]);
     };
     auto mma_unit = [&](const AF& a, const AF& b, int ip) __attribute__((always_inline)) {
 #pragma unroll
@@ -2302,7 +2478,8 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                hipFuncSetAttribute((const void*)pp_gemm_f16x3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES) == hipSuccess)
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS_BYTES) == hipSuccess)
                      ? 1 : -1;
     }
     if (big_ok < 0) return PP_ELAUNCH;
@@ -2310,10 +2487,13 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     const bool h_shape = asplit && d.conv_kh == 3 && d.conv_kw == 3 && d.conv_stride == 1 && d.conv_pad == 1 && d.conv_cin % BK == 0 &&
                          d.conv_ho == d.conv_h && d.conv_wo == d.conv_w && d.conv_w >= 16 && d.conv_w <= QBM && (d.conv_w & (d.conv_w - 1)) == 0 &&
                          d.lda == d.conv_cin && d.K == 9 * d.conv_cin && d.conv_bstride == (long long)d.conv_h * d.conv_w * d.lda;
-    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA, 4: persistent LDS-DMA, 5: persistent LDS-DMA with 256x256 tiles, 6: 5 with row-shared A delivery (3x3 convolutions)
+    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA, 4: persistent LDS-DMA, 5: persistent LDS-DMA with 256x256 tiles, 6: 5 with row-shared A delivery (3x3 convolutions), 7: 256x128 LDS-DMA @2 workgroups/CU (dense)
         const bool narrow = cfg == 2;
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
-        if (asplit && cfg == 6) {
+        if (asplit && cfg == 7) {  // two workgroups per CU, dense A
+            const int gx = (d.N + GBN - 1) / GBN, gy = (d.M + GBM - 1) / GBM;
+            hipLaunchKernelGGL(pp_gemm_f16x3d_kernel, dim3(gx * gy), dim3(256), D_LDS_BYTES, st, d, gx, gy);
+        } else if (asplit && cfg == 6) {
             const int gx = (d.N + QBN - 1) / QBN, gy = (d.M + QBM - 1) / QBM;
             const int nt = gx * gy, g = nt < cus ? (nt + 7) / 8 * 8 : cus / 8 * 8;
             hipLaunchKernelGGL(pp_gemm_f16x3h_kernel, dim3(g), dim3(512), H_LDS_BYTES, st, d, gx, gy);
@@ -2366,6 +2546,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     if (const char* f = getenv("PP_GEMM_FORCE_CFG")) {  // tests: pin one kernel configuration (3 needs pre-split operands)
         const int fc = atoi(f);
         const bool p_ok = asplit && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
+        if (fc == 7 && asplit) {   // two workgroups per CU (dense A), else the plain LDS-DMA kernel
+            launch(d.conv_kh == 0 && d.K >= 3 * D_KT ? 7 : 3);
+            return pp_last_launch();
+        }
         if (fc == 6 && asplit) {   // the row-shared kernel where the shape allows it, else the 256x256 / 256x128 persistent ones
             launch(h_shape && d.N > 128 ? 6 : (p_ok ? (d.N > 128 ? 5 : 4) : 3));
             return pp_last_launch();
@@ -2395,9 +2579,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             const bool big = asplit && (long long)((d.M + GBM - 1) / GBM) * ((d.N + GBN - 1) / GBN) >= cus / 2;
             const bool p_ok = big && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
             const bool q_ok = p_ok && d.N > 128 && (long long)((d.M + QBM - 1) / QBM) * ((d.N + QBN - 1) / QBN) >= cus / 2;
-            for (int c = 0; c < (asplit ? 6 : (vec ? 3 : 2)); ++c) {
+            for (int c = 0; c < (asplit ? 7 : (vec ? 3 : 2)); ++c) {
                 const int cand = asplit ? (c == 0 ? 0 : c == 1 ? 2 : c + 1) : (vec ? c : (c == 0 ? 0 : 2));
-                if ((cand == 3 && !big) || (cand == 4 && !p_ok) || (cand == 5 && !q_ok) || (cand == 6 && !(q_ok && h_shape))) continue;
+                if ((cand == 3 && !big) || (cand == 4 && !p_ok) || (cand == 5 && !q_ok) || (cand == 6 && !(q_ok && h_shape)) ||
+                    (cand == 7 && !(big && d.conv_kh == 0 && d.K >= 3 * D_KT))) continue;
                 launch(cand);  // warm
                 float ms = 1e30f;
                 // best of three bursts of four back-to-back launches: single synchronised launches run on a GPU that idles

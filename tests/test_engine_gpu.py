@@ -274,13 +274,16 @@ def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, 
     x, w, b = torch.randn(700, 768, generator=g).cuda(), (torch.randn(384, 768, generator=g) / 27).cuda(), torch.randn(384, generator=g).cuda()
     xi = torch.randn(2, 24, 24, 64, generator=g).cuda()
     wc = ops.pack_conv_weight((torch.randn(256, 64, 3, 3, generator=g) / 24).cuda())
+    x2, w2 = torch.randn(1300, 392, generator=g).cuda(), (torch.randn(200, 392, generator=g) / 20).cuda()   # K % 16 == 8, row / column tails
     outs = []
-    for cfg in ("0", "2", "3", "4", "5", "6"):
+    for cfg in ("0", "2", "3", "4", "5", "6", "7"):
         monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
-        outs.append((ops.linear(x, w, b, act="gelu"), ops.conv2d(xi, wc, None, 3, pad=1, act="relu")))
-    for lin, conv in outs[1:]:
+        outs.append((ops.linear(x, w, b, act="gelu"), ops.conv2d(xi, wc, None, 3, pad=1, act="relu"), ops.linear(x2, w2, None, residual=None)))
+    for lin, conv, lin2 in outs[1:]:
         assert torch.equal(lin, outs[0][0])
         assert torch.equal(conv, outs[0][1])
+        assert torch.equal(lin2, outs[0][2])
+    assert torch.allclose(outs[0][2].cpu(), x2.cpu() @ w2.cpu().t(), atol=2e-5, rtol=1e-5)
 
 
 @gpu
