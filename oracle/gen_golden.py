@@ -528,9 +528,75 @@ def gen_run_test():
     print(f"run_test fixture written: {len(rows)} rows")
 
 
+def gen_train_forward():
+    """The REFERENCE training forward itself: `Net.forward_train` (model/picopose.py:114-137) in train mode — key-point
+    sampler, both ViT passes, InfoNCE / stage-2 / flow + certainty losses, BatchNorm on batch statistics with running-buffer
+    updates — and `Loss.forward` (utils/loss_utils.py:10-21), on tests/netcfg.make_train_end_points (ViT-S, B=2, calibrated
+    seeded weights).  The noisy affines `aug_gtM_noise` drew are recorded (product and oracle take them as an input) together
+    with the numpy / torch seeds that reproduce them."""
+    _ref()
+    sys.path.insert(0, os.path.join(REF, "model"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import ref_shims
+
+    ref_shims.install()
+    import picopose as ref_picopose
+    from utils.loss_utils import Loss
+
+    from oracle.weights import AFFINE_CALIBRATION, HEAD_CALIBRATION, PROJ_BN_GAIN, apply_head_calibration, seeded_state_dict
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from netcfg import make_train_end_points
+
+    vit, B, seed, wseed = "dinov2_vits14", 2, 51, 4
+    net = ref_picopose.Net(_cfg(vit)).train()
+    cal = dict(HEAD_CALIBRATION[vit], affine=AFFINE_CALIBRATION, proj_bn=PROJ_BN_GAIN)
+    net.load_state_dict(apply_head_calibration(seeded_state_dict(net.state_dict(), wseed), cal))
+    ep = make_train_end_points(B, seed)
+    drawn = {}
+    orig = ref_picopose.aug_gtM_noise
+
+    def recording(end_points):
+        drawn["pred_Ms"] = orig(end_points)
+        return drawn["pred_Ms"]
+
+    ref_picopose.aug_gtM_noise = recording
+    np.random.seed(1000 + seed)
+    torch.manual_seed(2000 + seed)
+    with torch.no_grad():
+        kp = net.compute_keypoint_data({k: v.clone() for k, v in ep.items()})
+        res = net({k: v.clone() for k, v in ep.items()})
+        tot = Loss()(res)
+    ref_picopose.aug_gtM_noise = orig
+    out = {"meta": np.array([B, seed, wseed, 1000 + seed, 2000 + seed], dtype=np.int64), "vit": np.array(vit)}
+    for k, v in _cal_arrays(cal).items():
+        out[k] = v
+    out["real_pose"], out["tem_pose"] = ep["real_pose"].numpy(), ep["tem_pose"].numpy()
+    out["pred_Ms"] = drawn["pred_Ms"].numpy()
+    for k in ("src_pts", "tar_pts"):     # patch coordinates = integer pixels / 3.5 (or -1): stored as the integer pixels
+        px = torch.where(kp[k] == -1, kp[k], (kp[k] * 3.5).round())
+        assert px.abs().max() < 32000
+        assert torch.equal(torch.where(px == -1, px, px / 3.5), kp[k])
+        out[f"kp_{k}_px"] = px.numpy().astype(np.int16)
+    for k, v in res.items():
+        if "loss" in k:
+            out[k] = v.numpy()
+            print(k, float(v))
+    out["total_loss"] = tot["loss"].numpy()
+    print("total", float(tot["loss"]), "valid key-points", (kp["src_pts"][..., 0] != -1).sum(1).tolist())
+    sd = net.state_dict()
+    for name in ("offset_regressor.dpt_head.scratch.refinenet4.resConfUnit2.bn1", "offset_regressor.dpt_head.scratch.refinenet2.resConfUnit1.bn2",
+                 "offset_regressor.flow_decoder.proj.0.1", "offset_regressor.flow_decoder.proj.2.1"):
+        for buf in ("running_mean", "running_var", "num_batches_tracked"):
+            out[f"bn/{name}.{buf}"] = sd[f"{name}.{buf}"].numpy()
+    np.savez_compressed(os.path.join(OUT, "train_forward.npz"), **out)
+    print("training-forward fixture written")
+
+
 GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry, "nets": gen_nets, "e2e": gen_e2e,
               "e2e_calibrated": gen_e2e_calibrated, "vit_wide": gen_vit_wide, "state_dict": gen_state_dict,
-              "preprocess": gen_preprocess, "run_test": gen_run_test}
+              "preprocess": gen_preprocess, "run_test": gen_run_test, "train_forward": gen_train_forward}
+
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -84,24 +84,29 @@ def affine_regressor(sd, x, prefix="affine_regressor."):
 
 
 # ------------------------------------------------------------------------------------------ stage 3
-def _bn(sd, p, x):
+def _bn(sd, p, x, train=False):
+    """nn.BatchNorm2d(eps=1e-5, momentum=0.1).  train: normalise with the statistics of this batch and update the running
+    buffers of `sd` in place (unbiased variance, num_batches_tracked + 1), as the module does in training mode."""
+    if train:
+        sd[p + "num_batches_tracked"] += 1
+        return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], True, 0.1, 1e-5)
     return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, 0.0, 1e-5)
 
 
-def _rcu(sd, p, x):
-    h = _bn(sd, p + "bn1.", F.conv2d(F.relu(x), sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1))
-    h = _bn(sd, p + "bn2.", F.conv2d(F.relu(h), sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1))
+def _rcu(sd, p, x, train=False):
+    h = _bn(sd, p + "bn1.", F.conv2d(F.relu(x), sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1), train)
+    h = _bn(sd, p + "bn2.", F.conv2d(F.relu(h), sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1), train)
     return h + x
 
 
-def _fusion(sd, p, size, x0, x1=None):
-    out = x0 if x1 is None else x0 + _rcu(sd, p + "resConfUnit1.", x1)
-    out = _rcu(sd, p + "resConfUnit2.", out)
+def _fusion(sd, p, size, x0, x1=None, train=False):
+    out = x0 if x1 is None else x0 + _rcu(sd, p + "resConfUnit1.", x1, train)
+    out = _rcu(sd, p + "resConfUnit2.", out, train)
     out = F.interpolate(out, size=size, mode="bilinear", align_corners=True)
     return F.conv2d(out, sd[p + "out_conv.weight"], sd[p + "out_conv.bias"])
 
 
-def dpt_head(sd, feats, prefix="offset_regressor.dpt_head."):
+def dpt_head(sd, feats, prefix="offset_regressor.dpt_head.", train=False):
     p = prefix
     x = [F.conv2d(f, sd[f"{p}projects.{i}.weight"], sd[f"{p}projects.{i}.bias"]) for i, f in enumerate(feats)]
     l1 = F.conv_transpose2d(x[0], sd[p + "resize_layers.0.weight"], sd[p + "resize_layers.0.bias"], stride=4)
@@ -109,9 +114,9 @@ def dpt_head(sd, feats, prefix="offset_regressor.dpt_head."):
     l3 = x[2]
     l4 = F.conv2d(x[3], sd[p + "resize_layers.3.weight"], sd[p + "resize_layers.3.bias"], stride=2, padding=1)
     rn = [F.conv2d(l, sd[f"{p}scratch.layer{i + 1}_rn.weight"], None, padding=1) for i, l in enumerate((l1, l2, l3, l4))]
-    p4 = _fusion(sd, p + "scratch.refinenet4.", rn[2].shape[2:], rn[3])
-    p3 = _fusion(sd, p + "scratch.refinenet3.", rn[1].shape[2:], p4, rn[2])
-    p2 = _fusion(sd, p + "scratch.refinenet2.", rn[0].shape[2:], p3, rn[1])
+    p4 = _fusion(sd, p + "scratch.refinenet4.", rn[2].shape[2:], rn[3], train=train)
+    p3 = _fusion(sd, p + "scratch.refinenet3.", rn[1].shape[2:], p4, rn[2], train)
+    p2 = _fusion(sd, p + "scratch.refinenet2.", rn[0].shape[2:], p3, rn[1], train)
     return [p4, p3, p2]
 
 
@@ -150,13 +155,13 @@ def _cm(sd, p, x, pad):
 
 
 def flow_decoder(sd, feat_render_list, feat_real_list, init_flow, init_cert, num_levels=3, radius=4,
-                 prefix="offset_regressor.flow_decoder."):
+                 prefix="offset_regressor.flow_decoder.", train=False):
     r = int(radius / 2)
     flow, cert = init_flow, init_cert
     flows, certs = [], []
     for l in range(num_levels):
         p = f"{prefix}proj.{l}."
-        proj = lambda t: _bn(sd, p + "1.", F.conv2d(t, sd[p + "0.weight"], sd[p + "0.bias"]))  # noqa: E731
+        proj = lambda t: _bn(sd, p + "1.", F.conv2d(t, sd[p + "0.weight"], sd[p + "0.bias"]), train)  # noqa: E731
         fr, fq = proj(feat_render_list[l]), proj(feat_real_list[l])
         B, _, H, W = fr.shape
         corr = corr_lookup(fr, fq, flow, l + 1, r)

@@ -70,3 +70,68 @@ def make_end_points(B, N, seed, feature_fn=None, tem_pose=None, dome=False):
     if feature_fn is not None:
         ep["template_feature"] = torch.stack([feature_fn(ep["tem_rgb"][b])[-1] for b in range(B)])
     return ep
+
+
+def plane_depth(K, pose, height=480, width=640):
+    """Depth image (height, width) of the object plane z_obj = 0 seen by a camera with intrinsics K and object->camera pose
+    `pose` (4,4): z = n.t / n.(K^-1 [u, v, 1]) with n = R e_z.  Evaluated in float64, returned as float32."""
+    import torch
+
+    K, pose = K.double(), pose.double()
+    v, u = torch.meshgrid(torch.arange(height, dtype=torch.float64), torch.arange(width, dtype=torch.float64), indexing="ij")
+    d = torch.stack([(u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1], torch.ones_like(u)], dim=-1)
+    n, t = pose[:3, 2], pose[:3, 3]
+    return ((n @ t) / (d @ n)).float()
+
+
+def euler_pose(ax, ay, az, t):
+    """Object->camera pose from rotations about x, y, z (radians; R = Rz Ry Rx) and translation t, built in float64."""
+    import math
+
+    import torch
+
+    cx, sx, cy, sy, cz, sz = math.cos(ax), math.sin(ax), math.cos(ay), math.sin(ay), math.cos(az), math.sin(az)
+    Rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=torch.float64)
+    Ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=torch.float64)
+    Rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=torch.float64)
+    P = torch.eye(4, dtype=torch.float64)
+    P[:3, :3] = Rz @ Ry @ Rx
+    P[:3, 3] = torch.tensor(t, dtype=torch.float64)
+    return P.float()
+
+
+def make_train_end_points(B, seed, poses=None):
+    """Synthetic TRAINING batch (provider/training_dataset.py:152-167 layout): one template per real crop, both views of
+    the same planar object, so the key-point sampler finds correspondences.  N(0,1) crops, full-size depth images of the
+    plane, disk masks (the real one with a rectangular bite), BOP intrinsics, crops centred on the projected object centre
+    (template scale 1.5, real scale 2).  poses = (real_pose, tem_pose) (B,4,4) each overrides the seeded ones (fixtures
+    carry the poses they were generated with)."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(224.0), torch.arange(224.0), indexing="ij")
+    disk = (((yy - 111.5) ** 2 + (xx - 111.5) ** 2) < (0.4 * 224) ** 2).float()
+    K = torch.tensor([[572.4114, 0, 320], [0, 573.57043, 240], [0, 0, 1.0]])
+    ep = {"real_rgb": torch.randn(B, 3, 224, 224, generator=g), "tem_rgb": torch.randn(B, 3, 224, 224, generator=g)}
+    ang = (torch.rand(B, 6, generator=g) - 0.5).tolist()
+    if poses is None:
+        real = torch.stack([euler_pose(0.6 * a[0], 0.6 * a[1], 1.2 * a[2], (0.05, -0.03, 0.7)) for a in ang])
+        tem = torch.stack([euler_pose(0.6 * a[3], 0.6 * a[4], 1.2 * a[5], (0.0, 0.0, 0.8)) for a in ang])
+    else:
+        real, tem = poses
+    ep["real_pose"], ep["tem_pose"] = real, tem
+    ep["real_K"] = ep["tem_K"] = K[None].repeat(B, 1, 1)
+    for name, pose, s in (("real", real, 2.0), ("tem", tem, 1.5)):
+        c = (K @ pose[:, :3, 3:4])[:, :, 0]
+        c = c[:, :2] / c[:, 2:]                                     # projected object centre (image pixels)
+        M = torch.zeros(B, 3, 3)
+        M[:, 0, 0] = M[:, 1, 1] = s
+        M[:, 2, 2] = 1
+        M[:, :2, 2] = -s * (c - 112.0 / s).round()                   # integer crop corner, as a bounding box would give
+        ep[f"{name}_M"] = M
+        ep[f"{name}_full_depth"] = torch.stack([plane_depth(K, pose[b]) for b in range(B)])
+    ep["tem_mask"] = disk[None].repeat(B, 1, 1)
+    bite = disk.clone()
+    bite[150:, 130:] = 0
+    ep["real_mask"] = bite[None].repeat(B, 1, 1)
+    return ep
