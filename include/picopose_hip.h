@@ -325,6 +325,44 @@ int pp_pnp_ransac(const float* tar_pts_2d, const float* src_pts_3d, const float*
                   float reproj_threshold, double* rot, double* tvec, double* inlier_ratio, int32_t* success,
                   int32_t* num_points, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Training forward (model/picopose.py:114-137 — losses only, no gradients; csrc/pp_train.hip)
+ * ------------------------------------------------------------------------- */
+/* KeyPointSampler.sample_pts (utils/keypoints.py:120-205, Keypoint :47-92, torch_utils.py unproject_points :138-151,
+ * project_points :154-161) for B (template = "src", real = "tar") pairs: crop masks (B, mask_h, mask_w), full depth images
+ * (B, depth_h, depth_w), crop affines M and their inverses (torch_utils.inverse_affine :93-111), intrinsics K and their
+ * inverses, the rigid motions between the two cameras (B,4,4), all fp32 row-major.  The small matrix inverses are the
+ * caller's (the reference's torch.inverse); every per-point step is evaluated here as the reference evaluates it,
+ * including the comparison of re-projections in CROP pixels with grid points in IMAGE pixels against 1000 px.
+ * out: src_pts, tar_pts (B, 4096, 2) fp32 patch coordinates (integer pixel / 3.5), -1 where invalid. */
+size_t pp_train_keypoints_workspace_bytes(int B);
+int pp_train_keypoints(const float* src_mask, const float* tar_mask, int mask_h, int mask_w, const float* src_depth,
+                       const float* tar_depth, int depth_h, int depth_w, const float* src_Minv, const float* tar_Minv,
+                       const float* src_M, const float* tar_M, const float* src_Kinv, const float* tar_Kinv, const float* src_K,
+                       const float* tar_K, const float* T_src2tar, const float* T_tar2src, int B, float* src_pts, float* tar_pts,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* nn.BatchNorm2d in TRAINING mode (model/stage3/dpt.py:64-66,84-90, flow_decoder.py:22) on an NHWC map viewed as
+ * (rows, C), C % 4 == 0: y = relu?((x - mean_batch) / sqrt(var_batch + eps) * gamma + beta) + residual + residual2
+ * (residuals may be NULL); running_mean / running_var (may both be NULL) get the momentum update with the unbiased
+ * variance, as the module does.  Statistics are summed in fp64. */
+size_t pp_batchnorm_train_workspace_bytes(int rows, int C);
+int pp_batchnorm_train(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float momentum,
+                       float* running_mean, float* running_var, int relu, const float* residual, const float* residual2, float* y,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* compute_stage_one_loss (utils/loss_utils.py:144-175): out[i] = F.normalize(src[index[i] * row_stride ...][:C]) — the
+ * gather of torch_utils.gather (:257-284) on a token-major feature map and the normalisation of :169-170 in one pass */
+int pp_gather_normalize_rows(const float* src, long long row_stride, const int64_t* index, int n, int C, float eps, float* out,
+                             void* stream);
+/* ... and F.cross_entropy(scale * logits, arange(n)) per row (:171-174): row_loss[i] = logsumexp_j - the diagonal entry */
+int pp_xent_diag_rows(const float* logits, int n, int ld, float scale, float* row_loss, void* stream);
+/* compute_stage_three_loss for one level (utils/loss_utils.py:188-202 with compute_flow_loss :119-125, RAFTLoss :24-39):
+ * flow (B,H,W,2), certainty logits (B,H,W) NHWC, tar_pts (B,4096,2) from pp_train_keypoints.  Writes
+ * pp_flow_loss_blocks() x 3 doubles: per workgroup [sum of BCE-with-logits terms, sum over valid pixels with
+ * |gt flow| < max_flow of |flow - gt|_1, number of those pixels]; the caller adds the rows and forms the two means. */
+int pp_flow_loss_blocks(void);
+int pp_flow_loss_sums(const float* flow, const float* certainty, const float* tar_pts, int B, int H, int W, float max_flow,
+                      double* partial_sums, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

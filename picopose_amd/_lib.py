@@ -114,6 +114,16 @@ def lib():
         L.pp_corr_lookup_nhwc.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
         L.pp_corr_lookup_nhwc_ex.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
         L.pp_pnp_ransac.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]
+        L.pp_train_keypoints_workspace_bytes.restype = sz
+        L.pp_train_keypoints_workspace_bytes.argtypes = [i32]
+        L.pp_train_keypoints.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32] + [vp] * 10 + [i32, vp, vp, vp, sz, vp]
+        L.pp_batchnorm_train_workspace_bytes.restype = sz
+        L.pp_batchnorm_train_workspace_bytes.argtypes = [i32, i32]
+        L.pp_batchnorm_train.argtypes = [vp, vp, vp, i32, i32, f32, f32, vp, vp, i32, vp, vp, vp, vp, sz, vp]
+        L.pp_gather_normalize_rows.argtypes = [vp, c.c_longlong, vp, i32, i32, f32, vp, vp]
+        L.pp_xent_diag_rows.argtypes = [vp, i32, i32, f32, vp, vp]
+        L.pp_flow_loss_blocks.argtypes = []
+        L.pp_flow_loss_sums.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, vp]
         _lib = L
     return _lib
 

@@ -73,16 +73,17 @@ class Packed(nn.Module):
     def __init__(self):
         super().__init__()
         self._pack_cache = None
+        self._pack_train_cache = None   # training forward: convolutions whose BatchNorm is NOT folded (it runs on batch statistics)
 
     def _apply(self, fn, *a, **k):
-        self._pack_cache = None
+        self._pack_cache = self._pack_train_cache = None
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
         # nn.Module.load_state_dict recurses through `_load_from_state_dict` of EVERY module of the tree — this hook
         # fires when a checkpoint is loaded through any ancestor (Net.load_state_dict, Lite.load_from_checkpoint),
         # whereas an override of load_state_dict only sees loads that start at this very module
-        self._pack_cache = None
+        self._pack_cache = self._pack_train_cache = None
         return super()._load_from_state_dict(*a, **k)
 
     def packed(self):
@@ -90,3 +91,12 @@ class Packed(nn.Module):
             with torch.no_grad():
                 self._pack_cache = self._pack()
         return self._pack_cache
+
+    def packed_train(self):
+        """Weights of the layers that differ in training mode (the module's `_pack_train`).  A training step moves the
+        BatchNorm running buffers, so the eval packing (which folds them) is dropped here and rebuilt on the next eval call."""
+        self._pack_cache = None
+        if self._pack_train_cache is None:
+            with torch.no_grad():
+                self._pack_train_cache = self._pack_train()
+        return self._pack_train_cache

@@ -64,6 +64,25 @@ class DPTHead(Packed):
                     pk[f"f{i}_u{j}_c{c}"], pk[f"f{i}_u{j}_b{c}"] = ops.pack_conv_weight(w), b.contiguous()
         return pk
 
+    def _pack_train(self):
+        pk = {}
+        for i in (2, 3, 4):
+            f = getattr(self.scratch, f"refinenet{i}")
+            for j in (1, 2):
+                u = getattr(f, f"resConfUnit{j}")
+                for c in (1, 2):
+                    pk[f"f{i}_u{j}_c{c}"] = ops.pack_conv_weight(getattr(u, f"conv{c}").weight.float())
+        return pk
+
+    def _rcu_train(self, i, j, x, extra=None):
+        """ResidualConvUnit in training mode (dpt.py:72-95): both BatchNorms normalise with the statistics of this batch and
+        update their running buffers (ops.batchnorm_train); forward values only."""
+        u, pkt = getattr(getattr(self.scratch, f"refinenet{i}"), f"resConfUnit{j}"), self.packed_train()
+        h = ops.conv2d(x, pkt[f"f{i}_u{j}_c1"], u.conv1.bias, 3, pad=1, relu_in=True)
+        h = ops.batchnorm_train(h, u.bn1, relu=True)                        # relu(bn1(.)): the input of conv2
+        h = ops.conv2d(h, pkt[f"f{i}_u{j}_c2"], u.conv2.bias, 3, pad=1)
+        return ops.batchnorm_train(h, u.bn2, residual=x, residual2=extra)   # bn2(.) + x (+ the fusion block's other input)
+
     def _rcu(self, pk, key, x, extra=None, more=False):
         """ResidualConvUnit (dpt.py:72-95): bn2(conv2(relu(bn1(conv1(relu(x)))))) + x (+ extra)."""
         # conv1 hands relu(h) to conv2 as operand planes (out_split + split_relu): h itself is never stored.  The
@@ -74,16 +93,23 @@ class DPTHead(Packed):
         return ops.conv2d(h, pk[key + "_c2"], pk[key + "_b2"], 3, pad=1, relu_in=not isinstance(h, ops.Split), residual=x,
                           residual2=extra, also_split="relu" if more else None)
 
-    def _fuse(self, pk, i, size, x0, x1=None):
+    def _fuse(self, pk, i, size, x0, x1=None, train=False):
         """FeatureFusionBlock (dpt.py:129-156)."""
-        out = x0 if x1 is None else self._rcu(pk, f"f{i}_u1", x1, extra=x0, more=True)   # feeds resConfUnit2
-        out = self._rcu(pk, f"f{i}_u2", out)
+        if train:
+            out = x0 if x1 is None else self._rcu_train(i, 1, x1, extra=x0)
+            out = self._rcu_train(i, 2, out)
+        else:
+            out = x0 if x1 is None else self._rcu(pk, f"f{i}_u1", x1, extra=x0, more=True)   # feeds resConfUnit2
+            out = self._rcu(pk, f"f{i}_u2", out)
         out = ops.resize_bilinear(out, size[0], size[1], out_split=True)   # feeds only the 1x1 out_conv
         # the path map is an output (fp32) AND the input of the flow decoder's 1x1 projection: its operand form rides along
         return ops.conv2d(out, pk[f"f{i}_out"], getattr(self.scratch, f"refinenet{i}").out_conv.bias, 1, also_split="plain")
 
-    def forward_nhwc(self, feats):
-        """feats: 4 NHWC maps (B,16,16,C) (may be views with a free batch stride) -> [path_4, path_3, path_2] NHWC."""
+    def forward_nhwc(self, feats, train=False):
+        """feats: 4 NHWC maps (B,16,16,C) (may be views with a free batch stride) -> [path_4, path_3, path_2] NHWC.
+        train: the ResidualConvUnits' BatchNorms run in training mode (one statistics update per call)."""
+        if train:
+            self.packed_train()          # (drops the eval packing, whose folded BatchNorms this call makes stale)
         pk, r = self.packed(), self.resize_layers
         x = [ops.conv2d(f, pk[f"proj{i}"], self.projects[i].bias, 1) for i, f in enumerate(feats)]
         # (the up-sampled maps feed only their layerK_rn convolution: operand-only outputs on the f16x3 engine)
@@ -93,9 +119,11 @@ class DPTHead(Packed):
         l4 = ops.conv2d(x[3], pk["down3"], getattr(r, "3").bias, 3, stride=2, pad=1)
         # every layerK_rn output is the input of a ResidualConvUnit (fp32 for its skip, relu'd operand for its conv1)
         rn = [ops.conv2d(l, pk[f"rn{i + 1}"], None, 3, pad=1, also_split="relu") for i, l in enumerate((l1, l2, l3, l4))]
-        p4 = self._fuse(pk, 4, rn[2].shape[1:3], rn[3])
-        p3 = self._fuse(pk, 3, rn[1].shape[1:3], p4, rn[2])
-        p2 = self._fuse(pk, 2, rn[0].shape[1:3], p3, rn[1])
+        p4 = self._fuse(pk, 4, rn[2].shape[1:3], rn[3], train=train)
+        p3 = self._fuse(pk, 3, rn[1].shape[1:3], p4, rn[2], train)
+        p2 = self._fuse(pk, 2, rn[0].shape[1:3], p3, rn[1], train)
+        if train:
+            self._pack_cache = None      # the running buffers moved: eval re-folds them
         return [p4, p3, p2]
 
     def forward(self, out_features):
@@ -155,8 +183,13 @@ class FlowDecoder(Packed):
                 pk[f"{name}{l}_p"] = ops.pack_conv_weight(head.predict_layer.weight.float())
         return pk
 
-    def forward_nhwc(self, feat_render_list, feat_real_list, flow, cert):
-        """NHWC everywhere: lists of (B,H,W,256); flow (B,16,16,2), cert (B,16,16,1) -> lists of per-level flow/cert."""
+    def _pack_train(self):
+        return {f"proj{l}": ops.pack_conv_weight(getattr(self.proj[l], "0").weight.float()) for l in range(self.num_levels)}
+
+    def forward_nhwc(self, feat_render_list, feat_real_list, flow, cert, train=False):
+        """NHWC everywhere: lists of (B,H,W,256); flow (B,16,16,2), cert (B,16,16,1) -> lists of per-level flow/cert.
+        train: the projections' BatchNorms run in training mode (render maps first, then real maps, as flow_decoder.py:78)."""
+        pkt = self.packed_train() if train else None
         pk = self.packed()
         flows, certs = [], []
         for l in range(self.num_levels):
@@ -176,14 +209,23 @@ class FlowDecoder(Packed):
                 X = torch.empty(B, H, W, 640, dtype=torch.float32, device=dev)   # [render | warped real | motion]
             # query maps given once for all hypotheses (hypothesis-major batch): projected once; the lookup and the
             # warp read image b % (B / hyp) of them
-            fq = ops.conv2d(getattr(fq_in, "_hl", fq_in), pk[f"proj{l}"], pk[f"proj{l}_b"], 1)
             e = self.encoder[l]
             fr_src = getattr(fr_in, "_hl", fr_in)
-            if opcat:
-                fr = ops.conv2d(fr_src, pk[f"proj{l}"], pk[f"proj{l}_b"], 1, hl_into=(Xs, 0),
-                                out=torch.empty(B, H, W, 256, dtype=torch.float32, device=dev))
+            if train:   # conv -> BatchNorm on batch statistics, render maps first (flow_decoder.py:78)
+                pj = self.proj[l]
+                fr = ops.batchnorm_train(ops.conv2d(fr_src, pkt[f"proj{l}"], getattr(pj, "0").bias, 1), getattr(pj, "1"))
+                fq = ops.batchnorm_train(ops.conv2d(getattr(fq_in, "_hl", fq_in), pkt[f"proj{l}"], getattr(pj, "0").bias, 1), getattr(pj, "1"))
+                if opcat:
+                    ops.split_activation(fr, B, H * W, 256, H * W * 256, 256, into=(Xs, 0))
+                else:
+                    X[..., 0:256] = fr
             else:
-                fr = ops.conv2d(fr_src, pk[f"proj{l}"], pk[f"proj{l}_b"], 1, out=X[..., 0:256])   # straight into its slice of X
+                fq = ops.conv2d(getattr(fq_in, "_hl", fq_in), pk[f"proj{l}"], pk[f"proj{l}_b"], 1)
+                if opcat:
+                    fr = ops.conv2d(fr_src, pk[f"proj{l}"], pk[f"proj{l}_b"], 1, hl_into=(Xs, 0),
+                                    out=torch.empty(B, H, W, 256, dtype=torch.float32, device=dev))
+                else:
+                    fr = ops.conv2d(fr_src, pk[f"proj{l}"], pk[f"proj{l}_b"], 1, out=X[..., 0:256])   # straight into its slice of X
             ncorr = (l + 1) * (2 * self.r + 1) ** 2
             corr = ops.corr_lookup(fr, fq, flow, l + 1, self.r, c_pad=-(-ncorr // 8) * 8)
             # [corr feat 192 | flow feat 64]: on the f16x3 engine the concat exists only as the operand of out_net
@@ -225,6 +267,8 @@ class FlowDecoder(Packed):
             if l != self.num_levels - 1:
                 flow = ops.resize_bilinear(flow, 2 * H, 2 * W, mul=2.0)
                 cert = ops.resize_bilinear(cert, 2 * H, 2 * W)
+        if train:
+            self._pack_cache = None      # the running buffers moved: eval re-folds them
         return flows, certs
 
     def forward(self, feat_render_list, feat_real_list, init_flow, init_certainty, iters=1):
@@ -243,9 +287,11 @@ class OffsetRegressor(nn.Module):
                                 out_channels=[256, 512, 1024, 1024], use_clstoken=False)  # offset_regressor.py:13
         self.flow_decoder = FlowDecoder(cfg.num_levels, cfg.radius)
 
-    def forward_nhwc(self, feats_tem, feats_real, init_flow, init_cert):
-        return self.flow_decoder.forward_nhwc(self.dpt_head.forward_nhwc(feats_tem), self.dpt_head.forward_nhwc(feats_real),
-                                              init_flow, init_cert)
+    def forward_nhwc(self, feats_tem, feats_real, init_flow, init_cert, train=False):
+        # (template maps first, then real maps: offset_regressor.py:17 — the order of the BatchNorm updates in training)
+        tem = self.dpt_head.forward_nhwc(feats_tem, train)
+        real = self.dpt_head.forward_nhwc(feats_real, train)
+        return self.flow_decoder.forward_nhwc(tem, real, init_flow, init_cert, train)
 
     def forward(self, features_tem, features_real, init_flow, init_certainty):
         """Drop-in for offset_regressor.py:16-19."""

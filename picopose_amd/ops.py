@@ -396,6 +396,27 @@ def groupnorm(x, weight, bias, groups, eps=1e-5, relu=False):
     return y
 
 
+def batchnorm_train(x, bn, relu=False, residual=None, residual2=None, eps=1e-5, momentum=0.1):
+    """nn.BatchNorm2d in TRAINING mode on an NHWC map (training forward only): normalises with the statistics of this batch
+    and updates bn.running_mean / running_var / num_batches_tracked in place, as the module does.  `bn`: a parameter holder
+    with weight, bias and the three buffers (model/common.bn_p).  y = relu?(bn(x)) + residual + residual2."""
+    assert x.is_contiguous() and x.dtype == torch.float32
+    C = x.shape[-1]
+    rows = x.numel() // C
+    L = _lib.lib()
+    nbytes = L.pp_batchnorm_train_workspace_bytes(rows, C)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    y = torch.empty_like(x)
+    for r in (residual, residual2):
+        assert r is None or (r.is_contiguous() and r.shape == x.shape)
+    _lib.check(L.pp_batchnorm_train(_p(x), _p(bn.weight), _p(bn.bias), rows, C, float(eps), float(momentum), _p(bn.running_mean),
+                                    _p(bn.running_var), int(relu), _p(residual) if residual is not None else None,
+                                    _p(residual2) if residual2 is not None else None, _p(y), _p(ws), nbytes, _lib.stream_ptr()),
+               "pp_batchnorm_train")
+    bn.num_batches_tracked += 1
+    return y
+
+
 def to_nhwc(x, c_pad=None):
     """(B,C,H,W) -> (B,H,W,C); with c_pad > C the result has c_pad channels, the extra ones zero."""
     B, C, H, W = x.shape

@@ -4,7 +4,8 @@ Same constructor (`Net(cfg)` with cfg.stage1/2/3), same sub-module names (identi
 `Lite.load_from_checkpoint(..., network=model)` loads the authors' checkpoint), same eval call
 `model(end_points, hyp)` -> list of `hyp` dicts (model/picopose.py:97-112, 72-95), and
 `model.feature_extractor(x)` usable on its own (run_test.py:130).  All arithmetic runs in
-libpicopose_hip.so; the training branch is not part of this path."""
+libpicopose_hip.so.  In training mode `model(end_points)` is the reference's forward_train (:114-137): it returns
+`end_points` with the ten `loss*` entries — forward values only, there are no backward kernels."""
 import torch
 import torch.nn as nn
 
@@ -12,7 +13,10 @@ from . import ops
 from .model.stage1 import FeatureExtractor
 from .model.stage2 import AffineRegressor
 from .model.stage3 import OffsetRegressor
+from .utils.augment import aug_gtM_noise
 from .utils.correspondence import compute_init_correspondences, compute_stage3_correspondences
+from .utils.keypoints import KeypointInput, KeyPointSampler
+from .utils.loss_utils import compute_stage_two_loss, flow_level_losses, infonce_rows
 from .utils.matching import matching_features_similarity, matching_templates
 from .utils.pose_recovery import pose_recovery_2d_prediction
 from .utils.torch_utils import calc_pred_Ms
@@ -22,6 +26,7 @@ class Net(nn.Module):
     def __init__(self, cfg):
         super().__init__()
         self.cfg = cfg
+        self.keypoint_sampler = KeyPointSampler()
         self.feature_extractor = FeatureExtractor(cfg.stage1)
         self.affine_regressor = AffineRegressor(cfg.stage2)
         self.offset_regressor = OffsetRegressor(cfg.stage3)
@@ -154,8 +159,44 @@ class Net(nn.Module):
                 end_points["real_mask"], topk=hyp, mode=self.match_mode)
             return self.forward_hypotheses(end_points, pred_id_src, real)
 
+    # model/picopose.py:29-50
+    def compute_keypoint_data(self, end_points):
+        rel_pose = end_points["tem_pose"] @ torch.inverse(end_points["real_pose"])
+        tar = KeypointInput(full_depth=end_points["real_full_depth"], K=end_points["real_K"], M=end_points["real_M"], mask=end_points["real_mask"])
+        src = KeypointInput(full_depth=end_points["tem_full_depth"], K=end_points["tem_K"], M=end_points["tem_M"], mask=end_points["tem_mask"])
+        return self.keypoint_sampler.sample_pts(tar_data=tar, src_data=src, T_src2target=torch.inverse(rel_pose), T_tar2source=rel_pose)
+
+    # model/picopose.py:114-137
+    def forward_train(self, end_points, pred_Ms=None):
+        """The training forward: key-point ground truth, both ViT passes, the InfoNCE / stage-2 / flow + certainty losses,
+        BatchNorm layers on batch statistics (running buffers updated).  Returns `end_points` with the `loss*` entries the
+        reference adds (utils/loss_utils.Loss sums them).  FORWARD VALUES ONLY: the HIP engine has no backward kernels, the
+        returned losses carry no autograd graph (`loss.backward()` raises).  pred_Ms: the noisy ground-truth affines of
+        stage 3; drawn by utils/augment.aug_gtM_noise when not given (tests pass the ones a reference run drew)."""
+        with torch.no_grad():
+            kp = self.compute_keypoint_data(end_points)
+            fe, orr = self.feature_extractor, self.offset_regressor
+            real_tok, (h0, w0) = fe.forward_tokens(end_points["real_rgb"])
+            tem_tok, _ = fe.forward_tokens(end_points["tem_rgb"])
+            end_points["loss_info"] = infonce_rows(tem_tok[-1], real_tok[-1], kp["src_pts"], kp["tar_pts"])
+            sim = matching_features_similarity(ops.tokens_to_nchw(tem_tok[-1], 1, h0, w0), ops.tokens_to_nchw(real_tok[-1], 1, h0, w0),
+                                               end_points["tem_mask"], end_points["real_mask"])
+            pred_translation, pred_scale, pred_inplane = self.affine_regressor(sim)
+            end_points["loss_2d_trans"], end_points["loss_scale"], end_points["loss_inplane"] = compute_stage_two_loss(
+                end_points, pred_translation, pred_scale, pred_inplane)
+            if pred_Ms is None:
+                pred_Ms = aug_gtM_noise(end_points)
+            init_flow, init_certainty = compute_init_correspondences(pred_Ms, end_points["tem_mask"])
+            as_img = lambda t: t[:, 1:].unflatten(1, (h0, w0))  # noqa: E731
+            flows, certs = orr.forward_nhwc([as_img(t) for t in tem_tok], [as_img(t) for t in real_tok], ops.to_nhwc(init_flow),
+                                            ops.to_nhwc(init_certainty), train=True)
+            for idx, (fl, ce) in enumerate(zip(flows, certs)):
+                end_points[f"loss_flow{idx}"], end_points[f"loss_certainty{idx}"] = flow_level_losses(fl, ce, kp["tar_pts"])
+            if self.keep_stage3:
+                self.last_stage3 = (flows[-1], certs[-1])
+        return end_points
+
     def forward(self, end_points, hyp=5):
         if self.training:
-            raise NotImplementedError("picopose_amd implements the inference path (model/picopose.py:97-112); "
-                                      "forward_train (:114-137) is out of scope (SURVEY.md §8f)")
+            return self.forward_train(end_points)
         return self.forward_test(end_points, hyp)

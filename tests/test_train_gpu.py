@@ -1,0 +1,144 @@
+"""GPU: the training forward (Net.forward in train mode = model/picopose.py:114-137, forward values) against the REFERENCE's
+own run (tests/golden/train_forward.npz) and, piece by piece, against the fixture-pinned oracle (oracle/train.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from netcfg import make_train_end_points, small_cfg  # noqa: E402
+from test_train_oracle import LOSS_KEYS, load_train_fixture, patch_coords  # noqa: E402
+
+gpu = pytest.mark.gpu
+
+
+def _cuda(ep):
+    return {k: v.cuda() for k, v in ep.items()}
+
+
+@gpu
+def test_keypoint_sampler_matches_the_reference(golden_dir):
+    """Integer pixel coordinates of every key-point.  The per-point arithmetic is fp32 in both, but a GEMM's summation
+    order is the library's: a projection that lands within an ulp of an integer may truncate to the neighbouring pixel.
+    Stated tolerance: <= 0.1 % of the entries differ, each by one pixel or by validity."""
+    from picopose_amd.picopose import Net
+
+    z, ep, _, _ = load_train_fixture(golden_dir)
+    kp = Net(small_cfg()).compute_keypoint_data(_cuda(ep))
+    for k in ("src_pts", "tar_pts"):
+        got, ref = kp[k].cpu(), patch_coords(z[f"kp_{k}_px"])
+        assert got.shape == ref.shape == (ep["real_rgb"].shape[0], 4096, 2)
+        differ = (got != ref).any(dim=-1)
+        print(k, "entries differing from the reference:", int(differ.sum()), "of", differ.numel())
+        assert differ.float().mean() <= 1e-3, (k, int(differ.sum()))
+        d = (got[differ] - ref[differ]).abs() * 3.5
+        assert all(bool((row <= 1.01).all()) or bool((a == -1).all()) or bool((b == -1).all())
+                   for row, a, b in zip(d, got[differ], ref[differ]))
+    assert int((kp["src_pts"][..., 0] != -1).sum()) > 1000
+
+
+@gpu
+def test_keypoint_sampler_agrees_with_the_oracle_on_other_geometry():
+    from oracle import train as ot
+    from picopose_amd.picopose import Net
+
+    ep = make_train_end_points(3, 77)
+    ep["real_mask"][1] = 0                       # a pair without any correspondence
+    ref = ot.keypoint_data({k: v.clone() for k, v in ep.items()})
+    got = Net(small_cfg()).compute_keypoint_data(_cuda(ep))
+    for k in ("src_pts", "tar_pts"):
+        differ = (got[k].cpu() != ref[k]).any(dim=-1)
+        assert differ.float().mean() <= 1e-3, (k, int(differ.sum()))
+        assert bool((got[k][1] == -1).all())
+
+
+@gpu
+@pytest.mark.parametrize("rows,C,relu", [(2 * 16 * 16, 256, True), (3 * 64 * 64, 256, False), (77, 64, True)])
+def test_batchnorm_training_mode(rows, C, relu):
+    from picopose_amd import ops
+    from picopose_amd.model.common import bn_p
+
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, C, generator=g) * 3 + 5            # a mean well away from zero: E[x^2] - E[x]^2 in fp32 would lose digits
+    r1, r2 = torch.randn(rows, C, generator=g), torch.randn(rows, C, generator=g)
+    bn = bn_p(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+        bn.running_mean.copy_(torch.randn(C, generator=g))
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    ref = F.batch_norm(x.t()[None], rm, rv, bn.weight, bn.bias, True, 0.1, 1e-5)[0].t()
+    ref = (F.relu(ref) if relu else ref) + r1 + r2
+    bn = bn.cuda()
+    with torch.no_grad():
+        got = ops.batchnorm_train(x.cuda().reshape(1, 1, rows, C), bn, relu=relu, residual=r1.cuda().reshape(1, 1, rows, C),
+                                  residual2=r2.cuda().reshape(1, 1, rows, C)).reshape(rows, C).cpu()
+    assert (got - ref).abs().max() <= 2e-5 * ref.abs().max()
+    assert (bn.running_mean.cpu() - rm).abs().max() <= 1e-6 * rm.abs().max()
+    assert (bn.running_var.cpu() - rv).abs().max() <= 1e-5 * rv.abs().max()
+    assert int(bn.num_batches_tracked) == 1
+
+
+@gpu
+def test_loss_kernels_agree_with_the_oracle():
+    from oracle import train as ot
+    from picopose_amd.utils.loss_utils import compute_stage_one_loss, compute_stage_three_loss, compute_stage_two_loss
+
+    g = torch.Generator().manual_seed(3)
+    ep = make_train_end_points(2, 9)
+    kp = ot.keypoint_data({k: v.clone() for k, v in ep.items()})
+    fs, ft = torch.randn(2, 96, 16, 16, generator=g), torch.randn(2, 96, 16, 16, generator=g)
+    ref = ot.stage_one_loss(fs, ft, kp["src_pts"], kp["tar_pts"])
+    got = compute_stage_one_loss(fs.cuda(), ft.cuda(), kp["src_pts"].cuda(), kp["tar_pts"].cuda())
+    assert abs(float(got) - float(ref)) <= 1e-5 * float(ref)
+    flows = [torch.randn(2, 2, s, s, generator=g) * 5 for s in (16, 32, 64)]
+    certs = [torch.randn(2, 1, s, s, generator=g) * 3 for s in (16, 32, 64)]
+    ref3 = ot.stage_three_loss(flows, certs, kp["tar_pts"])
+    out = compute_stage_three_loss({}, [f.cuda() for f in flows], [c.cuda() for c in certs], kp["tar_pts"].cuda())
+    for i, (lf, lc) in enumerate(ref3):
+        assert abs(float(out[f"loss_flow{i}"]) - float(lf)) <= 1e-5 * float(lf)
+        assert abs(float(out[f"loss_certainty{i}"]) - float(lc)) <= 1e-5 * float(lc)
+    t, s, ip = torch.randn(2, 2, generator=g), torch.rand(2, generator=g) + 0.5, F.normalize(torch.randn(2, 2, generator=g), dim=1)
+    ref2 = ot.stage_two_loss(ep, t, s, ip)
+    got2 = compute_stage_two_loss(_cuda(ep), t.cuda(), s.cuda(), ip.cuda())
+    for a, b in zip(got2, ref2):
+        assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(b)))
+
+
+@gpu
+@pytest.mark.parametrize("engine_precision", ["f16x3", "f32"])
+def test_training_forward_matches_the_reference_run(golden_dir, engine_precision, monkeypatch):
+    """Net(train mode)(end_points) vs the reference's forward_train + Loss on the same batch, weights and noisy affines:
+    every loss within 1e-3 relative (fp32 networks on another summation order; the flow losses sum |flow - gt| over ~2k
+    pixels), the BatchNorm running buffers within 1e-4, the eval packing rebuilt afterwards."""
+    from picopose_amd import ops
+    from picopose_amd.picopose import Net
+    from picopose_amd.utils.loss_utils import Loss
+
+    monkeypatch.setattr(ops, "PRECISION", engine_precision)
+    z, ep, weights, _ = load_train_fixture(golden_dir)
+    net = Net(small_cfg())
+    net.load_state_dict(weights(net.state_dict()))
+    net = net.cuda().train()
+    res = net.forward_train(_cuda(ep), pred_Ms=torch.from_numpy(z["pred_Ms"]).cuda())
+    for k in LOSS_KEYS:
+        assert abs(float(res[k]) - float(z[k])) <= 1e-3 * max(1.0, abs(float(z[k]))), (k, float(res[k]), float(z[k]))
+    tot = Loss()(res)
+    assert abs(float(tot["loss"]) - float(z["total_loss"])) <= 1e-3 * float(z["total_loss"])
+    assert not res["loss_info"].requires_grad                 # forward values only
+    sd = net.state_dict()
+    for key in z.files:
+        if key.startswith("bn/"):
+            got, ref = sd[key[3:]].cpu().numpy(), z[key]
+            assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), key
+    # the eval packing folds the running buffers this step moved: it must have been dropped
+    assert net.offset_regressor.dpt_head._pack_cache is None and net.offset_regressor.flow_decoder._pack_cache is None
+    # `model(end_points)` dispatches on self.training, drawing its own noisy affines
+    np.random.seed(0)
+    torch.manual_seed(0)
+    again = net(_cuda(ep))
+    assert all(torch.isfinite(again[k]) for k in LOSS_KEYS)
