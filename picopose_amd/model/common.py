@@ -74,6 +74,7 @@ class Packed(nn.Module):
         super().__init__()
         self._pack_cache = None
         self._pack_train_cache = None   # training forward: convolutions whose BatchNorm is NOT folded (it runs on batch statistics)
+        self._bn_stale = False          # a training step moved the running buffers the eval packing has folded
 
     def _apply(self, fn, *a, **k):
         self._pack_cache = self._pack_train_cache = None
@@ -86,17 +87,22 @@ class Packed(nn.Module):
         self._pack_cache = self._pack_train_cache = None
         return super()._load_from_state_dict(*a, **k)
 
-    def packed(self):
-        if self._pack_cache is None:
+    def packed(self, for_training=False):
+        """The eval packing.  for_training: the caller reads only entries that do not fold a BatchNorm, so a packing whose
+        folds a training step has made stale is still good (and is not rebuilt every step)."""
+        if self._pack_cache is None or (self._bn_stale and not for_training):
             with torch.no_grad():
                 self._pack_cache = self._pack()
+            self._bn_stale = False
         return self._pack_cache
 
     def packed_train(self):
         """Weights of the layers that differ in training mode (the module's `_pack_train`).  A training step moves the
-        BatchNorm running buffers, so the eval packing (which folds them) is dropped here and rebuilt on the next eval call."""
-        self._pack_cache = None
+        BatchNorm running buffers: the eval packing, which folds them, is marked stale and re-folded by the next eval call."""
         if self._pack_train_cache is None:
             with torch.no_grad():
                 self._pack_train_cache = self._pack_train()
         return self._pack_train_cache
+
+    def bn_moved(self):
+        self._bn_stale = True

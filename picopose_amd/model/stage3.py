@@ -108,9 +108,7 @@ class DPTHead(Packed):
     def forward_nhwc(self, feats, train=False):
         """feats: 4 NHWC maps (B,16,16,C) (may be views with a free batch stride) -> [path_4, path_3, path_2] NHWC.
         train: the ResidualConvUnits' BatchNorms run in training mode (one statistics update per call)."""
-        if train:
-            self.packed_train()          # (drops the eval packing, whose folded BatchNorms this call makes stale)
-        pk, r = self.packed(), self.resize_layers
+        pk, r = self.packed(for_training=train), self.resize_layers
         x = [ops.conv2d(f, pk[f"proj{i}"], self.projects[i].bias, 1) for i, f in enumerate(feats)]
         # (the up-sampled maps feed only their layerK_rn convolution: operand-only outputs on the f16x3 engine)
         l1 = ops.conv_transpose2d(x[0], pk["up0"], pk["up0_b"], 4, out_split=True)
@@ -123,7 +121,7 @@ class DPTHead(Packed):
         p3 = self._fuse(pk, 3, rn[1].shape[1:3], p4, rn[2], train)
         p2 = self._fuse(pk, 2, rn[0].shape[1:3], p3, rn[1], train)
         if train:
-            self._pack_cache = None      # the running buffers moved: eval re-folds them
+            self.bn_moved()              # eval re-folds the running buffers on its next call
         return [p4, p3, p2]
 
     def forward(self, out_features):
@@ -190,7 +188,7 @@ class FlowDecoder(Packed):
         """NHWC everywhere: lists of (B,H,W,256); flow (B,16,16,2), cert (B,16,16,1) -> lists of per-level flow/cert.
         train: the projections' BatchNorms run in training mode (render maps first, then real maps, as flow_decoder.py:78)."""
         pkt = self.packed_train() if train else None
-        pk = self.packed()
+        pk = self.packed(for_training=train)
         flows, certs = [], []
         for l in range(self.num_levels):
             fr_in, fq_in = feat_render_list[l], feat_real_list[l]
@@ -268,7 +266,7 @@ class FlowDecoder(Packed):
                 flow = ops.resize_bilinear(flow, 2 * H, 2 * W, mul=2.0)
                 cert = ops.resize_bilinear(cert, 2 * H, 2 * W)
         if train:
-            self._pack_cache = None      # the running buffers moved: eval re-folds them
+            self.bn_moved()              # eval re-folds the running buffers on its next call
         return flows, certs
 
     def forward(self, feat_render_list, feat_real_list, init_flow, init_certainty, iters=1):

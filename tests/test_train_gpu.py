@@ -135,8 +135,18 @@ def test_training_forward_matches_the_reference_run(golden_dir, engine_precision
         if key.startswith("bn/"):
             got, ref = sd[key[3:]].cpu().numpy(), z[key]
             assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), key
-    # the eval packing folds the running buffers this step moved: it must have been dropped
-    assert net.offset_regressor.dpt_head._pack_cache is None and net.offset_regressor.flow_decoder._pack_cache is None
+    # the eval packing folds the running buffers this step moved: the next eval call must re-fold them — the trained-on
+    # module and a fresh one loaded with its state_dict give the same DPT maps
+    feats = [torch.randn(2, 16, 16, 384, generator=torch.Generator().manual_seed(i)).cuda() for i in range(4)]
+    fresh = Net(small_cfg())
+    fresh.load_state_dict(net.state_dict())
+    fresh = fresh.cuda().eval()
+    net.eval()
+    with torch.no_grad():
+        a = net.offset_regressor.dpt_head.forward_nhwc(feats)
+        b = fresh.offset_regressor.dpt_head.forward_nhwc(feats)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    net.train()
     # `model(end_points)` dispatches on self.training, drawing its own noisy affines
     np.random.seed(0)
     torch.manual_seed(0)
