@@ -2575,31 +2575,40 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             PP_CHECK_HIP(hipEventCreate(&e1));
             float bt = 1e30f;
             int bc = 0;
-            // pre-split operands: 128x128, 128x64 and (for problems that fill the chip with 256x128 tiles) the LDS-DMA kernel
+            // pre-split operands: 128x128, 128x64 and (for problems that fill the chip with 256x128 tiles) the LDS-DMA kernels
             const bool big = asplit && (long long)((d.M + GBM - 1) / GBM) * ((d.N + GBN - 1) / GBN) >= cus / 2;
             const bool p_ok = big && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
             const bool q_ok = p_ok && d.N > 128 && (long long)((d.M + QBM - 1) / QBM) * ((d.N + QBN - 1) / QBN) >= cus / 2;
+            int cands[8], nc = 0;
             for (int c = 0; c < (asplit ? 7 : (vec ? 3 : 2)); ++c) {
                 const int cand = asplit ? (c == 0 ? 0 : c == 1 ? 2 : c + 1) : (vec ? c : (c == 0 ? 0 : 2));
                 if ((cand == 3 && !big) || (cand == 4 && !p_ok) || (cand == 5 && !q_ok) || (cand == 6 && !(q_ok && h_shape)) ||
                     (cand == 7 && !(big && d.conv_kh == 0 && d.K >= 3 * D_KT))) continue;
-                launch(cand);  // warm
-                float ms = 1e30f;
-                // best of three bursts of four back-to-back launches: single synchronised launches run on a GPU that idles
-                // (and re-clocks) between samples and mis-ranked configurations within ~5-10 % from run to run
-                for (int rep = 0; rep < 3; ++rep) {
+                cands[nc++] = cand;
+            }
+            // Round-robin: every round times one burst of four back-to-back launches of EACH candidate, and a candidate keeps
+            // its best burst.  (Timing the candidates one after the other ranked them by the clock the chip happened to hold:
+            // the first ones ran on a cool chip, and configurations within ~5-10 % changed places from run to run.)
+            float ms[8];
+            for (int i = 0; i < nc; ++i) {
+                ms[i] = 1e30f;
+                launch(cands[i]);  // warm
+            }
+            for (int rep = 0; rep < 4; ++rep)
+                for (int i = 0; i < nc; ++i) {
                     (void)hipEventRecord(e0, st);
-                    for (int k = 0; k < 4; ++k) launch(cand);
+                    for (int k = 0; k < 4; ++k) launch(cands[i]);
                     (void)hipEventRecord(e1, st);
                     (void)hipEventSynchronize(e1);
                     float t = 0.f;
                     (void)hipEventElapsedTime(&t, e0, e1);
-                    ms = t < ms ? t : ms;
+                    ms[i] = t < ms[i] ? t : ms[i];
                 }
-                if (dbg) fprintf(stderr, "[pp_gemm] autotune %s cfg %d: %.4f ms\n", key, cand, ms);
-                if (ms < bt) {
-                    bt = ms;
-                    bc = cand;
+            for (int i = 0; i < nc; ++i) {
+                if (dbg) fprintf(stderr, "[pp_gemm] autotune %s cfg %d: %.4f ms\n", key, cands[i], ms[i]);
+                if (ms[i] < bt) {
+                    bt = ms[i];
+                    bc = cands[i];
                 }
             }
             (void)hipEventDestroy(e0);
