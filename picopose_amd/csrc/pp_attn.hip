@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     float mrun = -INFINITY, lrun = 0.f;
     const float* kp = base + heads * HD;
     const float* vp = base + 2 * heads * HD;
-    const float S_DESCALE = scale / (PP_A_SCALE * PP_A_SCALE);
+    // scores are kept in the base-2 domain (scaled by log2 e): the soft-max exponentials are single v_exp_f32 instructions
+    const float S_DESCALE = scale * 1.44269504088896340736f / (PP_A_SCALE * PP_A_SCALE);
     constexpr float O_RESCALE = 1.0f / (PP_A_SCALE * P_SCALE);
 
     // Keys are consumed in chunks of KC = 32 through LDS; a tail of up to TAILMAX keys (T = 257 = 8 x 32 + 1: the chunk
@@ -307,12 +308,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mnew = fmaxf(mrun, mx);
-        const float alpha = expf(mrun - mnew);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
         float ls = 0.f;
         h8 ph[2], pl[2];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float pe = expf(sacc[e] - mnew);
+            const float pe = __builtin_amdgcn_exp2f(sacc[e] - mnew);
             ls += pe;
             const float x = pe * P_SCALE;  // <= 1024: no saturation needed
             const _Float16 hh = (_Float16)x;
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             dot += __shfl_xor(dot, 32);
             const float sv = dot * S_DESCALE;
             const float mnew = fmaxf(mrun, sv);
-            const float alpha = expf(mrun - mnew), pe = expf(sv - mnew);
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew), pe = __builtin_amdgcn_exp2f(sv - mnew);
             lrun = lrun * alpha + pe;
             mrun = mnew;
             const float pw = pe * P_SCALE;     // the units of the MFMA path: (4 v) (1024 p)
