@@ -308,6 +308,14 @@ int pp_corr_lookup_nhwc_ex(const float* f1, int ld_f1, const float* f2_l0, const
                            int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius,
                            int ld_flow, int prec, float* out, int ld_out, void* stream);
 
+/* The tiled lookup on operands the producers already hold in the engine's hl format (fp16 [pixels][2 ld]: per 8 channels
+ * the 8 hi then the 8 lo terms; include "hl" above): f1_hl with rows of ld_f1 channels (a column block of a wider operand
+ * is fine), f2_hl_l{0,1,2} contiguous (f2_batch, H >> l, W >> l, C).  H, W multiples of 8 and C of 32 (else PP_EINVAL: use
+ * pp_corr_lookup_nhwc).  Same values as pp_corr_lookup_nhwc on the fp32 maps, without the split work per staged chunk. */
+int pp_corr_lookup_nhwc_hl(const void* f1_hl, int ld_f1, const void* f2_hl_l0, const void* f2_hl_l1, const void* f2_hl_l2,
+                           int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius, int ld_flow,
+                           float* out, int ld_out, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * utils/pose_recovery.py:68-105 pose_recovery_ransac_pnp, batched over P = instances x hypotheses
  * (run_test.py:168-184 calls it once per pair): gather of the valid 2D/3D correspondences, object-frame

@@ -249,9 +249,13 @@ typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 constexpr int CSP = CN + 4;                    // row pitch of S
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const float* __restrict__ f1, int ld_f1, int f2_batch,
-                                                                  const float* __restrict__ f2l0, const float* __restrict__ f2l1,
-                                                                  const float* __restrict__ f2l2, const float* __restrict__ flow,
+// HLIN: f1 / f2 arrive as the engine's hl operand (fp16 [rows][2 ld]: per 8 channels 8 hi then 8 lo terms — what the
+// producing convolution's epilogue writes): staging is 16-byte copies, no split arithmetic (it was as long as the MFMAs of a
+// chunk).  Same bits either way: the split of a value does not depend on who performs it.
+template <bool HLIN>
+__global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const void* __restrict__ f1v, int ld_f1, int f2_batch,
+                                                                  const void* __restrict__ f2l0, const void* __restrict__ f2l1,
+                                                                  const void* __restrict__ f2l2, const float* __restrict__ flow,
                                                                   int B, int H, int W, int C, int L, int r, int ld_flow,
                                                                   float inv_sqrt_c, float* __restrict__ out, int ld_out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -277,7 +281,11 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const float* _
     }
     for (int l = 0; l < L; ++l) {
         const int Hl = H >> l, Wl = W >> l;
-        const float* f2 = (l == 0 ? f2l0 : (l == 1 ? f2l1 : f2l2)) + (size_t)(b % f2_batch) * Hl * Wl * C;
+        const void* f2v = l == 0 ? f2l0 : (l == 1 ? f2l1 : f2l2);
+        const float* f2 = (const float*)f2v + (size_t)(b % f2_batch) * Hl * Wl * C;                 // fp32 input
+        const _Float16* f2h = (const _Float16*)f2v + (size_t)(b % f2_batch) * Hl * Wl * C * 2;      // hl input
+        const float* f1 = (const float*)f1v;
+        const _Float16* f1h = (const _Float16*)f1v;
         if (tid == 0) s_todo = 0;
         __syncthreads();
         if (tid < CM) {
@@ -314,35 +322,43 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const float* _
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-            f4 ra[2], rb[8];
+            f4 ra[2], rb[8];      // (HLIN: the 16 bytes are 8 halfs — piece `part` of the row's 128-byte chunk)
             const int part = tid & 7, row0 = tid >> 3;
             auto load_chunk = [&](int kc) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int m = row0 + 32 * i;
-                    ra[i] = *(const f4*)(f1 + ((size_t)b * H * W + (size_t)(y0 + (m >> 3)) * W + x0 + (m & 7)) * ld_f1 + kc * CK + 4 * part);
+                    const size_t px = (size_t)b * H * W + (size_t)(y0 + (m >> 3)) * W + x0 + (m & 7);
+                    ra[i] = HLIN ? *(const f4*)(f1h + (px * ld_f1 + kc * CK) * 2 + 8 * part) : *(const f4*)(f1 + px * ld_f1 + kc * CK + 4 * part);
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int n = row0 + 32 * i, qy = oy + (n >> 4), qx = ox + (n & 15);
                     const bool in = qx >= 0 && qx < Wl && qy >= 0 && qy < Hl;
-                    rb[i] = in ? *(const f4*)(f2 + ((size_t)qy * Wl + qx) * C + kc * CK + 4 * part) : f4{0.f, 0.f, 0.f, 0.f};
+                    const size_t px = (size_t)qy * Wl + qx;
+                    rb[i] = !in ? f4{0.f, 0.f, 0.f, 0.f}
+                                : (HLIN ? *(const f4*)(f2h + (px * C + kc * CK) * 2 + 8 * part) : *(const f4*)(f2 + px * C + kc * CK + 4 * part));
                 }
             };
             load_chunk(0);
             const int nk = C / CK;
             for (int kc = 0; kc < nk; ++kc) {
                 __syncthreads();                            // the previous chunk (or the previous pass's S) has been read
-                // split into the two fp16 planes of the row: halfs [0,32) = hi, [32,64) = lo
+                // LDS rows hold the chunk in hl order: per 8 channels 8 hi then 8 lo halfs (fp32 input: split here)
                 auto put = [&](float* rowp, f4 v) {
+                    if (HLIN) {
+                        *(f4*)((_Float16*)rowp + 8 * part) = v;
+                        return;
+                    }
                     _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
                     pp_split_f16(v.x, h0, l0);
                     pp_split_f16(v.y, h1, l1);
                     pp_split_f16(v.z, h2, l2);
                     pp_split_f16(v.w, h3, l3);
                     const h4_t hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
-                    *(h4_t*)((_Float16*)rowp + 4 * part) = hi;
-                    *(h4_t*)((_Float16*)rowp + 32 + 4 * part) = lo;
+                    _Float16* g8 = (_Float16*)rowp + 16 * (part >> 1) + 4 * (part & 1);   // channels 4 part .. + 3 of group part / 2
+                    *(h4_t*)g8 = hi;
+                    *(h4_t*)(g8 + 8) = lo;
                 };
 #pragma unroll
                 for (int i = 0; i < 2; ++i) put(As + (row0 + 32 * i) * CKP, ra[i]);
@@ -356,12 +372,12 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const float* _
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const _Float16* ar = (const _Float16*)(As + (i * 32 + l31) * CKP) + 16 * q + 8 * lh;
-                        const _Float16* br = (const _Float16*)(Bs + (wv * 64 + i * 32 + l31) * CKP) + 16 * q + 8 * lh;
+                        const _Float16* ar = (const _Float16*)(As + (i * 32 + l31) * CKP) + 16 * (2 * q + lh);
+                        const _Float16* br = (const _Float16*)(Bs + (wv * 64 + i * 32 + l31) * CKP) + 16 * (2 * q + lh);
                         ah[i][q] = *(const h8_t*)ar;
-                        al[i][q] = *(const h8_t*)(ar + 32);
+                        al[i][q] = *(const h8_t*)(ar + 8);
                         bh[i][q] = *(const h8_t*)br;
-                        bl[i][q] = *(const h8_t*)(br + 32);
+                        bl[i][q] = *(const h8_t*)(br + 8);
                     }
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
@@ -545,6 +561,28 @@ int pp_avgpool2_nhwc(const float* in, int B, int H, int W, int C, float* out, vo
     return pp_last_launch();
 }
 
+static int corr_tiled_launch(bool hl, const void* f1, int ld_f1, const void* f2_l0, const void* f2_l1, const void* f2_l2, int f2_batch,
+                             const float* flow, int B, int H, int W, int C, int levels, int radius, int ld_flow, float* out, int ld_out,
+                             void* stream) {
+    // matrix-core version: one workgroup per 8 x 8 pixel tile
+    const size_t lds = (size_t)(CM * CSP > (CM + CN) * CKP ? CM * CSP : (CM + CN) * CKP) * sizeof(float);
+    static signed char attr[PP_MAX_DEVICES];
+    signed char& ok = attr[pp_cur_device()];
+    if (ok == 0)
+        ok = hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess
+                 ? 1 : -1;
+    if (ok < 0) return PP_ELAUNCH;
+    const dim3 grid((unsigned)((H / CT) * (W / CT) * B));
+    if (hl)
+        hipLaunchKernelGGL(corr_lookup_mfma_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, f1, ld_f1, f2_batch, f2_l0, f2_l1, f2_l2,
+                           flow, B, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out, ld_out);
+    else
+        hipLaunchKernelGGL(corr_lookup_mfma_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, f1, ld_f1, f2_batch, f2_l0, f2_l1, f2_l2,
+                           flow, B, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out, ld_out);
+    return pp_last_launch();
+}
+
 int pp_corr_lookup_nhwc_ex(const float* f1, int ld_f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
                            int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius,
                            int ld_flow, int prec, float* out, int ld_out, void* stream) {
@@ -558,24 +596,28 @@ int pp_corr_lookup_nhwc_ex(const float* f1, int ld_f1, const float* f2_l0, const
     if (ld_out < levels * win * win) return PP_EINVAL;
     const char* te = getenv("PP_CORR_TILED");   // read per call: the tests run both kernels in one process
     const bool tiled = prec == PP_PREC_F16X3 && !(te && te[0] == '0');   // PP_PREC_F32: exact fp32 fmas, always
-    if (tiled && H % CT == 0 && W % CT == 0 && C % CK == 0 && ((uintptr_t)f2_l0 % 16) == 0) {
-        // matrix-core version: one workgroup per 8 x 8 pixel tile (PP_CORR_TILED=0 keeps the lane-per-position kernel)
-        const size_t lds = (size_t)(CM * CSP > (CM + CN) * CKP ? CM * CSP : (CM + CN) * CKP) * sizeof(float);
-        static signed char attr[PP_MAX_DEVICES];
-        signed char& ok = attr[pp_cur_device()];
-        if (ok == 0)
-            ok = hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
-        if (ok < 0) return PP_ELAUNCH;
-        hipLaunchKernelGGL(corr_lookup_mfma_kernel, dim3((unsigned)((H / CT) * (W / CT) * B)), dim3(256), lds, (hipStream_t)stream,
-                           f1, ld_f1, f2_batch, f2_l0, f2_l1, f2_l2, flow, B, H, W, C, levels, radius, ld_flow,
-                           1.0f / sqrtf((float)C), out, ld_out);
-        return pp_last_launch();
-    }
+    if (tiled && H % CT == 0 && W % CT == 0 && C % CK == 0 && ((uintptr_t)f2_l0 % 16) == 0)   // (PP_CORR_TILED=0 keeps the lane-per-position kernel)
+        return corr_tiled_launch(false, f1, ld_f1, f2_l0, f2_l1, f2_l2, f2_batch, flow, B, H, W, C, levels, radius, ld_flow, out, ld_out, stream);
     const size_t smem = (size_t)4 * (C + MAXL * TW * TW) * sizeof(float);
     hipLaunchKernelGGL(corr_lookup_kernel, dim3((H * W + 3) / 4, B), dim3(256), smem, (hipStream_t)stream, f1, ld_f1,
                        f2_batch, f2_l0, f2_l1, f2_l2, flow, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out,
                        ld_out);
     return pp_last_launch();
+}
+
+int pp_corr_lookup_nhwc_hl(const void* f1_hl, int ld_f1, const void* f2_hl_l0, const void* f2_hl_l1, const void* f2_hl_l2,
+                           int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius, int ld_flow,
+                           float* out, int ld_out, void* stream) {
+    if (!f1_hl || !f2_hl_l0 || !flow || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || f2_batch <= 0) return PP_EINVAL;
+    if (H % CT != 0 || W % CT != 0 || C % CK != 0 || ld_f1 < C || ld_f1 % 8 != 0) return PP_EINVAL;   // tiled shapes only
+    if (((uintptr_t)f1_hl | (uintptr_t)f2_hl_l0 | (uintptr_t)f2_hl_l1 | (uintptr_t)f2_hl_l2) % 16 != 0) return PP_EINVAL;
+    if (levels < 1 || levels > MAXL || radius < 1 || radius > MAXR) return PP_EINVAL;
+    if ((levels > 1 && !f2_hl_l1) || (levels > 2 && !f2_hl_l2)) return PP_EINVAL;
+    if ((H >> (levels - 1)) < 1 || (W >> (levels - 1)) < 1 || ld_flow < 2) return PP_EINVAL;
+    const int win = 2 * radius + 1;
+    if (ld_out < levels * win * win) return PP_EINVAL;
+    return corr_tiled_launch(true, f1_hl, ld_f1, f2_hl_l0, f2_hl_l1, f2_hl_l2, f2_batch, flow, B, H, W, C, levels, radius, ld_flow, out, ld_out,
+                             stream);
 }
 
 int pp_corr_lookup_nhwc(const float* f1, int ld_f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,

@@ -218,14 +218,17 @@ class FlowDecoder(Packed):
                 else:
                     X[..., 0:256] = fr
             else:
-                fq = ops.conv2d(getattr(fq_in, "_hl", fq_in), pk[f"proj{l}"], pk[f"proj{l}_b"], 1)
+                fq = ops.conv2d(getattr(fq_in, "_hl", fq_in), pk[f"proj{l}"], pk[f"proj{l}_b"], 1, also_split="plain" if opcat else None)
                 if opcat:
                     fr = ops.conv2d(fr_src, pk[f"proj{l}"], pk[f"proj{l}_b"], 1, hl_into=(Xs, 0),
                                     out=torch.empty(B, H, W, 256, dtype=torch.float32, device=dev))
                 else:
                     fr = ops.conv2d(fr_src, pk[f"proj{l}"], pk[f"proj{l}_b"], 1, out=X[..., 0:256])   # straight into its slice of X
             ncorr = (l + 1) * (2 * self.r + 1) ** 2
-            corr = ops.corr_lookup(fr, fq, flow, l + 1, self.r, c_pad=-(-ncorr // 8) * 8)
+            # (f16x3 engine: both maps already exist as operands — the render map as columns 0..255 of Xs, the real map from
+            # its projection's epilogue — so the lookup stages copies instead of splitting every chunk)
+            hl_maps = dict(f1_hl=(Xs, 0), f2_hl=getattr(fq, "_hl", None)) if opcat and not train else {}
+            corr = ops.corr_lookup(fr, fq, flow, l + 1, self.r, c_pad=-(-ncorr // 8) * 8, **hl_maps)
             # [corr feat 192 | flow feat 64]: on the f16x3 engine the concat exists only as the operand of out_net
             hl_cat = opcat
             if hl_cat:

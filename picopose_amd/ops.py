@@ -3,6 +3,7 @@
 All activations are token-major / NHWC fp32 device tensors: (rows, C) or (B, H, W, C).  Nothing
 here computes with torch ops — torch only allocates the outputs."""
 import ctypes
+import os
 
 import torch
 
@@ -488,10 +489,12 @@ def avgpool2(x):
     return out
 
 
-def corr_lookup(f1, f2, flow, levels, radius, c_pad=None):
+def corr_lookup(f1, f2, flow, levels, radius, c_pad=None, f1_hl=None, f2_hl=None):
     """Correlation pyramid + lookup, NHWC: (B,H,W,C) x2, flow (B,H,W,>=2) -> (B,H,W,levels*(2r+1)^2)
     (c_pad: channel count of the result, zero-filled beyond the levels*(2r+1)^2 real channels).
-    f1 may be a channel slice of a wider buffer; f2 may hold B / k images (image b reads f2[b % (B / k)])."""
+    f1 may be a channel slice of a wider buffer; f2 may hold B / k images (image b reads f2[b % (B / k)]).
+    f1_hl = (Split over (B*H*W, Ctot), col0), f2_hl = Split over (Bf*H*W, C): the same maps as operands the producers have
+    already written (f16x3 engine, tileable shapes): the kernel then stages 16-byte copies instead of splitting every chunk."""
     B, H, W, C = f1.shape
     assert f2.is_contiguous() and flow.stride(3) == 1 and B % f2.shape[0] == 0 and tuple(f2.shape[1:]) == (H, W, C)
     assert f1.stride(3) == 1 and f1.stride(1) == W * f1.stride(2) and f1.stride(0) == H * f1.stride(1)
@@ -501,6 +504,15 @@ def corr_lookup(f1, f2, flow, levels, radius, c_pad=None):
     n = levels * (2 * radius + 1) ** 2
     np_ = c_pad if c_pad and c_pad > n else n
     out = (torch.zeros if np_ > n else torch.empty)(B, H, W, np_, dtype=torch.float32, device=f1.device)
+    if (f1_hl is not None and f2_hl is not None and PRECISION == "f16x3" and H % 8 == 0 and W % 8 == 0 and C % 32 == 0
+            and os.environ.get("PP_CORR_TILED", "1") != "0" and os.environ.get("PP_CORR_HL", "1") != "0"):
+        tgt, col0 = f1_hl
+        assert tgt.shape[0] == B * H * W and col0 % 8 == 0 and col0 + C <= tgt.shape[1] and f2_hl.shape == (f2.shape[0] * H * W, C)
+        hls = [f2_hl.hl] + [split_activation(p, p.shape[0], p.shape[1] * p.shape[2], C, p.shape[1] * p.shape[2] * C, C) for p in pyr[1:]]
+        _lib.check(_lib.lib().pp_corr_lookup_nhwc_hl(tgt.hl.data_ptr() + 4 * col0, tgt.shape[1], _p(hls[0]), _p(hls[1]) if levels > 1 else None,
+                                                     _p(hls[2]) if levels > 2 else None, f2.shape[0], _p(flow), B, H, W, C, levels, radius,
+                                                     flow.stride(2), _p(out), np_, _lib.stream_ptr()), "pp_corr_lookup_nhwc_hl")
+        return out
     _lib.check(_lib.lib().pp_corr_lookup_nhwc_ex(_p(f1), f1.stride(2), _p(pyr[0]), _p(pyr[1]) if levels > 1 else None,
                                                  _p(pyr[2]) if levels > 2 else None, f2.shape[0], _p(flow), B, H, W, C,
                                                  levels, radius, flow.stride(2), _PREC[PRECISION], _p(out), np_,

@@ -186,3 +186,12 @@ def test_tiled_corr_lookup_equals_the_lane_per_position_kernel(monkeypatch, H, l
     assert float((exact[..., :n].cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
     assert float((tiled[..., :n].cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
     assert torch.equal(tiled[..., n:], torch.zeros_like(tiled[..., n:]))
+    if H % 8 == 0:
+        # the same lookup fed with the maps as hl operands (f1 as a column block of a wider operand, as the flow decoder
+        # holds it; the pooled levels split from the fp32 pools): identical bits — a value's split does not depend on who makes it
+        wide = ops.Split.empty(B * H * H, 96, f1.device)
+        wide.hl.zero_()
+        ops.split_activation(f1, B, H * H, C, H * H * C, C, into=(wide, 32))
+        f2s = ops.Split(ops.split_activation(f2, 2, H * H, C, H * H * C, C))
+        from_operands = ops.corr_lookup(f1, f2, flow, levels, 2, c_pad=pad, f1_hl=(wide, 32), f2_hl=f2s)
+        assert torch.equal(from_operands, tiled)
