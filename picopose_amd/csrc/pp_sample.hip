@@ -322,9 +322,11 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const void* __
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-            f4 ra[2], rb[8];      // (HLIN: the 16 bytes are 8 halfs — piece `part` of the row's 128-byte chunk)
+            // Two chunks of register prefetch: chunk kc + 2 is requested as soon as chunk kc has been stored to LDS, so a load has
+            // two chunk periods (MFMAs, fragment reads, two barriers each) to arrive; with one chunk ahead the L2 latency showed.
+            f4 ra0[2], rb0[8], ra1[2], rb1[8];   // (HLIN: the 16 bytes are 8 halfs — piece `part` of the row's 128-byte chunk)
             const int part = tid & 7, row0 = tid >> 3;
-            auto load_chunk = [&](int kc) {
+            auto load_chunk = [&](int kc, f4 (&ra)[2], f4 (&rb)[8]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int m = row0 + 32 * i;
@@ -340,55 +342,63 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const void* __
                                 : (HLIN ? *(const f4*)(f2h + (px * C + kc * CK) * 2 + 8 * part) : *(const f4*)(f2 + px * C + kc * CK + 4 * part));
                 }
             };
-            load_chunk(0);
+            // LDS rows hold the chunk in hl order: per 8 channels 8 hi then 8 lo halfs (fp32 input: split here)
+            auto put = [&](float* rowp, f4 v) __attribute__((always_inline)) {
+                if (HLIN) {
+                    *(f4*)((_Float16*)rowp + 8 * part) = v;
+                    return;
+                }
+                _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
+                pp_split_f16(v.x, h0, l0);
+                pp_split_f16(v.y, h1, l1);
+                pp_split_f16(v.z, h2, l2);
+                pp_split_f16(v.w, h3, l3);
+                const h4_t hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
+                _Float16* g8 = (_Float16*)rowp + 16 * (part >> 1) + 4 * (part & 1);   // channels 4 part .. + 3 of group part / 2
+                *(h4_t*)g8 = hi;
+                *(h4_t*)(g8 + 8) = lo;
+            };
+#ifdef PP_STUDY_CORR_NK1   // (timing-only study build: one channel chunk instead of C / 32 — sizes the K loop's share)
+            const int nk = 1;
+#else
             const int nk = C / CK;
-            for (int kc = 0; kc < nk; ++kc) {
+#endif
+            auto chunk = [&](int kc, f4 (&ra)[2], f4 (&rb)[8]) __attribute__((always_inline)) {
                 __syncthreads();                            // the previous chunk (or the previous pass's S) has been read
-                // LDS rows hold the chunk in hl order: per 8 channels 8 hi then 8 lo halfs (fp32 input: split here)
-                auto put = [&](float* rowp, f4 v) {
-                    if (HLIN) {
-                        *(f4*)((_Float16*)rowp + 8 * part) = v;
-                        return;
-                    }
-                    _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
-                    pp_split_f16(v.x, h0, l0);
-                    pp_split_f16(v.y, h1, l1);
-                    pp_split_f16(v.z, h2, l2);
-                    pp_split_f16(v.w, h3, l3);
-                    const h4_t hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
-                    _Float16* g8 = (_Float16*)rowp + 16 * (part >> 1) + 4 * (part & 1);   // channels 4 part .. + 3 of group part / 2
-                    *(h4_t*)g8 = hi;
-                    *(h4_t*)(g8 + 8) = lo;
-                };
 #pragma unroll
                 for (int i = 0; i < 2; ++i) put(As + (row0 + 32 * i) * CKP, ra[i]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) put(Bs + (row0 + 32 * i) * CKP, rb[i]);
                 __syncthreads();
-                if (kc + 1 < nk) load_chunk(kc + 1);        // in flight under the MFMAs
-                // lane (l31, lh) feeds row / column l31 with channels 16 s + 8 lh .. + 7 of the chunk in k-step s
-                h8_t ah[2][2], al[2][2], bh[2][2], bl[2][2];
+                if (kc + 2 < nk) load_chunk(kc + 2, ra, rb);    // in flight under two chunks of MFMAs
+                // lane (l31, lh) feeds row / column l31 with channels 16 q + 8 lh .. + 7 of the chunk in k-step q
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int q = 0; q < 2; ++q) {
+                    h8_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int i = 0; i < 2; ++i) {
                         const _Float16* ar = (const _Float16*)(As + (i * 32 + l31) * CKP) + 16 * (2 * q + lh);
                         const _Float16* br = (const _Float16*)(Bs + (wv * 64 + i * 32 + l31) * CKP) + 16 * (2 * q + lh);
-                        ah[i][q] = *(const h8_t*)ar;
-                        al[i][q] = *(const h8_t*)(ar + 8);
-                        bh[i][q] = *(const h8_t*)br;
-                        bl[i][q] = *(const h8_t*)(br + 8);
+                        ah[i] = *(const h8_t*)ar;
+                        al[i] = *(const h8_t*)(ar + 8);
+                        bh[i] = *(const h8_t*)br;
+                        bl[i] = *(const h8_t*)(br + 8);
                     }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i][q], bh[j][q], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i][q], bl[j][q], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i][q], bh[j][q], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
                         }
+                }
+            };
+            load_chunk(0, ra0, rb0);
+            if (nk > 1) load_chunk(1, ra1, rb1);
+            for (int kc = 0; kc < nk; kc += 2) {
+                chunk(kc, ra0, rb0);
+                if (kc + 1 < nk) chunk(kc + 1, ra1, rb1);
             }
             __syncthreads();                                // every wave is done reading As/Bs: S may overwrite them
 #pragma unroll
