@@ -493,6 +493,14 @@ def main():
                    "traffic_source": traffic_src, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kbytes,
                    "timing": "HIP events on the launch stream around this launch, " +
                              ("inside the timed steps" if kind == "stage1" else "3 extra untimed steps after the timed region")}
+        # the other roof of the same launch: the 256 x 256 x C contraction per (crop, template) on the matrix cores
+        # (fast mode: one fp16 MFMA term; exact mode: fp32 MFMA).  With an fp16-stored bank the intensity is 2 C 256^2 / (2 C 256)
+        # = 256 flop/B against a ridge of 2500 / 8 = 312: the kernel then sits between both roofs and this reading is the binding one.
+        s1_flops = 2.0 * B * n_local * 256 * 256 * C
+        s1_peak = MFMA_F16_PEAK_TF if a.mode == "fast" else MFMA_F32_PEAK_TF
+        s1_roof["mfma"] = {"achieved": s1_flops / (kern_ms * 1e-3) / 1e12, "peak": s1_peak, "unit": "TFLOP/s",
+                           "frac": s1_flops / (kern_ms * 1e-3) / 1e12 / s1_peak, "flops_per_launch": s1_flops,
+                           "intensity_flop_per_byte": s1_flops / kbytes}
         if kind == "full" and gemm and gemm["launches"][0] > 0:
             k = 0 if a.mode == "fast" else 1     # fast: pre-split f16x3 kernel; exact: the fp32-MFMA kernel
             mult, peak = (3, MFMA_F16_PEAK_TF) if a.mode == "fast" else (1, MFMA_F32_PEAK_TF)

@@ -210,6 +210,9 @@ int pp_split_activation(const float* x, long long batch_stride, int B, int P, in
  * group: a multiple of 8 columns into the row): the channel concatenation of operands without an fp32 concat buffer. */
 int pp_split_activation_ld(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu,
                            void* hl, int ld_h, void* stream);
+/* Columns col0 .. col0 + c - 1 (any alignment, c <= 64) of every row of an existing hl operand with rows of ld_h channels
+ * <- x (rows, c) fp32 with row pitch ld_x: the narrow member of a channel concatenation (raft_decoder.py:161, [out | flow]). */
+int pp_hl_patch_columns(const float* x, int ld_x, int c, long long rows, void* hl, int ld_h, int col0, void* stream);
 
 /* Fused multi-head self-attention (model/stage1/layers/attention.py:49-62): qkv (B,T,3,heads,64) as the qkv
  * linear produces it -> out (B,T,heads*64) = softmax((q*scale) k^T) v per head; exact fp32 MFMA, flash style. */

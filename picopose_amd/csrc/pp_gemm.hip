@@ -2404,6 +2404,29 @@ int pp_split_activation_ld(const float* x, long long batch_stride, int B, int P,
     return pp_last_launch();
 }
 
+// A few columns of an existing hl operand (channel concatenation with a narrow tensor: the flow decoder's [out_net | flow],
+// raft_decoder.py:161): columns col0 .. col0 + c - 1 of every row <- x[row][0 .. c-1]; any alignment, one element per thread.
+__global__ __launch_bounds__(256) void hl_patch_kernel(const float* __restrict__ x, int ld_x, int c, long long rows, _Float16* __restrict__ hl,
+                                                       int ldh, int col0) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * c) return;
+    const long long row = i / c;
+    const int j = (int)(i - row * c);
+    _Float16 h, l;
+    pp_split_f16(x[row * ld_x + j], h, l);
+    _Float16* hp = hl + row * ldh + pp_hl_col(col0 + j, 0);
+    hp[0] = h;
+    hp[8] = l;
+}
+
+int pp_hl_patch_columns(const float* x, int ld_x, int c, long long rows, void* hl, int ld_h, int col0, void* stream) {
+    if (!x || !hl || c <= 0 || c > 64 || rows <= 0 || ld_x < c || col0 < 0 || col0 + c > ld_h || ld_h % 8 != 0) return PP_EINVAL;
+    const long long n = rows * c;
+    hipLaunchKernelGGL(hl_patch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld_x, c, rows,
+                       (_Float16*)hl, 2 * ld_h, col0);
+    return pp_last_launch();
+}
+
 int pp_split_activation(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu, void* hl,
                         void* stream) {
     return pp_split_activation_ld(x, batch_stride, B, P, row_stride, C, relu, hl, C, stream);

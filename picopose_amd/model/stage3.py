@@ -109,12 +109,13 @@ class DPTHead(Packed):
         """feats: 4 NHWC maps (B,16,16,C) (may be views with a free batch stride) -> [path_4, path_3, path_2] NHWC.
         train: the ResidualConvUnits' BatchNorms run in training mode (one statistics update per call)."""
         pk, r = self.packed(for_training=train), self.resize_layers
-        x = [ops.conv2d(f, pk[f"proj{i}"], self.projects[i].bias, 1) for i, f in enumerate(feats)]
-        # (the up-sampled maps feed only their layerK_rn convolution: operand-only outputs on the f16x3 engine)
+        # (the projected maps feed only their resize layer, the resized maps only their layerK_rn convolution: operand-only
+        # outputs on the f16x3 engine — no fp32 store, no split pass)
+        x = [ops.conv2d(f, pk[f"proj{i}"], self.projects[i].bias, 1, out_split=True) for i, f in enumerate(feats)]
         l1 = ops.conv_transpose2d(x[0], pk["up0"], pk["up0_b"], 4, out_split=True)
         l2 = ops.conv_transpose2d(x[1], pk["up1"], pk["up1_b"], 2, out_split=True)
         l3 = x[2]
-        l4 = ops.conv2d(x[3], pk["down3"], getattr(r, "3").bias, 3, stride=2, pad=1)
+        l4 = ops.conv2d(x[3], pk["down3"], getattr(r, "3").bias, 3, stride=2, pad=1, out_split=True)
         # every layerK_rn output is the input of a ResidualConvUnit (fp32 for its skip, relu'd operand for its conv1)
         rn = [ops.conv2d(l, pk[f"rn{i + 1}"], None, 3, pad=1, also_split="relu") for i, l in enumerate((l1, l2, l3, l4))]
         p4 = self._fuse(pk, 4, rn[2].shape[1:3], rn[3], train=train)
@@ -175,6 +176,12 @@ class FlowDecoder(Packed):
                     # 25(l+1)-channel correlation / 2-channel flow inputs are zero-padded to a multiple of 8 channels
                     pad = -(-w.shape[1] // 8) * 8 if w.shape[1] % 8 else None
                     pk[f"e{l}_{name}{idx}"] = ops.pack_conv_weight(w, cin_pad=pad)
+            # [out_net (126) | flow (2)] as operand columns: the convolution writes 128 columns (two zero filters), the flow
+            # then replaces the last two
+            w126 = pk[f"e{l}_out0"]
+            pk[f"e{l}_out0_128"] = torch.cat([w126, w126.new_zeros(2, w126.shape[1])]).contiguous()
+            b126 = getattr(e.out_net, "0").conv.bias.float()
+            pk[f"e{l}_out0_b128"] = torch.cat([b126, b126.new_zeros(2)]).contiguous()
             for name, head in (("fp", self.flow_pred[l]), ("mp", self.mask_pred[l])):
                 for idx, sub in head.layers.named_children():
                     pk[f"{name}{l}_{idx}"] = ops.pack_conv_weight(sub.conv.weight.float())
@@ -245,11 +252,9 @@ class FlowDecoder(Packed):
             ops.conv2d(f1, pk[f"e{l}_flow1"], getattr(e.flow_net, "1").conv.bias, 3, pad=1, act="relu",
                        **(dict(hl_into=(cf, 192)) if hl_cat else dict(out=cf[..., 192:256])))
             if opcat:
-                # motion = cat([out_net (126), flow (2)]) (raft_decoder.py:161): a 128-channel fp32 map, split into its columns
-                mo = torch.empty(B, H, W, 128, dtype=torch.float32, device=dev)
-                ops.conv2d(cf, pk[f"e{l}_out0"], getattr(e.out_net, "0").conv.bias, 3, pad=1, act="relu", out=mo[..., 0:126])
-                mo[..., 126:128] = flow
-                ops.split_activation(mo, B, H * W, 128, H * W * 128, 128, into=(Xs, 512))
+                # motion = cat([out_net (126), flow (2)]) (raft_decoder.py:161), written straight into its operand columns
+                ops.conv2d(cf, pk[f"e{l}_out0_128"], pk[f"e{l}_out0_b128"], 3, pad=1, act="relu", hl_into=(Xs, 512))
+                ops.hl_patch_columns(flow[..., 0:2].contiguous() if flow.shape[-1] != 2 else flow, Xs, 638)
                 ops.warp(fq, flow, hl_into=(Xs, 256))               # feature_sample (flow_decoder.py:49-56)
             else:
                 ops.conv2d(cf, pk[f"e{l}_out0"], getattr(e.out_net, "0").conv.bias, 3, pad=1, act="relu", out=X[..., 512:638])

@@ -103,6 +103,16 @@ def split_activation(x, B, P, C, batch_stride, row_stride, relu=False, into=None
     return _chk(hl, "pp_split_activation")
 
 
+def hl_patch_columns(x, tgt, col0):
+    """Columns col0 .. col0 + c - 1 of the Split `tgt` <- x (..., c) fp32 (contiguous): the narrow member of an operand concat."""
+    c = x.shape[-1]
+    rows = x.numel() // c
+    assert x.is_contiguous() and rows == tgt.shape[0] and col0 + c <= tgt.shape[1]
+    _lib.check(_lib.lib().pp_hl_patch_columns(_p(x), c, c, rows, _p(tgt.hl), tgt.shape[1], col0, _lib.stream_ptr()), "pp_hl_patch_columns")
+    if CHECK_SATURATION:   # (the 8-channel groups holding the patched columns; their other members are already written)
+        _chk(tgt.hl[:, 2 * (col0 // 8 * 8):2 * (-(-(col0 + c) // 8) * 8)], "pp_hl_patch_columns")
+
+
 def _can_presplit(x, K, C, *strides):
     return (PRECISION == "f16x3" and K % 8 == 0 and C % 8 == 0 and x.data_ptr() % 16 == 0
             and all(st % 4 == 0 for st in strides))
@@ -319,20 +329,26 @@ def conv_transpose2d(x, wp, bias_tiled, r, out_split=False):
     """ConvTranspose2d(kernel = stride = r, padding 0) on NHWC: (B,H,W,Cin) -> (B,H*r,W*r,Cout).
     out_split (f16x3 engine): return the result only as a Split with .image (the pixel-shuffle store of the epilogue
     writes operand groups) for the convolution that follows — the fp32 map is never stored."""
-    B, H, W, Cin = x.shape
-    assert x.is_contiguous()
+    xs = x if isinstance(x, Split) else None
+    if xs is not None:
+        (B, H, W), Cin = xs.image, xs.shape[1]
+    else:
+        B, H, W, Cin = x.shape
+        assert x.is_contiguous()
     Cout = wp.shape[0] // (r * r)
     wargs = _weight_args(wp, Cin)
-    if "B_hl" in wargs and _can_presplit(x, Cin, Cin) and x.numel() < 2 ** 31:
-        hl = split_activation(x, 1, B * H * W, Cin, 0, Cin)
+    dev = xs.device if xs is not None else x.device
+    if xs is not None or ("B_hl" in wargs and _can_presplit(x, Cin, Cin) and x.numel() < 2 ** 31):
+        assert "B_hl" in wargs
+        hl = xs.hl if xs is not None else split_activation(x, 1, B * H * W, Cin, 0, Cin)
         if out_split and _split_ok(Cout):
-            sp = Split.empty(B * H * r * W * r, Cout, x.device)
+            sp = Split.empty(B * H * r * W * r, Cout, dev)
             sp.image = (B, H * r, W * r)
             _run(_desc(A_hl=_p(hl), B=_p(wp), C=None, bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin,
                        lda=Cin, ldb=Cin, ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W, C_hl=_p(sp.hl), ldc_h=Cout, **wargs),
                  written=sp)
             return sp
-        out = torch.empty(B, H * r, W * r, Cout, dtype=torch.float32, device=x.device)
+        out = torch.empty(B, H * r, W * r, Cout, dtype=torch.float32, device=dev)
         _run(_desc(A_hl=_p(hl), B=_p(wp), C=_p(out), bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin,
                    lda=Cin, ldb=Cin, ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W, **wargs))
         return out

@@ -13,11 +13,11 @@ with torch.no_grad():
 outs=net(ep,5); torch.cuda.synchronize()
 cnt=collections.Counter()
 orig=ops.split_activation
-def traced(x,B,P,C,bs,rs,relu=False):
+def traced(x,B,P,C,bs,rs,relu=False,into=None):
     st=traceback.extract_stack(limit=6)
     where=" <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in st[:-1][-4:])
     cnt[(B,P,C,relu,where)]+=1
-    return orig(x,B,P,C,bs,rs,relu)
+    return orig(x,B,P,C,bs,rs,relu,into=into)
 ops.split_activation=traced
 outs=net(ep,5); torch.cuda.synchronize()
 for k,v in sorted(cnt.items(), key=lambda kv:-kv[0][0]*kv[0][1]*kv[0][2]*kv[1]):
