@@ -311,6 +311,15 @@ int pp_corr_lookup_nhwc_ex(const float* f1, int ld_f1, const float* f2_l0, const
                            int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius,
                            int ld_flow, int prec, float* out, int ld_out, void* stream);
 
+/* Convolution with ONE or TWO output channels on an hl operand (the flow / certainty predict layers of the decoder heads,
+ * raft_decoder.py:287-289): x_hl (B,H,W) pixels with rows of ld_x channels (C of them read, C % 32 == 0), stride 1,
+ * padding ksize / 2, ksize 1 or 3, W in {16, 32, 64} and H a multiple of 256 / W; weight (n_out, ksize*ksize*C) fp32 in the
+ * engine's k order (tap-major, then channel), bias (n_out) or NULL, residual (B,H,W,n_out) or NULL added to the result;
+ * out (B,H,W,n_out) fp32.  Exact fp32 products of the operand's value (hi + lo) with the fp32 filters, fp32 accumulation —
+ * at least the accuracy of the f16x3 engine, independent of the batch size. */
+int pp_conv_narrow_hl(const void* x_hl, int ld_x, int B, int H, int W, int C, const float* weight, const float* bias, int ksize,
+                      int n_out, const float* residual, float* out, void* stream);
+
 /* The tiled lookup on operands the producers already hold in the engine's hl format (fp16 [pixels][2 ld]: per 8 channels
  * the 8 hi then the 8 lo terms; include "hl" above): f1_hl with rows of ld_f1 channels (a column block of a wider operand
  * is fine), f2_hl_l{0,1,2} contiguous (f2_batch, H >> l, W >> l, C).  H, W multiples of 8 and C of 32 (else PP_EINVAL: use

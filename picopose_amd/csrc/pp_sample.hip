@@ -517,6 +517,84 @@ __global__ __launch_bounds__(256) void depth_points_kernel(const float* __restri
     out[3 * i + 2] = z;
 }
 
+
+// ---- convolutions with one or two output channels (the flow / certainty predict layers, raft_decoder.py:287-289) -----
+// On the GEMM engine such a layer pads its 2 (or 1) filters to a 64-wide tile and re-reads every pixel per tap from L2
+// (0.6 ms for the 3x3 at 64 x 64 x 160, 10 TFLOP/s).  Here a workgroup takes a band of 256 / W full image rows (one output
+// pixel per thread), stages the band plus a one-pixel halo per 32-channel slice in LDS (the input is the hl operand its
+// producer wrote: 128 bytes per pixel and slice) and every thread walks the taps of its pixel: x = hi + lo is the exact
+// fp32 value / 4, the weights are the layer's fp32 filters (scalar loads: the index is uniform), fp32 fma accumulation.
+constexpr int NRW_PITCH = 144;   // bytes per staged pixel: 128 + 16 (conflict-free 16-byte reads along a row of pixels)
+
+template <int KS, int NOUT>
+__global__ __launch_bounds__(256) void conv_narrow_kernel(const _Float16* __restrict__ x, int ldx, int H, int W, int C,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const float* __restrict__ residual, float* __restrict__ out) {
+    constexpr int R = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char nsm[];
+    const int TH = 256 / W, bands = H / TH;
+    const int b = blockIdx.x / bands, y0 = (blockIdx.x % bands) * TH;
+    const int tid = threadIdx.x, ty = tid / W, tx = tid % W;
+    const int PW = W + 2 * R, PH = TH + 2 * R;       // staged pixels per row / rows
+    float acc[NOUT];
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
+    const int K = KS * KS * C;
+    // staged pieces of this thread (16 bytes each; at most 13 for the 6 x 66 band of a 64-wide image), fetched one slice ahead
+    constexpr int MAXP = 13;
+    const int npiece = PH * PW * 8;
+    float4 pre[MAXP];
+    auto fetch = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const int i = tid + 256 * j;
+            pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < npiece) {
+                const int piece = i & 7, px = i >> 3, sy = px / PW, sx = px - sy * PW;
+                const int iy = y0 + sy - R, ix = sx - R;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                    pre[j] = *(const float4*)(x + (((size_t)b * H + iy) * W + ix) * (size_t)(2 * ldx) + 2 * c0 + 8 * piece);
+            }
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        __syncthreads();                             // the previous slice has been read
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const int i = tid + 256 * j;
+            if (i < npiece) *(float4*)(nsm + (size_t)(i >> 3) * NRW_PITCH + 16 * (i & 7)) = pre[j];
+        }
+        __syncthreads();
+        if (c0 + 32 < C) fetch(c0 + 32);             // in flight under this slice's arithmetic
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) {
+                const unsigned char* p = nsm + (size_t)((ty + dy) * PW + tx + dx) * NRW_PITCH;
+                const float* wt = w + (dy * KS + dx) * C + c0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+                    const h8v hi = *(const h8v*)(p + 32 * g), lo = *(const h8v*)(p + 32 * g + 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xv = (float)hi[e] + (float)lo[e];
+#pragma unroll
+                        for (int n = 0; n < NOUT; ++n) acc[n] = fmaf(xv, wt[n * K + 8 * g + e], acc[n]);
+                    }
+                }
+            }
+    }
+    const size_t o = (((size_t)b * H + y0 + ty) * W + tx) * NOUT;
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+        float v = acc[n] * (1.0f / PP_A_SCALE) + (bias ? bias[n] : 0.f);
+        if (residual) v += residual[o + n];
+        out[o + n] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -667,6 +745,26 @@ int pp_depth_points_nearest(const float* depth_m, int H, int W, int y1, int y2, 
         return PP_EINVAL;
     hipLaunchKernelGGL(depth_points_kernel, dim3((P * P + 255) / 256), dim3(256), 0, (hipStream_t)stream, depth_m, W, y1, y2, x1,
                        x2, P, fx, fy, cx, cy, out_pts);
+    return pp_last_launch();
+}
+
+int pp_conv_narrow_hl(const void* x_hl, int ld_x, int B, int H, int W, int C, const float* weight, const float* bias, int ksize,
+                      int n_out, const float* residual, float* out, void* stream) {
+    if (!x_hl || !weight || !out || B <= 0 || H <= 0 || C <= 0 || C % 32 != 0 || ld_x < C || ld_x % 8 != 0) return PP_EINVAL;
+    if ((W != 16 && W != 32 && W != 64) || H % (256 / W) != 0 || (ksize != 1 && ksize != 3) || (n_out != 1 && n_out != 2)) return PP_EINVAL;
+    if (((uintptr_t)x_hl % 16) != 0) return PP_EINVAL;
+    const int TH = 256 / W, R = ksize / 2;
+    const size_t lds = (size_t)(TH + 2 * R) * (W + 2 * R) * NRW_PITCH;
+    const dim3 grid((unsigned)(B * (H / TH)));
+    hipStream_t st = (hipStream_t)stream;
+#define NRW_LAUNCH(KS_, N_)                                                                                                        \
+    hipLaunchKernelGGL((conv_narrow_kernel<KS_, N_>), grid, dim3(256), lds, st, (const _Float16*)x_hl, ld_x, H, W, C, weight, bias, \
+                       residual, out)
+    if (ksize == 3 && n_out == 2) NRW_LAUNCH(3, 2);
+    else if (ksize == 3) NRW_LAUNCH(3, 1);
+    else if (n_out == 2) NRW_LAUNCH(1, 2);
+    else NRW_LAUNCH(1, 1);
+#undef NRW_LAUNCH
     return pp_last_launch();
 }
 

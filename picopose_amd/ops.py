@@ -267,8 +267,19 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     assert wp.shape[1] == ksize * ksize * cin
     Ho = (H + 2 * pad - ksize) // stride + 1
     Wo = (W + 2 * pad - ksize) // stride + 1
-    wargs = _weight_args(wp, ksize * ksize * cin)
     dev = xs.device if xs is not None else x.device
+    if (xs is not None and Cout <= 2 and ksize in (1, 3) and stride == 1 and pad == ksize // 2 and act is None and out is None
+            and not out_split and also_split is None and hl_into is None and residual2 is None and Cx % 32 == 0 and W in (16, 32, 64)
+            and H % (256 // W) == 0 and wp.dtype == torch.float32 and wp.is_contiguous()
+            and (residual is None or (residual.is_contiguous() and tuple(residual.shape) == (B, H, W, Cout)))
+            and os.environ.get("PP_CONV_NARROW", "1") != "0"):
+        # one- / two-channel predict layers of the decoder heads: a direct convolution on the operand (pp_conv_narrow_hl)
+        # instead of a GEMM tile padded from 2 to 64 columns
+        out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().pp_conv_narrow_hl(_p(xs.hl), Cx, B, H, W, Cx, _p(wp), _p(bias), ksize, Cout, _p(residual), _p(out),
+                                                _lib.stream_ptr()), "pp_conv_narrow_hl")
+        return out
+    wargs = _weight_args(wp, ksize * ksize * cin)
     presplit = xs is not None or ("B_hl" in wargs and (Cout > 64 or ksize > 1)
                                   and _can_presplit(x, ksize * ksize * cin, cin, ld_in, x.stride(0)) and B * H * W * cin < 2 ** 30)
     sargs, ret = {}, None

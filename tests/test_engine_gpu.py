@@ -287,6 +287,33 @@ def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, 
 
 
 @gpu
+@pytest.mark.parametrize("k,nout,hw,B", [(3, 2, 64, 3), (1, 1, 64, 2), (3, 2, 32, 5), (1, 1, 16, 4), (3, 1, 16, 2), (1, 2, 32, 1)])
+def test_narrow_output_convolution(monkeypatch, k, nout, hw, B, engine_precision):
+    """The one- / two-channel predict layers on an operand input (pp_conv_narrow_hl) against torch and against the GEMM
+    route they replace (PP_CONV_NARROW=0), with bias and a residual, image borders and every band of rows."""
+    if engine_precision != "f16x3":
+        pytest.skip("operand inputs exist in f16x3 mode only")
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(k * 100 + hw + nout)
+    C = 256
+    x = torch.randn(B, hw, hw, C, generator=g)
+    w = torch.randn(nout, C, k, k, generator=g) / (C * k * k) ** 0.5
+    b, res = torch.randn(nout, generator=g), torch.randn(B, hw, hw, nout, generator=g)
+    xs = ops.split_image(x.cuda())
+    wp = ops.pack_conv_weight(w.cuda())
+    got = ops.conv2d(xs, wp, b.cuda(), k, pad=k // 2, residual=res.cuda())
+    monkeypatch.setenv("PP_CONV_NARROW", "0")
+    gemm = ops.conv2d(xs, wp, b.cuda(), k, pad=k // 2, residual=res.cuda())
+    monkeypatch.delenv("PP_CONV_NARROW")
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=k // 2).permute(0, 2, 3, 1) + res.double()
+    assert got.shape == (B, hw, hw, nout)
+    _close(got, ref.float(), 1e-5)
+    _close(gemm, ref.float(), 1e-5)
+    assert float((got - gemm).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@gpu
 def test_gelu_epilogue_accuracy():
     """The GELU of the GEMM epilogue (rational erf) against torch's erf GELU: <= 2e-6 absolute on [-10, 10]."""
     from picopose_amd import ops
