@@ -210,6 +210,10 @@ int pp_split_activation(const float* x, long long batch_stride, int B, int P, in
  * group: a multiple of 8 columns into the row): the channel concatenation of operands without an fp32 concat buffer. */
 int pp_split_activation_ld(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu,
                            void* hl, int ld_h, void* stream);
+/* Second half of a split-K linear layer (a few rows against a long K — stage 2's fc1, affine_regressor.py:77: 160 x 16384 x
+ * 1024 fills 8 workgroups as one GEMM): part (S, M, N) fp32 = the S K-slices' products from one batched pp_gemm;
+ * out[m, n] = act(sum_s part[s, m, n] + bias[n]), slices added in index order. */
+int pp_sum_slices(const float* part, int S, int M, int N, const float* bias, int act, float* out, void* stream);
 /* Columns col0 .. col0 + c - 1 (any alignment, c <= 64) of every row of an existing hl operand with rows of ld_h channels
  * <- x (rows, c) fp32 with row pitch ld_x: the narrow member of a channel concatenation (raft_decoder.py:161, [out | flow]). */
 int pp_hl_patch_columns(const float* x, int ld_x, int c, long long rows, void* hl, int ld_h, int col0, void* stream);

@@ -2404,6 +2404,23 @@ int pp_split_activation_ld(const float* x, long long batch_stride, int B, int P,
     return pp_last_launch();
 }
 
+// Second half of a split-K linear layer: out[m, n] = act(sum_s part[s, m, n] + bias[n]) (fixed summation order s = 0, 1, ...)
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ part, int S, long long mn, int N,
+                                                         const float* __restrict__ bias, int act, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mn) return;
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += part[(long long)s * mn + i];
+    out[i] = act_apply(v + (bias ? bias[i % N] : 0.f), act);
+}
+
+int pp_sum_slices(const float* part, int S, int M, int N, const float* bias, int act, float* out, void* stream) {
+    if (!part || !out || S <= 0 || M <= 0 || N <= 0 || act < 0 || act > PP_ACT_TANH) return PP_EINVAL;
+    const long long mn = (long long)M * N;
+    hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, S, mn, N, bias, act, out);
+    return pp_last_launch();
+}
+
 // A few columns of an existing hl operand (channel concatenation with a narrow tensor: the flow decoder's [out_net | flow],
 // raft_decoder.py:161): columns col0 .. col0 + c - 1 of every row <- x[row][0 .. c-1]; any alignment, one element per thread.
 __global__ __launch_bounds__(256) void hl_patch_kernel(const float* __restrict__ x, int ld_x, int c, long long rows, _Float16* __restrict__ hl,

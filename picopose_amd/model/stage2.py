@@ -50,7 +50,8 @@ class AffineRegressor(Packed):
             h = ops.groupnorm(h, getattr(f, "1").weight, getattr(f, "1").bias, 32, relu=True)
             h = ops.conv2d(h, pk["c3"], None, 3, stride=2, pad=1)
             h = ops.groupnorm(h, getattr(f, "4").weight, getattr(f, "4").bias, 32, relu=True)
-            h = ops.linear(h.view(B, -1), pk["fc1"], self.fc1.bias, act="leaky01")
+            # fc1: B rows x 16384 x 1024 — split along K into 32 slices that run as one batched GEMM (ops.linear_splitk)
+            h = ops.linear_splitk(h.view(B, -1), pk["fc1"], self.fc1.bias, act="leaky01")
             h = ops.linear(h, self.fc2.weight, self.fc2.bias, act="leaky01")
             translation = self._mlp(self.translation_predictor, h)
             scale = self._mlp(self.scale_predictor, h)

@@ -184,6 +184,20 @@ def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, 
     return ret
 
 
+def linear_splitk(x, weight, bias=None, act=None, slices=32):
+    """act(x @ weight.T + bias) for a FEW rows against a long K (stage 2's fc1: 160 x 16384 x 1024 is 8 tiles as one GEMM):
+    the K axis is cut into `slices` equal parts that run as ONE batched GEMM (slices x more workgroups) and are then added in
+    index order.  The same slicing whatever the number of rows, so a row's result does not depend on the batch it is in."""
+    M, K = x.shape
+    N = weight.shape[0]
+    assert x.is_contiguous() and weight.is_contiguous() and weight.shape[1] == K and K % slices == 0 and (K // slices) % 8 == 0
+    kc = K // slices
+    part = bmm_nt(x.view(M, slices, kc).permute(1, 0, 2)[None], weight.view(N, slices, kc).permute(1, 0, 2)[None])
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().pp_sum_slices(_p(part), slices, M, N, _p(bias), ACT[act], _p(out), _lib.stream_ptr()), "pp_sum_slices")
+    return out
+
+
 def bmm_nt(a, b, alpha=1.0, out=None):
     """out[z0,z1] = alpha * a[z0,z1] @ b[z0,z1].T for 4-D strided views (Z0,Z1,M,K) x (Z0,Z1,N,K)."""
     Z0, Z1, M, K = a.shape
