@@ -190,7 +190,9 @@ def linear_splitk(x, weight, bias=None, act=None, slices=32):
     index order.  The same slicing whatever the number of rows, so a row's result does not depend on the batch it is in."""
     M, K = x.shape
     N = weight.shape[0]
-    assert x.is_contiguous() and weight.is_contiguous() and weight.shape[1] == K and K % slices == 0 and (K // slices) % 8 == 0
+    assert x.is_contiguous() and weight.is_contiguous() and weight.shape[1] == K
+    if K % slices != 0 or (K // slices) % 8 != 0:
+        return linear(x, weight, bias, act=act)
     kc = K // slices
     part = bmm_nt(x.view(M, slices, kc).permute(1, 0, 2)[None], weight.view(N, slices, kc).permute(1, 0, 2)[None])
     out = torch.empty(M, N, dtype=torch.float32, device=x.device)
