@@ -281,7 +281,11 @@ def _cal_arrays(cal):
             **{f"cal_affine_{h}": np.array([g, *shift], np.float64) for h, (g, shift) in cal["affine"].items()}}
 
 
-def gen_e2e_calibrated():
+E2E_CAL_CASES = {"vits_b2n4": ("dinov2_vits14", 2, 4, 3, 41), "vitb_b1n3": ("dinov2_vitb14", 1, 3, 2, 42),
+                 "vitl_b1n2": ("dinov2_vitl14", 1, 2, 1, 43)}   # the last one: the backbone of BASELINE configs[4] / config/base.yaml
+
+
+def gen_e2e_calibrated(only=None):
     """Reference Net.forward (eval) with CALIBRATED heads and the dome geometry (tests/netcfg.dome_points): about half of
     the 4096 key-point slots are valid per hypothesis, so the network -> key-points -> PnP chain is compared on realistic
     occupancy.  ViT-S (B=2, N=4, hyp 3) and ViT-B (B=1, N=3, hyp 2: the 12-head / K=768/3072 shapes of
@@ -302,8 +306,14 @@ def gen_e2e_calibrated():
     from netcfg import make_end_points
 
     out = {}
+    path = os.path.join(OUT, "e2e_calibrated.npz")
+    if only is not None:   # add / refresh some cases, keep the stored arrays of the others
+        old = np.load(path)
+        out = {k: old[k] for k in old.files if k.split("/")[0] not in only}
     with torch.no_grad():
-        for tag, (vit, B, N, hyp, seed) in {"vits_b2n4": ("dinov2_vits14", 2, 4, 3, 41), "vitb_b1n3": ("dinov2_vitb14", 1, 3, 2, 42)}.items():
+        for tag, (vit, B, N, hyp, seed) in E2E_CAL_CASES.items():
+            if only is not None and tag not in only:
+                continue
             net = ref_picopose.Net(_cfg(vit)).eval()
             cal = dict(HEAD_CALIBRATION[vit], affine=AFFINE_CALIBRATION, proj_bn=PROJ_BN_GAIN)
             net.load_state_dict(apply_head_calibration(seeded_state_dict(net.state_dict(), 4), cal))
@@ -321,8 +331,12 @@ def gen_e2e_calibrated():
                     if key in ("tar_pts_2d", "src_pts_3d"):   # pure functions of the inputs (a permute of real_pts2d / the
                         continue                              # selected template's dome): rebuilt by the test, not stored
                     out[f"{tag}/h{k}/{key}"] = val.numpy()
-    np.savez_compressed(os.path.join(OUT, "e2e_calibrated.npz"), **out)
+    np.savez_compressed(path, **out)
     print("calibrated e2e fixtures written")
+
+
+def gen_e2e_calibrated_vitl():
+    gen_e2e_calibrated(only=("vitl_b1n2",))
 
 
 def gen_vit_wide():
@@ -595,7 +609,7 @@ def gen_train_forward():
 
 GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry, "nets": gen_nets, "e2e": gen_e2e,
               "e2e_calibrated": gen_e2e_calibrated, "vit_wide": gen_vit_wide, "state_dict": gen_state_dict,
-              "preprocess": gen_preprocess, "run_test": gen_run_test, "train_forward": gen_train_forward}
+              "preprocess": gen_preprocess, "run_test": gen_run_test, "train_forward": gen_train_forward, "e2e_calibrated_vitl": gen_e2e_calibrated_vitl}
 
 
 if __name__ == "__main__":

@@ -158,8 +158,9 @@ def test_infer_image_walks_instances_like_run_test():
 
 
 # ---- calibrated heads + dome geometry: the network -> key-points -> PnP chain on realistic occupancy ---------------------
-CAL_CASES = ["vits_b2n4", "vitb_b1n3"]
-VIT_CFG = {"dinov2_vits14": (384, 6, [[0, 2], [3, 5], [6, 8], [9, 11]]), "dinov2_vitb14": (768, 12, [[0, 2], [3, 5], [6, 8], [9, 11]])}
+CAL_CASES = ["vits_b2n4", "vitb_b1n3", "vitl_b1n2"]   # the last: ViT-L/14, the backbone of configs[4] / config/base.yaml
+VIT_CFG = {"dinov2_vits14": (384, 6, [[0, 2], [3, 5], [6, 8], [9, 11]]), "dinov2_vitb14": (768, 12, [[0, 2], [3, 5], [6, 8], [9, 11]]),
+           "dinov2_vitl14": (1024, 16, [[0, 5], [6, 11], [12, 17], [18, 23]])}
 
 
 def _vit_cfg(vit):
