@@ -15,7 +15,6 @@ Pinned by tests/golden/train_forward.npz: outputs of the reference's own `Net.fo
 gen_train_forward).  The reference evaluates several quirks literally and so does this file: grid "x" is the slowly varying
 coordinate; key-points are truncated to integer pixels before they are mapped back to the image; the visibility test compares
 re-projected points in CROP pixels with grid points in IMAGE pixels against a 1000-pixel threshold."""
-import math
 
 import numpy as np
 import torch
