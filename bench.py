@@ -67,8 +67,14 @@ WORKLOADS = {
     "full_b64_n64_vitl": ("full", 64, 64, "dinov2_vitl14",
                           "one rank's share of configs[4]: batch 64, 64 of the 512 templates (fp16 bank), ViT-L/14, stage1+2+3 + PnP/RANSAC, hyp 5, 224x224 "
                           "(256x256 is not a multiple of the 14-pixel patch: the reference asserts, patch_embed.py:73-74)"),
+    # ... and configs[4] at its full size on ONE GPU (the 17 GB fp16 bank of all 512 templates x 64 crops is resident: everything
+    # of that configuration except the 8-way sharding)
+    "stage1_b64_n512_c1024_f16bank": ("stage1", 64, 512, "dinov2_vitl14",
+                                      "configs[4] stage-1 shape on one GPU: 64 crops x 512 templates, ViT-L/14 width, bank stored fp16 (17.2 GB)"),
+    "full_b64_n512_vitl": ("full", 64, 512, "dinov2_vitl14",
+                           "configs[4] unsharded on one GPU: batch 64, 512 templates (fp16 bank), ViT-L/14, stage1+2+3 + PnP/RANSAC, hyp 5, 224x224"),
 }
-FP16_BANK = {"stage1_b64_n64_c1024_f16bank", "full_b64_n64_vitl"}   # workloads whose template feature bank is stored fp16
+FP16_BANK = {"stage1_b64_n64_c1024_f16bank", "full_b64_n64_vitl", "stage1_b64_n512_c1024_f16bank", "full_b64_n512_vitl"}   # workloads whose template feature bank is stored fp16
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a read-only probe reaches 6.2-6.4 TB/s
 MFMA_F32_PEAK_TF = 157.3   # dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16 MFMA peak (v_mfma_f32_32x32x16_f16), MI355X_MICROARCH.md
