@@ -1202,6 +1202,7 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_f16x3g_kernel(const PpGemmDesc
 // other; a wave's 128x64 block also needs 0.5 fragment reads per MFMA instead of 0.67.  Dense A only.  LDS row r holds
 // its four 16-byte chunks at positions c ^ ((r >> 2) & 3) (conflict-free ds_read_b128, applied to the DMA source side).
 // Same K order and accumulation as every other pre-split kernel.
+__device__ __forceinline__ void tile_rc(int t, int gx, int gy, int& r, int& c);
 constexpr int D_KT = 16, D_ROWH = 32;                          // halfs per LDS row: 16 k x (hi, lo) = 64 bytes
 constexpr int D_A_H = GBM * D_ROWH, D_B_H = GBN * D_ROWH;
 constexpr int D_STAGE = D_A_H + D_B_H;                         // 12288 halfs = 24 KB
@@ -1216,7 +1217,9 @@ __global__ __launch_bounds__(256, 2) void pp_gemm_f16x3d_kernel(const PpGemmDesc
     const int nwg = gx * gy, orig = blockIdx.x;
     const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int m0 = (wg / gx) * GBM, n0 = (wg % gx) * GBN;
+    int tr_, tc_;   // bands of 4 tile rows x groups of <= 8 tile columns (tile_rc): the 64 workgroups resident on an XCD share
+    tile_rc(wg, gx, gy, tr_, tc_);   // 4 A row slices and 8 B column slices instead of 3.5 rows x the whole width of B (within
+    const int m0 = tr_ * GBM, n0 = tc_ * GBN;   // 1 % of plain row-major order in an A/B on the ViT-B linears)
     const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
 
