@@ -300,11 +300,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
         }
         float mx = -INFINITY;
+        if (k0 + KC <= Tm) {   // (uniform) a full chunk — every chunk when T - tail is a multiple of 32, as for T = 257: no key masks
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            sacc[e] = key < Tm ? sacc[e] * S_DESCALE : -INFINITY;
-            mx = fmaxf(mx, sacc[e]);
+            for (int e = 0; e < 16; ++e) {
+                sacc[e] *= S_DESCALE;
+                mx = fmaxf(mx, sacc[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                sacc[e] = key < Tm ? sacc[e] * S_DESCALE : -INFINITY;
+                mx = fmaxf(mx, sacc[e]);
+            }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mnew = fmaxf(mrun, mx);
