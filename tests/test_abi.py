@@ -34,6 +34,18 @@ def test_argument_validation_needs_no_gpu():
     # null pointers / unsupported channel count are rejected before any HIP call
     assert L.pp_stage1_scores(None, None, None, 224, 224, 1, 1, 64, 1, 0.0, None, 0, None, None, None) == -1
     assert L.pp_topk(None, 1, 4, 2, None, None, None) == -1
+    # the entry points added for the training forward, the narrow predict layers and the operand-side helpers
+    assert L.pp_train_keypoints_workspace_bytes(0) == 0 and L.pp_train_keypoints_workspace_bytes(2) > 2 * 4096 * 24
+    assert L.pp_train_keypoints(*([None] * 2), 224, 224, *([None] * 2), 480, 640, *([None] * 10), 2, None, None, None, 0, None) == -1
+    assert L.pp_batchnorm_train_workspace_bytes(1000, 256) >= 4 * 256 * 16
+    assert L.pp_batchnorm_train(None, None, None, 10, 256, 1e-5, 0.1, None, None, 0, None, None, None, None, 0, None) == -1
+    assert L.pp_gather_normalize_rows(None, 64, None, 4, 64, 1e-12, None, None) == -1
+    assert L.pp_xent_diag_rows(None, 4, 4, 10.0, None, None) == -1
+    assert L.pp_flow_loss_blocks() > 0 and L.pp_flow_loss_sums(None, None, None, 2, 16, 16, 400.0, None, None) == -1
+    assert L.pp_conv_narrow_hl(None, 256, 1, 64, 64, 256, None, None, 3, 2, None, None, None) == -1
+    assert L.pp_corr_lookup_nhwc_hl(None, 256, None, None, None, 1, None, 1, 64, 64, 256, 3, 2, 2, None, 80, None) == -1
+    assert L.pp_hl_patch_columns(None, 2, 2, 10, None, 640, 638, None) == -1
+    assert L.pp_sum_slices(None, 32, 160, 1024, None, 3, None, None) == -1
 
 
 def test_state_dict_names_shapes_equal_the_reference(golden_dir):
