@@ -1359,6 +1359,133 @@ __global__ __launch_bounds__(256, 2) void pp_gemm_f16x3d_kernel(const PpGemmDesc
 #endif
 }
 
+// Three workgroups per CU ("e", cfg 8): the same scheme on a 128x128 tile (4 waves, 2 x 2, 64x64 each; ring of 3 x 16 KB) for
+// dense problems whose 256-row tiling leaves the chip badly filled (the query-side ViT GEMMs, M = 8 224: 3.09 waves of 256x128
+// tiles) — twice the tiles, 768 resident workgroups.  Same K order and accumulation as every other pre-split kernel.
+constexpr int EBM = 128, EBN = 128;
+constexpr int E_A_H = EBM * D_ROWH, E_B_H = EBN * D_ROWH;
+constexpr int E_STAGE = E_A_H + E_B_H;                         // 8192 halfs = 16 KB
+constexpr int E_LDS_BYTES = D_STAGES * E_STAGE * 2;            // 48 KB: three workgroups in the 160 KB of a CU
+
+__global__ __launch_bounds__(256, 3) void pp_gemm_f16x3e_kernel(const PpGemmDesc d, int gx, int gy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
+    const int nwg = gx * gy, orig = blockIdx.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    int tr_, tc_;
+    tile_rc(wg, gx, gy, tr_, tc_);
+    const int m0 = tr_ * EBM, n0 = tc_ * EBN;
+    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
+    // DMA slots: instruction q (0, 1) of wave w fills rows (q*4 + w)*16 + (lane >> 2) of A and of B; chunk swizzle as above
+    const int lr = lane >> 2;
+    const int sc = (lane & 3) ^ ((lr >> 2) & 3);
+    int kcur = (sc >> 1) * 8;
+    unsigned aoff[2], boff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + (j * 4 + w) * 16 + lr, nb = n0 + (j * 4 + w) * 16 + lr;
+        aoff[j] = m < d.M ? (unsigned)((long long)m * d.lda * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
+        boff[j] = nb < d.N ? (unsigned)((long long)nb * d.ldb * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
+    }
+    auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
+        const unsigned off = aoff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * E_STAGE + ((j * 4 + w) * 16) * D_ROWH), 16, off, 0, 0, 0);
+    };
+    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
+        const unsigned off = boff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * E_STAGE + E_A_H + ((j * 4 + w) * 16) * D_ROWH), 16, off, 0, 0, 0);
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            aoff[j] = aoff[j] == 0xFFFFFFFFu ? aoff[j] : aoff[j] + 4 * D_KT;
+            boff[j] = boff[j] == 0xFFFFFFFFu ? boff[j] : boff[j] + 4 * D_KT;
+        }
+        kcur += D_KT;
+    };
+    auto fetch = [&](int stage) __attribute__((always_inline)) {
+        dma_a(stage, 0);
+        dma_a(stage, 1);
+        dma_b(stage, 0);
+        dma_b(stage, 1);
+        advance();
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int sw = (l31 >> 2) & 3;
+    const int ch = ((lh * 2) ^ sw) * 8, cl = ((lh * 2 + 1) ^ sw) * 8;
+    const int arow = (wr * 64 + l31) * D_ROWH, brow = E_A_H + (wc * 64 + l31) * D_ROWH;
+    struct Frag {
+        h8 ah[2], al[2], bh[2], bl[2];
+    };
+    auto mma1 = [&](const Frag& f, int i, int j) __attribute__((always_inline)) {
+        acc[i][j] = pp_mfma(f.al[i], f.bh[j], acc[i][j]);
+        acc[i][j] = pp_mfma(f.ah[i], f.bl[j], acc[i][j]);
+        acc[i][j] = pp_mfma(f.ah[i], f.bh[j], acc[i][j]);
+    };
+    const int nk = (d.K + D_KT - 1) / D_KT;
+    fetch(0);
+    fetch(1);
+    fetch(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frag fa, fb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        fa.ah[i] = *(const h8*)(glds + arow + i * 32 * D_ROWH + ch);
+        fa.al[i] = *(const h8*)(glds + arow + i * 32 * D_ROWH + cl);
+        fa.bh[i] = *(const h8*)(glds + brow + i * 32 * D_ROWH + ch);
+        fa.bl[i] = *(const h8*)(glds + brow + i * 32 * D_ROWH + cl);
+    }
+    int cur = 0, nxt = 1;
+#define PP_E_TILE(F, G)                                                                      \
+    {                                                                                        \
+        mma1(F, 0, 0);                                                                       \
+        mma1(F, 0, 1);                                                                       \
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                          \
+        __builtin_amdgcn_s_barrier();                                                        \
+        const _Float16* st = glds + nxt * E_STAGE;                                           \
+        dma_a(cur, 0);                                                                       \
+        G.ah[0] = *(const h8*)(st + arow + ch);                                              \
+        G.al[0] = *(const h8*)(st + arow + cl);                                              \
+        mma1(F, 1, 0);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        dma_a(cur, 1);                                                                       \
+        G.bh[0] = *(const h8*)(st + brow + ch);                                              \
+        G.bl[0] = *(const h8*)(st + brow + cl);                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        dma_b(cur, 0);                                                                       \
+        G.ah[1] = *(const h8*)(st + arow + 32 * D_ROWH + ch);                                \
+        G.al[1] = *(const h8*)(st + arow + 32 * D_ROWH + cl);                                \
+        mma1(F, 1, 1);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        dma_b(cur, 1);                                                                       \
+        advance();                                                                           \
+        G.bh[1] = *(const h8*)(st + brow + 32 * D_ROWH + ch);                                \
+        G.bl[1] = *(const h8*)(st + brow + 32 * D_ROWH + cl);                                \
+        cur = nxt;                                                                           \
+        nxt = nxt == D_STAGES - 1 ? 0 : nxt + 1;                                             \
+    }
+    for (int kt = 0; kt < nk; kt += 2) {
+        PP_E_TILE(fa, fb)
+        if (kt + 1 < nk) PP_E_TILE(fb, fa)
+    }
+#undef PP_E_TILE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    epilogue_block<2>(d, d.alpha / (A_SCALE * d.b_scale), acc, (float*)glds + w * 32 * 68, m0 + wr * 64, n0 + wc * 64, lane);
+#endif
+}
+
 // Order in which the persistent kernels walk the output tiles: bands of 4 tile rows, inside a band column groups of
 // <= 8 tile columns, inside a group row-major.  The 32 workgroups of an XCD work on 32 consecutive tiles, i.e. on
 // ~4 tile rows x 8 tile columns: each A row slice and each B column slice missed in L2 serves 8 resp. 4 tiles (row-major
@@ -2522,7 +2649,8 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS_BYTES) == hipSuccess)
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3e_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES) == hipSuccess)
                      ? 1 : -1;
     }
     if (big_ok < 0) return PP_ELAUNCH;
@@ -2530,10 +2658,13 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     const bool h_shape = asplit && d.conv_kh == 3 && d.conv_kw == 3 && d.conv_stride == 1 && d.conv_pad == 1 && d.conv_cin % BK == 0 &&
                          d.conv_ho == d.conv_h && d.conv_wo == d.conv_w && d.conv_w >= 16 && d.conv_w <= QBM && (d.conv_w & (d.conv_w - 1)) == 0 &&
                          d.lda == d.conv_cin && d.K == 9 * d.conv_cin && d.conv_bstride == (long long)d.conv_h * d.conv_w * d.lda;
-    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA, 4: persistent LDS-DMA, 5: persistent LDS-DMA with 256x256 tiles, 6: 5 with row-shared A delivery (3x3 convolutions), 7: 256x128 LDS-DMA @2 workgroups/CU (dense)
+    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA, 4: persistent LDS-DMA, 5: persistent LDS-DMA with 256x256 tiles, 6: 5 with row-shared A delivery (3x3 convolutions), 7: 256x128 LDS-DMA @2 workgroups/CU (dense), 8: 128x128 LDS-DMA @3 workgroups/CU (dense)
         const bool narrow = cfg == 2;
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
-        if (asplit && cfg == 7) {  // two workgroups per CU, dense A
+        if (asplit && cfg == 8) {  // three workgroups per CU on 128x128 tiles, dense A
+            const int gx = (d.N + EBN - 1) / EBN, gy = (d.M + EBM - 1) / EBM;
+            hipLaunchKernelGGL(pp_gemm_f16x3e_kernel, dim3(gx * gy), dim3(256), E_LDS_BYTES, st, d, gx, gy);
+        } else if (asplit && cfg == 7) {  // two workgroups per CU, dense A
             const int gx = (d.N + GBN - 1) / GBN, gy = (d.M + GBM - 1) / GBM;
             hipLaunchKernelGGL(pp_gemm_f16x3d_kernel, dim3(gx * gy), dim3(256), D_LDS_BYTES, st, d, gx, gy);
         } else if (asplit && cfg == 6) {
@@ -2589,8 +2720,8 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     if (const char* f = getenv("PP_GEMM_FORCE_CFG")) {  // tests: pin one kernel configuration (3 needs pre-split operands)
         const int fc = atoi(f);
         const bool p_ok = asplit && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
-        if (fc == 7 && asplit) {   // two workgroups per CU (dense A), else the plain LDS-DMA kernel
-            launch(d.conv_kh == 0 && d.K >= 3 * D_KT ? 7 : 3);
+        if ((fc == 7 || fc == 8) && asplit) {   // two / three workgroups per CU (dense A), else the plain LDS-DMA kernel
+            launch(d.conv_kh == 0 && d.K >= 3 * D_KT ? fc : 3);
             return pp_last_launch();
         }
         if (fc == 6 && asplit) {   // the row-shared kernel where the shape allows it, else the 256x256 / 256x128 persistent ones
@@ -2622,17 +2753,20 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             const bool big = asplit && (long long)((d.M + GBM - 1) / GBM) * ((d.N + GBN - 1) / GBN) >= cus / 2;
             const bool p_ok = big && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
             const bool q_ok = p_ok && d.N > 128 && (long long)((d.M + QBM - 1) / QBM) * ((d.N + QBN - 1) / QBN) >= cus / 2;
-            int cands[8], nc = 0;
-            for (int c = 0; c < (asplit ? 7 : (vec ? 3 : 2)); ++c) {
+            int cands[9], nc = 0;
+            // (cfg 8, the 128x128 three-per-CU kernel: dense problems of at least half a chip of its tiles)
+            const bool e_ok = asplit && d.conv_kh == 0 && d.K >= 3 * D_KT &&
+                              (long long)((d.M + EBM - 1) / EBM) * ((d.N + EBN - 1) / EBN) >= cus / 2;
+            for (int c = 0; c < (asplit ? 8 : (vec ? 3 : 2)); ++c) {
                 const int cand = asplit ? (c == 0 ? 0 : c == 1 ? 2 : c + 1) : (vec ? c : (c == 0 ? 0 : 2));
                 if ((cand == 3 && !big) || (cand == 4 && !p_ok) || (cand == 5 && !q_ok) || (cand == 6 && !(q_ok && h_shape)) ||
-                    (cand == 7 && !(big && d.conv_kh == 0 && d.K >= 3 * D_KT))) continue;
+                    (cand == 7 && !(big && d.conv_kh == 0 && d.K >= 3 * D_KT)) || (cand == 8 && !e_ok)) continue;
                 cands[nc++] = cand;
             }
             // Round-robin: every round times one burst of four back-to-back launches of EACH candidate, and a candidate keeps
             // its best burst.  (Timing the candidates one after the other ranked them by the clock the chip happened to hold:
             // the first ones ran on a cool chip, and configurations within ~5-10 % changed places from run to run.)
-            float ms[8];
+            float ms[9];
             for (int i = 0; i < nc; ++i) {
                 ms[i] = 1e30f;
                 launch(cands[i]);  // warm

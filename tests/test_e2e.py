@@ -314,10 +314,10 @@ def test_hip_forward_vs_reference_calibrated_exact_mode(golden_dir, tag):
 
 
 @gpu
-@pytest.mark.parametrize("cfg", ["4", "5", "6", "7"])
+@pytest.mark.parametrize("cfg", ["4", "5", "6", "7", "8"])
 def test_hip_forward_vitb_with_pinned_persistent_kernels(golden_dir, monkeypatch, cfg):
     """The ViT-B net-vs-reference comparison with every pre-split GEMM / conv forced onto the persistent 256x128 (cfg 4),
-    256x256 (cfg 5), row-shared 3x3 (cfg 6) and two-workgroups-per-CU (cfg 7, dense layers) kernels — the kernels the
+    256x256 (cfg 5), row-shared 3x3 (cfg 6) and two- / three-workgroups-per-CU (cfg 7 / 8, dense layers) kernels — the kernels the
     headline bench runs — instead of the autotuner's pick."""
     monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
     z, B, N, hyp, ref, ep, dev, outs, flow, cert = _hip_calibrated_forward(golden_dir, "vitb_b1n3")

@@ -276,7 +276,7 @@ def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, 
     wc = ops.pack_conv_weight((torch.randn(256, 64, 3, 3, generator=g) / 24).cuda())
     x2, w2 = torch.randn(1300, 392, generator=g).cuda(), (torch.randn(200, 392, generator=g) / 20).cuda()   # K % 16 == 8, row / column tails
     outs = []
-    for cfg in ("0", "2", "3", "4", "5", "6", "7"):
+    for cfg in ("0", "2", "3", "4", "5", "6", "7", "8"):
         monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
         outs.append((ops.linear(x, w, b, act="gelu"), ops.conv2d(xi, wc, None, 3, pad=1, act="relu"), ops.linear(x2, w2, None, residual=None)))
     for lin, conv, lin2 in outs[1:]:

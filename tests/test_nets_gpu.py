@@ -132,7 +132,7 @@ def test_offset_regressor_vs_reference_golden(golden_dir):
 
 @gpu
 @pytest.mark.parametrize("vit", ["dinov2_vitb14", "dinov2_vitl14"])
-@pytest.mark.parametrize("force", [None, "4", "5", "7"])
+@pytest.mark.parametrize("force", [None, "4", "5", "7", "8"])
 def test_feature_extractor_vs_reference_golden_vitb_vitl(golden_dir, monkeypatch, vit, force):
     """FeatureExtractor at the widths of BASELINE configs[2] (ViT-B/14) and config/base.yaml (ViT-L/14) against the
     reference's outputs (tests/golden/vit_wide.npz) — with the autotuner's kernels, and with every pre-split GEMM pinned
