@@ -1209,6 +1209,8 @@ constexpr int D_STAGE = D_A_H + D_B_H;                         // 12288 halfs = 
 constexpr int D_STAGES = 3;
 constexpr int D_LDS_BYTES = D_STAGES * D_STAGE * 2;            // 72 KB: two workgroups in the 160 KB of a CU
 
+// MODE 0: dense A; 1: convolution, channel-slice-major K order (Cin % 32 == 0): a K tile of 16 is half of one tap's 32-channel slice
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void pp_gemm_f16x3d_kernel(const PpGemmDesc d, int gx, int gy) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
@@ -1229,10 +1231,27 @@ __global__ __launch_bounds__(256, 2) void pp_gemm_f16x3d_kernel(const PpGemmDesc
     const int sc = (lane & 3) ^ ((lr >> 2) & 3);
     int kcur = (sc >> 1) * 8;
     unsigned aoff[4], boff[2];  // byte offsets of this lane's chunks (0xFFFFFFFF: row past M / N -> zeros)
+    unsigned vmask[4] = {0u, 0u, 0u, 0u};   // MODE 1: bit t = tap t of A row j lies inside the image
+    int ctap = 0, cky = 0, ckx = 0, cci = 0, chalf = 0;   // MODE 1 (wave-uniform): tap / channel slice / half of the next K tile
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + (j * 4 + w) * 16 + lr;
-        aoff[j] = m < d.M ? (unsigned)((long long)m * d.lda * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
+        if (MODE == 0) {
+            aoff[j] = m < d.M ? (unsigned)((long long)m * d.lda * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
+        } else {
+            long long abase = 0;
+            if (m < d.M) {
+                const int per = d.conv_ho * d.conv_wo;
+                const int bi = m / per, r = m - bi * per;
+                const int oy = (r / d.conv_wo) * d.conv_stride - d.conv_pad, ox = (r % d.conv_wo) * d.conv_stride - d.conv_pad;
+                abase = (long long)bi * d.conv_bstride + ((long long)oy * d.conv_w + ox) * d.lda;
+                for (int t = 0; t < d.conv_kh * d.conv_kw; ++t) {
+                    const int iy = oy + t / d.conv_kw, ix = ox + t % d.conv_kw;
+                    if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) vmask[j] |= 1u << t;
+                }
+            }
+            aoff[j] = (unsigned)(abase * 4) + (unsigned)sc * 16u;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1240,14 +1259,38 @@ __global__ __launch_bounds__(256, 2) void pp_gemm_f16x3d_kernel(const PpGemmDesc
         boff[j] = nb < d.N ? (unsigned)((long long)nb * d.ldb * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
     }
     auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
-        const unsigned off = aoff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+        unsigned off;
+        if (MODE == 0) {
+            off = aoff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+        } else {   // (bitwise selects, no branches: the K loop body stays one basic block)
+            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci + D_KT * chalf) * 4);
+            const unsigned ok = (vmask[j] >> ctap) & (cci < d.conv_cin ? 1u : 0u);
+            off = (aoff[j] + tapoff) | (ok - 1u);
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * D_STAGE + ((j * 4 + w) * 16) * D_ROWH), 16, off, 0, 0, 0);
     };
     auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
-        const unsigned off = boff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+        unsigned off;
+        if (MODE == 0) {
+            off = boff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+        } else {
+            const unsigned ok = (cci < d.conv_cin ? 1u : 0u) & (boff[j] != 0xFFFFFFFFu ? 1u : 0u);
+            off = (boff[j] + (unsigned)((ctap * d.conv_cin + cci + D_KT * chalf) * 4)) | (ok - 1u);
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * D_STAGE + D_A_H + ((j * 4 + w) * 16) * D_ROWH), 16, off, 0, 0, 0);
     };
     auto advance = [&]() __attribute__((always_inline)) {
+        if (MODE == 1) {   // (tap, 32-channel slice) in channel-slice-major order, two 16-channel halves per tap
+            const bool tap_next = chalf == 1;
+            const bool row_end = ckx + 1 == d.conv_kw, tap_end = row_end && cky + 1 == d.conv_kh;
+            chalf ^= 1;
+            cci = tap_next && tap_end ? cci + BK : cci;
+            ctap = !tap_next ? ctap : (tap_end ? 0 : ctap + 1);
+            const int nky = tap_end ? 0 : (row_end ? cky + 1 : cky), nkx = row_end ? 0 : ckx + 1;
+            cky = tap_next ? nky : cky;
+            ckx = tap_next ? nkx : ckx;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) aoff[j] = aoff[j] == 0xFFFFFFFFu ? aoff[j] : aoff[j] + 4 * D_KT;
 #pragma unroll
@@ -1367,6 +1410,7 @@ constexpr int E_A_H = EBM * D_ROWH, E_B_H = EBN * D_ROWH;
 constexpr int E_STAGE = E_A_H + E_B_H;                         // 8192 halfs = 16 KB
 constexpr int E_LDS_BYTES = D_STAGES * E_STAGE * 2;            // 48 KB: three workgroups in the 160 KB of a CU
 
+template <int MODE>
 __global__ __launch_bounds__(256, 3) void pp_gemm_f16x3e_kernel(const PpGemmDesc d, int gx, int gy) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
@@ -1385,21 +1429,62 @@ __global__ __launch_bounds__(256, 3) void pp_gemm_f16x3e_kernel(const PpGemmDesc
     const int sc = (lane & 3) ^ ((lr >> 2) & 3);
     int kcur = (sc >> 1) * 8;
     unsigned aoff[2], boff[2];
+    unsigned vmask[2] = {0u, 0u};
+    int ctap = 0, cky = 0, ckx = 0, cci = 0, chalf = 0;   // MODE 1: as in the two-per-CU kernel above
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = m0 + (j * 4 + w) * 16 + lr, nb = n0 + (j * 4 + w) * 16 + lr;
-        aoff[j] = m < d.M ? (unsigned)((long long)m * d.lda * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
+        if (MODE == 0) {
+            aoff[j] = m < d.M ? (unsigned)((long long)m * d.lda * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
+        } else {
+            long long abase = 0;
+            if (m < d.M) {
+                const int per = d.conv_ho * d.conv_wo;
+                const int bi = m / per, r = m - bi * per;
+                const int oy = (r / d.conv_wo) * d.conv_stride - d.conv_pad, ox = (r % d.conv_wo) * d.conv_stride - d.conv_pad;
+                abase = (long long)bi * d.conv_bstride + ((long long)oy * d.conv_w + ox) * d.lda;
+                for (int t = 0; t < d.conv_kh * d.conv_kw; ++t) {
+                    const int iy = oy + t / d.conv_kw, ix = ox + t % d.conv_kw;
+                    if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) vmask[j] |= 1u << t;
+                }
+            }
+            aoff[j] = (unsigned)(abase * 4) + (unsigned)sc * 16u;
+        }
         boff[j] = nb < d.N ? (unsigned)((long long)nb * d.ldb * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
     }
     auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
-        const unsigned off = aoff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+        unsigned off;
+        if (MODE == 0) {
+            off = aoff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+        } else {
+            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci + D_KT * chalf) * 4);
+            const unsigned ok = (vmask[j] >> ctap) & (cci < d.conv_cin ? 1u : 0u);
+            off = (aoff[j] + tapoff) | (ok - 1u);
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * E_STAGE + ((j * 4 + w) * 16) * D_ROWH), 16, off, 0, 0, 0);
     };
     auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
-        const unsigned off = boff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+        unsigned off;
+        if (MODE == 0) {
+            off = boff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
+        } else {
+            const unsigned ok = (cci < d.conv_cin ? 1u : 0u) & (boff[j] != 0xFFFFFFFFu ? 1u : 0u);
+            off = (boff[j] + (unsigned)((ctap * d.conv_cin + cci + D_KT * chalf) * 4)) | (ok - 1u);
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * E_STAGE + E_A_H + ((j * 4 + w) * 16) * D_ROWH), 16, off, 0, 0, 0);
     };
     auto advance = [&]() __attribute__((always_inline)) {
+        if (MODE == 1) {
+            const bool tap_next = chalf == 1;
+            const bool row_end = ckx + 1 == d.conv_kw, tap_end = row_end && cky + 1 == d.conv_kh;
+            chalf ^= 1;
+            cci = tap_next && tap_end ? cci + BK : cci;
+            ctap = !tap_next ? ctap : (tap_end ? 0 : ctap + 1);
+            const int nky = tap_end ? 0 : (row_end ? cky + 1 : cky), nkx = row_end ? 0 : ckx + 1;
+            cky = tap_next ? nky : cky;
+            ckx = tap_next ? nkx : ckx;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             aoff[j] = aoff[j] == 0xFFFFFFFFu ? aoff[j] : aoff[j] + 4 * D_KT;
@@ -2649,8 +2734,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess &&
                hipFuncSetAttribute((const void*)pp_gemm_f16x3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3e_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES) == hipSuccess)
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3d_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3d_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3e_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)pp_gemm_f16x3e_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES) == hipSuccess)
                      ? 1 : -1;
     }
     if (big_ok < 0) return PP_ELAUNCH;
@@ -2663,10 +2750,12 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
         if (asplit && cfg == 8) {  // three workgroups per CU on 128x128 tiles, dense A
             const int gx = (d.N + EBN - 1) / EBN, gy = (d.M + EBM - 1) / EBM;
-            hipLaunchKernelGGL(pp_gemm_f16x3e_kernel, dim3(gx * gy), dim3(256), E_LDS_BYTES, st, d, gx, gy);
+            if (d.conv_kh == 0) hipLaunchKernelGGL(pp_gemm_f16x3e_kernel<0>, dim3(gx * gy), dim3(256), E_LDS_BYTES, st, d, gx, gy);
+            else hipLaunchKernelGGL(pp_gemm_f16x3e_kernel<1>, dim3(gx * gy), dim3(256), E_LDS_BYTES, st, d, gx, gy);
         } else if (asplit && cfg == 7) {  // two workgroups per CU, dense A
             const int gx = (d.N + GBN - 1) / GBN, gy = (d.M + GBM - 1) / GBM;
-            hipLaunchKernelGGL(pp_gemm_f16x3d_kernel, dim3(gx * gy), dim3(256), D_LDS_BYTES, st, d, gx, gy);
+            if (d.conv_kh == 0) hipLaunchKernelGGL(pp_gemm_f16x3d_kernel<0>, dim3(gx * gy), dim3(256), D_LDS_BYTES, st, d, gx, gy);
+            else hipLaunchKernelGGL(pp_gemm_f16x3d_kernel<1>, dim3(gx * gy), dim3(256), D_LDS_BYTES, st, d, gx, gy);
         } else if (asplit && cfg == 6) {
             const int gx = (d.N + QBN - 1) / QBN, gy = (d.M + QBM - 1) / QBM;
             const int nt = gx * gy, g = nt < cus ? (nt + 7) / 8 * 8 : cus / 8 * 8;
@@ -2720,8 +2809,9 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     if (const char* f = getenv("PP_GEMM_FORCE_CFG")) {  // tests: pin one kernel configuration (3 needs pre-split operands)
         const int fc = atoi(f);
         const bool p_ok = asplit && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
-        if ((fc == 7 || fc == 8) && asplit) {   // two / three workgroups per CU (dense A), else the plain LDS-DMA kernel
-            launch(d.conv_kh == 0 && d.K >= 3 * D_KT ? fc : 3);
+        if ((fc == 7 || fc == 8) && asplit) {   // two / three workgroups per CU (dense, or convolutions in channel-slice-major order)
+            const bool ok = d.K >= 3 * D_KT && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
+            launch(ok ? fc : 3);
             return pp_last_launch();
         }
         if (fc == 6 && asplit) {   // the row-shared kernel where the shape allows it, else the 256x256 / 256x128 persistent ones
@@ -2755,12 +2845,13 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             const bool q_ok = p_ok && d.N > 128 && (long long)((d.M + QBM - 1) / QBM) * ((d.N + QBN - 1) / QBN) >= cus / 2;
             int cands[9], nc = 0;
             // (cfg 8, the 128x128 three-per-CU kernel: dense problems of at least half a chip of its tiles)
-            const bool e_ok = asplit && d.conv_kh == 0 && d.K >= 3 * D_KT &&
+            const bool de_conv = d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32);
+            const bool e_ok = asplit && de_conv && d.K >= 3 * D_KT &&
                               (long long)((d.M + EBM - 1) / EBM) * ((d.N + EBN - 1) / EBN) >= cus / 2;
             for (int c = 0; c < (asplit ? 8 : (vec ? 3 : 2)); ++c) {
                 const int cand = asplit ? (c == 0 ? 0 : c == 1 ? 2 : c + 1) : (vec ? c : (c == 0 ? 0 : 2));
                 if ((cand == 3 && !big) || (cand == 4 && !p_ok) || (cand == 5 && !q_ok) || (cand == 6 && !(q_ok && h_shape)) ||
-                    (cand == 7 && !(big && d.conv_kh == 0 && d.K >= 3 * D_KT)) || (cand == 8 && !e_ok)) continue;
+                    (cand == 7 && !(big && de_conv && d.K >= 3 * D_KT)) || (cand == 8 && !e_ok)) continue;
                 cands[nc++] = cand;
             }
             // Round-robin: every round times one burst of four back-to-back launches of EACH candidate, and a candidate keeps

@@ -156,6 +156,16 @@ def test_persistent_lds_dma_kernel_pinned(monkeypatch, engine_precision):
 
 
 @gpu
+@pytest.mark.parametrize("cfg", ["7", "8"])
+def test_multi_workgroup_per_cu_kernels_pinned(monkeypatch, engine_precision, cfg):
+    """Same cases on the two- (256x128 tiles, configuration 7) and three-workgroups-per-CU (128x128, configuration 8) kernels:
+    dense layers and the convolutions they cover (Cin a multiple of 32: padded / strided taps, 1x1), tails, fall-backs."""
+    if engine_precision != "f16x3":
+        pytest.skip("pre-split operands exist in f16x3 mode only")
+    _pinned_big_kernel_cases(monkeypatch, cfg)
+
+
+@gpu
 def test_persistent_256x256_kernel_pinned(monkeypatch, engine_precision):
     """Same cases on the 256x256-tile persistent kernel (configuration 5; falls back where it does not apply)."""
     if engine_precision != "f16x3":
