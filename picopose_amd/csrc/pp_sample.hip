@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
                                                    float* __restrict__ out, int ld_out) {
     const int b = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= H * W) return;
+#ifdef PP_STUDY_ACQUIRE   // (study build for tests/stress_pc.py: two processes on one GPU; see tests/dist_worker_gpu.py)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: invalidate what this CU / XCD may hold of other agents' writes
+#endif
     const int y = p / W, x = p - y * W;
     const float* fl = flow + ((size_t)b * H * W + p) * ld_flow;
     const float ix = roundtrip((float)x + fl[0], W), iy = roundtrip((float)y + fl[1], H);
