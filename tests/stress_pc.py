@@ -44,7 +44,15 @@ torch.cuda.synchronize()
 ref, fq_ref = once(); torch.cuda.synchronize(); ref, fq_ref = once(); torch.cuda.synchronize()
 ref_holder.append(ref)
 bad = 0
+side = torch.cuda.Stream() if os.environ.get("SIDE") == "1" else None    # SIDE=1: a second stream of the SAME process keeps the GPU busy
+if side is not None:
+    la = torch.randn(8192, 256, device="cuda"); lw = torch.randn(256, 256, device="cuda") / 16
+    las = ops.Split(ops.split_activation(la, 1, 8192, 256, 0, 256))
 for r in range(int(sys.argv[1]) if len(sys.argv) > 1 else 300):
+    if side is not None:
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                ops.linear(las, lw, None)
     out, fq = once()
     if not torch.equal(out, ref):
         d = out != ref
