@@ -542,7 +542,7 @@ def gen_run_test():
     print(f"run_test fixture written: {len(rows)} rows")
 
 
-def gen_train_forward():
+def gen_train_forward(name="train_forward"):
     """The REFERENCE training forward itself: `Net.forward_train` (model/picopose.py:114-137) in train mode — key-point
     sampler, both ViT passes, InfoNCE / stage-2 / flow + certainty losses, BatchNorm on batch statistics with running-buffer
     updates — and `Loss.forward` (utils/loss_utils.py:10-21), on tests/netcfg.make_train_end_points (ViT-S, B=2, calibrated
@@ -560,13 +560,14 @@ def gen_train_forward():
     from oracle.weights import AFFINE_CALIBRATION, HEAD_CALIBRATION, PROJ_BN_GAIN, apply_head_calibration, seeded_state_dict
 
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-    from netcfg import make_train_end_points
+    from netcfg import make_train_end_points, train_case
 
-    vit, B, seed, wseed = "dinov2_vits14", 2, 51, 4
+    B, seed, edit = train_case(name)
+    vit, wseed = "dinov2_vits14", 4
     net = ref_picopose.Net(_cfg(vit)).train()
     cal = dict(HEAD_CALIBRATION[vit], affine=AFFINE_CALIBRATION, proj_bn=PROJ_BN_GAIN)
     net.load_state_dict(apply_head_calibration(seeded_state_dict(net.state_dict(), wseed), cal))
-    ep = make_train_end_points(B, seed)
+    ep = edit(make_train_end_points(B, seed))
     drawn = {}
     orig = ref_picopose.aug_gtM_noise
 
@@ -599,17 +600,21 @@ def gen_train_forward():
     out["total_loss"] = tot["loss"].numpy()
     print("total", float(tot["loss"]), "valid key-points", (kp["src_pts"][..., 0] != -1).sum(1).tolist())
     sd = net.state_dict()
-    for name in ("offset_regressor.dpt_head.scratch.refinenet4.resConfUnit2.bn1", "offset_regressor.dpt_head.scratch.refinenet2.resConfUnit1.bn2",
-                 "offset_regressor.flow_decoder.proj.0.1", "offset_regressor.flow_decoder.proj.2.1"):
+    for layer in ("offset_regressor.dpt_head.scratch.refinenet4.resConfUnit2.bn1", "offset_regressor.dpt_head.scratch.refinenet2.resConfUnit1.bn2",
+                  "offset_regressor.flow_decoder.proj.0.1", "offset_regressor.flow_decoder.proj.2.1"):
         for buf in ("running_mean", "running_var", "num_batches_tracked"):
-            out[f"bn/{name}.{buf}"] = sd[f"{name}.{buf}"].numpy()
-    np.savez_compressed(os.path.join(OUT, "train_forward.npz"), **out)
-    print("training-forward fixture written")
+            out[f"bn/{layer}.{buf}"] = sd[f"{layer}.{buf}"].numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("training-forward fixture written:", name)
+
+
+def gen_train_forward_edge():
+    gen_train_forward("train_forward_edge")
 
 
 GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry, "nets": gen_nets, "e2e": gen_e2e,
               "e2e_calibrated": gen_e2e_calibrated, "vit_wide": gen_vit_wide, "state_dict": gen_state_dict,
-              "preprocess": gen_preprocess, "run_test": gen_run_test, "train_forward": gen_train_forward, "e2e_calibrated_vitl": gen_e2e_calibrated_vitl}
+              "preprocess": gen_preprocess, "run_test": gen_run_test, "train_forward": gen_train_forward, "train_forward_edge": gen_train_forward_edge, "e2e_calibrated_vitl": gen_e2e_calibrated_vitl}
 
 
 if __name__ == "__main__":

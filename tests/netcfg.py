@@ -135,3 +135,15 @@ def make_train_end_points(B, seed, poses=None):
     bite[150:, 130:] = 0
     ep["real_mask"] = bite[None].repeat(B, 1, 1)
     return ep
+
+
+def train_case(name):
+    """The synthetic training batches of the fixtures tests/golden/train_forward*.npz: (B, seed, edit) with edit(ep) applied to
+    the batch of make_train_end_points.  "edge": three pairs, the second one with an empty real mask (no correspondence at all:
+    every key-point of the pair is -1, its pixels only enter the certainty loss) and the third with a real view far off the
+    template's (few correspondences)."""
+    def edge(ep):
+        ep["real_mask"][1] = 0
+        return ep
+
+    return {"train_forward": (2, 51, lambda ep: ep), "train_forward_edge": (3, 52, edge)}[name]

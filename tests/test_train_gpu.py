@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from netcfg import make_train_end_points, small_cfg  # noqa: E402
-from test_train_oracle import LOSS_KEYS, load_train_fixture, patch_coords  # noqa: E402
+from test_train_oracle import CASES, LOSS_KEYS, load_train_fixture, patch_coords  # noqa: E402
 
 gpu = pytest.mark.gpu
 
@@ -20,13 +20,14 @@ def _cuda(ep):
 
 
 @gpu
-def test_keypoint_sampler_matches_the_reference(golden_dir):
+@pytest.mark.parametrize("name", CASES)
+def test_keypoint_sampler_matches_the_reference(golden_dir, name):
     """Integer pixel coordinates of every key-point.  The per-point arithmetic is fp32 in both, but a GEMM's summation
     order is the library's: a projection that lands within an ulp of an integer may truncate to the neighbouring pixel.
     Stated tolerance: <= 0.1 % of the entries differ, each by one pixel or by validity."""
     from picopose_amd.picopose import Net
 
-    z, ep, _, _ = load_train_fixture(golden_dir)
+    z, ep, _, _ = load_train_fixture(golden_dir, name)
     kp = Net(small_cfg()).compute_keypoint_data(_cuda(ep))
     for k in ("src_pts", "tar_pts"):
         got, ref = kp[k].cpu(), patch_coords(z[f"kp_{k}_px"])
@@ -110,8 +111,9 @@ def test_loss_kernels_agree_with_the_oracle():
 
 
 @gpu
+@pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("engine_precision", ["f16x3", "f32"])
-def test_training_forward_matches_the_reference_run(golden_dir, engine_precision, monkeypatch):
+def test_training_forward_matches_the_reference_run(golden_dir, engine_precision, monkeypatch, name):
     """Net(train mode)(end_points) vs the reference's forward_train + Loss on the same batch, weights and noisy affines:
     every loss within 1e-3 relative (fp32 networks on another summation order; the flow losses sum |flow - gt| over ~2k
     pixels), the BatchNorm running buffers within 1e-4, the eval packing rebuilt afterwards."""
@@ -120,7 +122,7 @@ def test_training_forward_matches_the_reference_run(golden_dir, engine_precision
     from picopose_amd.utils.loss_utils import Loss
 
     monkeypatch.setattr(ops, "PRECISION", engine_precision)
-    z, ep, weights, _ = load_train_fixture(golden_dir)
+    z, ep, weights, _ = load_train_fixture(golden_dir, name)
     net = Net(small_cfg())
     net.load_state_dict(weights(net.state_dict()))
     net = net.cuda().train()

@@ -5,23 +5,26 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from netcfg import HEADS, TAKE, make_train_end_points, small_cfg  # noqa: E402
+from netcfg import HEADS, TAKE, make_train_end_points, small_cfg, train_case  # noqa: E402
 
 from oracle import train as ot  # noqa: E402
 from oracle.weights import apply_head_calibration, seeded_state_dict  # noqa: E402
 
+CASES = ["train_forward", "train_forward_edge"]   # the second: a pair without any correspondence (tests/netcfg.train_case)
 LOSS_KEYS = ["loss_info", "loss_2d_trans", "loss_scale", "loss_inplane"] + [f"loss_{k}{i}" for i in range(3) for k in ("flow", "certainty")]
 
 
-def load_train_fixture(golden_dir):
-    z = np.load(os.path.join(golden_dir, "train_forward.npz"))
+def load_train_fixture(golden_dir, name="train_forward"):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
     B, seed, wseed, np_seed, torch_seed = (int(v) for v in z["meta"])
+    assert (B, seed) == train_case(name)[:2]
     cal = {"flow": [tuple(r) for r in z["cal_flow"]], "cert": [tuple(r) for r in z["cal_cert"]], "proj_bn": float(z["cal_proj_bn"]),
            "affine": {h: (float(z[f"cal_affine_{h}"][0]), tuple(z[f"cal_affine_{h}"][1:])) for h in ("translation", "scale", "inplane")}}
-    ep = make_train_end_points(B, seed, poses=(torch.from_numpy(z["real_pose"]), torch.from_numpy(z["tem_pose"])))
+    ep = train_case(name)[2](make_train_end_points(B, seed, poses=(torch.from_numpy(z["real_pose"]), torch.from_numpy(z["tem_pose"]))))
     weights = lambda template: apply_head_calibration(seeded_state_dict(template, wseed), cal)  # noqa: E731
     return z, ep, weights, (np_seed, torch_seed)
 
@@ -32,27 +35,32 @@ def patch_coords(px):
     return torch.where(p == -1, p, p / 3.5)
 
 
-def test_keypoint_sampler_is_bit_exact(golden_dir):
-    z, ep, _, _ = load_train_fixture(golden_dir)
+@pytest.mark.parametrize("name", CASES)
+def test_keypoint_sampler_is_bit_exact(golden_dir, name):
+    z, ep, _, _ = load_train_fixture(golden_dir, name)
     kp = ot.keypoint_data({k: v.clone() for k, v in ep.items()})
     for k in ("src_pts", "tar_pts"):
         assert torch.equal(kp[k], patch_coords(z[f"kp_{k}_px"])), k
     assert int((kp["src_pts"][..., 0] != -1).sum()) > 1000        # the fixture exercises the sampler
+    if name == "train_forward_edge":
+        assert bool((kp["src_pts"][1] == -1).all())                # the pair without a real mask has no correspondence
 
 
-def test_noise_draws_reproduce_the_reference_affines(golden_dir):
-    z, ep, _, (np_seed, torch_seed) = load_train_fixture(golden_dir)
+@pytest.mark.parametrize("name", CASES)
+def test_noise_draws_reproduce_the_reference_affines(golden_dir, name):
+    z, ep, _, (np_seed, torch_seed) = load_train_fixture(golden_dir, name)
     np.random.seed(np_seed)
     torch.manual_seed(torch_seed)
     M = ot.noisy_M(ot.relative_M(ep), *ot.draw_noise(ep["real_rgb"].shape[0]))
     assert np.abs(M.numpy() - z["pred_Ms"]).max() < 2e-4 * np.abs(z["pred_Ms"]).max()
 
 
-def test_training_forward_losses_and_batchnorm_buffers(golden_dir):
+@pytest.mark.parametrize("name", CASES)
+def test_training_forward_losses_and_batchnorm_buffers(golden_dir, name):
     from picopose_amd.picopose import Net
 
     torch.set_num_threads(8)
-    z, ep, weights, _ = load_train_fixture(golden_dir)
+    z, ep, weights, _ = load_train_fixture(golden_dir, name)
     sd = {k: v.clone() for k, v in weights(Net(small_cfg()).state_dict()).items()}
     with torch.no_grad():
         losses, aux = ot.net_forward_train(sd, {k: v.clone() for k, v in ep.items()}, HEADS, TAKE, torch.from_numpy(z["pred_Ms"]))
