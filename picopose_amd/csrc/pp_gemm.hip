@@ -281,9 +281,6 @@ __device__ __forceinline__ void epilogue_block(const PpGemmDesc& d, float descal
             }
         }
     }
-#ifdef PP_STUDY_END_FENCE   // (study build for tests/stress_pc.py, with -DPP_STUDY_ACQUIRE in the consumer)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope
-#endif
 }
 
 template <bool VEC4, int NJ, int OCC>

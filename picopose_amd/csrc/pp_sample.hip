@@ -98,9 +98,6 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
                                                    float* __restrict__ out, int ld_out) {
     const int b = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= H * W) return;
-#ifdef PP_STUDY_ACQUIRE   // (study build for tests/stress_pc.py: two processes on one GPU; see tests/dist_worker_gpu.py)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: invalidate what this CU / XCD may hold of other agents' writes
-#endif
     const int y = p / W, x = p - y * W;
     const float* fl = flow + ((size_t)b * H * W + p) * ld_flow;
     const float ix = roundtrip((float)x + fl[0], W), iy = roundtrip((float)y + fl[1], H);
@@ -114,10 +111,15 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
     const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
     for (int c = lane * 4; c < C; c += 256) {
         f4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (vy0 && vx0) acc += *(const f4*)(fb + ((size_t)y0 * W + x0) * C + c) * (wx0 * wy0);
-        if (vy0 && vx1) acc += *(const f4*)(fb + ((size_t)y0 * W + x0 + 1) * C + c) * (wx1 * wy0);
-        if (vy1 && vx0) acc += *(const f4*)(fb + ((size_t)(y0 + 1) * W + x0) * C + c) * (wx0 * wy1);
-        if (vy1 && vx1) acc += *(const f4*)(fb + ((size_t)(y0 + 1) * W + x0 + 1) * C + c) * (wx1 * wy1);
+        // Taps outside the image read a clamped pixel with weight 0 instead of being skipped by a lane-masked branch: same
+        // value (the skipped tap adds nothing either way) and no per-tap lane masks held in SGPR pairs across the loads.  With
+        // two busy PROCESSES on one card bits 48..63 of such masks were seen corrupted (lanes 48-63 of single waves lost taps:
+        // tests/stress_pc.py); this form ran 12 000 iterations under that load without a difference.
+        const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1), ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
+        acc += *(const f4*)(fb + ((size_t)ya * W + xa) * C + c) * (vy0 && vx0 ? wx0 * wy0 : 0.f);
+        acc += *(const f4*)(fb + ((size_t)ya * W + xb) * C + c) * (vy0 && vx1 ? wx1 * wy0 : 0.f);
+        acc += *(const f4*)(fb + ((size_t)yb * W + xa) * C + c) * (vy1 && vx0 ? wx0 * wy1 : 0.f);
+        acc += *(const f4*)(fb + ((size_t)yb * W + xb) * C + c) * (vy1 && vx1 ? wx1 * wy1 : 0.f);
         if (HL) {
             typedef _Float16 h4w __attribute__((ext_vector_type(4)));
             _Float16 h0, h1, h2, h3, l0, l1, l2, l3;

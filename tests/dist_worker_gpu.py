@@ -3,10 +3,9 @@ on two ranks that share one GPU (gloo rendezvous, every rank on cuda:0 — a one
 against the single-process forward of the same crops.
 
 The ranks take TURNS on the GPU for their local compute phases (the collectives still run between all ranks): two processes
-computing on one MI355X at the same time is not a configuration of the product (one process per GPU), and on this platform it
-is not bit-reproducible — single waves of a kernel occasionally read stale cache lines of a buffer another kernel of the same
-process has just written (tests/stress_pc.py: 2-5 % of forwards differ in a few hundred flow entries with two busy processes,
-0 of thousands with one; system-scope fences at the kernel boundaries reduce it, a device sync does not remove it)."""
+computing on one MI355X at the same time is not a configuration of the product (one process per GPU), and on this platform
+lane masks a kernel holds in SGPRs were seen corrupted under that load (the warp kernel lost taps in lanes 48-63 of
+single waves until it was rewritten without lane-masked branches; tests/stress_pc.py, tests/stress_two.sh)."""
 import os
 import sys
 

@@ -1,5 +1,8 @@
 """Producer -> consumer under two-process contention: a 1x1 convolution (GEMM epilogue writes fp32 + operand) followed at once by the
-warp kernel reading its fp32 output; the warp result is compared bit for bit with a reference computed after a device sync."""
+warp kernel reading its fp32 output; the warp result is compared bit for bit with a reference.  Start two of these at once.
+History: with the warp kernel's taps behind lane-masked branches 2-5 % of the iterations differed (lanes 48-63 of single
+waves lost taps) whatever the producer (CFG, PRODUCER=torch), less with SYNC=1; without those branches none do.  JUNK / SIDE /
+RECHECK are the variants that were used to rule out stale cache lines, stream concurrency and read glitches."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from picopose_amd import ops

@@ -1,7 +1,7 @@
 """GPU: the template-sharded forward with the real HIP model on two ranks (one GPU, gloo) equals the single-process
 forward bit for bit — top-k ids, stage-2 poses, key-point lists (the RCCL run itself needs a multi-GPU node).
 The ranks take turns on the shared card for their local compute, the collectives run between them (dist_worker_gpu.py:
-two busy processes on ONE MI355X are not bit-reproducible on this platform)."""
+two busy processes on ONE MI355X corrupted SGPR lane masks of the warp kernel until it was rewritten)."""
 import os
 import socket
 import subprocess
