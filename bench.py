@@ -17,10 +17,14 @@ spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CH
 and return code (a process that has initialised the GPU is never re-exec'ed).  Under torch.distributed.run
 (WORLD_SIZE set) it is a rank.
 
-N > 1 (one rank per GPU, RCCL): weak scaling — every rank owns 32 crops (global
-batch 32*N); the template FEATURE bank is sharded over the ranks along N (each rank scores its slice of all
-crops), exchanged with all-gathers of the query features/masks and of the (B, N/G) score slices; stages 2-3
-and PnP run data-parallel on the rank's own crops.
+N > 1 (one rank per GPU, RCCL), two modes:
+  --scaling weak (default; the 1/2/4/8-GPU curve of BASELINE's metric): every rank owns 32 crops (global batch 32*N);
+  --scaling strong (BASELINE configs[3] as written: "batch = 32 ... sharded 8-ways"): the GLOBAL batch stays at the
+    workload's 32 crops (or --global-batch), every rank owns 32/N of them.
+In both the template FEATURE bank is sharded over the ranks along the template axis (each rank scores its
+ceil(162/N)-template slice of ALL crops of the global batch), exchanged with all-gathers of the query features / masks
+and of the (B, 162/N) score slices; stages 2-3 and PnP run data-parallel on the rank's own crops.  The line carries
+`phases_ms` (HIP events at the phase boundaries of one extra untimed step: features, exchange, stage1, tail, pnp).
 
 JSON extras: `roofline` = the dominant kernel of the workload.  Full path: the pre-split f16x3 GEMM/conv kernel
 (75 % of the step; MFMA-bound) — executed MFMA flops of all its launches in one step / their summed durations,
@@ -223,6 +227,49 @@ def cpu_baseline_full(N, vit, sd, budget=25.0):
                       f"each on average, 1 thread)"}
 
 
+CFG_KERNEL = {0: "gemm_f16x3s_kernel<2,2> (128x128, register-staged)", 2: "gemm_f16x3s_kernel<1,3> (128x64, register-staged)",
+              3: "pp_gemm_f16x3g_kernel (256x128 LDS-DMA, one-shot)", 4: "pp_gemm_f16x3p_kernel (256x128 LDS-DMA, persistent)",
+              5: "pp_gemm_f16x3q_kernel (256x256 LDS-DMA, persistent)", 6: "pp_gemm_f16x3h_kernel (256x256 persistent, row-shared 3x3)",
+              7: "pp_gemm_f16x3d_kernel (256x128 LDS-DMA, 2 workgroups/CU)", 8: "pp_gemm_f16x3e_kernel (128x128 LDS-DMA, 3 workgroups/CU)"}
+
+
+def gemm_per_kernel(L, cap=8192):
+    """Per-kernel view of the GEMM launches the event pass recorded: [{kernel, cfg, conv, launches, ms, algorithmic_flops,
+    useful_tflops}] — every per-kernel roofline fraction can be recomputed from it (executed MFMA flops = 3 x algorithmic in
+    the f16x3 kernels, 1 x in the fp32-MFMA ones)."""
+    from picopose_amd import _lib
+
+    shape, ms, fl, cnt = (ctypes.c_int * (6 * cap))(), (ctypes.c_float * cap)(), (ctypes.c_double * cap)(), ctypes.c_int()
+    _lib.check(L.pp_prof_gemm_records(cap, shape, ms, fl, ctypes.byref(cnt)), "pp_prof_gemm_records")
+    agg = {}
+    for i in range(cnt.value):
+        M, N, K, ck, cfg, kind = (shape[6 * i + k] for k in range(6))
+        name = CFG_KERNEL.get(cfg, f"cfg {cfg}") if kind == 0 else "gemm_f16x3_kernel / gemm_kernel (operands split on the fly or fp32 MFMA)"
+        key = (name, "conv" if ck else "dense")
+        a_ = agg.setdefault(key, {"kernel": name, "a_operand": key[1], "launches": 0, "ms": 0.0, "algorithmic_flops": 0.0})
+        a_["launches"] += 1
+        a_["ms"] += ms[i]
+        a_["algorithmic_flops"] += fl[i]
+    out = sorted(agg.values(), key=lambda r: -r["ms"])
+    for r in out:
+        r["useful_tflops"] = r["algorithmic_flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else None
+    return out
+
+
+def batch_plan(workload_crops, world, scaling="weak", global_batch=None):
+    """(global batch B, crops per rank, scaling) of a run on `world` ranks.  weak: every rank owns the workload's crops
+    (B grows with the ranks — the 1/2/4/8-GPU throughput curve); strong: the workload's crops (or --global-batch) ARE the
+    global batch and every rank owns B / world of them (BASELINE configs[3]: "batch = 32 ... sharded 8-ways")."""
+    if global_batch is not None:
+        scaling = "strong"
+    if scaling == "strong":
+        B = global_batch if global_batch is not None else workload_crops
+        if B <= 0 or B % world != 0:
+            raise SystemExit(f"--scaling strong: the global batch {B} is not a positive multiple of the {world} ranks")
+        return B, B // world, "strong"
+    return workload_crops * world, workload_crops, "weak"
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` from a plain shell: run the N ranks as a child torch.distributed.run job (nothing in
     this process has touched the GPU) and hand back its return code; rank 0 of the child prints the JSON line."""
@@ -248,6 +295,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="full_b32_n162_vitb", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = the workload's crops PER RANK (global batch grows with N); strong = the workload's crops as "
+                         "the GLOBAL batch, split over the ranks (BASELINE configs[3])")
+    ap.add_argument("--global-batch", type=int, default=None, help="strong scaling with this global batch (implies --scaling strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the untimed --mode exact comparison leg")
     a = ap.parse_args()
@@ -266,6 +317,9 @@ def main():
     rehearse = os.environ.get("PP_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+        if rank == 0:
+            print("bench.py: PP_BENCH_REHEARSE=1 puts every rank on cuda:0 — a rehearsal of the N > 1 code path, NOT a supported "
+                  "configuration of the product (one process per GPU; DESIGN.md section 6) and not a measurement", file=sys.stderr, flush=True)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
@@ -288,7 +342,7 @@ def main():
 
     kind, Bl, N, vit, desc = WORKLOADS[a.workload]
     C = VIT[vit][0]
-    B = Bl * world                      # global batch
+    B, Bl, a.scaling = batch_plan(Bl, world, a.scaling, a.global_batch)
     lo, hi = shard_bounds(N, world, rank)
     n_local = hi - lo
     sd = None
@@ -337,8 +391,8 @@ def main():
         else:
             ep["template_feature"] = feats
 
-        def forward():
-            return sharded_forward(net, ep, bank, N, hyp=5) if distributed else net(ep, 5)
+        def forward(mark=None):
+            return sharded_forward(net, ep, bank, N, hyp=5, mark=mark) if distributed else net(ep, 5)
 
         def step():
             outs = forward()
@@ -380,7 +434,7 @@ def main():
         _lib.check(L.pp_prof_enable(0), "pp_prof_enable")
         return sum(buf[i] for i in range(cnt.value)) / max(cnt.value, 1)
 
-    gemm = pnp = exact = None
+    gemm = pnp = exact = phases = None
     if kind == "stage1":
         kern_ms = collect_stage1(a.steps)
     else:
@@ -395,10 +449,31 @@ def main():
         outs = forward()
         net.keep_stage3 = False
         torch.cuda.synchronize()
+        per_kernel = gemm_per_kernel(L)
         g_ms, g_fl, g_n = (ctypes.c_double * 2)(), (ctypes.c_double * 2)(), (ctypes.c_int * 2)()
         _lib.check(L.pp_prof_gemm_collect(g_ms, g_fl, g_n), "pp_prof_gemm_collect")
         _lib.check(L.pp_prof_gemm_enable(0), "pp_prof_gemm_enable")
-        gemm = {"ms": list(g_ms), "flops": list(g_fl), "launches": list(g_n)}
+        gemm = {"ms": list(g_ms), "flops": list(g_fl), "launches": list(g_n), "per_kernel": per_kernel}
+        phases = None
+        if distributed:   # one more untimed step with a HIP event at every phase boundary of the sharded forward
+            evs = []
+
+            def mark(name):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append((name, e))
+
+            po = forward(mark)
+            pnp_for_outputs(po, ep["real_K"])
+            mark("pnp")
+            torch.cuda.synchronize()
+            d_ = {evs[i + 1][0]: evs[i][1].elapsed_time(evs[i + 1][1]) for i in range(len(evs) - 1)}
+            phases = {"features": d_["features"], "exchange": d_["exchange_q"] + d_["exchange_s"], "exchange_query_wait": d_["exchange_q"],
+                      "exchange_scores_topk": d_["exchange_s"], "stage1": d_["stage1"], "tail": d_["tail"], "pnp": d_["pnp"],
+                      "note": "HIP events on the compute stream of rank 0 at the phase boundaries of ONE extra untimed step; features = "
+                              "query ViT + query-side DPT head (the query all-gathers are in flight beside the DPT head), exchange = what the "
+                              "compute stream still waits for the query / mask all-gathers + the score all-gather and top-k, stage1 = this "
+                              "rank's score slices of ALL crops, tail = stages 2-3 of the own crops, pnp = batched PnP/RANSAC + D2H"}
         sat_checked = None
         if a.mode == "fast":    # one more untimed forward that verifies every f16x3 operand buffer it produces (raises on saturation)
             n0, ops.CHECK_SATURATION = ops.saturation_checks, True
@@ -431,11 +506,24 @@ def main():
             for _ in range(2):
                 xo = step()
             torch.cuda.synchronize()
+            x_steps = 5
+            xm = [torch.cuda.Event(enable_timing=True) for _ in range(x_steps + 1)]
             t1 = time.perf_counter()
-            for _ in range(2):
+            xm[0].record()
+            for i in range(x_steps):
                 xo = step()
+                xm[i + 1].record()
             torch.cuda.synchronize()
-            x_dt = (time.perf_counter() - t1) / 2
+            x_dt = (time.perf_counter() - t1) / x_steps
+            x_ms = sorted(xm[i].elapsed_time(xm[i + 1]) for i in range(x_steps))
+            # its own roofline: HIP events around every GEMM launch of one more (untimed) exact step, fp32-MFMA peak
+            _lib.check(L.pp_prof_gemm_enable(8192), "pp_prof_gemm_enable")
+            forward()
+            torch.cuda.synchronize()
+            x_per_kernel = gemm_per_kernel(L)
+            xg_ms, xg_fl, xg_n = (ctypes.c_double * 2)(), (ctypes.c_double * 2)(), (ctypes.c_int * 2)()
+            _lib.check(L.pp_prof_gemm_collect(xg_ms, xg_fl, xg_n), "pp_prof_gemm_collect")
+            _lib.check(L.pp_prof_gemm_enable(0), "pp_prof_gemm_enable")
             net.keep_stage3 = False
             ops.PRECISION, net.match_mode = "f16x3", a.mode
             xouts, (xrot, xtvec, _, xok) = xo
@@ -450,15 +538,23 @@ def main():
             flat = same.reshape(-1)
             both = ok & xok & sm
             dpose = (torch.stack([o["pred_poses"] for o in xouts]) - fast["poses"]).abs()[same]
-            exact = {"value": Bl / x_dt, "unit": "crops/s", "ms_per_step": x_dt * 1e3,
+            any_same = bool(same.any())   # (no pair picked the same template in both modes: nothing to compare, report None)
+            xk_ms, xk_fl = xg_ms[0] + xg_ms[1], xg_fl[0] + xg_fl[1]
+            exact = {"value": Bl / x_dt, "unit": "crops/s", "ms_per_step": x_dt * 1e3, "steps": x_steps,
+                     "ms_per_step_median_hip_events": x_ms[len(x_ms) // 2],
                      "dtype": "f32 (v_mfma_f32_32x32x2_f32 in every kernel, exact-fp32 stage 1; PnP f64)",
+                     "roofline": {"bound": "mfma", "kernel": "gemm_kernel (v_mfma_f32_32x32x2_f32), all GEMM / conv launches of one step",
+                                  "achieved": xk_fl / (xk_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                  "frac": xk_fl / (xk_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "launches_per_step": xg_n[0] + xg_n[1],
+                                  "kernel_ms_per_step": xk_ms, "algorithmic_flops_per_step": xk_fl, "per_kernel": x_per_kernel,
+                                  "timing": "HIP events on the launch stream around every launch of one extra, untimed exact-mode step"},
                      "f16x3_vs_exact": {
                          "pairs": int(same.numel()), "pairs_with_same_template": int(same.sum()),
-                         "pred_poses_max_abs": float(dpose.max()),
-                         "flow_max_abs_px": float((net.last_stage3[0] - fast["flow"]).abs()[flat].max()),
+                         "pred_poses_max_abs": float(dpose.max()) if any_same else None,
+                         "flow_max_abs_px": float((net.last_stage3[0] - fast["flow"]).abs()[flat].max()) if any_same else None,
                          "flow_max_abs_value": float(fast["flow"].abs().max()),
-                         "certainty_logit_max_abs": float((net.last_stage3[1] - fast["cert"]).abs()[flat].max()),
-                         "keypoint_slots_equal": float((xtar == fast["tar"]).all(-1)[same].float().mean()),
+                         "certainty_logit_max_abs": float((net.last_stage3[1] - fast["cert"]).abs()[flat].max()) if any_same else None,
+                         "keypoint_slots_equal": float((xtar == fast["tar"]).all(-1)[same].float().mean()) if any_same else None,
                          "pnp_translation_max_abs_m": float(abs(xtvec - tvec)[both].max()) if both.any() else None,
                          "pnp_translation_median_abs_m": float(np.median(abs(xtvec - tvec)[both])) if both.any() else None,
                          "note": "compared on the (crop, hypothesis) pairs for which both modes picked the same template"}}
@@ -473,7 +569,7 @@ def main():
         bpe = 2 if bank_dtype == torch.float16 else 4
         kbytes = stage1_bytes(B, n_local, C, bpe)   # bytes one launch of the stage-1 kernel streams on this rank
         achieved = kbytes / (kern_ms * 1e-3) / 1e9
-        prof_dir = next((d for d in ("r02", "r01") if os.path.isdir(os.path.join(ROOT, "profiles", d))), "r01")
+        prof_dir = next((d for d in ("r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_traffic_stage1.json"))), "r01")
         traffic = traffic_src = None  # HBM bytes per launch from a separate PMC pass (tools/pmc.sh): same kernel, same shape
         pmc = os.path.join(ROOT, "profiles", prof_dir, "pmc_traffic_stage1.json")
         if world == 1 and a.mode == "fast" and (B, N, C, bpe) == (32, 162, 768, 4) and os.path.exists(pmc):
@@ -483,20 +579,22 @@ def main():
                       + (", extended template bank (SURVEY 8f row 1: template ViT/DPT precomputed)" if cached else ""),
             "value": B / (dt / a.steps), "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "ms_per_step_median_hip_events": step_ms[len(step_ms) // 2],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32 tensors; networks: f32 operands split into 2 f16 terms (22 bits) on f16 MFMA with f32 accumulate; stage-1 "
                      "contraction: f16 MFMA operands, f32 accumulate, exact f32 re-evaluation of near-ties; PnP f64"
                      if a.mode == "fast" else "f32 (fp32 MFMA everywhere; PnP f64)",
             "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {desc}", "global_batch": B, "templates": N, "backbone": vit, "channels": C,
+            "config": {"workload": f"{a.workload}: {desc}", "global_batch": B, "crops_per_rank": Bl, "templates": N,
+                       "templates_per_rank": n_local, "backbone": vit, "channels": C,
                        "hypotheses": 5, "mode": a.mode, "bank_dtype": "f16" if bpe == 2 else "f32",
                        "weights": "seeded random init, prediction heads calibrated (picopose_amd/utils/seeding.py)",
                        "parallelism": "single GPU" if world == 1 else
-                       f"crops data-parallel x{world}; feature bank template-sharded x{world} + all-gathers (query features, sampled masks, scores); {backend}"},
+                       f"{a.scaling} scaling: {Bl} crops per rank x{world} (global batch {B}); feature bank template-sharded x{world} "
+                       f"({n_local} of {N} templates on rank 0) + all-gathers (query features, sampled masks, scores); {backend}"},
         }
         s1_roof = {"bound": "hbm", "kernel": f"s1_main<{a.mode}> (stage-1 fused similarity)", "achieved": achieved,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                   "traffic_source": traffic_src, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kbytes,
+                   "traffic_source": traffic_src, "traffic_measured_in_this_run": False, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kbytes,
                    "timing": "HIP events on the launch stream around this launch, " +
                              ("inside the timed steps" if kind == "stage1" else "3 extra untimed steps after the timed region")}
         # the other roof of the same launch: the 256 x 256 x C contraction per (crop, template) on the matrix cores
@@ -527,6 +625,10 @@ def main():
                              "frac_algorithmic = 2MNK / time / the same peak (ceiling 1/3 under the 3-term scheme)"
                              if a.mode == "fast" else "fp32 MFMA: executed = algorithmic",
                 "traffic": None if g_traffic is None else g_traffic / n, "traffic_bytes_per_step": g_traffic, "traffic_source": g_src,
+                "traffic_measured_in_this_run": False,
+                "per_kernel": gemm.get("per_kernel"),
+                "per_kernel_note": "every GEMM / conv launch of the event pass grouped by kernel: frac_algorithmic of a kernel = "
+                                   "algorithmic_flops / ms / peak; its executed fraction = 3 x that for the f16x3 kernels",
                 "launches_per_step": n, "kernel_ms_per_step": msum, "avg_launch_ms": msum / n,
                 "algorithmic_flops_per_step": fl, "mfma_flops_per_step": mult * fl,
                 "useful_tflops": fl / (msum * 1e-3) / 1e12, "share_of_step": msum / ms,
@@ -549,6 +651,8 @@ def main():
                                 "engine": "f32: v_mfma_f32_32x32x2_f32", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
                                 "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "gflop_per_crop": full_gflop_per_crop(N, vit, cached=cached)}
             line["pnp"] = pnp
+            if phases is not None:
+                line["phases_ms"] = phases
             if sat_checked is not None:
                 line["f16x3_operand_range"] = {"operands_verified": sat_checked, "saturated": 0,
                                                "note": "every operand buffer of one untimed forward checked against the fp16 clamp "

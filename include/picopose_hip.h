@@ -54,6 +54,10 @@ int pp_prof_collect(float* out_ms, int max_out, int* count);
  * GEMM kernels.  pp_prof_gemm_enable(0) switches the hooks off. */
 int pp_prof_gemm_enable(int max_records);
 int pp_prof_gemm_collect(double* ms, double* flops, int* launches);
+/* Per-launch view of the same records (call BEFORE pp_prof_gemm_collect, which resets them): for record i < *count,
+ * shape[6 i ..] = {M, N, K, conv kernel size (0: dense), tile configuration the launch used (PP_GEMM_FORCE_CFG numbering),
+ * kind (0 = both operands pre-split, 1 = other)}, ms[i] its duration, flops[i] = 2 M N K batch. */
+int pp_prof_gemm_records(int max_records, int* shape, float* ms, double* flops, int* count);
 
 /* ------------------------------------------------------------------------- *
  * Stage 1: template matching — utils/matching.py:29-69 (matching_templates)

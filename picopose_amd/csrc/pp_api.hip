@@ -100,4 +100,19 @@ int pp_prof_gemm_collect(double* ms, double* flops, int* launches) {
     return PP_OK;
 }
 
+int pp_prof_gemm_records(int max_records, int* shape, float* ms, double* flops, int* count) {
+    PpGemmProf& p = g_gemm_prof;
+    if (!shape || !ms || !flops || !count || max_records < 0) return PP_EINVAL;
+    const int n = p.count < max_records ? p.count : max_records;
+    for (int i = 0; i < n; ++i) {
+        if (hipEventSynchronize(p.ev[2 * i + 1]) != hipSuccess) return PP_ELAUNCH;
+        if (hipEventElapsedTime(&ms[i], p.ev[2 * i], p.ev[2 * i + 1]) != hipSuccess) return PP_ELAUNCH;
+        for (int k = 0; k < 5; ++k) shape[6 * i + k] = p.shape[i][k];
+        shape[6 * i + 5] = p.kind[i];
+        flops[i] = p.flops[i];
+    }
+    *count = n;
+    return PP_OK;
+}
+
 }  // extern "C"

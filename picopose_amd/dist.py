@@ -57,7 +57,7 @@ def sharded_matching_templates(local_bank, tar_feat, tar_mask, n_total, topk=5, 
 
 
 def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=None, features_fn=None, scores_fn=None,
-                    topk_fn=None, tail_fn=None, overlap_fn=None):
+                    topk_fn=None, tail_fn=None, overlap_fn=None, mark=None):
     """Net.forward (eval) with the template FEATURE bank sharded over the ranks and the crops data-parallel.
 
     Every rank owns `b_local` crops (`local_end_points`, with the raw template data of ITS crops) and the slice
@@ -66,7 +66,11 @@ def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=Non
     against all crops) and the all-gather of the (B_total, n_local) score slices; stages 2-3 run on the rank's own
     crops.  The query-side DPT head (overlap_fn: state -> state) does not feed stage 1, so it runs while the all-gathers
     of the query features are in flight.  *_fn default to the HIP model; tests inject CPU stand-ins to run under gloo.
+    mark(name): optional hook called on the compute stream at the phase boundaries "start", "features" (query ViT + DPT done),
+    "exchange_q" (query / mask all-gathers waited for), "stage1" (local score slices), "exchange_s" (score all-gather + top-k),
+    "tail" (stages 2-3 of the own crops) — bench.py records a HIP event at each to decompose a step.
     Returns the list (hyp) of output dicts for the rank's own crops."""
+    mark = mark or (lambda name: None)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if features_fn is None:
         from .utils import matching as hm
@@ -85,6 +89,7 @@ def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=Non
         topk_fn = hm.topk_templates
         tail_fn = net.forward_hypotheses
     with torch.no_grad():
+        mark("start")
         real, q_local = features_fn(local_end_points["real_rgb"])          # (state for stages 2-3, (b,C,16,16))
         b_local = q_local.shape[0]
         q_all = q_local.new_empty((world * b_local,) + tuple(q_local.shape[1:]))
@@ -99,10 +104,17 @@ def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=Non
         pending.append(dist.all_gather_into_tensor(m_all, m_local, group=group, async_op=True))
         if overlap_fn is not None:
             real = overlap_fn(real)
+        mark("features")
         for wk in pending:
             wk.wait()
+        mark("exchange_q")
         lo, hi = shard_bounds(n_total, world, rank)
         assert local_bank.shape[0] == world * b_local and local_bank.shape[1] == hi - lo
-        full = gather_scores(scores_fn(local_bank, q_all, m_all), n_total, group=group)      # (B_total, N)
+        local = scores_fn(local_bank, q_all, m_all)
+        mark("stage1")
+        full = gather_scores(local, n_total, group=group)                                    # (B_total, N)
         _, ids = topk_fn(full[rank * b_local:(rank + 1) * b_local].contiguous(), hyp)
-        return tail_fn(local_end_points, ids, real)
+        mark("exchange_s")
+        outs = tail_fn(local_end_points, ids, real)
+        mark("tail")
+        return outs

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "stress: load / repetition tests outside the product's configuration (PP_RUN_STRESS=1 to run)")
 
 
 @pytest.fixture(scope="session")

@@ -1,6 +1,11 @@
 """Rank body of tests/test_dist_gpu.py: the REAL template-sharded forward (HIP model, picopose_amd.dist.sharded_forward)
 on two ranks that share one GPU (gloo rendezvous, every rank on cuda:0 — a one-GPU box cannot run RCCL between ranks),
-against the single-process forward of the same crops.
+against the single-process forward of the same crops.  This IS the strong-scaling form of BASELINE configs[3] in small:
+a global batch of 4 crops and 7 templates -> 2 crops + 4 / 3 templates per rank.
+
+Environment: PP_DIST_BACKEND = gloo (default) | nccl (RCCL; on a one-GPU box only world size 1 can run — it proves that the
+RCCL path loads, takes the device tensors of dist.py and returns what gloo returns); PP_DIST_TURNS = 1 (default: the ranks take
+turns on the shared card for their local compute) | 0 (fully concurrent: the stress form, see below).
 
 The ranks take TURNS on the GPU for their local compute phases (the collectives still run between all ranks): two processes
 computing on one MI355X at the same time is not a configuration of the product (one process per GPU), and on this platform
@@ -24,12 +29,20 @@ def main():
     from picopose_amd.utils import matching as hm
     from picopose_amd.utils.seeding import calibrated_state_dict
 
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    backend = os.environ.get("PP_DIST_BACKEND", "gloo")
     torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))       # exactly bench.py's call
+    else:
+        dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    turns = os.environ.get("PP_DIST_TURNS", "1") == "1" and world > 1
 
     def in_turn(fn):
         """fn runs on one rank at a time (every rank calls the wrapped hooks in the same order, so the barriers line up)."""
+        if not turns:
+            return fn
+
         def wrapped(*a, **k):
             out = None
             for r in range(world):
@@ -89,7 +102,13 @@ def main():
         print(f"RANK{rank} stage-1 entry point: ids equal {torch.equal(i, wi)}, max score diff {float((s - ws).abs().max()):.3e}", flush=True)
     ok = ok and torch.equal(i, wi) and torch.equal(s, ws)
     torch.cuda.synchronize()
-    print(f"RANK{rank} {'OK' if ok else 'MISMATCH'}", flush=True)
+    # gather_scores on its own: uneven slices, -inf padding, rank-major reassembly
+    from picopose_amd.dist import gather_scores
+
+    full = torch.arange(bl * world * N, device="cuda", dtype=torch.float32).view(bl * world, N)
+    ok = ok and torch.equal(gather_scores(full[:, lo:hi].contiguous(), N), full)
+    torch.cuda.synchronize()
+    print(f"RANK{rank} {'OK' if ok else 'MISMATCH'} backend={dist.get_backend()} world={world} turns={int(turns)}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
 

@@ -12,17 +12,43 @@ import pytest
 gpu = pytest.mark.gpu
 
 
-@gpu
-def test_sharded_forward_two_ranks_one_gpu_equals_single_process():
+def _run_ranks(n, **extra_env):
     here = os.path.dirname(os.path.abspath(__file__))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **extra_env)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(here, "dist_worker_gpu.py")],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
-    assert "RANK0 OK" in out and "RANK1 OK" in out, out[-3000:]
+    for k in range(n):
+        assert f"RANK{k} OK" in out, out[-3000:]
+    return out
+
+
+@gpu
+def test_sharded_forward_two_ranks_one_gpu_equals_single_process():
+    """Strong-scaling form in small (BASELINE configs[3]): global batch 4, 7 templates -> 2 crops + 4 / 3 templates per rank."""
+    _run_ranks(2)
+
+
+@gpu
+def test_sharded_forward_over_rccl_world_size_one():
+    """The RCCL path itself: dist.init_process_group("nccl", device_id=...) exactly as bench.py calls it, at the only world
+    size a one-GPU box can run, with gather_scores / sharded_matching_templates / sharded_forward pushed through it on
+    device tensors — bit-equal to the single-process forward (and hence to what the gloo ranks return)."""
+    out = _run_ranks(1, PP_DIST_BACKEND="nccl")
+    assert "backend=nccl world=1" in out, out[-2000:]
+
+
+@gpu
+@pytest.mark.stress
+@pytest.mark.skipif(os.environ.get("PP_RUN_STRESS") != "1", reason="stress form (two BUSY processes on one card): PP_RUN_STRESS=1")
+def test_sharded_forward_two_ranks_fully_concurrent():
+    """The two-rank test without the turn-taking: both processes compute on the one card at the same time — not a
+    configuration of the product (one process per GPU), but the only rehearsal of overlapped ranks a one-GPU box allows,
+    and the load under which lane-masked branches were seen to lose lanes."""
+    _run_ranks(2, PP_DIST_TURNS="0")

@@ -325,27 +325,30 @@ def test_hip_forward_vitb_with_pinned_persistent_kernels(golden_dir, monkeypatch
 
 
 @gpu
-def test_full_size_forward_is_batch_independent():
+@pytest.mark.parametrize("vit,B,N,half_bank", [("dinov2_vitb14", 32, 162, False), ("dinov2_vitl14", 64, 64, True)],
+                         ids=["configs2_b32_n162_vitb", "configs4_share_b64_n64_vitl_f16bank"])
+def test_full_size_forward_is_batch_independent(vit, B, N, half_bank):
     """BASELINE configs[2] at full size (32 crops x 162 templates, ViT-B/14, hyp 5, the bench's inputs and calibrated
-    weights) through a size-independent property: every crop's outputs — template ids, stage-2 poses, key-point lists —
-    are bit for bit what the same crop gives in a batch of 3.  Each layer then runs with other GEMM shapes, other tile
-    configurations (the autotuner's pick per shape, the persistent / row-shared kernels at M = 655 360 against the small
-    kernels at M = 61 440) and other tile tails, so any dependence of a row on its neighbours or on the kernel shows."""
+    weights) and ONE RANK'S SHARE of configs[4] (64 crops x 64 of the 512 templates, ViT-L/14, feature bank stored fp16 —
+    bench.py's `full_b64_n64_vitl`) through a size-independent property: every crop's outputs — template ids, stage-2 poses,
+    key-point lists — are bit for bit what the same crop gives in a batch of 3.  Each layer then runs with other GEMM shapes,
+    other tile configurations (the autotuner's pick per shape, the persistent / row-shared kernels at M = 655 360 against the
+    small kernels at M = 61 440) and other tile tails, so any dependence of a row on its neighbours or on the kernel shows."""
     import bench
     from picopose_amd.picopose import Net
 
-    vit = "dinov2_vitb14"
     net = Net(bench.make_cfg(vit))
     bench.seeded_weights(net, 4, vit)
     net = net.cuda().eval()
-    B, N = 32, 162
     ep = bench.make_end_points(B, N, "cuda", 100)
     fe = net.feature_extractor
     with torch.no_grad():
         ep["template_feature"] = torch.stack([torch.cat([fe(ep["tem_rgb"][b, s:s + 54])[-1] for s in range(0, N, 54)]) for b in range(B)])
+    if half_bank:
+        ep["template_feature"] = ep["template_feature"].half()
     full = net(ep, 5)
     assert min(int((o["pred_tar_pts"][..., 0] >= 0).sum(1).min()) for o in full) >= 1000
-    pick = [3, 17, 31]
+    pick = [3, 17, B - 1]
     sub = {k: v[pick].contiguous() for k, v in ep.items()}
     small = net(sub, 5)
     for h in range(5):

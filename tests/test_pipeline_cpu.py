@@ -88,6 +88,27 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stdout.decode()
 
 
+def test_bench_batch_plan_weak_and_strong():
+    """bench.py --scaling: weak keeps the workload's crops per rank (global batch x world), strong keeps the GLOBAL batch
+    (BASELINE configs[3]: batch 32 sharded 8 ways = 4 crops + 21/20 templates per rank)."""
+    import os
+    import sys
+
+    import pytest
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from picopose_amd.dist import shard_bounds
+
+    assert bench.batch_plan(32, 8) == (256, 32, "weak")
+    assert bench.batch_plan(32, 8, "strong") == (32, 4, "strong")
+    assert bench.batch_plan(32, 2, "weak", global_batch=32) == (32, 16, "strong")        # --global-batch implies strong
+    assert bench.batch_plan(32, 1, "strong") == (32, 32, "strong")
+    assert [shard_bounds(162, 8, r)[1] - shard_bounds(162, 8, r)[0] for r in range(8)] == [21, 21, 20, 20, 20, 20, 20, 20]
+    with pytest.raises(SystemExit):
+        bench.batch_plan(32, 3, "strong")
+
+
 def test_compat_import_installs_the_pnp_drop_in(tmp_path):
     """run_test.py:26 does `from utils.pose_recovery import pose_recovery_ransac_pnp` at start-up and imports the model
     module by name only at :234.  With picopose_amd/compat on sys.path that import must re-bind the evaluator's PnP to the
