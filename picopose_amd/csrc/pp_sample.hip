@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
     if (p >= H * W) return;
     const int y = p / W, x = p - y * W;
     const float* fl = flow + ((size_t)b * H * W + p) * ld_flow;
-    const float ix = roundtrip((float)x + fl[0], W), iy = roundtrip((float)y + fl[1], H);
+    // (clamped as floats BEFORE the integer conversion: a huge or NaN flow lands two pixels outside the image — every tap
+    // invalid, like any other out-of-image sample — instead of in an undefined float -> int conversion; fmaxf drops a NaN)
+    const float ix = fminf(fmaxf(roundtrip((float)x + fl[0], W), -2.f), (float)W + 1.f);
+    const float iy = fminf(fmaxf(roundtrip((float)y + fl[1], H), -2.f), (float)H + 1.f);
     const float x0f = floorf(ix), y0f = floorf(iy);
     const int x0 = (int)x0f, y0 = (int)y0f;
     const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix, wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
@@ -109,17 +112,25 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
     _Float16* oh = HL ? (_Float16*)out + ((size_t)b * H * W + p) * 2 * ld_out : nullptr;
     const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
     const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+    // Taps outside the image read a clamped pixel whose VALUE is then masked to zero (bitwise: all-ones / all-zeros mask) —
+    // zeros padding exactly like grid_sample, also when the clamped pixel holds Inf / NaN (a zero WEIGHT would turn those
+    // into NaN) — instead of being skipped by a lane-masked branch: no per-tap lane masks held in SGPR pairs across the
+    // loads.  With two busy PROCESSES on one card bits 48..63 of such masks were seen corrupted (lanes 48-63 of single
+    // waves lost taps: tests/stress_pc.py); the branch-free form ran 12 000 iterations under that load clean.
+    typedef unsigned u4w __attribute__((ext_vector_type(4)));
+    const unsigned m00 = 0u - (unsigned)(vy0 & vx0), m01 = 0u - (unsigned)(vy0 & vx1), m10 = 0u - (unsigned)(vy1 & vx0),
+                   m11 = 0u - (unsigned)(vy1 & vx1);
+    const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1), ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
+    auto tap = [&](int yy, int xx, int c, unsigned m) __attribute__((always_inline)) -> f4 {
+        const u4w raw = *(const u4w*)(fb + ((size_t)yy * W + xx) * C + c) & m;
+        return __builtin_bit_cast(f4, raw);
+    };
     for (int c = lane * 4; c < C; c += 256) {
         f4 acc = {0.f, 0.f, 0.f, 0.f};
-        // Taps outside the image read a clamped pixel with weight 0 instead of being skipped by a lane-masked branch: same
-        // value (the skipped tap adds nothing either way) and no per-tap lane masks held in SGPR pairs across the loads.  With
-        // two busy PROCESSES on one card bits 48..63 of such masks were seen corrupted (lanes 48-63 of single waves lost taps:
-        // tests/stress_pc.py); this form ran 12 000 iterations under that load without a difference.
-        const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1), ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
-        acc += *(const f4*)(fb + ((size_t)ya * W + xa) * C + c) * (vy0 && vx0 ? wx0 * wy0 : 0.f);
-        acc += *(const f4*)(fb + ((size_t)ya * W + xb) * C + c) * (vy0 && vx1 ? wx1 * wy0 : 0.f);
-        acc += *(const f4*)(fb + ((size_t)yb * W + xa) * C + c) * (vy1 && vx0 ? wx0 * wy1 : 0.f);
-        acc += *(const f4*)(fb + ((size_t)yb * W + xb) * C + c) * (vy1 && vx1 ? wx1 * wy1 : 0.f);
+        acc += tap(ya, xa, c, m00) * (wx0 * wy0);
+        acc += tap(ya, xb, c, m01) * (wx1 * wy0);
+        acc += tap(yb, xa, c, m10) * (wx0 * wy1);
+        acc += tap(yb, xb, c, m11) * (wx1 * wy1);
         if (HL) {
             typedef _Float16 h4w __attribute__((ext_vector_type(4)));
             _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
@@ -191,8 +202,9 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
             const int Hl = H >> l, Wl = W >> l;
             const float sc = (float)(1 << l);
             // centre sample (offset 0): its integer corner anchors the table, offsets shift by integers
-            cx[l] = roundtrip(gx / sc, Wl);
-            cy[l] = roundtrip(gy / sc, Hl);
+            // (clamped as floats before the integer conversion: a huge / NaN flow is an out-of-image sample, all zeros)
+            cx[l] = fminf(fmaxf(roundtrip(gx / sc, Wl), -(float)(r + 2)), (float)(Wl + r + 1));
+            cy[l] = fminf(fmaxf(roundtrip(gy / sc, Hl), -(float)(r + 2)), (float)(Hl + r + 1));
             bx[l] = (int)floorf(cx[l]) - r;
             by[l] = (int)floorf(cy[l]) - r;
         }
@@ -202,18 +214,20 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
             const int Hl = H >> l, Wl = W >> l;
             const int qx = bx[l] + dx, qy = by[l] + dy;
             float dot = 0.f;
-            if (qx >= 0 && qx < Wl && qy >= 0 && qy < Hl) {
-                const float* f2 = l == 0 ? f2l0 : (l == 1 ? f2l1 : f2l2);
-                const float* q = f2 + (((size_t)(b % f2_batch) * Hl + qy) * Wl + qx) * C;
-                for (int c = 0; c < C; c += 4) {
-                    const f4 u = *(const f4*)(a + c), v = *(const f4*)(q + c);
-                    dot = fmaf(u.x, v.x, dot);
-                    dot = fmaf(u.y, v.y, dot);
-                    dot = fmaf(u.z, v.z, dot);
-                    dot = fmaf(u.w, v.w, dot);
-                }
+            // positions outside the (pooled) map: the dot product runs on a clamped position and its VALUE is then replaced
+            // by zero (one select, no lane-masked branch around the loads — DESIGN section 6)
+            const bool inside = qx >= 0 && qx < Wl && qy >= 0 && qy < Hl;
+            const int qxc = min(max(qx, 0), Wl - 1), qyc = min(max(qy, 0), Hl - 1);
+            const float* f2 = l == 0 ? f2l0 : (l == 1 ? f2l1 : f2l2);
+            const float* q = f2 + (((size_t)(b % f2_batch) * Hl + qyc) * Wl + qxc) * C;
+            for (int c = 0; c < C; c += 4) {
+                const f4 u = *(const f4*)(a + c), v = *(const f4*)(q + c);
+                dot = fmaf(u.x, v.x, dot);
+                dot = fmaf(u.y, v.y, dot);
+                dot = fmaf(u.z, v.z, dot);
+                dot = fmaf(u.w, v.w, dot);
             }
-            tab[i] = dot * inv_sqrt_c;
+            tab[i] = inside ? dot * inv_sqrt_c : 0.f;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -552,14 +566,16 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const _Float16* __rest
     auto fetch = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
-            const int i = tid + 256 * j;
-            pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < npiece) {
-                const int piece = i & 7, px = i >> 3, sy = px / PW, sx = px - sy * PW;
-                const int iy = y0 + sy - R, ix = sx - R;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                    pre[j] = *(const float4*)(x + (((size_t)b * H + iy) * W + ix) * (size_t)(2 * ldx) + 2 * c0 + 8 * piece);
-            }
+            // halo pixels outside the image and slots past the band: the load runs on a clamped pixel and its value is masked
+            // to zero bit-wise (zero padding) — no per-lane guarded load, no lane masks held across it
+            const int i = min(tid + 256 * j, npiece - 1);
+            const int piece = i & 7, px = i >> 3, sy = px / PW, sx = px - sy * PW;
+            const int iy = y0 + sy - R, ix = sx - R;
+            const unsigned m = 0u - (unsigned)((tid + 256 * j < npiece) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W));
+            const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
+            typedef unsigned u4n __attribute__((ext_vector_type(4)));
+            const u4n raw = *(const u4n*)(x + (((size_t)b * H + iyc) * W + ixc) * (size_t)(2 * ldx) + 2 * c0 + 8 * piece) & m;
+            pre[j] = __builtin_bit_cast(float4, raw);
         }
     };
     fetch(0);
@@ -689,7 +705,10 @@ int pp_corr_lookup_nhwc_ex(const float* f1, int ld_f1, const float* f2_l0, const
     if (ld_out < levels * win * win) return PP_EINVAL;
     const char* te = getenv("PP_CORR_TILED");   // read per call: the tests run both kernels in one process
     const bool tiled = prec == PP_PREC_F16X3 && !(te && te[0] == '0');   // PP_PREC_F32: exact fp32 fmas, always
-    if (tiled && H % CT == 0 && W % CT == 0 && C % CK == 0 && ((uintptr_t)f2_l0 % 16) == 0)   // (PP_CORR_TILED=0 keeps the lane-per-position kernel)
+    // every pyramid level the tiled kernel reads goes through 16-byte vector loads: a misaligned one falls back (as the hl entry
+    // point below rejects it) instead of faulting
+    const bool aligned = (((uintptr_t)f2_l0 | (levels > 1 ? (uintptr_t)f2_l1 : 0) | (levels > 2 ? (uintptr_t)f2_l2 : 0)) % 16) == 0;
+    if (tiled && H % CT == 0 && W % CT == 0 && C % CK == 0 && aligned)   // (PP_CORR_TILED=0 keeps the lane-per-position kernel)
         return corr_tiled_launch(false, f1, ld_f1, f2_l0, f2_l1, f2_l2, f2_batch, flow, B, H, W, C, levels, radius, ld_flow, out, ld_out, stream);
     const size_t smem = (size_t)4 * (C + MAXL * TW * TW) * sizeof(float);
     hipLaunchKernelGGL(corr_lookup_kernel, dim3((H * W + 3) / 4, B), dim3(256), smem, (hipStream_t)stream, f1, ld_f1,

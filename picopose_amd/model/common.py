@@ -87,18 +87,42 @@ class Packed(nn.Module):
         self._pack_cache = self._pack_train_cache = None
         return super()._load_from_state_dict(*a, **k)
 
+    def _signatures(self):
+        """(address, version) of every parameter / of every buffer the packings are derived from: an in-place update between
+        two calls (`param.data.copy_`, an optimizer step, an EMA) changes the version, a re-allocation the address."""
+        sig = lambda ts: tuple((t.data_ptr(), t._version) for t in ts)  # noqa: E731
+        return sig(self.parameters()), sig(self.buffers())
+
+    def _check_sources(self, buffers_too):
+        psig, bsig = self._signatures()
+        if psig != getattr(self, "_pack_psig", None):            # a weight moved: every derived copy is stale
+            self._pack_cache = self._pack_train_cache = None
+            self._pack_psig = psig
+        if buffers_too and bsig != getattr(self, "_pack_bsig", None):   # a BatchNorm buffer moved: the eval packing folds them
+            self._pack_cache = None
+            self._pack_bsig = bsig
+
+    def invalidate_packed(self):
+        """Drop the derived copies of the weights explicitly (they are also dropped by .to() / load_state_dict and whenever a
+        parameter's or buffer's version counter or address has changed since they were built)."""
+        self._pack_cache = self._pack_train_cache = None
+        self._pack_psig = self._pack_bsig = None
+
     def packed(self, for_training=False):
         """The eval packing.  for_training: the caller reads only entries that do not fold a BatchNorm, so a packing whose
         folds a training step has made stale is still good (and is not rebuilt every step)."""
+        self._check_sources(buffers_too=not for_training)
         if self._pack_cache is None or (self._bn_stale and not for_training):
             with torch.no_grad():
                 self._pack_cache = self._pack()
             self._bn_stale = False
+            self._pack_psig, self._pack_bsig = self._signatures()
         return self._pack_cache
 
     def packed_train(self):
         """Weights of the layers that differ in training mode (the module's `_pack_train`).  A training step moves the
         BatchNorm running buffers: the eval packing, which folds them, is marked stale and re-folded by the next eval call."""
+        self._check_sources(buffers_too=False)
         if self._pack_train_cache is None:
             with torch.no_grad():
                 self._pack_train_cache = self._pack_train()

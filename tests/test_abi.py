@@ -105,6 +105,39 @@ def test_pack_cache_is_dropped_when_a_checkpoint_loads_through_the_top_level_net
     assert fd._pack_cache is None
 
 
+def test_pack_cache_follows_in_place_parameter_updates():
+    """the packed / BN-folded copies are derived from the parameters; an in-place update between two forwards
+    (`param.data.copy_`, an optimizer step, an EMA) must not leave them stale.  The cache records every source tensor's
+    (address, version) and rebuilds on a mismatch; a BatchNorm buffer update re-folds the eval packing only."""
+    import os
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from netcfg import small_cfg
+
+    from picopose_amd.picopose import Net
+    from picopose_amd.utils.seeding import seeded_state_dict
+
+    net = Net(small_cfg())
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 1))
+    fd = net.offset_regressor.flow_decoder
+    first = fd.packed()
+    assert fd.packed() is first                                              # unchanged sources: the cache is reused
+    old = first["proj0"].clone()
+    with torch.no_grad():
+        getattr(fd.proj[0], "0").weight.mul_(2.0)                                       # an optimizer-style in-place step
+    assert not torch.equal(fd.packed()["proj0"], old)
+    second = fd.packed()
+    with torch.no_grad():
+        getattr(fd.proj[0], "1").running_var.add_(1.0)                                  # a BatchNorm buffer moved: the fold is stale
+    third = fd.packed()
+    assert third is not second and not torch.equal(third["proj0"], second["proj0"])
+    fd.invalidate_packed()
+    assert fd._pack_cache is None and torch.equal(fd.packed()["proj0"], third["proj0"])
+
+
 @pytest.mark.gpu
 def test_library_loaded_before_torch_still_launches():
     """`__graft_entry__.build()` opens the library before anything has imported torch.  PyTorch-ROCm bundles its own HIP

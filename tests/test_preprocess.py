@@ -71,6 +71,29 @@ def test_oracle_resize_known_answers():
     assert np.allclose(op.resize_linear(np.full((5, 7, 3), 0.3), 224), 0.3)
 
 
+@pytest.mark.parametrize("h,w", [(120, 120), (400, 400), (37, 53), (224, 224), (225, 223), (448, 448), (61, 61), (333, 333), (20, 20), (479, 479)])
+def test_oracle_resize_second_opinion_torch_interpolate(h, w):
+    """A second, independent implementation beside the restatement of OpenCV in oracle/preprocess.py (cv2 itself cannot be had
+    here): torch.nn.functional.interpolate(mode="bilinear", align_corners=False) implements the same half-pixel definition as
+    cv2.INTER_LINEAR — source coordinate (x + 0.5) * in / out - 0.5, clamped at the first pixel, second tap clamped at the last
+    — and mode="nearest" the same floor(x * in / out) as cv2.INTER_NEAREST.  Crop shapes of get_instance
+    (provider/bop_test_dataset.py:186-190): float images, up- and down-scaling, square and not.  In float64 the two agree to
+    rounding (measured <= 4e-14) and the nearest maps are equal.  Where real OpenCV would still differ from both: its float
+    path keeps the interpolation WEIGHTS in float32 (HResizeLinear / VResizeLinear coefficient buffers), a relative 6e-8 on a
+    [0, 1] image, and its uint8 path (not used by the reference, which resizes rgb / 255.0) is 11-bit fixed point."""
+    import torch
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(h * 1000 + w)
+    img = rng.random((h, w, 3))
+    ours = op.resize_linear(img, 224)
+    theirs = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(224, 224), mode="bilinear", align_corners=False)[0]
+    assert np.abs(ours - theirs.permute(1, 2, 0).numpy()).max() <= 1e-12
+    m = rng.integers(0, 2, (h, w)).astype(np.float64)
+    near = F.interpolate(torch.from_numpy(m)[None, None], size=(224, 224), mode="nearest")[0, 0].numpy()
+    assert np.array_equal(op.resize_nearest(m, 224), near)
+
+
 @gpu
 @pytest.mark.parametrize("seed,flag", [(0, False), (1, True), (2, False), (3, True)])
 def test_crop_instance_device_vs_oracle(seed, flag):
