@@ -227,10 +227,9 @@ def cpu_baseline_full(N, vit, sd, budget=25.0):
                       f"each on average, 1 thread)"}
 
 
-CFG_KERNEL = {0: "gemm_f16x3s_kernel<2,2> (128x128, register-staged)", 2: "gemm_f16x3s_kernel<1,3> (128x64, register-staged)",
-              3: "pp_gemm_f16x3g_kernel (256x128 LDS-DMA, one-shot)", 4: "pp_gemm_f16x3p_kernel (256x128 LDS-DMA, persistent)",
-              5: "pp_gemm_f16x3q_kernel (256x256 LDS-DMA, persistent)", 6: "pp_gemm_f16x3h_kernel (256x256 persistent, row-shared 3x3)",
-              7: "pp_gemm_f16x3d_kernel (256x128 LDS-DMA, 2 workgroups/CU)", 8: "pp_gemm_f16x3e_kernel (128x128 LDS-DMA, 3 workgroups/CU)"}
+CFG_KERNEL = {0: "pp_gemm_u_kernel<128x128, 4 waves, 2-stage ring, 2 workgroups/CU>", 2: "pp_gemm_u_kernel<128x64, 4 waves, 3-stage ring, 2 workgroups/CU>",
+              4: "pp_gemm_u_kernel<256x128, 8 waves, 3-stage ring>", 5: "pp_gemm_u_kernel<256x256, 8 waves, 2-stage ring>",
+              6: "pp_gemm_uh_kernel (256x256, row-shared A delivery of 3x3 convolutions)"}
 
 
 def gemm_per_kernel(L, cap=8192):
@@ -616,8 +615,8 @@ def main():
                 g_traffic, g_src = json.load(open(pmc_step)).get("gemm_f16x3_hbm_bytes_per_step"), os.path.relpath(pmc_step, ROOT)
             line["roofline"] = {
                 "bound": "mfma",
-                "kernel": "pp_gemm f16x3 family: pp_gemm_f16x3{q,p,g}_kernel + gemm_f16x3s_kernel (GEMM / implicit-im2col conv, both operands pre-split into 2 fp16 planes; "
-                          "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)" if a.mode == "fast" else
+                "kernel": "pp_gemm_u_kernel / pp_gemm_uh_kernel, all tile instantiations (GEMM / implicit-im2col conv, persistent, LDS-DMA ring; both operands "
+                          "pre-split into 2 fp16 terms; 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)" if a.mode == "fast" else
                           "gemm_kernel (v_mfma_f32_32x32x2_f32)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "frac_algorithmic": fl / (msum * 1e-3) / 1e12 / peak,
@@ -641,7 +640,7 @@ def main():
             tf = Bl * full_gflop_per_crop(N, vit, cached=cached) / (dt / a.steps) / 1e3   # useful (fp32-equivalent) TFLOP/s per GPU
             if a.mode == "fast":   # every product = 3 fp16 MFMA products
                 line["mfma"] = {"bound": "mfma", "scope": "whole step, all kernels (the GEMM/conv engine is >85 % of it)",
-                                "engine": "f16x3: operands split into 2 fp16 terms, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate",
+                                "engine": "f16x3: operands split into 2 fp16 terms, 3 x v_mfma_f32_16x16x32_f16, fp32 accumulate",
                                 "useful_tflops": tf, "achieved": 3 * tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                                 "frac": 3 * tf / MFMA_F16_PEAK_TF, "frac_algorithmic": tf / MFMA_F16_PEAK_TF,
                                 "frac_of_fp32_mfma_peak_equivalent": tf / MFMA_F32_PEAK_TF,

@@ -162,7 +162,10 @@ int pp_gather_valid(const float* features, const int64_t* index_patches, int B, 
 
 /* arithmetic of the GEMM engine */
 #define PP_PREC_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate                       */
-#define PP_PREC_F16X3 1 /* operands scaled and split into 2 fp16 terms, 3 x v_mfma_f32_32x32x16_f16, fp32 acc. */
+#define PP_PREC_F16X3 1 /* operands scaled and split into 2 fp16 terms, 3 x v_mfma_f32_16x16x32_f16, fp32 acc. */
+#define PP_PREC_F16 2   /* plain fp16 operands f16(4 x) [rows][ld] ("h" format), ONE v_mfma_f32_16x16x32_f16 per product, fp32
+                           accumulate — the arithmetic BASELINE configs[4] names; pre-split operands only (A_hl / B_hl / C_hl
+                           then hold the h format) */
 
 /* C[m,n] = residual[m,n] + gamma[n] * act(alpha * sum_k A(m,k) * B(n,k) + bias[n])
  * for every batch index z = z0*batch1 + z1 (operand offsets z0*bs0 + z1*bs1, in floats). */

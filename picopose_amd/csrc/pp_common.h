@@ -24,6 +24,9 @@ __device__ __forceinline__ void pp_split_f16(float v, _Float16& hi, _Float16& lo
 #endif
 }
 
+// plain-fp16 operand ("h" format, PP_PREC_F16): v -> f16(4 v), saturated like the hi term above
+__device__ __forceinline__ _Float16 pp_to_f16(float v) { return (_Float16)fminf(fmaxf(v * PP_A_SCALE, -65504.f), 65504.f); }
+
 // "hl" operand format (include/picopose_hip.h): half index of element (k, term p) inside a row
 __device__ __forceinline__ int pp_hl_col(int k, int p) { return ((k >> 3) << 4) + (p << 3) + (k & 7); }
 

@@ -28,62 +28,15 @@
 #include <unordered_map>
 #include "../../include/picopose_hip.h"
 #include "pp_common.h"
+#include "pp_gemm_dev.h"
+#include "pp_gemm_u.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-
-// One f16x3 term: D = A(32 x 16) * B(16 x 32) + C on the matrix cores.  (-DPP_STUDY_MFMA16: timing-only study build that
-// issues the same flops as two 16x16x32 instructions on quarter accumulators — results are NOT valid.)
-__device__ __forceinline__ f32x16 pp_mfma(const h8 a, const h8 b, f32x16 c) {
-#ifdef PP_STUDY_MFMA16
-    typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    f32x4_ c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[8], c[9], c[10], c[11]};
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
-    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
-    c[8] = c1[0]; c[9] = c1[1]; c[10] = c1[2]; c[11] = c1[3];
-    return c;
-#else
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-#endif
-}
+// One f16x3 term of the kernels that split fp32 operands on the fly: D = A(32 x 16) * B(16 x 32) + C on the matrix cores.
+__device__ __forceinline__ f32x16 pp_mfma(const h8 a, const h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 constexpr int BM = 128, BK = 32, LDT = 36;  // BN = 64 * NJ (template): 128x128 or 128x64 block tiles
-
-// erf(z) = z P(z^2) / Q(z^2) on |z| <= 3.925 (clamped beyond: erf = +-1 to fp32 precision), a least-squares
-// rational fit (coefficients derived and checked against scipy.special.erf: max |error| 4.2e-7, i.e. GELU within
-// 1.5e-6 absolute over |x| <= 10).  13 FMAs + v_rcp_f32 instead of libm's branchy erff (~50 instructions, 15 % of the
-// fc1 GEMM of a ViT block).
-__device__ __forceinline__ float erf_rational(float z) {
-    const float zc = fminf(fmaxf(z, -3.925f), 3.925f), t = zc * zc;
-    float p = 2.086927816e-06f, q = 3.855828442e-05f;
-    p = fmaf(p, t, 2.864863205e-04f);
-    p = fmaf(p, t, 3.736014319e-03f);
-    p = fmaf(p, t, 5.266064834e-02f);
-    p = fmaf(p, t, 1.894152597e-01f);
-    p = fmaf(p, t, 1.128379076e+00f);
-    q = fmaf(q, t, 1.159680598e-03f);
-    q = fmaf(q, t, 1.490643815e-02f);
-    q = fmaf(q, t, 1.137392213e-01f);
-    q = fmaf(q, t, 5.011971411e-01f);
-    q = fmaf(q, t, 1.0f);
-    return zc * p * __builtin_amdgcn_rcpf(q);
-}
-
-__device__ __forceinline__ float act_apply(float v, int act) {
-    switch (act) {
-        case PP_ACT_RELU: return v > 0.f ? v : 0.f;
-        case PP_ACT_GELU: return 0.5f * v * (1.0f + erf_rational(v * 0.70710678118654752440f));
-        case PP_ACT_LEAKY01: return v > 0.f ? v : 0.1f * v;
-        case PP_ACT_TANH: return tanhf(v);
-        default: return v;
-    }
-}
 
 // one A element group: 4 consecutive k of row m (zero outside the matrix / image)
 template <bool VEC4>
@@ -165,121 +118,6 @@ __device__ __forceinline__ void epilogue_store(const PpGemmDesc& d, float* C, co
         _Float16* hp = (_Float16*)d.C_hl + orow * 2 * d.ldc_h + pp_hl_col(ocol, 0);
         hp[0] = h;
         hp[8] = l;
-    }
-}
-
-// Epilogue of a wave's 64 x (32 NJ) accumulator block: out = residual + residual2 + gamma * act(descale * acc + bias).
-// The block leaves through a wave-private LDS patch (32 rows at a time) so that a lane owns 8 consecutive columns of a
-// row: 32-byte fp32 stores / residual loads and one 32-byte group of the hl operand, instead of 64 (or, for hl, 128)
-// scattered 4- and 2-byte accesses per lane.  Os: 32 x (32 NJ + 4) floats, free for this wave (no other wave touches it).
-// Pixel-shuffle stores (ConvTranspose2d), N % 8 != 0 and unaligned rows go element-wise from the accumulator layout.
-template <int NJ, int RP = 32>
-__device__ __forceinline__ void epilogue_block(const PpGemmDesc& d, float descale, f32x16 (&acc)[2][NJ], float* Os, int mw, int nw,
-                                               int lane) {
-    const int l31 = lane & 31, lh = lane >> 5;
-    float* C = d.C;
-    const float* R = d.residual;
-    const float* R2 = d.residual2;
-    // (pixel-shuffle stores stay vectorised when the 8 columns of a lane are 8 channels of one output pixel)
-    const bool shuffle_vec = d.shuffle_r == 0 || ((d.N / (d.shuffle_r * d.shuffle_r)) & 7) == 0;
-    if (!shuffle_vec || (d.N & 7) != 0 || (d.ldc & 3) != 0 || ((uintptr_t)C & 15) != 0 ||
-        (R && ((uintptr_t)R & 15) != 0) || (R2 && ((uintptr_t)R2 & 15) != 0)) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = nw + j * 32 + l31;
-            if (n >= d.N) continue;
-            const float bias = d.bias ? d.bias[n] : 0.f;
-            const float gamma = d.gamma ? d.gamma[n] : 1.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    if (m >= d.M) continue;
-                    float v = act_apply(acc[i][j][e] * descale + bias, d.act) * gamma;
-                    epilogue_store(d, C, R, R2, m, n, v);
-                }
-        }
-        return;
-    }
-    // RP = 32: a 32-row block per pass in a 32 x (32 NJ + 4) patch; RP = 8 (NJ = 2): 8-row groups in a 2 KB patch
-    constexpr int OSLD = RP == 32 ? 32 * NJ + 4 : 32 * NJ;  // floats per staged row
-    constexpr int LPR = 4 * NJ;           // lanes per row (8 columns each)
-    constexpr int RPP = 64 / LPR;         // rows per read pass
-    static_assert(RP == 32 || (RP == 8 && RPP == 8), "8-row groups need 8 lanes per row");
-    const int rr = lane / LPR, c8 = (lane % LPR) * 8;
-    const int n = nw + c8;  // columns n .. n + 7 (N % 8 == 0: a group is in or out as a whole)
-    f4 bias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gam[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
-    const bool ncol_ok = n < d.N;
-    if (ncol_ok) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (d.bias) bias[h][c] = d.bias[n + 4 * h + c];
-                if (d.gamma) gam[h][c] = d.gamma[n + 4 * h + c];
-            }
-    }
-    auto emit_row = [&](int r, int m) __attribute__((always_inline)) {  // staged row r -> output row m
-        f4 v[2];
-        v[0] = *(const f4*)(Os + r * OSLD + c8);
-        v[1] = *(const f4*)(Os + r * OSLD + c8 + 4);
-        if (m >= d.M || !ncol_ok) return;
-        size_t off, orow = (size_t)m;     // output row / first column of this lane's 8 values (fp32 and hl alike)
-        int ocol = n;
-        if (d.shuffle_r == 0) {
-            off = (size_t)m * d.ldc + n;
-        } else {  // ConvTranspose2d(kernel = stride = r): columns n .. n + 7 = channels co .. co + 7 of sub-pixel (dy, dx)
-            const int rr_ = d.shuffle_r, cout = d.N / (rr_ * rr_);
-            const int sub = n / cout, co = n - sub * cout, dy = sub / rr_, dx = sub - dy * rr_;
-            const int per = d.shuffle_h * d.shuffle_w;
-            const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
-            orow = ((size_t)b * d.shuffle_h * rr_ + y * rr_ + dy) * (d.shuffle_w * rr_) + x * rr_ + dx;
-            ocol = co;
-            off = orow * d.ldc + co;
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[h][c] = act_apply(v[h][c] * descale + bias[h][c], d.act) * gam[h][c];
-            if (R) v[h] += *(const f4*)(R + off + 4 * h);
-            if (R2) v[h] += *(const f4*)(R2 + off + 4 * h);
-            if (C) *(f4*)(C + off + 4 * h) = v[h];
-        }
-        if (d.C_hl) {
-            h8 hh, ll;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float x = v[c >> 2][c & 3];
-                _Float16 a, b;
-                pp_split_f16(d.c_relu ? fmaxf(x, 0.f) : x, a, b);
-                hh[c] = a;
-                ll[c] = b;
-            }
-            _Float16* hp = (_Float16*)d.C_hl + orow * 2 * d.ldc_h + 2 * ocol;
-            *(h8*)hp = hh;
-            *(h8*)(hp + 8) = ll;
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (RP == 32) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) Os[((e & 3) + 8 * (e >> 2) + 4 * lh) * OSLD + j * 32 + l31] = acc[i][j][e];
-#pragma unroll
-            for (int it = 0; it < 32 / RPP; ++it) emit_row(it * RPP + rr, mw + i * 32 + it * RPP + rr);
-        } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {  // rows 8 g .. 8 g + 7 of the block = accumulator registers 4 g .. 4 g + 3
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Os[(e + 4 * lh) * OSLD + j * 32 + l31] = acc[i][j][4 * g + e];
-                emit_row(rr, mw + i * 32 + 8 * g + rr);
-            }
-        }
     }
 }
 
@@ -667,1644 +505,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const PpGemmDesc d
     }
 }
 
-// ---------------------------------------------------------------------------
-// f16x3 with BOTH operands pre-split: the activation operand is split once by pp_split_activation
-// (instead of by every column-tile workgroup and, for a 3x3 convolution, nine times per element), so this
-// kernel has no conversion work at all.  A planes are indexed exactly like the fp32 operand would be (dense
-// [M][lda] or an NHWC image for the implicit im2col); Cin % 8 == 0.
-//   - 16-byte loads of the hi/lo planes (8 k per lane), next K tile prefetched into registers;
-//   - LDS: four planes of [rows][32 k] halfs (64-byte rows, no padding), double buffered; the 16-byte chunk c
-//     of row r sits at chunk c ^ ((r >> 2) & 3), which makes both the ds_write_b128 of a tile and the
-//     ds_read_b128 of the MFMA fragments bank-conflict free;
-//   - one barrier per K tile: the stores of tile k+1 overlap the MFMAs of tile k;
-//   - 3 x v_mfma_f32_32x32x16_f16 per fragment pair.
-// ---------------------------------------------------------------------------
-template <int NJ, int OCC>
-__global__ __launch_bounds__(256, OCC) void gemm_f16x3s_kernel(const PpGemmDesc d) {
-    constexpr int BN = 64 * NJ;
-    constexpr int PLANE_A = BM * 32, PLANE_B = BN * 32;           // halfs per plane
-    constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;              // halfs per stage
-    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    // operand planes are read with raw buffer loads: an out-of-range offset (0xFFFFFFFF for the padded taps,
-    // the row / column / K tails) returns zeros, so the loads need neither branches nor selects
-    // hl operands: element offset e of the fp32 view (a multiple of 8) -> byte 4 e, hi term; lo term 16 bytes on
-    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
-
-    // this thread's slots: rows r0 + 64 j, chunk (tid & 3) = 8 consecutive k starting at k8
-    const int r0 = tid >> 2, k8 = (tid & 3) * 8;
-    const int wchunk = ((tid & 3) ^ ((r0 >> 2) & 3)) * 8;       // swizzled chunk position (halfs) of the stores
-    int aoy[2], aox[2];
-    long long abase[2];
-    bool arow_ok[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = m0 + r0 + 64 * j;
-        arow_ok[j] = m < d.M;
-        aoy[j] = aox[j] = 0;
-        abase[j] = arow_ok[j] ? (long long)m * d.lda : 0;
-        if (d.conv_kh != 0 && arow_ok[j]) {
-            const int per = d.conv_ho * d.conv_wo;
-            const int bi = m / per, r = m - bi * per;
-            aoy[j] = (r / d.conv_wo) * d.conv_stride - d.conv_pad;
-            aox[j] = (r % d.conv_wo) * d.conv_stride - d.conv_pad;
-            abase[j] = (long long)bi * d.conv_bstride + ((long long)aoy[j] * d.conv_w + aox[j]) * d.lda;
-        }
-    }
-    // conv: tap (tky, tkx) and channel tci of k = k0 + k8; offsets/validity are refreshed only when the tap moves
-    int tky = 0, tkx = 0, tci = 0;
-    long long aoff[2] = {abase[0] + k8, abase[1] + k8};
-    bool aval[2] = {arow_ok[0], arow_ok[1]};
-    auto refresh_tap = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int iy = aoy[j] + tky, ix = aox[j] + tkx;
-            aval[j] = arow_ok[j] && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w;
-            aoff[j] = abase[j] + (long long)(tky * d.conv_w + tkx) * d.lda + tci;
-        }
-    };
-    if (d.conv_kh != 0) {
-        const int tap = k8 / d.conv_cin;
-        tci = k8 - tap * d.conv_cin;
-        tky = tap / d.conv_kw;
-        tkx = tap - tky * d.conv_kw;
-        refresh_tap();
-    }
-    unsigned boff[NJ];  // byte offset of this thread's B slot (0xFFFFFFFF: column past N)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + r0 + 64 * j;
-        boff[j] = n < d.N ? (unsigned)(((long long)n * d.ldb + k8) * 4) : 0xFFFFFFFFu;
-    }
-
-    // Convolutions with Cin % 32 == 0 walk K channel-slice-major, exactly like the LDS-DMA kernel (same summation
-    // order in every pre-split kernel: the result does not depend on the tile configuration the autotuner picks;
-    // the taps of a slice re-read L2-resident pixels).  Per row: a bit mask of the taps inside the image.
-    const int ntaps = d.conv_kh * d.conv_kw;
-    const bool cmajor = d.conv_kh != 0 && d.conv_cin % BK == 0 && ntaps <= 32;
-    unsigned vmask[2] = {0u, 0u}, abyte[2] = {0u, 0u}, bbyte[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) bbyte[j] = boff[j];
-    if (cmajor) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            for (int t = 0; t < ntaps; ++t) {
-                const int iy = aoy[j] + t / d.conv_kw, ix = aox[j] + t % d.conv_kw;
-                if (arow_ok[j] && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) vmask[j] |= 1u << t;
-            }
-            abyte[j] = (unsigned)((abase[j] + k8) * 4);
-        }
-    }
-    int ctap = 0, cky = 0, ckx = 0, cci = 0;  // wave-uniform position of the next tile in channel-major order
-
-    f32x16 acc[2][NJ];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // three K tiles in flight in registers (a tile's MFMAs are ~1000 cycles, an L2/HBM round trip is longer)
-    struct Stage {
-        u4 ah[2], al[2], bh[NJ], bl[NJ];
-    };
-    Stage s0, s1, s2;
-    int kcur = k8;  // k of this thread's slot in the tile being fetched
-    auto fetch = [&](Stage& sg) __attribute__((always_inline)) {
-        if (cmajor) {
-            const unsigned kin = cci < d.conv_cin ? 1u : 0u;
-            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci) * 4);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const unsigned dead = ((vmask[j] >> ctap) & kin) - 1u;  // 0 or 0xFFFFFFFF (out of range: reads zeros)
-                sg.ah[j] = __builtin_amdgcn_raw_buffer_load_b128(Ar, (abyte[j] + tapoff) | dead, 0, 0);
-                sg.al[j] = __builtin_amdgcn_raw_buffer_load_b128(Ar, (abyte[j] + tapoff + 16) | dead, 0, 0);
-            }
-            const unsigned koff = (unsigned)((ctap * d.conv_cin + cci) * 4);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const unsigned dead = (kin & (bbyte[j] != 0xFFFFFFFFu ? 1u : 0u)) - 1u;
-                sg.bh[j] = __builtin_amdgcn_raw_buffer_load_b128(Br, (bbyte[j] + koff) | dead, 0, 0);
-                sg.bl[j] = __builtin_amdgcn_raw_buffer_load_b128(Br, (bbyte[j] + koff + 16) | dead, 0, 0);
-            }
-            const bool row_end = ckx + 1 == d.conv_kw, tap_end = row_end && cky + 1 == d.conv_kh;
-            ckx = row_end ? 0 : ckx + 1;
-            cky = tap_end ? 0 : (row_end ? cky + 1 : cky);
-            ctap = tap_end ? 0 : ctap + 1;
-            cci = tap_end ? cci + BK : cci;
-            return;
-        }
-        const bool kin = kcur < d.K;  // tiles past the end read zeros (never consumed)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool ok = aval[j] && kin;
-            const unsigned off = ok ? (unsigned)(aoff[j] * 4) : 0xFFFFFFFFu;
-            sg.ah[j] = __builtin_amdgcn_raw_buffer_load_b128(Ar, off, 0, 0);
-            sg.al[j] = __builtin_amdgcn_raw_buffer_load_b128(Ar, ok ? off + 16 : off, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const bool ok = kin && boff[j] != 0xFFFFFFFFu;
-            const unsigned off = ok ? boff[j] : 0xFFFFFFFFu;
-            sg.bh[j] = __builtin_amdgcn_raw_buffer_load_b128(Br, off, 0, 0);
-            sg.bl[j] = __builtin_amdgcn_raw_buffer_load_b128(Br, ok ? off + 16 : off, 0, 0);
-            boff[j] = boff[j] == 0xFFFFFFFFu ? boff[j] : boff[j] + 4 * BK;
-        }
-        kcur += BK;
-        if (d.conv_kh == 0) {
-            aoff[0] += BK;
-            aoff[1] += BK;
-        } else {
-            tci += BK;
-            if (tci >= d.conv_cin) {  // the tap moves (for Cin % 32 == 0: in every lane at once)
-                while (tci >= d.conv_cin) {
-                    tci -= d.conv_cin;
-                    if (++tkx == d.conv_kw) {
-                        tkx = 0;
-                        ++tky;
-                    }
-                }
-                refresh_tap();
-            } else {
-                aoff[0] += BK;
-                aoff[1] += BK;
-            }
-        }
-    };
-    auto stash = [&](int buf, const Stage& sg) __attribute__((always_inline)) {
-        _Float16* st = lds + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *(u4*)(st + (r0 + 64 * j) * 32 + wchunk) = sg.ah[j];
-            *(u4*)(st + PLANE_A + (r0 + 64 * j) * 32 + wchunk) = sg.al[j];
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            *(u4*)(st + 2 * PLANE_A + (r0 + 64 * j) * 32 + wchunk) = sg.bh[j];
-            *(u4*)(st + 2 * PLANE_A + PLANE_B + (r0 + 64 * j) * 32 + wchunk) = sg.bl[j];
-        }
-    };
-
-    const int nk = (d.K + BK - 1) / BK;
-    const int sw = (l31 >> 2) & 3;  // read-side swizzle of this lane's rows
-    auto mma = [&](int buf) __attribute__((always_inline)) {
-        const _Float16* st = lds + buf * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ch = ((ks * 2 + lh) ^ sw) * 8;
-            h8 ah[2], al[2], bh[NJ], bl[NJ];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * 32 + ch);
-                al[i] = *(const h8*)(st + PLANE_A + (wr * 64 + i * 32 + l31) * 32 + ch);
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                bh[j] = *(const h8*)(st + 2 * PLANE_A + (wc * 32 * NJ + j * 32 + l31) * 32 + ch);
-                bl[j] = *(const h8*)(st + 2 * PLANE_A + PLANE_B + (wc * 32 * NJ + j * 32 + l31) * 32 + ch);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    acc[i][j] = pp_mfma(al[i], bh[j], acc[i][j]);
-                    acc[i][j] = pp_mfma(ah[i], bl[j], acc[i][j]);
-                    acc[i][j] = pp_mfma(ah[i], bh[j], acc[i][j]);
-                }
-        }
-    };
-    // tile t lives in register stage t % 3; LDS buffer t & 1.  Per tile: publish tile t+1 into the other LDS
-    // buffer (last read before the previous barrier), refill its registers with tile t+4, MFMAs on tile t, barrier.
-    fetch(s0);       // tile 0
-    stash(0, s0);
-    fetch(s1);       // tile 1
-    fetch(s2);       // tile 2
-    fetch(s0);       // tile 3
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 3) {
-        stash((kt + 1) & 1, s1);
-        fetch(s1);   // tile kt + 4
-        mma(kt & 1);
-        __syncthreads();
-        if (kt + 1 < nk) {
-            stash((kt + 2) & 1, s2);
-            fetch(s2);
-            mma((kt + 1) & 1);
-            __syncthreads();
-        }
-        if (kt + 2 < nk) {
-            stash((kt + 3) & 1, s0);
-            fetch(s0);
-            mma((kt + 2) & 1);
-            __syncthreads();
-        }
-    }
-    // (the K loop ends with a barrier: the staging buffers are free; each wave uses a private patch)
-    epilogue_block<NJ>(d, d.alpha / (A_SCALE * d.b_scale), acc, (float*)lds + w * 32 * (32 * NJ + 4), m0 + wr * 64, n0 + wc * 32 * NJ,
-                       lane);
-}
-
-// ---------------------------------------------------------------------------
-// f16x3, both operands pre-split, LARGE problems: 256x128 block tile, 8 waves (4 x 2, 64x64 each), one
-// workgroup per CU.  The operand tiles go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging
-// registers, no ds_write pass (the VGPR->LDS store path was the busiest unit of the register-staged kernel).
-//   - hl operands: a K tile of 32 is ONE 128-byte segment per row (hi and lo terms interleaved per 8 k), so an
-//     LDS-DMA wave instruction (1 KB) moves 8 full cache lines; with separate hi / lo planes the same bytes were
-//     64-byte segments and the L2 -> LDS delivery (tools/dma_probe.hip: 12.6 vs 18.8 TB/s), not the MFMAs, set
-//     the pace of the K loop;
-//   - LDS ring of 3 stages x 48 KB (A 256 rows, B 128 rows of 128 bytes); a DMA instruction fills 8 rows
-//     lane-linearly, so the bank swizzle (16-byte chunk c of row r at position c ^ ((r >> 1) & 7): conflict-free
-//     ds_read_b128 fragments) is applied to the per-lane SOURCE address;
-//   - two K tiles in flight across the barrier: in the middle of iteration t — after the second-half fragments
-//     of tile t are in registers — a counted `s_waitcnt vmcnt(6)` (6 DMA per wave per tile) retires this wave's
-//     loads of tile t+1, the raw s_barrier publishes it and frees tile t's stage, tile t+3 is issued into it and
-//     the first-half fragments of tile t+1 are read while the second-half MFMAs of tile t run; one barrier per tile;
-//   - padded taps / row, column and K tails: an out-of-range buffer offset makes the DMA write zeros;
-//   - convolutions with Cin % 32 == 0 walk K channel-slice-major (all taps of a 32-channel slice back to back:
-//     the taps re-read L2-resident pixels); only the fp32 summation order differs;
-//   - workgroup ids are remapped bijectively so the column tiles of one row tile (which share the A rows) and
-//     neighbouring row tiles (3x3 halo) run on the same XCD and hit its L2.
-// ---------------------------------------------------------------------------
-constexpr int GBM = 256, GBN = 128;
-constexpr int G_ROWH = 64;                                      // halfs per LDS row: 32 k x (hi, lo)
-constexpr int G_A_H = GBM * G_ROWH, G_B_H = GBN * G_ROWH;        // halfs per operand per stage
-constexpr int G_STAGE = G_A_H + G_B_H;                          // 24576 halfs = 48 KB
-constexpr int G_STAGES = 3;
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
 }  // namespace
-
-// MODE 0: dense A; 1: convolution, channel-slice-major K order (Cin % 32 == 0); 2: convolution, natural K order
-// (external linkage: hipcc does not emit the host-side handle of this templated kernel from the unnamed namespace)
-template <int MODE>
-__global__ __launch_bounds__(512, 1) void pp_gemm_f16x3g_kernel(const PpGemmDesc d, int gx, int gy) {
-#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (it cannot instantiate the LDS-DMA builtins)
-    extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
-    // XCD-aware (bijective) remap: ids that land on one XCD (id % 8) walk consecutive tiles
-    const int nwg = gx * gy, orig = blockIdx.x;
-    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int m0 = (wg / gx) * GBM, n0 = (wg % gx) * GBN;
-    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
-
-    // DMA slots of this lane: instruction q of the wave fills rows (q*8 + w)*8 + (lane >> 3) (A: q = 0..3, B: q = 0, 1);
-    // LDS chunk position lane & 7 holds source chunk sc = (lane & 7) ^ ((row >> 1) & 7) — the same for all six rows —
-    // = term (sc & 1) of the 8 k starting at 8 (sc >> 1)
-    const int lr = lane >> 3;
-    const int sc = (lane & 7) ^ ((((w & 1) << 2) + (lr >> 1)) & 7);
-    const int k8 = (sc >> 1) * 8;                // first k of this lane's chunk inside a K tile
-    const unsigned pbyte = (unsigned)(sc & 1) * 16;  // hi / lo term: byte offset inside the 32-byte group
-    int aoy[4], aox[4];
-    long long abase[4];
-    bool arow_ok[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + (j * 8 + w) * 8 + lr;
-        arow_ok[j] = m < d.M;
-        aoy[j] = aox[j] = 0;
-        abase[j] = arow_ok[j] ? (long long)m * d.lda : 0;
-        if (d.conv_kh != 0 && arow_ok[j]) {
-            const int per = d.conv_ho * d.conv_wo;
-            const int bi = m / per, r = m - bi * per;
-            aoy[j] = (r / d.conv_wo) * d.conv_stride - d.conv_pad;
-            aox[j] = (r % d.conv_wo) * d.conv_stride - d.conv_pad;
-            abase[j] = (long long)bi * d.conv_bstride + ((long long)aoy[j] * d.conv_w + aox[j]) * d.lda;
-        }
-    }
-    // natural K order (k = (ky*kw + kx)*Cin + ci): per-lane tap / channel of k = k0 + k8, refreshed when the tap moves
-    int tky = 0, tkx = 0, tci = 0;
-    long long aoff[4];
-    bool aval[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        aoff[j] = abase[j] + k8;
-        aval[j] = arow_ok[j];
-    }
-    auto refresh_tap = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int iy = aoy[j] + tky, ix = aox[j] + tkx;
-            aval[j] = arow_ok[j] && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w;
-            aoff[j] = abase[j] + (long long)(tky * d.conv_w + tkx) * d.lda + tci;
-        }
-    };
-    if (MODE == 2) {
-        const int tap = k8 / d.conv_cin;
-        tci = k8 - tap * d.conv_cin;
-        tky = tap / d.conv_kw;
-        tkx = tap - tky * d.conv_kw;
-        refresh_tap();
-    }
-    unsigned boff[2];  // byte offset of this lane's B chunks (0xFFFFFFFF: column past N)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int nb = n0 + (j * 8 + w) * 8 + lr;
-        boff[j] = nb < d.N ? (unsigned)(((long long)nb * d.ldb + k8) * 4) + pbyte : 0xFFFFFFFFu;
-    }
-    // channel-slice-major K order for convolutions with Cin % 32 == 0: per row a bit mask of the taps inside the image
-    const int ntaps = d.conv_kh * d.conv_kw;
-    unsigned vmask[4] = {0u, 0u, 0u, 0u}, abyte[4] = {0u, 0u, 0u, 0u};
-    const unsigned bbyte[2] = {boff[0], boff[1]};
-    if (MODE == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            for (int t = 0; t < ntaps; ++t) {
-                const int iy = aoy[j] + t / d.conv_kw, ix = aox[j] + t % d.conv_kw;
-                if (arow_ok[j] && iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) vmask[j] |= 1u << t;
-            }
-            abyte[j] = (unsigned)((abase[j] + k8) * 4) + pbyte;
-        }
-    }
-    int ctap = 0, cky = 0, ckx = 0, cci = 0;  // wave-uniform position of the next tile in channel-major order
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    int kcur = k8;
-    constexpr bool cmajor = MODE == 1;
-    // Offsets of the 6 LDS-DMA pieces of the next K tile (A rows j = 0..3, B rows j = 0, 1), then `advance`.  For
-    // MODE 0 / 1 everything here is straight-line code (selects, no branches), so the K loop body is one basic
-    // block and the pieces can be spread between the MFMAs (an LDS-DMA costs the wave ~60-180 issue cycles: six in
-    // a row right after the barrier stall the matrix pipe of both waves of a SIMD at once).
-    auto off_a = [&](int j) __attribute__((always_inline)) -> unsigned {
-        if (cmajor) {  // (bitwise, not &&: a short-circuit on the wave-uniform term would become a branch)
-            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci) * 4);
-            const unsigned ok = (vmask[j] >> ctap) & (cci < d.conv_cin ? 1u : 0u);
-            return (abyte[j] + tapoff) | (ok - 1u);  // ok = 0 -> 0xFFFFFFFF (plain ALU: `?:` here compiles to exec-masked blocks)
-        }
-        const unsigned ok = (aval[j] ? 1u : 0u) & (kcur < d.K ? 1u : 0u);
-        return ((unsigned)(aoff[j] * 4) + pbyte) | (ok - 1u);
-    };
-    auto off_b = [&](int j) __attribute__((always_inline)) -> unsigned {
-        if (cmajor) {
-            const unsigned ok = (cci < d.conv_cin ? 1u : 0u) & (bbyte[j] != 0xFFFFFFFFu ? 1u : 0u);
-            return (bbyte[j] + (unsigned)((ctap * d.conv_cin + cci) * 4)) | (ok - 1u);
-        }
-        return boff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
-    };
-    auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * G_STAGE + ((j * 8 + w) * 8) * G_ROWH), 16, off_a(j), 0, 0, 0);
-    };
-    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * G_STAGE + G_A_H + ((j * 8 + w) * 8) * G_ROWH), 16, off_b(j), 0, 0, 0);
-    };
-    auto advance = [&]() __attribute__((always_inline)) {
-        if (cmajor) {
-            const bool row_end = ckx + 1 == d.conv_kw, tap_end = row_end && cky + 1 == d.conv_kh;
-            ckx = row_end ? 0 : ckx + 1;
-            cky = tap_end ? 0 : (row_end ? cky + 1 : cky);
-            ctap = tap_end ? 0 : ctap + 1;
-            cci = tap_end ? cci + BK : cci;
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) boff[j] = boff[j] == 0xFFFFFFFFu ? boff[j] : boff[j] + 4 * BK;
-        kcur += BK;
-        if (MODE == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) aoff[j] += BK;
-        } else {
-            tci += BK;
-            if (tci >= d.conv_cin) {
-                while (tci >= d.conv_cin) {
-                    tci -= d.conv_cin;
-                    if (++tkx == d.conv_kw) {
-                        tkx = 0;
-                        ++tky;
-                    }
-                }
-                refresh_tap();
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) aoff[j] += BK;
-            }
-        }
-    };
-    auto fetch = [&](int stage) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma_a(stage, j);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dma_b(stage, j);
-        advance();
-    };
-    const int sw = (l31 >> 1) & 7;  // read-side swizzle of this lane's rows (tile row offsets are multiples of 16)
-    struct Frag {
-        h8 ah[2], al[2], bh[2], bl[2];
-    };
-    // fragments of K half `ks` (16 k) of the tile in ring stage `stage`: 8 conflict-free ds_read_b128
-    auto load_frag = [&](Frag& f, int stage, int ks) __attribute__((always_inline)) {
-        const _Float16* st = glds + stage * G_STAGE;
-        const int ch = (((ks * 2 + lh) * 2) ^ sw) * 8, cl = (((ks * 2 + lh) * 2 + 1) ^ sw) * 8;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f.ah[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * G_ROWH + ch);
-            f.al[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * G_ROWH + cl);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            f.bh[j] = *(const h8*)(st + G_A_H + (wc * 64 + j * 32 + l31) * G_ROWH + ch);
-            f.bl[j] = *(const h8*)(st + G_A_H + (wc * 64 + j * 32 + l31) * G_ROWH + cl);
-        }
-    };
-    auto mma = [&](const Frag& f) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = pp_mfma(f.al[i], f.bh[j], acc[i][j]);
-                acc[i][j] = pp_mfma(f.ah[i], f.bl[j], acc[i][j]);
-                acc[i][j] = pp_mfma(f.ah[i], f.bh[j], acc[i][j]);
-            }
-    };
-    // Ring: tile t lives in stage t % 3.  Iteration t holds tile t (being read), t+1 and t+2 (DMA in flight).
-    const int nk = (d.K + BK - 1) / BK;
-    fetch(0);
-    fetch(1);
-    fetch(2);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    Frag f0, f1;
-    load_frag(f0, 0, 0);
-    int cur = 0, nxt = 1;  // ring stage of tile kt / of tile kt + 1
-    // one accumulator tile (i, j): the three MFMAs of the f16x3 product
-    auto mma1 = [&](const Frag& f, int i, int j) __attribute__((always_inline)) {
-        acc[i][j] = pp_mfma(f.al[i], f.bh[j], acc[i][j]);
-        acc[i][j] = pp_mfma(f.ah[i], f.bl[j], acc[i][j]);
-        acc[i][j] = pp_mfma(f.ah[i], f.bh[j], acc[i][j]);
-    };
-    for (int kt = 0; kt < nk; ++kt) {
-        load_frag(f1, cur, 1);
-        mma(f0);
-        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (MODE == 2) {
-            fetch(cur);  // tile kt + 3 (tiles past the end: zeros, never used)
-            load_frag(f0, nxt, 0);
-            mma(f1);
-        } else {
-            // The 6 DMA pieces of tile kt + 3 and the 8 fragment reads of the next half tile spread over the 12
-            // MFMAs of this half (order pinned: hipcc would issue all DMA pieces first)
-            const _Float16* st = glds + nxt * G_STAGE;
-            const int ch = ((lh * 2) ^ sw) * 8, cl = ((lh * 2 + 1) ^ sw) * 8;
-            const _Float16* ap = st + (wr * 64 + l31) * G_ROWH;
-            const _Float16* bp = st + G_A_H + (wc * 64 + l31) * G_ROWH;
-            dma_a(cur, 0);
-            f0.ah[0] = *(const h8*)(ap + ch);
-            f0.al[0] = *(const h8*)(ap + cl);
-            mma1(f1, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_a(cur, 1);
-            f0.bh[0] = *(const h8*)(bp + ch);
-            f0.bl[0] = *(const h8*)(bp + cl);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_a(cur, 2);
-            mma1(f1, 0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_a(cur, 3);
-            f0.ah[1] = *(const h8*)(ap + 32 * G_ROWH + ch);
-            f0.al[1] = *(const h8*)(ap + 32 * G_ROWH + cl);
-            mma1(f1, 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_b(cur, 0);
-            f0.bh[1] = *(const h8*)(bp + 32 * G_ROWH + ch);
-            f0.bl[1] = *(const h8*)(bp + 32 * G_ROWH + cl);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_b(cur, 1);
-            advance();
-            mma1(f1, 1, 1);
-        }
-        cur = nxt;
-        nxt = nxt == G_STAGES - 1 ? 0 : nxt + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS at exit
-
-    // epilogue through LDS: the ring is free once every wave is past its last fragment read
-    __builtin_amdgcn_s_barrier();
-    epilogue_block<2>(d, d.alpha / (A_SCALE * d.b_scale), acc, (float*)glds + w * 32 * 68, m0 + wr * 64, n0 + wc * 64, lane);
-#endif
-}
-
-// Two workgroups per CU ("d", cfg 7): the 256x128 tile of the kernel above with 4 waves (2 x 2, 128x64 each) and K tiles
-// of 16 (one MFMA step; 64-byte row segments) in a ring of 3 x 24 KB, so two workgroups share a CU and the epilogue of
-// one (20-25 % of a K = 768 tile, during which the matrix pipe of a one-workgroup CU idles) runs under the K loop of the
-// other; a wave's 128x64 block also needs 0.5 fragment reads per MFMA instead of 0.67.  Dense A only.  LDS row r holds
-// its four 16-byte chunks at positions c ^ ((r >> 2) & 3) (conflict-free ds_read_b128, applied to the DMA source side).
-// Same K order and accumulation as every other pre-split kernel.
-__device__ __forceinline__ void tile_rc(int t, int gx, int gy, int& r, int& c);
-constexpr int D_KT = 16, D_ROWH = 32;                          // halfs per LDS row: 16 k x (hi, lo) = 64 bytes
-constexpr int D_A_H = GBM * D_ROWH, D_B_H = GBN * D_ROWH;
-constexpr int D_STAGE = D_A_H + D_B_H;                         // 12288 halfs = 24 KB
-constexpr int D_STAGES = 3;
-constexpr int D_LDS_BYTES = D_STAGES * D_STAGE * 2;            // 72 KB: two workgroups in the 160 KB of a CU
-
-// MODE 0: dense A; 1: convolution, channel-slice-major K order (Cin % 32 == 0): a K tile of 16 is half of one tap's 32-channel slice
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void pp_gemm_f16x3d_kernel(const PpGemmDesc d, int gx, int gy) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
-    const int nwg = gx * gy, orig = blockIdx.x;
-    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    int tr_, tc_;   // bands of 4 tile rows x groups of <= 8 tile columns (tile_rc): the 64 workgroups resident on an XCD share
-    tile_rc(wg, gx, gy, tr_, tc_);   // 4 A row slices and 8 B column slices instead of 3.5 rows x the whole width of B (within
-    const int m0 = tr_ * GBM, n0 = tc_ * GBN;   // 1 % of plain row-major order in an A/B on the ViT-B linears)
-    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
-
-    // DMA slots: instruction q of wave w fills rows (q*4 + w)*16 + (lane >> 2) (A: q = 0..3, B: q = 0, 1); LDS chunk
-    // position lane & 3 holds source chunk sc = term (sc & 1) of the 8 k starting at 8 (sc >> 1)
-    const int lr = lane >> 2;
-    const int sc = (lane & 3) ^ ((lr >> 2) & 3);
-    int kcur = (sc >> 1) * 8;
-    unsigned aoff[4], boff[2];  // byte offsets of this lane's chunks (0xFFFFFFFF: row past M / N -> zeros)
-    unsigned vmask[4] = {0u, 0u, 0u, 0u};   // MODE 1: bit t = tap t of A row j lies inside the image
-    int ctap = 0, cky = 0, ckx = 0, cci = 0, chalf = 0;   // MODE 1 (wave-uniform): tap / channel slice / half of the next K tile
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + (j * 4 + w) * 16 + lr;
-        if (MODE == 0) {
-            aoff[j] = m < d.M ? (unsigned)((long long)m * d.lda * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
-        } else {
-            long long abase = 0;
-            if (m < d.M) {
-                const int per = d.conv_ho * d.conv_wo;
-                const int bi = m / per, r = m - bi * per;
-                const int oy = (r / d.conv_wo) * d.conv_stride - d.conv_pad, ox = (r % d.conv_wo) * d.conv_stride - d.conv_pad;
-                abase = (long long)bi * d.conv_bstride + ((long long)oy * d.conv_w + ox) * d.lda;
-                for (int t = 0; t < d.conv_kh * d.conv_kw; ++t) {
-                    const int iy = oy + t / d.conv_kw, ix = ox + t % d.conv_kw;
-                    if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) vmask[j] |= 1u << t;
-                }
-            }
-            aoff[j] = (unsigned)(abase * 4) + (unsigned)sc * 16u;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int nb = n0 + (j * 4 + w) * 16 + lr;
-        boff[j] = nb < d.N ? (unsigned)((long long)nb * d.ldb * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
-    }
-    auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
-        unsigned off;
-        if (MODE == 0) {
-            off = aoff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
-        } else {   // (bitwise selects, no branches: the K loop body stays one basic block)
-            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci + D_KT * chalf) * 4);
-            const unsigned ok = (vmask[j] >> ctap) & (cci < d.conv_cin ? 1u : 0u);
-            off = (aoff[j] + tapoff) | (ok - 1u);
-        }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * D_STAGE + ((j * 4 + w) * 16) * D_ROWH), 16, off, 0, 0, 0);
-    };
-    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
-        unsigned off;
-        if (MODE == 0) {
-            off = boff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
-        } else {
-            const unsigned ok = (cci < d.conv_cin ? 1u : 0u) & (boff[j] != 0xFFFFFFFFu ? 1u : 0u);
-            off = (boff[j] + (unsigned)((ctap * d.conv_cin + cci + D_KT * chalf) * 4)) | (ok - 1u);
-        }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * D_STAGE + D_A_H + ((j * 4 + w) * 16) * D_ROWH), 16, off, 0, 0, 0);
-    };
-    auto advance = [&]() __attribute__((always_inline)) {
-        if (MODE == 1) {   // (tap, 32-channel slice) in channel-slice-major order, two 16-channel halves per tap
-            const bool tap_next = chalf == 1;
-            const bool row_end = ckx + 1 == d.conv_kw, tap_end = row_end && cky + 1 == d.conv_kh;
-            chalf ^= 1;
-            cci = tap_next && tap_end ? cci + BK : cci;
-            ctap = !tap_next ? ctap : (tap_end ? 0 : ctap + 1);
-            const int nky = tap_end ? 0 : (row_end ? cky + 1 : cky), nkx = row_end ? 0 : ckx + 1;
-            cky = tap_next ? nky : cky;
-            ckx = tap_next ? nkx : ckx;
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) aoff[j] = aoff[j] == 0xFFFFFFFFu ? aoff[j] : aoff[j] + 4 * D_KT;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) boff[j] = boff[j] == 0xFFFFFFFFu ? boff[j] : boff[j] + 4 * D_KT;
-        kcur += D_KT;
-    };
-    auto fetch = [&](int stage) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma_a(stage, j);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dma_b(stage, j);
-        advance();
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int sw = (l31 >> 2) & 3;
-    const int ch = ((lh * 2) ^ sw) * 8, cl = ((lh * 2 + 1) ^ sw) * 8;   // hi / lo chunk of this lane's 8 k
-    const int arow = (wr * 128 + l31) * D_ROWH, brow = D_A_H + (wc * 64 + l31) * D_ROWH;
-    struct Frag {
-        h8 ah[4], al[4], bh[2], bl[2];
-    };
-    auto mma1 = [&](const Frag& f, int i, int j) __attribute__((always_inline)) {
-        acc[i][j] = pp_mfma(f.al[i], f.bh[j], acc[i][j]);
-        acc[i][j] = pp_mfma(f.ah[i], f.bl[j], acc[i][j]);
-        acc[i][j] = pp_mfma(f.ah[i], f.bh[j], acc[i][j]);
-    };
-    const int nk = (d.K + D_KT - 1) / D_KT;
-    fetch(0);
-    fetch(1);
-    fetch(2);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    Frag fa, fb;
-    {
-        const _Float16* st = glds;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fa.ah[i] = *(const h8*)(st + arow + i * 32 * D_ROWH + ch);
-            fa.al[i] = *(const h8*)(st + arow + i * 32 * D_ROWH + cl);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            fa.bh[j] = *(const h8*)(st + brow + j * 32 * D_ROWH + ch);
-            fa.bl[j] = *(const h8*)(st + brow + j * 32 * D_ROWH + cl);
-        }
-    }
-    int cur = 0, nxt = 1;
-    // One K tile: first half of the MFMAs of tile kt (fragments F, complete), then the barrier that publishes tile kt + 1
-    // and frees tile kt's stage, then the 6 DMA pieces of tile kt + 3 and the 12 fragment reads of tile kt + 1 (into G)
-    // spread over the second half of the MFMAs.
-#define PP_D_TILE(F, G)                                                                      \
-    {                                                                                        \
-        mma1(F, 0, 0);                                                                       \
-        mma1(F, 0, 1);                                                                       \
-        mma1(F, 1, 0);                                                                       \
-        mma1(F, 1, 1);                                                                       \
-        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                          \
-        __builtin_amdgcn_s_barrier();                                                        \
-        const _Float16* st = glds + nxt * D_STAGE;                                           \
-        dma_a(cur, 0);                                                                       \
-        G.ah[0] = *(const h8*)(st + arow + ch);                                              \
-        G.al[0] = *(const h8*)(st + arow + cl);                                              \
-        mma1(F, 2, 0);                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        dma_a(cur, 1);                                                                       \
-        G.bh[0] = *(const h8*)(st + brow + ch);                                              \
-        G.bl[0] = *(const h8*)(st + brow + cl);                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        dma_a(cur, 2);                                                                       \
-        G.ah[1] = *(const h8*)(st + arow + 32 * D_ROWH + ch);                                \
-        G.al[1] = *(const h8*)(st + arow + 32 * D_ROWH + cl);                                \
-        mma1(F, 2, 1);                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        dma_a(cur, 3);                                                                       \
-        G.bh[1] = *(const h8*)(st + brow + 32 * D_ROWH + ch);                                \
-        G.bl[1] = *(const h8*)(st + brow + 32 * D_ROWH + cl);                                \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        dma_b(cur, 0);                                                                       \
-        G.ah[2] = *(const h8*)(st + arow + 64 * D_ROWH + ch);                                \
-        G.al[2] = *(const h8*)(st + arow + 64 * D_ROWH + cl);                                \
-        mma1(F, 3, 0);                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        dma_b(cur, 1);                                                                       \
-        advance();                                                                           \
-        G.ah[3] = *(const h8*)(st + arow + 96 * D_ROWH + ch);                                \
-        G.al[3] = *(const h8*)(st + arow + 96 * D_ROWH + cl);                                \
-        mma1(F, 3, 1);                                                                       \
-        cur = nxt;                                                                           \
-        nxt = nxt == D_STAGES - 1 ? 0 : nxt + 1;                                             \
-    }
-    for (int kt = 0; kt < nk; kt += 2) {
-        PP_D_TILE(fa, fb)
-        if (kt + 1 < nk) PP_D_TILE(fb, fa)
-    }
-#undef PP_D_TILE
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS at exit
-    __builtin_amdgcn_s_barrier();
-    const float descale = d.alpha / (A_SCALE * d.b_scale);
-    float* Os = (float*)glds + w * 32 * 68;
-    epilogue_block<2>(d, descale, reinterpret_cast<f32x16(&)[2][2]>(acc[0]), Os, m0 + wr * 128, n0 + wc * 64, lane);
-    epilogue_block<2>(d, descale, reinterpret_cast<f32x16(&)[2][2]>(acc[2]), Os, m0 + wr * 128 + 64, n0 + wc * 64, lane);
-#endif
-}
-
-// Three workgroups per CU ("e", cfg 8): the same scheme on a 128x128 tile (4 waves, 2 x 2, 64x64 each; ring of 3 x 16 KB) for
-// dense problems whose 256-row tiling leaves the chip badly filled (the query-side ViT GEMMs, M = 8 224: 3.09 waves of 256x128
-// tiles) — twice the tiles, 768 resident workgroups.  Same K order and accumulation as every other pre-split kernel.
-constexpr int EBM = 128, EBN = 128;
-constexpr int E_A_H = EBM * D_ROWH, E_B_H = EBN * D_ROWH;
-constexpr int E_STAGE = E_A_H + E_B_H;                         // 8192 halfs = 16 KB
-constexpr int E_LDS_BYTES = D_STAGES * E_STAGE * 2;            // 48 KB: three workgroups in the 160 KB of a CU
-
-template <int MODE>
-__global__ __launch_bounds__(256, 3) void pp_gemm_f16x3e_kernel(const PpGemmDesc d, int gx, int gy) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
-    const int nwg = gx * gy, orig = blockIdx.x;
-    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    int tr_, tc_;
-    tile_rc(wg, gx, gy, tr_, tc_);
-    const int m0 = tr_ * EBM, n0 = tc_ * EBN;
-    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
-    // DMA slots: instruction q (0, 1) of wave w fills rows (q*4 + w)*16 + (lane >> 2) of A and of B; chunk swizzle as above
-    const int lr = lane >> 2;
-    const int sc = (lane & 3) ^ ((lr >> 2) & 3);
-    int kcur = (sc >> 1) * 8;
-    unsigned aoff[2], boff[2];
-    unsigned vmask[2] = {0u, 0u};
-    int ctap = 0, cky = 0, ckx = 0, cci = 0, chalf = 0;   // MODE 1: as in the two-per-CU kernel above
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = m0 + (j * 4 + w) * 16 + lr, nb = n0 + (j * 4 + w) * 16 + lr;
-        if (MODE == 0) {
-            aoff[j] = m < d.M ? (unsigned)((long long)m * d.lda * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
-        } else {
-            long long abase = 0;
-            if (m < d.M) {
-                const int per = d.conv_ho * d.conv_wo;
-                const int bi = m / per, r = m - bi * per;
-                const int oy = (r / d.conv_wo) * d.conv_stride - d.conv_pad, ox = (r % d.conv_wo) * d.conv_stride - d.conv_pad;
-                abase = (long long)bi * d.conv_bstride + ((long long)oy * d.conv_w + ox) * d.lda;
-                for (int t = 0; t < d.conv_kh * d.conv_kw; ++t) {
-                    const int iy = oy + t / d.conv_kw, ix = ox + t % d.conv_kw;
-                    if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) vmask[j] |= 1u << t;
-                }
-            }
-            aoff[j] = (unsigned)(abase * 4) + (unsigned)sc * 16u;
-        }
-        boff[j] = nb < d.N ? (unsigned)((long long)nb * d.ldb * 4) + (unsigned)sc * 16u : 0xFFFFFFFFu;
-    }
-    auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
-        unsigned off;
-        if (MODE == 0) {
-            off = aoff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
-        } else {
-            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci + D_KT * chalf) * 4);
-            const unsigned ok = (vmask[j] >> ctap) & (cci < d.conv_cin ? 1u : 0u);
-            off = (aoff[j] + tapoff) | (ok - 1u);
-        }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * E_STAGE + ((j * 4 + w) * 16) * D_ROWH), 16, off, 0, 0, 0);
-    };
-    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
-        unsigned off;
-        if (MODE == 0) {
-            off = boff[j] | ((kcur < d.K ? 1u : 0u) - 1u);
-        } else {
-            const unsigned ok = (cci < d.conv_cin ? 1u : 0u) & (boff[j] != 0xFFFFFFFFu ? 1u : 0u);
-            off = (boff[j] + (unsigned)((ctap * d.conv_cin + cci + D_KT * chalf) * 4)) | (ok - 1u);
-        }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * E_STAGE + E_A_H + ((j * 4 + w) * 16) * D_ROWH), 16, off, 0, 0, 0);
-    };
-    auto advance = [&]() __attribute__((always_inline)) {
-        if (MODE == 1) {
-            const bool tap_next = chalf == 1;
-            const bool row_end = ckx + 1 == d.conv_kw, tap_end = row_end && cky + 1 == d.conv_kh;
-            chalf ^= 1;
-            cci = tap_next && tap_end ? cci + BK : cci;
-            ctap = !tap_next ? ctap : (tap_end ? 0 : ctap + 1);
-            const int nky = tap_end ? 0 : (row_end ? cky + 1 : cky), nkx = row_end ? 0 : ckx + 1;
-            cky = tap_next ? nky : cky;
-            ckx = tap_next ? nkx : ckx;
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            aoff[j] = aoff[j] == 0xFFFFFFFFu ? aoff[j] : aoff[j] + 4 * D_KT;
-            boff[j] = boff[j] == 0xFFFFFFFFu ? boff[j] : boff[j] + 4 * D_KT;
-        }
-        kcur += D_KT;
-    };
-    auto fetch = [&](int stage) __attribute__((always_inline)) {
-        dma_a(stage, 0);
-        dma_a(stage, 1);
-        dma_b(stage, 0);
-        dma_b(stage, 1);
-        advance();
-    };
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int sw = (l31 >> 2) & 3;
-    const int ch = ((lh * 2) ^ sw) * 8, cl = ((lh * 2 + 1) ^ sw) * 8;
-    const int arow = (wr * 64 + l31) * D_ROWH, brow = E_A_H + (wc * 64 + l31) * D_ROWH;
-    struct Frag {
-        h8 ah[2], al[2], bh[2], bl[2];
-    };
-    auto mma1 = [&](const Frag& f, int i, int j) __attribute__((always_inline)) {
-        acc[i][j] = pp_mfma(f.al[i], f.bh[j], acc[i][j]);
-        acc[i][j] = pp_mfma(f.ah[i], f.bl[j], acc[i][j]);
-        acc[i][j] = pp_mfma(f.ah[i], f.bh[j], acc[i][j]);
-    };
-    const int nk = (d.K + D_KT - 1) / D_KT;
-    fetch(0);
-    fetch(1);
-    fetch(2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    Frag fa, fb;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        fa.ah[i] = *(const h8*)(glds + arow + i * 32 * D_ROWH + ch);
-        fa.al[i] = *(const h8*)(glds + arow + i * 32 * D_ROWH + cl);
-        fa.bh[i] = *(const h8*)(glds + brow + i * 32 * D_ROWH + ch);
-        fa.bl[i] = *(const h8*)(glds + brow + i * 32 * D_ROWH + cl);
-    }
-    int cur = 0, nxt = 1;
-#define PP_E_TILE(F, G)                                                                      \
-    {                                                                                        \
-        mma1(F, 0, 0);                                                                       \
-        mma1(F, 0, 1);                                                                       \
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                          \
-        __builtin_amdgcn_s_barrier();                                                        \
-        const _Float16* st = glds + nxt * E_STAGE;                                           \
-        dma_a(cur, 0);                                                                       \
-        G.ah[0] = *(const h8*)(st + arow + ch);                                              \
-        G.al[0] = *(const h8*)(st + arow + cl);                                              \
-        mma1(F, 1, 0);                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        dma_a(cur, 1);                                                                       \
-        G.bh[0] = *(const h8*)(st + brow + ch);                                              \
-        G.bl[0] = *(const h8*)(st + brow + cl);                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        dma_b(cur, 0);                                                                       \
-        G.ah[1] = *(const h8*)(st + arow + 32 * D_ROWH + ch);                                \
-        G.al[1] = *(const h8*)(st + arow + 32 * D_ROWH + cl);                                \
-        mma1(F, 1, 1);                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        dma_b(cur, 1);                                                                       \
-        advance();                                                                           \
-        G.bh[1] = *(const h8*)(st + brow + 32 * D_ROWH + ch);                                \
-        G.bl[1] = *(const h8*)(st + brow + 32 * D_ROWH + cl);                                \
-        cur = nxt;                                                                           \
-        nxt = nxt == D_STAGES - 1 ? 0 : nxt + 1;                                             \
-    }
-    for (int kt = 0; kt < nk; kt += 2) {
-        PP_E_TILE(fa, fb)
-        if (kt + 1 < nk) PP_E_TILE(fb, fa)
-    }
-#undef PP_E_TILE
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    epilogue_block<2>(d, d.alpha / (A_SCALE * d.b_scale), acc, (float*)glds + w * 32 * 68, m0 + wr * 64, n0 + wc * 64, lane);
-#endif
-}
-
-// Order in which the persistent kernels walk the output tiles: bands of 4 tile rows, inside a band column groups of
-// <= 8 tile columns, inside a group row-major.  The 32 workgroups of an XCD work on 32 consecutive tiles, i.e. on
-// ~4 tile rows x 8 tile columns: each A row slice and each B column slice missed in L2 serves 8 resp. 4 tiles (row-major
-// order over a wide N would be 1.3 rows x 24 columns: the B operand streams from the Infinity Cache all the time —
-// 29 % L2 misses on the fc1 GEMM).  For gx <= 8 this is plain row-major.  A bijection of [0, gx*gy).
-__device__ __forceinline__ void tile_rc(int t, int gx, int gy, int& r, int& c) {
-    const int ncg = (gx + 7) >> 3, band = 4 * gx;
-    const int rg = t / band;
-    int u = t - rg * band;
-    int br = gy - 4 * rg;
-    br = br > 4 ? 4 : br;  // (the last band may be short; the bands before it are full, so rg is right)
-    const int wq = gx / ncg, wrem = gx - wq * ncg;  // the first wrem groups have wq + 1 columns
-    int c0 = 0;
-    r = c = 0;
-    for (int g = 0; g < ncg; ++g) {
-        const int wg = wq + (g < wrem ? 1 : 0), cnt = br * wg;
-        if (u < cnt) {
-            r = 4 * rg + u / wg;
-            c = c0 + u % wg;
-            return;
-        }
-        u -= cnt;
-        c0 += wg;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Persistent form of the LDS-DMA kernel (MODE 0 dense, 1 channel-slice-major convolution): one workgroup per CU
-// walks a sequence of 256x128 output tiles, and the DMA stream runs ahead ACROSS tile boundaries — while the last
-// K tiles of one output tile are being multiplied the first K tiles of the next are already landing in the ring, so
-// a new tile starts without the launch + first-tile latency and its epilogue overlaps the next tile's loads.  The
-// K loop, ring protocol and arithmetic (hence every result bit) are those of pp_gemm_f16x3g_kernel; the epilogue
-// stages through a separate 16 KB LDS patch (8-row groups) because the ring is never idle.
-//   vmcnt: the epilogue's stores / residual loads are younger than the DMA pieces in flight; `vmcnt(6)` after an
-//   epilogue therefore over-waits (at most six operations of any kind outstanding implies the older tile has
-//   landed: loads retire in order) — never under-waits.
-// ---------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(512, 1) void pp_gemm_f16x3p_kernel(const PpGemmDesc d, int gx, int gy) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(MODE == 0 || MODE == 1, "natural-order convolutions use pp_gemm_f16x3g_kernel");
-    extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1, l31 = lane & 31, lh = lane >> 5;
-    // tiles of this workgroup: XCD x = id % 8 owns a contiguous chunk of the tile list; its workgroups interleave
-    // over it, so the tiles in flight on one XCD at any time are neighbours (shared A rows / halo / B columns in L2)
-    const int ntiles = gx * gy, nxw = (int)gridDim.x >> 3;  // gridDim.x is a multiple of 8
-    const int xcd = blockIdx.x & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
-    const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int chunk1 = chunk0 + (xcd < r8 ? q8 + 1 : q8);
-    const int first = chunk0 + (int)(blockIdx.x >> 3);
-    if (first >= chunk1) return;
-    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
-    const int lr = lane >> 3;
-    const int sc = (lane & 7) ^ ((((w & 1) << 2) + (lr >> 1)) & 7);
-    const int k8 = (sc >> 1) * 8;
-    const unsigned pbyte = (unsigned)(sc & 1) * 16;
-    const int ntaps = d.conv_kh * d.conv_kw;
-    const int nk = (d.K + BK - 1) / BK;
-
-    // ---- fetch side: addressing state of the tile the DMA stream is in
-    unsigned abyte[4], amask[4], bbyte[2];   // A rows: byte offset of k = 0 (+ this lane's chunk); tap mask / row-valid bit
-    int ftile = first, fkt = 0;              // tile and K-tile index of the next DMA group (wave-uniform)
-    int ctap = 0, cky = 0, ckx = 0, cci = 0;
-    // (macros, not nested lambdas: state captured by reference stayed in scratch memory, and every scratch store /
-    // reload counts in vmcnt — hipcc then drained the DMA pipeline with vmcnt(0) inside the K loop)
-#define PP_P_SETUP(TILE)                                                                                             \
-    {                                                                                                                \
-        int tr_, tc_;                                                                                                \
-        tile_rc((TILE), gx, gy, tr_, tc_);                                                                           \
-        const int m0_ = tr_ * GBM, n0_ = tc_ * GBN;                                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
-            const int m = m0_ + (j * 8 + w) * 8 + lr;                                                                \
-            const bool ok = m < d.M;                                                                                 \
-            long long base = ok ? (long long)m * d.lda : 0;                                                          \
-            unsigned mask = ok ? 1u : 0u;                                                                            \
-            if (MODE == 1) {                                                                                         \
-                mask = 0u;                                                                                           \
-                if (ok) {                                                                                            \
-                    const int per = d.conv_ho * d.conv_wo;                                                           \
-                    const int bi = m / per, r = m - bi * per;                                                        \
-                    const int oy = (r / d.conv_wo) * d.conv_stride - d.conv_pad,                                     \
-                              ox = (r % d.conv_wo) * d.conv_stride - d.conv_pad;                                     \
-                    base = (long long)bi * d.conv_bstride + ((long long)oy * d.conv_w + ox) * d.lda;                 \
-                    for (int t = 0; t < ntaps; ++t) {                                                                \
-                        const int iy = oy + t / d.conv_kw, ix = ox + t % d.conv_kw;                                  \
-                        if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) mask |= 1u << t;                   \
-                    }                                                                                                \
-                }                                                                                                    \
-            }                                                                                                        \
-            abyte[j] = (unsigned)((base + k8) * 4) + pbyte;                                                          \
-            amask[j] = mask;                                                                                         \
-        }                                                                                                            \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
-            const int nb = n0_ + (j * 8 + w) * 8 + lr;                                                               \
-            bbyte[j] = nb < d.N ? (unsigned)(((long long)nb * d.ldb + k8) * 4) + pbyte : 0xFFFFFFFFu;                \
-        }                                                                                                            \
-        fkt = 0;                                                                                                     \
-        ctap = cky = ckx = cci = 0;                                                                                  \
-    }
-    // the DMA stream moves to the workgroup's next tile once a tile's nk K tiles have been issued
-#define PP_P_NEXT_TILE_IF_DONE()                                \
-    if (fkt == nk && ftile < chunk1) {                          \
-        ftile += nxw;                                           \
-        if (ftile < chunk1) PP_P_SETUP(ftile) else fkt = 0;     \
-    }
-    // byte offsets of the six pieces of K tile fkt of tile ftile (0xFFFFFFFF reads zeros: padding, tails, past the end)
-    auto off_a = [&](int j) __attribute__((always_inline)) -> unsigned {
-        if (MODE == 1) {
-            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci) * 4);
-            const unsigned ok = (amask[j] >> ctap) & (ftile < chunk1 ? 1u : 0u);
-            return (abyte[j] + tapoff) | (ok - 1u);
-        }
-        const unsigned ok = amask[j] & (ftile < chunk1 ? 1u : 0u) & (fkt * BK + k8 < d.K ? 1u : 0u);
-        return (abyte[j] + (unsigned)(fkt * BK * 4)) | (ok - 1u);
-    };
-    auto off_b = [&](int j) __attribute__((always_inline)) -> unsigned {
-        const unsigned live = (ftile < chunk1 ? 1u : 0u) & (bbyte[j] != 0xFFFFFFFFu ? 1u : 0u);
-        if (MODE == 1) return (bbyte[j] + (unsigned)((ctap * d.conv_cin + cci) * 4)) | (live - 1u);
-        return (bbyte[j] + (unsigned)(fkt * BK * 4)) | ((live & (fkt * BK + k8 < d.K ? 1u : 0u)) - 1u);
-    };
-    auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * G_STAGE + ((j * 8 + w) * 8) * G_ROWH), 16, off_a(j), 0, 0, 0);
-    };
-    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * G_STAGE + G_A_H + ((j * 8 + w) * 8) * G_ROWH), 16, off_b(j), 0, 0, 0);
-    };
-#define PP_P_ADVANCE() /* after the six pieces of a K tile */                                       \
-    {                                                                                              \
-        if (MODE == 1) {                                                                           \
-            const bool row_end = ckx + 1 == d.conv_kw, tap_end = row_end && cky + 1 == d.conv_kh;  \
-            ckx = row_end ? 0 : ckx + 1;                                                           \
-            cky = tap_end ? 0 : (row_end ? cky + 1 : cky);                                         \
-            ctap = tap_end ? 0 : ctap + 1;                                                         \
-            cci = tap_end ? cci + BK : cci;                                                        \
-        }                                                                                          \
-        ++fkt;                                                                                     \
-    }
-#define PP_P_FETCH(STAGE)                                               \
-    {                                                                   \
-        PP_P_NEXT_TILE_IF_DONE()                                        \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) dma_a(STAGE, j);  \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) dma_b(STAGE, j);  \
-        PP_P_ADVANCE()                                                  \
-    }
-
-    const int sw = (l31 >> 1) & 7;
-    struct Frag {
-        h8 ah[2], al[2], bh[2], bl[2];
-    };
-    f32x16 acc[2][2];
-    auto load_frag = [&](Frag& f, int stage, int ks) __attribute__((always_inline)) {
-        const _Float16* st = glds + stage * G_STAGE;
-        const int ch = (((ks * 2 + lh) * 2) ^ sw) * 8, cl = (((ks * 2 + lh) * 2 + 1) ^ sw) * 8;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f.ah[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * G_ROWH + ch);
-            f.al[i] = *(const h8*)(st + (wr * 64 + i * 32 + l31) * G_ROWH + cl);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            f.bh[j] = *(const h8*)(st + G_A_H + (wc * 64 + j * 32 + l31) * G_ROWH + ch);
-            f.bl[j] = *(const h8*)(st + G_A_H + (wc * 64 + j * 32 + l31) * G_ROWH + cl);
-        }
-    };
-    auto mma1 = [&](const Frag& f, int i, int j) __attribute__((always_inline)) {
-        acc[i][j] = pp_mfma(f.al[i], f.bh[j], acc[i][j]);
-        acc[i][j] = pp_mfma(f.ah[i], f.bl[j], acc[i][j]);
-        acc[i][j] = pp_mfma(f.ah[i], f.bh[j], acc[i][j]);
-    };
-    auto mma = [&](const Frag& f) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma1(f, i, j);
-    };
-
-    PP_P_SETUP(first)
-    PP_P_FETCH(0)
-    PP_P_FETCH(1)
-    PP_P_FETCH(2)
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    Frag f0, f1;
-    load_frag(f0, 0, 0);
-    int cur = 0, nxt = 1;
-    float* patch = (float*)(glds + G_STAGES * G_STAGE) + w * 512;  // 2 KB per wave behind the ring
-    const float descale = d.alpha / (A_SCALE * d.b_scale);
-    for (int tile = first; tile < chunk1; tile += nxw) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int kt = 0; kt < nk; ++kt) {
-            load_frag(f1, cur, 1);
-            mma(f0);
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            PP_P_NEXT_TILE_IF_DONE()
-            const _Float16* st = glds + nxt * G_STAGE;
-            const int ch = ((lh * 2) ^ sw) * 8, cl = ((lh * 2 + 1) ^ sw) * 8;
-            const _Float16* ap = st + (wr * 64 + l31) * G_ROWH;
-            const _Float16* bp = st + G_A_H + (wc * 64 + l31) * G_ROWH;
-            dma_a(cur, 0);
-            f0.ah[0] = *(const h8*)(ap + ch);
-            f0.al[0] = *(const h8*)(ap + cl);
-            mma1(f1, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_a(cur, 1);
-            f0.bh[0] = *(const h8*)(bp + ch);
-            f0.bl[0] = *(const h8*)(bp + cl);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_a(cur, 2);
-            mma1(f1, 0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_a(cur, 3);
-            f0.ah[1] = *(const h8*)(ap + 32 * G_ROWH + ch);
-            f0.al[1] = *(const h8*)(ap + 32 * G_ROWH + cl);
-            mma1(f1, 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_b(cur, 0);
-            f0.bh[1] = *(const h8*)(bp + 32 * G_ROWH + ch);
-            f0.bl[1] = *(const h8*)(bp + 32 * G_ROWH + cl);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_b(cur, 1);
-            PP_P_ADVANCE()
-            mma1(f1, 1, 1);
-            cur = nxt;
-            nxt = nxt == G_STAGES - 1 ? 0 : nxt + 1;
-        }
-        // epilogue of this tile; the ring keeps receiving the next tile meanwhile (f0 already holds its first fragments)
-        int tr, tc;
-        tile_rc(tile, gx, gy, tr, tc);
-        epilogue_block<2, 8>(d, descale, acc, patch, tr * GBM + wr * 64, tc * GBN + wc * 64, lane);
-        // a compiler-visible full wait: with the epilogue's loads / stores pending at the loop header hipcc would put a
-        // vmcnt(0) in front of the fragment reads of EVERY K tile (the stores have to retire before the next counted
-        // wait anyway, and the two tiles in flight have landed during the epilogue)
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS at exit
-#undef PP_P_SETUP
-#undef PP_P_NEXT_TILE_IF_DONE
-#undef PP_P_ADVANCE
-#undef PP_P_FETCH
-#endif
-}
-
-// ---------------------------------------------------------------------------
-// Persistent LDS-DMA kernel with a 256x256 block tile (MODE 0 dense, 1 channel-slice-major convolution): 8 waves as
-// 2 x 4, each a 128x64 output block in 128 accumulator registers.  Per MFMA it needs 25 % fewer LDS fragment reads
-// and a third fewer L2 -> LDS bytes / DMA instructions than the 256x128 tile.  To fit 256 VGPRs the fragments are
-// handled in quarter-tile units (K half x pair of 32-row blocks: 12 MFMAs), the next unit's A fragments (and, at a K
-// half change, B fragments) are read while the current unit multiplies.  LDS: 2 stages x 64 KB + the 16 KB
-// epilogue patch; one tile in flight: the DMA of tile t+2 is issued (interleaved with the last unit's MFMAs) right
-// after the barrier that frees tile t's stage and has the three other units of tile t+1 to land.
-// Same summation order as every other pre-split kernel.
-// ---------------------------------------------------------------------------
-constexpr int QBM = 256, QBN = 256;
-constexpr int Q_A_H = QBM * G_ROWH, Q_B_H = QBN * G_ROWH;  // halfs per operand per stage
-constexpr int Q_STAGE = Q_A_H + Q_B_H;                      // 32768 halfs = 64 KB
-
-template <int MODE>
-__global__ __launch_bounds__(512, 1) void pp_gemm_f16x3q_kernel(const PpGemmDesc d, int gx, int gy) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(MODE == 0 || MODE == 1, "natural-order convolutions use pp_gemm_f16x3g_kernel");
-    extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 2, wc = w & 3, l31 = lane & 31, lh = lane >> 5;
-    const int ntiles = gx * gy, nxw = (int)gridDim.x >> 3;
-    const int xcd = blockIdx.x & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
-    const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int chunk1 = chunk0 + (xcd < r8 ? q8 + 1 : q8);
-    const int first = chunk0 + (int)(blockIdx.x >> 3);
-    if (first >= chunk1) return;
-    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
-    const int lr = lane >> 3;
-    const int sc = (lane & 7) ^ ((((w & 1) << 2) + (lr >> 1)) & 7);
-    const int k8 = (sc >> 1) * 8;
-    const unsigned pbyte = (unsigned)(sc & 1) * 16;
-    const int ntaps = d.conv_kh * d.conv_kw;
-    const int nk = (d.K + BK - 1) / BK;
-
-    unsigned abyte[4], amask[4], bbyte[4];
-    int ftile = first, fkt = 0;
-    int ctap = 0, cky = 0, ckx = 0, cci = 0;
-#define PP_Q_SETUP(TILE)                                                                                             \
-    {                                                                                                                \
-        int tr_, tc_;                                                                                                \
-        tile_rc((TILE), gx, gy, tr_, tc_);                                                                           \
-        const int m0_ = tr_ * QBM, n0_ = tc_ * QBN;                                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
-            const int m = m0_ + (j * 8 + w) * 8 + lr;                                                                \
-            const bool ok = m < d.M;                                                                                 \
-            long long base = ok ? (long long)m * d.lda : 0;                                                          \
-            unsigned mask = ok ? 1u : 0u;                                                                            \
-            if (MODE == 1) {                                                                                         \
-                mask = 0u;                                                                                           \
-                if (ok) {                                                                                            \
-                    const int per = d.conv_ho * d.conv_wo;                                                           \
-                    const int bi = m / per, r = m - bi * per;                                                        \
-                    const int oy = (r / d.conv_wo) * d.conv_stride - d.conv_pad,                                     \
-                              ox = (r % d.conv_wo) * d.conv_stride - d.conv_pad;                                     \
-                    base = (long long)bi * d.conv_bstride + ((long long)oy * d.conv_w + ox) * d.lda;                 \
-                    for (int t = 0; t < ntaps; ++t) {                                                                \
-                        const int iy = oy + t / d.conv_kw, ix = ox + t % d.conv_kw;                                  \
-                        if (iy >= 0 && iy < d.conv_h && ix >= 0 && ix < d.conv_w) mask |= 1u << t;                   \
-                    }                                                                                                \
-                }                                                                                                    \
-            }                                                                                                        \
-            abyte[j] = (unsigned)((base + k8) * 4) + pbyte;                                                          \
-            amask[j] = mask;                                                                                         \
-            const int nb = n0_ + (j * 8 + w) * 8 + lr;                                                               \
-            bbyte[j] = nb < d.N ? (unsigned)(((long long)nb * d.ldb + k8) * 4) + pbyte : 0xFFFFFFFFu;                \
-        }                                                                                                            \
-        fkt = 0;                                                                                                     \
-        ctap = cky = ckx = cci = 0;                                                                                  \
-    }
-#define PP_Q_NEXT_TILE_IF_DONE()                                \
-    if (fkt == nk && ftile < chunk1) {                          \
-        ftile += nxw;                                           \
-        if (ftile < chunk1) PP_Q_SETUP(ftile) else fkt = 0;     \
-    }
-    auto off_a = [&](int j) __attribute__((always_inline)) -> unsigned {
-        if (MODE == 1) {
-            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci) * 4);
-            const unsigned ok = (amask[j] >> ctap) & (ftile < chunk1 ? 1u : 0u);
-            return (abyte[j] + tapoff) | (ok - 1u);
-        }
-        const unsigned ok = amask[j] & (ftile < chunk1 ? 1u : 0u) & (fkt * BK + k8 < d.K ? 1u : 0u);
-        return (abyte[j] + (unsigned)(fkt * BK * 4)) | (ok - 1u);
-    };
-    auto off_b = [&](int j) __attribute__((always_inline)) -> unsigned {
-        const unsigned live = (ftile < chunk1 ? 1u : 0u) & (bbyte[j] != 0xFFFFFFFFu ? 1u : 0u);
-        if (MODE == 1) return (bbyte[j] + (unsigned)((ctap * d.conv_cin + cci) * 4)) | (live - 1u);
-        return (bbyte[j] + (unsigned)(fkt * BK * 4)) | ((live & (fkt * BK + k8 < d.K ? 1u : 0u)) - 1u);
-    };
-    auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * Q_STAGE + ((j * 8 + w) * 8) * G_ROWH), 16, off_a(j), 0, 0, 0);
-    };
-    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * Q_STAGE + Q_A_H + ((j * 8 + w) * 8) * G_ROWH), 16, off_b(j), 0, 0, 0);
-    };
-#define PP_Q_ADVANCE()                                                                             \
-    {                                                                                              \
-        if (MODE == 1) {                                                                           \
-            const bool row_end = ckx + 1 == d.conv_kw, tap_end = row_end && cky + 1 == d.conv_kh;  \
-            ckx = row_end ? 0 : ckx + 1;                                                           \
-            cky = tap_end ? 0 : (row_end ? cky + 1 : cky);                                         \
-            ctap = tap_end ? 0 : ctap + 1;                                                         \
-            cci = tap_end ? cci + BK : cci;                                                        \
-        }                                                                                          \
-        ++fkt;                                                                                     \
-    }
-
-    const int sw = (l31 >> 1) & 7;
-    struct AF {
-        h8 h[2], l[2];  // two 32-row blocks, hi / lo terms
-    };
-    f32x16 acc[4][2];
-    // A fragments of K half ks, row blocks 2 ip, 2 ip + 1; B fragments of K half ks (column blocks 0, 1)
-    auto load_a = [&](AF& f, int stage, int ks, int ip) __attribute__((always_inline)) {
-        const _Float16* st = glds + stage * Q_STAGE + (wr * 128 + ip * 64 + l31) * G_ROWH;
-        const int ch = (((ks * 2 + lh) * 2) ^ sw) * 8, cl = (((ks * 2 + lh) * 2 + 1) ^ sw) * 8;
-        f.h[0] = *(const h8*)(st + ch);
-        f.l[0] = *(const h8*)(st + cl);
-        f.h[1] = *(const h8*)(st + 32 * G_ROWH + ch);
-        f.l[1] = *(const h8*)(st + 32 * G_ROWH + cl);
-    };
-    auto load_b = [&](AF& f, int stage, int ks) __attribute__((always_inline)) {
-        const _Float16* st = glds + stage * Q_STAGE + Q_A_H + (wc * 64 + l31) * G_ROWH;
-        const int ch = (((ks * 2 + lh) * 2) ^ sw) * 8, cl = (((ks * 2 + lh) * 2 + 1) ^ sw) * 8;
-        f.h[0] = *(const h8*)(st + ch);
-        f.l[0] = *(const h8*)(st + cl);
-        f.h[1] = *(const h8*)(st + 32 * G_ROWH + ch);
-        f.l[1] = *(const h8*)(st + 32 * G_ROWH + cl);
-    };
-    auto mma1 = [&](const AF& a, const AF& b, int ip, int i, int j) __attribute__((always_inline)) {
-        acc[2 * ip + i][j] = pp_mfma(a.l[i], b.h[j], acc[2 * ip + i][j]);
-        acc[2 * ip + i][j] = pp_mfma(a.h[i], b.l[j], acc[2 * ip + i][j]);
-        acc[2 * ip + i][j] = pp_mfma(a.h[i], b.h[j], acc[2 * ip + i][j]);
-    };
-    auto mma_unit = [&](const AF& a, const AF& b, int ip) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma1(a, b, ip, i, j);
-    };
-
-    PP_Q_SETUP(first)
-    {
-        PP_Q_NEXT_TILE_IF_DONE()
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma_a(0, j);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma_b(0, j);
-        PP_Q_ADVANCE()
-        PP_Q_NEXT_TILE_IF_DONE()
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma_a(1, j);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma_b(1, j);
-        PP_Q_ADVANCE()
-    }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    AF a0, a1, b0, b1;
-    load_a(a0, 0, 0, 0);
-    load_b(b0, 0, 0);
-    int cur = 0;
-    float* patch = (float*)(glds + 2 * Q_STAGE) + w * 512;
-    const float descale = d.alpha / (A_SCALE * d.b_scale);
-    for (int tile = first; tile < chunk1; tile += nxw) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int kt = 0; kt < nk; ++kt) {
-            // unit 0: (ks 0, rows 0-63)   | reads A(ks 0, rows 64-127)
-            load_a(a1, cur, 0, 1);
-            mma_unit(a0, b0, 0);
-            // unit 1: (ks 0, rows 64-127) | reads A(ks 1, rows 0-63), B(ks 1)
-            load_a(a0, cur, 1, 0);
-            load_b(b1, cur, 1);
-            mma_unit(a1, b0, 1);
-            // unit 2: (ks 1, rows 0-63)   | reads A(ks 1, rows 64-127)
-            load_a(a1, cur, 1, 1);
-            mma_unit(a0, b1, 0);
-            // tile kt+1 has landed (its DMA was issued one iteration ago), all fragment reads of tile kt are done
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // unit 3: (ks 1, rows 64-127) | DMA of tile kt+2 into the stage just freed, reads A(ks 0, rows 0-63), B(ks 0)
-            // of tile kt+1
-            PP_Q_NEXT_TILE_IF_DONE()
-            const int nst = cur ^ 1;
-            dma_a(cur, 0);
-            load_a(a0, nst, 0, 0);
-            mma1(a1, b1, 1, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_a(cur, 1);
-            dma_a(cur, 2);
-            load_b(b0, nst, 0);
-            mma1(a1, b1, 1, 0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_a(cur, 3);
-            dma_b(cur, 0);
-            mma1(a1, b1, 1, 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_b(cur, 1);
-            dma_b(cur, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_b(cur, 3);
-            PP_Q_ADVANCE()
-            mma1(a1, b1, 1, 1, 1);
-            cur = nst;
-        }
-        // epilogue: the wave's 128 x 64 block as two 64-row halves through the 2 KB patch
-        {
-            int tr, tc;
-            tile_rc(tile, gx, gy, tr, tc);
-            const int mw = tr * QBM + wr * 128, nw = tc * QBN + wc * 64;
-            f32x16(&lo)[2][2] = *reinterpret_cast<f32x16(*)[2][2]>(&acc[0]);
-            f32x16(&hi)[2][2] = *reinterpret_cast<f32x16(*)[2][2]>(&acc[2]);
-            epilogue_block<2, 8>(d, descale, lo, patch, mw, nw, lane);
-            epilogue_block<2, 8>(d, descale, hi, patch, mw + 64, nw, lane);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), visible to hipcc (see pp_gemm_f16x3p_kernel)
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef PP_Q_SETUP
-#undef PP_Q_NEXT_TILE_IF_DONE
-#undef PP_Q_ADVANCE
-#endif
-}
-
-// ---------------------------------------------------------------------------
-// 3x3 / stride 1 / pad 1 convolutions (Cin % 32 == 0, W a power of two in [16, 256]) on the persistent 256x256 kernel
-// with ROW-SHARED A delivery.  pp_gemm_f16x3q_kernel<1> copies the 256-pixel A tile into LDS once per TAP — nine
-// LDS-DMA tiles per 32-channel slice although the three taps of a filter row read the same pixels shifted by one.
-// Here the A buffer is filled once per (slice, filter row dy) and the three taps read it at row offsets dx: A copies
-// / 3, all LDS-DMA instructions of the K loop - 30 % (the copies, not the MFMAs, set this kernel's pace).  For the shift
-// to be exact at the image's left / right edge the buffer holds the tile's 256 / W image rows with an explicit ZERO
-// pixel before and after each of them (LDS row pitch W + 2 pixels): those rows are out-of-range DMA offsets — written
-// as zeros without traffic, like the rows y + dy outside the image.  W divides the tile and tiles start at multiples
-// of 256, so the LDS row of a tile row is the same for every tile and every lane keeps it in four registers.  Two A
-// buffers alternate per filter row; the weight tiles keep their per-tap ring.  K order, MFMA order and hence every
-// result bit are those of pp_gemm_f16x3q_kernel<1>.
-// ---------------------------------------------------------------------------
-constexpr int H_A_ROWS = 288;                       // 256 + 2 * 256 / W rows used (W >= 16), 36 LDS-DMA instructions
-constexpr int H_A_H = H_A_ROWS * G_ROWH;            // halfs per A buffer (36 KB)
-constexpr int H_LDS_BYTES = (2 * H_A_H + 2 * Q_B_H) * 2 + 16384;
-
-__global__ __launch_bounds__(512, 1) void pp_gemm_f16x3h_kernel(const PpGemmDesc d, int gx, int gy) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 2, wc = w & 3, l31 = lane & 31, lh = lane >> 5;
-    const int ntiles = gx * gy, nxw = (int)gridDim.x >> 3;
-    const int xcd = blockIdx.x & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
-    const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int chunk1 = chunk0 + (xcd < r8 ? q8 + 1 : q8);
-    const int first = chunk0 + (int)(blockIdx.x >> 3);
-    if (first >= chunk1) return;
-    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)d.A_hl, 0, (int)d.a_hl_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, (int)d.b_hl_bytes, 0x00020000);
-    const int lr = lane >> 3;
-    const int sc = (lane & 7) ^ ((((w & 1) << 2) + (lr >> 1)) & 7);
-    const int k8 = (sc >> 1) * 8;
-    const unsigned pbyte = (unsigned)(sc & 1) * 16;
-    const int nk = (d.K + BK - 1) / BK;       // 9 * Cin / 32
-    const int W = d.conv_w, WP = W + 2, nrows = (QBM / W) * WP;
-    _Float16* const Bbase = glds + 2 * H_A_H;
-
-    // Per lane, constant over the tiles: its (up to five) A rows rho = (j * 8 + w) * 8 + lr of the padded buffer ->
-    // tile pixel mu (or a zero pixel), as a byte offset relative to the tile's first pixel; its four weight rows.
-    unsigned arel[5];
-    auto a_pixel = [&](int j, int& mu) __attribute__((always_inline)) -> bool {   // row j is a pixel (not a pad / unused row)
-        const int rho = (j * 8 + w) * 8 + lr, ir = rho / WP, c = rho - ir * WP;
-        mu = ir * W + c - 1;
-        return rho < nrows && c >= 1 && c <= W;
-    };
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        int mu;
-        const bool pix = a_pixel(j, mu);
-        arel[j] = (unsigned)(((long long)(pix ? mu : 0) * d.lda + k8) * 4) + pbyte;
-    }
-    const unsigned brel = (unsigned)(((long long)(w * 8 + lr) * d.ldb + k8) * 4) + pbyte;
-    const unsigned bstep = (unsigned)(64 * d.ldb * 4);
-    unsigned amask = 0u, bmask = 0u;          // per tile: bit 3 j + dy = source row y + dy - 1 of A row j exists; bit j = column in range
-    unsigned abase = 0u, bbase = 0u;          // per tile (scalar): byte offset of the tile's first pixel / first weight row
-    int ftile = first, fkt = 0, fab = 0;      // fetch cursor: tile, K step, A buffer of the filter row being fetched
-    int cky = 0, ckx = 0, cci = 0;
-#define PP_H_SETUP(TILE)                                                                                             \
-    {                                                                                                                \
-        int tr_, tc_;                                                                                                \
-        tile_rc((TILE), gx, gy, tr_, tc_);                                                                           \
-        const int m0_ = tr_ * QBM, n0_ = tc_ * QBN;                                                                  \
-        abase = (unsigned)((long long)m0_ * d.lda * 4);                                                              \
-        bbase = (unsigned)((long long)n0_ * d.ldb * 4);                                                              \
-        amask = bmask = 0u;                                                                                          \
-        _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                              \
-            int mu_;                                                                                                 \
-            const bool pix_ = a_pixel(j, mu_);                                                                       \
-            const int m = m0_ + mu_;                                                                                 \
-            if (pix_ && m < d.M) {                                                                                   \
-                const int y = (m % (d.conv_h * W)) / W;                                                              \
-                _Pragma("unroll") for (int t = 0; t < 3; ++t) if (y + t - 1 >= 0 && y + t - 1 < d.conv_h) amask |= 1u << (3 * j + t); \
-            }                                                                                                        \
-            if (j < 4 && n0_ + w * 8 + lr + 64 * j < d.N) bmask |= 1u << j;                                          \
-        }                                                                                                            \
-        fkt = 0;                                                                                                     \
-        cky = ckx = cci = 0;                                                                                         \
-    }
-#define PP_H_NEXT_TILE_IF_DONE()                                \
-    if (fkt == nk && ftile < chunk1) {                          \
-        ftile += nxw;                                           \
-        if (ftile < chunk1) PP_H_SETUP(ftile) else fkt = 0;     \
-    }
-    auto off_a = [&](int j) __attribute__((always_inline)) -> unsigned {
-        const unsigned tapoff = abase + (unsigned)((((cky - 1) * W) * d.lda + cci) * 4);
-        const unsigned ok = (amask >> (3 * j + cky)) & (ftile < chunk1 ? 1u : 0u);
-        return (arel[j] + tapoff) | ((ok & 1u) - 1u);
-    };
-    auto off_b = [&](int j) __attribute__((always_inline)) -> unsigned {
-        const unsigned live = (ftile < chunk1 ? 1u : 0u) & (bmask >> j);
-        return (brel + bbase + (unsigned)(((cky * 3 + ckx) * d.conv_cin + cci) * 4) + (unsigned)j * bstep) | ((live & 1u) - 1u);
-    };
-    auto dma_a = [&](int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + fab * H_A_H + ((j * 8 + w) * 8) * G_ROWH), 16, off_a(j), 0, 0, 0);
-    };
-    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(Bbase + stage * Q_B_H + ((j * 8 + w) * 8) * G_ROWH), 16, off_b(j), 0, 0, 0);
-    };
-#define PP_H_ADVANCE()                                                                   \
-    {                                                                                    \
-        const bool row_end = ckx == 2, tap_end = row_end && cky == 2;                    \
-        fab = row_end ? fab ^ 1 : fab;    /* the next filter row goes to the other buffer */ \
-        ckx = row_end ? 0 : ckx + 1;                                                     \
-        cky = tap_end ? 0 : (row_end ? cky + 1 : cky);                                   \
-        cci = tap_end ? cci + BK : cci;                                                  \
-        ++fkt;                                                                           \
-    }
-
-    // LDS row (at dx = 0) of this lane's row in the wave's 32-row block q: rowlane + srow(q), the second term uniform
-    // (tile row base_q + l31 with base_q a multiple of 32: for W >= 32 the block lies inside one image row)
-    const int rowlane = (l31 / W) * WP + (l31 & (W - 1)) + 1;
-    auto srow = [&](int q) __attribute__((always_inline)) -> int {
-        const int bq = wr * 128 + q * 32;
-        return W >= 32 ? (bq / W) * WP + (bq & (W - 1)) : (bq / W) * WP;
-    };
-    struct AF {
-        h8 h[2], l[2];  // two 32-row blocks, hi / lo terms
-    };
-    f32x16 acc[4][2];
-    // A fragments of K half ks, row blocks 2 ip, 2 ip + 1 of tap column dx (a compile-time constant at every call site:
-    // the K loop is unrolled over the three taps of a filter row) from A buffer ab
-    // The address of a fragment = row * 128 B + ((k chunk) ^ key(row)) * 16 B with key = (row >> 1) & 7 depends on the
-    // lane AND on dx: it is recomputed at every read from ONE per-lane register (5 VALU operations per row) — left to
-    // itself hipcc hoists the 48 distinct addresses out of the K loop and then spills them (20 scratch reloads per K step).
-    int rl = rowlane;
-    auto load_a = [&](AF& f, int ab, const int dx, int ks, int ip) __attribute__((always_inline)) {
-        asm volatile("" : "+v"(rl));      // opaque: nothing derived from it is loop-invariant
-        const char* base = (const char*)(glds + ab * H_A_H);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = rl + (srow(2 * ip + i) + dx);
-            const int key = (r >> 1) & 7;
-            const int chunk = ((ks * 2 + lh) * 2) ^ key;
-            const char* st = base + r * (G_ROWH * 2) + chunk * 16;
-            f.h[i] = *(const h8*)st;
-            f.l[i] = *(const h8*)(base + r * (G_ROWH * 2) + (chunk ^ 1) * 16);
-        }
-    };
-    auto load_b = [&](AF& f, int stage, int ks) __attribute__((always_inline)) {
-        const _Float16* st = Bbase + stage * Q_B_H + (wc * 64 + l31) * G_ROWH;
-        const int sw = (l31 >> 1) & 7;
-        const int ch = (((ks * 2 + lh) * 2) ^ sw) * 8, cl = (((ks * 2 + lh) * 2 + 1) ^ sw) * 8;
-        f.h[0] = *(const h8*)(st + ch);
-        f.l[0] = *(const h8*)(st + cl);
-        f.h[1] = *(const h8*)(st + 32 * G_ROWH + ch);
-        f.l[1] = *(const h8*)(st + 32 * G_ROWH + cl);
-    };
-    auto mma1 = [&](const AF& a, const AF& b, int ip, int i, int j) __attribute__((always_inline)) {
-        acc[2 * ip + i][j] = pp_mfma(a.l[i], b.h[j], acc[2 * ip + i][j]);
-        acc[2 * ip + i][j] = pp_mfma(a.h[i], b.l[j], acc[2 * ip + i][j]);
-        acc[2 * ip + i][j] = pp_mfma(a.h[i], b.h[j], acc[2 * ip + i][j]);
-    };
-    auto mma_unit = [&](const AF& a, const AF& b, int ip) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma1(a, b, ip, i, j);
-    };
-    const bool five = w < 4;    // rows 256 .. 287 of an A buffer belong to the fifth instruction of waves 0-3
-
-    PP_H_SETUP(first)
-    {   // K steps 0 (filter row 0: A buffer 0 + weights of tap 0) and 1 (weights of tap 1)
-        PP_H_NEXT_TILE_IF_DONE()
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma_a(j);
-        if (five) dma_a(4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma_b(0, j);
-        PP_H_ADVANCE()
-        PP_H_NEXT_TILE_IF_DONE()
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma_b(1, j);
-        PP_H_ADVANCE()
-    }
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // K step 0 has landed (the 4 weight pieces of step 1 may fly)
-    __builtin_amdgcn_s_barrier();
-    AF a0, a1, b0, b1;
-    int cab = 0;                 // compute cursor: A buffer of the current filter row
-    load_a(a0, 0, -1, 0, 0);
-    load_b(b0, 0, 0);
-    int cur = 0;
-    float* patch = (float*)(Bbase + 2 * Q_B_H) + w * 512;
-    const float descale = d.alpha / (A_SCALE * d.b_scale);
-    for (int tile = first; tile < chunk1; tile += nxw) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        // One K step with the tap column DX a compile-time constant; NDX / NAB: the next step's.
-#define PP_H_STEP(DX, NDX, NAB)                                                                                       \
-        {                                                                                                             \
-            load_a(a1, cab, DX, 0, 1);                                                                                \
-            mma_unit(a0, b0, 0);                                                                                      \
-            load_a(a0, cab, DX, 1, 0);                                                                                \
-            load_b(b1, cur, 1);                                                                                       \
-            mma_unit(a1, b0, 1);                                                                                      \
-            load_a(a1, cab, DX, 1, 1);                                                                                \
-            mma_unit(a0, b1, 0);                                                                                      \
-            /* the next K step has landed, every fragment read of this one is done */                                \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
-            __builtin_amdgcn_s_barrier();                                                                             \
-            /* unit 3 | DMA of the step after next: its weights into the stage just freed and, when it opens a filter \
-               row (every third step: DX == 0 here), that row's pixels into the A buffer the row before last used */ \
-            PP_H_NEXT_TILE_IF_DONE()                                                                                  \
-            const int nst = cur ^ 1;                                                                                  \
-            if (DX == 0) dma_a(0);                                                                                    \
-            load_a(a0, NAB, NDX, 0, 0);                                                                               \
-            mma1(a1, b1, 1, 0, 0);                                                                                    \
-            __builtin_amdgcn_sched_barrier(0);                                                                        \
-            if (DX == 0) { dma_a(1); dma_a(2); }                                                                      \
-            load_b(b0, nst, 0);                                                                                       \
-            mma1(a1, b1, 1, 0, 1);                                                                                    \
-            __builtin_amdgcn_sched_barrier(0);                                                                        \
-            if (DX == 0) { dma_a(3); if (five) dma_a(4); }                                                            \
-            dma_b(cur, 0);                                                                                            \
-            mma1(a1, b1, 1, 1, 0);                                                                                    \
-            __builtin_amdgcn_sched_barrier(0);                                                                        \
-            dma_b(cur, 1);                                                                                            \
-            dma_b(cur, 2);                                                                                            \
-            __builtin_amdgcn_sched_barrier(0);                                                                        \
-            dma_b(cur, 3);                                                                                            \
-            PP_H_ADVANCE()                                                                                            \
-            mma1(a1, b1, 1, 1, 1);                                                                                    \
-            cur = nst;                                                                                                \
-        }
-        // (the fetch cursor runs two steps ahead: while tap dx = 0 of a filter row computes, the step being fetched is
-        // tap dx = -1 of the NEXT filter row — the one that opens it)
-        for (int kt = 0; kt < nk; kt += 3) {
-            PP_H_STEP(-1, 0, cab)
-            PP_H_STEP(0, 1, cab)
-            PP_H_STEP(1, -1, cab ^ 1)
-            cab ^= 1;
-        }
-#undef PP_H_STEP
-        {
-            int tr, tc;
-            tile_rc(tile, gx, gy, tr, tc);
-            const int mw = tr * QBM + wr * 128, nw = tc * QBN + wc * 64;
-            f32x16(&lo)[2][2] = *reinterpret_cast<f32x16(*)[2][2]>(&acc[0]);
-            f32x16(&hi)[2][2] = *reinterpret_cast<f32x16(*)[2][2]>(&acc[2]);
-            epilogue_block<2, 8>(d, descale, lo, patch, mw, nw, lane);
-            epilogue_block<2, 8>(d, descale, hi, patch, mw + 64, nw, lane);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), visible to hipcc (see pp_gemm_f16x3p_kernel)
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef PP_H_SETUP
-#undef PP_H_NEXT_TILE_IF_DONE
-#undef PP_H_ADVANCE
-#endif
-}
 
 namespace {
 
@@ -2696,92 +897,57 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     if (dbg && !vec)
         fprintf(stderr, "[pp_gemm] scalar path: M=%d N=%d K=%d lda=%d ldb=%d conv=%dx%d cin=%d b_kn=%d batch=%d A%%16=%d B%%16=%d\n", d.M, d.N, d.K, d.lda,
                 d.ldb, d.conv_kh, d.conv_kw, d.conv_cin, d.b_kn, d.batch0 * d.batch1, (int)((uintptr_t)d.A % 16), (int)((uintptr_t)d.B % 16));
-    // block tile 128x128 (3 workgroups/CU) or 128x64 (4/CU): take the one with the shorter makespan
-    // rounds(tiles / resident slots) x relative tile time — fixes the wave-quantisation tail of mid-size GEMMs
     const int cus = pp_cu_count();   // cached per device (two runtime calls per GEMM launch otherwise)
     const long long rows = (d.M + BM - 1) / BM, z = (long long)d.batch0 * d.batch1;
     hipStream_t st = (hipStream_t)stream;
+    const bool f16 = d.prec == PP_PREC_F16;          // plain fp16 operands: pre-split kernels only
+    const int terms = f16 ? 1 : 2, eb = 2 * terms;   // operand terms / bytes per element
     const bool split = d.prec == PP_PREC_F16X3 && vec;  // unaligned (tiny) layers stay on the fp32 kernel
     const bool asplit = d.A_hl != nullptr;
+    if (f16 && !asplit) return PP_EINVAL;
     if (asplit) {
-        const bool ok = d.B_hl && d.prec == PP_PREC_F16X3 && z == 1 && !d.b_kn && !d.relu_in &&
+        const bool ok = d.B_hl && (d.prec == PP_PREC_F16X3 || f16) && z == 1 && !d.b_kn && !d.relu_in &&
                         d.K % 8 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.b_scale > 0.f &&
                         (d.conv_kh == 0 || (d.conv_cin % 8 == 0 && d.conv_bstride % 8 == 0)) &&
                         ((uintptr_t)d.A_hl % 16 == 0) && ((uintptr_t)d.B_hl % 16 == 0);
         if (!ok) return PP_EINVAL;
-        // extents of the hl buffers for the bounds-checked buffer loads
+        // extents of the operand buffers for the bounds-checked buffer loads
         const long long a_elems = d.conv_kh != 0
             ? ((long long)((d.M + (long long)d.conv_ho * d.conv_wo - 1) / ((long long)d.conv_ho * d.conv_wo) - 1) * d.conv_bstride +
                (long long)d.conv_h * d.conv_w * d.lda)
             : (long long)(d.M - 1) * d.lda + d.K;
         const long long b_elems = (long long)(d.N - 1) * d.ldb + d.K;
         // (32-bit byte offsets; 0xFFFFFFFF is the "reads zero" marker)
-        if (a_elems * 4 >= 0xFFFFFF00LL || b_elems * 4 >= 0xFFFFFF00LL) return PP_EINVAL;
-        d.a_hl_bytes = a_elems * 4;
-        d.b_hl_bytes = b_elems * 4;
+        if (a_elems * eb >= 0xFFFFFF00LL || b_elems * eb >= 0xFFFFFF00LL) return PP_EINVAL;
+        d.a_hl_bytes = a_elems * eb;
+        d.b_hl_bytes = b_elems * eb;
     }
     if (d.B_hl && (d.b_kn || d.ldb % 8 != 0 || d.K % 8 != 0 || z != 1 || !(d.b_scale > 0.f))) return PP_EINVAL;
-    if (d.B_hl && !split) d.B_hl = nullptr;  // unaligned layer: the fp32 kernel reads d.B
-    static signed char big_state[PP_MAX_DEVICES];   // the > 64 KB dynamic-LDS opt-in is per device
-    signed char& big_ok = big_state[pp_cur_device()];
-    if (big_ok == 0) {
-        const int lds = G_STAGES * G_STAGE * 2;
-        big_ok = (hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3g_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3q_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q_STAGE * 2 + 16384) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3d_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3d_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3e_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)pp_gemm_f16x3e_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES) == hipSuccess)
-                     ? 1 : -1;
-    }
-    if (big_ok < 0) return PP_ELAUNCH;
-    // row-shared 3x3 kernel (cfg 6): 3x3 / stride 1 / pad 1, Cin % 32 == 0, W a power of two dividing the 256-row tile
-    const bool h_shape = asplit && d.conv_kh == 3 && d.conv_kw == 3 && d.conv_stride == 1 && d.conv_pad == 1 && d.conv_cin % BK == 0 &&
-                         d.conv_ho == d.conv_h && d.conv_wo == d.conv_w && d.conv_w >= 16 && d.conv_w <= QBM && (d.conv_w & (d.conv_w - 1)) == 0 &&
-                         d.lda == d.conv_cin && d.K == 9 * d.conv_cin && d.conv_bstride == (long long)d.conv_h * d.conv_w * d.lda;
-    auto launch = [&](int cfg) {  // 0: 128x128 tile @2 workgroups/CU, 1: 128x128 @3/CU, 2: 128x64 @4/CU, 3: 256x128 LDS-DMA, 4: persistent LDS-DMA, 5: persistent LDS-DMA with 256x256 tiles, 6: 5 with row-shared A delivery (3x3 convolutions), 7: 256x128 LDS-DMA @2 workgroups/CU (dense), 8: 128x128 LDS-DMA @3 workgroups/CU (dense)
+    if (d.B_hl && !split && !f16) d.B_hl = nullptr;  // unaligned layer: the fp32 kernel reads d.B
+    // Tile configurations ("cfg", PP_GEMM_FORCE_CFG numbering).  Both operands pre-split (pp_gemm_u_kernel.h): 0 = 128x128 tile, two
+    // workgroups per CU; 2 = 128x64, two per CU; 4 = 256x128 (3, the former one-shot launch of it, is an alias); 5 = 256x256;
+    // 6 = 256x256 with row-shared A delivery (3x3 convolutions); 7 / 8 (the former two / three-workgroups-per-CU K-16 kernels) are
+    // aliases of 0.  All of them persistent (a launch with fewer tiles than slots is one tile per workgroup) and bit-identical
+    // in their results.  fp32 operands (split on the fly, or fp32 MFMA): 0 / 1 = 128x128 at 2 / 3 workgroups per CU, 2 = 128x64.
+    const bool h_shape = asplit && pp_gemm_uh_shape_ok(d, terms) && pp_gemm_u_vec_ok(d);
+    auto u_cfg = [&](int cfg) {   // canonical pre-split configuration
+        if (cfg == 3) cfg = 4;
+        if (cfg == 7 || cfg == 8 || cfg == 1) cfg = 0;
+        if (cfg == 6 && !(h_shape && d.N > 128)) cfg = 5;
+        if (cfg == 5 && d.N <= 128) cfg = 4;
+        return cfg;
+    };
+    int launch_rc = PP_OK;
+    auto launch = [&](int cfg) {
+        if (asplit) {
+            cfg = u_cfg(cfg);
+            if (cfg == 6) launch_rc = pp_gemm_uh_launch(d, terms, cus, st);
+            else launch_rc = pp_gemm_u_launch(d, cfg == 5 ? PP_U_256x256 : cfg == 4 ? PP_U_256x128 : cfg == 2 ? PP_U_128x64 : PP_U_128x128, terms, cus, st);
+            return;
+        }
         const bool narrow = cfg == 2;
         const dim3 grid((d.N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), (unsigned)rows, (unsigned)z);
-        if (asplit && cfg == 8) {  // three workgroups per CU on 128x128 tiles, dense A
-            const int gx = (d.N + EBN - 1) / EBN, gy = (d.M + EBM - 1) / EBM;
-            if (d.conv_kh == 0) hipLaunchKernelGGL(pp_gemm_f16x3e_kernel<0>, dim3(gx * gy), dim3(256), E_LDS_BYTES, st, d, gx, gy);
-            else hipLaunchKernelGGL(pp_gemm_f16x3e_kernel<1>, dim3(gx * gy), dim3(256), E_LDS_BYTES, st, d, gx, gy);
-        } else if (asplit && cfg == 7) {  // two workgroups per CU, dense A
-            const int gx = (d.N + GBN - 1) / GBN, gy = (d.M + GBM - 1) / GBM;
-            if (d.conv_kh == 0) hipLaunchKernelGGL(pp_gemm_f16x3d_kernel<0>, dim3(gx * gy), dim3(256), D_LDS_BYTES, st, d, gx, gy);
-            else hipLaunchKernelGGL(pp_gemm_f16x3d_kernel<1>, dim3(gx * gy), dim3(256), D_LDS_BYTES, st, d, gx, gy);
-        } else if (asplit && cfg == 6) {
-            const int gx = (d.N + QBN - 1) / QBN, gy = (d.M + QBM - 1) / QBM;
-            const int nt = gx * gy, g = nt < cus ? (nt + 7) / 8 * 8 : cus / 8 * 8;
-            hipLaunchKernelGGL(pp_gemm_f16x3h_kernel, dim3(g), dim3(512), H_LDS_BYTES, st, d, gx, gy);
-        } else if (asplit && cfg == 5) {  // persistent LDS-DMA kernel, 256x256 tiles
-            const int gx = (d.N + QBN - 1) / QBN, gy = (d.M + QBM - 1) / QBM;
-            const int nt = gx * gy, g = nt < cus ? (nt + 7) / 8 * 8 : cus / 8 * 8;
-            const int lds = 2 * Q_STAGE * 2 + 16384;
-            if (d.conv_kh == 0) hipLaunchKernelGGL(pp_gemm_f16x3q_kernel<0>, dim3(g), dim3(512), lds, st, d, gx, gy);
-            else hipLaunchKernelGGL(pp_gemm_f16x3q_kernel<1>, dim3(g), dim3(512), lds, st, d, gx, gy);
-        } else if (asplit && cfg == 4) {  // persistent LDS-DMA kernel: one workgroup per CU (a multiple of 8), dense / channel-major conv
-            const int gx = (d.N + GBN - 1) / GBN, gy = (d.M + GBM - 1) / GBM;
-            const int nt = gx * gy, g = nt < cus ? (nt + 7) / 8 * 8 : cus / 8 * 8;
-            const int lds = G_STAGES * G_STAGE * 2 + 16384;
-            if (d.conv_kh == 0) hipLaunchKernelGGL(pp_gemm_f16x3p_kernel<0>, dim3(g), dim3(512), lds, st, d, gx, gy);
-            else hipLaunchKernelGGL(pp_gemm_f16x3p_kernel<1>, dim3(g), dim3(512), lds, st, d, gx, gy);
-        } else if (asplit && cfg == 3) {
-            const int gx = (d.N + GBN - 1) / GBN, gy = (d.M + GBM - 1) / GBM;
-            const int mode = d.conv_kh == 0 ? 0 : (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32 ? 1 : 2);
-            if (mode == 0) hipLaunchKernelGGL(pp_gemm_f16x3g_kernel<0>, dim3(gx * gy), dim3(512), G_STAGES * G_STAGE * 2, st, d, gx, gy);
-            else if (mode == 1) hipLaunchKernelGGL(pp_gemm_f16x3g_kernel<1>, dim3(gx * gy), dim3(512), G_STAGES * G_STAGE * 2, st, d, gx, gy);
-            else hipLaunchKernelGGL(pp_gemm_f16x3g_kernel<2>, dim3(gx * gy), dim3(512), G_STAGES * G_STAGE * 2, st, d, gx, gy);
-        } else if (asplit) {
-            if (narrow) hipLaunchKernelGGL((gemm_f16x3s_kernel<1, 3>), grid, dim3(256), 0, st, d);
-            else hipLaunchKernelGGL((gemm_f16x3s_kernel<2, 2>), grid, dim3(256), 0, st, d);  // 64 KB LDS: 2 per CU
-        } else if (split) {
+        if (split) {
             if (d.B_hl) {
                 if (narrow) hipLaunchKernelGGL((gemm_f16x3_kernel<1, 4, true>), grid, dim3(256), 0, st, d);
                 else if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, true>), grid, dim3(256), 0, st, d);
@@ -2802,25 +968,16 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             hipLaunchKernelGGL((gemm_kernel<true, 2, 3>), grid, dim3(256), 0, st, d);
         }
     };
+    auto finish = [&]() { return launch_rc != PP_OK ? launch_rc : pp_last_launch(); };
     // Which block tile / occupancy is fastest depends on how the tile count fills the CUs (wave quantisation)
-    // and on K; it is measured once per problem shape (three timed launches of the same GEMM — idempotent
+    // and on K; it is measured once per problem shape (timed launches of the same GEMM — idempotent
     // unless the output aliases a residual) and remembered.  PP_GEMM_AUTOTUNE=0 keeps the static choice.
     int cfg = d.N <= 64 ? 2 : 0;
-    if (const char* f = getenv("PP_GEMM_FORCE_CFG")) {  // tests: pin one kernel configuration (3 needs pre-split operands)
+    if (const char* f = getenv("PP_GEMM_FORCE_CFG")) {  // tests: pin one kernel configuration
         const int fc = atoi(f);
-        const bool p_ok = asplit && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
-        if ((fc == 7 || fc == 8) && asplit) {   // two / three workgroups per CU (dense, or convolutions in channel-slice-major order)
-            const bool ok = d.K >= 3 * D_KT && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
-            launch(ok ? fc : 3);
-            return pp_last_launch();
-        }
-        if (fc == 6 && asplit) {   // the row-shared kernel where the shape allows it, else the 256x256 / 256x128 persistent ones
-            launch(h_shape && d.N > 128 ? 6 : (p_ok ? (d.N > 128 ? 5 : 4) : 3));
-            return pp_last_launch();
-        }
-        if (fc >= 0 && fc <= 5 && (fc < 3 || asplit) && (fc != 1 || !asplit)) {
-            launch(fc >= 4 && !(p_ok && (fc == 4 || d.N > 128)) ? 3 : fc);
-            return pp_last_launch();
+        if (fc >= 0 && fc <= 8 && (asplit || fc <= 2)) {
+            launch(fc);
+            return finish();
         }
     }
     const bool alias = d.C != nullptr && (d.residual == d.C || d.residual2 == d.C);  // (C is null for operand-only outputs)
@@ -2830,7 +987,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         static std::unordered_map<std::string, int> best;
         char key[160];
         snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%lld.%d.%d.%d.%d.%d.%d", d.M, d.N, d.K, (int)vec, d.b_kn, z, d.conv_kh,
-                 d.conv_cin, d.conv_stride, d.conv_h, d.shuffle_r, (int)split + 2 * (d.B_hl != nullptr) + 4 * (int)asplit);
+                 d.conv_cin, d.conv_stride, d.conv_h, d.shuffle_r, (int)split + 2 * (d.B_hl != nullptr) + 4 * (int)asplit + 8 * (int)f16);
         std::lock_guard<std::mutex> lock(mu);
         auto it = best.find(key);
         if (it == best.end()) {
@@ -2839,25 +996,22 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             PP_CHECK_HIP(hipEventCreate(&e1));
             float bt = 1e30f;
             int bc = 0;
-            // pre-split operands: 128x128, 128x64 and (for problems that fill the chip with 256x128 tiles) the LDS-DMA kernels
-            const bool big = asplit && (long long)((d.M + GBM - 1) / GBM) * ((d.N + GBN - 1) / GBN) >= cus / 2;
-            const bool p_ok = big && d.K >= 3 * BK && (d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32));
-            const bool q_ok = p_ok && d.N > 128 && (long long)((d.M + QBM - 1) / QBM) * ((d.N + QBN - 1) / QBN) >= cus / 2;
-            int cands[9], nc = 0;
-            // (cfg 8, the 128x128 three-per-CU kernel: dense problems of at least half a chip of its tiles)
-            const bool de_conv = d.conv_kh == 0 || (d.conv_cin % BK == 0 && d.conv_kh * d.conv_kw <= 32);
-            const bool e_ok = asplit && de_conv && d.K >= 3 * D_KT &&
-                              (long long)((d.M + EBM - 1) / EBM) * ((d.N + EBN - 1) / EBN) >= cus / 2;
-            for (int c = 0; c < (asplit ? 8 : (vec ? 3 : 2)); ++c) {
-                const int cand = asplit ? (c == 0 ? 0 : c == 1 ? 2 : c + 1) : (vec ? c : (c == 0 ? 0 : 2));
-                if ((cand == 3 && !big) || (cand == 4 && !p_ok) || (cand == 5 && !q_ok) || (cand == 6 && !(q_ok && h_shape)) ||
-                    (cand == 7 && !(big && de_conv && d.K >= 3 * D_KT)) || (cand == 8 && !e_ok)) continue;
-                cands[nc++] = cand;
+            int cands[8], nc = 0;
+            if (asplit) {
+                // the 128-row tiles always; the 256-row ones for problems that give at least half the chip a tile of theirs
+                const long long t4 = (long long)((d.M + 255) / 256) * ((d.N + 127) / 128), t5 = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256);
+                cands[nc++] = 0;
+                cands[nc++] = 2;
+                if (t4 >= cus / 2) cands[nc++] = 4;
+                if (t5 >= cus / 2 && d.N > 128) cands[nc++] = 5;
+                if (t5 >= cus / 2 && d.N > 128 && h_shape) cands[nc++] = 6;
+            } else {
+                for (int c = 0; c < (vec ? 3 : 2); ++c) cands[nc++] = vec ? c : (c == 0 ? 0 : 2);
             }
             // Round-robin: every round times one burst of four back-to-back launches of EACH candidate, and a candidate keeps
             // its best burst.  (Timing the candidates one after the other ranked them by the clock the chip happened to hold:
             // the first ones ran on a cool chip, and configurations within ~5-10 % changed places from run to run.)
-            float ms[9];
+            float ms[8];
             for (int i = 0; i < nc; ++i) {
                 ms[i] = 1e30f;
                 launch(cands[i]);  // warm
@@ -2882,7 +1036,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             best[key] = bc;
-            return pp_last_launch();  // the last timed launch already produced the result
+            return finish();  // the last timed launch already produced the result
         }
         cfg = it->second;
     }
@@ -2898,10 +1052,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         gp->shape[gp->count][1] = d.N;
         gp->shape[gp->count][2] = d.K;
         gp->shape[gp->count][3] = d.conv_kh;
-        gp->shape[gp->count][4] = cfg;
+        gp->shape[gp->count][4] = asplit ? u_cfg(cfg) : cfg;
         gp->count++;
     }
-    return pp_last_launch();
+    return finish();
 }
 
 int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
