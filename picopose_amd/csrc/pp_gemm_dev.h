@@ -83,103 +83,209 @@ __device__ __forceinline__ void pp_tile_rc(int t, int gx, int gy, int& r, int& c
 //   PP_PREC_F16   "h" : fp16 [rows][ld] = f16(4 x) (16 bytes per 8 k).
 // TERMS = 2 / 1.  A 128-byte row segment is one K tile: 32 k (hl) or 64 k (h).
 
-// Store the 8 consecutive output columns n .. n + 7 of output row m held in v (already descaled / biased / activated):
-// fp32 (C, with the residuals added) and / or operand form (C_hl, in the engine's current operand format).
-template <int TERMS>
-__device__ __forceinline__ void epilogue_emit8(const PpGemmDesc& d, f4 (&v)[2], int m, int n) {
-    float* C = d.C;
-    const float* R = d.residual;
-    const float* R2 = d.residual2;
-    size_t off, orow = (size_t)m;     // output row / first column of this lane's 8 values (fp32 and operand alike)
-    int ocol = n;
-    if (d.shuffle_r == 0) {
-        off = (size_t)m * d.ldc + n;
-    } else {  // ConvTranspose2d(kernel = stride = r): columns n .. n + 7 = channels co .. co + 7 of sub-pixel (dy, dx)
-        const int rr_ = d.shuffle_r, cout = d.N / (rr_ * rr_);
-        const int sub = n / cout, co = n - sub * cout, dy = sub / rr_, dx = sub - dy * rr_;
-        const int per = d.shuffle_h * d.shuffle_w;
-        const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
-        orow = ((size_t)b * d.shuffle_h * rr_ + y * rr_ + dy) * (d.shuffle_w * rr_) + x * rr_ + dx;
-        ocol = co;
-        off = orow * d.ldc + co;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (R) v[h] += *(const f4*)(R + off + 4 * h);
-        if (R2) v[h] += *(const f4*)(R2 + off + 4 * h);
-        if (C) *(f4*)(C + off + 4 * h) = v[h];
-    }
-    if (d.C_hl) {
-        if (TERMS == 2) {
-            h8 hh, ll;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float x = v[c >> 2][c & 3];
-                _Float16 a, b;
-                pp_split_f16(d.c_relu ? fmaxf(x, 0.f) : x, a, b);
-                hh[c] = a;
-                ll[c] = b;
-            }
-            _Float16* hp = (_Float16*)d.C_hl + orow * 2 * d.ldc_h + 2 * ocol;
-            *(h8*)hp = hh;
-            *(h8*)(hp + 8) = ll;
-        } else {
-            h8 hh;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float x = v[c >> 2][c & 3];
-                hh[c] = pp_to_f16(d.c_relu ? fmaxf(x, 0.f) : x);
-            }
-            *(h8*)((_Float16*)d.C_hl + orow * d.ldc_h + ocol) = hh;
-        }
-    }
+// ---- the vector epilogue --------------------------------------------------------------------------------------------
+// Accumulator layout of every pre-split kernel.  The MFMAs are issued TRANSPOSED — weights as the instruction's A matrix,
+// activations as its B matrix (v_mfma_f32_16x16x32: D[i][j] with i from A, j from B; lane l holds column j = l & 15 and rows
+// i = 4 (l >> 4) + r in register r) — so a lane holds ONE output row m = l & 15 of a 16-row block and, per 16-column weight
+// tile, the four weight-tile rows 4 q + r (q = l >> 4).  The weight tile is laid into LDS with its rows permuted inside each
+// block of 32 (pp_wperm: LDS row rho <- output column n_off(rho)), so that the registers of the tile PAIR (2 jp, 2 jp + 1)
+// are the 8 CONSECUTIVE output columns 32 jp + 8 q + {0 .. 7}: the accumulators leave straight from the registers as 32-byte
+// fp32 stores / one operand group per lane, 4 lanes = one 128-byte line of a row — no LDS staging, no transposition pass.
+// LDS weight row rho (low five bits t q1 q0 r1 r0) holds output column (rho & ~31) + 8 q + 4 t + r.
+__host__ __device__ __forceinline__ int pp_wperm(int rho) {
+    return (rho & ~31) | (((rho >> 2) & 3) << 3) | (((rho >> 4) & 1) << 2) | (rho & 3);
 }
 
-// Epilogue of a wave's (16 MI) x (16 NJ) block held as 16x16 MFMA tiles (v_mfma_f32_16x16x32: lane l holds column l & 15,
-// rows 4 (l >> 4) + r of a tile in register r).  The block leaves through a wave-private 2 KB LDS patch, one 16-row x
-// 32-column slab at a time, so that a lane owns 8 consecutive columns of a row: 32-byte fp32 stores / residual loads and
-// one 32-byte (16-byte) group of the operand output, 4 lanes = one 128-byte line per row.  Requires the vector conditions
-// (N % 8 == 0, aligned rows); the caller falls back to epilogue_scalar16 otherwise.  Os: 512 floats, private to the wave.
+// All global accesses of the epilogue are raw buffer accesses with 32-bit byte offsets (the host checks the extents,
+// pp_gemm_u_vec_ok): a row m >= M or a column group n >= N gets the offset 0xFFFFFFFF — out of range: the store is dropped,
+// a load returns zeros — so the row loop has no branches and no 64-bit address arithmetic (measured on the K = 768 ViT linears:
+// the epilogue was 24 % of the kernel, almost all of it VALU / scalar-branch issue, 4 % the stores themselves).
+// (the pointer goes through v_readfirstlane: left to itself hipcc parked the descriptor of a kernel argument in VGPRs when SGPRs
+// ran short and then wrapped EVERY store in a waterfall loop — readfirstlane x 4, compare, saveexec, branch)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pp_rsrc(const void* p) {
+    const uint64_t a = (uint64_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned n = __builtin_amdgcn_readfirstlane(p ? 0xFFFFFFFFu : 0u);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ void pp_bstore(__amdgpu_buffer_rsrc_t r, f4 v, unsigned off) {
+#ifdef PP_STUDY_NOSTORE   // (timing study builds only: the epilogue's arithmetic without its stores)
+    if (v[0] != -12345.f) return;
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, off, 0, 0);
+}
+__device__ __forceinline__ f4 pp_bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+// split 8 values (already in the operand's 4x scale, any input ReLU applied) into the operand group(s) and store them:
+// hl: [8 hi | 8 lo] at byte offset `off`; h: 8 halfs at `off`
+template <int TERMS>
+__device__ __forceinline__ void pp_store_operand8(__amdgpu_buffer_rsrc_t H, const f4 (&x4)[2], unsigned off) {
+    h8 hh, ll;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float x = x4[c >> 2][c & 3];
+        const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+        hh[c] = h;
+        if (TERMS == 2) ll[c] = (_Float16)fminf(fmaxf(x - (float)h, -65504.f), 65504.f);
+#ifdef PP_STUDY_ACT_LO_ZERO
+        if (TERMS == 2) ll[c] = (_Float16)0.f;
+#endif
+    }
+    pp_bstore(H, __builtin_bit_cast(f4, hh), off);
+    if (TERMS == 2) pp_bstore(H, __builtin_bit_cast(f4, ll), off == 0xFFFFFFFFu ? off : off + 16);
+}
+
+// Epilogue of a wave's (16 MI) x (16 NJ) block: out = residual + residual2 + gamma * act(descale * acc + bias) for the 8
+// columns a lane holds per tile pair.  Requires the vector conditions (N % 8 == 0, aligned rows, extents below 4 GB:
+// pp_gemm_u_vec_ok on the host); the element-wise form below covers the rest.  Two code paths, chosen once per tile:
+//   * operand-only outputs without residual / LayerScale / pixel shuffle (the qkv and fc1 linears, the convolution chains):
+//     everything happens in the operand's 4x scale — one fma (descale and bias pre-multiplied), the activation as
+//     max(x, slope x) for the positively homogeneous ones (none / ReLU / LeakyReLU: slope 1 / 0 / 0.1) or the rational-erf
+//     GELU, the consumer's input ReLU as a max with 0 or -inf, the split, two 16-byte stores;
+//   * the general form (fp32 output, residuals, LayerScale, pixel-shuffle stores, optional operand output as well), with the
+//     residual rows of the next 16-row block loaded while the current one is processed.
 template <int MI, int NJ, int TERMS>
-__device__ __forceinline__ void epilogue_wave16(const PpGemmDesc& d, float descale, f32x4 (&acc)[MI][NJ], float* Os, int mw, int nw,
-                                                int lane) {
-    static_assert(NJ % 2 == 0, "slabs are two 16-column tiles wide");
+__device__ __forceinline__ void epilogue_wave16(const PpGemmDesc& d, float descale, f32x4 (&acc)[MI][NJ], int mw, int nw, int lane) {
+    static_assert(NJ % 2 == 0, "a lane's 8 columns come from a pair of 16-column tiles");
     const int l15 = lane & 15, lq = lane >> 4;
-    const int rr = lane >> 2, c8 = (lane & 3) * 8;             // read side: row of the slab, first of 8 columns
-    // patch image: element (row, col) at row * 32 + (((col >> 3) ^ ((row >> 1) & 3)) << 3) + (col & 7): the 16-byte reads of
-    // a lane group then spread over all banks
-    const int rd = rr * 32 + (((c8 >> 3) ^ ((rr >> 1) & 3)) << 3);
+    const __amdgpu_buffer_rsrc_t Hr = pp_rsrc(d.C_hl);
+    const unsigned hrow = (unsigned)d.ldc_h * (2u * TERMS);       // operand bytes per output row
+    const float slope = d.act == PP_ACT_RELU ? 0.f : (d.act == PP_ACT_LEAKY01 ? 0.1f : 1.f);
+    const float hfloor = d.c_relu ? 0.f : -INFINITY;              // the consumer's input ReLU folded into the operand
+    const bool lin_act = d.act != PP_ACT_GELU && d.act != PP_ACT_TANH;
+    const int m0 = mw + l15;
+    if (!d.C && !d.residual && !d.residual2 && !d.gamma && d.shuffle_r == 0 && d.act != PP_ACT_TANH) {
+        const float ds4 = descale * PP_A_SCALE;
+#pragma unroll
+        for (int jp = 0; jp < NJ / 2; ++jp) {
+            const int n = nw + jp * 32 + 8 * lq;
+            const bool ncol = n < d.N;                        // N % 8 == 0: a group of 8 is in or out as a whole
+            f4 bias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (d.bias && ncol) {
+                bias[0] = *(const f4*)(d.bias + n);
+                bias[1] = *(const f4*)(d.bias + n + 4);
+            }
+            const f4 bias4[2] = {bias[0] * PP_A_SCALE, bias[1] * PP_A_SCALE};
+            unsigned off = (unsigned)m0 * hrow + (unsigned)n * (2u * TERMS);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                f4 x[2] = {acc[mi][2 * jp], acc[mi][2 * jp + 1]};
+                if (lin_act) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float v = fmaf(x[h][c], ds4, bias4[h][c]);
+                            v = fmaxf(v, v * slope);
+                            x[h][c] = fmaxf(v, hfloor);
+                        }
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float v = fmaf(x[h][c], descale, bias[h][c]);
+                            const float g = 0.5f * v * (1.0f + erf_rational(v * 0.70710678118654752440f));
+                            x[h][c] = fmaxf(g * PP_A_SCALE, hfloor);
+                        }
+                }
+                const bool ok = ncol && m0 + mi * 16 < d.M;
+                pp_store_operand8<TERMS>(Hr, x, ok ? off : 0xFFFFFFFFu);
+                off += 16u * hrow;
+            }
+        }
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t Cr = pp_rsrc(d.C), Rr = pp_rsrc(d.residual), R2r = pp_rsrc(d.residual2);
+    const bool hasR = d.residual != nullptr, hasR2 = d.residual2 != nullptr;
+    const unsigned crow = (unsigned)d.ldc * 4u;
+    // byte offsets of the 8 columns n .. n + 7 of output row m: fp32 image and operand image (pixel-shuffle stores move both)
+    auto offsets = [&](int m, int n, unsigned& coff, unsigned& hoff) __attribute__((always_inline)) {
+        if (d.shuffle_r == 0) {
+            coff = (unsigned)m * crow + (unsigned)n * 4u;
+            hoff = (unsigned)m * hrow + (unsigned)n * (2u * TERMS);
+        } else {  // ConvTranspose2d(kernel = stride = r): columns n .. n + 7 = channels co .. co + 7 of sub-pixel (dy, dx)
+            const int rr_ = d.shuffle_r, cout = d.N / (rr_ * rr_);
+            const int sub = n / cout, co = n - sub * cout, dy = sub / rr_, dx = sub - dy * rr_;
+            const int per = d.shuffle_h * d.shuffle_w;
+            const int b = m / per, rem = m - b * per, y = rem / d.shuffle_w, x = rem - y * d.shuffle_w;
+            const unsigned orow = ((unsigned)b * d.shuffle_h * rr_ + y * rr_ + dy) * (d.shuffle_w * rr_) + x * rr_ + dx;
+            coff = orow * crow + (unsigned)co * 4u;
+            hoff = orow * hrow + (unsigned)co * (2u * TERMS);
+        }
+    };
 #pragma unroll
     for (int jp = 0; jp < NJ / 2; ++jp) {
-        const int n = nw + jp * 32 + c8;
-        const bool ncol_ok = n < d.N;                        // N % 8 == 0: a group of 8 is in or out as a whole
+        const int n = nw + jp * 32 + 8 * lq;
+        const bool ncol = n < d.N;
         f4 bias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gam[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
-        if (ncol_ok) {
+        if (ncol) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (d.bias) bias[h] = *(const f4*)(d.bias + n + 4 * h);
                 if (d.gamma) gam[h] = *(const f4*)(d.gamma + n + 4 * h);
             }
         }
+        unsigned coff, hoff;
+        offsets(m0, n, coff, hoff);
+        bool ok = ncol && m0 < d.M;
+        f4 r[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, r2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (hasR) {
+            r[0] = pp_bload(Rr, ok ? coff : 0xFFFFFFFFu);
+            r[1] = pp_bload(Rr, ok ? coff + 16 : 0xFFFFFFFFu);
+        }
+        if (hasR2) {
+            r2[0] = pp_bload(R2r, ok ? coff : 0xFFFFFFFFu);
+            r2[1] = pp_bload(R2r, ok ? coff + 16 : 0xFFFFFFFFu);
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * lq + r, col = jj * 16 + l15;
-                    Os[row * 32 + (((col >> 3) ^ ((row >> 1) & 3)) << 3) + (col & 7)] = acc[mi][2 * jp + jj][r];
+            // the next block's residual rows are on their way while this one is processed
+            unsigned ncoff = 0xFFFFFFFFu, nhoff = 0xFFFFFFFFu;
+            bool nok = false;
+            f4 rn[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, r2n[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (mi + 1 < MI) {
+                offsets(m0 + (mi + 1) * 16, n, ncoff, nhoff);
+                nok = ncol && m0 + (mi + 1) * 16 < d.M;
+                if (hasR) {
+                    rn[0] = pp_bload(Rr, nok ? ncoff : 0xFFFFFFFFu);
+                    rn[1] = pp_bload(Rr, nok ? ncoff + 16 : 0xFFFFFFFFu);
                 }
-            f4 v[2];
-            v[0] = *(const f4*)(Os + rd);
-            v[1] = *(const f4*)(Os + rd + 4);
-            const int m = mw + mi * 16 + rr;
-            if (m < d.M && ncol_ok) {
+                if (hasR2) {
+                    r2n[0] = pp_bload(R2r, nok ? ncoff : 0xFFFFFFFFu);
+                    r2n[1] = pp_bload(R2r, nok ? ncoff + 16 : 0xFFFFFFFFu);
+                }
+            }
+            f4 v[2] = {acc[mi][2 * jp], acc[mi][2 * jp + 1]};
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float t = fmaf(v[h][c], descale, bias[h][c]);
+                    t = lin_act ? fmaxf(t, t * slope) : act_apply(t, d.act);
+                    v[h][c] = fmaf(t, gam[h][c], r[h][c] + r2[h][c]);
+                }
+            if (d.C) {
+                pp_bstore(Cr, v[0], ok ? coff : 0xFFFFFFFFu);
+                pp_bstore(Cr, v[1], ok ? coff + 16 : 0xFFFFFFFFu);
+            }
+            if (d.C_hl) {
+                f4 x[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[h][c] = act_apply(v[h][c] * descale + bias[h][c], d.act) * gam[h][c];
-                epilogue_emit8<TERMS>(d, v, m, n);
+                    for (int c = 0; c < 4; ++c) x[h][c] = fmaxf(v[h][c] * PP_A_SCALE, hfloor);
+                pp_store_operand8<TERMS>(Hr, x, ok ? hoff : 0xFFFFFFFFu);
+            }
+            coff = ncoff;
+            hoff = nhoff;
+            ok = nok;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                r[h] = rn[h];
+                r2[h] = r2n[h];
             }
         }
     }
@@ -190,18 +296,18 @@ template <int MI, int NJ, int TERMS>
 __device__ __forceinline__ void epilogue_scalar16(const PpGemmDesc& d, float descale, f32x4 (&acc)[MI][NJ], int mw, int nw, int lane) {
     const int l15 = lane & 15, lq = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = nw + j * 16 + l15;
-        if (n >= d.N) continue;
-        const float bias = d.bias ? d.bias[n] : 0.f;
-        const float gamma = d.gamma ? d.gamma[n] : 1.f;
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int r = 0; r < 4; ++r) {
+            const int n = nw + (j >> 1) * 32 + 8 * lq + 4 * (j & 1) + r;
+            if (n >= d.N) continue;
+            const float bias = d.bias ? d.bias[n] : 0.f;
+            const float gamma = d.gamma ? d.gamma[n] : 1.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = mw + i * 16 + 4 * lq + r;
+            for (int i = 0; i < MI; ++i) {
+                const int m = mw + i * 16 + l15;
                 if (m >= d.M) continue;
-                float v = act_apply(acc[i][j][r] * descale + bias, d.act) * gamma;
+                float v = act_apply(fmaf(acc[i][j][r], descale, bias), d.act) * gamma;
                 size_t off, orow = (size_t)m;
                 int ocol = n;
                 if (d.shuffle_r == 0) {
@@ -231,7 +337,7 @@ __device__ __forceinline__ void epilogue_scalar16(const PpGemmDesc& d, float des
                     }
                 }
             }
-    }
+        }
 }
 
 __device__ __forceinline__ bool epilogue_vector_ok(const PpGemmDesc& d) {

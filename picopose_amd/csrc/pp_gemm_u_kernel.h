@@ -23,6 +23,8 @@
 //     applied to the per-lane SOURCE address because an LDS-DMA writes lane-linearly;
 //   * ring of S stages, S - 1 K tiles in flight; one counted `s_waitcnt vmcnt((S - 2) P)` + raw s_barrier per K tile
 //     (P = DMA pieces per wave and K tile), placed before the LAST unit of the tile;
+//   * the MFMAs are issued transposed (weights as the instruction's A matrix) and the weight tile's LDS rows are permuted, so
+//     a lane's accumulators are 8 consecutive columns of one output row: the epilogue stores straight from the registers;
 //   * a wave's block (16 MI x 16 NJ) is multiplied in units (pair of 16-row blocks) x (half of the column blocks):
 //     A fragment pairs alternate between two register sets, the two B halves are refilled in place one unit after their
 //     last use, so the fragment registers of the next unit are always loading while the current one multiplies;
@@ -47,7 +49,7 @@ struct TileCfg {
     static constexpr int PA = BM_ / 8 / NW, PB = BN_ / 8 / NW;   // LDS-DMA pieces (8 rows each) per wave and K tile
     static constexpr int A_H = BM_ * 64, B_H = BN_ * 64;   // halfs per operand per stage (128-byte rows)
     static constexpr int STAGE = A_H + B_H;
-    static constexpr int LDS_BYTES = S_ * STAGE * 2 + NW * 2048;   // ring + a 2 KB epilogue patch per wave
+    static constexpr int LDS_BYTES = S_ * STAGE * 2;          // the ring (the epilogue leaves from the registers)
     static_assert(MI % 2 == 0 && NJ % 2 == 0 && (MI / 2) % 2 == 0, "unit schedule: pairs of row blocks, an even number of them");
     static_assert(BM_ % (8 * NW) == 0 && BN_ % (8 * NW) == 0, "DMA pieces are 8 rows per wave instruction");
 };
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             amask[j] = mask;                                                                                         \
         }                                                                                                            \
         _Pragma("unroll") for (int j = 0; j < PB; ++j) {                                                             \
-            const int nb = n0_ + (j * NW + w) * 8 + lr;                                                              \
+            const int nb = n0_ + pp_wperm((j * NW + w) * 8 + lr);   /* LDS weight rows are permuted: pp_gemm_dev.h */  \
             bbyte[j] = nb < d.N ? (unsigned)((long long)nb * d.ldb * EB) + cbyte : 0xFFFFFFFFu;                      \
         }                                                                                                            \
         fkt = 0;                                                                                                     \
@@ -241,13 +243,14 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
     // one 16x16 accumulator tile: the MFMAs of one K tile in the engine's fixed term order
     auto mma1 = [&](const FA& a, const FB& b, int ip, int jh, int i, int j) __attribute__((always_inline)) {
         f32x4& c = acc[2 * ip + i][jh * NJH + j];
+        // (transposed: the weight fragment is the instruction's A matrix — accumulator layout in pp_gemm_dev.h)
         if (TERMS == 2) {
-            c = pp_mfma16(a.x[i][1], b.x[j][0], c);
-            c = pp_mfma16(a.x[i][0], b.x[j][1], c);
-            c = pp_mfma16(a.x[i][0], b.x[j][0], c);
+            c = pp_mfma16(b.x[j][0], a.x[i][1], c);
+            c = pp_mfma16(b.x[j][1], a.x[i][0], c);
+            c = pp_mfma16(b.x[j][0], a.x[i][0], c);
         } else {
-            c = pp_mfma16(a.x[i][0], b.x[j][0], c);
-            c = pp_mfma16(a.x[i][1], b.x[j][1], c);
+            c = pp_mfma16(b.x[j][0], a.x[i][0], c);
+            c = pp_mfma16(b.x[j][1], a.x[i][1], c);
         }
     };
     auto mma_unit = [&](const FA& a, const FB& b, int ip, int jh) __attribute__((always_inline)) {
@@ -268,8 +271,12 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
     load_a(fa0, 0, 0);
     load_b(fb0, 0, 0);
     int cur = 0, nxt = S > 1 ? 1 : 0;
-    float* patch = (float*)(glds + S * STAGE) + w * 512;  // 2 KB per wave behind the ring
     const float descale = d.alpha / (PP_A_SCALE * d.b_scale);
+    // The vector epilogue issues a fixed number of VMEM operations per wave, whatever the tile (rows / columns out of range
+    // are out-of-range offsets, not skipped instructions): at least one 16-byte store per 4 accumulator registers.
+    constexpr int EPI_ST = MI * NJ;
+    static_assert((S - 2) * (PA + PB) + EPI_ST <= 63, "vmcnt is a 6-bit counter");
+    int since_epi = S;   // K tiles since the last epilogue (>= S - 1: nothing of it in flight)
     for (int tile = first; tile < chunk1; tile += nxw) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -300,7 +307,11 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             mma_unit(fa1, fb0, NIP - 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             // K tile kt + 1 has landed (this wave's pieces: counted wait; every wave's: barrier); every fragment of tile kt is in registers
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((S - 2) * (PA + PB)) : "memory");
+            // (the first S - 1 K tiles after an epilogue: its stores — at least EPI_ST per wave, all younger than the pieces waited
+            // for here — may stay in flight; from then on they are older than the awaited pieces and have had S - 1 K tiles to retire)
+            if (since_epi < S - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((S - 2) * (PA + PB) + EPI_ST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((S - 2) * (PA + PB)) : "memory");
+            ++since_epi;
             __builtin_amdgcn_s_barrier();
             // last unit | DMA of K tile kt + S into the stage just freed, first fragments of K tile kt + 1
             PP_U_NEXT_TILE_IF_DONE()
@@ -339,12 +350,21 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
         int tr, tc;
         pp_tile_rc(tile, gx, gy, tr, tc);
         const int mw = tr * T::BM + wr * T::TM, nw = tc * T::BN + wc * T::TN;
-        if (VEC) epilogue_wave16<MI, NJ, TERMS>(d, descale, acc, patch, mw, nw, lane);
+#ifdef PP_STUDY_NOEPI   // (timing study builds only: the K loop alone; one store keeps the accumulators alive)
+        {
+            f32x4 keep = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) keep += acc[i][j];
+            if (keep[0] + keep[1] + keep[2] + keep[3] == -12345.f) d.C[lane] = keep[0];
+        }
+#else
+        if (VEC) epilogue_wave16<MI, NJ, TERMS>(d, descale, acc, mw, nw, lane);
         else epilogue_scalar16<MI, NJ, TERMS>(d, descale, acc, mw, nw, lane);
-        // a compiler-visible full wait: with the epilogue's loads / stores pending at the loop header hipcc would put a
-        // vmcnt(0) in front of the fragment reads of EVERY K tile (the stores have to retire before the next counted
-        // wait anyway, and the tiles in flight have landed during the epilogue)
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#endif
+        since_epi = VEC ? 0 : S;   // (the element-wise epilogue issues a data-dependent number of stores: full waits)
+        if (!VEC) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS at exit
 #undef PP_U_SETUP
@@ -370,7 +390,7 @@ constexpr int H_BM = 256, H_BN = 256;
 constexpr int H_A_ROWS = 288;                       // 256 + 2 * 256 / W rows used (W >= 16), 36 LDS-DMA instructions
 constexpr int H_A_H = H_A_ROWS * 64;                // halfs per A buffer (36 KB)
 constexpr int H_B_H = H_BN * 64;                    // halfs per weight stage (32 KB)
-constexpr int H_LDS_BYTES = (2 * H_A_H + 2 * H_B_H) * 2 + 16384;
+constexpr int H_LDS_BYTES = (2 * H_A_H + 2 * H_B_H) * 2;
 
 template <int TERMS>
 __global__ __launch_bounds__(512, 1) void pp_gemm_uh_kernel(const PpGemmDesc d, int gx, int gy) {
@@ -409,7 +429,9 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_uh_kernel(const PpGemmDesc d, 
         const bool pix = a_pixel(j, mu);
         arel[j] = (unsigned)((long long)(pix ? mu : 0) * d.lda * EB) + cbyte;
     }
-    const unsigned brel = (unsigned)((long long)(w * 8 + lr) * d.ldb * EB) + cbyte;
+    // (LDS weight row rho = w 8 + lr + 64 j holds output column pp_wperm(rho) = pp_wperm(w 8 + lr) + 64 j: pp_gemm_dev.h)
+    const int wrow = pp_wperm(w * 8 + lr);
+    const unsigned brel = (unsigned)((long long)wrow * d.ldb * EB) + cbyte;
     const unsigned bstep = (unsigned)(64 * d.ldb * EB);
     unsigned amask = 0u, bmask = 0u;          // per tile: bit 3 j + dy = source row y + dy - 1 of A row j exists; bit j = column in range
     unsigned abase = 0u, bbase = 0u;          // per tile (scalar): byte offset of the tile's first pixel / first weight row
@@ -431,7 +453,7 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_uh_kernel(const PpGemmDesc d, 
                 const int y = (m % (d.conv_h * W)) / W;                                                              \
                 _Pragma("unroll") for (int t = 0; t < 3; ++t) if (y + t - 1 >= 0 && y + t - 1 < d.conv_h) amask |= 1u << (3 * j + t); \
             }                                                                                                        \
-            if (j < 4 && n0_ + w * 8 + lr + 64 * j < d.N) bmask |= 1u << j;                                          \
+            if (j < 4 && n0_ + wrow + 64 * j < d.N) bmask |= 1u << j;                                                \
         }                                                                                                            \
         fkt = 0;                                                                                                     \
         cky = ckx = cci = 0;                                                                                         \
@@ -509,13 +531,14 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_uh_kernel(const PpGemmDesc d, 
     };
     auto mma1 = [&](const FA& a, const FB& b, int ip, int jh, int i, int j) __attribute__((always_inline)) {
         f32x4& c = acc[2 * ip + i][jh * NJH + j];
+        // (transposed: the weight fragment is the instruction's A matrix — accumulator layout in pp_gemm_dev.h)
         if (TERMS == 2) {
-            c = pp_mfma16(a.x[i][1], b.x[j][0], c);
-            c = pp_mfma16(a.x[i][0], b.x[j][1], c);
-            c = pp_mfma16(a.x[i][0], b.x[j][0], c);
+            c = pp_mfma16(b.x[j][0], a.x[i][1], c);
+            c = pp_mfma16(b.x[j][1], a.x[i][0], c);
+            c = pp_mfma16(b.x[j][0], a.x[i][0], c);
         } else {
-            c = pp_mfma16(a.x[i][0], b.x[j][0], c);
-            c = pp_mfma16(a.x[i][1], b.x[j][1], c);
+            c = pp_mfma16(b.x[j][0], a.x[i][0], c);
+            c = pp_mfma16(b.x[j][1], a.x[i][1], c);
         }
     };
     auto mma_unit = [&](const FA& a, const FB& b, int ip, int jh) __attribute__((always_inline)) {
@@ -548,7 +571,6 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_uh_kernel(const PpGemmDesc d, 
     load_a(fa0, 0, -1, 0);
     load_b(fb0, 0, 0);
     int cur = 0;
-    float* patch = (float*)(Bbase + 2 * H_B_H) + w * 512;
     const float descale = d.alpha / (PP_A_SCALE * d.b_scale);
     for (int tile = first; tile < chunk1; tile += nxw) {
 #pragma unroll
@@ -617,7 +639,7 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_uh_kernel(const PpGemmDesc d, 
             int tr, tc;
             pp_tile_rc(tile, gx, gy, tr, tc);
             const int mw = tr * H_BM + wr * 128, nw = tc * H_BN + wc * 64;
-            if (VEC) epilogue_wave16<MI, NJ, TERMS>(d, descale, acc, patch, mw, nw, lane);
+            if (VEC) epilogue_wave16<MI, NJ, TERMS>(d, descale, acc, mw, nw, lane);
             else epilogue_scalar16<MI, NJ, TERMS>(d, descale, acc, mw, nw, lane);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), visible to hipcc (see pp_gemm_u_kernel)

@@ -44,9 +44,14 @@ int pp_gemm_uh_launch(const PpGemmDesc& d, int terms, int cus, hipStream_t st) {
 
 // the vector epilogue's conditions (pp_gemm_dev.h epilogue_wave16), evaluated on the host
 bool pp_gemm_u_vec_ok(const PpGemmDesc& d) {
-    const bool shuffle_vec = d.shuffle_r == 0 || ((d.N / (d.shuffle_r * d.shuffle_r)) & 7) == 0;
+    const int r2 = d.shuffle_r > 0 ? d.shuffle_r * d.shuffle_r : 1;
+    const bool shuffle_vec = d.shuffle_r == 0 || ((d.N / r2) & 7) == 0;
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    return shuffle_vec && (d.N & 7) == 0 && (d.ldc & 3) == 0 && al(d.C) && al(d.residual) && al(d.residual2) && al(d.bias) && al(d.gamma) &&
+    // the epilogue addresses its outputs with 32-bit byte offsets: the fp32 image (C and the residuals) and the operand image
+    // (4 bytes per element in the hl format, 2 in the h format) must stay below 4 GB
+    const long long out_rows = (long long)d.M * r2, out_cols = d.N / r2;
+    const bool small = (out_rows - 1) * d.ldc * 4 + out_cols * 4 < 0xFFFFFF00LL && (!d.C_hl || (out_rows - 1) * d.ldc_h * 4 + out_cols * 4 < 0xFFFFFF00LL);
+    return shuffle_vec && small && (d.N & 7) == 0 && (d.ldc & 3) == 0 && al(d.C) && al(d.residual) && al(d.residual2) && al(d.bias) && al(d.gamma) &&
            al(d.C_hl) && (!d.C_hl || (d.ldc_h & 7) == 0);
 }
 
