@@ -293,7 +293,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="full_b32_n162_vitb", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--mode", default="fast", choices=["fast", "exact", "fp16"],
+                    help="fast: f16x3 networks (fp32-grade: 2 fp16 terms per operand) + fp16-MFMA stage 1 with exact re-evaluation of near-ties; "
+                         "exact: fp32 MFMA everywhere; fp16: plain fp16 operands, ONE MFMA per product (BASELINE configs[4]'s arithmetic)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = the workload's crops PER RANK (global batch grows with N); strong = the workload's crops as "
                          "the GLOBAL batch, split over the ranks (BASELINE configs[3])")
@@ -336,7 +338,8 @@ def main():
     from picopose_amd import _lib, ops
     from picopose_amd.dist import shard_bounds, sharded_forward, sharded_matching_templates
 
-    ops.PRECISION = "f16x3" if a.mode == "fast" else "f32"   # --mode exact: fp32 MFMA in every kernel
+    ops.PRECISION = {"fast": "f16x3", "exact": "f32", "fp16": "f16"}[a.mode]   # --mode exact: fp32 MFMA in every kernel
+    s1_mode = "exact" if a.mode == "exact" else "fast"       # stage 1's own switch (fp16 MFMA + exact re-evaluation of near-ties | fp32 MFMA)
     from picopose_amd.utils import matching as hm
 
     kind, Bl, N, vit, desc = WORKLOADS[a.workload]
@@ -358,8 +361,8 @@ def main():
 
         def step():
             if distributed:
-                return sharded_matching_templates(bank, query, mask, N, topk=5, mode=a.mode)
-            return hm.matching_templates(bank, query, None, mask, topk=5, mode=a.mode)
+                return sharded_matching_templates(bank, query, mask, N, topk=5, mode=s1_mode)
+            return hm.matching_templates(bank, query, None, mask, topk=5, mode=s1_mode)
     else:
         from picopose_amd.picopose import Net
         from picopose_amd.pipeline import pnp_for_outputs, pnp_inputs
@@ -368,7 +371,7 @@ def main():
         net = Net(make_cfg(vit))
         sd = seeded_weights(net, 4, vit)
         net = net.to(dev).eval()
-        net.match_mode = a.mode
+        net.match_mode = s1_mode
         ep = make_end_points(Bl, N, dev, 100 + rank)                     # this rank's crops + their raw templates
         fe = net.feature_extractor
         # feature bank (outside the timed region, run_test.py:120-134): this rank's template slice of ALL crops.
@@ -474,7 +477,7 @@ def main():
                               "compute stream still waits for the query / mask all-gathers + the score all-gather and top-k, stage1 = this "
                               "rank's score slices of ALL crops, tail = stages 2-3 of the own crops, pnp = batched PnP/RANSAC + D2H"}
         sat_checked = None
-        if a.mode == "fast":    # one more untimed forward that verifies every f16x3 operand buffer it produces (raises on saturation)
+        if a.mode in ("fast", "fp16"):    # one more untimed forward that verifies every operand buffer it produces (raises on saturation)
             n0, ops.CHECK_SATURATION = ops.saturation_checks, True
             forward()
             ops.CHECK_SATURATION, sat_checked = False, ops.saturation_checks - n0
@@ -524,7 +527,7 @@ def main():
             _lib.check(L.pp_prof_gemm_collect(xg_ms, xg_fl, xg_n), "pp_prof_gemm_collect")
             _lib.check(L.pp_prof_gemm_enable(0), "pp_prof_gemm_enable")
             net.keep_stage3 = False
-            ops.PRECISION, net.match_mode = "f16x3", a.mode
+            ops.PRECISION, net.match_mode = "f16x3", s1_mode
             xouts, (xrot, xtvec, _, xok) = xo
             import numpy as np
 
@@ -579,9 +582,12 @@ def main():
             "value": B / (dt / a.steps), "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "ms_per_step_median_hip_events": step_ms[len(step_ms) // 2],
             "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None,
-            "dtype": "f32 tensors; networks: f32 operands split into 2 f16 terms (22 bits) on f16 MFMA with f32 accumulate; stage-1 "
-                     "contraction: f16 MFMA operands, f32 accumulate, exact f32 re-evaluation of near-ties; PnP f64"
-                     if a.mode == "fast" else "f32 (fp32 MFMA everywhere; PnP f64)",
+            "dtype": {"fast": "f32 tensors; networks: f32 operands split into 2 f16 terms (22 bits) on f16 MFMA with f32 accumulate; stage-1 "
+                              "contraction: f16 MFMA operands, f32 accumulate, exact f32 re-evaluation of near-ties; PnP f64",
+                      "exact": "f32 (fp32 MFMA everywhere; PnP f64)",
+                      "fp16": "fp16 operands (activations and weights stored f16(4 x), ONE v_mfma_f32_16x16x32_f16 per product), f32 accumulate "
+                              "and f32 epilogues / residual stream; stage-1 contraction: f16 MFMA operands, exact f32 re-evaluation of near-ties; "
+                              "PnP f64"}[a.mode],
             "data": "synthetic",
             "config": {"workload": f"{a.workload}: {desc}", "global_batch": B, "crops_per_rank": Bl, "templates": N,
                        "templates_per_rank": n_local, "backbone": vit, "channels": C,
@@ -591,7 +597,7 @@ def main():
                        f"{a.scaling} scaling: {Bl} crops per rank x{world} (global batch {B}); feature bank template-sharded x{world} "
                        f"({n_local} of {N} templates on rank 0) + all-gathers (query features, sampled masks, scores); {backend}"},
         }
-        s1_roof = {"bound": "hbm", "kernel": f"s1_main<{a.mode}> (stage-1 fused similarity)", "achieved": achieved,
+        s1_roof = {"bound": "hbm", "kernel": f"s1_main<{s1_mode}> (stage-1 fused similarity)", "achieved": achieved,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                    "traffic_source": traffic_src, "traffic_measured_in_this_run": False, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kbytes,
                    "timing": "HIP events on the launch stream around this launch, " +
@@ -600,13 +606,13 @@ def main():
         # (fast mode: one fp16 MFMA term; exact mode: fp32 MFMA).  With an fp16-stored bank the intensity is 2 C 256^2 / (2 C 256)
         # = 256 flop/B against a ridge of 2500 / 8 = 312: the kernel then sits between both roofs and this reading is the binding one.
         s1_flops = 2.0 * B * n_local * 256 * 256 * C
-        s1_peak = MFMA_F16_PEAK_TF if a.mode == "fast" else MFMA_F32_PEAK_TF
+        s1_peak = MFMA_F32_PEAK_TF if a.mode == "exact" else MFMA_F16_PEAK_TF
         s1_roof["mfma"] = {"achieved": s1_flops / (kern_ms * 1e-3) / 1e12, "peak": s1_peak, "unit": "TFLOP/s",
                            "frac": s1_flops / (kern_ms * 1e-3) / 1e12 / s1_peak, "flops_per_launch": s1_flops,
                            "intensity_flop_per_byte": s1_flops / kbytes}
         if kind == "full" and gemm and gemm["launches"][0] > 0:
-            k = 0 if a.mode == "fast" else 1     # fast: pre-split f16x3 kernel; exact: the fp32-MFMA kernel
-            mult, peak = (3, MFMA_F16_PEAK_TF) if a.mode == "fast" else (1, MFMA_F32_PEAK_TF)
+            k = 1 if a.mode == "exact" else 0     # fast / fp16: the pre-split kernel; exact: the fp32-MFMA kernel
+            mult, peak = {"fast": (3, MFMA_F16_PEAK_TF), "fp16": (1, MFMA_F16_PEAK_TF), "exact": (1, MFMA_F32_PEAK_TF)}[a.mode]
             n, msum, fl = gemm["launches"][k], gemm["ms"][k], gemm["flops"][k]
             ach = mult * fl / (msum * 1e-3) / 1e12
             g_traffic = g_src = None   # HBM bytes of these kernels over one step, from separate PMC passes (tools/pmc_step.sh)
@@ -617,12 +623,13 @@ def main():
                 "bound": "mfma",
                 "kernel": "pp_gemm_u_kernel / pp_gemm_uh_kernel, all tile instantiations (GEMM / implicit-im2col conv, persistent, LDS-DMA ring; both operands "
                           "pre-split into 2 fp16 terms; 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)" if a.mode == "fast" else
-                          "gemm_kernel (v_mfma_f32_32x32x2_f32)",
+                          ("pp_gemm_u_kernel / pp_gemm_uh_kernel, h operand format (plain fp16 operands, 1 x v_mfma_f32_16x16x32_f16 per product, "
+                           "fp32 accumulate)" if a.mode == "fp16" else "gemm_kernel (v_mfma_f32_32x32x2_f32)"),
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "frac_algorithmic": fl / (msum * 1e-3) / 1e12 / peak,
                 "frac_note": "frac = EXECUTED MFMA flops (3 fp16 MFMA products per fp32-grade product) / time / fp16 dense peak; "
                              "frac_algorithmic = 2MNK / time / the same peak (ceiling 1/3 under the 3-term scheme)"
-                             if a.mode == "fast" else "fp32 MFMA: executed = algorithmic",
+                             if a.mode == "fast" else "one MFMA product per product: executed = algorithmic (frac = frac_algorithmic)",
                 "traffic": None if g_traffic is None else g_traffic / n, "traffic_bytes_per_step": g_traffic, "traffic_source": g_src,
                 "traffic_measured_in_this_run": False,
                 "per_kernel": gemm.get("per_kernel"),
@@ -638,7 +645,12 @@ def main():
             line["roofline"] = s1_roof
         if kind == "full":
             tf = Bl * full_gflop_per_crop(N, vit, cached=cached) / (dt / a.steps) / 1e3   # useful (fp32-equivalent) TFLOP/s per GPU
-            if a.mode == "fast":   # every product = 3 fp16 MFMA products
+            if a.mode == "fp16":
+                line["mfma"] = {"bound": "mfma", "scope": "whole step, all kernels (the GEMM/conv engine is >85 % of it)",
+                                "engine": "f16: plain fp16 operands, 1 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate", "achieved": tf,
+                                "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TF,
+                                "gflop_per_crop": full_gflop_per_crop(N, vit, cached=cached)}
+            elif a.mode == "fast":   # every product = 3 fp16 MFMA products
                 line["mfma"] = {"bound": "mfma", "scope": "whole step, all kernels (the GEMM/conv engine is >85 % of it)",
                                 "engine": "f16x3: operands split into 2 fp16 terms, 3 x v_mfma_f32_16x16x32_f16, fp32 accumulate",
                                 "useful_tflops": tf, "achieved": 3 * tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
@@ -653,7 +665,7 @@ def main():
             if phases is not None:
                 line["phases_ms"] = phases
             if sat_checked is not None:
-                line["f16x3_operand_range"] = {"operands_verified": sat_checked, "saturated": 0,
+                line["operand_range"] = {"operands_verified": sat_checked, "saturated": 0,
                                                "note": "every operand buffer of one untimed forward checked against the fp16 clamp "
                                                        "(|activation| < 16376, picopose_amd/ops.py CHECK_SATURATION); a hit aborts the bench"}
             if exact is not None:

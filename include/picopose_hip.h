@@ -225,6 +225,23 @@ int pp_sum_slices(const float* part, int S, int M, int N, const float* bias, int
  * <- x (rows, c) fp32 with row pitch ld_x: the narrow member of a channel concatenation (raft_decoder.py:161, [out | flow]). */
 int pp_hl_patch_columns(const float* x, int ld_x, int c, long long rows, void* hl, int ld_h, int col0, void* stream);
 
+/* ---- operand-format ("terms") forms of the producers above.  terms = 2: the hl format of PP_PREC_F16X3 (fp16 [rows][ld/8][2][8]);
+ * terms = 1: the h format of PP_PREC_F16 (plain fp16 f16(4 x) [rows][ld]) — BASELINE configs[4]'s "fp16 storage / MFMA with fp32
+ * accumulate".  Same arguments as the entries they generalise, which are these with terms = 2. */
+int pp_split_weights_t(const float* w, long long n, int terms, void* out, float* scale, void* stream);
+int pp_split_activation_t(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu, void* out,
+                          int ld_h, int terms, void* stream);
+int pp_hl_patch_columns_t(const float* x, int ld_x, int c, long long rows, void* out, int ld_h, int col0, int terms, void* stream);
+int pp_layernorm_t(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y, void* out, int terms,
+                   void* stream);
+int pp_resize_bilinear_nhwc_t(const float* in, int B, int H, int W, int C, int Ho, int Wo, float mul, void* out, int terms,
+                              void* stream);
+int pp_warp_nhwc_t(const float* feat, int feat_batch, const float* flow, int B, int H, int W, int C, int ld_flow, void* out,
+                   int ld_h, int terms, void* stream);
+/* attention on the operand the qkv GEMM wrote, result as fp32 (out) and / or as an operand (out_operand), both optional */
+int pp_attention_t(const void* qkv_operand, int terms, int B, int T, int heads, int head_dim, float scale, float* out,
+                   void* out_operand, void* stream);
+
 /* Fused multi-head self-attention (model/stage1/layers/attention.py:49-62): qkv (B,T,3,heads,64) as the qkv
  * linear produces it -> out (B,T,heads*64) = softmax((q*scale) k^T) v per head; exact fp32 MFMA, flash style. */
 int pp_attention(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, void* stream);

@@ -163,7 +163,9 @@ __device__ __forceinline__ int vt_slot(int key) {  // key (0..31) of a chunk -> 
 
 // HLIN: q, k, v arrive as the hl operand the qkv GEMM epilogue wrote (no split work here at all: fragments and the
 // K / V chunks are 16-byte copies); otherwise fp32 qkv, split while staging.  Both give the same bits.
-template <bool HLIN>
+// TERMS = 1 (HLIN only): the h operand format (plain fp16 q, k, v, probabilities) — one MFMA per product
+// (ops.PRECISION = "f16", BASELINE configs[4]); the lo-term registers / LDS planes / MFMAs compile away.
+template <bool HLIN, int TERMS = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_f16x3_kernel(const void* __restrict__ qkv_any, int T, int heads, float scale,
                                                          float* __restrict__ out, _Float16* __restrict__ out_hl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -175,18 +177,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int b = blockIdx.y / heads, h = blockIdx.y % heads;
     const int C3 = 3 * heads * HD;
     const float* base = (const float*)qkv_any + (size_t)b * T * C3 + h * HD;            // fp32 input
-    const _Float16* hbase = (const _Float16*)qkv_any + ((size_t)b * T * C3 + h * HD) * 2;  // hl input (h*HD % 8 == 0)
+    const _Float16* hbase = (const _Float16*)qkv_any + ((size_t)b * T * C3 + h * HD) * TERMS;  // operand input (h*HD % 8 == 0)
     const int q = (blockIdx.x * (nthr >> 6) + w) * 32 + l31;
     const int qc = q < T ? q : T - 1;
 
     // Q fragments: step s holds d = 16 s + 8 lh .. + 7 of query l31 (unscaled: the scores are scaled after the MFMAs)
     h8 qh[4], ql[4];
     if (HLIN) {
-        const _Float16* qp = hbase + (size_t)qc * C3 * 2;
+        const _Float16* qp = hbase + (size_t)qc * C3 * TERMS;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            qh[s] = *(const h8*)(qp + 2 * (16 * s + 8 * lh));
-            ql[s] = *(const h8*)(qp + 2 * (16 * s + 8 * lh) + 8);
+            qh[s] = *(const h8*)(qp + TERMS * (16 * s + 8 * lh));
+            if (TERMS == 2) ql[s] = *(const h8*)(qp + 2 * (16 * s + 8 * lh) + 8);
+            else ql[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     } else {
         const float* qp = base + (size_t)qc * C3;
@@ -233,12 +236,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                 pk[2 * it] = pk[2 * it + 1] = pv[2 * it] = pv[2 * it + 1] = z;
                 if (idx < KC * (HD / 8) && k0 + row < Tm) {
-                    const _Float16* kp2 = hbase + ((size_t)(k0 + row) * C3 + heads * HD + 8 * g) * 2;
-                    const _Float16* vp2 = hbase + ((size_t)(k0 + row) * C3 + 2 * heads * HD + 8 * g) * 2;
+                    const _Float16* kp2 = hbase + ((size_t)(k0 + row) * C3 + heads * HD + 8 * g) * TERMS;
+                    const _Float16* vp2 = hbase + ((size_t)(k0 + row) * C3 + 2 * heads * HD + 8 * g) * TERMS;
                     pk[2 * it] = *(const h8*)kp2;
-                    pk[2 * it + 1] = *(const h8*)(kp2 + 8);
                     pv[2 * it] = *(const h8*)vp2;
-                    pv[2 * it + 1] = *(const h8*)(vp2 + 8);
+                    if (TERMS == 2) {
+                        pk[2 * it + 1] = *(const h8*)(kp2 + 8);
+                        pv[2 * it + 1] = *(const h8*)(vp2 + 8);
+                    }
                 }
             } else {
                 const int row = idx >> 4, c4 = (idx & 15) * 4;
@@ -258,9 +263,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if (idx >= KC * (HD / 8)) continue;
                 const int row = idx >> 3, g = idx & 7, slot = vt_slot(row);   // K [key][d], V [slot(key)][d]
                 *(h8*)(Kh + row * KHLD + 8 * g) = pk[2 * it];
-                *(h8*)(Kl + row * KHLD + 8 * g) = pk[2 * it + 1];
                 *(h8*)(Vh + slot * VLD + 8 * g) = pv[2 * it];
-                *(h8*)(Vl + slot * VLD + 8 * g) = pv[2 * it + 1];
+                if (TERMS == 2) {
+                    *(h8*)(Kl + row * KHLD + 8 * g) = pk[2 * it + 1];
+                    *(h8*)(Vl + slot * VLD + 8 * g) = pv[2 * it + 1];
+                }
             } else {
                 if (idx >= KC * (HD / 4)) continue;
                 const int row = idx >> 4, c4 = (idx & 15) * 4, slot = vt_slot(row);
@@ -294,9 +301,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const h8 kh = *(const h8*)(Kh + l31 * KHLD + 16 * s + 8 * lh);
-            const h8 kl = *(const h8*)(Kl + l31 * KHLD + 16 * s + 8 * lh);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
+            if (TERMS == 2) {
+                const h8 kl = *(const h8*)(Kl + l31 * KHLD + 16 * s + 8 * lh);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
+            }
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
         }
         float mx = -INFINITY;
@@ -353,12 +362,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         };
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const h8 v0h = vfrag(Vh, s, 0), v0l = vfrag(Vl, s, 0), v1h = vfrag(Vh, s, 1), v1l = vfrag(Vl, s, 1);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph[s], o0, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl[s], o0, 0, 0, 0);
+            const h8 v0h = vfrag(Vh, s, 0), v1h = vfrag(Vh, s, 1);
+            if (TERMS == 2) {
+                const h8 v0l = vfrag(Vl, s, 0), v1l = vfrag(Vl, s, 1);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph[s], o0, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl[s], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph[s], o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl[s], o1, 0, 0, 0);
+            }
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph[s], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph[s], o1, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl[s], o1, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph[s], o1, 0, 0, 0);
         }
     }
@@ -372,7 +384,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int idx = tid; idx < ntail * HD; idx += nthr) {
             const int r = idx / HD, dd = idx - r * HD;
             float kf, vf;
-            if (HLIN) {
+            if (HLIN && TERMS == 1) {
+                kf = (float)hbase[(size_t)(Tm + r) * C3 + heads * HD + dd];
+                vf = (float)hbase[(size_t)(Tm + r) * C3 + 2 * heads * HD + dd];
+            } else if (HLIN) {
                 const _Float16* kp2 = hbase + ((size_t)(Tm + r) * C3 + heads * HD) * 2 + pp_hl_col(dd, 0);
                 const _Float16* vp2 = hbase + ((size_t)(Tm + r) * C3 + 2 * heads * HD) * 2 + pp_hl_col(dd, 0);
                 kf = (float)kp2[0] + (float)kp2[8];
@@ -445,9 +460,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     hh[i] = a;
                     ll[i] = c;
                 }
-                _Float16* hp = out_hl + 2 * obase + pp_hl_col(4 * j, 0);
-                *(h4*)hp = hh;
-                *(h4*)(hp + 8) = ll;
+                if (TERMS == 2) {
+                    _Float16* hp = out_hl + 2 * obase + pp_hl_col(4 * j, 0);
+                    *(h4*)hp = hh;
+                    *(h4*)(hp + 8) = ll;
+                } else {
+                    *(h4*)(out_hl + obase + 4 * j) = hh;
+                }
             }
         }
     }
@@ -458,8 +477,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 extern "C" {
 
 static int attention_launch(const void* qkv, bool hl_in, int B, int T, int heads, int head_dim, float scale, int prec, float* out,
-                            void* out_hl, void* stream) {
+                            void* out_hl, void* stream, int terms = 2) {
     if (!qkv || (!out && !out_hl) || B <= 0 || T <= 0 || heads <= 0 || (hl_in && prec != PP_PREC_F16X3)) return PP_EINVAL;
+    if (terms == 1 && !hl_in) return PP_EINVAL;
     if (head_dim != HD || ((uintptr_t)qkv % 16) != 0) return PP_EINVAL;
     if (prec == PP_PREC_F16X3) {
         // waves per workgroup: the split of the ceil(T/32) query tiles that wastes the fewest wave slots
@@ -473,7 +493,10 @@ static int attention_launch(const void* qkv, bool hl_in, int B, int T, int heads
             }
         }
         const size_t kv = (size_t)(2 * KC * KHLD + 2 * KC * VLD) * sizeof(_Float16), os = (size_t)wpb * 32 * OLD * sizeof(float);
-        if (hl_in)
+        if (hl_in && terms == 1)
+            hipLaunchKernelGGL((attn_f16x3_kernel<true, 1>), dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
+                               (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl);
+        else if (hl_in)
             hipLaunchKernelGGL(attn_f16x3_kernel<true>, dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
                                (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl);
         else
@@ -507,6 +530,12 @@ int pp_attention_hl(const void* qkv_hl, int B, int T, int heads, int head_dim, f
                     void* stream) {
     if (((uintptr_t)qkv_hl % 16) != 0) return PP_EINVAL;
     return attention_launch(qkv_hl, true, B, T, heads, head_dim, scale, PP_PREC_F16X3, out, out_hl, stream);
+}
+
+int pp_attention_t(const void* qkv_operand, int terms, int B, int T, int heads, int head_dim, float scale, float* out, void* out_operand,
+                   void* stream) {
+    if (((uintptr_t)qkv_operand % 16) != 0 || (terms != 1 && terms != 2)) return PP_EINVAL;
+    return attention_launch(qkv_operand, true, B, T, heads, head_dim, scale, PP_PREC_F16X3, out, out_operand, stream, terms);
 }
 
 }  // extern "C"

@@ -513,7 +513,8 @@ namespace {
 // one thread = 8 channels = 32 bytes in, 32 contiguous bytes (8 hi + 8 lo) out
 __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict__ x, long long bstride, int P, int ld,
                                                         int C, long long total8, int relu, _Float16* __restrict__ hl,
-                                                        int ldh) {
+                                                        int ldh, int terms) {
+    // terms = 2: hl format, 32 bytes per 8 channels (ldh = 2 ld_h halfs per row); terms = 1: h format, 16 bytes (ldh = ld_h)
     const int c8n = C >> 3;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
         const long long row = i / c8n;
@@ -531,11 +532,13 @@ __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict_
         h4 h0, l0, h1, l1;
         split_f16x4(v0, A_SCALE, h0, l0);
         split_f16x4(v1, A_SCALE, h1, l1);
-        _Float16* o = hl + row * ldh + 2 * c;
+        _Float16* o = hl + row * ldh + terms * c;
         *(h4*)o = h0;
         *(h4*)(o + 4) = h1;
-        *(h4*)(o + 8) = l0;
-        *(h4*)(o + 12) = l1;
+        if (terms == 2) {
+            *(h4*)(o + 8) = l0;
+            *(h4*)(o + 12) = l1;
+        }
     }
 }
 
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict_
 template <int NG>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ b, int rows, int C, float eps,
-                                                        float* __restrict__ y, _Float16* __restrict__ hl) {
+                                                        float* __restrict__ y, _Float16* __restrict__ hl, int terms) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (size_t)row * C;
@@ -609,11 +612,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 h4 h0, l0, h1, l1;
                 split_f16x4(o[0], A_SCALE, h0, l0);
                 split_f16x4(o[1], A_SCALE, h1, l1);
-                _Float16* hp = hl + (size_t)row * 2 * C + gi * 16;
+                _Float16* hp = hl + ((size_t)row * C + gi * 8) * terms;
                 *(h4*)hp = h0;
                 *(h4*)(hp + 4) = h1;
-                *(h4*)(hp + 8) = l0;
-                *(h4*)(hp + 12) = l1;
+                if (terms == 2) {
+                    *(h4*)(hp + 8) = l0;
+                    *(h4*)(hp + 12) = l1;
+                }
             }
         }
     } else {
@@ -636,25 +641,29 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (hl) {  // f16x3 operand of the following linear layer
                 _Float16 h, l;
                 pp_split_f16(o, h, l);
-                _Float16* hp = hl + (size_t)row * 2 * C + pp_hl_col(c, 0);
-                hp[0] = h;
-                hp[8] = l;
+                if (terms == 2) {
+                    _Float16* hp = hl + (size_t)row * 2 * C + pp_hl_col(c, 0);
+                    hp[0] = h;
+                    hp[8] = l;
+                } else {
+                    hl[(size_t)row * C + c] = h;
+                }
             }
         }
     }
 }
 
 static void launch_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
-                             _Float16* hl, hipStream_t st) {
+                             _Float16* hl, hipStream_t st, int terms = 2) {
     const dim3 grid((rows + 3) / 4), block(256);
     const bool vec = C % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
                      ((uintptr_t)beta % 16 == 0) && (!y || (uintptr_t)y % 16 == 0) && (!hl || (uintptr_t)hl % 16 == 0);
     if (vec && C <= 512)
-        hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, rows, C, eps, y, hl);
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, rows, C, eps, y, hl, terms);
     else if (vec && C <= 1024)
-        hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, gamma, beta, rows, C, eps, y, hl);
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, gamma, beta, rows, C, eps, y, hl, terms);
     else
-        hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, st, x, gamma, beta, rows, C, eps, y, hl);
+        hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, st, x, gamma, beta, rows, C, eps, y, hl, terms);
 }
 
 // softmax over the last dimension, in place: one wave per row (layers/attention.py:57)
@@ -781,8 +790,13 @@ __global__ __launch_bounds__(1024) void absmax_scale_kernel(const float* __restr
 }
 
 __global__ void split_f16x3_kernel(const float* __restrict__ w, long long n, const float* __restrict__ scale,
-                                   _Float16* __restrict__ hl) {
+                                   _Float16* __restrict__ hl, int terms) {
     const float s = scale[0];
+    if (terms == 1) {   // h format: f16(s w)
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+            hl[i] = (_Float16)fminf(fmaxf(w[i] * s, -65504.f), 65504.f);
+        return;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float x = w[i] * s;
         const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
@@ -800,24 +814,31 @@ __global__ void split_f16x3_kernel(const float* __restrict__ w, long long n, con
 
 extern "C" {
 
-int pp_split_f16x3(const float* w, long long n, void* hl, float* scale, void* stream) {
-    if (!w || !hl || !scale || n <= 0 || n % 8 != 0) return PP_EINVAL;
+int pp_split_weights_t(const float* w, long long n, int terms, void* out, float* scale, void* stream) {
+    if (!w || !out || !scale || n <= 0 || n % 8 != 0 || (terms != 1 && terms != 2)) return PP_EINVAL;
     hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, n, scale);
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(split_f16x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, n, scale, (_Float16*)hl);
+    hipLaunchKernelGGL(split_f16x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, n, scale, (_Float16*)out, terms);
+    return pp_last_launch();
+}
+
+int pp_split_f16x3(const float* w, long long n, void* hl, float* scale, void* stream) { return pp_split_weights_t(w, n, 2, hl, scale, stream); }
+
+int pp_split_activation_t(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu, void* hl,
+                          int ld_h, int terms, void* stream) {
+    if (!x || !hl || B <= 0 || P <= 0 || C <= 0 || C % 8 != 0 || row_stride % 4 != 0 || batch_stride % 4 != 0 ||
+        ((uintptr_t)x % 16) != 0 || ((uintptr_t)hl % 16) != 0 || ld_h < C || ld_h % 8 != 0 || (terms != 1 && terms != 2))
+        return PP_EINVAL;
+    const long long total8 = (long long)B * P * (C / 8);
+    const int grid = (int)((total8 + 255) / 256 < 8192 ? (total8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, batch_stride, P, row_stride, C,
+                       total8, relu, (_Float16*)hl, terms * ld_h, terms);
     return pp_last_launch();
 }
 
 int pp_split_activation_ld(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu, void* hl,
                            int ld_h, void* stream) {
-    if (!x || !hl || B <= 0 || P <= 0 || C <= 0 || C % 8 != 0 || row_stride % 4 != 0 || batch_stride % 4 != 0 ||
-        ((uintptr_t)x % 16) != 0 || ((uintptr_t)hl % 16) != 0 || ld_h < C || ld_h % 8 != 0)
-        return PP_EINVAL;
-    const long long total8 = (long long)B * P * (C / 8);
-    const int grid = (int)((total8 + 255) / 256 < 8192 ? (total8 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(split_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, batch_stride, P, row_stride, C,
-                       total8, relu, (_Float16*)hl, 2 * ld_h);
-    return pp_last_launch();
+    return pp_split_activation_t(x, batch_stride, B, P, row_stride, C, relu, hl, ld_h, 2, stream);
 }
 
 // Second half of a split-K linear layer: out[m, n] = act(sum_s part[s, m, n] + bias[n]) (fixed summation order s = 0, 1, ...)
@@ -840,24 +861,33 @@ int pp_sum_slices(const float* part, int S, int M, int N, const float* bias, int
 // A few columns of an existing hl operand (channel concatenation with a narrow tensor: the flow decoder's [out_net | flow],
 // raft_decoder.py:161): columns col0 .. col0 + c - 1 of every row <- x[row][0 .. c-1]; any alignment, one element per thread.
 __global__ __launch_bounds__(256) void hl_patch_kernel(const float* __restrict__ x, int ld_x, int c, long long rows, _Float16* __restrict__ hl,
-                                                       int ldh, int col0) {
+                                                       int ldh, int col0, int terms) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * c) return;
     const long long row = i / c;
     const int j = (int)(i - row * c);
     _Float16 h, l;
     pp_split_f16(x[row * ld_x + j], h, l);
-    _Float16* hp = hl + row * ldh + pp_hl_col(col0 + j, 0);
-    hp[0] = h;
-    hp[8] = l;
+    if (terms == 2) {
+        _Float16* hp = hl + row * ldh + pp_hl_col(col0 + j, 0);
+        hp[0] = h;
+        hp[8] = l;
+    } else {
+        hl[row * ldh + col0 + j] = h;
+    }
+}
+
+int pp_hl_patch_columns_t(const float* x, int ld_x, int c, long long rows, void* hl, int ld_h, int col0, int terms, void* stream) {
+    if (!x || !hl || c <= 0 || c > 64 || rows <= 0 || ld_x < c || col0 < 0 || col0 + c > ld_h || ld_h % 8 != 0 || (terms != 1 && terms != 2))
+        return PP_EINVAL;
+    const long long n = rows * c;
+    hipLaunchKernelGGL(hl_patch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld_x, c, rows,
+                       (_Float16*)hl, terms * ld_h, col0, terms);
+    return pp_last_launch();
 }
 
 int pp_hl_patch_columns(const float* x, int ld_x, int c, long long rows, void* hl, int ld_h, int col0, void* stream) {
-    if (!x || !hl || c <= 0 || c > 64 || rows <= 0 || ld_x < c || col0 < 0 || col0 + c > ld_h || ld_h % 8 != 0) return PP_EINVAL;
-    const long long n = rows * c;
-    hipLaunchKernelGGL(hl_patch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld_x, c, rows,
-                       (_Float16*)hl, 2 * ld_h, col0);
-    return pp_last_launch();
+    return pp_hl_patch_columns_t(x, ld_x, c, rows, hl, ld_h, col0, 2, stream);
 }
 
 int pp_split_activation(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu, void* hl,
@@ -1065,11 +1095,16 @@ int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows
     return pp_last_launch();
 }
 
+int pp_layernorm_t(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
+                   void* hl, int terms, void* stream) {
+    if (!x || !gamma || !beta || !hl || rows <= 0 || C <= 0 || C % 8 != 0 || (terms != 1 && terms != 2)) return PP_EINVAL;
+    launch_layernorm(x, gamma, beta, rows, C, eps, y, (_Float16*)hl, (hipStream_t)stream, terms);
+    return pp_last_launch();
+}
+
 int pp_layernorm_split(const float* x, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
                        void* hl, void* stream) {
-    if (!x || !gamma || !beta || !hl || rows <= 0 || C <= 0 || C % 8 != 0) return PP_EINVAL;
-    launch_layernorm(x, gamma, beta, rows, C, eps, y, (_Float16*)hl, (hipStream_t)stream);
-    return pp_last_launch();
+    return pp_layernorm_t(x, gamma, beta, rows, C, eps, y, hl, 2, stream);
 }
 
 int pp_softmax_rows(float* x, int rows, int n, int ld, void* stream) {

@@ -16,7 +16,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // ATen: src = dst * (in-1)/(out-1); i0 = floor, i1 = min(i0+1, in-1), lambda = src - i0.
 __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ in, int H, int W, int C,
                                                      int Ho, int Wo, float mul, float* __restrict__ out,
-                                                     _Float16* __restrict__ out_hl) {
+                                                     _Float16* __restrict__ out_hl, int terms) {
     const int b = blockIdx.z, oy = blockIdx.y, tid = threadIdx.x;
     const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
     const float ly = fy - (float)y0, hy = 1.f - ly;
     const float* ib = in + (size_t)b * H * W * C;
     if (out_hl) {  // the result only as the f16x3 operand of the following 1x1 convolution: 8 channels per thread
-        _Float16* oh = out_hl + ((size_t)b * Ho + oy) * Wo * 2 * C;
+        _Float16* oh = out_hl + ((size_t)b * Ho + oy) * Wo * terms * C;   // terms = 2: hl format, 1: h format
         const int C8 = C >> 3;
         for (int i = blockIdx.x * 256 + tid; i < Wo * C8; i += gridDim.x * 256) {
             const int ox = i / C8, c = (i - ox * C8) * 8;
@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
                     ll[4 * q + k] = l;
                 }
             }
-            *(h8*)(oh + (size_t)ox * 2 * C + 2 * c) = hh;
-            *(h8*)(oh + (size_t)ox * 2 * C + 2 * c + 8) = ll;
+            *(h8*)(oh + ((size_t)ox * C + c) * terms) = hh;
+            if (terms == 2) *(h8*)(oh + (size_t)ox * 2 * C + 2 * c + 8) = ll;
         }
         return;
     }
@@ -95,7 +95,7 @@ __device__ __forceinline__ float roundtrip(float x, int size) {
 template <bool HL>
 __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ feat, int feat_batch,
                                                    const float* __restrict__ flow, int H, int W, int C, int ld_flow,
-                                                   float* __restrict__ out, int ld_out) {
+                                                   float* __restrict__ out, int ld_out, int terms) {
     const int b = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= H * W) return;
     const int y = p / W, x = p - y * W;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
     const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix, wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
     const float* fb = feat + (size_t)(b % feat_batch) * H * W * C;  // feat given once for several hypotheses
     float* o = HL ? nullptr : out + ((size_t)b * H * W + p) * ld_out;
-    _Float16* oh = HL ? (_Float16*)out + ((size_t)b * H * W + p) * 2 * ld_out : nullptr;
+    _Float16* oh = HL ? (_Float16*)out + ((size_t)b * H * W + p) * terms * ld_out : nullptr;   // terms = 2: hl, 1: h format
     const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
     const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
     // Taps outside the image read a clamped pixel whose VALUE is then masked to zero (bitwise: all-ones / all-zeros mask) —
@@ -138,9 +138,13 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
             pp_split_f16(acc.y, h1, l1);
             pp_split_f16(acc.z, h2, l2);
             pp_split_f16(acc.w, h3, l3);
-            _Float16* q = oh + pp_hl_col(c, 0);
-            *(h4w*)q = h4w{h0, h1, h2, h3};
-            *(h4w*)(q + 8) = h4w{l0, l1, l2, l3};
+            if (terms == 2) {
+                _Float16* q = oh + pp_hl_col(c, 0);
+                *(h4w*)q = h4w{h0, h1, h2, h3};
+                *(h4w*)(q + 8) = h4w{l0, l1, l2, l3};
+            } else {
+                *(h4w*)(oh + c) = h4w{h0, h1, h2, h3};
+            }
         } else {
             *(f4*)(o + c) = acc;
         }
@@ -627,19 +631,24 @@ int pp_resize_bilinear_nhwc(const float* in, int B, int H, int W, int C, int Ho,
     const int work = vec ? Wo * (C / 4) : Wo * C;
     const int gx = (work + 1023) / 1024;  // four items per thread: one workgroup per output row for 64 x 256 channels
     hipLaunchKernelGGL(resize_kernel, dim3(gx < 64 ? gx : 64, Ho, B), dim3(256), 0, (hipStream_t)stream, in, H, W,
-                       C, Ho, Wo, mul, out, (_Float16*)nullptr);
+                       C, Ho, Wo, mul, out, (_Float16*)nullptr, 2);
+    return pp_last_launch();
+}
+
+int pp_resize_bilinear_nhwc_t(const float* in, int B, int H, int W, int C, int Ho, int Wo, float mul, void* out_hl,
+                              int terms, void* stream) {
+    if (!in || !out_hl || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || Ho <= 0 || Wo <= 0 ||
+        (((uintptr_t)in | (uintptr_t)out_hl) & 15) != 0 || (terms != 1 && terms != 2))
+        return PP_EINVAL;
+    const int gx = (Wo * (C / 8) + 1023) / 1024;
+    hipLaunchKernelGGL(resize_kernel, dim3(gx < 64 ? gx : 64, Ho, B), dim3(256), 0, (hipStream_t)stream, in, H, W,
+                       C, Ho, Wo, mul, (float*)nullptr, (_Float16*)out_hl, terms);
     return pp_last_launch();
 }
 
 int pp_resize_bilinear_nhwc_hl(const float* in, int B, int H, int W, int C, int Ho, int Wo, float mul, void* out_hl,
                                void* stream) {
-    if (!in || !out_hl || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || Ho <= 0 || Wo <= 0 ||
-        (((uintptr_t)in | (uintptr_t)out_hl) & 15) != 0)
-        return PP_EINVAL;
-    const int gx = (Wo * (C / 8) + 1023) / 1024;
-    hipLaunchKernelGGL(resize_kernel, dim3(gx < 64 ? gx : 64, Ho, B), dim3(256), 0, (hipStream_t)stream, in, H, W,
-                       C, Ho, Wo, mul, (float*)nullptr, (_Float16*)out_hl);
-    return pp_last_launch();
+    return pp_resize_bilinear_nhwc_t(in, B, H, W, C, Ho, Wo, mul, out_hl, 2, stream);
 }
 
 int pp_warp_nhwc(const float* feat, int feat_batch, const float* flow, int B, int H, int W, int C, int ld_flow,
@@ -648,18 +657,23 @@ int pp_warp_nhwc(const float* feat, int feat_batch, const float* flow, int B, in
         ld_out < C || ld_out % 4 != 0 || ((uintptr_t)out % 16) != 0)
         return PP_EINVAL;
     hipLaunchKernelGGL(warp_kernel<false>, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, feat_batch, flow,
-                       H, W, C, ld_flow, out, ld_out);
+                       H, W, C, ld_flow, out, ld_out, 2);
+    return pp_last_launch();
+}
+
+int pp_warp_nhwc_t(const float* feat, int feat_batch, const float* flow, int B, int H, int W, int C, int ld_flow,
+                   void* out_hl, int ld_h, int terms, void* stream) {
+    if (!feat || !flow || !out_hl || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || ld_flow < 2 || feat_batch <= 0 ||
+        ld_h < C || ld_h % 8 != 0 || ((uintptr_t)out_hl % 16) != 0 || (terms != 1 && terms != 2))
+        return PP_EINVAL;
+    hipLaunchKernelGGL(warp_kernel<true>, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, feat_batch, flow,
+                       H, W, C, ld_flow, (float*)out_hl, ld_h, terms);
     return pp_last_launch();
 }
 
 int pp_warp_nhwc_hl(const float* feat, int feat_batch, const float* flow, int B, int H, int W, int C, int ld_flow,
                     void* out_hl, int ld_h, void* stream) {
-    if (!feat || !flow || !out_hl || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || ld_flow < 2 || feat_batch <= 0 ||
-        ld_h < C || ld_h % 8 != 0 || ((uintptr_t)out_hl % 16) != 0)
-        return PP_EINVAL;
-    hipLaunchKernelGGL(warp_kernel<true>, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, feat_batch, flow,
-                       H, W, C, ld_flow, (float*)out_hl, ld_h);
-    return pp_last_launch();
+    return pp_warp_nhwc_t(feat, feat_batch, flow, B, H, W, C, ld_flow, out_hl, ld_h, 2, stream);
 }
 
 int pp_avgpool2_nhwc(const float* in, int B, int H, int W, int C, float* out, void* stream) {

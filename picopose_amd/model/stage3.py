@@ -204,7 +204,7 @@ class FlowDecoder(Packed):
             # write their slices of.  f16x3 engine: X never exists — the producers write their columns of the OPERAND Xs the
             # two heads read (the 1x1 projection also keeps its fp32 map for the correlation lookup), which removes the
             # read + write of the whole concat by a separate split pass.
-            opcat = ops.PRECISION == "f16x3"
+            opcat = ops.presplit()
             dev = fr_in.device
             if opcat:
                 Xs = ops.Split.empty(B * H * W, 640, dev)
@@ -234,7 +234,7 @@ class FlowDecoder(Packed):
             ncorr = (l + 1) * (2 * self.r + 1) ** 2
             # (f16x3 engine: both maps already exist as operands — the render map as columns 0..255 of Xs, the real map from
             # its projection's epilogue — so the lookup stages copies instead of splitting every chunk)
-            hl_maps = dict(f1_hl=(Xs, 0), f2_hl=getattr(fq, "_hl", None)) if opcat and not train else {}
+            hl_maps = dict(f1_hl=(Xs, 0), f2_hl=getattr(fq, "_hl", None)) if opcat and not train and ops.terms() == 2 else {}
             corr = ops.corr_lookup(fr, fq, flow, l + 1, self.r, c_pad=-(-ncorr // 8) * 8, **hl_maps)
             # [corr feat 192 | flow feat 64]: on the f16x3 engine the concat exists only as the operand of out_net
             hl_cat = opcat

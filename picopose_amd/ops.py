@@ -16,9 +16,22 @@ ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "leaky01": 3, "tanh": 4}
 #   "f32"   v_mfma_f32_32x32x2_f32 — exact fp32 products;
 #   "f16x3" every operand split into two fp16 terms (22 bits), 3 fp16 MFMAs, fp32 accumulate: fp32-grade results
 #           (operand rounding 2^-22 instead of 2^-24) at a fraction of the matrix-pipe time.
+#   "f16"   plain fp16 operands f16(4 x) ("h" format), ONE fp16 MFMA per product, fp32 accumulate — the arithmetic BASELINE
+#           configs[4] names ("fp16 storage / MFMA with fp32 accumulate"); half the operand bytes and a third of the MFMAs
+#           of f16x3, at fp16-grade results (error ~5e-4 .. 5e-3 of a tensor's maximum, profiles/r02/precision_study.md).
 PRECISION = "f16x3"
-_PREC = {"f32": 0, "f16x3": 1}
+_PREC = {"f32": 0, "f16x3": 1, "f16": 2}
 _split_cache = {}
+
+
+def terms():
+    """fp16 terms per operand element of the engine's current operand format: 2 = hl (f16x3), 1 = h (f16); 0 = no operands (f32)."""
+    return {"f32": 0, "f16x3": 2, "f16": 1}[PRECISION]
+
+
+def presplit():
+    """The engine runs on pre-split operands (Split objects between producers and consumers)."""
+    return PRECISION != "f32"
 
 # The f16x3 engine stores an activation operand as hi = f16(4 x), lo = f16(4 x - hi): |x| must stay below
 # 65504 / 4 = 16376, beyond which the split SATURATES (finite, but wrong) — fp32 has no such limit.  Trained networks
@@ -45,13 +58,14 @@ def _chk(hl, what):
 def split_weight(w):
     """(hl, scale) — the f16x3 "hl" operand (fp16 (N, 2K): per 8 k the hi then the lo terms) and power-of-two scale
     of a weight matrix; split once per tensor version (one host sync to read the scale back)."""
-    key = (w.data_ptr(), w._version, tuple(w.shape))
+    t = terms()
+    key = (w.data_ptr(), w._version, tuple(w.shape), t)
     hit = _split_cache.get(key)
     if hit is None:
         assert w.is_contiguous()
-        hl = torch.empty(w.shape[0], 2 * w.shape[1], dtype=torch.float16, device=w.device)
+        hl = torch.empty(w.shape[0], t * w.shape[1], dtype=torch.float16, device=w.device)
         scale = torch.empty(1, dtype=torch.float32, device=w.device)
-        _lib.check(_lib.lib().pp_split_f16x3(_p(w), w.numel(), _p(hl), _p(scale), _lib.stream_ptr()), "pp_split_f16x3")
+        _lib.check(_lib.lib().pp_split_weights_t(_p(w), w.numel(), t, _p(hl), _p(scale), _lib.stream_ptr()), "pp_split_weights_t")
         if len(_split_cache) > 4096:
             _split_cache.clear()
         hit = _split_cache[key] = (hl, float(scale.item()), w)  # keep w alive so its address is not reused
@@ -62,15 +76,16 @@ class Split:
     """An activation that exists only as the f16x3 engine's "hl" operand: fp16 (rows, 2C), per 8 channels the 8 hi
     terms then the 8 lo terms (include/picopose_hip.h).  Producers (layernorm, attention, a GEMM epilogue) write it
     directly, so the consuming GEMM needs no split pass and the fp32 tensor is never stored."""
-    __slots__ = ("hl", "image")
+    __slots__ = ("hl", "image", "terms")
 
-    def __init__(self, hl):
+    def __init__(self, hl, t=None):
         self.hl = hl
         self.image = None  # (B, H, W) when the rows are the pixels of NHWC images (operand of a convolution)
+        self.terms = t or terms()   # 2: hl format (rows, 2C); 1: h format (rows, C) — ops.PRECISION = "f16"
 
     @property
     def shape(self):
-        return torch.Size((self.hl.shape[0], self.hl.shape[1] // 2))
+        return torch.Size((self.hl.shape[0], self.hl.shape[1] // self.terms))
 
     @property
     def device(self):
@@ -78,29 +93,38 @@ class Split:
 
     @staticmethod
     def empty(rows, C, device):
-        return Split(torch.empty(rows, 2 * C, dtype=torch.float16, device=device))
+        return Split(torch.empty(rows, terms() * C, dtype=torch.float16, device=device))
+
+    def cols(self, col0, c):
+        """The fp16 columns of the buffer that hold operand columns col0 .. col0 + c (col0, c multiples of 8)."""
+        return self.hl[:, self.terms * col0:self.terms * (col0 + c)]
+
+    def col_ptr(self, col0):
+        """Device address of operand column col0's group (col0 % 8 == 0)."""
+        return self.hl.data_ptr() + 2 * self.terms * col0
 
 
 def _split_ok(C):
-    return PRECISION == "f16x3" and C % 8 == 0
+    return presplit() and C % 8 == 0
 
 
 def split_activation(x, B, P, C, batch_stride, row_stride, relu=False, into=None):
     """Pre-split an activation operand (B, P, C) into a contiguous hl buffer (B*P, 2C) for the f16x3 engine.
     into = (Split over (B*P, Ctot), col0): write columns col0 .. col0 + C of that wider operand instead (col0 % 8 == 0)."""
+    t = terms()
     if into is not None:
         tgt, col0 = into
         ctot = tgt.shape[1]
         assert tgt.shape[0] == B * P and col0 % 8 == 0 and col0 + C <= ctot
-        _lib.check(_lib.lib().pp_split_activation_ld(_p(x), batch_stride, B, P, row_stride, C, int(relu),
-                                                     tgt.hl.data_ptr() + 4 * col0, ctot, _lib.stream_ptr()), "pp_split_activation_ld")
+        _lib.check(_lib.lib().pp_split_activation_t(_p(x), batch_stride, B, P, row_stride, C, int(relu),
+                                                    tgt.col_ptr(col0), ctot, t, _lib.stream_ptr()), "pp_split_activation_t")
         if CHECK_SATURATION:
-            _chk(tgt.hl[:, 2 * col0:2 * (col0 + C)], "pp_split_activation_ld")
+            _chk(tgt.cols(col0, C), "pp_split_activation_t")
         return None
-    hl = torch.empty(B * P, 2 * C, dtype=torch.float16, device=x.device)
-    _lib.check(_lib.lib().pp_split_activation(_p(x), batch_stride, B, P, row_stride, C, int(relu), _p(hl),
-                                              _lib.stream_ptr()), "pp_split_activation")
-    return _chk(hl, "pp_split_activation")
+    hl = torch.empty(B * P, t * C, dtype=torch.float16, device=x.device)
+    _lib.check(_lib.lib().pp_split_activation_t(_p(x), batch_stride, B, P, row_stride, C, int(relu), _p(hl), C, t,
+                                                _lib.stream_ptr()), "pp_split_activation_t")
+    return _chk(hl, "pp_split_activation_t")
 
 
 def hl_patch_columns(x, tgt, col0):
@@ -108,22 +132,37 @@ def hl_patch_columns(x, tgt, col0):
     c = x.shape[-1]
     rows = x.numel() // c
     assert x.is_contiguous() and rows == tgt.shape[0] and col0 + c <= tgt.shape[1]
-    _lib.check(_lib.lib().pp_hl_patch_columns(_p(x), c, c, rows, _p(tgt.hl), tgt.shape[1], col0, _lib.stream_ptr()), "pp_hl_patch_columns")
+    _lib.check(_lib.lib().pp_hl_patch_columns_t(_p(x), c, c, rows, _p(tgt.hl), tgt.shape[1], col0, tgt.terms, _lib.stream_ptr()),
+               "pp_hl_patch_columns_t")
     if CHECK_SATURATION:   # (the 8-channel groups holding the patched columns; their other members are already written)
-        _chk(tgt.hl[:, 2 * (col0 // 8 * 8):2 * (-(-(col0 + c) // 8) * 8)], "pp_hl_patch_columns")
+        _chk(tgt.cols(col0 // 8 * 8, -(-(col0 + c) // 8) * 8 - col0 // 8 * 8), "pp_hl_patch_columns_t")
 
 
 def _can_presplit(x, K, C, *strides):
-    return (PRECISION == "f16x3" and K % 8 == 0 and C % 8 == 0 and x.data_ptr() % 16 == 0
+    return (presplit() and K % 8 == 0 and C % 8 == 0 and x.data_ptr() % 16 == 0
             and all(st % 4 == 0 for st in strides))
 
 
 def _weight_args(w, K):
-    """desc fields for a weight operand under the current precision (pre-split planes when it is aligned)."""
-    if PRECISION == "f16x3" and K % 8 == 0 and w.data_ptr() % 16 == 0:
+    """desc fields for a weight operand under the current precision (pre-split operand when it is aligned)."""
+    if presplit() and K % 8 == 0 and w.data_ptr() % 16 == 0:
         hl, scale = split_weight(w)
-        return dict(prec=1, B_hl=_p(hl), b_scale=scale)
-    return dict(prec=_PREC[PRECISION])
+        return dict(prec=_PREC[PRECISION], B_hl=_p(hl), b_scale=scale)
+    return dict(prec=_fly_prec())
+
+
+def _fly_prec():
+    """Arithmetic of the kernels that take fp32 operands (tiny / unaligned layers, batched products): exact fp32 MFMA, or the
+    f16x3 split on the fly — also in "f16" mode, whose single-term kernels exist for pre-split operands only."""
+    return 0 if PRECISION == "f32" else 1
+
+
+def _fly_args(wargs):
+    """`wargs` for a launch whose A operand is NOT pre-split: the on-the-fly kernels read fp32 weights (f16 mode: the h-format
+    weights cannot be used there) or hl weights (f16x3)."""
+    if PRECISION == "f16":
+        return dict(prec=1)
+    return wargs
 
 
 def _p(t):
@@ -180,7 +219,7 @@ def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, 
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
         ret, ldc, sargs = out, N, {}
     _run(_desc(A=_p(x), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual), M=M, N=N, K=K,
-               lda=x.stride(0), ldb=K, ldc=ldc, act=ACT[act], relu_in=int(relu_in), **wargs))
+               lda=x.stride(0), ldb=K, ldc=ldc, act=ACT[act], relu_in=int(relu_in), **_fly_args(wargs)))
     return ret
 
 
@@ -209,7 +248,7 @@ def bmm_nt(a, b, alpha=1.0, out=None):
         out = torch.empty(Z0, Z1, M, N, dtype=torch.float32, device=a.device)
     _run(_desc(A=_p(a), B=_p(b), C=_p(out), M=M, N=N, K=K, lda=a.stride(2), ldb=b.stride(2), ldc=out.stride(2),
                batch0=Z0, batch1=Z1, a_bs0=a.stride(0), a_bs1=a.stride(1), b_bs0=b.stride(0), b_bs1=b.stride(1),
-               c_bs0=out.stride(0), c_bs1=out.stride(1), alpha=float(alpha), prec=_PREC[PRECISION]))
+               c_bs0=out.stride(0), c_bs1=out.stride(1), alpha=float(alpha), prec=_fly_prec()))
     return out
 
 
@@ -220,7 +259,7 @@ def bmm_nn(a, b, out):
     assert a.stride(3) == 1 and b.stride(3) == 1 and out.stride(3) == 1
     _run(_desc(A=_p(a), B=_p(b), C=_p(out), M=M, N=N, K=K, lda=a.stride(2), ldb=b.stride(2), ldc=out.stride(2), b_kn=1,
                batch0=Z0, batch1=Z1, a_bs0=a.stride(0), a_bs1=a.stride(1), b_bs0=b.stride(0), b_bs1=b.stride(1),
-               c_bs0=out.stride(0), c_bs1=out.stride(1), prec=_PREC[PRECISION]))
+               c_bs0=out.stride(0), c_bs1=out.stride(1), prec=_fly_prec()))
     return out
 
 
@@ -284,7 +323,7 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     Ho = (H + 2 * pad - ksize) // stride + 1
     Wo = (W + 2 * pad - ksize) // stride + 1
     dev = xs.device if xs is not None else x.device
-    if (xs is not None and Cout <= 2 and ksize in (1, 3) and stride == 1 and pad == ksize // 2 and act is None and out is None
+    if (xs is not None and xs.terms == 2 and Cout <= 2 and ksize in (1, 3) and stride == 1 and pad == ksize // 2 and act is None and out is None
             and not out_split and also_split is None and hl_into is None and residual2 is None and Cx % 32 == 0 and W in (16, 32, 64)
             and H % (256 // W) == 0 and wp.dtype == torch.float32 and wp.is_contiguous()
             and (residual is None or (residual.is_contiguous() and tuple(residual.shape) == (B, H, W, Cout)))
@@ -312,8 +351,8 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
         _run(_desc(A_hl=_p(hl), B=_p(wp), C=_p(out), bias=_p(bias), conv_bstride=H * W * cin, M=B * Ho * Wo, N=Cout,
                    K=ksize * ksize * cin, lda=cin, ldb=wp.shape[1], ldc=ldc, act=ACT[act], conv_kh=ksize, conv_kw=ksize,
                    conv_cin=cin, conv_stride=stride, conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo,
-                   C_hl=tgt.hl.data_ptr() + 4 * col0, ldc_h=ctot, c_relu=int(split_relu), **wargs),
-             written=Split(tgt.hl[:, 2 * col0:2 * (col0 + Cout)]) if CHECK_SATURATION else None)
+                   C_hl=tgt.col_ptr(col0), ldc_h=ctot, c_relu=int(split_relu), **wargs),
+             written=Split(tgt.cols(col0, Cout), tgt.terms) if CHECK_SATURATION else None)
         return out
     if out_split and out is None and presplit and _split_ok(Cout) and residual is None and residual2 is None:
         ret = Split.empty(B * Ho * Wo, Cout, dev)
@@ -348,7 +387,7 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
                conv_bstride=x.stride(0), M=B * Ho * Wo, N=Cout,
                K=ksize * ksize * cin, lda=ld_in, ldb=wp.shape[1], ldc=ldc, act=ACT[act], relu_in=int(relu_in),
                conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride, conv_pad=pad, conv_h=H, conv_w=W,
-               conv_ho=Ho, conv_wo=Wo, **wargs))
+               conv_ho=Ho, conv_wo=Wo, **_fly_args(wargs)))
     return ret
 
 
@@ -381,7 +420,7 @@ def conv_transpose2d(x, wp, bias_tiled, r, out_split=False):
         return out
     out = torch.empty(B, H * r, W * r, Cout, dtype=torch.float32, device=x.device)
     _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias_tiled), M=B * H * W, N=r * r * Cout, K=Cin, lda=Cin, ldb=Cin,
-               ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W, **wargs))
+               ldc=Cout, shuffle_r=r, shuffle_h=H, shuffle_w=W, **_fly_args(wargs)))
     return out
 
 
@@ -396,11 +435,13 @@ def attention(qkv, B, T, heads, hd, out_split=False):
     else:
         out = torch.empty(B * T, heads * hd, dtype=torch.float32, device=dev)
     if isinstance(qkv, Split):
-        _lib.check(_lib.lib().pp_attention_hl(_p(qkv.hl), B, T, heads, hd, float(hd) ** -0.5, _p(out),
-                                              _p(sp.hl) if sp else None, _lib.stream_ptr()), "pp_attention_hl")
+        _lib.check(_lib.lib().pp_attention_t(_p(qkv.hl), qkv.terms, B, T, heads, hd, float(hd) ** -0.5, _p(out),
+                                             _p(sp.hl) if sp else None, _lib.stream_ptr()), "pp_attention_t")
     else:
         assert qkv.is_contiguous()
-        _lib.check(_lib.lib().pp_attention_ex(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, _PREC[PRECISION], _p(out),
+        if sp is not None and sp.terms == 1:    # (f16 mode with an fp32 qkv: the fp32-input kernel writes hl operands only)
+            sp, out = None, torch.empty(B * T, heads * hd, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().pp_attention_ex(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, _fly_prec(), _p(out),
                                               _p(sp.hl) if sp else None, _lib.stream_ptr()), "pp_attention_ex")
     if sp is not None:
         _chk(sp.hl, "pp_attention")
@@ -413,9 +454,9 @@ def layernorm(x, weight, bias, eps, out_split=False):
     assert x.is_contiguous()
     if out_split and _split_ok(C):
         sp = Split.empty(rows, C, x.device)
-        _lib.check(_lib.lib().pp_layernorm_split(_p(x), _p(weight), _p(bias), rows, C, float(eps), None, _p(sp.hl),
-                                                 _lib.stream_ptr()), "pp_layernorm_split")
-        _chk(sp.hl, "pp_layernorm_split")
+        _lib.check(_lib.lib().pp_layernorm_t(_p(x), _p(weight), _p(bias), rows, C, float(eps), None, _p(sp.hl), sp.terms,
+                                             _lib.stream_ptr()), "pp_layernorm_t")
+        _chk(sp.hl, "pp_layernorm_t")
         return sp
     y = torch.empty_like(x)
     _lib.check(_lib.lib().pp_layernorm(_p(x), _p(weight), _p(bias), rows, C, float(eps), _p(y), _lib.stream_ptr()),
@@ -490,9 +531,9 @@ def resize_bilinear(x, Ho, Wo, mul=1.0, out_split=False):
     if out_split and _split_ok(C) and x.data_ptr() % 16 == 0:
         sp = Split.empty(B * Ho * Wo, C, x.device)
         sp.image = (B, Ho, Wo)
-        _lib.check(_lib.lib().pp_resize_bilinear_nhwc_hl(_p(x), B, H, W, C, Ho, Wo, float(mul), _p(sp.hl), _lib.stream_ptr()),
-                   "pp_resize_bilinear_nhwc_hl")
-        _chk(sp.hl, "pp_resize_bilinear_nhwc_hl")
+        _lib.check(_lib.lib().pp_resize_bilinear_nhwc_t(_p(x), B, H, W, C, Ho, Wo, float(mul), _p(sp.hl), sp.terms, _lib.stream_ptr()),
+                   "pp_resize_bilinear_nhwc_t")
+        _chk(sp.hl, "pp_resize_bilinear_nhwc_t")
         return sp
     out = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().pp_resize_bilinear_nhwc(_p(x), B, H, W, C, Ho, Wo, float(mul), _p(out), _lib.stream_ptr()),
@@ -512,10 +553,10 @@ def warp(feat, flow, out=None, hl_into=None):
         tgt, col0 = hl_into
         ctot = tgt.shape[1]
         assert tgt.shape[0] == B * H * W and col0 % 8 == 0 and col0 + C <= ctot and C % 8 == 0
-        _lib.check(_lib.lib().pp_warp_nhwc_hl(_p(feat), Bf, _p(flow), B, H, W, C, flow.stride(2), tgt.hl.data_ptr() + 4 * col0,
-                                              ctot, _lib.stream_ptr()), "pp_warp_nhwc_hl")
+        _lib.check(_lib.lib().pp_warp_nhwc_t(_p(feat), Bf, _p(flow), B, H, W, C, flow.stride(2), tgt.col_ptr(col0),
+                                             ctot, tgt.terms, _lib.stream_ptr()), "pp_warp_nhwc_t")
         if CHECK_SATURATION:
-            _chk(tgt.hl[:, 2 * col0:2 * (col0 + C)], "pp_warp_nhwc_hl")
+            _chk(tgt.cols(col0, C), "pp_warp_nhwc_t")
         return None
     if out is None:
         out = torch.empty(B, H, W, C, dtype=torch.float32, device=feat.device)
@@ -547,7 +588,7 @@ def corr_lookup(f1, f2, flow, levels, radius, c_pad=None, f1_hl=None, f2_hl=None
     n = levels * (2 * radius + 1) ** 2
     np_ = c_pad if c_pad and c_pad > n else n
     out = (torch.zeros if np_ > n else torch.empty)(B, H, W, np_, dtype=torch.float32, device=f1.device)
-    if (f1_hl is not None and f2_hl is not None and PRECISION == "f16x3" and H % 8 == 0 and W % 8 == 0 and C % 32 == 0
+    if (f1_hl is not None and f2_hl is not None and PRECISION == "f16x3" and f2_hl.terms == 2 and H % 8 == 0 and W % 8 == 0 and C % 32 == 0
             and os.environ.get("PP_CORR_TILED", "1") != "0" and os.environ.get("PP_CORR_HL", "1") != "0"):
         tgt, col0 = f1_hl
         assert tgt.shape[0] == B * H * W and col0 % 8 == 0 and col0 + C <= tgt.shape[1] and f2_hl.shape == (f2.shape[0] * H * W, C)
@@ -558,7 +599,7 @@ def corr_lookup(f1, f2, flow, levels, radius, c_pad=None, f1_hl=None, f2_hl=None
         return out
     _lib.check(_lib.lib().pp_corr_lookup_nhwc_ex(_p(f1), f1.stride(2), _p(pyr[0]), _p(pyr[1]) if levels > 1 else None,
                                                  _p(pyr[2]) if levels > 2 else None, f2.shape[0], _p(flow), B, H, W, C,
-                                                 levels, radius, flow.stride(2), _PREC[PRECISION], _p(out), np_,
+                                                 levels, radius, flow.stride(2), _fly_prec(), _p(out), np_,
                                                  _lib.stream_ptr()), "pp_corr_lookup_nhwc_ex")
     return out
 
