@@ -131,10 +131,10 @@ def seeded_weights(net, seed, vit):
     return sd
 
 
-def dome_points(K, M, device, size=64, crop=224, z0=0.8, relief=0.05, radius=0.4):
-    """(size,size,3) template-camera-frame points of a shallow dome seen through crop affine M with intrinsics K: a
-    geometrically consistent synthetic object, so that the key-points of stage 3 describe a pose PnP/RANSAC can find
-    (a crop-to-crop similarity of a near-planar object is a rigid motion).  Same construction as tests/netcfg.py."""
+def dome_points(K, M, device, size=64, crop=224, z0=0.8, relief=0.08, radius=0.4):
+    """(size,size,3) template-camera-frame points of a dome (8 cm of relief on a 17 cm wide object at 0.8 m) seen through crop
+    affine M with intrinsics K: a geometrically consistent synthetic object, so that the key-points of stage 3 describe a pose
+    PnP/RANSAC can find.  Same construction as tests/netcfg.py (DOME_M, DOME_RELIEF)."""
     c = torch.arange(size, dtype=torch.float32, device=device) * (crop / size) + crop / (2 * size)
     cy, cx = torch.meshgrid(c, c, indexing="ij")
     u, v = (cx - M[0, 2]) / M[0, 0], (cy - M[1, 2]) / M[1, 1]
@@ -145,14 +145,17 @@ def dome_points(K, M, device, size=64, crop=224, z0=0.8, relief=0.05, radius=0.4
 
 def make_end_points(B, N, device, seed):
     """Synthetic eval inputs of SURVEY.md §8(d), generated on the device (N(0,1) crops/templates, disk masks, BOP K).
-    One deviation from §8(d): `tem_pts3d` is the dome of dome_points() instead of U(-0.1, 0.1) noise — random 3-D
-    points admit no pose, and the PnP/RANSAC leg of the step must do the work it does on real data."""
+    Deviations from §8(d), all for the PnP/RANSAC leg to do the work it does on real data: `tem_pts3d` is the dome of
+    dome_points() instead of U(-0.1, 0.1) noise (random 3-D points admit no pose), both crop affines are centred on the
+    principal point at scale 2 and the template mask is full (tests/netcfg.make_end_points explains why)."""
     g = torch.Generator(device=device).manual_seed(seed)
     K = torch.tensor([[572.4114, 0, 320], [0, 573.57043, 240], [0, 0, 1.0]], device=device)
-    tem_M = torch.tensor([[1.5, 0, -300.0], [0, 1.5, -200.0], [0, 0, 1.0]], device=device)
+    # both crops: scale 2, centred on the principal point (tests/netcfg.DOME_M): the object sits on the optical axis, so the
+    # crop-to-crop similarity stage 2 predicts is a rigid motion for any relief (up to sub-pixel parallax)
+    M = torch.tensor([[2.0, 0, 112.0 - 640.0], [0, 2.0, 112.0 - 480.0], [0, 0, 1.0]], device=device)
     c = torch.arange(64, device=device).float() * 3.5 + 1.75
-    gy, gx = torch.meshgrid(c, c, indexing="ij")
-    pts = (torch.stack([gx, gy], dim=-1) - torch.tensor([-100.0, -80.0], device=device)) / 2.0
+    cx, cy = torch.meshgrid(c, c, indexing="ij")     # the dataset's layout: entry [i][j] = image point of crop pixel (x = c[i], y = c[j])
+    pts = (torch.stack([cx, cy], dim=-1) - M[:2, 2]) / M[0, 0]
     ang = torch.rand(B, N, generator=g, device=device) * 6.2831853
     pose = torch.eye(4, device=device)[None, None].repeat(B, N, 1, 1)
     pose[..., 0, 0], pose[..., 0, 1], pose[..., 1, 0], pose[..., 1, 1] = ang.cos(), -ang.sin(), ang.sin(), ang.cos()
@@ -160,12 +163,14 @@ def make_end_points(B, N, device, seed):
     return {
         "real_rgb": torch.randn(B, 3, 224, 224, device=device, generator=g),
         "real_mask": disk_mask(B, device), "real_K": K[None].repeat(B, 1, 1),
-        "real_M": torch.tensor([[2.0, 0, -100.0], [0, 2.0, -80.0], [0, 0, 1.0]], device=device)[None].repeat(B, 1, 1),
+        "real_M": M[None].repeat(B, 1, 1),
         "real_pose": torch.eye(4, device=device)[None].repeat(B, 1, 1), "real_pts2d": pts[None].repeat(B, 1, 1, 1),
         "tem_rgb": torch.randn(B, N, 3, 224, 224, device=device, generator=g),
-        "tem_mask": disk_mask(1, device)[None].repeat(B, N, 1, 1),
-        "tem_pts3d": dome_points(K, tem_M, device)[None, None].repeat(B, N, 1, 1, 1), "tem_pose": pose,
-        "tem_K": K[None, None].repeat(B, N, 1, 1), "tem_M": tem_M[None, None].repeat(B, N, 1, 1),
+        # (the object fills the template crop: a disk mask would put half of the valid key-points into the band where the
+        # up-sampled masked init flow is garbage — tests/netcfg.make_end_points)
+        "tem_mask": torch.ones(B, N, 224, 224, device=device),
+        "tem_pts3d": dome_points(K, M, device)[None, None].repeat(B, N, 1, 1, 1), "tem_pose": pose,
+        "tem_K": K[None, None].repeat(B, N, 1, 1), "tem_M": M[None, None].repeat(B, N, 1, 1),
     }
 
 

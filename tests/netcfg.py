@@ -17,11 +17,17 @@ HEADS = 6
 TAKE = [2, 5, 8, 11]
 
 
-def dome_points(K, M, size=64, crop=224, z0=0.8, relief=0.05, radius=0.4):
-    """Template-camera-frame 3-D points of a shallow dome seen through the crop affine M (crop px = M . image px) with
-    intrinsics K: the 64x64 lookup map `tem_pts3d` of a geometrically consistent synthetic object.  A similarity
-    between template crop and query crop is then (up to the dome's small parallax) a rigid motion, so the key-point
-    lists of stage 3 give PnP/RANSAC a pose to find.  K, M: (3,3) tensors -> (size, size, 3)."""
+# The geometrically consistent synthetic object (dome=True): crop affine of BOTH views (scale 2, centred on the principal point —
+# the object sits on the optical axis, so the crop-to-crop similarity stage 2 predicts is a rotation about the axis / a small
+# depth change / a small shift: a rigid motion for ANY relief, up to sub-pixel parallax) and the dome's relief in metres.
+DOME_M = [[2.0, 0.0, 112.0 - 2.0 * 320.0], [0.0, 2.0, 112.0 - 2.0 * 240.0], [0.0, 0.0, 1.0]]
+DOME_RELIEF = 0.08
+
+
+def dome_points(K, M, size=64, crop=224, z0=0.8, relief=DOME_RELIEF, radius=0.4):
+    """Template-camera-frame 3-D points of a dome (8 cm of relief on a 17 cm wide object at 0.8 m) seen through the crop affine M
+    (crop px = M . image px) with intrinsics K: the 64x64 lookup map `tem_pts3d` of a geometrically consistent synthetic
+    object, so the key-point lists of stage 3 give PnP/RANSAC a pose to find.  K, M: (3,3) tensors -> (size, size, 3)."""
     import torch
 
     c = torch.arange(size, dtype=torch.float32) * (crop / size) + crop / (2 * size)
@@ -46,18 +52,26 @@ def make_end_points(B, N, seed, feature_fn=None, tem_pose=None, dome=False):
     ep["real_rgb"] = torch.randn(B, 3, 224, 224, generator=g)
     ep["real_mask"] = disk[None].repeat(B, 1, 1)
     ep["real_K"] = K[None].repeat(B, 1, 1)
-    ep["real_M"] = torch.tensor([[2.0, 0, -100.0], [0, 2.0, -80.0], [0, 0, 1.0]])[None].repeat(B, 1, 1)
+    real_M = torch.tensor(DOME_M) if dome else torch.tensor([[2.0, 0, -100.0], [0, 2.0, -80.0], [0, 0, 1.0]])
+    ep["real_M"] = real_M[None].repeat(B, 1, 1)
     ep["real_pose"] = torch.eye(4)[None].repeat(B, 1, 1)
     c = torch.arange(64).float() * 3.5 + 1.75                      # 64x64 lookup grid of the 224 crop
-    gy, gx = torch.meshgrid(c, c, indexing="ij")
-    pts = torch.stack([gx, gy], dim=-1)                             # (64,64,2) crop pixels (x,y)
-    ep["real_pts2d"] = ((pts - torch.tensor([-100.0, -80.0])) / 2.0)[None].repeat(B, 1, 1, 1)  # inv(real_M) applied
+    # the dataset's layout (provider/bop_test_dataset.py:192-196 with utils/torch_utils.py:287-295): entry [i][j] is the image
+    # point of crop pixel (x = c[i], y = c[j]) — FIRST index = x; model/picopose.py:75 transposes it back for the lookup.
+    # (Rounds 1-2 filled it [y][x]: the 2-D side of every PnP problem was mirrored about the diagonal, which no rigid motion of
+    # an object with relief explains — the inlier ratios of 0.3-0.5 and the solver-dependent RANSAC winners came from that.)
+    cx, cy = torch.meshgrid(c, c, indexing="ij")                    # cx[i][j] = c[i], cy[i][j] = c[j]
+    pts = torch.stack([cx, cy], dim=-1)
+    ep["real_pts2d"] = ((pts - real_M[:2, 2]) / real_M[0, 0])[None].repeat(B, 1, 1, 1)         # inv(real_M) applied
     ep["tem_rgb"] = torch.randn(B, N, 3, 224, 224, generator=g)
     ep["tem_mask"] = disk[None, None].repeat(B, N, 1, 1)
     ep["tem_pts3d"] = (torch.rand(B, N, 64, 64, 3, generator=g) - 0.5) * 0.2
     if dome:   # (the random map above is still drawn, so both variants share every other tensor of a seed)
-        tem_M = torch.tensor([[1.5, 0, -300.0], [0, 1.5, -200.0], [0, 0, 1.0]])
-        ep["tem_pts3d"] = dome_points(K, tem_M)[None, None].repeat(B, N, 1, 1, 1)
+        ep["tem_pts3d"] = dome_points(K, torch.tensor(DOME_M))[None, None].repeat(B, N, 1, 1, 1)
+        # the object fills the template crop: with a disk mask the bilinear up-sampling of the masked init flow (0 outside
+        # the mask -> flow = -grid index) bleeds tens of cells of garbage into a band around the mask that holds half of the
+        # valid key-points — a trained certainty head suppresses that band, random weights do not
+        ep["tem_mask"] = torch.ones(B, N, 224, 224)
     q, _ = torch.linalg.qr(torch.randn(B, N, 3, 3, generator=g))
     q = q * torch.sign(torch.det(q))[..., None, None]
     pose = torch.eye(4)[None, None].repeat(B, N, 1, 1)
@@ -66,7 +80,8 @@ def make_end_points(B, N, seed, feature_fn=None, tem_pose=None, dome=False):
     # LAPACK's QR is not bit-reproducible across hosts: fixtures carry the poses they were generated with
     ep["tem_pose"] = pose if tem_pose is None else tem_pose
     ep["tem_K"] = K[None, None].repeat(B, N, 1, 1)
-    ep["tem_M"] = torch.tensor([[1.5, 0, -300.0], [0, 1.5, -200.0], [0, 0, 1.0]])[None, None].repeat(B, N, 1, 1)
+    tem_M = torch.tensor(DOME_M) if dome else torch.tensor([[1.5, 0, -300.0], [0, 1.5, -200.0], [0, 0, 1.0]])
+    ep["tem_M"] = tem_M[None, None].repeat(B, N, 1, 1)
     if feature_fn is not None:
         ep["template_feature"] = torch.stack([feature_fn(ep["tem_rgb"][b])[-1] for b in range(B)])
     return ep

@@ -72,7 +72,7 @@ def main():
     # ---- end to end, calibrated ViT-B (tests/golden/e2e_calibrated.npz): the discrete outputs
     import test_e2e as te
 
-    zz, B, N, hyp, ref, ep, dev, outs, flow, cert = te._hip_calibrated_forward(G, "vitb_b1n3")
+    zz, B, N, hyp, ref, ep, dev, outs, flow, cert = te._hip_calibrated_forward(G, "vitb_b2n6")
     same_t = all(np.array_equal(outs[h]["tem_pose"].cpu().numpy(), ref[h]["tem_pose"]) for h in range(hyp))
     slots = [float((outs[h]["pred_tar_pts"].cpu().numpy() == ref[h]["pred_tar_pts"]).all(-1).mean()) for h in range(hyp)]
     out["e2e_vitb"] = {"same_templates": bool(same_t), "pred_poses_max_abs": max(float(np.abs(outs[h]["pred_poses"].cpu().numpy() - ref[h]["pred_poses"]).max()) for h in range(hyp)),

@@ -24,10 +24,12 @@ def _load(golden_dir, tag):
     return z, B, N, hyp, seed, wseed, ref
 
 
-def _keypoint_mismatch_is_explained(got_tar, got_src, ref_tar, ref_src, flow, cert, rel=5e-4):
+def _keypoint_mismatch_is_explained(got_tar, got_src, ref_tar, ref_src, flow, cert, rel=2e-5):
     """Keypoint lists are discontinuous in (flow, logit): entries may differ only where the oracle's logit is
     within the float tolerance of 0 or a target coordinate is within it of an integer / of the bounds.  The
-    tolerance is the one stated for the offset tensors: rel * max|tensor| (tests/test_nets_gpu.py)."""
+    tolerance is rel * max(1, max|tensor|) with rel = 2e-5 — about ten times the deviation measured between the engine's two
+    arithmetic modes on the bench inputs (flow <= 7e-5 px at max|flow| 60, logits <= 5e-5: bench.py exact_mode) — instead of
+    round 2's 5e-4, which declared 12 % of all slots "fragile"."""
     bad = (got_tar != ref_tar).any(-1) | (got_src != ref_src).any(-1)       # (B, H*W), k = w*H + h
     if not bad.any():
         return 0
@@ -89,8 +91,10 @@ def test_hip_forward_vs_reference(golden_dir, tag):
         assert np.array_equal(o["tem_pose"], ref[h]["tem_pose"])                        # template ids: exact
         assert np.array_equal(o["tar_pts_2d"], ref[h]["tar_pts_2d"]) and np.array_equal(o["src_pts_3d"], ref[h]["src_pts_3d"])
         assert np.abs(o["pred_poses"] - ref[h]["pred_poses"]).max() <= 1e-4             # north_star tolerance
+        # (plain random weights: flows of +-1500 px and logits of +-100 — fp32 reassociation alone moves them by 1e-4 of that;
+        # the calibrated fixtures below carry the tight bar)
         total_bad += _keypoint_mismatch_is_explained(o["pred_tar_pts"], o["pred_src_pts"], ref[h]["pred_tar_pts"],
-                                                     ref[h]["pred_src_pts"], aux["flow"][h].numpy(), aux["cert"][h].numpy())
+                                                     ref[h]["pred_src_pts"], aux["flow"][h].numpy(), aux["cert"][h].numpy(), rel=5e-4)
     assert total_bad <= 0.002 * hyp * B * 4096
 
 
@@ -158,7 +162,7 @@ def test_infer_image_walks_instances_like_run_test():
 
 
 # ---- calibrated heads + dome geometry: the network -> key-points -> PnP chain on realistic occupancy ---------------------
-CAL_CASES = ["vits_b2n4", "vitb_b1n3", "vitl_b1n2"]   # the last: ViT-L/14, the backbone of configs[4] / config/base.yaml
+CAL_CASES = ["vits_b2n4", "vitb_b2n6", "vitl_b2n4"]   # the last: ViT-L/14, the backbone of configs[4] / config/base.yaml
 VIT_CFG = {"dinov2_vits14": (384, 6, [[0, 2], [3, 5], [6, 8], [9, 11]]), "dinov2_vitb14": (768, 12, [[0, 2], [3, 5], [6, 8], [9, 11]]),
            "dinov2_vitl14": (1024, 16, [[0, 5], [6, 11], [12, 17], [18, 23]])}
 
@@ -269,18 +273,18 @@ def test_hip_forward_vs_reference_calibrated(golden_dir, tag):
     _check_hip_vs_reference(z, tag, B, hyp, ref, outs, flow, cert)
     rot, tvec, ratio, ok, npts = pnp_for_outputs(outs, dev["real_K"], return_npts=True)
     assert npts.min() >= 1000 and ok.all()
-    # (a) like for like: the HIP PnP kernel fed with the REFERENCE's key-point lists against the CPU oracle of PnP/RANSAC
-    # on the same lists (same sampling sequence, problem id h*B+b).  A 5-point sample leaves M^T M with a 2-dimensional
-    # null space whose basis is the eigensolver's choice; with solver="kernel" the oracle resolves it by the kernel's own
-    # Jacobi sequence restated in numpy (with LAPACK's basis some of the 150 hypotheses differ, and on these shallow,
-    # grid-quantised correspondences so does the winner): consensus within 3 points, t within 2 mm, R within 1e-2 (the tilt of a shallow dome moves with a single inlier);
-    # (b) the chain: PnP on the HIP net's own lists (a few threshold slots differ, so the sample indices address other
-    # points): a consensus of the same size.
-    from picopose_amd.utils.pose_recovery import pose_recovery_ransac_pnp_batched
-
+    # (a) like for like: the HIP PnP kernel fed with the REFERENCE's key-point lists against the CPU oracle of PnP/RANSAC on the
+    # same lists (same sampling sequence, problem id h*B+b) in its solver-INDEPENDENT form: solver="lapack" (eigh / svd / lstsq —
+    # nothing of the kernel's Jacobi sequences).  On the round-3 synthetic object (8 cm of relief on the optical axis, the
+    # dataset's layout of real_pts2d, tests/netcfg.py) nearly every correspondence is an inlier of the true motion, so the
+    # RANSAC winner does not depend on how a 5-point sample's 2-dimensional null space is resolved: consensus within 1 % of the
+    # points (measured: identical), t within 5 mm, R within 1.5e-2 (measured <= 3.2 mm / 6.8e-3: the scatter of EPnP's own choice between
+    # its null-space solutions on the refit, profiles/r03/pnp_e2e_agreement.txt);
+    # (b) the chain: PnP on the HIP net's own lists (a few threshold slots may differ): the same consensus within 2 %.
     ref_outs = [dict(outs[h], pred_tar_pts=torch.from_numpy(ref[h]["pred_tar_pts"]).cuda(),
                      pred_src_pts=torch.from_numpy(ref[h]["pred_src_pts"]).cuda()) for h in range(hyp)]
     rrot, rtvec, rratio, rok, rnpts = pnp_for_outputs(ref_outs, dev["real_K"], return_npts=True)
+    worst = [0.0, 0.0, 0.0]
     for h in range(hyp):
         for b in range(B):
             t2 = ep["real_pts2d"][b].permute(2, 1, 0).numpy()
@@ -288,14 +292,19 @@ def test_hip_forward_vs_reference_calibrated(golden_dir, tag):
             s3 = ep["tem_pts3d"][b, sel].permute(2, 0, 1).numpy()
             orot, otvec, oratio, ook = opnp.pose_recovery_ransac_pnp(t2, s3, ep["real_K"][b].numpy(), ref[h]["tem_pose"][b],
                                                                      ref[h]["pred_tar_pts"][b], ref[h]["pred_src_pts"][b], prob=h * B + b,
-                                                                     solver="kernel")
+                                                                     solver="lapack")
             n = int(rnpts[h, b])
             assert ook and rok[h, b] and n == int(_valid(ref[h]["pred_tar_pts"][b:b + 1])[0])
-            assert abs(oratio - rratio[h, b]) * n <= 3, (h, b, oratio * n, rratio[h, b] * n)
-            assert np.abs(otvec - rtvec[h, b]).max() < 2e-3 and np.abs(orot - rrot[h, b]).max() < 1e-2, (h, b, otvec.ravel(), rtvec[h, b].ravel())
-            assert abs(ratio[h, b] - rratio[h, b]) < 0.1
-            # and it is the pose stage 2 predicted, refined (the dome is consistent with the affine): same ballpark
-            assert np.abs(tvec[h, b, :, 0] - ref[h]["pred_poses"][b, :3, 3]).max() < 0.15
+            worst = [max(worst[0], abs(oratio - rratio[h, b])), max(worst[1], float(np.abs(otvec - rtvec[h, b]).max())),
+                     max(worst[2], float(np.abs(orot - rrot[h, b]).max()))]
+            assert rratio[h, b] > 0.8, (h, b, rratio[h, b])
+            assert abs(oratio - rratio[h, b]) <= 0.01, (h, b, oratio * n, rratio[h, b] * n)
+            assert np.abs(otvec - rtvec[h, b]).max() < 5e-3 and np.abs(orot - rrot[h, b]).max() < 1.5e-2, (h, b, otvec.ravel(), rtvec[h, b].ravel())
+            assert abs(ratio[h, b] - rratio[h, b]) < 0.02
+            # and it is the pose stage 2 predicted, refined: same ballpark
+            assert np.abs(tvec[h, b, :, 0] - ref[h]["pred_poses"][b, :3, 3]).max() < 0.05
+    print(f"PnP {tag}: HIP kernel vs solver-independent oracle on the reference's key-points: max |consensus ratio diff| {worst[0]:.4f}, "
+          f"max |dt| {worst[1]:.2e} m, max |dR| {worst[2]:.2e}; inlier ratios {rratio.min():.3f}..{rratio.max():.3f}")
 
 
 @gpu
@@ -314,7 +323,7 @@ def test_hip_forward_vs_reference_calibrated_exact_mode(golden_dir, tag):
 
 
 @gpu
-@pytest.mark.parametrize("tag", ["vits_b2n4", "vitb_b1n3", "vitl_b1n2"])
+@pytest.mark.parametrize("tag", ["vits_b2n4", "vitb_b2n6", "vitl_b2n4"])
 def test_hip_forward_vs_reference_calibrated_f16_mode(golden_dir, tag):
     """`ops.PRECISION = "f16"` (bench.py --mode fp16): plain fp16 operands, ONE MFMA per product, fp32 accumulation — the
     arithmetic BASELINE configs[4] names (ViT-L/14 "fp16").  Operands carry 11 bits instead of the f16x3 engine's 22, so the
@@ -352,8 +361,8 @@ def test_hip_forward_vitb_with_pinned_persistent_kernels(golden_dir, monkeypatch
     256x256 (cfg 5), row-shared 3x3 (cfg 6) and two- / three-workgroups-per-CU (cfg 7 / 8, dense layers) kernels — the kernels the
     headline bench runs — instead of the autotuner's pick."""
     monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
-    z, B, N, hyp, ref, ep, dev, outs, flow, cert = _hip_calibrated_forward(golden_dir, "vitb_b1n3")
-    _check_hip_vs_reference(z, "vitb_b1n3", B, hyp, ref, outs, flow, cert)
+    z, B, N, hyp, ref, ep, dev, outs, flow, cert = _hip_calibrated_forward(golden_dir, "vitb_b2n6")
+    _check_hip_vs_reference(z, "vitb_b2n6", B, hyp, ref, outs, flow, cert)
 
 
 @gpu
