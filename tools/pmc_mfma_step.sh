@@ -20,11 +20,11 @@ for r in rows:
     if not (lo <= int(r["Dispatch_Id"]) < hi):
         continue
     n = r["Kernel_Name"]
-    n = re.sub(r"\(.*", "", n.replace("void ", "").replace("(anonymous namespace)::", ""))[:44]
+    n = re.sub(r"\(.*", "", n.replace("void ", "").replace("(anonymous namespace)::", ""))[:64]
     agg[n][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "GRBM_GUI_ACTIVE": cnt[n] += 1
 print(f"ONE timed step of bench.py (default workload), dispatches {lo}..{hi - 1}")
-print(f"{'kernel':46s} {'launches':>8s} {'MFMA busy':>10s} {'share of GPU-active cycles':>27s}")
+print(f"{'kernel':66s} {'launches':>8s} {'MFMA busy':>10s} {'share of GPU-active cycles':>27s}")
 tot = sum(v["GRBM_GUI_ACTIVE"] for v in agg.values())
 tb = 0.0
 vit = [0.0, 0.0]
@@ -33,6 +33,6 @@ for n, v in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"]):
 for n, v in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])[:18]:
     act = v["GRBM_GUI_ACTIVE"] / 8 * 1024
     busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / act if act else 0.0
-    print(f"{n:46s} {cnt[n]:8d} {busy:10.3f} {v['GRBM_GUI_ACTIVE'] / tot:27.3f}")
+    print(f"{n:66s} {cnt[n]:8d} {busy:10.3f} {v['GRBM_GUI_ACTIVE'] / tot:27.3f}")
 print(f"whole step: MFMA busy {tb / (tot / 8 * 1024):.3f} of the SIMD cycles while a kernel is active")
 PY

@@ -19,12 +19,12 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows[lo:hi]:
         n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
-        n = re.sub(r"\(.*", "", n)[:48] if not n.startswith("_Z") else n[:48]
+        n = re.sub(r"\(.*", "", n)[:72] if not n.startswith("_Z") else n[:48]
         agg[n][0] += 1
         agg[n][1] += float(r["Counter_Value"]) * 1024 * (2 if cname == "FETCH_SIZE" else 1)
-    out[cname] = {k: {"launches": v[0], "bytes": v[1]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]}
+    out[cname] = {k: {"launches": v[0], "bytes": v[1]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]}
     out[cname + "_total_bytes"] = sum(v[1] for v in agg.values())
-gemm = [k for k in out["FETCH_SIZE"] if "gemm_f16x3" in k]
+gemm = [k for k in out["FETCH_SIZE"] if "pp_gemm_u" in k]   # the pre-split kernel, every instantiation
 out["gemm_f16x3_hbm_bytes_per_step"] = sum(out["FETCH_SIZE"][k]["bytes"] for k in gemm) + sum(
     out["WRITE_SIZE"].get(k, {"bytes": 0})["bytes"] for k in gemm)
 out["gemm_f16x3_launches_per_step"] = sum(out["FETCH_SIZE"][k]["launches"] for k in gemm)
