@@ -411,6 +411,37 @@ int pp_flow_loss_blocks(void);
 int pp_flow_loss_sums(const float* flow, const float* certainty, const float* tar_pts, int B, int H, int W, float max_flow,
                       double* partial_sums, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * First backward slice of the training path (utils/lite.py:33-49 -> loss.backward()): the row-wise /
+ * element-wise adjoints whose matrix products run on pp_gemm (picopose_amd/autograd.py: dgrad = dz W, wgrad = dz^T x).  Scope:
+ * InfoNCE (utils/loss_utils.py:144-175) -> the last ViT block (layers/block.py:82-107); the stage-2 losses (:177-186) -> the
+ * AffineRegressor (model/stage2/affine_regressor.py:72-84).  Deterministic (fixed-order reductions, no atomics); csrc/pp_backward.hip.
+ * ------------------------------------------------------------------------- */
+/* out[c] = sum_r x[r][c] over `rows` rows of ld floats (bias / LayerScale / norm-parameter gradients) */
+size_t pp_colsum_workspace_bytes(long long rows, int cols);
+int pp_colsum(const float* x, long long rows, int cols, int ld, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* y = act(z) and dz = dy * act'(z) for the PP_ACT_* activations (exact erf GELU, as nn.GELU) */
+int pp_act_forward(const float* z, long long n, int act, float* y, void* stream);
+int pp_act_backward(const float* z, const float* dy, long long n, int act, float* dz, void* stream);
+/* op 0: out = a * b; 1: out = a * b[col] (b a vector of `cols`); 2: out = a + b — n elements, rows of `cols` */
+int pp_elementwise(int op, const float* a, const float* b, long long n, int cols, float* out, void* stream);
+/* nn.LayerNorm backward: dx (rows, C) and gx = dy * xhat (dgamma = column sums of gx, dbeta = column sums of dy) */
+int pp_layernorm_backward(const float* x, const float* gamma, const float* dy, int rows, int C, float eps, float* dx, float* gx, void* stream);
+/* nn.GroupNorm(groups, C) (+ReLU when relu != 0) backward on NHWC (B, HW, C): dx, gx = d * xhat and gy = d with d = dy masked by the
+ * ReLU (dgamma / dbeta = their column sums) */
+int pp_groupnorm_backward_nhwc(const float* x, const float* gamma, const float* beta, const float* dy, int B, int HW, int C, int groups,
+                               float eps, int relu, float* dx, float* gx, float* gy, void* stream);
+/* softmax backward per row: ds = p * (dp - sum_j dp_j p_j) */
+int pp_softmax_backward_rows(const float* p, const float* dp, long long rows, int n, float* ds, void* stream);
+/* gradient of pp_xent_diag_rows's mean: dlogits[i][j] = upstream[0] * scale / n * (softmax_j(scale * logits[i]) - [i == j]) */
+int pp_xent_diag_backward(const float* logits, int n, int ld, float scale, const float* upstream, float* dlogits, void* stream);
+/* F.normalize backward for the rows x[index[i] * row_stride ...] (index NULL: row i): dx (rows, C) contiguous */
+int pp_normalize_rows_backward(const float* x, long long row_stride, const int64_t* index, const float* dq, int rows, int C, float eps,
+                               float* dx, void* stream);
+/* im2col of an NHWC image for a ksize x ksize / stride / pad convolution (k order (ky, kx, ci), as pack_conv_weight) and its adjoint */
+int pp_im2col_nhwc(const float* x, int B, int H, int W, int C, int ksize, int stride, int pad, float* col, void* stream);
+int pp_col2im_nhwc(const float* col, int B, int H, int W, int C, int ksize, int stride, int pad, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -614,9 +614,66 @@ def gen_train_forward_edge():
     gen_train_forward("train_forward_edge")
 
 
+GRAD_SAMPLES = 65536   # entries kept of a gradient tensor larger than this (evenly strided over the flattened tensor)
+
+
+def gen_train_grads():
+    """The reference's OWN gradients for the first backward slice (picopose_amd/autograd.py): `Net.forward_train` in train mode
+    under autograd on CPU (ViT-S, B = 2, the batch of train_forward.npz), then
+      * d(loss_2d_trans + loss_scale + loss_inplane) / d(every parameter of affine_regressor)   (utils/loss_utils.py:177-186),
+      * d(loss_info) / d(every parameter of the last ViT block)                                 (utils/loss_utils.py:144-175)
+    by torch.autograd.grad.  Tensors above GRAD_SAMPLES entries are stored as an evenly strided sample of the flattened gradient
+    plus its full L2 norm (affine_regressor.fc1.weight alone is 67 MB)."""
+    _ref()
+    sys.path.insert(0, os.path.join(REF, "model"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import ref_shims
+
+    ref_shims.install()
+    import picopose as ref_picopose
+
+    from oracle.weights import AFFINE_CALIBRATION, HEAD_CALIBRATION, PROJ_BN_GAIN, apply_head_calibration, seeded_state_dict
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from netcfg import make_train_end_points, train_case
+
+    B, seed, edit = train_case("train_forward")
+    vit, wseed = "dinov2_vits14", 4
+    net = ref_picopose.Net(_cfg(vit)).train()
+    cal = dict(HEAD_CALIBRATION[vit], affine=AFFINE_CALIBRATION, proj_bn=PROJ_BN_GAIN)
+    net.load_state_dict(apply_head_calibration(seeded_state_dict(net.state_dict(), wseed), cal))
+    ep = edit(make_train_end_points(B, seed))
+    np.random.seed(1000 + seed)
+    torch.manual_seed(2000 + seed)
+    res = net({k: v.clone() for k, v in ep.items()})
+    out = {"meta": np.array([B, seed, wseed], dtype=np.int64), "vit": np.array(vit)}
+    for k, v in _cal_arrays(cal).items():
+        out[k] = v
+    out["real_pose"], out["tem_pose"] = ep["real_pose"].numpy(), ep["tem_pose"].numpy()
+    for k in ("loss_info", "loss_2d_trans", "loss_scale", "loss_inplane"):
+        out[k] = res[k].detach().numpy()
+        print(k, float(res[k]))
+    groups = {"affine": ([(n, p) for n, p in net.named_parameters() if n.startswith("affine_regressor.")],
+                         res["loss_2d_trans"] + res["loss_scale"] + res["loss_inplane"]),
+              "vit_last": ([(n, p) for n, p in net.named_parameters() if n.startswith(f"feature_extractor.dinov2.blocks.{len(net.feature_extractor.dinov2.blocks) - 1}.")],
+                           res["loss_info"])}
+    for gname, (params, loss) in groups.items():
+        grads = torch.autograd.grad(loss, [p for _, p in params], retain_graph=True, allow_unused=True)
+        for (n, p), g in zip(params, grads):
+            g = torch.zeros_like(p) if g is None else g
+            flat = g.detach().reshape(-1)
+            stride = max(1, -(-flat.numel() // GRAD_SAMPLES))
+            out[f"grad/{n}"] = flat[::stride].numpy()
+            out[f"gradnorm/{n}"] = np.float64(flat.double().norm())
+            print(gname, n, tuple(p.shape), "stride", stride, "norm %.4g" % float(flat.double().norm()))
+    np.savez_compressed(os.path.join(OUT, "train_grads.npz"), **out)
+    print("training-gradient fixture written")
+
+
 GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry, "nets": gen_nets, "e2e": gen_e2e,
               "e2e_calibrated": gen_e2e_calibrated, "vit_wide": gen_vit_wide, "state_dict": gen_state_dict,
-              "preprocess": gen_preprocess, "run_test": gen_run_test, "train_forward": gen_train_forward, "train_forward_edge": gen_train_forward_edge, "e2e_calibrated_vitl": gen_e2e_calibrated_vitl}
+              "preprocess": gen_preprocess, "run_test": gen_run_test, "train_forward": gen_train_forward, "train_forward_edge": gen_train_forward_edge, "e2e_calibrated_vitl": gen_e2e_calibrated_vitl,
+              "train_grads": gen_train_grads}
 
 
 if __name__ == "__main__":

@@ -136,6 +136,20 @@ def lib():
         L.pp_xent_diag_rows.argtypes = [vp, i32, i32, f32, vp, vp]
         L.pp_flow_loss_blocks.argtypes = []
         L.pp_flow_loss_sums.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, vp]
+        ll = c.c_longlong
+        L.pp_colsum_workspace_bytes.restype = sz
+        L.pp_colsum_workspace_bytes.argtypes = [ll, i32]
+        L.pp_colsum.argtypes = [vp, ll, i32, i32, vp, vp, sz, vp]
+        L.pp_act_forward.argtypes = [vp, ll, i32, vp, vp]
+        L.pp_act_backward.argtypes = [vp, vp, ll, i32, vp, vp]
+        L.pp_elementwise.argtypes = [i32, vp, vp, ll, i32, vp, vp]
+        L.pp_layernorm_backward.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp]
+        L.pp_groupnorm_backward_nhwc.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp]
+        L.pp_softmax_backward_rows.argtypes = [vp, vp, ll, i32, vp, vp]
+        L.pp_xent_diag_backward.argtypes = [vp, i32, i32, f32, vp, vp, vp]
+        L.pp_normalize_rows_backward.argtypes = [vp, ll, vp, vp, i32, i32, f32, vp, vp]
+        L.pp_im2col_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+        L.pp_col2im_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
         _lib = L
     return _lib
 

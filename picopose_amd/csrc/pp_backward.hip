@@ -1,0 +1,350 @@
+// First backward slice of the training path (utils/lite.py:33-49 calls loss.backward() on the sum of the
+// `loss*` entries of model/picopose.py:114-137): the row-wise / element-wise pieces whose matrix products run on the GEMM engine
+// (picopose_amd/autograd.py: dgrad = dz W, wgrad = dz^T x as pp_gemm launches).  Everything here is deterministic: reductions
+// run in a fixed order (no atomics), so a gradient does not depend on the launch configuration.
+//   scope: InfoNCE (utils/loss_utils.py:144-175) -> the last ViT block (layers/block.py:82-107, attention.py:49-62, mlp.py:35-41,
+//   layer_scale.py:27-28, nn.LayerNorm) and the stage-2 losses (:177-186) -> AffineRegressor (model/stage2/affine_regressor.py).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "../../include/picopose_hip.h"
+#include "pp_common.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// out[c] = sum_r x[r][c] (x rows of ld floats), rows cut into gridDim.y slabs summed in slab order: part[slab][c]
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, long long rows, int cols, int ld, float* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const long long per = (rows + gridDim.y - 1) / gridDim.y, r0 = per * blockIdx.y, r1 = r0 + per < rows ? r0 + per : rows;
+    float s = 0.f;
+    for (long long r = r0; r < r1; ++r) s += x[r * ld + c];
+    part[(size_t)blockIdx.y * cols + c] = s;
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int slabs, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int k = 0; k < slabs; ++k) s += part[(size_t)k * cols + c];
+    out[c] = s;
+}
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    switch (act) {
+        case PP_ACT_RELU: return z > 0.f ? z : 0.f;
+        case PP_ACT_GELU: return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));
+        case PP_ACT_LEAKY01: return z > 0.f ? z : 0.1f * z;
+        case PP_ACT_TANH: return tanhf(z);
+        default: return z;
+    }
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+    switch (act) {
+        case PP_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case PP_ACT_GELU: return 0.5f * (1.0f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * expf(-0.5f * z * z);
+        case PP_ACT_LEAKY01: return z > 0.f ? 1.f : 0.1f;
+        case PP_ACT_TANH: {
+            const float t = tanhf(z);
+            return 1.f - t * t;
+        }
+        default: return 1.f;
+    }
+}
+__global__ __launch_bounds__(256) void act_forward_kernel(const float* __restrict__ z, long long n, int act, float* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = act_fwd(z[i], act);
+}
+__global__ __launch_bounds__(256) void act_backward_kernel(const float* __restrict__ z, const float* __restrict__ dy, long long n, int act,
+                                                           float* __restrict__ dz) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dz[i] = dy[i] * act_grad(z[i], act);
+}
+
+// element-wise helpers of the slice: op 0: out = a * b; 1: out = a * v[col]; 2: out = a + b
+__global__ __launch_bounds__(256) void ew_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, long long n, int cols,
+                                                 float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float x = a[i];
+        out[i] = op == 0 ? x * b[i] : (op == 1 ? x * b[i % cols] : x + b[i]);
+    }
+}
+
+// nn.LayerNorm backward, one wave per row: xhat = (x - mean) rstd; dxhat = dy gamma;
+// dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)); gx = dy xhat (for dgamma = column sums of gx; dbeta = column sums of dy)
+__global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                 const float* __restrict__ dy, int rows, int C, float eps,
+                                                                 float* __restrict__ dx, float* __restrict__ gx) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    const float* dr = dy + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = xr[c] - mean;
+        v = fmaf(d, d, v);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)C + eps);
+    float a = 0.f, b = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, dh = dr[c] * g[c];
+        a += dh;
+        b = fmaf(dh, xh, b);
+    }
+    a = wave_sum(a) / (float)C;
+    b = wave_sum(b) / (float)C;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, dh = dr[c] * g[c];
+        dx[(size_t)row * C + c] = rstd * (dh - a - xh * b);
+        gx[(size_t)row * C + c] = dr[c] * xh;
+    }
+}
+
+// nn.GroupNorm(G, C) (+ReLU) backward on NHWC, one workgroup per (image, group); y = relu?(xhat gamma + beta).
+// dy is masked by the ReLU first (y_pre > 0), then the LayerNorm formulas over the group's HW x C/G elements.
+__global__ __launch_bounds__(256) void groupnorm_backward_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                 const float* __restrict__ bta, const float* __restrict__ dy, int HW, int C,
+                                                                 int G, float eps, int relu, float* __restrict__ dx, float* __restrict__ gx,
+                                                                 float* __restrict__ gy) {
+    __shared__ float red[16];
+    const int img = blockIdx.x / G, grp = blockIdx.x % G, cg = C / G, tid = threadIdx.x;
+    const size_t base = (size_t)img * HW * C + grp * cg;
+    const int n = HW * cg;
+    auto block_sum2 = [&](float u, float w, float& su, float& sw) {
+        u = wave_sum(u);
+        w = wave_sum(w);
+        __syncthreads();
+        if ((tid & 63) == 0) {
+            red[tid >> 6] = u;
+            red[4 + (tid >> 6)] = w;
+        }
+        __syncthreads();
+        su = red[0] + red[1] + red[2] + red[3];
+        sw = red[4] + red[5] + red[6] + red[7];
+    };
+    float s = 0.f, dummy;
+    for (int i = tid; i < n; i += 256) s += x[base + (size_t)(i / cg) * C + (i % cg)];
+    float mean;
+    block_sum2(s, 0.f, mean, dummy);
+    mean /= (float)n;
+    float v = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float d = x[base + (size_t)(i / cg) * C + (i % cg)] - mean;
+        v = fmaf(d, d, v);
+    }
+    float var;
+    block_sum2(v, 0.f, var, dummy);
+    const float rstd = 1.0f / sqrtf(var / (float)n + eps);
+    float a = 0.f, b = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const int c = grp * cg + i % cg;
+        const size_t off = base + (size_t)(i / cg) * C + (i % cg);
+        const float xh = (x[off] - mean) * rstd;
+        float d = dy[off];
+        if (relu && !(xh * g[c] + bta[c] > 0.f)) d = 0.f;
+        const float dh = d * g[c];
+        a += dh;
+        b = fmaf(dh, xh, b);
+    }
+    float sa, sb;
+    block_sum2(a, b, sa, sb);
+    sa /= (float)n;
+    sb /= (float)n;
+    for (int i = tid; i < n; i += 256) {
+        const int c = grp * cg + i % cg;
+        const size_t off = base + (size_t)(i / cg) * C + (i % cg);
+        const float xh = (x[off] - mean) * rstd;
+        float d = dy[off];
+        if (relu && !(xh * g[c] + bta[c] > 0.f)) d = 0.f;
+        dx[off] = rstd * (d * g[c] - sa - xh * sb);
+        gx[off] = d * xh;
+        gy[off] = d;
+    }
+}
+
+// softmax backward per row: ds = p (dp - sum_j dp_j p_j)
+__global__ __launch_bounds__(256) void softmax_backward_kernel(const float* __restrict__ p, const float* __restrict__ dp, long long rows, int n,
+                                                               float* __restrict__ ds) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* pr = p + row * n;
+    const float* dr = dp + row * n;
+    float s = 0.f;
+    for (int c = lane; c < n; c += 64) s = fmaf(pr[c], dr[c], s);
+    s = wave_sum(s);
+    for (int c = lane; c < n; c += 64) ds[row * n + c] = pr[c] * (dr[c] - s);
+}
+
+// d/dlogits of mean_i [logsumexp_j(scale L_ij) - scale L_ii]: (softmax_j(scale L_i.) - delta_ij) scale / n, times the upstream scalar
+__global__ __launch_bounds__(256) void xent_diag_backward_kernel(const float* __restrict__ logits, int n, int ld, float scale, const float* __restrict__ up,
+                                                                 float* __restrict__ dl) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float* lr = logits + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < n; c += 64) mx = fmaxf(mx, lr[c] * scale);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float s = 0.f;
+    for (int c = lane; c < n; c += 64) s += expf(lr[c] * scale - mx);
+    s = wave_sum(s);
+    const float k = up[0] * scale / (float)n;
+    for (int c = lane; c < n; c += 64) dl[(size_t)row * n + c] = (expf(lr[c] * scale - mx) / s - (c == row ? 1.f : 0.f)) * k;
+}
+
+// F.normalize backward per row: q = x / max(|x|, eps); dx = (dq - q (q . dq)) / max(|x|, eps)
+__global__ __launch_bounds__(256) void normalize_backward_kernel(const float* __restrict__ x, long long row_stride, const long long* __restrict__ index,
+                                                                 const float* __restrict__ dq, int rows, int C, float eps, float* __restrict__ dx) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (index ? index[row] : (long long)row) * row_stride;
+    const float* dr = dq + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(xr[c], xr[c], s);
+    const float nrm = fmaxf(sqrtf(wave_sum(s)), eps);
+    float d = 0.f;
+    for (int c = lane; c < C; c += 64) d = fmaf(xr[c] / nrm, dr[c], d);
+    d = wave_sum(d);
+    for (int c = lane; c < C; c += 64) dx[(size_t)row * C + c] = (dr[c] - (xr[c] / nrm) * d) / nrm;
+}
+
+// im2col of an NHWC image for a k x k / stride s / pad p convolution: col[(b, oy, ox)][(ky, kx, ci)]
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, int H, int W, int C, int k, int s, int p, int Ho, int Wo,
+                                                     long long total, float* __restrict__ col) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ci = (int)(i % C);
+        long long t = i / C;
+        const int kx = (int)(t % k);
+        t /= k;
+        const int ky = (int)(t % k);
+        t /= k;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const int iy = oy * s - p + ky, ix = ox * s - p + kx;
+        col[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * H + iy) * W + ix) * C + ci] : 0.f;
+    }
+}
+// ... and its adjoint in gather form (an input pixel sums the windows it belongs to, in a fixed order)
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ col, int H, int W, int C, int k, int s, int p, int Ho, int Wo,
+                                                     long long total, float* __restrict__ dx) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ci = (int)(i % C);
+        long long t = i / C;
+        const int ix = (int)(t % W);
+        t /= W;
+        const int iy = (int)(t % H);
+        const int b = (int)(t / H);
+        float acc = 0.f;
+        for (int ky = 0; ky < k; ++ky) {
+            const int oyn = iy + p - ky;
+            if (oyn < 0 || oyn % s != 0 || oyn / s >= Ho) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int oxn = ix + p - kx;
+                if (oxn < 0 || oxn % s != 0 || oxn / s >= Wo) continue;
+                acc += col[((((size_t)b * Ho + oyn / s) * Wo + oxn / s) * k * k + ky * k + kx) * C + ci];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+inline int grid_for(long long n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+}  // namespace
+
+extern "C" {
+
+size_t pp_colsum_workspace_bytes(long long rows, int cols) {
+    const int slabs = rows < 64 ? 1 : (rows < 4096 ? 16 : 128);
+    return (size_t)slabs * cols * sizeof(float);
+}
+
+int pp_colsum(const float* x, long long rows, int cols, int ld, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !out || !workspace || rows <= 0 || cols <= 0 || ld < cols) return PP_EINVAL;
+    const int slabs = rows < 64 ? 1 : (rows < 4096 ? 16 : 128);
+    if (workspace_bytes < (size_t)slabs * cols * sizeof(float)) return PP_EWORKSPACE;
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((cols + 255) / 256, slabs), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, (float*)workspace);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, slabs, cols, out);
+    return pp_last_launch();
+}
+
+int pp_act_forward(const float* z, long long n, int act, float* y, void* stream) {
+    if (!z || !y || n <= 0 || act < 0 || act > PP_ACT_TANH) return PP_EINVAL;
+    hipLaunchKernelGGL(act_forward_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, n, act, y);
+    return pp_last_launch();
+}
+
+int pp_act_backward(const float* z, const float* dy, long long n, int act, float* dz, void* stream) {
+    if (!z || !dy || !dz || n <= 0 || act < 0 || act > PP_ACT_TANH) return PP_EINVAL;
+    hipLaunchKernelGGL(act_backward_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, dy, n, act, dz);
+    return pp_last_launch();
+}
+
+int pp_elementwise(int op, const float* a, const float* b, long long n, int cols, float* out, void* stream) {
+    if (!a || !b || !out || n <= 0 || op < 0 || op > 2 || (op == 1 && cols <= 0)) return PP_EINVAL;
+    hipLaunchKernelGGL(ew_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, op, a, b, n, cols > 0 ? cols : 1, out);
+    return pp_last_launch();
+}
+
+int pp_layernorm_backward(const float* x, const float* gamma, const float* dy, int rows, int C, float eps, float* dx, float* gx, void* stream) {
+    if (!x || !gamma || !dy || !dx || !gx || rows <= 0 || C <= 0) return PP_EINVAL;
+    hipLaunchKernelGGL(layernorm_backward_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, rows, C, eps, dx, gx);
+    return pp_last_launch();
+}
+
+int pp_groupnorm_backward_nhwc(const float* x, const float* gamma, const float* beta, const float* dy, int B, int HW, int C, int groups,
+                               float eps, int relu, float* dx, float* gx, float* gy, void* stream) {
+    if (!x || !gamma || !beta || !dy || !dx || !gx || !gy || B <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0) return PP_EINVAL;
+    hipLaunchKernelGGL(groupnorm_backward_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy, HW, C, groups, eps,
+                       relu, dx, gx, gy);
+    return pp_last_launch();
+}
+
+int pp_softmax_backward_rows(const float* p, const float* dp, long long rows, int n, float* ds, void* stream) {
+    if (!p || !dp || !ds || rows <= 0 || n <= 0) return PP_EINVAL;
+    hipLaunchKernelGGL(softmax_backward_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp, rows, n, ds);
+    return pp_last_launch();
+}
+
+int pp_xent_diag_backward(const float* logits, int n, int ld, float scale, const float* upstream, float* dlogits, void* stream) {
+    if (!logits || !upstream || !dlogits || n <= 0 || ld < n) return PP_EINVAL;
+    hipLaunchKernelGGL(xent_diag_backward_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, n, ld, scale, upstream, dlogits);
+    return pp_last_launch();
+}
+
+int pp_normalize_rows_backward(const float* x, long long row_stride, const int64_t* index, const float* dq, int rows, int C, float eps, float* dx,
+                               void* stream) {
+    if (!x || !dq || !dx || rows <= 0 || C <= 0) return PP_EINVAL;
+    hipLaunchKernelGGL(normalize_backward_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, row_stride, (const long long*)index, dq,
+                       rows, C, eps, dx);
+    return pp_last_launch();
+}
+
+int pp_im2col_nhwc(const float* x, int B, int H, int W, int C, int ksize, int stride, int pad, float* col, void* stream) {
+    if (!x || !col || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0 || stride <= 0 || pad < 0) return PP_EINVAL;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const long long total = (long long)B * Ho * Wo * ksize * ksize * C;
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, H, W, C, ksize, stride, pad, Ho, Wo, total, col);
+    return pp_last_launch();
+}
+
+int pp_col2im_nhwc(const float* col, int B, int H, int W, int C, int ksize, int stride, int pad, float* dx, void* stream) {
+    if (!col || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0 || stride <= 0 || pad < 0) return PP_EINVAL;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const long long total = (long long)B * H * W * C;
+    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, col, H, W, C, ksize, stride, pad, Ho, Wo, total, dx);
+    return pp_last_launch();
+}
+
+}  // extern "C"

@@ -104,8 +104,10 @@ class FeatureExtractor(Packed):
         return pk["pos"][key]
 
     # ---- forward -------------------------------------------------------------------------
-    def forward_tokens(self, x):
-        """(B,3,H,W) -> list of token tensors (B, 1+hw, C) at the taken blocks (cls row first)."""
+    def forward_tokens(self, x, last_block_fn=None):
+        """(B,3,H,W) -> list of token tensors (B, 1+hw, C) at the taken blocks (cls row first).
+        last_block_fn(block, xs, B, T, heads, hd) -> xs': computes the LAST block instead of the fused engine path (the training
+        slice runs it under autograd: picopose_amd/autograd.last_block_forward)."""
         v = self.dinov2
         B, _, H, W = x.shape
         p = v.patch_size
@@ -121,6 +123,11 @@ class FeatureExtractor(Packed):
         xs = tok.view(B * T, C)
         outs = []
         for i, blk in enumerate(v.blocks):
+            if last_block_fn is not None and i == len(v.blocks) - 1:
+                xs = last_block_fn(blk, xs, B, T, heads, hd)
+                if i in self.blocks_to_take:
+                    outs.append(xs.view(B, T, C))
+                continue
             # out_split: on the f16x3 engine each producer writes the next linear's operand planes directly
             h = ops.layernorm(xs, blk.norm1.weight, blk.norm1.bias, 1e-6, out_split=True)
             qkv = ops.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias, out_split=True)       # (B*T, 3*heads*hd)

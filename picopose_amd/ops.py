@@ -252,14 +252,14 @@ def bmm_nt(a, b, alpha=1.0, out=None):
     return out
 
 
-def bmm_nn(a, b, out):
-    """out[z0,z1] = a[z0,z1] @ b[z0,z1] for (Z0,Z1,M,K) x (Z0,Z1,K,N) strided views (b: n contiguous)."""
+def bmm_nn(a, b, out, alpha=1.0):
+    """out[z0,z1] = alpha * a[z0,z1] @ b[z0,z1] for (Z0,Z1,M,K) x (Z0,Z1,K,N) strided views (b: n contiguous)."""
     Z0, Z1, M, K = a.shape
     N = b.shape[3]
     assert a.stride(3) == 1 and b.stride(3) == 1 and out.stride(3) == 1
     _run(_desc(A=_p(a), B=_p(b), C=_p(out), M=M, N=N, K=K, lda=a.stride(2), ldb=b.stride(2), ldc=out.stride(2), b_kn=1,
                batch0=Z0, batch1=Z1, a_bs0=a.stride(0), a_bs1=a.stride(1), b_bs0=b.stride(0), b_bs1=b.stride(1),
-               c_bs0=out.stride(0), c_bs1=out.stride(1), prec=_fly_prec()))
+               c_bs0=out.stride(0), c_bs1=out.stride(1), alpha=float(alpha), prec=_fly_prec()))
     return out
 
 

@@ -31,16 +31,23 @@ def _feature_grid_index(pts, h):
     return torch.where(ok, q[..., 1] * h + q[..., 0], torch.full_like(q[..., 0], -1)).reshape(B, h * h)
 
 
-def infonce_rows(tokens_src, tokens_tar, src_pts, tar_pts, tau=0.1):
-    """InfoNCE on token-major features: tokens_* (B, 1 + h*h, C) (cls row first) -> scalar loss."""
-    B, T, C = tokens_src.shape
+def infonce_index_rows(token_shape, src_pts, tar_pts):
+    """Rows (into the (B*T, C) token matrix, cls row skipped) of the key-point pairs the InfoNCE loss uses, batch-major."""
+    B, T, C = token_shape
     h = int(round((T - 1) ** 0.5))
     si, ti = _feature_grid_index(src_pts, h), _feature_grid_index(tar_pts, h)
     base = (torch.arange(B, device=si.device) * T + 1)[:, None]
     s_rows, t_rows = (si + base)[si >= 0], (ti + base)[ti >= 0]        # batch-major order of the valid entries (one sync)
-    n = s_rows.numel()
-    if n != t_rows.numel():
+    if s_rows.numel() != t_rows.numel():
         raise _lib.PicoPoseHipError("key-point lists disagree on which entries are valid")
+    return s_rows.contiguous(), t_rows.contiguous()
+
+
+def infonce_rows(tokens_src, tokens_tar, src_pts, tar_pts, tau=0.1):
+    """InfoNCE on token-major features: tokens_* (B, 1 + h*h, C) (cls row first) -> scalar loss."""
+    B, T, C = tokens_src.shape
+    s_rows, t_rows = infonce_index_rows(tokens_src.shape, src_pts, tar_pts)
+    n = s_rows.numel()
     if n == 0:
         return torch.full((), float("nan"), device=tokens_src.device)    # F.cross_entropy of an empty batch
     L = _lib.lib()

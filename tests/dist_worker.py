@@ -44,6 +44,24 @@ def main():
                            topk_fn=lambda sc, k: torch.topk(sc, k, dim=1), tail_fn=lambda e, ids, real: ids)
     _, want = om.matching_templates(bank_all[own], rgb_all[own], None, mask_all[own], topk=3)
     ok = ok and torch.equal(outs, want)
+    # DDP gradient averaging of the backward slice: rank r holds (r + 1) x the REFERENCE's gradients of the slice's parameters
+    # (tests/golden/train_grads.npz); after allreduce_gradients every rank holds their mean, 1.5 x — in several buckets
+    import numpy as np
+
+    from picopose_amd.dist import allreduce_gradients
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_grads.npz"))
+    names = sorted(k for k in z.files if k.startswith("grad/"))
+    params = []
+    for k in names:
+        p = torch.nn.Parameter(torch.zeros(z[k].shape))
+        p.grad = torch.from_numpy(z[k]).clone() * (rank + 1)
+        params.append(p)
+    frozen = torch.nn.Parameter(torch.zeros(3))             # a parameter outside the slice: no .grad, skipped
+    nb = allreduce_gradients(params + [frozen], bucket_bytes=1 << 18)
+    ok = ok and nb >= 3 and frozen.grad is None
+    for k, p in zip(names, params):
+        ok = ok and torch.allclose(p.grad, torch.from_numpy(z[k]) * 1.5, rtol=1e-6, atol=1e-12)
     print(f"RANK{rank} {'OK' if ok else 'MISMATCH'}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
