@@ -224,6 +224,44 @@ def test_backward_slice_matches_the_reference_autograd(golden_dir, precision):
 
 
 @gpu
+def test_sgd_steps_on_the_slice_lower_its_losses(golden_dir):
+    """The optimiser loop of run_train.py:109-130 on the slice: forward_train -> Loss -> backward -> allreduce_gradients (a no-op
+    at world size 1, called as a trainer would) -> SGD step over the parameters that received a gradient, four times on one batch
+    with the same stage-3 noise.  The slice's own losses (InfoNCE + the three stage-2 terms) must fall monotonically, every
+    updated parameter must move, every other parameter must stay bit-identical, and the weight re-pack must follow the in-place
+    updates (the second forward sees the new weights: ADVICE r02 on the pack cache)."""
+    from picopose_amd.dist import allreduce_gradients
+    from picopose_amd.picopose import Net
+    from picopose_amd.utils.loss_utils import Loss
+
+    z, ep, weights = _load_grad_fixture(golden_dir)
+    net = Net(small_cfg())
+    net.load_state_dict(weights(net.state_dict()))
+    net = net.cuda().train()
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    ep = _cuda(ep)
+    slice_loss, opt = [], None
+    for step in range(4):
+        res = net(dict(ep))
+        total = Loss()(res)
+        slice_loss.append(float(res["loss_info"] + res["loss_2d_trans"] + res["loss_scale"] + res["loss_inplane"]))
+        total["loss"].backward()
+        trained = [p for p in net.parameters() if p.grad is not None]
+        if opt is None:
+            opt = torch.optim.SGD(trained, lr=2e-3)
+        allreduce_gradients(trained)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    print("slice losses over four SGD steps:", [f"{v:.5f}" for v in slice_loss])
+    assert all(b < a for a, b in zip(slice_loss, slice_loss[1:])), slice_loss
+    last = len(net.feature_extractor.dinov2.blocks) - 1
+    for name, p in net.named_parameters():
+        in_slice = name.startswith("affine_regressor.") or name.startswith(f"feature_extractor.dinov2.blocks.{last}.")
+        same = torch.equal(p.detach(), before[name])
+        assert same != in_slice, (name, in_slice, same)
+
+
+@gpu
 def test_backward_kernels_against_torch_autograd():
     """The row-wise adjoints of csrc/pp_backward.hip one by one against torch's autograd on CPU (fp32)."""
     from picopose_amd import autograd as ag
