@@ -127,6 +127,8 @@ def allreduce_gradients(parameters, group=None, bucket_bytes=25 << 20):
     set of parameters with a gradient is the same on all ranks), each bucket is ONE all-reduce (RCCL over xGMI: a ring per bucket,
     per-link bound — 25 MB buckets keep the ring's latency term below 1 % of its transfer time at ~50 GB/s per link), then divided
     by the world size and copied back.  Returns the number of buckets.  Call after loss.backward(), before optimizer.step()."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0                                           # a single process: nothing to average
     world = dist.get_world_size(group)
     grads = [p.grad for p in parameters if p.grad is not None]
     if not grads or world == 1:

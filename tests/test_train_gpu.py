@@ -131,7 +131,15 @@ def test_training_forward_matches_the_reference_run(golden_dir, engine_precision
         assert abs(float(res[k]) - float(z[k])) <= 1e-3 * max(1.0, abs(float(z[k]))), (k, float(res[k]), float(z[k]))
     tot = Loss()(res)
     assert abs(float(tot["loss"]) - float(z["total_loss"])) <= 1e-3 * float(z["total_loss"])
-    assert not res["loss_info"].requires_grad                 # forward values only
+    assert res["loss_info"].requires_grad and not res["loss_flow0"].requires_grad      # the backward slice is live by default
+    # the forward-only training step (no autograd) takes the fused inference kernels for the slice: same losses to 1e-5
+    bn_state = {k: v.clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        plain = net.forward_train(_cuda(ep), pred_Ms=torch.from_numpy(z["pred_Ms"]).cuda())
+    net.load_state_dict(bn_state)                             # (that second step moved the running buffers again)
+    for k in ("loss_info", "loss_2d_trans", "loss_scale", "loss_inplane"):
+        assert not plain[k].requires_grad
+        assert abs(float(plain[k]) - float(res[k])) <= 1e-5 * max(1.0, abs(float(res[k]))), (k, float(plain[k]), float(res[k]))
     sd = net.state_dict()
     for key in z.files:
         if key.startswith("bn/"):
@@ -226,8 +234,8 @@ def test_backward_slice_matches_the_reference_autograd(golden_dir, precision):
 @gpu
 def test_sgd_steps_on_the_slice_lower_its_losses(golden_dir):
     """The optimiser loop of run_train.py:109-130 on the slice: forward_train -> Loss -> backward -> allreduce_gradients (a no-op
-    at world size 1, called as a trainer would) -> SGD step over the parameters that received a gradient, four times on one batch
-    with the same stage-3 noise.  The slice's own losses (InfoNCE + the three stage-2 terms) must fall monotonically, every
+    at world size 1, called as a trainer would) -> SGD step over the parameters that received a gradient, five times on one batch.
+    Each of the slice's own losses (InfoNCE and the three stage-2 terms) must fall monotonically, every
     updated parameter must move, every other parameter must stay bit-identical, and the weight re-pack must follow the in-place
     updates (the second forward sees the new weights: ADVICE r02 on the pack cache)."""
     from picopose_amd.dist import allreduce_gradients
@@ -240,20 +248,23 @@ def test_sgd_steps_on_the_slice_lower_its_losses(golden_dir):
     net = net.cuda().train()
     before = {k: v.detach().clone() for k, v in net.named_parameters()}
     ep = _cuda(ep)
-    slice_loss, opt = [], None
-    for step in range(4):
+    keys = ("loss_info", "loss_2d_trans", "loss_scale", "loss_inplane")
+    rows, opt = [], None
+    for step in range(5):
         res = net(dict(ep))
         total = Loss()(res)
-        slice_loss.append(float(res["loss_info"] + res["loss_2d_trans"] + res["loss_scale"] + res["loss_inplane"]))
+        rows.append([float(res[k].detach()) for k in keys])
         total["loss"].backward()
         trained = [p for p in net.parameters() if p.grad is not None]
         if opt is None:
-            opt = torch.optim.SGD(trained, lr=2e-3)
+            opt = torch.optim.SGD(trained, lr=3e-5)           # (tools/sgd_sweep.py: the L1 translation loss oscillates from 1e-4 up)
         allreduce_gradients(trained)
         opt.step()
         opt.zero_grad(set_to_none=True)
-    print("slice losses over four SGD steps:", [f"{v:.5f}" for v in slice_loss])
-    assert all(b < a for a, b in zip(slice_loss, slice_loss[1:])), slice_loss
+    print("slice losses over five SGD steps:", [[round(v, 5) for v in r] for r in rows])
+    for j, k in enumerate(keys):
+        col = [r[j] for r in rows]
+        assert all(b <= a for a, b in zip(col, col[1:])) and col[-1] < col[0], (k, col)
     last = len(net.feature_extractor.dinov2.blocks) - 1
     for name, p in net.named_parameters():
         in_slice = name.startswith("affine_regressor.") or name.startswith(f"feature_extractor.dinov2.blocks.{last}.")
