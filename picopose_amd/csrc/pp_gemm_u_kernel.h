@@ -39,10 +39,16 @@
 #include "pp_gemm_u.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#ifdef PP_STUDY_OFFMASK   // (timing study builds only: every operand read lands in a small cache-resident window)
+#define PP_STUDY_OFF(x) ((x) & (unsigned)(PP_STUDY_OFFMASK))
+#else
+#define PP_STUDY_OFF(x) (x)
+#endif
 
-template <int BM_, int BN_, int WM_, int WN_, int S_, int OCC_>
+template <int BM_, int BN_, int WM_, int WN_, int S_, int OCC_, int PREF_ = 0>
 struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, S = S_, OCC = OCC_;
+    static constexpr bool PREF = PREF_ != 0;             // fragments of K tile kt + 1 are read during K tile kt (two register sets)
     static constexpr int NW = WM_ * WN_;                 // waves
     static constexpr int TM = BM_ / WM_, TN = BN_ / WN_;   // wave block
     static constexpr int MI = TM / 16, NJ = TN / 16;     // 16x16 MFMA tiles per wave block
@@ -50,7 +56,8 @@ struct TileCfg {
     static constexpr int A_H = BM_ * 64, B_H = BN_ * 64;   // halfs per operand per stage (128-byte rows)
     static constexpr int STAGE = A_H + B_H;
     static constexpr int LDS_BYTES = S_ * STAGE * 2;          // the ring (the epilogue leaves from the registers)
-    static_assert(MI % 2 == 0 && NJ % 2 == 0 && (MI / 2) % 2 == 0, "unit schedule: pairs of row blocks, an even number of them");
+    static_assert(PREF_ || (MI % 2 == 0 && NJ % 2 == 0 && (MI / 2) % 2 == 0), "unit schedule: pairs of row blocks, an even number of them");
+    static_assert(!PREF_ || S_ >= 3, "the prefetching schedule refills the stage read one K tile earlier: a ring of three");
     static_assert(BM_ % (8 * NW) == 0 && BN_ % (8 * NW) == 0, "DMA pieces are 8 rows per wave instruction");
 };
 
@@ -91,6 +98,13 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
     const unsigned cbyte = (unsigned)sc * 16u;
     const int ntaps = d.conv_kh * d.conv_kw;
     const int nk = MODE == 1 ? ntaps * (d.conv_cin / KT) : (d.K + KT - 1) / KT;
+    // MODE 0 / 1: a piece's address is  base + voffset (per lane, fixed for a tile) + soffset (wave-uniform, per K tile) — the K
+    // loop spends no vector instruction on a dense piece's address and two on a convolution's (the tap's padding bit).  The
+    // range check looks at voffset alone: MODE 1 moves the base back by the largest negative window offset (pad rows + pad
+    // pixels) so that every voffset is >= 0; past the end of the workgroup's tile list the descriptor has zero records.
+    const long long abias = MODE == 1 ? ((long long)d.conv_pad * d.conv_w + d.conv_pad) * d.lda : 0;   // elements
+    const bool ktail = MODE == 0 && d.K % KT != 0;
+    unsigned tmask = 0u;   // MODE 0, K % KT != 0: all-ones in the lanes whose chunk of the current K tile lies past K
 
     // ---- fetch side: addressing state of the tile the DMA stream is in
     unsigned abyte[PA], amask[PA], bbyte[PB];   // A rows: byte offset of k = 0 (+ this lane's chunk); tap mask / row-valid bit
@@ -133,8 +147,11 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
                     aox[MODE == 2 ? j : 0] = ox;                                                                     \
                 }                                                                                                    \
             }                                                                                                        \
-            abyte[j] = (unsigned)(base * EB) + cbyte;                                                                \
-            amask[j] = mask;                                                                                         \
+            /* MODE 0: an invalid row is an out-of-range offset; MODE 1: offsets relative to the biased base (>= 0), amask = the */ \
+            /* INVALID taps (one v_bfe_i32 turns the tap's bit into the all-ones mask); MODE 2: as computed              */ \
+            abyte[j] = MODE == 0 ? (ok ? (unsigned)(base * EB) + cbyte : 0xFFFFFFFFu)                                \
+                                 : (unsigned)((base + (MODE == 1 ? abias : 0)) * EB) + cbyte;                        \
+            amask[j] = MODE == 1 ? ~mask : mask;                                                                     \
         }                                                                                                            \
         _Pragma("unroll") for (int j = 0; j < PB; ++j) {                                                             \
             const int nb = n0_ + pp_wperm((j * NW + w) * 8 + lr);   /* LDS weight rows are permuted: pp_gemm_dev.h */  \
@@ -155,34 +172,53 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
         ftile += nxw;                                           \
         if (ftile < chunk1) PP_U_SETUP(ftile) else fkt = 0;     \
     }
-    // byte offsets of the pieces of K tile fkt of tile ftile (0xFFFFFFFF reads zeros: padding, tails, past the end)
-    auto off_a = [&](int j) __attribute__((always_inline)) -> unsigned {
+    // pieces of K tile fkt of tile ftile (an offset of 0xFFFFFFFF reads zeros without traffic: padding, tails)
+    auto off_a2 = [&](int j) __attribute__((always_inline)) -> unsigned {   // MODE 2: everything per lane
         const unsigned live = ftile < chunk1 ? 1u : 0u;
-        if (MODE == 1) {  // (bitwise, not &&: a short-circuit on the wave-uniform term would become a branch)
-            const unsigned tapoff = (unsigned)(((cky * d.conv_w + ckx) * d.lda + cci) * EB);
-            const unsigned ok = (amask[j] >> ctap) & live;
-            return (abyte[j] + tapoff) | ((ok & 1u) - 1u);  // ok = 0 -> 0xFFFFFFFF (plain ALU: `?:` here compiles to exec-masked blocks)
-        }
-        if (MODE == 2) {
-            const int iy = aoy[MODE == 2 ? j : 0] + tky, ix = aox[MODE == 2 ? j : 0] + tkx;
-            const unsigned ok = amask[j] & live & (fkt * KT + kch < d.K ? 1u : 0u) & (iy >= 0 ? 1u : 0u) & (iy < d.conv_h ? 1u : 0u) &
-                                (ix >= 0 ? 1u : 0u) & (ix < d.conv_w ? 1u : 0u);
-            return (abyte[j] + (unsigned)(((tky * d.conv_w + tkx) * d.lda + tci) * EB) - (unsigned)(kch * EB)) | (ok - 1u);
-        }
-        const unsigned ok = amask[j] & live & (fkt * KT + kch < d.K ? 1u : 0u);
-        return (abyte[j] + (unsigned)(fkt * 128)) | (ok - 1u);
+        const int iy = aoy[MODE == 2 ? j : 0] + tky, ix = aox[MODE == 2 ? j : 0] + tkx;
+        const unsigned ok = amask[j] & live & (fkt * KT + kch < d.K ? 1u : 0u) & (iy >= 0 ? 1u : 0u) & (iy < d.conv_h ? 1u : 0u) &
+                            (ix >= 0 ? 1u : 0u) & (ix < d.conv_w ? 1u : 0u);
+        return (abyte[j] + (unsigned)(((tky * d.conv_w + tkx) * d.lda + tci) * EB) - (unsigned)(kch * EB)) | (ok - 1u);
     };
-    auto off_b = [&](int j) __attribute__((always_inline)) -> unsigned {
+    auto off_b2 = [&](int j) __attribute__((always_inline)) -> unsigned {
         const unsigned live = (ftile < chunk1 ? 1u : 0u) & (bbyte[j] != 0xFFFFFFFFu ? 1u : 0u);
-        if (MODE == 1) return (bbyte[j] + (unsigned)((ctap * d.conv_cin + cci) * EB)) | (live - 1u);
         return (bbyte[j] + (unsigned)(fkt * 128)) | ((live & (fkt * KT + kch < d.K ? 1u : 0u)) - 1u);
     };
     auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + stage * STAGE + ((j * NW + w) * 8) * 64), 16, off_a(j), 0, 0, 0);
+#ifdef PP_STUDY_NODMA   // (timing study builds only: the K loop without its operand traffic)
+        if (d.M > 0) return;
+#endif
+        const lds_ptr_t dst = (lds_ptr_t)(glds + stage * STAGE + ((j * NW + w) * 8) * 64);
+        if (MODE == 2) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, dst, 16, PP_STUDY_OFF(off_a2(j)), 0, 0, 0);
+        } else {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((const char*)d.A_hl - abias * EB), 0, ftile < chunk1 ? (int)(d.a_hl_bytes + abias * EB) : 0, 0x00020000);
+            const unsigned v = MODE == 0 ? abyte[j] | tmask : abyte[j] | (unsigned)__builtin_amdgcn_sbfe((int)amask[j], (unsigned)ctap, 1u);
+            const int so = MODE == 0 ? fkt * 128 : ((cky * d.conv_w + ckx) * d.lda + cci) * EB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, PP_STUDY_OFF(v), so, 0, 0);
+        }
     };
     auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(glds + stage * STAGE + A_H + ((j * NW + w) * 8) * 64), 16, off_b(j), 0, 0, 0);
+#ifdef PP_STUDY_NODMA
+        if (d.M > 0) return;
+#endif
+        const lds_ptr_t dst = (lds_ptr_t)(glds + stage * STAGE + A_H + ((j * NW + w) * 8) * 64);
+        if (MODE == 2) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, dst, 16, PP_STUDY_OFF(off_b2(j)), 0, 0, 0);
+        } else {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, ftile < chunk1 ? (int)d.b_hl_bytes : 0, 0x00020000);
+            const unsigned v = MODE == 0 ? bbyte[j] | tmask : bbyte[j];
+            const int so = MODE == 0 ? fkt * 128 : (ctap * d.conv_cin + cci) * EB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, PP_STUDY_OFF(v), so, 0, 0);
+        }
     };
+    // before the pieces of a K tile: move to the next tile if this one is issued; the K-tail lane mask
+#define PP_U_KTILE()                                                               \
+    {                                                                              \
+        PP_U_NEXT_TILE_IF_DONE()                                                   \
+        if (ktail) tmask = fkt * KT + kch < d.K ? 0u : 0xFFFFFFFFu;                \
+    }
 #define PP_U_ADVANCE() /* after the pieces of a K tile */                                           \
     {                                                                                              \
         if (MODE == 1) {                                                                           \
@@ -206,7 +242,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
     }
 #define PP_U_FETCH(STAGE_)                                               \
     {                                                                    \
-        PP_U_NEXT_TILE_IF_DONE()                                         \
+        PP_U_KTILE()                                                     \
         _Pragma("unroll") for (int j = 0; j < PA; ++j) dma_a(STAGE_, j); \
         _Pragma("unroll") for (int j = 0; j < PB; ++j) dma_b(STAGE_, j); \
         PP_U_ADVANCE()                                                   \
@@ -224,7 +260,23 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
         h8 x[NJH][2];      // [column block of the half][sub]
     };
     f32x4 acc[MI][NJ];
+#ifdef PP_STUDY_LDSNODEP
+    f32x4 sink = {0.f, 0.f, 0.f, 0.f};
+#endif
     auto load_a = [&](FA& f, int stage, int ip) __attribute__((always_inline)) {
+#ifdef PP_STUDY_NOLDS   // (timing study builds only: the K loop without its fragment reads)
+        if (d.M > 0) return;
+#endif
+#ifdef PP_STUDY_LDSNODEP   // (timing study builds only: the fragment reads are issued, the MFMAs do not depend on them)
+        {
+            const unsigned a0 = (unsigned)(uintptr_t)(lds_ptr_t)(glds + stage * STAGE + (wr * T::TM + ip * 32) * 64);
+            for (int i = 0; i < 2; ++i) {
+                asm volatile("ds_read_b128 %0, %1" : "+v"(sink) : "v"(a0 + (i * 16 * 64 + fo0) * 2));
+                asm volatile("ds_read_b128 %0, %1" : "+v"(sink) : "v"(a0 + (i * 16 * 64 + fo1) * 2));
+            }
+            return;
+        }
+#endif
         const _Float16* st = glds + stage * STAGE + (wr * T::TM + ip * 32) * 64;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -233,6 +285,19 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
         }
     };
     auto load_b = [&](FB& f, int stage, int jh) __attribute__((always_inline)) {
+#ifdef PP_STUDY_NOLDS
+        if (d.M > 0) return;
+#endif
+#ifdef PP_STUDY_LDSNODEP
+        {
+            const unsigned b0 = (unsigned)(uintptr_t)(lds_ptr_t)(glds + stage * STAGE + A_H + (wc * T::TN + jh * NJH * 16) * 64);
+            for (int j = 0; j < NJH; ++j) {
+                asm volatile("ds_read_b128 %0, %1" : "+v"(sink) : "v"(b0 + (j * 16 * 64 + fo0) * 2));
+                asm volatile("ds_read_b128 %0, %1" : "+v"(sink) : "v"(b0 + (j * 16 * 64 + fo1) * 2));
+            }
+            return;
+        }
+#endif
         const _Float16* st = glds + stage * STAGE + A_H + (wc * T::TN + jh * NJH * 16) * 64;
 #pragma unroll
         for (int j = 0; j < NJH; ++j) {
@@ -260,14 +325,179 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             for (int j = 0; j < NJH; ++j) mma1(a, b, ip, jh, i, j);
     };
     (void)NSUB;
+    // SPREAD (rings of three stages or more): the stage read in K tile kt - 1 is free from that tile's barrier on, so the pieces
+    // of K tile kt + S - 1 are issued one by one over ALL units of K tile kt instead of together in its last unit.  A burst of
+    // LDS-DMA instructions blocks the issuing wave for 60-180 cycles apiece, and the two waves of a SIMD — in step after the
+    // barrier — burst at the same time: the matrix pipe idles (profiles/r03/engine_study.md, "K loop without DMA").
+    constexpr int EPI_ST_ = MI * NJ;   // VMEM operations of a vector epilogue, at least (see EPI_ST below)
+    constexpr bool SPREAD = S >= 3 && MODE != 2;
+    constexpr int NU = 2 * NIP, NM = 2 * NJH, NSLOT = NU * NM, NP = PA + PB;   // units / accumulator tiles per unit / per K tile
+    constexpr int NBEFORE = SPREAD ? ((NU - 1) * NM * NP) / NSLOT : 0;          // pieces of a K tile issued before its wait point
+    constexpr int INFLIGHT = SPREAD ? (S - 3) * NP + NBEFORE : (S - 2) * NP;   // DMA pieces younger than the awaited K tile
+    constexpr int RELAX = SPREAD ? S - 2 : S - 1;   // K tiles after an epilogue whose awaited pieces are OLDER than its stores
+    int fill = S - 1;                               // SPREAD: the stage being refilled during the current K tile
+    auto piece = [&](int stage, int q) __attribute__((always_inline)) {
+        if (q < PA) dma_a(stage, q);
+        else dma_b(stage, q - PA);
+    };
+    // unit u of a K tile: its accumulator tiles, with (SPREAD) the DMA pieces that fall into its slots pinned between them
+    auto unit = [&](const FA& a, const FB& b, int ip, int jh, int u) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NM; ++t) {
+            const int slot = u * NM + t;
+            if (SPREAD && (slot * NP) / NSLOT != ((slot + 1) * NP) / NSLOT) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = (slot * NP) / NSLOT; q < ((slot + 1) * NP) / NSLOT; ++q) piece(fill, q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma1(a, b, ip, jh, t / NJH, t % NJH);
+        }
+    };
 
+    if constexpr (T::PREF) {
+        // ---- the prefetching schedule (wave blocks of at most 64x64: two full fragment sets fit the register budget) ----------
+        // Measured on the unit schedule (profiles/r03/engine_study.md): with the LDS-DMA stream running, a fragment read issued
+        // one unit (12 MFMAs) ahead of its use is late — the same loop with the MFMAs made independent of the reads runs 20 %
+        // faster, while reads or DMA alone cost 0 % / 13 %.  Here EVERY fragment of K tile kt + 1 is read during the first half
+        // of K tile kt into the other register set; the MFMAs of a K tile never wait for LDS.  Ring: K tile kt + 1 is being
+        // read, kt + 2 .. kt + S - 1 are landed or in flight, the stage of K tile kt (in registers since the last barrier) is
+        // refilled with K tile kt + S, its pieces spread over the K tile's accumulator tiles.
+        constexpr int NBLK = MI + NJ;                          // 16-row fragment blocks per K tile (A then B), two reads each
+        constexpr int NSL = MI * NJ;                           // accumulator tiles = slots of a K tile
+#ifndef PP_PREF_RDSL_DIV
+#define PP_PREF_RDSL_DIV 2
+#endif
+#ifndef PP_PREF_WAIT_BACK
+#define PP_PREF_WAIT_BACK (NSL / 4)
+#endif
+        constexpr int RDSL = NSL / PP_PREF_RDSL_DIV;           // the reads go into the first slots
+        constexpr int WAITSL = NSL - PP_PREF_WAIT_BACK;        // wait + barrier before this slot
+        constexpr int NBEF = (WAITSL * NP) / NSL;              // pieces of the current K tile issued before the wait
+        constexpr int INFL = (S - 3) * NP + NBEF;              // DMA pieces younger than the awaited K tile (kt + 2)
+        static_assert(INFL + EPI_ST_ <= 63, "vmcnt is a 6-bit counter");
+        struct FS {
+            h8 a[MI][2], b[NJ][2];
+        };
+        FS f0, f1;
+        auto load_blk = [&](FS& f, int stage, int blk) __attribute__((always_inline)) {
+            if (blk < MI) {
+                const _Float16* st = glds + stage * STAGE + (wr * T::TM + blk * 16) * 64;
+                f.a[blk][0] = *(const h8*)(st + fo0);
+                f.a[blk][1] = *(const h8*)(st + fo1);
+            } else {
+                const _Float16* st = glds + stage * STAGE + A_H + (wc * T::TN + (blk - MI) * 16) * 64;
+                f.b[blk - MI][0] = *(const h8*)(st + fo0);
+                f.b[blk - MI][1] = *(const h8*)(st + fo1);
+            }
+        };
+        auto mma_p = [&](const FS& f, int i, int j) __attribute__((always_inline)) {
+            f32x4& c = acc[i][j];
+            if (TERMS == 2) {
+                c = pp_mfma16(f.b[j][0], f.a[i][1], c);
+                c = pp_mfma16(f.b[j][1], f.a[i][0], c);
+                c = pp_mfma16(f.b[j][0], f.a[i][0], c);
+            } else {
+                c = pp_mfma16(f.b[j][0], f.a[i][0], c);
+                c = pp_mfma16(f.b[j][1], f.a[i][1], c);
+            }
+        };
+        int cur = 0, nxt = 1;
+        int since_epi = S;
+        const float descale = d.alpha / (PP_A_SCALE * d.b_scale);
+        // one K tile: MFMAs from set FC; fragments of the next K tile (stage nxt) into FN; pieces of K tile + S into stage cur
+        // (a macro: through a nested lambda the two sets stayed in scratch memory)
+#define PP_U_KTILE_PREF(FC, FN)                                                                                          \
+    {                                                                                                                    \
+        PP_U_KTILE()                                                                                                     \
+        _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl) {                                                             \
+            if (sl == WAITSL) {                                                                                          \
+                /* K tile kt + 2 has landed (this wave's pieces: counted wait; every wave's: barrier) and every wave */  \
+                /* holds K tile kt + 1 in registers: its stage is the next K tile's refill target                    */  \
+                if (since_epi < S - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFL + EPI_ST_) : "memory");  \
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFL) : "memory");                              \
+                ++since_epi;                                                                                             \
+                PP_U_BARRIER()                                                                                           \
+            }                                                                                                            \
+            if ((sl * NP) / NSL != ((sl + 1) * NP) / NSL) {                                                              \
+                __builtin_amdgcn_sched_barrier(0);                                                                       \
+                _Pragma("unroll") for (int q = (sl * NP) / NSL; q < ((sl + 1) * NP) / NSL; ++q) piece(cur, q);           \
+                __builtin_amdgcn_sched_barrier(0);                                                                       \
+            }                                                                                                            \
+            if (sl < RDSL) {                                                                                             \
+                _Pragma("unroll") for (int bk = (sl * NBLK) / RDSL; bk < ((sl + 1) * NBLK) / RDSL; ++bk)                 \
+                    load_blk(FN, nxt, bk);                                                                               \
+            }                                                                                                            \
+            mma_p(FC, sl / NJ, sl % NJ);                                                                                 \
+        }                                                                                                                \
+        PP_U_ADVANCE()                                                                                                   \
+        cur = nxt;                                                                                                       \
+        nxt = nxt == S - 1 ? 0 : nxt + 1;                                                                                \
+    }
+#ifdef PP_STUDY_NOBAR
+#define PP_U_BARRIER()
+#else
+#define PP_U_BARRIER() __builtin_amdgcn_s_barrier();
+#endif
+        PP_U_SETUP(first)
+#pragma unroll
+        for (int s = 0; s < S; ++s) PP_U_FETCH(s)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * NP) : "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int bk = 0; bk < NBLK; ++bk) load_blk(f0, 0, bk);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((S - 2) * NP) : "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int tile = first; tile < chunk1; tile += nxw) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // (two K tiles per trip, the sets named statically: selected by a parity branch they cost 200 spilled registers)
+            for (int kt = 0; kt + 1 < nk; kt += 2) {
+                PP_U_KTILE_PREF(f0, f1)
+                PP_U_KTILE_PREF(f1, f0)
+            }
+            if (nk & 1) {
+                PP_U_KTILE_PREF(f0, f1)
+                f0 = f1;   // an odd K tile count: the next tile's first fragments move to the set every tile starts from
+            }
+            int tr, tc;
+            pp_tile_rc(tile, gx, gy, tr, tc);
+            const int mw = tr * T::BM + wr * T::TM, nw = tc * T::BN + wc * T::TN;
+#ifdef PP_STUDY_NOEPI
+            {
+                f32x4 keep = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) keep += acc[i][j];
+                if (keep[0] + keep[1] + keep[2] + keep[3] == -12345.f) d.C[lane] = keep[0];
+            }
+#else
+            if (VEC) epilogue_wave16<MI, NJ, TERMS>(d, descale, acc, mw, nw, lane);
+            else epilogue_scalar16<MI, NJ, TERMS>(d, descale, acc, mw, nw, lane);
+#endif
+            since_epi = VEC ? 0 : S;
+            if (!VEC) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        }
+    } else {
     PP_U_SETUP(first)
 #pragma unroll
-    for (int s = 0; s < S; ++s) PP_U_FETCH(s)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * (PA + PB)) : "memory");
+    for (int s = 0; s < (SPREAD ? S - 1 : S); ++s) PP_U_FETCH(s)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((SPREAD ? S - 1 : S) - 1) * (PA + PB)) : "memory");
     __builtin_amdgcn_s_barrier();
     FA fa0, fa1;
     FB fb0, fb1;
+#if defined(PP_STUDY_NOLDS) || defined(PP_STUDY_LDSNODEP)
+    {
+        const h8 seed = {(_Float16)lane, (_Float16)1, (_Float16)2, (_Float16)3, (_Float16)w, (_Float16)5, (_Float16)6, (_Float16)7};
+        for (int i = 0; i < 2; ++i)
+            for (int k = 0; k < 2; ++k) fa0.x[i][k] = fa1.x[i][k] = seed;
+        for (int i = 0; i < NJH; ++i)
+            for (int k = 0; k < 2; ++k) fb0.x[i][k] = fb1.x[i][k] = seed;
+    }
+#endif
     load_a(fa0, 0, 0);
     load_b(fb0, 0, 0);
     int cur = 0, nxt = S > 1 ? 1 : 0;
@@ -275,7 +505,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
     // The vector epilogue issues a fixed number of VMEM operations per wave, whatever the tile (rows / columns out of range
     // are out-of-range offsets, not skipped instructions): at least one 16-byte store per 4 accumulator registers.
     constexpr int EPI_ST = MI * NJ;
-    static_assert((S - 2) * (PA + PB) + EPI_ST <= 63, "vmcnt is a 6-bit counter");
+    static_assert(INFLIGHT + EPI_ST <= 63, "vmcnt is a 6-bit counter");
     int since_epi = S;   // K tiles since the last epilogue (>= S - 1: nothing of it in flight)
     for (int tile = first; tile < chunk1; tile += nxw) {
 #pragma unroll
@@ -286,35 +516,59 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             // unit (0, 0): fragments of the second column half and of the next row pair start loading
             // (sched_barrier: the fragment reads of a unit stay in that unit — hoisted further up they lengthen the live ranges
             // past the 256 registers of a 512-thread workgroup and hipcc spills inside the loop)
+            if (SPREAD) PP_U_KTILE()
             load_b(fb1, cur, 1);
             load_a(fa1, cur, 1);
-            mma_unit(fa0, fb0, 0, 0);
+            unit(fa0, fb0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            mma_unit(fa0, fb1, 0, 1);
+            unit(fa0, fb1, 0, 1, 1);
             __builtin_amdgcn_sched_barrier(0);
             if (NIP == 4) {
                 load_a(fa0, cur, 2);
-                mma_unit(fa1, fb0, 1, 0);
+                unit(fa1, fb0, 1, 0, 2);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_unit(fa1, fb1, 1, 1);
+                unit(fa1, fb1, 1, 1, 3);
                 __builtin_amdgcn_sched_barrier(0);
                 load_a(fa1, cur, 3);
-                mma_unit(fa0, fb0, 2, 0);
+                unit(fa0, fb0, 2, 0, 4);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_unit(fa0, fb1, 2, 1);
+                unit(fa0, fb1, 2, 1, 5);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            mma_unit(fa1, fb0, NIP - 1, 0);
+            unit(fa1, fb0, NIP - 1, 0, NU - 2);
             __builtin_amdgcn_sched_barrier(0);
             // K tile kt + 1 has landed (this wave's pieces: counted wait; every wave's: barrier); every fragment of tile kt is in registers
             // (the first S - 1 K tiles after an epilogue: its stores — at least EPI_ST per wave, all younger than the pieces waited
             // for here — may stay in flight; from then on they are older than the awaited pieces and have had S - 1 K tiles to retire)
-            if (since_epi < S - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((S - 2) * (PA + PB) + EPI_ST) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((S - 2) * (PA + PB)) : "memory");
+#ifdef PP_STUDY_NOWAIT   // (timing study builds only: the DMA stream is issued but never waited for)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+            if (since_epi < RELAX) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT + EPI_ST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
+#endif
             ++since_epi;
+#ifndef PP_STUDY_NOBAR   // (timing study builds only)
             __builtin_amdgcn_s_barrier();
+#endif
             // last unit | DMA of K tile kt + S into the stage just freed, first fragments of K tile kt + 1
-            PP_U_NEXT_TILE_IF_DONE()
+            if (SPREAD) {
+                load_a(fa0, nxt, 0);
+#pragma unroll
+                for (int t = 0; t < NM; ++t) {
+                    const int slot = (NU - 1) * NM + t;
+#pragma unroll
+                    for (int q = (slot * NP) / NSLOT; q < ((slot + 1) * NP) / NSLOT; ++q) piece(fill, q);
+                    if (t == 1) load_b(fb0, nxt, 0);
+                    mma1(fa1, fb1, NIP - 1, 1, t / NJH, t % NJH);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                PP_U_ADVANCE()
+                fill = cur;
+                cur = nxt;
+                nxt = nxt == S - 1 ? 0 : nxt + 1;
+                continue;
+            }
+            PP_U_KTILE()
             if (MODE == 2) {
 #pragma unroll
                 for (int j = 0; j < PA; ++j) dma_a(cur, j);
@@ -326,8 +580,6 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
                 mma_unit(fa1, fb1, NIP - 1, 1);
             } else {
                 // pieces spread over the MFMAs of the unit (order pinned: hipcc would issue all DMA pieces first)
-                constexpr int NM = 2 * NJH;            // accumulator tiles of the unit
-                constexpr int NP = PA + PB;
                 load_a(fa0, nxt, 0);
 #pragma unroll
                 for (int t = 0; t < NM; ++t) {
@@ -357,6 +609,9 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) keep += acc[i][j];
+#ifdef PP_STUDY_LDSNODEP
+            keep += sink;
+#endif
             if (keep[0] + keep[1] + keep[2] + keep[3] == -12345.f) d.C[lane] = keep[0];
         }
 #else
@@ -366,9 +621,13 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
         since_epi = VEC ? 0 : S;   // (the element-wise epilogue issues a data-dependent number of stores: full waits)
         if (!VEC) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still target this workgroup's LDS at exit
 #undef PP_U_SETUP
 #undef PP_U_NEXT_TILE_IF_DONE
+#undef PP_U_KTILE
+#undef PP_U_KTILE_PREF
+#undef PP_U_BARRIER
 #undef PP_U_ADVANCE
 #undef PP_U_FETCH
 #endif
@@ -473,10 +732,10 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_uh_kernel(const PpGemmDesc d, 
         return (brel + bbase + (unsigned)(((cky * 3 + ckx) * d.conv_cin + cci) * EB) + (unsigned)j * bstep) | ((live & 1u) - 1u);
     };
     auto dma_a = [&](int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + fab * H_A_H + ((j * 8 + w) * 8) * 64), 16, off_a(j), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (lds_ptr_t)(glds + fab * H_A_H + ((j * 8 + w) * 8) * 64), 16, PP_STUDY_OFF(off_a(j)), 0, 0, 0);
     };
     auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(Bbase + stage * H_B_H + ((j * 8 + w) * 8) * 64), 16, off_b(j), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, (lds_ptr_t)(Bbase + stage * H_B_H + ((j * 8 + w) * 8) * 64), 16, PP_STUDY_OFF(off_b(j)), 0, 0, 0);
     };
 #define PP_H_ADVANCE()                                                                   \
     {                                                                                    \
@@ -652,7 +911,7 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_uh_kernel(const PpGemmDesc d, 
 }
 
 typedef TileCfg<256, 256, 2, 4, 2, 1> T256x256;   // 8 waves, 128x64 each, 2 x 64 KB ring
-typedef TileCfg<256, 128, 4, 2, 3, 1> T256x128;   // 8 waves, 64x64 each, 3 x 48 KB ring
+typedef TileCfg<256, 128, 4, 2, 3, 1, 1> T256x128;   // 8 waves, 64x64 each, 3 x 48 KB ring, prefetching schedule
 typedef TileCfg<128, 128, 2, 2, 2, 2> T128x128;   // 4 waves, 64x64 each, 2 x 32 KB ring: two workgroups per CU
 typedef TileCfg<128, 64, 2, 2, 3, 2> T128x64;     // 4 waves, 64x32 each, 3 x 24 KB ring: two workgroups per CU
 
