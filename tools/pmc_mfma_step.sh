@@ -20,11 +20,11 @@ for r in rows:
     if not (lo <= int(r["Dispatch_Id"]) < hi):
         continue
     n = r["Kernel_Name"]
-    n = re.sub(r"\(.*", "", n.replace("void ", "").replace("(anonymous namespace)::", ""))[:64]
+    n = re.sub(r"\(.*", "", n.replace("void ", "").replace("(anonymous namespace)::", ""))[:80]
     agg[n][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "GRBM_GUI_ACTIVE": cnt[n] += 1
 print(f"ONE timed step of bench.py (default workload), dispatches {lo}..{hi - 1}")
-print(f"{'kernel':66s} {'launches':>8s} {'MFMA busy':>10s} {'share of GPU-active cycles':>27s}")
+print(f"{'kernel':82s} {'launches':>8s} {'MFMA busy':>10s} {'share of GPU-active cycles':>27s}")
 tot = sum(v["GRBM_GUI_ACTIVE"] for v in agg.values())
 tb = 0.0
 vit = [0.0, 0.0]
@@ -33,6 +33,13 @@ for n, v in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"]):
 for n, v in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])[:18]:
     act = v["GRBM_GUI_ACTIVE"] / 8 * 1024
     busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / act if act else 0.0
-    print(f"{n:66s} {cnt[n]:8d} {busy:10.3f} {v['GRBM_GUI_ACTIVE'] / tot:27.3f}")
+    print(f"{n:82s} {cnt[n]:8d} {busy:10.3f} {v['GRBM_GUI_ACTIVE'] / tot:27.3f}")
+def is_vit(n):   # the ViT path: dense (MODE 0) engine kernels, attention, LayerNorm, token assembly
+    return (re.search(r"pp_gemm_u_kernel<TileCfg<[^>]*>, 0,", n) is not None) or any(k in n for k in ("attn_", "layernorm_kernel", "assemble_tokens"))
+va = sum(v["GRBM_GUI_ACTIVE"] for n, v in agg.items() if is_vit(n))
+vb = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for n, v in agg.items() if is_vit(n))
+vg = sum(v["GRBM_GUI_ACTIVE"] for n, v in agg.items() if re.search(r"pp_gemm_u_kernel<TileCfg<[^>]*>, 0,", n))
+vgb = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for n, v in agg.items() if re.search(r"pp_gemm_u_kernel<TileCfg<[^>]*>, 0,", n))
+print(f"ViT path (dense engine kernels + attention + LayerNorm + token assembly): MFMA busy {vb / (va / 8 * 1024):.3f}, {va / tot:.3f} of the GPU-active cycles; its dense engine kernels alone {vgb / (vg / 8 * 1024):.3f}")
 print(f"whole step: MFMA busy {tb / (tot / 8 * 1024):.3f} of the SIMD cycles while a kernel is active")
 PY

@@ -16,7 +16,7 @@ agg = collections.defaultdict(lambda: [0, 0])
 for r in rows[lo:hi]:
     n = r["Kernel_Name"]
     n = n.replace("void ", "").replace("(anonymous namespace)::", "")
-    n = re.sub(r"\(.*", "", n)[:60] if not n.startswith("_Z") else n[:60]
+    n = re.sub(r"\(.*", "", n)[:80] if not n.startswith("_Z") else n[:80]
     a = agg[n]
     a[0] += 1
     a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
@@ -24,4 +24,4 @@ span = int(rows[hi]["Start_Timestamp"]) - int(rows[lo]["Start_Timestamp"])
 busy = sum(a[1] for a in agg.values())
 print(f"step span {span/1e6:.2f} ms, kernel time {busy/1e6:.2f} ms, {hi-lo} dispatches")
 for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
-    print(f"{n:60s} n={a[0]:5d} {a[1]/1e6:8.3f} ms {100*a[1]/span:5.1f}%")
+    print(f"{n:80s} n={a[0]:5d} {a[1]/1e6:8.3f} ms {100*a[1]/span:5.1f}%")
