@@ -657,14 +657,20 @@ def gen_train_grads():
                          res["loss_2d_trans"] + res["loss_scale"] + res["loss_inplane"]),
               "vit_last": ([(n, p) for n, p in net.named_parameters() if n.startswith(f"feature_extractor.dinov2.blocks.{len(net.feature_extractor.dinov2.blocks) - 1}.")],
                            res["loss_info"])}
+    # the wide slice ("vit+stage2"): what the stage-1 and stage-2 losses TOGETHER send into the whole ViT (InfoNCE directly, the
+    # stage-2 losses through the similarity volume, utils/matching.py:6-26) — keys grad2/..., every parameter of dinov2
+    groups["vit_all"] = ([(n, p) for n, p in net.named_parameters() if n.startswith("feature_extractor.dinov2.")],
+                         res["loss_info"] + res["loss_2d_trans"] + res["loss_scale"] + res["loss_inplane"])
     for gname, (params, loss) in groups.items():
         grads = torch.autograd.grad(loss, [p for _, p in params], retain_graph=True, allow_unused=True)
+        prefix = "grad2" if gname == "vit_all" else "grad"
         for (n, p), g in zip(params, grads):
+            out[f"{prefix}used/{n}"] = np.bool_(g is not None)
             g = torch.zeros_like(p) if g is None else g
             flat = g.detach().reshape(-1)
-            stride = max(1, -(-flat.numel() // GRAD_SAMPLES))
-            out[f"grad/{n}"] = flat[::stride].numpy()
-            out[f"gradnorm/{n}"] = np.float64(flat.double().norm())
+            stride = max(1, -(-flat.numel() // (GRAD_SAMPLES if prefix == "grad" else GRAD_SAMPLES // 16)))   # (the wide group: 176 tensors)
+            out[f"{prefix}/{n}"] = flat[::stride].numpy()
+            out[f"{prefix}norm/{n}"] = np.float64(flat.double().norm())
             print(gname, n, tuple(p.shape), "stride", stride, "norm %.4g" % float(flat.double().norm()))
     np.savez_compressed(os.path.join(OUT, "train_grads.npz"), **out)
     print("training-gradient fixture written")

@@ -150,6 +150,7 @@ def lib():
         L.pp_normalize_rows_backward.argtypes = [vp, ll, vp, vp, i32, i32, f32, vp, vp]
         L.pp_im2col_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
         L.pp_col2im_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+        L.pp_simvol_backward.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
         _lib = L
     return _lib
 

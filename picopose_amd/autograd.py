@@ -2,14 +2,18 @@
 
 `torch.autograd.Function` wrappers whose forward AND backward run on libpicopose_hip.so: the matrix products are pp_gemm
 launches (dgrad = dz @ W, wgrad = dz^T @ x through ops.bmm_nn), the row-wise adjoints are the kernels of csrc/pp_backward.hip.
-torch keeps the graph, allocates tensors and makes the transposed copies — no torch arithmetic on the gradient path.
+torch keeps the graph, allocates tensors, makes the transposed / gathered copies and sums the gradients of a tensor that is used
+twice (the residual stream, the two ViT passes over shared weights: autograd's own accumulation) — nothing else on the gradient
+path is torch arithmetic.
 
-Scope (exactly the parameters that receive a gradient from `Net.forward_train` today):
-  * the stage-2 losses (utils/loss_utils.py:177-186)  ->  every parameter of `affine_regressor` (model/stage2/affine_regressor.py);
-    the gradient stops at the similarity volume (stage 2's input);
-  * the InfoNCE loss (utils/loss_utils.py:144-175)   ->  every parameter of the LAST ViT block (layers/block.py:82-107:
-    norm1, attn.qkv, attn.proj, ls1, norm2, mlp.fc1, mlp.fc2, ls2); the gradient stops at that block's input.
-Everything else (the other ViT blocks, the DPT head, the flow decoder, the stage-3 losses) still runs forward-only.
+Scope (exactly the parameters that receive a gradient from `Net.forward_train`), by `Net.train_backward`:
+  * "vit+stage2" (= True, the default): the stage-1 and stage-2 losses train what the reference trains with them —
+      InfoNCE (utils/loss_utils.py:144-175) and the three stage-2 losses (:177-186, through the similarity volume of
+      utils/matching.py:6-26)  ->  EVERY ViT block, the patch embedding, cls token and position embedding (through the bicubic
+      resampling of vision_transformer.py:179-207); the stage-2 losses  ->  every parameter of `affine_regressor`;
+  * "slice1": the first slice only — stage-2 losses -> `affine_regressor` (the gradient stops at the similarity volume), InfoNCE ->
+      the LAST ViT block (stops at its input).
+The stage-3 losses (DPT head, flow decoder) still run forward-only, so the ViT misses their contribution.
 Parity: tests/test_train_gpu.py compares these gradients with the reference's own autograd on CPU (tests/golden/train_grads.npz).
 """
 import torch
@@ -256,6 +260,115 @@ class _InfoNCE(torch.autograd.Function):
         return out[0], out[1], None, None, None
 
 
+class _AssembleTokens(torch.autograd.Function):
+    """tokens = [cls ; patches] + pos (vision_transformer.py:209-228) on rows: patches (B*P, C), cls (1,1,C), pos (P+1, C)."""
+
+    @staticmethod
+    def forward(ctx, patches, cls, pos, B):
+        patches = _f32c(patches)
+        P, C = patches.shape[0] // B, patches.shape[1]
+        ctx.dims = (B, P, C)
+        out = ops.assemble_tokens(patches.view(B, P, C), _f32c(cls).reshape(C), _f32c(pos))
+        return out.view(B * (P + 1), C)
+
+    @staticmethod
+    def backward(ctx, dtok):
+        B, P, C = ctx.dims
+        d3 = _f32c(dtok).view(B, P + 1, C)
+        dpatches = d3[:, 1:].reshape(B * P, C)
+        dcls = colsum(d3[:, 0]).view(1, 1, C)                         # rows b, stride (P + 1) C
+        dpos = colsum(d3.view(B, (P + 1) * C)).view(P + 1, C)
+        return dpatches, dcls, dpos, None
+
+
+class _InterpPos(torch.autograd.Function):
+    """interpolate_pos_encoding (vision_transformer.py:179-207) as a function of pos_embed: the value is the table the module
+    resamples at pack time (`pos`), the gradient goes through the resampling MATRIX `wt` (N, P) = W^T, W[p][n] = the bicubic
+    weight of source cell n in output cell p (FeatureExtractor._pos_wt): dpos_embed[1:] = W^T dpos[1:] on the engine."""
+
+    @staticmethod
+    def forward(ctx, pos_embed, pos, wt):
+        ctx.save_for_backward(wt)
+        ctx.shape = pos_embed.shape
+        return pos.clone()
+
+    @staticmethod
+    def backward(ctx, dpos):
+        (wt,) = ctx.saved_tensors
+        dpos = _f32c(dpos)
+        out = torch.empty(ctx.shape, dtype=torch.float32, device=dpos.device)
+        out[0, 0].copy_(dpos[0])
+        if wt is None:                                                  # the grid is the stored one: no resampling
+            out[0, 1:].copy_(dpos[1:])
+        else:
+            _mm(wt, dpos[1:], out=out[0, 1:])
+        return out, None, None
+
+
+class _SimilarityVolume(torch.autograd.Function):
+    """matching_features_similarity (utils/matching.py:6-26) of token tensors (B, 1 + 256, C) [cls row first]: the value is
+    pp_similarity_volume's (the forward-only path's bits); backward through mask / clamp / layout (pp_simvol_backward), the two
+    products dS src_hat and dS^T tar_hat on the engine, and F.normalize's adjoint per patch row."""
+
+    @staticmethod
+    def forward(ctx, tok_src, tok_tar, src_mask):
+        from .utils.matching import matching_features_similarity
+
+        ts, tt = _f32c(tok_src), _f32c(tok_tar)
+        out = matching_features_similarity(ops.tokens_to_nchw(ts, 1, 16, 16), ops.tokens_to_nchw(tt, 1, 16, 16), src_mask, None)
+        ctx.save_for_backward(ts, tt, src_mask, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ts, tt, mask, out = ctx.saved_tensors
+        L = _lib.lib()
+        B, T, C = ts.shape
+        P = T - 1
+        rows = (torch.arange(B, device=ts.device)[:, None] * T + 1 + torch.arange(P, device=ts.device)[None]).reshape(-1)
+        q = torch.empty(B * P, C, dtype=torch.float32, device=ts.device)
+        r = torch.empty_like(q)
+        _lib.check(L.pp_gather_normalize_rows(_p(ts), C, _p(rows), B * P, C, 1e-12, _p(q), _lib.stream_ptr()), "pp_gather_normalize_rows")
+        _lib.check(L.pp_gather_normalize_rows(_p(tt), C, _p(rows), B * P, C, 1e-12, _p(r), _lib.stream_ptr()), "pp_gather_normalize_rows")
+        mask = _f32c(mask)
+        dS = torch.empty(B, P, P, dtype=torch.float32, device=ts.device)           # [b][t][s]
+        _lib.check(L.pp_simvol_backward(_p(out), _p(_f32c(dout)), _p(mask), mask.shape[1], mask.shape[2], B, _p(dS), _lib.stream_ptr()),
+                   "pp_simvol_backward")
+        dr = torch.empty(1, B, P, C, dtype=torch.float32, device=ts.device)
+        dq = torch.empty_like(dr)
+        ops.bmm_nn(dS[None], q.view(1, B, P, C), dr)                                # d tar_hat[t] = sum_s dS[t][s] src_hat[s]
+        ops.bmm_nn(dS.transpose(1, 2).contiguous()[None], r.view(1, B, P, C), dq)   # d src_hat[s] = sum_t dS[t][s] tar_hat[t]
+        grads = []
+        for tok, dn in ((ts, dq), (tt, dr)):
+            dx = torch.empty(B * P, C, dtype=torch.float32, device=ts.device)
+            _lib.check(L.pp_normalize_rows_backward(_p(tok), C, _p(rows), _p(dn), B * P, C, 1e-12, _p(dx), _lib.stream_ptr()),
+                       "pp_normalize_rows_backward")
+            g = torch.zeros(B * T, C, dtype=torch.float32, device=ts.device)
+            g.index_copy_(0, rows, dx)
+            grads.append(g.view(B, T, C))
+        return grads[0], grads[1], None
+
+
+def similarity_volume(tok_src, tok_tar, src_mask):
+    return _SimilarityVolume.apply(tok_src, tok_tar, src_mask)
+
+
+def embed_tokens(fe, x):
+    """prepare_tokens_with_masks (vision_transformer.py:209-228) under autograd: the 14x14 / stride 14 patch embedding as im2col +
+    linear (the image needs no gradient), cls token, resampled position embedding.  Returns token rows (B*T, C)."""
+    v = fe.dinov2
+    B, _, H, W = x.shape
+    p = v.patch_size
+    h0, w0 = H // p, W // p
+    img = ops.to_nhwc(x, c_pad=8)
+    col = torch.empty(B * h0 * w0, p * p * 8, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().pp_im2col_nhwc(_p(img), B, H, W, 8, p, p, 0, _p(col), _lib.stream_ptr()), "pp_im2col_nhwc")
+    wp = ops.pack_conv_weight(v.patch_embed.proj.weight.float(), cin_pad=8)            # views + a zero pad: torch differentiates them
+    patches = linear(col, wp, v.patch_embed.proj.bias)
+    pos = _InterpPos.apply(v.pos_embed, fe._pos(h0, w0), fe._pos_wt(h0, w0))
+    return _AssembleTokens.apply(patches, v.cls_token, pos, B)
+
+
 # ---- the two sub-graphs of Net.forward_train that carry gradients -------------------------------------------------------------
 def last_block_forward(blk, xs, B, T, heads, hd):
     """One pre-norm ViT block (layers/block.py:82-107) on token rows xs (B*T, C) under autograd."""
@@ -269,11 +382,12 @@ def last_block_forward(blk, xs, B, T, heads, hd):
 
 
 def affine_regressor_forward(reg, sim):
-    """AffineRegressor.forward (model/stage2/affine_regressor.py:72-84) under autograd; sim (B,256,16,16) is a constant."""
+    """AffineRegressor.forward (model/stage2/affine_regressor.py:72-84) under autograd; sim (B,256,16,16) is a constant or the
+    output of similarity_volume (then the gradient continues into the ViT)."""
     f = reg.features
     B = sim.shape[0]
     hd, fs = reg.hidden_dim, reg.feat_size
-    x = ops.to_nhwc(sim)                                                             # (B,16,16,256)
+    x = sim.permute(0, 2, 3, 1).contiguous() if sim.requires_grad else ops.to_nhwc(sim)   # (B,16,16,256)
     c0, c3 = getattr(f, "0"), getattr(f, "3")
     w0 = c0.weight.reshape(c0.weight.shape[0], -1)                                   # 1x1 convolution = a linear layer on the pixels
     h = linear(x.view(-1, x.shape[-1]), w0, c0.bias).view(B, 16, 16, hd)

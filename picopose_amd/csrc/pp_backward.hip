@@ -263,6 +263,23 @@ inline int grid_for(long long n) { return (int)((n + 255) / 256 < 8192 ? (n + 25
 
 }  // namespace
 
+// adjoint of the tail of matching_features_similarity (utils/matching.py:21-25): out[b][s][h][w] = max(S[b][t][s] m[b][s], 0) with
+// t = w 16 + h and m the template mask sampled at the patch (F.interpolate nearest, :16)  ->  dS[b][t][s] = dout m [out > 0]
+__global__ void simvol_backward_kernel(const float* __restrict__ out, const float* __restrict__ dout, const float* __restrict__ mask, int mh,
+                                       int mw, long long total, float* __restrict__ dS) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over dS: ((b 256 + t) 256 + s)
+    if (i >= total) return;
+    const int s = (int)(i & 255), t = (int)((i >> 8) & 255);
+    const long long b = i >> 16;
+    const int sy = s >> 4, sx = s & 15;
+    int my = (int)floorf((float)sy * ((float)mh / 16.0f)), mx = (int)floorf((float)sx * ((float)mw / 16.0f));
+    my = my < mh - 1 ? my : mh - 1;
+    mx = mx < mw - 1 ? mx : mw - 1;
+    const float m = mask[(b * mh + my) * mw + mx];
+    const long long o = ((b * 256 + s) * 16 + (t & 15)) * 16 + (t >> 4);
+    dS[i] = out[o] > 0.f ? dout[o] * m : 0.f;
+}
+
 extern "C" {
 
 size_t pp_colsum_workspace_bytes(long long rows, int cols) {
@@ -344,6 +361,13 @@ int pp_col2im_nhwc(const float* col, int B, int H, int W, int C, int ksize, int 
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const long long total = (long long)B * H * W * C;
     hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, col, H, W, C, ksize, stride, pad, Ho, Wo, total, dx);
+    return pp_last_launch();
+}
+
+int pp_simvol_backward(const float* out, const float* dout, const float* src_mask, int mask_h, int mask_w, int B, float* dS, void* stream) {
+    if (!out || !dout || !src_mask || !dS || B <= 0 || mask_h <= 0 || mask_w <= 0) return PP_EINVAL;
+    const long long total = (long long)B * 256 * 256;
+    hipLaunchKernelGGL(simvol_backward_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, out, dout, src_mask, mask_h, mask_w, total, dS);
     return pp_last_launch();
 }
 

@@ -95,6 +95,26 @@ class FeatureExtractor(Packed):
             "pos": {},
         }
 
+    def _pos_wt(self, w0, h0):
+        """Transposed matrix (N, w0 h0) of the bicubic resampling above (None when the grid is the stored one): the same
+        F.interpolate call applied to the N basis images — a constant of the input size, built once; the backward of the position
+        embedding is one GEMM with it (picopose_amd/autograd._InterpPos)."""
+        pk = self.packed()
+        key = ("wt", w0, h0)
+        if key not in pk["pos"]:
+            v = self.dinov2
+            N = v.pos_embed.shape[1] - 1
+            if w0 * h0 == N:
+                pk["pos"][key] = None
+            else:
+                sq = int(math.sqrt(N))
+                sx, sy = float(w0 + v.interpolate_offset) / math.sqrt(N), float(h0 + v.interpolate_offset) / math.sqrt(N)
+                with torch.no_grad():
+                    basis = torch.eye(N, dtype=torch.float32, device=v.pos_embed.device).reshape(1, N, sq, sq)
+                    grid = F.interpolate(basis, scale_factor=(sx, sy), mode="bicubic", antialias=False)
+                pk["pos"][key] = grid.reshape(N, w0 * h0).contiguous()
+        return pk["pos"][key]
+
     def _pos(self, w0, h0):
         pk = self.packed()
         key = (w0, h0)
@@ -104,10 +124,11 @@ class FeatureExtractor(Packed):
         return pk["pos"][key]
 
     # ---- forward -------------------------------------------------------------------------
-    def forward_tokens(self, x, last_block_fn=None):
+    def forward_tokens(self, x, last_block_fn=None, all_blocks=False, embed_fn=None):
         """(B,3,H,W) -> list of token tensors (B, 1+hw, C) at the taken blocks (cls row first).
-        last_block_fn(block, xs, B, T, heads, hd) -> xs': computes the LAST block instead of the fused engine path (the training
-        slice runs it under autograd: picopose_amd/autograd.last_block_forward)."""
+        last_block_fn(block, xs, B, T, heads, hd) -> xs': computes the LAST block (all_blocks: every block) instead of the fused
+        engine path — the training slices run them under autograd (picopose_amd/autograd.last_block_forward); embed_fn(self, x) ->
+        token rows (B*T, C): the embedding under autograd (autograd.embed_tokens)."""
         v = self.dinov2
         B, _, H, W = x.shape
         p = v.patch_size
@@ -116,14 +137,17 @@ class FeatureExtractor(Packed):
         C, heads = v.embed_dim, v.num_heads
         hd = C // heads
         pk = self.packed()
-        img = ops.to_nhwc(x, c_pad=8)
-        patches = ops.conv2d(img, pk["patch_w"], v.patch_embed.proj.bias, p, stride=p)        # (B,h0,w0,C)
-        tok = ops.assemble_tokens(patches.view(B, h0 * w0, C), v.cls_token.reshape(C), self._pos(h0, w0))
-        T = tok.shape[1]
-        xs = tok.view(B * T, C)
+        T = h0 * w0 + 1
+        if embed_fn is not None:
+            xs = embed_fn(self, x)
+        else:
+            img = ops.to_nhwc(x, c_pad=8)
+            patches = ops.conv2d(img, pk["patch_w"], v.patch_embed.proj.bias, p, stride=p)        # (B,h0,w0,C)
+            tok = ops.assemble_tokens(patches.view(B, h0 * w0, C), v.cls_token.reshape(C), self._pos(h0, w0))
+            xs = tok.view(B * T, C)
         outs = []
         for i, blk in enumerate(v.blocks):
-            if last_block_fn is not None and i == len(v.blocks) - 1:
+            if last_block_fn is not None and (all_blocks or i == len(v.blocks) - 1):
                 xs = last_block_fn(blk, xs, B, T, heads, hd)
                 if i in self.blocks_to_take:
                     outs.append(xs.view(B, T, C))

@@ -36,7 +36,7 @@ class Net(nn.Module):
         # (NHWC, hypothesis-major when batched) of the latest forward in self.last_stage3
         self.keep_stage3 = False
         self.last_stage3 = None
-        self.train_backward = True   # training mode with autograd enabled: run the backward slice of picopose_amd/autograd.py
+        self.train_backward = True   # True / "vit+stage2" | "slice1" | False: what trains under autograd (picopose_amd/autograd.py)
 
     # model/picopose.py:52-70 — pick hypothesis k's template for every crop (pure indexing)
     def select_template_data(self, end_points, pred_id_src, k):
@@ -171,34 +171,39 @@ class Net(nn.Module):
     def forward_train(self, end_points, pred_Ms=None):
         """The training forward: key-point ground truth, both ViT passes, the InfoNCE / stage-2 / flow + certainty losses,
         BatchNorm layers on batch statistics (running buffers updated).  Returns `end_points` with the `loss*` entries the
-        reference adds (utils/loss_utils.Loss sums them).  With autograd enabled (`self.train_backward`, the default) the FIRST
-        BACKWARD SLICE is live (picopose_amd/autograd.py): `loss_info` carries a graph down to the parameters of the last ViT
-        block, `loss_2d_trans` / `loss_scale` / `loss_inplane` one to every parameter of the affine regressor — `Loss()(end_points)
-        ["loss"].backward()` fills exactly those `.grad`s; the stage-3 losses and the rest of the backbone are forward values
-        without a graph (the engine has no backward kernels for them yet).  pred_Ms: the noisy ground-truth affines of stage 3;
+        reference adds (utils/loss_utils.Loss sums them).  With autograd enabled the backward of picopose_amd/autograd.py is live,
+        scope by `self.train_backward`: True / "vit+stage2" (default) — `loss_info` and the three stage-2 losses carry a graph
+        through the similarity volume and EVERY ViT block down to the patch embedding, cls token and position embedding, and to
+        every parameter of the affine regressor; "slice1" — the first slice (affine regressor from the stage-2 losses, last ViT
+        block from InfoNCE); False — forward values only.  `Loss()(end_points)["loss"].backward()` fills exactly those `.grad`s;
+        the stage-3 losses are forward values without a graph (no backward kernels for the DPT head / flow decoder yet).  pred_Ms: the noisy ground-truth affines of stage 3;
         drawn by utils/augment.aug_gtM_noise when not given (tests pass the ones a reference run drew)."""
         from . import autograd as ag
         from .utils.loss_utils import infonce_index_rows
 
-        live = torch.is_grad_enabled() and self.train_backward
+        live = torch.is_grad_enabled() and bool(self.train_backward)
+        wide = live and self.train_backward != "slice1"          # "vit+stage2" (True): the whole ViT + stage 2 from the stage-1/2 losses
         fe, orr = self.feature_extractor, self.offset_regressor
         with torch.no_grad():
             kp = self.compute_keypoint_data(end_points)
         with torch.set_grad_enabled(live):
-            last = ag.last_block_forward if live else None
-            real_tok, (h0, w0) = fe.forward_tokens(end_points["real_rgb"], last_block_fn=last)
-            tem_tok, _ = fe.forward_tokens(end_points["tem_rgb"], last_block_fn=last)
+            kw = dict(last_block_fn=ag.last_block_forward if live else None, all_blocks=wide, embed_fn=ag.embed_tokens if wide else None)
+            real_tok, (h0, w0) = fe.forward_tokens(end_points["real_rgb"], **kw)
+            tem_tok, _ = fe.forward_tokens(end_points["tem_rgb"], **kw)
             if live:
                 s_rows, t_rows = infonce_index_rows(tem_tok[-1].shape, kp["src_pts"], kp["tar_pts"])
                 end_points["loss_info"] = (ag.infonce(tem_tok[-1], real_tok[-1], s_rows, t_rows) if s_rows.numel() else
                                            torch.full((), float("nan"), device=s_rows.device))
-                real_tok = real_tok[:-1] + [real_tok[-1].detach()]
-                tem_tok = tem_tok[:-1] + [tem_tok[-1].detach()]
             else:
                 end_points["loss_info"] = infonce_rows(tem_tok[-1], real_tok[-1], kp["src_pts"], kp["tar_pts"])
-            with torch.no_grad():
-                sim = matching_features_similarity(ops.tokens_to_nchw(tem_tok[-1], 1, h0, w0), ops.tokens_to_nchw(real_tok[-1], 1, h0, w0),
-                                                   end_points["tem_mask"], end_points["real_mask"])
+            if wide:
+                sim = ag.similarity_volume(tem_tok[-1], real_tok[-1], end_points["tem_mask"])
+            else:
+                with torch.no_grad():
+                    sim = matching_features_similarity(ops.tokens_to_nchw(tem_tok[-1].detach(), 1, h0, w0), ops.tokens_to_nchw(real_tok[-1].detach(), 1, h0, w0),
+                                                       end_points["tem_mask"], end_points["real_mask"])
+            real_tok = [t.detach() for t in real_tok]            # stage 3 is forward-only: its inputs carry no graph
+            tem_tok = [t.detach() for t in tem_tok]
             if live:
                 pred_translation, pred_scale, pred_inplane = ag.affine_regressor_forward(self.affine_regressor, sim)
             else:
