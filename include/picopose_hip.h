@@ -445,6 +445,29 @@ int pp_col2im_nhwc(const float* col, int B, int H, int W, int C, int ksize, int 
  * out / dout (B,256,16,16) -> dS (B, t = 256, s = 256), the gradient of the cosine matrix <tar_hat[t], src_hat[s]> */
 int pp_simvol_backward(const float* out, const float* dout, const float* src_mask, int mask_h, int mask_w, int B, float* dS, void* stream);
 
+/* ---- adjoints of stage 3's training path (csrc/pp_backward3.hip; each restates its forward kernel's coordinate arithmetic) ---- */
+/* nn.BatchNorm2d in training mode (pp_batchnorm_train: batch statistics, biased variance) on (rows, C), y = relu?(bn(x)):
+ * dx, dgamma, dbeta from dy; the ReLU mask is recomputed from x (beta is needed for it) */
+size_t pp_batchnorm_train_backward_workspace_bytes(long long rows, int C);
+int pp_batchnorm_train_backward(const float* x, const float* gamma, const float* beta, const float* dy, long long rows, int C, float eps,
+                                int relu, float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+/* adjoint of pp_resize_bilinear_nhwc (align_corners = True, result scaled by mul): dy (B,Ho,Wo,C) -> dx (B,H,W,C), gather form */
+int pp_resize_bilinear_backward_nhwc(const float* dy, int B, int H, int W, int C, int Ho, int Wo, float mul, float* dx, void* stream);
+/* adjoint of pp_avgpool2_nhwc: dy (B,H/2,W/2,C) -> dx (B,H,W,C) (accumulate != 0: added to dx) */
+int pp_avgpool2_backward_nhwc(const float* dy, int B, int H, int W, int C, int accumulate, float* dx, void* stream);
+/* adjoint of pp_warp_nhwc (FlowDecoder.feature_sample): dfeat (B,H,W,C) must be ZERO on entry (atomic scatter), dflow (B,H,W,2) */
+int pp_warp_backward_nhwc(const float* feat, const float* flow, const float* dy, int B, int H, int W, int C, int ld_flow, float* dfeat,
+                          float* dflow, void* stream);
+/* adjoint of pp_corr_lookup_nhwc (correlation pyramid + lookup): f2_levels[l] = the query map pooled l times (B, H>>l, W>>l, C);
+ * df1 (B,H,W,C) is written, df2_levels[l] must be ZERO on entry (atomic scatter), dflow (B,H,W,2).  C <= 256, levels <= 3 */
+int pp_corr_lookup_backward_nhwc(const float* f1, const float* const* f2_levels, const float* flow, const float* dout, int B, int H, int W,
+                                 int C, int levels, int radius, int ld_flow, int ld_dout, float* df1, float* const* df2_levels, float* dflow,
+                                 void* stream);
+/* adjoint of pp_flow_loss_sums for one level: g_flow[0] = upstream * flow_weight / (count + eps), g_cert[0] = upstream * mask_weight /
+ * (B H W) (device scalars) -> dflow (B,H,W,2), dcertainty (B,H,W) */
+int pp_flow_loss_backward(const float* flow, const float* certainty, const float* tar_pts, int B, int H, int W, float max_flow,
+                          const float* g_flow, const float* g_cert, float* dflow, float* dcertainty, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -643,14 +643,27 @@ def gen_train_grads():
     cal = dict(HEAD_CALIBRATION[vit], affine=AFFINE_CALIBRATION, proj_bn=PROJ_BN_GAIN)
     net.load_state_dict(apply_head_calibration(seeded_state_dict(net.state_dict(), wseed), cal))
     ep = edit(make_train_end_points(B, seed))
+    drawn = {}
+    orig = ref_picopose.aug_gtM_noise
+
+    def recording(end_points):
+        drawn["pred_Ms"] = orig(end_points)
+        return drawn["pred_Ms"]
+
+    ref_picopose.aug_gtM_noise = recording
     np.random.seed(1000 + seed)
     torch.manual_seed(2000 + seed)
     res = net({k: v.clone() for k, v in ep.items()})
-    out = {"meta": np.array([B, seed, wseed], dtype=np.int64), "vit": np.array(vit)}
+    ref_picopose.aug_gtM_noise = orig
+    out = {"meta": np.array([B, seed, wseed], dtype=np.int64), "vit": np.array(vit), "pred_Ms": drawn["pred_Ms"].detach().numpy()}
     for k, v in _cal_arrays(cal).items():
         out[k] = v
     out["real_pose"], out["tem_pose"] = ep["real_pose"].numpy(), ep["tem_pose"].numpy()
-    for k in ("loss_info", "loss_2d_trans", "loss_scale", "loss_inplane"):
+    from utils.loss_utils import Loss
+
+    total = Loss()(res)["loss"]
+    out["total_loss"] = total.detach().numpy()
+    for k in [k for k in res if "loss" in k]:
         out[k] = res[k].detach().numpy()
         print(k, float(res[k]))
     groups = {"affine": ([(n, p) for n, p in net.named_parameters() if n.startswith("affine_regressor.")],
@@ -661,14 +674,16 @@ def gen_train_grads():
     # stage-2 losses through the similarity volume, utils/matching.py:6-26) — keys grad2/..., every parameter of dinov2
     groups["vit_all"] = ([(n, p) for n, p in net.named_parameters() if n.startswith("feature_extractor.dinov2.")],
                          res["loss_info"] + res["loss_2d_trans"] + res["loss_scale"] + res["loss_inplane"])
+    # the full training step: d(Loss()(end_points)["loss"]) / d(EVERY parameter) — keys grad3/...
+    groups["full"] = (list(net.named_parameters()), total)
     for gname, (params, loss) in groups.items():
         grads = torch.autograd.grad(loss, [p for _, p in params], retain_graph=True, allow_unused=True)
-        prefix = "grad2" if gname == "vit_all" else "grad"
+        prefix = {"vit_all": "grad2", "full": "grad3"}.get(gname, "grad")
         for (n, p), g in zip(params, grads):
             out[f"{prefix}used/{n}"] = np.bool_(g is not None)
             g = torch.zeros_like(p) if g is None else g
             flat = g.detach().reshape(-1)
-            stride = max(1, -(-flat.numel() // (GRAD_SAMPLES if prefix == "grad" else GRAD_SAMPLES // 16)))   # (the wide group: 176 tensors)
+            stride = max(1, -(-flat.numel() // {"grad": GRAD_SAMPLES, "grad2": GRAD_SAMPLES // 16, "grad3": GRAD_SAMPLES // 32}[prefix]))   # (176 / 380 tensors)
             out[f"{prefix}/{n}"] = flat[::stride].numpy()
             out[f"{prefix}norm/{n}"] = np.float64(flat.double().norm())
             print(gname, n, tuple(p.shape), "stride", stride, "norm %.4g" % float(flat.double().norm()))

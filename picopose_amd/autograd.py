@@ -7,13 +7,18 @@ twice (the residual stream, the two ViT passes over shared weights: autograd's o
 path is torch arithmetic.
 
 Scope (exactly the parameters that receive a gradient from `Net.forward_train`), by `Net.train_backward`:
-  * "vit+stage2" (= True, the default): the stage-1 and stage-2 losses train what the reference trains with them —
-      InfoNCE (utils/loss_utils.py:144-175) and the three stage-2 losses (:177-186, through the similarity volume of
-      utils/matching.py:6-26)  ->  EVERY ViT block, the patch embedding, cls token and position embedding (through the bicubic
-      resampling of vision_transformer.py:179-207); the stage-2 losses  ->  every parameter of `affine_regressor`;
-  * "slice1": the first slice only — stage-2 losses -> `affine_regressor` (the gradient stops at the similarity volume), InfoNCE ->
+  * "full" (= True, the default): the reference's training step — all ten losses under autograd, every parameter the reference
+      trains receives its gradient: the ViT (blocks, patch / cls / position embeddings), `affine_regressor`, the DPT head and the
+      flow decoder (stage 3 in training mode, unfused: im2col + engine GEMM convolutions, training-mode BatchNorm, align_corners
+      resize, ConvTranspose, feature warp, the fused correlation pyramid + lookup, flow / certainty losses — adjoints in
+      csrc/pp_backward3.hip);
+  * "vit+stage2": only the stage-1 and stage-2 losses (InfoNCE, utils/loss_utils.py:144-175; the three stage-2 losses, :177-186,
+      through the similarity volume of utils/matching.py:6-26) -> every ViT block, the embeddings, `affine_regressor`; stage 3
+      forward-only;
+  * "slice1": the first slice — stage-2 losses -> `affine_regressor` (the gradient stops at the similarity volume), InfoNCE ->
       the LAST ViT block (stops at its input).
-The stage-3 losses (DPT head, flow decoder) still run forward-only, so the ViT misses their contribution.
+Backward products run on range-normalised operands (`_ranged`: gradients span 1e-9 .. 1, the f16x3 operand format is full precision
+only above ~3e-5): each operand is scaled by a power of two chosen on the device from its max, the product is scaled back — exact.
 Parity: tests/test_train_gpu.py compares these gradients with the reference's own autograd on CPU (tests/golden/train_grads.npz).
 """
 import torch
@@ -48,11 +53,52 @@ def _ew(op, a, b, cols=0):
     return out
 
 
+def _pow2_scale(t):
+    """Device scalar 2^k with max|t| 2^k in [512, 1024): gradient tensors span 1e-9 .. 1, the engine's operand format holds
+    4 x as two fp16 terms (full 22 bits only above ~3e-5) — backward products are taken on range-normalised copies and scaled
+    back, exactly (powers of two).  No host sync; the scale never enters a value except through rounding."""
+    amax = t.detach().abs().amax().clamp_min(1e-30)
+    return torch.exp2(torch.floor(torch.log2(1024.0 / amax))).reshape(1)
+
+
+def _ranged(t):
+    """(range-normalised contiguous copy, its scale) — identity in fp32 engine mode."""
+    if ops.PRECISION == "f32":
+        return t, None
+    s = _pow2_scale(t)
+    return _ew(1, t.contiguous(), s, 1), s
+
+
+def _unscale(out, sa, sb, target=None):
+    """out / (sa sb) (exact), into `target` (a possibly strided view) when given."""
+    if sa is not None or sb is not None:
+        inv = 1.0 / ((sa if sa is not None else 1.0) * (sb if sb is not None else 1.0))
+        out = _ew(1, out, inv.reshape(1).float(), 1)
+    if target is not None:
+        target.copy_(out)
+        return target
+    return out
+
+
+def bmm_nn_b(a, b, out=None, alpha=1.0):
+    """Backward product out = alpha a @ b for 4-D views (Z0,Z1,M,K) x (Z0,Z1,K,N) with both operands range-normalised."""
+    a2, sa = _ranged(a)
+    b2, sb = _ranged(b)
+    tmp = torch.empty(a.shape[0], a.shape[1], a.shape[2], b.shape[3], dtype=torch.float32, device=a.device)
+    ops.bmm_nn(a2, b2, tmp, alpha=alpha)
+    return _unscale(tmp, sa, sb, out)
+
+
+def bmm_nt_b(a, b, alpha=1.0):
+    a2, sa = _ranged(a)
+    b2, sb = _ranged(b)
+    return _unscale(ops.bmm_nt(a2, b2, alpha=alpha), sa, sb)
+
+
 def _mm(a, b, alpha=1.0, out=None):
-    """a (M,K) @ b (K,N) on the GEMM engine (b rows contiguous)."""
-    o = ops.bmm_nn(a[None, None], b[None, None], torch.empty(1, 1, a.shape[0], b.shape[1], dtype=torch.float32, device=a.device) if out is None
-                   else out[None, None], alpha=alpha)
-    return o[0, 0]
+    """a (M,K) @ b (K,N) on the GEMM engine (b rows contiguous), operands range-normalised (backward products)."""
+    r = bmm_nn_b(a[None, None], b[None, None], None if out is None else out[None, None], alpha=alpha)
+    return r[0, 0]
 
 
 class _Linear(torch.autograd.Function):
@@ -153,15 +199,15 @@ class _Attention(torch.autograd.Function):
         v5 = qkv.view(B, T, 3, heads, hd)
         q, k, v = (v5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         dO = _f32c(dout).view(B, T, heads, hd).permute(0, 2, 1, 3)
-        dP = ops.bmm_nt(dO, v)                                                        # dO v^T
+        dP = bmm_nt_b(dO, v)                                                          # dO v^T
         dS = torch.empty_like(P)
         _lib.check(_lib.lib().pp_softmax_backward_rows(_p(P), _p(dP), B * heads * T, T, _p(dS), _lib.stream_ptr()), "pp_softmax_backward_rows")
         dqkv = torch.empty_like(qkv)
         d5 = dqkv.view(B, T, 3, heads, hd)
         s = float(hd) ** -0.5
-        ops.bmm_nn(dS, k.contiguous(), d5[:, :, 0].permute(0, 2, 1, 3), alpha=s)                          # dq = dS k / sqrt(hd)
-        ops.bmm_nn(dS.transpose(2, 3).contiguous(), q.contiguous(), d5[:, :, 1].permute(0, 2, 1, 3), alpha=s)   # dk = dS^T q / sqrt(hd)
-        ops.bmm_nn(P.transpose(2, 3).contiguous(), dO.contiguous(), d5[:, :, 2].permute(0, 2, 1, 3))      # dv = P^T dO
+        bmm_nn_b(dS, k.contiguous(), d5[:, :, 0].permute(0, 2, 1, 3), alpha=s)                          # dq = dS k / sqrt(hd)
+        bmm_nn_b(dS.transpose(2, 3).contiguous(), q.contiguous(), d5[:, :, 1].permute(0, 2, 1, 3), alpha=s)   # dk = dS^T q / sqrt(hd)
+        bmm_nn_b(P.transpose(2, 3).contiguous(), dO.contiguous(), d5[:, :, 2].permute(0, 2, 1, 3))      # dv = P^T dO
         return dqkv, None, None, None, None
 
 
@@ -336,8 +382,8 @@ class _SimilarityVolume(torch.autograd.Function):
                    "pp_simvol_backward")
         dr = torch.empty(1, B, P, C, dtype=torch.float32, device=ts.device)
         dq = torch.empty_like(dr)
-        ops.bmm_nn(dS[None], q.view(1, B, P, C), dr)                                # d tar_hat[t] = sum_s dS[t][s] src_hat[s]
-        ops.bmm_nn(dS.transpose(1, 2).contiguous()[None], r.view(1, B, P, C), dq)   # d src_hat[s] = sum_t dS[t][s] tar_hat[t]
+        bmm_nn_b(dS[None], q.view(1, B, P, C), dr)                                  # d tar_hat[t] = sum_s dS[t][s] src_hat[s]
+        bmm_nn_b(dS.transpose(1, 2).contiguous()[None], r.view(1, B, P, C), dq)     # d src_hat[s] = sum_t dS[t][s] tar_hat[t]
         grads = []
         for tok, dn in ((ts, dq), (tt, dr)):
             dx = torch.empty(B * P, C, dtype=torch.float32, device=ts.device)
@@ -413,3 +459,288 @@ def affine_regressor_forward(reg, sim):
 
 def infonce(tokens_src, tokens_tar, s_rows, t_rows, tau=0.1):
     return _InfoNCE.apply(tokens_src, tokens_tar, s_rows, t_rows, tau)
+
+
+# ---- stage 3 under autograd (DPT head + flow decoder in training mode, unfused) ---------------------------------------------------
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = _f32c(x)
+        ctx.act = ACT[act]
+        ctx.save_for_backward(x)
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().pp_act_forward(_p(x), x.numel(), ctx.act, _p(y), _lib.stream_ptr()), "pp_act_forward")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        _lib.check(_lib.lib().pp_act_backward(_p(x), _p(_f32c(dy)), x.numel(), ctx.act, _p(dx), _lib.stream_ptr()), "pp_act_backward")
+        return dx, None
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return _ew(2, _f32c(a), _f32c(b))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    """nn.BatchNorm2d in training mode on an NHWC map (+ ReLU): the forward is ops.batchnorm_train (running buffers updated)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, relu):
+        x = _f32c(x)
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.relu = relu
+        return ops.batchnorm_train(x, bn, relu=relu)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        C = x.shape[-1]
+        rows = x.numel() // C
+        L = _lib.lib()
+        nbytes = L.pp_batchnorm_train_backward_workspace_bytes(rows, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        dx = torch.empty_like(x)
+        dg, db = torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device)
+        _lib.check(L.pp_batchnorm_train_backward(_p(x), _p(gamma), _p(beta), _p(_f32c(dy)), rows, C, 1e-5, int(ctx.relu), _p(dx), _p(dg), _p(db),
+                                                 _p(ws), nbytes, _lib.stream_ptr()), "pp_batchnorm_train_backward")
+        return dx, dg, db, None, None
+
+
+def batchnorm_train(x, bn, relu=False):
+    return _BatchNormTrain.apply(x, bn.weight, bn.bias, bn, relu)
+
+
+class _Resize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, mul):
+        x = _f32c(x)
+        ctx.geom = (x.shape, Ho, Wo, mul)
+        return ops.resize_bilinear(x, Ho, Wo, mul=mul)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (B, H, W, C), Ho, Wo, mul = ctx.geom
+        dx = torch.empty(B, H, W, C, dtype=torch.float32, device=dy.device)
+        _lib.check(_lib.lib().pp_resize_bilinear_backward_nhwc(_p(_f32c(dy)), B, H, W, C, Ho, Wo, float(mul), _p(dx), _lib.stream_ptr()),
+                   "pp_resize_bilinear_backward_nhwc")
+        return dx, None, None, None
+
+
+def resize(x, Ho, Wo, mul=1.0):
+    return _Resize.apply(x, Ho, Wo, mul)
+
+
+class _Warp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, flow):
+        feat, flow = _f32c(feat), _f32c(flow)
+        ctx.save_for_backward(feat, flow)
+        return ops.warp(feat, flow)
+
+    @staticmethod
+    def backward(ctx, dy):
+        feat, flow = ctx.saved_tensors
+        B, H, W, C = feat.shape
+        dfeat = torch.zeros_like(feat)
+        dflow = torch.empty(B, H, W, 2, dtype=torch.float32, device=feat.device)
+        _lib.check(_lib.lib().pp_warp_backward_nhwc(_p(feat), _p(flow), _p(_f32c(dy)), B, H, W, C, flow.shape[-1], _p(dfeat), _p(dflow),
+                                                    _lib.stream_ptr()), "pp_warp_backward_nhwc")
+        return dfeat, dflow
+
+
+class _CorrLookup(torch.autograd.Function):
+    """CorrelationPyramid + CorrLookup (raft_decoder.py:30-53, utils/corr_lookup.py:100-134), fused in both directions: the
+    pyramid is never stored — level l is the correlation with the query map pooled l times."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, flow, levels, r, c_pad):
+        f1, f2, flow = _f32c(f1), _f32c(f2), _f32c(flow)
+        ctx.save_for_backward(f1, f2, flow)
+        ctx.cfg = (levels, r)
+        return ops.corr_lookup(f1, f2, flow, levels, r, c_pad=c_pad)
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+
+        f1, f2, flow = ctx.saved_tensors
+        levels, r = ctx.cfg
+        B, H, W, C = f1.shape
+        dout = _f32c(dout)
+        pyr = [f2]
+        for _ in range(levels - 1):
+            pyr.append(ops.avgpool2(pyr[-1]))
+        dpyr = [torch.zeros_like(t) for t in pyr]
+        df1 = torch.empty_like(f1)
+        dflow = torch.empty(B, H, W, 2, dtype=torch.float32, device=f1.device)
+        arr = ctypes.c_void_p * 3
+        fl = arr(*[_p(t) for t in pyr] + [None] * (3 - levels))
+        dl = arr(*[_p(t) for t in dpyr] + [None] * (3 - levels))
+        _lib.check(_lib.lib().pp_corr_lookup_backward_nhwc(_p(f1), fl, _p(flow), _p(dout), B, H, W, C, levels, r, flow.shape[-1], dout.shape[-1],
+                                                           _p(df1), dl, _p(dflow), _lib.stream_ptr()), "pp_corr_lookup_backward_nhwc")
+        for l in range(levels - 1, 0, -1):       # the pooling chain's adjoint, coarse to fine
+            t = dpyr[l - 1]
+            _lib.check(_lib.lib().pp_avgpool2_backward_nhwc(_p(dpyr[l]), B, t.shape[1], t.shape[2], C, 1, _p(t), _lib.stream_ptr()),
+                       "pp_avgpool2_backward_nhwc")
+        return df1, dpyr[0], dflow, None, None, None
+
+
+class _ConvTranspose(torch.autograd.Function):
+    """ConvTranspose2d(kernel = stride = r) on NHWC (dpt.py resize_layers 0 / 1): a GEMM whose store is a pixel shuffle."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, r):
+        x = _f32c(x)
+        wp, bp = ops.pack_convT_weight(weight.detach().float(), bias.detach().float())
+        ctx.save_for_backward(x, wp)
+        ctx.r, ctx.wshape = r, weight.shape
+        return ops.conv_transpose2d(x, wp, bp, r)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp = ctx.saved_tensors
+        r = ctx.r
+        B, H, W, Cin = x.shape
+        Cout = wp.shape[0] // (r * r)
+        d = _f32c(dy).view(B, H, r, W, r, Cout).permute(0, 1, 3, 2, 4, 5).reshape(B * H * W, r * r * Cout)   # un-shuffle (a copy)
+        dx = _mm(d, wp).view(B, H, W, Cin)
+        dwp = _mm(d.t().contiguous(), x.view(-1, Cin))                                                       # (r r Cout, Cin)
+        dw = dwp.view(r, r, Cout, Cin).permute(3, 2, 0, 1).contiguous()                                      # -> (Cin, Cout, r, r)
+        db = colsum(d.view(-1, Cout))
+        return dx, dw, db, None
+
+
+class _FlowLoss(torch.autograd.Function):
+    """One level of compute_stage_three_loss (utils/loss_utils.py:188-202): (loss_flow, loss_certainty) of NHWC maps."""
+
+    @staticmethod
+    def forward(ctx, flow, cert, tar_pts, flow_weight, mask_weight, max_flow, eps):
+        fl, ce, tp = _f32c(flow), _f32c(cert), _f32c(tar_pts)
+        B, H, W, _ = fl.shape
+        L = _lib.lib()
+        part = torch.empty(L.pp_flow_loss_blocks(), 3, dtype=torch.float64, device=fl.device)
+        _lib.check(L.pp_flow_loss_sums(_p(fl), _p(ce), _p(tp), B, H, W, float(max_flow), _p(part), _lib.stream_ptr()), "pp_flow_loss_sums")
+        bce, l1, cnt = part.sum(0)
+        ctx.save_for_backward(fl, ce, tp, cnt)
+        ctx.cfg = (flow_weight, mask_weight, max_flow, eps)
+        return (flow_weight * l1 / (cnt + eps)).float(), (mask_weight * bce / (B * H * W)).float()
+
+    @staticmethod
+    def backward(ctx, up_f, up_c):
+        fl, ce, tp, cnt = ctx.saved_tensors
+        fw, mw, max_flow, eps = ctx.cfg
+        B, H, W, _ = fl.shape
+        gf = (up_f.double() * fw / (cnt + eps)).float().reshape(1).contiguous()      # two device scalars (no host sync)
+        gc = (up_c.double() * mw / (B * H * W)).float().reshape(1).contiguous()
+        dfl, dce = torch.empty_like(fl), torch.empty_like(ce)
+        _lib.check(_lib.lib().pp_flow_loss_backward(_p(fl), _p(ce), _p(tp), B, H, W, float(max_flow), _p(gf), _p(gc), _p(dfl), _p(dce),
+                                                    _lib.stream_ptr()), "pp_flow_loss_backward")
+        return dfl, dce, None, None, None, None, None
+
+
+def flow_level_losses(flow, cert, tar_pts, mask_weight=1.0, flow_weight=0.1, max_flow=400.0, eps=1e-10):
+    return _FlowLoss.apply(flow, cert, tar_pts, flow_weight, mask_weight, max_flow, eps)
+
+
+def conv2d(x, weight, bias, k, stride=1, pad=0, act=None, cin_pad=None):
+    """NHWC convolution under autograd: x (B,H,W,Cx), weight in torch layout (Cout, Cin, k, k) (Cx = cin_pad >= Cin: the map carries
+    zero pad channels).  1x1: a linear layer on the pixels; otherwise im2col + linear (dgrad through col2im)."""
+    B, H, W, Cx = x.shape
+    Cout = weight.shape[0]
+    if k == 1 and stride == 1 and pad == 0:
+        w2 = weight.reshape(Cout, -1)
+        if Cx > w2.shape[1]:
+            w2 = torch.cat([w2, w2.new_zeros(Cout, Cx - w2.shape[1])], dim=1)
+        return linear(x.reshape(-1, Cx), w2.contiguous(), bias, act=act).view(B, H, W, Cout)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    w2 = ops.pack_conv_weight(weight.float(), cin_pad=Cx if Cx > weight.shape[1] else None)
+    return linear(_Im2col.apply(x, k, stride, pad), w2, bias, act=act).view(B, Ho, Wo, Cout)
+
+
+def _rcu(u, x, extra=None):
+    """ResidualConvUnit in training mode (dpt.py:72-95): bn2(conv2(relu(bn1(conv1(relu(x)))))) + x (+ the fusion block's other input)."""
+    h = conv2d(_Act.apply(x, "relu"), u.conv1.weight, u.conv1.bias, 3, pad=1)
+    h = batchnorm_train(h, u.bn1, relu=True)
+    h = conv2d(h, u.conv2.weight, u.conv2.bias, 3, pad=1)
+    h = add(batchnorm_train(h, u.bn2), x)
+    return h if extra is None else add(h, extra)
+
+
+def dpt_head_forward(dpt, feats):
+    """DPTHead.forward (dpt.py:252-272) in training mode under autograd: feats = 4 NHWC maps (B,16,16,C) -> [path_4, path_3, path_2]."""
+    r, s = dpt.resize_layers, dpt.scratch
+    x = [conv2d(f, dpt.projects[i].weight, dpt.projects[i].bias, 1) for i, f in enumerate(feats)]
+    l1 = _ConvTranspose.apply(x[0], getattr(r, "0").weight, getattr(r, "0").bias, 4)
+    l2 = _ConvTranspose.apply(x[1], getattr(r, "1").weight, getattr(r, "1").bias, 2)
+    l3 = x[2]
+    l4 = conv2d(x[3], getattr(r, "3").weight, getattr(r, "3").bias, 3, stride=2, pad=1)
+    rn = [conv2d(l, getattr(s, f"layer{i + 1}_rn").weight, None, 3, pad=1) for i, l in enumerate((l1, l2, l3, l4))]
+
+    def fuse(i, size, x0, x1=None):
+        f = getattr(s, f"refinenet{i}")
+        out = x0 if x1 is None else _rcu(f.resConfUnit1, x1, extra=x0)
+        out = _rcu(f.resConfUnit2, out)
+        out = resize(out, size[0], size[1])
+        return conv2d(out, f.out_conv.weight, f.out_conv.bias, 1)
+
+    p4 = fuse(4, rn[2].shape[1:3], rn[3])
+    p3 = fuse(3, rn[1].shape[1:3], p4, rn[2])
+    p2 = fuse(2, rn[0].shape[1:3], p3, rn[1])
+    dpt.bn_moved()
+    return [p4, p3, p2]
+
+
+def flow_decoder_forward(fd, feat_render_list, feat_real_list, flow, cert):
+    """FlowDecoder.forward (flow_decoder.py:74-94, forward_flow :58-72) in training mode under autograd, NHWC."""
+    flows, certs = [], []
+    for l in range(fd.num_levels):
+        pj, e, fp, mp = fd.proj[l], fd.encoder[l], fd.flow_pred[l], fd.mask_pred[l]
+        c0, bn = getattr(pj, "0"), getattr(pj, "1")
+        fr = batchnorm_train(conv2d(feat_render_list[l], c0.weight, c0.bias, 1), bn)      # render maps first (flow_decoder.py:78)
+        fq = batchnorm_train(conv2d(feat_real_list[l], c0.weight, c0.bias, 1), bn)
+        B, H, W, _ = fr.shape
+        ncorr = (l + 1) * (2 * fd.r + 1) ** 2
+        corr = _CorrLookup.apply(fr, fq, flow, l + 1, fd.r, -(-ncorr // 8) * 8)
+        cn0, cn1 = getattr(e.corr_net, "0").conv, getattr(e.corr_net, "1").conv
+        c = conv2d(conv2d(corr, cn0.weight, cn0.bias, 1, act="relu"), cn1.weight, cn1.bias, 3, pad=1, act="relu")
+        fn0, fn1 = getattr(e.flow_net, "0").conv, getattr(e.flow_net, "1").conv
+        flow8 = torch.cat([flow, flow.new_zeros(B, H, W, 6)], dim=-1)
+        f = conv2d(conv2d(flow8, fn0.weight, fn0.bias, 7, pad=3, act="relu"), fn1.weight, fn1.bias, 3, pad=1, act="relu")
+        on = getattr(e.out_net, "0").conv
+        out = conv2d(torch.cat([c, f], dim=-1), on.weight, on.bias, 3, pad=1, act="relu")
+        X = torch.cat([fr, _Warp.apply(fq, flow), out, flow], dim=-1)                       # [render | warped real | motion (126 + flow)]
+
+        def head(hd, k_last):
+            h = conv2d(X, getattr(hd.layers, "0").conv.weight, getattr(hd.layers, "0").conv.bias, 3, pad=1, act="relu")
+            h = conv2d(h, getattr(hd.layers, "1").conv.weight, getattr(hd.layers, "1").conv.bias, 3, pad=1, act="relu")
+            return conv2d(h, hd.predict_layer.weight, hd.predict_layer.bias, k_last, pad=k_last // 2)
+
+        flow = add(flow, head(fp, 3))
+        cert = add(cert, head(mp, 1))
+        flows.append(flow)
+        certs.append(cert)
+        if l != fd.num_levels - 1:
+            flow = resize(flow, 2 * H, 2 * W, mul=2.0)
+            cert = resize(cert, 2 * H, 2 * W)
+    fd.bn_moved()
+    return flows, certs
+
+
+def offset_regressor_forward(orr, feats_tem, feats_real, init_flow, init_cert):
+    """OffsetRegressor.forward (offset_regressor.py:16-19) in training mode under autograd (template maps first)."""
+    tem = dpt_head_forward(orr.dpt_head, feats_tem)
+    real = dpt_head_forward(orr.dpt_head, feats_real)
+    return flow_decoder_forward(orr.flow_decoder, tem, real, init_flow, init_cert)

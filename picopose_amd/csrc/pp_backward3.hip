@@ -1,0 +1,432 @@
+// Adjoint kernels of stage 3's training path (picopose_amd/autograd.py: offset_regressor_forward): BatchNorm in training mode,
+// bilinear resize (align_corners=True), the feature warp, the fused correlation pyramid + lookup, 2x2 average pooling and the
+// flow / certainty losses.  Convolutions go through pp_im2col_nhwc / pp_col2im_nhwc + pp_gemm (pp_backward.hip).  Every kernel
+// restates the FORWARD kernel's own coordinate arithmetic (pp_sample.hip, pp_train.hip) so that value and gradient describe the
+// same function; reductions over rows run in double in a fixed order, scatters (warp / lookup into the sampled maps) are fp32
+// atomic adds.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/picopose_hip.h"
+#include "pp_common.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+inline int grid_for(long long n) { return (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384); }
+
+// ---------------------------------------------------------------------------------------------------------- BatchNorm (training)
+// y = relu?(gamma xhat + beta), xhat = (x - mean) rstd with the batch statistics (biased variance): per channel
+//   g = dy [y > 0],  dgamma = sum g xhat,  dbeta = sum g,  dx = gamma rstd (g - mean(g) - xhat mean(g xhat))
+constexpr int BNB_ROWS = 256;
+
+__global__ __launch_bounds__(256) void bnb_stats_kernel(const float* __restrict__ x, int rows, int C, double* __restrict__ part) {
+    const int r0 = blockIdx.x * BNB_ROWS, r1 = min(rows, r0 + BNB_ROWS);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s = 0.0, q = 0.0;
+        for (int r = r0; r < r1; ++r) {
+            const double v = (double)x[(size_t)r * C + c];
+            s += v;
+            q = fma(v, v, q);
+        }
+        part[((size_t)blockIdx.x * C + c) * 2] = s;
+        part[((size_t)blockIdx.x * C + c) * 2 + 1] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void bnb_stats_finish_kernel(const double* __restrict__ part, int nblk, int rows, int C, float eps,
+                                                               float* __restrict__ mean, float* __restrict__ rstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        s += part[((size_t)k * C + c) * 2];
+        q += part[((size_t)k * C + c) * 2 + 1];
+    }
+    const double m = s / rows;
+    double var = q / rows - m * m;
+    var = var > 0.0 ? var : 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void bnb_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, int rows, int C, int relu, double* __restrict__ part) {
+    const int r0 = blockIdx.x * BNB_ROWS, r1 = min(rows, r0 + BNB_ROWS);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float m = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+        double s = 0.0, q = 0.0;
+        for (int r = r0; r < r1; ++r) {
+            const float xh = (x[(size_t)r * C + c] - m) * rs;
+            float g = dy[(size_t)r * C + c];
+            if (relu && !(fmaf(xh, ga, be) > 0.f)) g = 0.f;
+            s += (double)g;
+            q = fma((double)g, (double)xh, q);
+        }
+        part[((size_t)blockIdx.x * C + c) * 2] = s;
+        part[((size_t)blockIdx.x * C + c) * 2 + 1] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void bnb_sums_finish_kernel(const double* __restrict__ part, int nblk, int rows, int C,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ mg, float* __restrict__ mgx) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        s += part[((size_t)k * C + c) * 2];
+        q += part[((size_t)k * C + c) * 2 + 1];
+    }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+    mg[c] = (float)(s / rows);
+    mgx[c] = (float)(q / rows);
+}
+
+__global__ __launch_bounds__(256) void bnb_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ mg,
+                                                     const float* __restrict__ mgx, long long n, int C, int relu, float* __restrict__ dx) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float xh = (x[i] - mean[c]) * rstd[c];
+        float g = dy[i];
+        if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.f)) g = 0.f;
+        dx[i] = gamma[c] * rstd[c] * (g - mg[c] - xh * mgx[c]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- bilinear resize
+// adjoint of resize_kernel (pp_sample.hip: src = dst (in - 1) / (out - 1), taps i0 = (int)src and i1 = min(i0 + 1, in - 1)) in
+// GATHER form: an input pixel collects from the output pixels whose two taps include it — a fixed order, no atomics.
+__device__ __forceinline__ void resize_taps(int o, float s, int in, int& i0, int& i1, float& l) {
+    const float f = s * (float)o;
+    i0 = (int)f;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l = f - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void resize_backward_kernel(const float* __restrict__ dy, int H, int W, int C, int Ho, int Wo, float mul,
+                                                              long long total, float* __restrict__ dx) {
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long long q = i / C;
+        const int ix = (int)(q % W);
+        q /= W;
+        const int iy = (int)(q % H);
+        const long long b = q / H;
+        // candidate outputs: src in (i - 1, i + 1)
+        int oy0 = 0, oy1 = Ho - 1, ox0 = 0, ox1 = Wo - 1;
+        if (sy > 0.f) {
+            oy0 = max(0, (int)floorf(((float)iy - 1.f) / sy) - 1);
+            oy1 = min(Ho - 1, (int)ceilf(((float)iy + 1.f) / sy) + 1);
+        }
+        if (sx > 0.f) {
+            ox0 = max(0, (int)floorf(((float)ix - 1.f) / sx) - 1);
+            ox1 = min(Wo - 1, (int)ceilf(((float)ix + 1.f) / sx) + 1);
+        }
+        float acc = 0.f;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            int y0, y1;
+            float ly;
+            resize_taps(oy, sy, H, y0, y1, ly);
+            const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                int x0, x1;
+                float lx;
+                resize_taps(ox, sx, W, x0, x1, lx);
+                const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                if (wx != 0.f) acc = fmaf(wy * wx, dy[((b * Ho + oy) * Wo + ox) * C + c], acc);
+            }
+        }
+        dx[i] = acc * mul;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- 2x2 average pooling
+__global__ __launch_bounds__(256) void avgpool2_backward_kernel(const float* __restrict__ dy, int H, int W, int C, long long total,
+                                                                int accumulate, float* __restrict__ dx) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long long q = i / C;
+        const int x = (int)(q % W);
+        q /= W;
+        const int y = (int)(q % H);
+        const long long b = q / H;
+        float v = 0.f;
+        if ((y >> 1) < Ho && (x >> 1) < Wo) v = 0.25f * dy[((b * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c];
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+
+// coordinate round trip of the forward kernels (pp_sample.hip: roundtrip)
+__device__ __forceinline__ float roundtrip(float x, int size) {
+    const float n = x * 2.f / (float)(size - 1 > 1 ? size - 1 : 1) - 1.f;
+    return ((n + 1.f) / 2.f) * (float)(size - 1);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------- feature warp
+// adjoint of warp_kernel: out[p] = bilinear(feat, p + flow[p]), zeros padding.  One wave per pixel, lanes over channels.
+__global__ __launch_bounds__(256) void warp_backward_kernel(const float* __restrict__ feat, const float* __restrict__ flow,
+                                                            const float* __restrict__ dy, int H, int W, int C, int ld_flow,
+                                                            float* __restrict__ dfeat, float* __restrict__ dflow) {
+    const int b = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    const float* fl = flow + ((size_t)b * H * W + p) * ld_flow;
+    const float rx = roundtrip((float)x + fl[0], W), ry = roundtrip((float)y + fl[1], H);
+    const float ix = fminf(fmaxf(rx, -2.f), (float)W + 1.f), iy = fminf(fmaxf(ry, -2.f), (float)H + 1.f);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix, wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+    const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1), ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
+    const size_t base = (size_t)b * H * W * C;
+    const float* g = dy + ((size_t)b * H * W + p) * C;
+    float gx = 0.f, gy = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = g[c];
+        const float t00 = vy0 && vx0 ? feat[base + ((size_t)ya * W + xa) * C + c] : 0.f;
+        const float t01 = vy0 && vx1 ? feat[base + ((size_t)ya * W + xb) * C + c] : 0.f;
+        const float t10 = vy1 && vx0 ? feat[base + ((size_t)yb * W + xa) * C + c] : 0.f;
+        const float t11 = vy1 && vx1 ? feat[base + ((size_t)yb * W + xb) * C + c] : 0.f;
+        gx = fmaf(d, (t01 - t00) * wy0 + (t11 - t10) * wy1, gx);
+        gy = fmaf(d, (t10 - t00) * wx0 + (t11 - t01) * wx1, gy);
+        if (vy0 && vx0) atomicAdd(dfeat + base + ((size_t)ya * W + xa) * C + c, d * (wx0 * wy0));
+        if (vy0 && vx1) atomicAdd(dfeat + base + ((size_t)ya * W + xb) * C + c, d * (wx1 * wy0));
+        if (vy1 && vx0) atomicAdd(dfeat + base + ((size_t)yb * W + xa) * C + c, d * (wx0 * wy1));
+        if (vy1 && vx1) atomicAdd(dfeat + base + ((size_t)yb * W + xb) * C + c, d * (wx1 * wy1));
+    }
+    gx = wave_sum(gx);
+    gy = wave_sum(gy);
+    if (lane == 0) {   // (a clamped coordinate is outside every tap's range: all taps invalid, the sums above are zero)
+        dflow[((size_t)b * H * W + p) * 2] = rx == ix ? gx : 0.f;
+        dflow[((size_t)b * H * W + p) * 2 + 1] = ry == iy ? gy : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- correlation lookup
+// adjoint of corr_lookup_kernel (pp_sample.hip): corr_l[p, q] = <f1[p], pool_l(f2)[q]> / sqrt(C), output channel
+// l win^2 + a win + b = bilinear sample of corr_l[p, .] at ((p + flow[p]) / 2^l) + (a - r, b - r), zeros padding.
+// One wave per pixel: the (2r+2)^2 table positions per level are visited one after the other, lanes over channels.
+constexpr int CLB_MAXL = 3, CLB_TW = 8;   // levels, table width for r <= 3
+
+__global__ __launch_bounds__(256) void corr_lookup_backward_kernel(const float* __restrict__ f1, const float* __restrict__ f2l0,
+                                                                   const float* __restrict__ f2l1, const float* __restrict__ f2l2,
+                                                                   const float* __restrict__ flow, const float* __restrict__ dout, int H,
+                                                                   int W, int C, int L, int r, int ld_flow, int ld_dout, float inv_sqrt_c,
+                                                                   float* __restrict__ df1, float* __restrict__ df2l0,
+                                                                   float* __restrict__ df2l1, float* __restrict__ df2l2,
+                                                                   float* __restrict__ dflow) {
+    __shared__ float dtab_s[4][CLB_MAXL * CLB_TW * CLB_TW];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y, p = blockIdx.x * 4 + wv;
+    if (p >= H * W) return;
+    float* dtab = dtab_s[wv];
+    const int y = p / W, x = p - y * W;
+    const int tw = 2 * r + 2, win = 2 * r + 1;
+    const float* fl = flow + ((size_t)b * H * W + p) * ld_flow;
+    const float gx0 = (float)x + fl[0], gy0 = (float)y + fl[1];
+    const float* a = f1 + ((size_t)b * H * W + p) * C;
+    const float* g = dout + ((size_t)b * H * W + p) * ld_dout;
+    float dfx = 0.f, dfy = 0.f;           // gradient of the flow (lane-partial)
+    // accumulators of df1[p]: up to 4 channels per lane (C <= 256)
+    float acc1[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < L; ++l) {
+        const int Hl = H >> l, Wl = W >> l;
+        const float sc = (float)(1 << l);
+        const float rx = roundtrip(gx0 / sc, Wl), ry = roundtrip(gy0 / sc, Hl);
+        const float cx = fminf(fmaxf(rx, -(float)(r + 2)), (float)(Wl + r + 1)), cy = fminf(fmaxf(ry, -(float)(r + 2)), (float)(Hl + r + 1));
+        const int bx = (int)floorf(cx) - r, by = (int)floorf(cy) - r;
+        const float wx1 = cx - floorf(cx), wy1 = cy - floorf(cy), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const float* f2 = l == 0 ? f2l0 : (l == 1 ? f2l1 : f2l2);
+        float* df2 = l == 0 ? df2l0 : (l == 1 ? df2l1 : df2l2);
+        const size_t lb = (size_t)b * Hl * Wl * C;
+        // dtab[dy][dx] = sum over the outputs (a, b) whose four corners include (dy, dx)
+        for (int i = lane; i < tw * tw; i += 64) {
+            const int dy_ = i / tw, dx_ = i - dy_ * tw;
+            float s = 0.f;
+#pragma unroll
+            for (int cy_ = 0; cy_ < 2; ++cy_)
+#pragma unroll
+                for (int cx_ = 0; cx_ < 2; ++cx_) {
+                    const int bi = dy_ - cy_, ai = dx_ - cx_;      // output (ai, bi) has this position as corner (cy_, cx_)
+                    if (ai >= 0 && ai < win && bi >= 0 && bi < win)
+                        s = fmaf(g[l * win * win + ai * win + bi], (cx_ ? wx1 : wx0) * (cy_ ? wy1 : wy0), s);
+                }
+            dtab[l * CLB_TW * CLB_TW + i] = s;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        // the table VALUES are needed for the coordinate gradient: value(dy, dx) = <f1[p], f2_l[q]> / sqrt(C) or 0 outside
+        float gcx = 0.f, gcy = 0.f;
+        for (int i = 0; i < tw * tw; ++i) {
+            const int dy_ = i / tw, dx_ = i - dy_ * tw;
+            const int qx = bx + dx_, qy = by + dy_;
+            if (!(qx >= 0 && qx < Wl && qy >= 0 && qy < Hl)) continue;   // (wave-uniform)
+            const float* qv = f2 + lb + ((size_t)qy * Wl + qx) * C;
+            float* dq = df2 + lb + ((size_t)qy * Wl + qx) * C;
+            const float dt = dtab[l * CLB_TW * CLB_TW + i] * inv_sqrt_c;
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = lane + 64 * k;
+                if (c < C) {
+                    const float u = a[c], v = qv[c];
+                    dot = fmaf(u, v, dot);
+                    acc1[k] = fmaf(dt, v, acc1[k]);
+                    if (dt != 0.f) atomicAdd(dq + c, dt * u);
+                }
+            }
+            const float val = wave_sum(dot) * inv_sqrt_c;
+            // d out(ai, bi) / d wx1 for the outputs that use this position: corner (cy_, cx_) carries sign (cx_ ? +1 : -1) wy
+            float sx = 0.f, sy = 0.f;
+#pragma unroll
+            for (int cy_ = 0; cy_ < 2; ++cy_)
+#pragma unroll
+                for (int cx_ = 0; cx_ < 2; ++cx_) {
+                    const int bi = dy_ - cy_, ai = dx_ - cx_;
+                    if (ai >= 0 && ai < win && bi >= 0 && bi < win) {
+                        const float go = g[l * win * win + ai * win + bi];
+                        sx = fmaf(go, (cx_ ? 1.f : -1.f) * (cy_ ? wy1 : wy0), sx);
+                        sy = fmaf(go, (cy_ ? 1.f : -1.f) * (cx_ ? wx1 : wx0), sy);
+                    }
+                }
+            gcx = fmaf(val, sx, gcx);
+            gcy = fmaf(val, sy, gcy);
+        }
+        if (rx == cx) dfx += gcx / sc;   // (every lane holds the same sums)
+        if (ry == cy) dfy += gcy / sc;
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) df1[((size_t)b * H * W + p) * C + c] = acc1[k];
+    }
+    if (lane == 0) {
+        dflow[((size_t)b * H * W + p) * 2] = dfx;
+        dflow[((size_t)b * H * W + p) * 2 + 1] = dfy;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- flow / certainty losses
+// adjoint of flow_loss_kernel (pp_train.hip; utils/loss_utils.py:119-125, RAFTLoss :24-39): gf = upstream * weight / (count + eps),
+// gc = upstream * weight / (B H W) are formed by the caller.
+constexpr int KP_GRID = 64, KP_N = KP_GRID * KP_GRID;
+
+__global__ __launch_bounds__(256) void flow_loss_backward_kernel(const float* __restrict__ flow, const float* __restrict__ cert,
+                                                                 const float* __restrict__ tar_pts, int B, int H, int W, float max_flow,
+                                                                 const float* __restrict__ gf, const float* __restrict__ gc,
+                                                                 float* __restrict__ dflow, float* __restrict__ dcert) {
+    const long long total = (long long)B * H * W;
+    const float kf = gf[0], kc = gc[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((long long)W * H));
+        const int iy = min((int)floorf((float)y * ((float)KP_GRID / H)), KP_GRID - 1);
+        const int ix = min((int)floorf((float)x * ((float)KP_GRID / W)), KP_GRID - 1);
+        const float* p = tar_pts + ((size_t)b * KP_N + (size_t)ix * KP_GRID + iy) * 2;
+        const bool valid = p[0] != -1.f && p[1] != -1.f;
+        const float k = (float)H / KP_GRID;
+        const float g0 = (valid ? k * p[0] : 0.f) - (float)x, g1 = (valid ? k * p[1] : 0.f) - (float)y;
+        const float z = cert[i], t = valid ? 1.f : 0.f;
+        dcert[i] = kc * (1.f / (1.f + expf(-z)) - t);
+        float d0 = 0.f, d1 = 0.f;
+        if (valid && sqrtf(g0 * g0 + g1 * g1) < max_flow) {
+            const float e0 = flow[2 * i] - g0, e1 = flow[2 * i + 1] - g1;
+            d0 = e0 > 0.f ? kf : (e0 < 0.f ? -kf : 0.f);
+            d1 = e1 > 0.f ? kf : (e1 < 0.f ? -kf : 0.f);
+        }
+        dflow[2 * i] = d0;
+        dflow[2 * i + 1] = d1;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pp_batchnorm_train_backward_workspace_bytes(long long rows, int C) {
+    const long long nblk = (rows + BNB_ROWS - 1) / BNB_ROWS;
+    return (size_t)nblk * C * 2 * sizeof(double) + (size_t)4 * C * sizeof(float);
+}
+
+int pp_batchnorm_train_backward(const float* x, const float* gamma, const float* beta, const float* dy, long long rows, int C, float eps,
+                                int relu, float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0) return PP_EINVAL;
+    if (workspace_bytes < pp_batchnorm_train_backward_workspace_bytes(rows, C)) return PP_EWORKSPACE;
+    const int nblk = (int)((rows + BNB_ROWS - 1) / BNB_ROWS);
+    double* part = (double*)workspace;
+    float* mean = (float*)(part + (size_t)nblk * C * 2);
+    float *rstd = mean + C, *mg = rstd + C, *mgx = mg + C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bnb_stats_kernel, dim3(nblk), dim3(256), 0, st, x, (int)rows, C, part);
+    hipLaunchKernelGGL(bnb_stats_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)part, nblk, (int)rows, C, eps, mean, rstd);
+    hipLaunchKernelGGL(bnb_sums_kernel, dim3(nblk), dim3(256), 0, st, x, dy, gamma, beta, (const float*)mean, (const float*)rstd, (int)rows, C, relu, part);
+    hipLaunchKernelGGL(bnb_sums_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)part, nblk, (int)rows, C, dgamma, dbeta, mg, mgx);
+    const long long n = rows * C;
+    hipLaunchKernelGGL(bnb_dx_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, dy, gamma, beta, (const float*)mean, (const float*)rstd,
+                       (const float*)mg, (const float*)mgx, n, C, relu, dx);
+    return pp_last_launch();
+}
+
+int pp_resize_bilinear_backward_nhwc(const float* dy, int B, int H, int W, int C, int Ho, int Wo, float mul, float* dx, void* stream) {
+    if (!dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return PP_EINVAL;
+    const long long total = (long long)B * H * W * C;
+    hipLaunchKernelGGL(resize_backward_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, H, W, C, Ho, Wo, mul, total, dx);
+    return pp_last_launch();
+}
+
+int pp_avgpool2_backward_nhwc(const float* dy, int B, int H, int W, int C, int accumulate, float* dx, void* stream) {
+    if (!dy || !dx || B <= 0 || H < 2 || W < 2 || C <= 0) return PP_EINVAL;
+    const long long total = (long long)B * H * W * C;
+    hipLaunchKernelGGL(avgpool2_backward_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, H, W, C, total, accumulate, dx);
+    return pp_last_launch();
+}
+
+int pp_warp_backward_nhwc(const float* feat, const float* flow, const float* dy, int B, int H, int W, int C, int ld_flow, float* dfeat,
+                          float* dflow, void* stream) {
+    if (!feat || !flow || !dy || !dfeat || !dflow || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld_flow < 2) return PP_EINVAL;
+    hipLaunchKernelGGL(warp_backward_kernel, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, flow, dy, H, W, C, ld_flow, dfeat,
+                       dflow);
+    return pp_last_launch();
+}
+
+int pp_corr_lookup_backward_nhwc(const float* f1, const float* const* f2_levels, const float* flow, const float* dout, int B, int H, int W,
+                                 int C, int levels, int radius, int ld_flow, int ld_dout, float* df1, float* const* df2_levels, float* dflow,
+                                 void* stream) {
+    if (!f1 || !f2_levels || !flow || !dout || !df1 || !df2_levels || !dflow || B <= 0 || H <= 0 || W <= 0) return PP_EINVAL;
+    if (levels < 1 || levels > CLB_MAXL || radius < 0 || 2 * radius + 2 > CLB_TW || C <= 0 || C > 256 || ld_flow < 2) return PP_EINVAL;
+    if (ld_dout < levels * (2 * radius + 1) * (2 * radius + 1)) return PP_EINVAL;
+    for (int l = 0; l < levels; ++l)
+        if (!f2_levels[l] || !df2_levels[l]) return PP_EINVAL;
+    hipLaunchKernelGGL(corr_lookup_backward_kernel, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, f1, f2_levels[0],
+                       levels > 1 ? f2_levels[1] : nullptr, levels > 2 ? f2_levels[2] : nullptr, flow, dout, H, W, C, levels, radius, ld_flow,
+                       ld_dout, 1.0f / sqrtf((float)C), df1, df2_levels[0], levels > 1 ? df2_levels[1] : nullptr,
+                       levels > 2 ? df2_levels[2] : nullptr, dflow);
+    return pp_last_launch();
+}
+
+int pp_flow_loss_backward(const float* flow, const float* certainty, const float* tar_pts, int B, int H, int W, float max_flow,
+                          const float* g_flow, const float* g_cert, float* dflow, float* dcertainty, void* stream) {
+    if (!flow || !certainty || !tar_pts || !g_flow || !g_cert || !dflow || !dcertainty || B <= 0 || H <= 0 || W <= 0) return PP_EINVAL;
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(flow_loss_backward_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, flow, certainty, tar_pts, B, H, W,
+                       max_flow, g_flow, g_cert, dflow, dcertainty);
+    return pp_last_launch();
+}
+
+}  // extern "C"

@@ -36,7 +36,7 @@ class Net(nn.Module):
         # (NHWC, hypothesis-major when batched) of the latest forward in self.last_stage3
         self.keep_stage3 = False
         self.last_stage3 = None
-        self.train_backward = True   # True / "vit+stage2" | "slice1" | False: what trains under autograd (picopose_amd/autograd.py)
+        self.train_backward = True   # True / "full" | "vit+stage2" | "slice1" | False: what trains under autograd (picopose_amd/autograd.py)
 
     # model/picopose.py:52-70 — pick hypothesis k's template for every crop (pure indexing)
     def select_template_data(self, end_points, pred_id_src, k):
@@ -172,17 +172,18 @@ class Net(nn.Module):
         """The training forward: key-point ground truth, both ViT passes, the InfoNCE / stage-2 / flow + certainty losses,
         BatchNorm layers on batch statistics (running buffers updated).  Returns `end_points` with the `loss*` entries the
         reference adds (utils/loss_utils.Loss sums them).  With autograd enabled the backward of picopose_amd/autograd.py is live,
-        scope by `self.train_backward`: True / "vit+stage2" (default) — `loss_info` and the three stage-2 losses carry a graph
-        through the similarity volume and EVERY ViT block down to the patch embedding, cls token and position embedding, and to
-        every parameter of the affine regressor; "slice1" — the first slice (affine regressor from the stage-2 losses, last ViT
-        block from InfoNCE); False — forward values only.  `Loss()(end_points)["loss"].backward()` fills exactly those `.grad`s;
-        the stage-3 losses are forward values without a graph (no backward kernels for the DPT head / flow decoder yet).  pred_Ms: the noisy ground-truth affines of stage 3;
+        scope by `self.train_backward`: True / "full" (default) — all ten losses carry a graph: `Loss()(end_points)["loss"].
+        backward()` is the reference's training step (every parameter the reference trains receives its gradient: the ViT, the
+        affine regressor, the DPT head, the flow decoder); "vit+stage2" — only `loss_info` and the three stage-2 losses (through
+        the similarity volume, every ViT block, the embeddings, the affine regressor), stage 3 forward-only; "slice1" — the first
+        slice (affine regressor from the stage-2 losses, last ViT block from InfoNCE); False — forward values only.  pred_Ms: the noisy ground-truth affines of stage 3;
         drawn by utils/augment.aug_gtM_noise when not given (tests pass the ones a reference run drew)."""
         from . import autograd as ag
         from .utils.loss_utils import infonce_index_rows
 
         live = torch.is_grad_enabled() and bool(self.train_backward)
-        wide = live and self.train_backward != "slice1"          # "vit+stage2" (True): the whole ViT + stage 2 from the stage-1/2 losses
+        wide = live and self.train_backward != "slice1"          # the whole ViT + stage 2 from the stage-1/2 losses
+        full = wide and self.train_backward != "vit+stage2"      # True / "full": stage 3 under autograd too — the reference's training step
         fe, orr = self.feature_extractor, self.offset_regressor
         with torch.no_grad():
             kp = self.compute_keypoint_data(end_points)
@@ -202,8 +203,9 @@ class Net(nn.Module):
                 with torch.no_grad():
                     sim = matching_features_similarity(ops.tokens_to_nchw(tem_tok[-1].detach(), 1, h0, w0), ops.tokens_to_nchw(real_tok[-1].detach(), 1, h0, w0),
                                                        end_points["tem_mask"], end_points["real_mask"])
-            real_tok = [t.detach() for t in real_tok]            # stage 3 is forward-only: its inputs carry no graph
-            tem_tok = [t.detach() for t in tem_tok]
+            if not full:
+                real_tok = [t.detach() for t in real_tok]        # stage 3 forward-only: its inputs carry no graph
+                tem_tok = [t.detach() for t in tem_tok]
             if live:
                 pred_translation, pred_scale, pred_inplane = ag.affine_regressor_forward(self.affine_regressor, sim)
             else:
@@ -214,7 +216,16 @@ class Net(nn.Module):
             if pred_Ms is None:
                 pred_Ms = aug_gtM_noise(end_points)
             init_flow, init_certainty = compute_init_correspondences(pred_Ms, end_points["tem_mask"])
-            as_img = lambda t: t[:, 1:].unflatten(1, (h0, w0))  # noqa: E731
+        as_img = lambda t: t[:, 1:].unflatten(1, (h0, w0))  # noqa: E731
+        if full:
+            flows, certs = ag.offset_regressor_forward(orr, [as_img(t) for t in tem_tok], [as_img(t) for t in real_tok],
+                                                       ops.to_nhwc(init_flow), ops.to_nhwc(init_certainty))
+            for idx, (fl, ce) in enumerate(zip(flows, certs)):
+                end_points[f"loss_flow{idx}"], end_points[f"loss_certainty{idx}"] = ag.flow_level_losses(fl, ce, kp["tar_pts"])
+            if self.keep_stage3:
+                self.last_stage3 = (flows[-1].detach(), certs[-1].detach())
+            return end_points
+        with torch.no_grad():
             flows, certs = orr.forward_nhwc([as_img(t) for t in tem_tok], [as_img(t) for t in real_tok], ops.to_nhwc(init_flow),
                                             ops.to_nhwc(init_certainty), train=True)
             for idx, (fl, ce) in enumerate(zip(flows, certs)):
