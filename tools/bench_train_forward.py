@@ -29,6 +29,7 @@ net = net.cuda().train()
 ep = {k: v.cuda() for k, v in make_train_end_points(B, 11).items()}
 np.random.seed(0)
 torch.manual_seed(0)
+net.train_backward = False   # this tool times the forward-only training step (fused kernels); bench_train_step.py the full step
 for _ in range(3):
     out = net(dict(ep))
 torch.cuda.synchronize()
