@@ -96,7 +96,14 @@ def bmm_nt_b(a, b, alpha=1.0):
 
 
 def _mm(a, b, alpha=1.0, out=None):
-    """a (M,K) @ b (K,N) on the GEMM engine (b rows contiguous), operands range-normalised (backward products)."""
+    """a (M,K) @ b (K,N) on the GEMM engine (b rows contiguous), operands range-normalised (backward products).  Large products
+    take the pre-split engine (both operands split as activations, b through a transposed copy); small ones the batched kernel."""
+    M, K = a.shape
+    N = b.shape[1]
+    if ops.PRECISION == "f16x3" and alpha == 1.0 and K % 8 == 0 and M >= 64 and N >= 64 and M * N * K >= 1 << 24:
+        a2, sa = _ranged(a)
+        b2, sb = _ranged(b)
+        return _unscale(ops.matmul_nt_presplit(a2.contiguous(), b2.t().contiguous()), sa, sb, out)
     r = bmm_nn_b(a[None, None], b[None, None], None if out is None else out[None, None], alpha=alpha)
     return r[0, 0]
 
@@ -107,8 +114,9 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, act):
+        cache = w.is_leaf                      # a parameter itself: its operand form is cached per version; a re-packed one is transient
         x, w = _f32c(x), _f32c(w)
-        z = ops.linear(x, w, b)
+        z = ops.linear(x, w, b, cache_weight=cache)
         ctx.act = ACT[act]
         if ctx.act:
             y = torch.empty_like(z)

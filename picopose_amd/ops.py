@@ -55,10 +55,16 @@ def _chk(hl, what):
     return hl
 
 
-def split_weight(w):
+def split_weight(w, cache=True):
     """(hl, scale) — the f16x3 "hl" operand (fp16 (N, 2K): per 8 k the hi then the lo terms) and power-of-two scale
-    of a weight matrix; split once per tensor version (one host sync to read the scale back)."""
+    of a weight matrix; split once per tensor version (one host sync to read the scale back).  cache=False: a transient matrix
+    (the training graph's re-packed convolution weights): split, not remembered, not kept alive."""
     t = terms()
+    if not cache:
+        hl = torch.empty(w.shape[0], t * w.shape[1], dtype=torch.float16, device=w.device)
+        scale = torch.empty(1, dtype=torch.float32, device=w.device)
+        _lib.check(_lib.lib().pp_split_weights_t(_p(w), w.numel(), t, _p(hl), _p(scale), _lib.stream_ptr()), "pp_split_weights_t")
+        return hl, float(scale.item())
     key = (w.data_ptr(), w._version, tuple(w.shape), t)
     hit = _split_cache.get(key)
     if hit is None:
@@ -143,11 +149,11 @@ def _can_presplit(x, K, C, *strides):
             and all(st % 4 == 0 for st in strides))
 
 
-def _weight_args(w, K):
+def _weight_args(w, K, cache=True):
     """desc fields for a weight operand under the current precision (pre-split operand when it is aligned)."""
     if presplit() and K % 8 == 0 and w.data_ptr() % 16 == 0:
-        hl, scale = split_weight(w)
-        return dict(prec=_PREC[PRECISION], B_hl=_p(hl), b_scale=scale)
+        hl, scale = split_weight(w, cache)
+        return dict(prec=_PREC[PRECISION], B_hl=_p(hl), b_scale=scale, _hl=hl)
     return dict(prec=_fly_prec())
 
 
@@ -181,17 +187,19 @@ def _desc(**kw):
     d.batch0 = d.batch1 = 1
     d.alpha = 1.0
     for k, v in kw.items():
-        setattr(d, k, v)
+        if not k.startswith("_"):     # (_hl: the operand tensor itself, carried so that it outlives the enqueue)
+            setattr(d, k, v)
     return d
 
 
-def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, relu_in=False, out_split=False):
+def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, relu_in=False, out_split=False, cache_weight=True):
     """y = residual + gamma * act(x @ weight.T + bias); x (M,K) fp32 with row stride or a Split, weight (N,K).
-    out_split (f16x3 engine only; ignored otherwise): return y as a Split for the next linear instead of fp32."""
+    out_split (f16x3 engine only; ignored otherwise): return y as a Split for the next linear instead of fp32.
+    cache_weight=False: `weight` is a transient matrix — its operand form is not remembered."""
     M, K = x.shape
     N = weight.shape[0]
     assert weight.shape[1] == K and weight.is_contiguous()
-    wargs = _weight_args(weight, K)
+    wargs = _weight_args(weight, K, cache_weight)
     sargs, ret = {}, None
     if out_split and "B_hl" in wargs and _split_ok(N) and out is None:
         ret = Split.empty(M, N, x.device)
@@ -221,6 +229,24 @@ def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, 
     _run(_desc(A=_p(x), B=_p(weight), C=_p(out), bias=_p(bias), gamma=_p(gamma), residual=_p(residual), M=M, N=N, K=K,
                lda=x.stride(0), ldb=K, ldc=ldc, act=ACT[act], relu_in=int(relu_in), **_fly_args(wargs)))
     return ret
+
+
+def matmul_nt_presplit(a, bt):
+    """a (M,K) @ bt (N,K)^T with BOTH operands split as activations (scale PP_A_SCALE) — the pre-split engine for products of two
+    transient matrices (the backward GEMMs of picopose_amd/autograd.py: their operands are range-normalised first).  Unlike
+    `linear`, nothing is cached and nothing is read back.  Falls to the on-the-fly kernel when the shapes do not qualify."""
+    M, K = a.shape
+    N = bt.shape[0]
+    assert bt.shape[1] == K and a.is_contiguous() and bt.is_contiguous()
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if presplit() and PRECISION == "f16x3" and N >= 64 and M >= 64 and _can_presplit(a, K, K, K) and bt.data_ptr() % 16 == 0 \
+            and M * K < 2 ** 30 and N * K < 2 ** 30:
+        ah = split_activation(a, 1, M, K, 0, K)
+        bh = split_activation(bt, 1, N, K, 0, K)
+        _run(_desc(A_hl=_p(ah), B=_p(bt), B_hl=_p(bh), b_scale=4.0, C=_p(out), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, prec=_PREC[PRECISION]))
+        return out
+    _run(_desc(A=_p(a), B=_p(bt), C=_p(out), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, prec=_fly_prec()))
+    return out
 
 
 def linear_splitk(x, weight, bias=None, act=None, slices=32):
