@@ -131,7 +131,7 @@ def allreduce_gradients(parameters, group=None, bucket_bytes=25 << 20):
         return 0                                           # a single process: nothing to average
     world = dist.get_world_size(group)
     grads = [p.grad for p in parameters if p.grad is not None]
-    if not grads or world == 1:
+    if not grads:
         return 0
     buckets, cur, size = [], [], 0
     for g in grads:

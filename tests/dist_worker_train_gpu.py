@@ -1,0 +1,78 @@
+"""Rank body of tests/test_dist_gpu.py::test_data_parallel_training_step_*: the DDP training step of run_train.py:109-130 with the
+real HIP model — every rank runs forward_train + Loss + backward on ITS OWN batch of pairs, picopose_amd.dist.allreduce_gradients
+averages the gradients (several buckets), then every rank must hold the mean of the per-rank gradients, which rank-independent
+recomputation checks: each rank also computes every other rank's gradients locally (fresh model copies: training-mode BatchNorm
+moves the running buffers) and averages them itself.  The scatter adjoints (warp, correlation lookup) use fp32 atomics, so two
+computations of the same gradient agree to rounding, not bit for bit: 2e-5 of a tensor's largest gradient.
+Two ranks share one GPU (gloo rendezvous; PP_DIST_BACKEND=nccl at world size 1 pushes the same buckets through RCCL); the ranks take
+turns on the card for their compute, as in dist_worker_gpu.py."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    from netcfg import make_train_end_points, small_cfg
+
+    from picopose_amd.dist import allreduce_gradients
+    from picopose_amd.picopose import Net
+    from picopose_amd.utils.loss_utils import Loss
+    from picopose_amd.utils.seeding import calibrated_state_dict
+
+    backend = os.environ.get("PP_DIST_BACKEND", "gloo")
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    def grads_of(r):
+        """a fresh copy of the model (same weights on every rank) holding the gradients of rank r's batch"""
+        import numpy as np
+
+        net = Net(small_cfg())
+        net.load_state_dict(calibrated_state_dict(net.state_dict(), 4, "dinov2_vits14"))
+        net = net.cuda().train()
+        ep = {k: v.cuda() for k, v in make_train_end_points(2, 100 + r).items()}
+        np.random.seed(700 + r)                     # the stage-3 noise of utils/augment.aug_gtM_noise
+        torch.manual_seed(900 + r)
+        Loss()(net(ep))["loss"].backward()
+        torch.cuda.synchronize()
+        return net
+
+    def in_turn(fn):
+        out = None
+        for q in range(world):                      # one rank at a time on the card
+            if q == rank:
+                out = fn()
+            dist.barrier()
+        return out
+
+    mine = in_turn(lambda: grads_of(rank))                                   # the copy that is all-reduced
+    local = in_turn(lambda: {r: grads_of(r) for r in range(world)})          # every rank's gradients, recomputed here
+    nb = allreduce_gradients(list(mine.parameters()), bucket_bytes=4 << 20)
+    torch.cuda.synchronize()
+    ok, worst, n = nb >= 3, 0.0, 0
+    for (name, p), *cols in zip(mine.named_parameters(), *[local[r].parameters() for r in range(world)]):
+        if p.grad is None:
+            ok = ok and all(c.grad is None for c in cols)
+            continue
+        want = sum(c.grad for c in cols) / world
+        top = float(want.abs().max())
+        n += 1
+        if top > 1e-7:                               # (analytically zero gradients hold rounding noise)
+            worst = max(worst, float((p.grad - want).abs().max()) / top)
+    ok = ok and n >= 300 and worst <= 2e-5
+    print(f"RANK{rank} {'OK' if ok else 'MISMATCH'} backend={dist.get_backend()} world={world} buckets={nb} tensors={n} worst={worst:.2e}", flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

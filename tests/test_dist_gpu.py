@@ -12,7 +12,7 @@ import pytest
 gpu = pytest.mark.gpu
 
 
-def _run_ranks(n, **extra_env):
+def _run_ranks(n, worker="dist_worker_gpu.py", **extra_env):
     here = os.path.dirname(os.path.abspath(__file__))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -20,7 +20,7 @@ def _run_ranks(n, **extra_env):
     s.close()
     env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **extra_env)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(here, "dist_worker_gpu.py")],
+                        "--master-port", str(port), os.path.join(here, worker)],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
@@ -52,3 +52,18 @@ def test_sharded_forward_two_ranks_fully_concurrent():
     configuration of the product (one process per GPU), but the only rehearsal of overlapped ranks a one-GPU box allows,
     and the load under which lane-masked branches were seen to lose lanes."""
     _run_ranks(2, PP_DIST_TURNS="0")
+
+
+@gpu
+def test_data_parallel_training_step_two_ranks_one_gpu():
+    """DDP's step with the real model: two ranks, each forward_train + Loss + backward on its own two pairs, allreduce_gradients
+    in 4 MB buckets over gloo -> every rank holds the mean of the per-rank gradients (recomputed rank-independently), to 2e-5."""
+    out = _run_ranks(2, worker="dist_worker_train_gpu.py")
+    assert "world=2" in out and "tensors=338" in out, out[-2000:]
+
+
+@gpu
+def test_data_parallel_training_step_over_rccl_world_size_one():
+    """The same buckets through RCCL (`ncclAllReduce` on device tensors) at the world size a one-GPU box can run."""
+    out = _run_ranks(1, worker="dist_worker_train_gpu.py", PP_DIST_BACKEND="nccl")
+    assert "backend=nccl world=1" in out, out[-2000:]
