@@ -18,13 +18,18 @@ and return code (a process that has initialised the GPU is never re-exec'ed).  U
 (WORLD_SIZE set) it is a rank.
 
 N > 1 (one rank per GPU, RCCL), two modes:
-  --scaling weak (default; the 1/2/4/8-GPU curve of BASELINE's metric): every rank owns 32 crops (global batch 32*N);
+  --scaling weak (default; the 1/2/4/8-GPU curve of BASELINE's metric): every rank owns 32 crops (global batch 32*N) AND
+    their banks — crops are independent units of the path (a crop is matched against its OWN template bank,
+    run_test.py:157-162), so they are sharded across the ranks with NO data-path collective; the ranks meet only at the
+    barrier around the timed region and in the max-over-ranks of its duration.  (`--shard templates` runs the weak batch
+    on the template-sharded bank instead: every rank then scores (32 N) x (162 / N) pairs — the work of the unsharded
+    32 x 162 — plus a 201 MB query all-gather at N = 8: overhead without benefit, kept for comparison.)
   --scaling strong (BASELINE configs[3] as written: "batch = 32 ... sharded 8-ways"): the GLOBAL batch stays at the
-    workload's 32 crops (or --global-batch), every rank owns 32/N of them.
-In both the template FEATURE bank is sharded over the ranks along the template axis (each rank scores its
-ceil(162/N)-template slice of ALL crops of the global batch), exchanged with all-gathers of the query features / masks
-and of the (B, 162/N) score slices; stages 2-3 and PnP run data-parallel on the rank's own crops.  The line carries
-`phases_ms` (HIP events at the phase boundaries of one extra untimed step: features, exchange, stage1, tail, pnp).
+    workload's 32 crops (or --global-batch), every rank owns 32/N of them, and the template FEATURE bank is sharded over
+    the ranks along the template axis (each rank scores its ceil(162/N)-template slice of ALL crops of the global batch),
+    exchanged with all-gathers of the query features / masks and of the (B, 162/N) score slices; stages 2-3 and PnP run
+    data-parallel on the rank's own crops.  The line carries `phases_ms` (HIP events at the phase boundaries of one extra
+    untimed step: features, exchange, stage1, tail, pnp).
 
 JSON extras: `roofline` = the dominant kernel of the workload.  Full path: the pre-split f16x3 GEMM/conv kernel
 (75 % of the step; MFMA-bound) — executed MFMA flops of all its launches in one step / their summed durations,
@@ -305,6 +310,9 @@ def main():
                     help="N > 1: weak = the workload's crops PER RANK (global batch grows with N); strong = the workload's crops as "
                          "the GLOBAL batch, split over the ranks (BASELINE configs[3])")
     ap.add_argument("--global-batch", type=int, default=None, help="strong scaling with this global batch (implies --scaling strong)")
+    ap.add_argument("--shard", default="auto", choices=["auto", "crops", "templates"],
+                    help="N > 1: what is sharded over the ranks. auto = crops for weak scaling (independent replicas, no data-path "
+                         "collective), templates for strong scaling (configs[3] / [4]: template-sharded bank + all-gathers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the untimed --mode exact comparison leg")
     a = ap.parse_args()
@@ -350,8 +358,14 @@ def main():
     kind, Bl, N, vit, desc = WORKLOADS[a.workload]
     C = VIT[vit][0]
     B, Bl, a.scaling = batch_plan(Bl, world, a.scaling, a.global_batch)
-    lo, hi = shard_bounds(N, world, rank)
+    if a.shard == "auto":
+        a.shard = "templates" if a.scaling == "strong" else "crops"
+    if a.scaling == "strong" and a.shard != "templates":
+        raise SystemExit("--scaling strong shards the template bank (configs[3] / [4]): --shard templates")
+    sharded = distributed and a.shard == "templates"       # the template-sharded forward of picopose_amd/dist.py
+    lo, hi = shard_bounds(N, world, rank) if sharded else (0, N)
     n_local = hi - lo
+    Bq = B if sharded else Bl                               # crops whose scores this rank computes
     sd = None
     bank_dtype = torch.float16 if a.workload in FP16_BANK else torch.float32
 
@@ -360,12 +374,12 @@ def main():
         kind = "full"
     if kind == "stage1":
         g0 = torch.Generator(device=dev).manual_seed(0)
-        query = torch.randn(B, C, 16, 16, device=dev, generator=g0)     # identical on every rank
-        mask = disk_mask(B, dev)
-        bank = torch.randn(B, n_local, C, 16, 16, device=dev, generator=torch.Generator(device=dev).manual_seed(1 + rank)).to(bank_dtype)
+        query = torch.randn(Bq, C, 16, 16, device=dev, generator=g0)    # (template-sharded: identical on every rank)
+        mask = disk_mask(Bq, dev)
+        bank = torch.randn(Bq, n_local, C, 16, 16, device=dev, generator=torch.Generator(device=dev).manual_seed(1 + rank)).to(bank_dtype)
 
         def step():
-            if distributed:
+            if sharded:
                 return sharded_matching_templates(bank, query, mask, N, topk=5, mode=s1_mode)
             return hm.matching_templates(bank, query, None, mask, topk=5, mode=s1_mode)
     else:
@@ -383,7 +397,7 @@ def main():
         # Synthetic stand-in for the other ranks' crops: features of this rank's own renders (same shapes/bytes).
         with torch.no_grad():
             if cached:   # extended bank (single GPU): last-level features + template-side DPT maps of every template
-                assert not distributed, "the extended-bank workload is single-GPU"
+                assert not sharded, "the extended-bank workload does not take the template-sharded bank"
                 banks = [net.precompute_templates(ep["tem_rgb"][b]) for b in range(Bl)]
                 feats = torch.stack([bk["feature"] for bk in banks])
                 ep["template_cache"] = {"obj_index": torch.arange(Bl, device=dev),
@@ -393,13 +407,13 @@ def main():
                 feats = torch.stack([torch.cat([fe(ep["tem_rgb"][b, s:min(s + 54, hi)])[-1] for s in range(lo, hi, 54)])
                                      for b in range(Bl)])
         feats = feats.to(bank_dtype)
-        if distributed:
+        if sharded:
             bank = feats.repeat(world, 1, 1, 1, 1).contiguous()
         else:
             ep["template_feature"] = feats
 
         def forward(mark=None):
-            return sharded_forward(net, ep, bank, N, hyp=5, mark=mark) if distributed else net(ep, 5)
+            return sharded_forward(net, ep, bank, N, hyp=5, mark=mark) if sharded else net(ep, 5)
 
         def step():
             outs = forward()
@@ -462,7 +476,7 @@ def main():
         _lib.check(L.pp_prof_gemm_enable(0), "pp_prof_gemm_enable")
         gemm = {"ms": list(g_ms), "flops": list(g_fl), "launches": list(g_n), "per_kernel": per_kernel}
         phases = None
-        if distributed:   # one more untimed step with a HIP event at every phase boundary of the sharded forward
+        if sharded:   # one more untimed step with a HIP event at every phase boundary of the sharded forward
             evs = []
 
             def mark(name):
@@ -574,7 +588,7 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         bpe = 2 if bank_dtype == torch.float16 else 4
-        kbytes = stage1_bytes(B, n_local, C, bpe)   # bytes one launch of the stage-1 kernel streams on this rank
+        kbytes = stage1_bytes(Bq, n_local, C, bpe)  # bytes one launch of the stage-1 kernel streams on this rank
         achieved = kbytes / (kern_ms * 1e-3) / 1e9
         prof_dir = next((d for d in ("r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_traffic_stage1.json"))), "r01")
         traffic = traffic_src = None  # HBM bytes per launch from a separate PMC pass (tools/pmc.sh): same kernel, same shape
@@ -598,9 +612,12 @@ def main():
                        "templates_per_rank": n_local, "backbone": vit, "channels": C,
                        "hypotheses": 5, "mode": a.mode, "bank_dtype": "f16" if bpe == 2 else "f32",
                        "weights": "seeded random init, prediction heads calibrated (picopose_amd/utils/seeding.py)",
+                       "shard": "none" if world == 1 else a.shard,
                        "parallelism": "single GPU" if world == 1 else
-                       f"{a.scaling} scaling: {Bl} crops per rank x{world} (global batch {B}); feature bank template-sharded x{world} "
-                       f"({n_local} of {N} templates on rank 0) + all-gathers (query features, sampled masks, scores); {backend}"},
+                       (f"{a.scaling} scaling: {Bl} crops per rank x{world} (global batch {B}); feature bank template-sharded x{world} "
+                        f"({n_local} of {N} templates on rank 0) + all-gathers (query features, sampled masks, scores); {backend}" if sharded else
+                        f"weak scaling: {Bl} crops per rank x{world} (global batch {B}), each rank its own crops and their banks — independent "
+                        f"units, no data-path collective (barrier + max-over-ranks of the timed region only); {backend}")},
         }
         s1_roof = {"bound": "hbm", "kernel": f"s1_main<{s1_mode}> (stage-1 fused similarity)", "achieved": achieved,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -610,7 +627,7 @@ def main():
         # the other roof of the same launch: the 256 x 256 x C contraction per (crop, template) on the matrix cores
         # (fast mode: one fp16 MFMA term; exact mode: fp32 MFMA).  With an fp16-stored bank the intensity is 2 C 256^2 / (2 C 256)
         # = 256 flop/B against a ridge of 2500 / 8 = 312: the kernel then sits between both roofs and this reading is the binding one.
-        s1_flops = 2.0 * B * n_local * 256 * 256 * C
+        s1_flops = 2.0 * Bq * n_local * 256 * 256 * C
         s1_peak = MFMA_F32_PEAK_TF if a.mode == "exact" else MFMA_F16_PEAK_TF
         s1_roof["mfma"] = {"achieved": s1_flops / (kern_ms * 1e-3) / 1e12, "peak": s1_peak, "unit": "TFLOP/s",
                            "frac": s1_flops / (kern_ms * 1e-3) / 1e12 / s1_peak, "flops_per_launch": s1_flops,
