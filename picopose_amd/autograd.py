@@ -104,6 +104,17 @@ def _mm(a, b, alpha=1.0, out=None):
         a2, sa = _ranged(a)
         b2, sb = _ranged(b)
         return _unscale(ops.matmul_nt_presplit(a2.contiguous(), b2.t().contiguous()), sa, sb, out)
+    if min(M, N) <= 16 and K >= 8192 and K % 64 == 0 and alpha == 1.0:
+        # a skinny product over a long K (the gradients of the 1- / 2-channel predict layers: 2 x 131072 x 2304): one tile
+        # walking all of K leaves the chip idle — cut K into 64 slices that run as one batched launch, then add them in index order
+        S, kc = 64, K // 64
+        a2, sa = _ranged(a)
+        b2, sb = _ranged(b)
+        part = torch.empty(1, S, M, N, dtype=torch.float32, device=a.device)
+        ops.bmm_nn(a2.contiguous().view(M, S, kc).permute(1, 0, 2)[None], b2.contiguous().view(S, kc, N)[None], part)
+        r = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        _lib.check(_lib.lib().pp_sum_slices(_p(part), S, M, N, None, 0, _p(r), _lib.stream_ptr()), "pp_sum_slices")
+        return _unscale(r, sa, sb, out)
     r = bmm_nn_b(a[None, None], b[None, None], None if out is None else out[None, None], alpha=alpha)
     return r[0, 0]
 
