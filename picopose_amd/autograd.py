@@ -100,14 +100,15 @@ def _mm(a, b, alpha=1.0, out=None):
     take the pre-split engine (both operands split as activations, b through a transposed copy); small ones the batched kernel."""
     M, K = a.shape
     N = b.shape[1]
-    if ops.PRECISION == "f16x3" and alpha == 1.0 and K % 8 == 0 and M >= 64 and N >= 64 and M * N * K >= 1 << 24:
-        a2, sa = _ranged(a)
-        b2, sb = _ranged(b)
-        return _unscale(ops.matmul_nt_presplit(a2.contiguous(), b2.t().contiguous()), sa, sb, out)
-    if min(M, N) <= 16 and K >= 8192 and K % 64 == 0 and alpha == 1.0:
-        # a skinny product over a long K (the gradients of the 1- / 2-channel predict layers: 2 x 131072 x 2304): one tile
-        # walking all of K leaves the chip idle — cut K into 64 slices that run as one batched launch, then add them in index order
-        S, kc = 64, K // 64
+    tiles = -(-M // 128) * -(-N // 128)
+    if tiles <= 24 and K >= 8192 and K % 64 == 0 and alpha == 1.0:     # (above ~24 tiles the pre-split engine at tiles / 256 of its rate beats the batched kernel)
+        # few output tiles over a long K (weight gradients: the rows of the batch are the K axis, e.g. 256 x 256 x 131072 or the
+        # 2 x 131072 x 2304 of a predict layer): a handful of tiles walking all of K leave the chip idle — cut K into S slices
+        # that run as one batched launch, then add them in index order
+        S = 64 if tiles <= 8 else 16
+        while K % S or (K // S) % 8:
+            S //= 2
+        kc = K // S
         a2, sa = _ranged(a)
         b2, sb = _ranged(b)
         part = torch.empty(1, S, M, N, dtype=torch.float32, device=a.device)
@@ -115,6 +116,10 @@ def _mm(a, b, alpha=1.0, out=None):
         r = torch.empty(M, N, dtype=torch.float32, device=a.device)
         _lib.check(_lib.lib().pp_sum_slices(_p(part), S, M, N, None, 0, _p(r), _lib.stream_ptr()), "pp_sum_slices")
         return _unscale(r, sa, sb, out)
+    if ops.PRECISION == "f16x3" and alpha == 1.0 and K % 8 == 0 and M >= 64 and N >= 64 and M * N * K >= 1 << 24:
+        a2, sa = _ranged(a)
+        b2, sb = _ranged(b)
+        return _unscale(ops.matmul_nt_presplit(a2.contiguous(), b2.t().contiguous()), sa, sb, out)
     r = bmm_nn_b(a[None, None], b[None, None], None if out is None else out[None, None], alpha=alpha)
     return r[0, 0]
 
@@ -674,6 +679,73 @@ def flow_level_losses(flow, cert, tar_pts, mask_weight=1.0, flow_weight=0.1, max
     return _FlowLoss.apply(flow, cert, tar_pts, flow_weight, mask_weight, max_flow, eps)
 
 
+class _Conv2d(torch.autograd.Function):
+    """Stride-1 'same' convolution (k odd, pad = k // 2) on NHWC with optional ReLU, implicit GEMM in all three directions:
+    forward = the inference engine's convolution (no im2col matrix); dgrad = the same kernel on dz with the spatially flipped,
+    in/out-swapped weights; wgrad = dz^T colT with the K-major im2col written only for the duration of the product."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, k, act):
+        x = _f32c(x)
+        Cx = x.shape[-1]
+        w = weight.detach().float()
+        wp = ops.pack_conv_weight(w, cin_pad=Cx if Cx > w.shape[1] else None)
+        y = ops.conv2d(x, wp, bias, k, pad=k // 2, act=act, cache_weight=False)
+        ctx.save_for_backward(x, w, y if act else None)
+        ctx.cfg = (k, act, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        k, act, has_bias = ctx.cfg
+        B, H, W, Cx = x.shape
+        Cout, Cin = w.shape[0], w.shape[1]
+        dz = _f32c(dy)
+        if act:
+            g = torch.empty_like(dz)
+            _lib.check(_lib.lib().pp_act_backward(_p(y), _p(dz), dz.numel(), ACT[act], _p(g), _lib.stream_ptr()), "pp_act_backward")
+            dz = g                                                        # relu'(z) = [y > 0]
+        dzs, s = _ranged(dz)                                              # the gradient operand of both products
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wf = w.flip(2, 3).permute(1, 0, 2, 3)                         # (Cin, Cout, k, k): dx = conv(dz, flipped weights)
+            if Cx > Cin:
+                wf = torch.cat([wf, wf.new_zeros(Cx - Cin, Cout, k, k)], dim=0)
+            dx = ops.conv2d(dzs, ops.pack_conv_weight(wf.contiguous()), None, k, pad=k // 2, cache_weight=False)
+            dx = _unscale(dx, s, None)
+        if ctx.needs_input_grad[1]:
+            rows = B * H * W
+            colT = torch.empty(k * k * Cx, rows, dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().pp_im2col_t_nhwc(_p(x), B, H, W, Cx, k, 1, k // 2, _p(colT), _lib.stream_ptr()), "pp_im2col_t_nhwc")
+            dzt = dzs.view(rows, Cout).t().contiguous()                   # (Cout, rows)
+            tiles = -(-Cout // 128) * -(-(k * k * Cx) // 128)
+            if ops.PRECISION == "f16x3" and Cout >= 64 and tiles > 24 and rows % 8 == 0:
+                dwp = ops.matmul_nt_presplit(dzt, colT)                   # x is a forward activation: in range as it is
+            else:
+                dwp = _mm_kmajor(dzt, colT)
+            dwp = _unscale(dwp, s, None)                                  # (Cout, k k Cx)
+            dw = dwp.view(Cout, k, k, Cx)[..., :Cin].permute(0, 3, 1, 2).contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dz.view(-1, Cout))
+        return dx, dw, db, None, None
+
+
+def _mm_kmajor(a, bt):
+    """a (M,K) @ bt (N,K)^T for products with few output tiles over a long K: K cut into slices that run as one batched launch."""
+    M, K = a.shape
+    N = bt.shape[0]
+    tiles = -(-M // 128) * -(-N // 128)
+    S = 64 if tiles <= 8 else 16
+    while S > 1 and (K % S or (K // S) % 8):
+        S //= 2
+    kc = K // S
+    part = ops.bmm_nt(a.view(M, S, kc).permute(1, 0, 2)[None], bt.view(N, S, kc).permute(1, 0, 2)[None])     # (1,S,M,N)
+    r = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().pp_sum_slices(_p(part), S, M, N, None, 0, _p(r), _lib.stream_ptr()), "pp_sum_slices")
+    return r
+
+
 def conv2d(x, weight, bias, k, stride=1, pad=0, act=None, cin_pad=None):
     """NHWC convolution under autograd: x (B,H,W,Cx), weight in torch layout (Cout, Cin, k, k) (Cx = cin_pad >= Cin: the map carries
     zero pad channels).  1x1: a linear layer on the pixels; otherwise im2col + linear (dgrad through col2im)."""
@@ -684,6 +756,8 @@ def conv2d(x, weight, bias, k, stride=1, pad=0, act=None, cin_pad=None):
         if Cx > w2.shape[1]:
             w2 = torch.cat([w2, w2.new_zeros(Cout, Cx - w2.shape[1])], dim=1)
         return linear(x.reshape(-1, Cx), w2.contiguous(), bias, act=act).view(B, H, W, Cout)
+    if stride == 1 and k % 2 == 1 and pad == k // 2 and act in (None, "relu") and Cx % 8 == 0:
+        return _Conv2d.apply(x, weight, bias, k, act)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     w2 = ops.pack_conv_weight(weight.float(), cin_pad=Cx if Cx > weight.shape[1] else None)
     return linear(_Im2col.apply(x, k, stride, pad), w2, bias, act=act).view(B, Ho, Wo, Cout)

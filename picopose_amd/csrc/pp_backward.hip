@@ -280,6 +280,38 @@ __global__ void simvol_backward_kernel(const float* __restrict__ out, const floa
     dS[i] = out[o] > 0.f ? dout[o] * m : 0.f;
 }
 
+// im2col written TRANSPOSED: colT[(ky, kx, c)][row], row = (b, oy, ox) — the K-major operand of the weight-gradient product
+// dW = dz^T col (its K axis is the rows of the batch).  A 32 x 32 (pixels x channels) tile per tap goes through LDS so that both the
+// reads (channels contiguous) and the writes (rows contiguous) are coalesced.
+__global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__ x, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo,
+                                                       long long rows, float* __restrict__ colT) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z, ky = tap / k, kx = tap - ky * k;
+    const long long r0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long row = r0 + ty + 8 * j;
+        const int c = c0 + tx;
+        float v = 0.f;
+        if (row < rows && c < C) {
+            const int ox = (int)(row % Wo), oy = (int)((row / Wo) % Ho);
+            const long long b = row / ((long long)Wo * Ho);
+            const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((b * H + iy) * W + ix) * C + c];
+        }
+        tile[ty + 8 * j][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j;
+        const long long row = r0 + tx;
+        if (row < rows && c < C) colT[((long long)tap * C + c) * rows + row] = tile[tx][ty + 8 * j];
+    }
+}
+
 extern "C" {
 
 size_t pp_colsum_workspace_bytes(long long rows, int cols) {
@@ -361,6 +393,16 @@ int pp_col2im_nhwc(const float* col, int B, int H, int W, int C, int ksize, int 
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const long long total = (long long)B * H * W * C;
     hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, col, H, W, C, ksize, stride, pad, Ho, Wo, total, dx);
+    return pp_last_launch();
+}
+
+int pp_im2col_t_nhwc(const float* x, int B, int H, int W, int C, int ksize, int stride, int pad, float* colT, void* stream) {
+    if (!x || !colT || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0 || stride <= 0 || pad < 0) return PP_EINVAL;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const long long rows = (long long)B * Ho * Wo;
+    if (rows <= 0 || (rows + 31) / 32 > 0x7FFFFFFFLL || ksize * ksize > 65535) return PP_EINVAL;
+    hipLaunchKernelGGL(im2col_t_kernel, dim3((unsigned)((rows + 31) / 32), (C + 31) / 32, ksize * ksize), dim3(256), 0, (hipStream_t)stream, x, H, W, C,
+                       ksize, stride, pad, Ho, Wo, rows, colT);
     return pp_last_launch();
 }
 

@@ -322,7 +322,7 @@ def split_image(x, relu=False):
 
 
 def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residual=None, out=None, cin=None,
-           residual2=None, out_split=False, split_relu=False, also_split=None, hl_into=None):
+           residual2=None, out_split=False, split_relu=False, also_split=None, hl_into=None, cache_weight=True):
     """NHWC convolution. x (B,H,W,Cx) (channel-contiguous, may be a channel slice: cin <= Cx stride) or a Split
     carrying .image (a pre-split operand: no split pass, the producer has already applied any input ReLU),
     wp (Cout, k*k*cin) from pack_conv_weight.  out may be a channel slice of a wider NHWC buffer.
@@ -360,7 +360,7 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
         _lib.check(_lib.lib().pp_conv_narrow_hl(_p(xs.hl), Cx, B, H, W, Cx, _p(wp), _p(bias), ksize, Cout, _p(residual), _p(out),
                                                 _lib.stream_ptr()), "pp_conv_narrow_hl")
         return out
-    wargs = _weight_args(wp, ksize * ksize * cin)
+    wargs = _weight_args(wp, ksize * ksize * cin, cache_weight)   # (cache_weight=False: a transient packed weight of the training graph)
     presplit = xs is not None or ("B_hl" in wargs and (Cout > 64 or ksize > 1)
                                   and _can_presplit(x, ksize * ksize * cin, cin, ld_in, x.stride(0)) and B * H * W * cin < 2 ** 30)
     sargs, ret = {}, None
