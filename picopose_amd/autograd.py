@@ -61,9 +61,10 @@ def _pow2_scale(t):
     return torch.exp2(torch.floor(torch.log2(1024.0 / amax))).reshape(1)
 
 
-def _ranged(t):
-    """(range-normalised contiguous copy, its scale) — identity in fp32 engine mode."""
-    if ops.PRECISION == "f32":
+def _ranged(t, on=True):
+    """(range-normalised contiguous copy, its scale) — identity in fp32 engine mode and for operands that are forward quantities
+    (activations, weights, probabilities: in the operand format's range as they are; on=False)."""
+    if ops.PRECISION == "f32" or not on:
         return t, None
     s = _pow2_scale(t)
     return _ew(1, t.contiguous(), s, 1), s
@@ -80,22 +81,23 @@ def _unscale(out, sa, sb, target=None):
     return out
 
 
-def bmm_nn_b(a, b, out=None, alpha=1.0):
-    """Backward product out = alpha a @ b for 4-D views (Z0,Z1,M,K) x (Z0,Z1,K,N) with both operands range-normalised."""
-    a2, sa = _ranged(a)
-    b2, sb = _ranged(b)
+def bmm_nn_b(a, b, out=None, alpha=1.0, ra=True, rb=True):
+    """Backward product out = alpha a @ b for 4-D views (Z0,Z1,M,K) x (Z0,Z1,K,N); ra / rb: range-normalise that operand (a
+    gradient) or take it as it is (a forward quantity)."""
+    a2, sa = _ranged(a, ra)
+    b2, sb = _ranged(b, rb)
     tmp = torch.empty(a.shape[0], a.shape[1], a.shape[2], b.shape[3], dtype=torch.float32, device=a.device)
     ops.bmm_nn(a2, b2, tmp, alpha=alpha)
     return _unscale(tmp, sa, sb, out)
 
 
-def bmm_nt_b(a, b, alpha=1.0):
-    a2, sa = _ranged(a)
-    b2, sb = _ranged(b)
+def bmm_nt_b(a, b, alpha=1.0, ra=True, rb=True):
+    a2, sa = _ranged(a, ra)
+    b2, sb = _ranged(b, rb)
     return _unscale(ops.bmm_nt(a2, b2, alpha=alpha), sa, sb)
 
 
-def _mm(a, b, alpha=1.0, out=None):
+def _mm(a, b, alpha=1.0, out=None, ra=True, rb=True):
     """a (M,K) @ b (K,N) on the GEMM engine (b rows contiguous), operands range-normalised (backward products).  Large products
     take the pre-split engine (both operands split as activations, b through a transposed copy); small ones the batched kernel."""
     M, K = a.shape
@@ -109,18 +111,18 @@ def _mm(a, b, alpha=1.0, out=None):
         while K % S or (K // S) % 8:
             S //= 2
         kc = K // S
-        a2, sa = _ranged(a)
-        b2, sb = _ranged(b)
+        a2, sa = _ranged(a, ra)
+        b2, sb = _ranged(b, rb)
         part = torch.empty(1, S, M, N, dtype=torch.float32, device=a.device)
         ops.bmm_nn(a2.contiguous().view(M, S, kc).permute(1, 0, 2)[None], b2.contiguous().view(S, kc, N)[None], part)
         r = torch.empty(M, N, dtype=torch.float32, device=a.device)
         _lib.check(_lib.lib().pp_sum_slices(_p(part), S, M, N, None, 0, _p(r), _lib.stream_ptr()), "pp_sum_slices")
         return _unscale(r, sa, sb, out)
     if ops.PRECISION == "f16x3" and alpha == 1.0 and K % 8 == 0 and M >= 64 and N >= 64 and M * N * K >= 1 << 24:
-        a2, sa = _ranged(a)
-        b2, sb = _ranged(b)
+        a2, sa = _ranged(a, ra)
+        b2, sb = _ranged(b, rb)
         return _unscale(ops.matmul_nt_presplit(a2.contiguous(), b2.t().contiguous()), sa, sb, out)
-    r = bmm_nn_b(a[None, None], b[None, None], None if out is None else out[None, None], alpha=alpha)
+    r = bmm_nn_b(a[None, None], b[None, None], None if out is None else out[None, None], alpha=alpha, ra=ra, rb=rb)
     return r[0, 0]
 
 
@@ -152,8 +154,8 @@ class _Linear(torch.autograd.Function):
             _lib.check(_lib.lib().pp_act_backward(_p(z), _p(dy), dy.numel(), ctx.act, _p(dz), _lib.stream_ptr()), "pp_act_backward")
         else:
             dz = dy
-        dx = _mm(dz, w) if ctx.needs_input_grad[0] else None
-        dw = _mm(dz.t().contiguous(), x) if ctx.needs_input_grad[1] else None
+        dx = _mm(dz, w, rb=False) if ctx.needs_input_grad[0] else None                       # (weights / activations: forward quantities)
+        dw = _mm(dz.t().contiguous(), x, rb=False) if ctx.needs_input_grad[1] else None
         db = colsum(dz) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None
 
@@ -223,15 +225,15 @@ class _Attention(torch.autograd.Function):
         v5 = qkv.view(B, T, 3, heads, hd)
         q, k, v = (v5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         dO = _f32c(dout).view(B, T, heads, hd).permute(0, 2, 1, 3)
-        dP = bmm_nt_b(dO, v)                                                          # dO v^T
+        dP = bmm_nt_b(dO, v, rb=False)                                                # dO v^T
         dS = torch.empty_like(P)
         _lib.check(_lib.lib().pp_softmax_backward_rows(_p(P), _p(dP), B * heads * T, T, _p(dS), _lib.stream_ptr()), "pp_softmax_backward_rows")
         dqkv = torch.empty_like(qkv)
         d5 = dqkv.view(B, T, 3, heads, hd)
         s = float(hd) ** -0.5
-        bmm_nn_b(dS, k.contiguous(), d5[:, :, 0].permute(0, 2, 1, 3), alpha=s)                          # dq = dS k / sqrt(hd)
-        bmm_nn_b(dS.transpose(2, 3).contiguous(), q.contiguous(), d5[:, :, 1].permute(0, 2, 1, 3), alpha=s)   # dk = dS^T q / sqrt(hd)
-        bmm_nn_b(P.transpose(2, 3).contiguous(), dO.contiguous(), d5[:, :, 2].permute(0, 2, 1, 3))      # dv = P^T dO
+        bmm_nn_b(dS, k.contiguous(), d5[:, :, 0].permute(0, 2, 1, 3), alpha=s, rb=False)                # dq = dS k / sqrt(hd)
+        bmm_nn_b(dS.transpose(2, 3).contiguous(), q.contiguous(), d5[:, :, 1].permute(0, 2, 1, 3), alpha=s, rb=False)   # dk = dS^T q / sqrt(hd)
+        bmm_nn_b(P.transpose(2, 3).contiguous(), dO.contiguous(), d5[:, :, 2].permute(0, 2, 1, 3), ra=False)      # dv = P^T dO
         return dqkv, None, None, None, None
 
 
@@ -318,7 +320,7 @@ class _InfoNCE(torch.autograd.Function):
         dl = torch.empty(n, n, dtype=torch.float32, device=q.device)
         _lib.check(L.pp_xent_diag_backward(_p(logits), n, logits.stride(0), 1.0 / ctx.tau, _p(_f32c(up).reshape(1)), _p(dl), _lib.stream_ptr()),
                    "pp_xent_diag_backward")
-        dq, dr = _mm(dl, r), _mm(dl.t().contiguous(), q)
+        dq, dr = _mm(dl, r, rb=False), _mm(dl.t().contiguous(), q, rb=False)
         out = []
         for tok, rows_, dn in ((ts, s_rows, dq), (tt, t_rows, dr)):
             dx = torch.empty(n, C, dtype=torch.float32, device=q.device)
@@ -371,7 +373,7 @@ class _InterpPos(torch.autograd.Function):
         if wt is None:                                                  # the grid is the stored one: no resampling
             out[0, 1:].copy_(dpos[1:])
         else:
-            _mm(wt, dpos[1:], out=out[0, 1:])
+            _mm(wt, dpos[1:], out=out[0, 1:], ra=False)
         return out, None, None
 
 
@@ -406,8 +408,8 @@ class _SimilarityVolume(torch.autograd.Function):
                    "pp_simvol_backward")
         dr = torch.empty(1, B, P, C, dtype=torch.float32, device=ts.device)
         dq = torch.empty_like(dr)
-        bmm_nn_b(dS[None], q.view(1, B, P, C), dr)                                  # d tar_hat[t] = sum_s dS[t][s] src_hat[s]
-        bmm_nn_b(dS.transpose(1, 2).contiguous()[None], r.view(1, B, P, C), dq)     # d src_hat[s] = sum_t dS[t][s] tar_hat[t]
+        bmm_nn_b(dS[None], q.view(1, B, P, C), dr, rb=False)                        # d tar_hat[t] = sum_s dS[t][s] src_hat[s]
+        bmm_nn_b(dS.transpose(1, 2).contiguous()[None], r.view(1, B, P, C), dq, rb=False)   # d src_hat[s] = sum_t dS[t][s] tar_hat[t]
         grads = []
         for tok, dn in ((ts, dq), (tt, dr)):
             dx = torch.empty(B * P, C, dtype=torch.float32, device=ts.device)
@@ -640,8 +642,8 @@ class _ConvTranspose(torch.autograd.Function):
         B, H, W, Cin = x.shape
         Cout = wp.shape[0] // (r * r)
         d = _f32c(dy).view(B, H, r, W, r, Cout).permute(0, 1, 3, 2, 4, 5).reshape(B * H * W, r * r * Cout)   # un-shuffle (a copy)
-        dx = _mm(d, wp).view(B, H, W, Cin)
-        dwp = _mm(d.t().contiguous(), x.view(-1, Cin))                                                       # (r r Cout, Cin)
+        dx = _mm(d, wp, rb=False).view(B, H, W, Cin)
+        dwp = _mm(d.t().contiguous(), x.view(-1, Cin), rb=False)                                             # (r r Cout, Cin)
         dw = dwp.view(r, r, Cout, Cin).permute(3, 2, 0, 1).contiguous()                                      # -> (Cin, Cout, r, r)
         db = colsum(d.view(-1, Cout))
         return dx, dw, db, None
