@@ -441,6 +441,9 @@ int pp_normalize_rows_backward(const float* x, long long row_stride, const int64
 /* im2col of an NHWC image for a ksize x ksize / stride / pad convolution (k order (ky, kx, ci), as pack_conv_weight) and its adjoint */
 int pp_im2col_nhwc(const float* x, int B, int H, int W, int C, int ksize, int stride, int pad, float* col, void* stream);
 int pp_col2im_nhwc(const float* col, int B, int H, int W, int C, int ksize, int stride, int pad, float* dx, void* stream);
+/* scale2[0] = the power of two s with max|x| s in [512, 1024) (1 for an all-zero x), scale2[1] = 1 / s — the range normalisation of a
+ * gradient operand before a backward product (picopose_amd/autograd.py: _ranged); device scalars, no host sync */
+int pp_pow2_scale(const float* x, long long n, float* scale2, void* stream);
 /* im2col written transposed: colT (ksize^2 C, rows), rows = B Ho Wo — the K-major operand of the weight-gradient product */
 int pp_im2col_t_nhwc(const float* x, int B, int H, int W, int C, int ksize, int stride, int pad, float* colT, void* stream);
 /* adjoint of pp_similarity_volume's tail (mask, clamp at 0, the [s][h][w] layout with t = w 16 + h; utils/matching.py:21-25):

@@ -54,27 +54,30 @@ def _ew(op, a, b, cols=0):
 
 
 def _pow2_scale(t):
-    """Device scalar 2^k with max|t| 2^k in [512, 1024): gradient tensors span 1e-9 .. 1, the engine's operand format holds
+    """Device scalars (2^k, 2^-k) with max|t| 2^k in [512, 1024): gradient tensors span 1e-9 .. 1, the engine's operand format holds
     4 x as two fp16 terms (full 22 bits only above ~3e-5) — backward products are taken on range-normalised copies and scaled
-    back, exactly (powers of two).  No host sync; the scale never enters a value except through rounding."""
-    amax = t.detach().abs().amax().clamp_min(1e-30)
-    return torch.exp2(torch.floor(torch.log2(1024.0 / amax))).reshape(1)
+    back, exactly (powers of two).  One reduction on the device (pp_pow2_scale), no host sync; the scale never enters a value
+    except through rounding."""
+    s2 = torch.empty(2, dtype=torch.float32, device=t.device)
+    _lib.check(_lib.lib().pp_pow2_scale(_p(t), t.numel(), _p(s2), _lib.stream_ptr()), "pp_pow2_scale")
+    return s2
 
 
 def _ranged(t, on=True):
-    """(range-normalised contiguous copy, its scale) — identity in fp32 engine mode and for operands that are forward quantities
-    (activations, weights, probabilities: in the operand format's range as they are; on=False)."""
+    """(range-normalised contiguous copy, its (scale, 1 / scale) pair) — identity in fp32 engine mode and for operands that are
+    forward quantities (activations, weights, probabilities: in the operand format's range as they are; on=False)."""
     if ops.PRECISION == "f32" or not on:
         return t, None
-    s = _pow2_scale(t)
-    return _ew(1, t.contiguous(), s, 1), s
+    t = t.contiguous()
+    s2 = _pow2_scale(t)
+    return _ew(1, t, s2[0:1], 1), s2
 
 
 def _unscale(out, sa, sb, target=None):
-    """out / (sa sb) (exact), into `target` (a possibly strided view) when given."""
-    if sa is not None or sb is not None:
-        inv = 1.0 / ((sa if sa is not None else 1.0) * (sb if sb is not None else 1.0))
-        out = _ew(1, out, inv.reshape(1).float(), 1)
+    """out / (sa sb) (exact: powers of two), into `target` (a possibly strided view) when given."""
+    for s2 in (sa, sb):
+        if s2 is not None:
+            out = _ew(1, out, s2[1:2], 1)
     if target is not None:
         target.copy_(out)
         return target

@@ -767,26 +767,41 @@ __global__ void normalize_rows_kernel(const float* __restrict__ x, int rows, int
     for (int i = 0; i < n; ++i) y[(size_t)r * n + i] = x[(size_t)r * n + i] / d;
 }
 
-// max |w| -> power-of-two scale with max |s w| in [512, 1024)
-__global__ __launch_bounds__(1024) void absmax_scale_kernel(const float* __restrict__ w, long long n,
-                                                            float* __restrict__ scale) {
-    __shared__ float red[16];
+// max |w| -> power-of-two scale with max |s w| in [512, 1024): init / grid-wide max (the bit pattern of a non-negative float
+// orders like an unsigned integer: one atomicMax per workgroup) / finish, three small launches without a workspace
+__global__ void absmax_init_kernel(float* __restrict__ scale) { ((unsigned*)scale)[0] = 0u; }
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ w, long long n, float* __restrict__ scale) {
+    __shared__ float red[4];
     float m = 0.f;
-    for (long long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(w[i]));
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
-        int e = 0;
-        if (m > 0.f && m < INFINITY) {
-            (void)frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)
-            e = 10 - e;           // s m in [512, 1024)
-        }
-        e = e > 30 ? 30 : (e < -30 ? -30 : e);
-        scale[0] = ldexpf(1.f, e);
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m == m) atomicMax((unsigned*)scale, __float_as_uint(m));   // (a NaN never enters the maximum)
     }
+}
+
+__global__ void absmax_finish_kernel(float* __restrict__ scale, int with_inverse, int emax) {
+    const float m = scale[0];
+    int e = 0;
+    if (m > 0.f && m < INFINITY) {
+        (void)frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)
+        e = 10 - e;           // s m in [512, 1024)
+    }
+    e = e > emax ? emax : (e < -emax ? -emax : e);
+    scale[0] = ldexpf(1.f, e);
+    if (with_inverse) scale[1] = ldexpf(1.f, -e);
+}
+
+static void launch_pow2_scale(const float* w, long long n, float* scale, int with_inverse, int emax, hipStream_t st) {
+    hipLaunchKernelGGL(absmax_init_kernel, dim3(1), dim3(1), 0, st, scale);
+    const int grid = (int)((n + 2047) / 2048 < 1024 ? (n + 2047) / 2048 : 1024);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, st, w, n, scale);
+    hipLaunchKernelGGL(absmax_finish_kernel, dim3(1), dim3(1), 0, st, scale, with_inverse, emax);
 }
 
 __global__ void split_f16x3_kernel(const float* __restrict__ w, long long n, const float* __restrict__ scale,
@@ -816,13 +831,19 @@ extern "C" {
 
 int pp_split_weights_t(const float* w, long long n, int terms, void* out, float* scale, void* stream) {
     if (!w || !out || !scale || n <= 0 || n % 8 != 0 || (terms != 1 && terms != 2)) return PP_EINVAL;
-    hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, n, scale);
+    launch_pow2_scale(w, n, scale, 0, 30, (hipStream_t)stream);
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(split_f16x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, n, scale, (_Float16*)out, terms);
     return pp_last_launch();
 }
 
 int pp_split_f16x3(const float* w, long long n, void* hl, float* scale, void* stream) { return pp_split_weights_t(w, n, 2, hl, scale, stream); }
+
+int pp_pow2_scale(const float* x, long long n, float* scale2, void* stream) {
+    if (!x || !scale2 || n <= 0) return PP_EINVAL;
+    launch_pow2_scale(x, n, scale2, 1, 100, (hipStream_t)stream);
+    return pp_last_launch();
+}
 
 int pp_split_activation_t(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu, void* hl,
                           int ld_h, int terms, void* stream) {
