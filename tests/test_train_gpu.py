@@ -525,7 +525,7 @@ def test_full_backward_matches_the_reference_autograd(golden_dir, precision):
         tot.backward()
     finally:
         ops.PRECISION = old
-    TOL = 3e-3     # measured 8.0e-4 (f16x3) / 1.1e-3 (f32) per tensor, norms 8.6e-5 / 8.2e-5
+    TOL = 3e-3     # measured 2.9e-4 (f16x3) / 1.1e-3 (f32) per tensor, norms 8.6e-5 / 8.2e-5
     report, n_checked, n_zero = [], 0, 0
     gmax = max(float(z[k]) for k in z.files if k.startswith("grad3norm/"))
     for name, p in net.named_parameters():
