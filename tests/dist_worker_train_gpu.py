@@ -54,14 +54,32 @@ def main():
             dist.barrier()
         return out
 
-    mine = in_turn(lambda: grads_of(rank))                                   # the copy that is all-reduced
     local = in_turn(lambda: {r: grads_of(r) for r in range(world)})          # every rank's gradients, recomputed here
-    nb = allreduce_gradients(list(mine.parameters()), bucket_bytes=4 << 20)
+    if os.environ.get("PP_DDP") == "torch":
+        # torch's own DistributedDataParallel around the HIP model (what LightningLite's strategy='ddp' builds, utils/lite.py):
+        # its reducer all-reduces gradient buckets INSIDE backward, so the ranks compute concurrently on the shared card here
+        # (the stress form); find_unused_parameters for the checkpoint's dead layers (dpt.py:241-249, dinov2.norm, mask_token)
+        import numpy as np
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        mine = Net(small_cfg())
+        mine.load_state_dict(calibrated_state_dict(mine.state_dict(), 4, "dinov2_vits14"))
+        mine = mine.cuda().train()
+        ddp = DDP(mine, device_ids=[0], find_unused_parameters=True, bucket_cap_mb=4)
+        ep = {k: v.cuda() for k, v in make_train_end_points(2, 100 + rank).items()}
+        np.random.seed(700 + rank)
+        torch.manual_seed(900 + rank)
+        Loss()(ddp(ep))["loss"].backward()
+        torch.cuda.synchronize()
+        nb = 3
+    else:
+        mine = in_turn(lambda: grads_of(rank))                               # the copy that is all-reduced
+        nb = allreduce_gradients(list(mine.parameters()), bucket_bytes=4 << 20)
     torch.cuda.synchronize()
     ok, worst, n = nb >= 3, 0.0, 0
     for (name, p), *cols in zip(mine.named_parameters(), *[local[r].parameters() for r in range(world)]):
-        if p.grad is None:
-            ok = ok and all(c.grad is None for c in cols)
+        if p.grad is None or all(c.grad is None for c in cols):        # (DDP's reducer leaves zeros in the unused parameters)
+            ok = ok and all(c.grad is None for c in cols) and (p.grad is None or float(p.grad.abs().max()) == 0.0)
             continue
         want = sum(c.grad for c in cols) / world
         top = float(want.abs().max())
