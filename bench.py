@@ -310,6 +310,8 @@ def main():
                     help="N > 1: weak = the workload's crops PER RANK (global batch grows with N); strong = the workload's crops as "
                          "the GLOBAL batch, split over the ranks (BASELINE configs[3])")
     ap.add_argument("--global-batch", type=int, default=None, help="strong scaling with this global batch (implies --scaling strong)")
+    ap.add_argument("--sync-loop", action="store_true", help="the host reads every step's poses before it launches the next step "
+                                                             "(rounds 1-2; default now: a serving loop, one step of read latency)")
     ap.add_argument("--shard", default="auto", choices=["auto", "crops", "templates"],
                     help="N > 1: what is sharded over the ranks. auto = crops for weak scaling (independent replicas, no data-path "
                          "collective), templates for strong scaling (configs[3] / [4]: template-sharded bank + all-gathers)")
@@ -419,6 +421,16 @@ def main():
             outs = forward()
             return outs, pnp_for_outputs(outs, ep["real_K"])            # PnP/RANSAC + D2H of the poses
 
+        # the timed loop is a serving loop: step i + 1 is launched before the host reads step i's poses (asynchronous D2H into
+        # two alternating pinned buffers on the same stream), so the GPU does not wait for the host between batches; every
+        # step's poses are read, the last ones before the closing synchronisation
+        from picopose_amd.pipeline import pnp_collect, pnp_for_outputs_async
+        pinned = [torch.empty(5 * Bl, 15, dtype=torch.float64, pin_memory=True) for _ in range(2)]
+
+        def step_launch(i):
+            outs = forward()
+            return pnp_for_outputs_async(outs, ep["real_K"], host=pinned[i % 2])
+
     if kind == "stage1":   # a step is ~1 ms: without ~0.3 s of load first, the timed steps run while the clocks still ramp
         t_ramp = time.perf_counter()
         while time.perf_counter() - t_ramp < 0.3:
@@ -439,9 +451,18 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
+    pending = None
     for i in range(a.steps):
-        out = step()
+        if kind == "stage1" or a.sync_loop:
+            out = step()
+        else:
+            h = step_launch(i)
+            if pending is not None:
+                poses = pnp_collect(pending, 5, Bl)       # the previous step's poses, while this step runs
+            pending = h
         marks[i + 1].record()
+    if pending is not None:
+        poses = pnp_collect(pending, 5, Bl)               # noqa: F841
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -608,6 +629,10 @@ def main():
                               "and f32 epilogues / residual stream; stage-1 contraction: f16 MFMA operands, exact f32 re-evaluation of near-ties; "
                               "PnP f64"}[a.mode],
             "data": "synthetic",
+            "loop": ("every timed step = forward + PnP/RANSAC launch + asynchronous D2H of its poses; the host reads step i's poses after "
+                     "launching step i + 1 (serving loop), the last step's before the closing synchronisation" if kind != "stage1" and not a.sync_loop else
+                     "every timed step = forward + PnP/RANSAC + D2H of its poses, read by the host before the next step is launched" if kind != "stage1" else
+                     "every timed step = one matching call, results left on the device"),
             "config": {"workload": f"{a.workload}: {desc}", "global_batch": B, "crops_per_rank": Bl, "templates": N,
                        "templates_per_rank": n_local, "backbone": vit, "channels": C,
                        "hypotheses": 5, "mode": a.mode, "bank_dtype": "f16" if bpe == 2 else "f32",

@@ -26,6 +26,18 @@ def pnp_for_outputs(outputs, real_K, return_npts=False):
     return out + (res[4].reshape(hyp, B),) if return_npts else out
 
 
+def pnp_for_outputs_async(outputs, real_K, host=None):
+    """pnp_for_outputs without the host wait -> handle; `pnp_collect(handle, hyp, B)` reads it (one batch later in a serving loop)."""
+    from .utils.pose_recovery import pose_recovery_ransac_pnp_batched_async
+
+    return pose_recovery_ransac_pnp_batched_async(*pnp_inputs(outputs, real_K), host=host)
+
+
+def pnp_collect(handle, hyp, B):
+    rot, tvec, ratio, ok = handle.result()
+    return rot.reshape(hyp, B, 3, 3), tvec.reshape(hyp, B, 3, 1), ratio.reshape(hyp, B), ok.reshape(hyp, B)
+
+
 def infer_batch(net, end_points, hyp=5, pnp_fn=None):
     """-> per-instance pose hypotheses sorted by inlier ratio (run_test.py:168-186):
     list over instances of list over hypotheses of dict(R (3,3), t (3,), inliers_ratio, pnp_success).

@@ -60,6 +60,37 @@ def pose_recovery_ransac_pnp_batched(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pt
     return res + (host[:, 14].astype("int32"),) if return_npts else res
 
 
+class PnPHandle:
+    """A batched PnP launch whose result is on its way to the host (pose_recovery_ransac_pnp_batched_async)."""
+    __slots__ = ("host", "event", "P")
+
+    def __init__(self, host, event, P):
+        self.host, self.event, self.P = host, event, P
+
+    def result(self, return_npts=False):
+        """Wait for the copy and unpack: rot (P,3,3) f64, tvec (P,3,1) f64, inliers_ratio (P) f64, success (P) bool [+ npts]."""
+        self.event.synchronize()
+        host, P = self.host.numpy(), self.P
+        res = (host[:, :9].reshape(P, 3, 3).copy(), host[:, 9:12].reshape(P, 3, 1).copy(), host[:, 12].copy(), host[:, 13] != 0)
+        return res + (host[:, 14].astype("int32"),) if return_npts else res
+
+
+def pose_recovery_ransac_pnp_batched_async(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations=150, reproj_error=2.0,
+                                           host=None):
+    """pose_recovery_ransac_pnp_batched without the host wait: the launch and ONE asynchronous device->host copy (P x 15 doubles
+    into a pinned buffer, `host` to reuse one) are enqueued on the current stream; `.result()` of the returned handle waits for
+    them.  A serving loop launches batch i + 1 before it reads batch i's poses, so the GPU never waits for the host."""
+    rot, tvec, ratio, ok, npts = pnp_launch(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations, reproj_error)
+    P = rot.shape[0]
+    packed = torch.cat([rot.reshape(P, 9), tvec, ratio[:, None], ok.double()[:, None], npts.double()[:, None]], dim=1)
+    if host is None or tuple(host.shape) != (P, 15):
+        host = torch.empty(P, 15, dtype=torch.float64, pin_memory=True)
+    host.copy_(packed, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return PnPHandle(host, ev, P)
+
+
 def pose_recovery_ransac_pnp(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts):
     """Drop-in for reference utils/pose_recovery.py:68-105 (one instance/hypothesis):
     -> (rot ndarray(3,3), tvecs ndarray(3,1), inliers_ratio float, success bool); never raises for bad
