@@ -76,7 +76,8 @@ class DPTHead(Packed):
 
     def _rcu_train(self, i, j, x, extra=None):
         """ResidualConvUnit in training mode (dpt.py:72-95): both BatchNorms normalise with the statistics of this batch and
-        update their running buffers (ops.batchnorm_train); forward values only."""
+        update their running buffers (ops.batchnorm_train).  The forward-only training step; under autograd the same layers run through
+        picopose_amd/autograd.dpt_head_forward."""
         u, pkt = getattr(getattr(self.scratch, f"refinenet{i}"), f"resConfUnit{j}"), self.packed_train()
         h = ops.conv2d(x, pkt[f"f{i}_u{j}_c1"], u.conv1.bias, 3, pad=1, relu_in=True)
         h = ops.batchnorm_train(h, u.bn1, relu=True)                        # relu(bn1(.)): the input of conv2

@@ -5,7 +5,8 @@ Same constructor (`Net(cfg)` with cfg.stage1/2/3), same sub-module names (identi
 `model(end_points, hyp)` -> list of `hyp` dicts (model/picopose.py:97-112, 72-95), and
 `model.feature_extractor(x)` usable on its own (run_test.py:130).  All arithmetic runs in
 libpicopose_hip.so.  In training mode `model(end_points)` is the reference's forward_train (:114-137): it returns
-`end_points` with the ten `loss*` entries — forward values only, there are no backward kernels."""
+`end_points` with the ten `loss*` entries, under autograd (picopose_amd/autograd.py: `loss.backward()` is the reference's training
+step — SURVEY.md 8f rank 4; `Net.train_backward` narrows or switches off the graph)."""
 import torch
 import torch.nn as nn
 
