@@ -560,3 +560,60 @@ def test_full_backward_matches_the_reference_autograd(golden_dir, precision):
     assert n_checked + n_zero == 338 and n_zero <= 40
     assert report[0][0] <= TOL, report[:3]
     assert max(b for _, b, _ in report) <= 3e-4     # (the L2 norms of the gradient tensors)
+
+
+@gpu
+def test_full_backward_directional_derivative_at_vitb_width(monkeypatch):
+    """A size-independent property of the whole backward at the configs[2] width (ViT-B/14, 4 pairs), against an INDEPENDENT
+    evaluator: the forward-only training step (fused inference kernels, no autograd).  With g = the gradient of the total loss
+    from the autograd graph and d = g / |g|, the central difference (L(theta + eps d) - L(theta - eps d)) / (2 eps) of the
+    forward-only loss equals |g| — checked on the fp32 engine (the difference of two losses of ~19 needs their last digits) to 2 %."""
+    import types
+
+    from netcfg import make_train_end_points
+    from picopose_amd import ops
+    from picopose_amd.picopose import Net
+    from picopose_amd.utils.loss_utils import Loss
+    from picopose_amd.utils.seeding import calibrated_state_dict
+
+    monkeypatch.setattr(ops, "PRECISION", "f32")
+    ns = types.SimpleNamespace
+    cfg = ns(hypothesis=5, stage1=ns(vit_type="dinov2_vitb14", pretrained=False, interaction_indexes=[[0, 2], [3, 5], [6, 8], [9, 11]]),
+             stage2=ns(in_channel=256, hidden_dim=256),
+             stage3=ns(nclass=1, in_channels=768, use_bn=True, out_channels=[256, 512, 1024, 1024], num_levels=3, radius=4))
+    net = Net(cfg)
+    net.load_state_dict(calibrated_state_dict(net.state_dict(), 4, "dinov2_vitb14"))
+    net = net.cuda().train()
+    ep = {k: v.cuda() for k, v in make_train_end_points(4, 21).items()}
+    from picopose_amd.utils.augment import aug_gtM_noise
+
+    np.random.seed(5)
+    torch.manual_seed(5)
+    pred_Ms = aug_gtM_noise(ep)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def loss_plain():
+        net.load_state_dict(state)                      # (the BatchNorm buffers: every evaluation starts from the same ones)
+        with torch.no_grad():
+            return float(Loss()(net.forward_train(dict(ep), pred_Ms=pred_Ms))["loss"])
+
+    net.load_state_dict(state)
+    total = Loss()(net.forward_train(dict(ep), pred_Ms=pred_Ms))["loss"]
+    total.backward()
+    params = [(n, p) for n, p in net.named_parameters() if p.grad is not None]
+    gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in params)))
+    l0 = loss_plain()
+    assert abs(l0 - float(total.detach())) <= 2e-5 * abs(l0)
+    eps = 0.02 / gnorm                                  # a first-order change of 0.02 in a loss of ~20
+    base = {n: state[n].clone() for n, _ in params}
+    vals = []
+    for sign in (+1.0, -1.0):
+        for n, p in params:
+            state[n] = base[n] + sign * eps * p.grad / gnorm
+        vals.append(loss_plain())
+    for n, _ in params:
+        state[n] = base[n]
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    print(f"directional derivative at ViT-B width: |grad| = {gnorm:.5f}, central difference of the forward-only loss = {fd:.5f} "
+          f"(L = {l0:.5f}, L+ = {vals[0]:.5f}, L- = {vals[1]:.5f})")
+    assert abs(fd - gnorm) <= 2e-2 * gnorm, (fd, gnorm)
