@@ -441,6 +441,9 @@ int pp_normalize_rows_backward(const float* x, long long row_stride, const int64
 /* im2col of an NHWC image for a ksize x ksize / stride / pad convolution (k order (ky, kx, ci), as pack_conv_weight) and its adjoint */
 int pp_im2col_nhwc(const float* x, int B, int H, int W, int C, int ksize, int stride, int pad, float* col, void* stream);
 int pp_col2im_nhwc(const float* col, int B, int H, int W, int C, int ksize, int stride, int pad, float* dx, void* stream);
+/* pp_split_weights_t with a GIVEN scale (device scalar; a power of two): the operand of a weight whose scale the host already knows
+ * (the training graph re-splits every weight each step with the scale read back one step earlier: no host wait) */
+int pp_split_with_scale_t(const float* w, long long n, int terms, const float* scale, void* out, void* stream);
 /* scale2[0] = the power of two s with max|x| s in [512, 1024) (1 for an all-zero x), scale2[1] = 1 / s — the range normalisation of a
  * gradient operand before a backward product (picopose_amd/autograd.py: _ranged); device scalars, no host sync */
 int pp_pow2_scale(const float* x, long long n, float* scale2, void* stream);

@@ -153,6 +153,7 @@ def lib():
         L.pp_simvol_backward.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
         L.pp_im2col_t_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
         L.pp_pow2_scale.argtypes = [vp, ll, vp, vp]
+        L.pp_split_with_scale_t.argtypes = [vp, ll, i32, vp, vp, vp]
         L.pp_batchnorm_train_backward_workspace_bytes.restype = sz
         L.pp_batchnorm_train_backward_workspace_bytes.argtypes = [ll, i32]
         L.pp_batchnorm_train_backward.argtypes = [vp, vp, vp, vp, ll, i32, f32, i32, vp, vp, vp, vp, sz, vp]

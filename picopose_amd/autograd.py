@@ -134,8 +134,10 @@ class _Linear(torch.autograd.Function):
     pre-activation z is kept), backward dz = dy act'(z), dx = dz @ w, dw = dz^T @ x, db = column sums of dz."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act):
-        cache = w.is_leaf                      # a parameter itself: its operand form is cached per version; a re-packed one is transient
+    def forward(ctx, x, w, b, act, owner=None):
+        # a parameter itself: its operand form is cached per version; a matrix derived from the parameter `owner` (reshaped,
+        # re-packed): split every step with the scale read back one step earlier; otherwise transient (one host wait)
+        cache = True if w.is_leaf else ((owner, "lin") if owner is not None else False)
         x, w = _f32c(x), _f32c(w)
         z = ops.linear(x, w, b, cache_weight=cache)
         ctx.act = ACT[act]
@@ -160,11 +162,11 @@ class _Linear(torch.autograd.Function):
         dx = _mm(dz, w, rb=False) if ctx.needs_input_grad[0] else None                       # (weights / activations: forward quantities)
         dw = _mm(dz.t().contiguous(), x, rb=False) if ctx.needs_input_grad[1] else None
         db = colsum(dz) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear(x, w, b=None, act=None):
-    return _Linear.apply(x, w, b, act)
+def linear(x, w, b=None, act=None, owner=None):
+    return _Linear.apply(x, w, b, act, owner)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -695,9 +697,10 @@ class _Conv2d(torch.autograd.Function):
         Cx = x.shape[-1]
         w = weight.detach().float()
         wp = ops.pack_conv_weight(w, cin_pad=Cx if Cx > w.shape[1] else None)
-        y = ops.conv2d(x, wp, bias, k, pad=k // 2, act=act, cache_weight=False)
+        y = ops.conv2d(x, wp, bias, k, pad=k // 2, act=act, cache_weight=(weight, "conv"))
         ctx.save_for_backward(x, w, y if act else None)
         ctx.cfg = (k, act, bias is not None)
+        ctx.owner = weight
         return y
 
     @staticmethod
@@ -717,7 +720,7 @@ class _Conv2d(torch.autograd.Function):
             wf = w.flip(2, 3).permute(1, 0, 2, 3)                         # (Cin, Cout, k, k): dx = conv(dz, flipped weights)
             if Cx > Cin:
                 wf = torch.cat([wf, wf.new_zeros(Cx - Cin, Cout, k, k)], dim=0)
-            dx = ops.conv2d(dzs, ops.pack_conv_weight(wf.contiguous()), None, k, pad=k // 2, cache_weight=False)
+            dx = ops.conv2d(dzs, ops.pack_conv_weight(wf.contiguous()), None, k, pad=k // 2, cache_weight=(ctx.owner, "flip"))
             dx = _unscale(dx, s, None)
         if ctx.needs_input_grad[1]:
             rows = B * H * W
@@ -760,12 +763,12 @@ def conv2d(x, weight, bias, k, stride=1, pad=0, act=None, cin_pad=None):
         w2 = weight.reshape(Cout, -1)
         if Cx > w2.shape[1]:
             w2 = torch.cat([w2, w2.new_zeros(Cout, Cx - w2.shape[1])], dim=1)
-        return linear(x.reshape(-1, Cx), w2.contiguous(), bias, act=act).view(B, H, W, Cout)
+        return linear(x.reshape(-1, Cx), w2.contiguous(), bias, act=act, owner=weight).view(B, H, W, Cout)
     if stride == 1 and k % 2 == 1 and pad == k // 2 and act in (None, "relu") and Cx % 8 == 0:
         return _Conv2d.apply(x, weight, bias, k, act)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     w2 = ops.pack_conv_weight(weight.float(), cin_pad=Cx if Cx > weight.shape[1] else None)
-    return linear(_Im2col.apply(x, k, stride, pad), w2, bias, act=act).view(B, Ho, Wo, Cout)
+    return linear(_Im2col.apply(x, k, stride, pad), w2, bias, act=act, owner=weight).view(B, Ho, Wo, Cout)
 
 
 def _rcu(u, x, extra=None):

@@ -839,6 +839,13 @@ int pp_split_weights_t(const float* w, long long n, int terms, void* out, float*
 
 int pp_split_f16x3(const float* w, long long n, void* hl, float* scale, void* stream) { return pp_split_weights_t(w, n, 2, hl, scale, stream); }
 
+int pp_split_with_scale_t(const float* w, long long n, int terms, const float* scale, void* out, void* stream) {
+    if (!w || !out || !scale || n <= 0 || n % 8 != 0 || (terms != 1 && terms != 2)) return PP_EINVAL;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(split_f16x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, n, scale, (_Float16*)out, terms);
+    return pp_last_launch();
+}
+
 int pp_pow2_scale(const float* x, long long n, float* scale2, void* stream) {
     if (!x || !scale2 || n <= 0) return PP_EINVAL;
     launch_pow2_scale(x, n, scale2, 1, 100, (hipStream_t)stream);

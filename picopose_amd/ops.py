@@ -78,6 +78,44 @@ def split_weight(w, cache=True):
     return hit[0], hit[1]
 
 
+_tracked_scale = {}   # (id(parameter), tag) -> [scale (host float), pending (pinned tensor, event) | None, weakref to the parameter]
+
+
+def split_weight_tracked(w, owner, tag=""):
+    """(hl, scale) of a matrix DERIVED from the parameter `owner` (a re-packed / flipped / reshaped copy made by the training graph
+    every step) without a host wait: the split uses the power-of-two scale the host read back one step EARLIER (any power of two
+    near max|w| serves — the weights move by far less than a factor of two per step), and this call schedules the next read
+    (pp_pow2_scale + an asynchronous copy into pinned memory).  Only the first use of a (parameter, tag) waits."""
+    import weakref
+
+    key = (id(owner), tag)
+    ent = _tracked_scale.get(key)
+    if ent is None or ent[2]() is not owner:
+        hl, scale = split_weight(w, cache=False)
+        if len(_tracked_scale) > 8192:
+            _tracked_scale.clear()
+        _tracked_scale[key] = [scale, None, weakref.ref(owner)]
+        return hl, scale
+    if ent[1] is not None and ent[1][1].query():
+        v = float(ent[1][0][0])
+        if v > 0.0 and v == v and v != float("inf"):
+            ent[0] = v
+        ent[1] = None
+    t = terms()
+    hl = torch.empty(w.shape[0], t * w.shape[1], dtype=torch.float16, device=w.device)
+    sdev = torch.full((1,), ent[0], dtype=torch.float32, device=w.device)
+    _lib.check(_lib.lib().pp_split_with_scale_t(_p(w), w.numel(), t, _p(sdev), _p(hl), _lib.stream_ptr()), "pp_split_with_scale_t")
+    if ent[1] is None:
+        s2 = torch.empty(2, dtype=torch.float32, device=w.device)
+        _lib.check(_lib.lib().pp_pow2_scale(_p(w), w.numel(), _p(s2), _lib.stream_ptr()), "pp_pow2_scale")
+        host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+        host.copy_(s2, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ent[1] = (host, ev)
+    return hl, ent[0]
+
+
 class Split:
     """An activation that exists only as the f16x3 engine's "hl" operand: fp16 (rows, 2C), per 8 channels the 8 hi
     terms then the 8 lo terms (include/picopose_hip.h).  Producers (layernorm, attention, a GEMM epilogue) write it
@@ -150,9 +188,13 @@ def _can_presplit(x, K, C, *strides):
 
 
 def _weight_args(w, K, cache=True):
-    """desc fields for a weight operand under the current precision (pre-split operand when it is aligned)."""
+    """desc fields for a weight operand under the current precision (pre-split operand when it is aligned).
+    cache: True (a parameter: remembered per version) | False (transient: split now, one host wait for its scale) |
+    (owner, tag) (derived from the parameter `owner` every step: split_weight_tracked, no host wait)."""
+    if isinstance(cache, tuple) and os.environ.get("PP_TRACK_SCALE", "1") == "0":
+        cache = False                      # (A/B switch: the scale of every derived weight read back at once, one host wait each)
     if presplit() and K % 8 == 0 and w.data_ptr() % 16 == 0:
-        hl, scale = split_weight(w, cache)
+        hl, scale = split_weight_tracked(w, *cache) if isinstance(cache, tuple) else split_weight(w, cache)
         return dict(prec=_PREC[PRECISION], B_hl=_p(hl), b_scale=scale, _hl=hl)
     return dict(prec=_fly_prec())
 
