@@ -45,17 +45,19 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define PP_STUDY_OFF(x) (x)
 #endif
 
-template <int BM_, int BN_, int WM_, int WN_, int S_, int OCC_, int PREF_ = 0>
+template <int BM_, int BN_, int WM_, int WN_, int S_, int OCC_, int PREF_ = 0, int B3_ = 0>
 struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, S = S_, OCC = OCC_;
     static constexpr bool PREF = PREF_ != 0;             // fragments of K tile kt + 1 are read during K tile kt (two register sets)
+    static constexpr bool B3 = B3_ != 0;                 // S = 2 for the A operand, a ring of THREE stages for the B operand
     static constexpr int NW = WM_ * WN_;                 // waves
     static constexpr int TM = BM_ / WM_, TN = BN_ / WN_;   // wave block
     static constexpr int MI = TM / 16, NJ = TN / 16;     // 16x16 MFMA tiles per wave block
     static constexpr int PA = BM_ / 8 / NW, PB = BN_ / 8 / NW;   // LDS-DMA pieces (8 rows each) per wave and K tile
     static constexpr int A_H = BM_ * 64, B_H = BN_ * 64;   // halfs per operand per stage (128-byte rows)
     static constexpr int STAGE = A_H + B_H;
-    static constexpr int LDS_BYTES = S_ * STAGE * 2;          // the ring (the epilogue leaves from the registers)
+    static constexpr int LDS_BYTES = (B3_ ? 2 * A_H + 3 * B_H : S_ * STAGE) * 2;   // the ring (the epilogue leaves from the registers)
+    static_assert(!B3_ || (S_ == 2 && !PREF_), "the 2 + 3 ring is a variant of the two-stage schedule");
     static_assert(PREF_ || (MI % 2 == 0 && NJ % 2 == 0 && (MI / 2) % 2 == 0), "unit schedule: pairs of row blocks, an even number of them");
     static_assert(!PREF_ || S_ >= 3, "the prefetching schedule refills the stage read one K tile earlier: a ring of three");
     static_assert(BM_ % (8 * NW) == 0 && BN_ % (8 * NW) == 0, "DMA pieces are 8 rows per wave instruction");
@@ -76,6 +78,8 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
     constexpr int KT = 64 / TERMS;       // k per K tile (one 128-byte row segment)
     constexpr int EB = 2 * TERMS;        // operand bytes per element
     constexpr int STAGE = T::STAGE, A_H = T::A_H;
+    // LDS image: stages of [A | B] (A_STR = B_STR = STAGE, B0 = A_H) or, for the 2 + 3 ring, two A stages then three B stages
+    constexpr int A_STR = T::B3 ? A_H : STAGE, B_STR = T::B3 ? T::B_H : STAGE, B0 = T::B3 ? 2 * A_H : A_H;
     constexpr int NSUB = TERMS == 2 ? 3 : 2;   // MFMAs per (16x16 tile, K tile)
     extern __shared__ __attribute__((aligned(16))) _Float16 glds[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
 #ifdef PP_STUDY_NODMA   // (timing study builds only: the K loop without its operand traffic)
         if (d.M > 0) return;
 #endif
-        const lds_ptr_t dst = (lds_ptr_t)(glds + stage * STAGE + ((j * NW + w) * 8) * 64);
+        const lds_ptr_t dst = (lds_ptr_t)(glds + stage * A_STR + ((j * NW + w) * 8) * 64);
         if (MODE == 2) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, dst, 16, PP_STUDY_OFF(off_a2(j)), 0, 0, 0);
         } else {
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
 #ifdef PP_STUDY_NODMA
         if (d.M > 0) return;
 #endif
-        const lds_ptr_t dst = (lds_ptr_t)(glds + stage * STAGE + A_H + ((j * NW + w) * 8) * 64);
+        const lds_ptr_t dst = (lds_ptr_t)(glds + stage * B_STR + B0 + ((j * NW + w) * 8) * 64);
         if (MODE == 2) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, dst, 16, PP_STUDY_OFF(off_b2(j)), 0, 0, 0);
         } else {
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
 #endif
 #ifdef PP_STUDY_LDSNODEP   // (timing study builds only: the fragment reads are issued, the MFMAs do not depend on them)
         {
-            const unsigned a0 = (unsigned)(uintptr_t)(lds_ptr_t)(glds + stage * STAGE + (wr * T::TM + ip * 32) * 64);
+            const unsigned a0 = (unsigned)(uintptr_t)(lds_ptr_t)(glds + stage * A_STR + (wr * T::TM + ip * 32) * 64);
             for (int i = 0; i < 2; ++i) {
                 asm volatile("ds_read_b128 %0, %1" : "+v"(sink) : "v"(a0 + (i * 16 * 64 + fo0) * 2));
                 asm volatile("ds_read_b128 %0, %1" : "+v"(sink) : "v"(a0 + (i * 16 * 64 + fo1) * 2));
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             return;
         }
 #endif
-        const _Float16* st = glds + stage * STAGE + (wr * T::TM + ip * 32) * 64;
+        const _Float16* st = glds + stage * A_STR + (wr * T::TM + ip * 32) * 64;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f.x[i][0] = *(const h8*)(st + i * 16 * 64 + fo0);
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
 #endif
 #ifdef PP_STUDY_LDSNODEP
         {
-            const unsigned b0 = (unsigned)(uintptr_t)(lds_ptr_t)(glds + stage * STAGE + A_H + (wc * T::TN + jh * NJH * 16) * 64);
+            const unsigned b0 = (unsigned)(uintptr_t)(lds_ptr_t)(glds + stage * B_STR + B0 + (wc * T::TN + jh * NJH * 16) * 64);
             for (int j = 0; j < NJH; ++j) {
                 asm volatile("ds_read_b128 %0, %1" : "+v"(sink) : "v"(b0 + (j * 16 * 64 + fo0) * 2));
                 asm volatile("ds_read_b128 %0, %1" : "+v"(sink) : "v"(b0 + (j * 16 * 64 + fo1) * 2));
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             return;
         }
 #endif
-        const _Float16* st = glds + stage * STAGE + A_H + (wc * T::TN + jh * NJH * 16) * 64;
+        const _Float16* st = glds + stage * B_STR + B0 + (wc * T::TN + jh * NJH * 16) * 64;
 #pragma unroll
         for (int j = 0; j < NJH; ++j) {
             f.x[j][0] = *(const h8*)(st + j * 16 * 64 + fo0);
@@ -332,8 +336,12 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
     constexpr int EPI_ST_ = MI * NJ;   // VMEM operations of a vector epilogue, at least (see EPI_ST below)
     constexpr bool SPREAD = S >= 3 && MODE != 2;
     constexpr int NU = 2 * NIP, NM = 2 * NJH, NSLOT = NU * NM, NP = PA + PB;   // units / accumulator tiles per unit / per K tile
-    constexpr int NBEFORE = SPREAD ? ((NU - 1) * NM * NP) / NSLOT : 0;          // pieces of a K tile issued before its wait point
-    constexpr int INFLIGHT = SPREAD ? (S - 3) * NP + NBEFORE : (S - 2) * NP;   // DMA pieces younger than the awaited K tile
+    // B3 (A ring of two, B ring of three — all of the 160 KB of LDS for the 256x256 tile): the B stage read one K tile earlier is
+    // free during the whole K tile, so the B pieces of K tile kt + 2 are spread over units 0 .. NU - 2 and only the A pieces wait
+    // for the barrier (half the burst of the two-stage schedule; same prefetch distance, same arithmetic)
+    constexpr bool B3 = T::B3 && MODE != 2;
+    constexpr int NBEFORE = SPREAD ? ((NU - 1) * NM * NP) / NSLOT : (B3 ? PB : 0);  // pieces of a K tile issued before its wait point
+    constexpr int INFLIGHT = SPREAD ? (S - 3) * NP + NBEFORE : (S - 2) * NP + NBEFORE;   // DMA pieces younger than the awaited K tile
     constexpr int RELAX = SPREAD ? S - 2 : S - 1;   // K tiles after an epilogue whose awaited pieces are OLDER than its stores
     int fill = S - 1;                               // SPREAD: the stage being refilled during the current K tile
     auto piece = [&](int stage, int q) __attribute__((always_inline)) {
@@ -341,7 +349,14 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
         else dma_b(stage, q - PA);
     };
     // unit u of a K tile: its accumulator tiles, with (SPREAD) the DMA pieces that fall into its slots pinned between them
+    int bfill = 2;                                  // B3: the B stage being refilled during the current K tile ((kt + 2) % 3)
     auto unit = [&](const FA& a, const FB& b, int ip, int jh, int u) __attribute__((always_inline)) {
+        if (B3 && u < NU - 1 && (u * PB) / (NU - 1) != ((u + 1) * PB) / (NU - 1)) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = (u * PB) / (NU - 1); q < ((u + 1) * PB) / (NU - 1); ++q) dma_b(bfill, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int t = 0; t < NM; ++t) {
             const int slot = u * NM + t;
@@ -382,11 +397,11 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
         FS f0, f1;
         auto load_blk = [&](FS& f, int stage, int blk) __attribute__((always_inline)) {
             if (blk < MI) {
-                const _Float16* st = glds + stage * STAGE + (wr * T::TM + blk * 16) * 64;
+                const _Float16* st = glds + stage * A_STR + (wr * T::TM + blk * 16) * 64;
                 f.a[blk][0] = *(const h8*)(st + fo0);
                 f.a[blk][1] = *(const h8*)(st + fo1);
             } else {
-                const _Float16* st = glds + stage * STAGE + A_H + (wc * T::TN + (blk - MI) * 16) * 64;
+                const _Float16* st = glds + stage * B_STR + B0 + (wc * T::TN + (blk - MI) * 16) * 64;
                 f.b[blk - MI][0] = *(const h8*)(st + fo0);
                 f.b[blk - MI][1] = *(const h8*)(st + fo1);
             }
@@ -501,6 +516,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
     load_a(fa0, 0, 0);
     load_b(fb0, 0, 0);
     int cur = 0, nxt = S > 1 ? 1 : 0;
+    int bcur = 0, bnxt = 1;             // B3: the B ring's cursors (three stages); otherwise the B operand shares cur / nxt
     const float descale = d.alpha / (PP_A_SCALE * d.b_scale);
     // The vector epilogue issues a fixed number of VMEM operations per wave, whatever the tile (rows / columns out of range
     // are out-of-range offsets, not skipped instructions): at least one 16-byte store per 4 accumulator registers.
@@ -516,8 +532,8 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             // unit (0, 0): fragments of the second column half and of the next row pair start loading
             // (sched_barrier: the fragment reads of a unit stay in that unit — hoisted further up they lengthen the live ranges
             // past the 256 registers of a 512-thread workgroup and hipcc spills inside the loop)
-            if (SPREAD) PP_U_KTILE()
-            load_b(fb1, cur, 1);
+            if (SPREAD || B3) PP_U_KTILE()
+            load_b(fb1, B3 ? bcur : cur, 1);
             load_a(fa1, cur, 1);
             unit(fa0, fb0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
                 nxt = nxt == S - 1 ? 0 : nxt + 1;
                 continue;
             }
-            PP_U_KTILE()
+            if (!B3) PP_U_KTILE()
             if (MODE == 2) {
 #pragma unroll
                 for (int j = 0; j < PA; ++j) dma_a(cur, j);
@@ -583,13 +599,15 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
                 load_a(fa0, nxt, 0);
 #pragma unroll
                 for (int t = 0; t < NM; ++t) {
-                    // pieces [t NP / NM, (t + 1) NP / NM) before tile t's MFMAs
+                    // pieces [t NP / NM, (t + 1) NP / NM) before tile t's MFMAs (B3: the A pieces only — the B pieces went out
+                    // over the earlier units)
+                    constexpr int NPL = B3 ? PA : NP;
 #pragma unroll
-                    for (int q = t * NP / NM; q < (t + 1) * NP / NM; ++q) {
+                    for (int q = t * NPL / NM; q < (t + 1) * NPL / NM; ++q) {
                         if (q < PA) dma_a(cur, q);
                         else dma_b(cur, q - PA);
                     }
-                    if (t == 1) load_b(fb0, nxt, 0);
+                    if (t == 1) load_b(fb0, B3 ? bnxt : nxt, 0);
                     mma1(fa1, fb1, NIP - 1, 1, t / NJH, t % NJH);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -597,6 +615,11 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             }
             cur = nxt;
             nxt = nxt == S - 1 ? 0 : nxt + 1;
+            if (B3) {
+                bfill = bcur;
+                bcur = bnxt;
+                bnxt = bnxt == 2 ? 0 : bnxt + 1;
+            }
         }
         // epilogue of this tile; the ring keeps receiving the next tile meanwhile (fa0 / fb0 already hold its first fragments)
         int tr, tc;
@@ -910,7 +933,7 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_uh_kernel(const PpGemmDesc d, 
 #endif
 }
 
-typedef TileCfg<256, 256, 2, 4, 2, 1> T256x256;   // 8 waves, 128x64 each, 2 x 64 KB ring
+typedef TileCfg<256, 256, 2, 4, 2, 1, 0, 1> T256x256;   // 8 waves, 128x64 each, 2 x 64 KB ring
 typedef TileCfg<256, 128, 4, 2, 3, 1, 1> T256x128;   // 8 waves, 64x64 each, 3 x 48 KB ring, prefetching schedule
 typedef TileCfg<128, 128, 2, 2, 2, 2> T128x128;   // 4 waves, 64x64 each, 2 x 32 KB ring: two workgroups per CU
 typedef TileCfg<128, 64, 2, 2, 3, 2> T128x64;     // 4 waves, 64x32 each, 3 x 24 KB ring: two workgroups per CU
