@@ -340,7 +340,11 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
     // free during the whole K tile, so the B pieces of K tile kt + 2 are spread over units 0 .. NU - 2 and only the A pieces wait
     // for the barrier (half the burst of the two-stage schedule; same prefetch distance, same arithmetic)
     constexpr bool B3 = T::B3 && MODE != 2;
-    constexpr int NBEFORE = SPREAD ? ((NU - 1) * NM * NP) / NSLOT : (B3 ? PB : 0);  // pieces of a K tile issued before its wait point
+    // B3E: with four row pairs (NIP == 4) every fragment of the K tile is in registers one unit earlier than the two-stage schedule
+    // assumes (the last two units multiply the LAST row pair by the two column halves), so wait + barrier move in front of unit NU - 2
+    // and the A pieces go out two and two over the last TWO units
+    constexpr bool B3E = B3 && NIP == 4;
+    constexpr int NBEFORE = SPREAD ? ((NU - 1) * NM * NP) / NSLOT : (B3E ? ((NU - 2) * PB) / (NU - 1) : (B3 ? PB : 0));  // pieces issued before the wait
     constexpr int INFLIGHT = SPREAD ? (S - 3) * NP + NBEFORE : (S - 2) * NP + NBEFORE;   // DMA pieces younger than the awaited K tile
     constexpr int RELAX = SPREAD ? S - 2 : S - 1;   // K tiles after an epilogue whose awaited pieces are OLDER than its stores
     int fill = S - 1;                               // SPREAD: the stage being refilled during the current K tile
@@ -350,11 +354,16 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
     };
     // unit u of a K tile: its accumulator tiles, with (SPREAD) the DMA pieces that fall into its slots pinned between them
     int bfill = 2;                                  // B3: the B stage being refilled during the current K tile ((kt + 2) % 3)
+    int a_fill = 0;                                 // B3E: the A stage of the current K tile (refilled from unit NU - 2 on)
     auto unit = [&](const FA& a, const FB& b, int ip, int jh, int u) __attribute__((always_inline)) {
-        if (B3 && u < NU - 1 && (u * PB) / (NU - 1) != ((u + 1) * PB) / (NU - 1)) {
+        if (B3 && u < NU - 1 && ((u * PB) / (NU - 1) != ((u + 1) * PB) / (NU - 1) || (B3E && u == NU - 2))) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = (u * PB) / (NU - 1); q < ((u + 1) * PB) / (NU - 1); ++q) dma_b(bfill, q);
+            if (B3E && u == NU - 2) {   // (after the barrier: the first half of the A pieces of K tile kt + 2)
+#pragma unroll
+                for (int q = 0; q < PA / 2; ++q) dma_a(a_fill, q);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -551,8 +560,10 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
                 unit(fa0, fb1, 2, 1, 5);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            unit(fa1, fb0, NIP - 1, 0, NU - 2);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!B3E) {
+                unit(fa1, fb0, NIP - 1, 0, NU - 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // K tile kt + 1 has landed (this wave's pieces: counted wait; every wave's: barrier); every fragment of tile kt is in registers
             // (the first S - 1 K tiles after an epilogue: its stores — at least EPI_ST per wave, all younger than the pieces waited
             // for here — may stay in flight; from then on they are older than the awaited pieces and have had S - 1 K tiles to retire)
@@ -566,6 +577,11 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
 #ifndef PP_STUDY_NOBAR   // (timing study builds only)
             __builtin_amdgcn_s_barrier();
 #endif
+            if (B3E) {
+                a_fill = cur;
+                unit(fa1, fb0, NIP - 1, 0, NU - 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // last unit | DMA of K tile kt + S into the stage just freed, first fragments of K tile kt + 1
             if (SPREAD) {
                 load_a(fa0, nxt, 0);
@@ -601,9 +617,9 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
                 for (int t = 0; t < NM; ++t) {
                     // pieces [t NP / NM, (t + 1) NP / NM) before tile t's MFMAs (B3: the A pieces only — the B pieces went out
                     // over the earlier units)
-                    constexpr int NPL = B3 ? PA : NP;
+                    constexpr int NPL = B3 ? PA : NP, Q0 = B3E ? PA / 2 : 0;   // (B3E: the first half went out in unit NU - 2)
 #pragma unroll
-                    for (int q = t * NPL / NM; q < (t + 1) * NPL / NM; ++q) {
+                    for (int q = Q0 + t * (NPL - Q0) / NM; q < Q0 + (t + 1) * (NPL - Q0) / NM; ++q) {
                         if (q < PA) dma_a(cur, q);
                         else dma_b(cur, q - PA);
                     }
