@@ -13,7 +13,8 @@ import numpy as np
 import torch
 
 REF = os.environ.get("PICOPOSE_REFERENCE", "/root/reference")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+# PICOPOSE_GOLDEN_OUT: write somewhere else (tests/test_fixture_provenance.py regenerates into a temp dir and compares)
+OUT = os.environ.get("PICOPOSE_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
 def _ref():
