@@ -373,6 +373,17 @@ int pp_pnp_ransac(const float* tar_pts_2d, const float* src_pts_3d, const float*
                   float reproj_threshold, double* rot, double* tvec, double* inlier_ratio, int32_t* success,
                   int32_t* num_points, void* stream);
 
+/* pp_pnp_ransac with one more output for parity work: refit_branches (P, 40) f64 = for the final EPnP refit on the consensus
+ * set, the candidate pose of each of EPnP's three beta initialisations (N = 1 / 2 / 3 null-space vectors; OpenCV's epnp.cpp
+ * find_betas_approx_1 / _2 / _3 behind cv2.solvePnPRansac, utils/pose_recovery.py:93-95) as [R (9, row-major), t (3), mean
+ * reprojection error in px (1e300: the branch gave no pose)] x 3, then the index of the branch the refit kept (-1: none, the
+ * RANSAC winner's pose is returned).  Two correct EPnP implementations may keep different branches when their errors are
+ * within rounding of each other; compared branch by branch they must agree to solver accuracy (tests/test_e2e.py). */
+int pp_pnp_ransac_debug(const float* tar_pts_2d, const float* src_pts_3d, const float* K, const float* tem_pose,
+                        const int64_t* tar_pts, const int64_t* src_pts, int P, int H, int W, int N, int iterations,
+                        float reproj_threshold, double* rot, double* tvec, double* inlier_ratio, int32_t* success,
+                        int32_t* num_points, double* refit_branches, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Training forward (model/picopose.py:114-137 — losses only, no gradients; csrc/pp_train.hip)
  * ------------------------------------------------------------------------- */

@@ -152,8 +152,10 @@ def _hestenes12(G):
     return (g * g).sum(axis=0), v
 
 
-def epnp(p3, p2, cam, solver="lapack"):
+def epnp(p3, p2, cam, solver="lapack", branches=None):
     """EPnP on the given points: returns (mean reprojection error, R (3,3), t (3,)); error = inf if no solution.
+    branches: a list that receives, per beta initialisation (N = 1 / 2 / 3), the candidate (err, R, t) — err = inf where the
+    branch gave no pose (what pp_pnp_ransac_debug returns for the refit).
     solver="lapack": numpy eigh (independent of the kernel); solver="kernel": the kernel's own eigen-solvers restated
     (_eig3_jacobi, _hestenes12), which fixes the basis of the degenerate null space of a minimal sample the same way."""
     fu, fv, uc, vc = cam
@@ -214,6 +216,8 @@ def epnp(p3, p2, cam, solver="lapack"):
                 if approx == 2:
                     b[2] = x[3] / b[0] if abs(b[0]) > 1e-300 else 0.0
             if not np.all(np.isfinite(b)):
+                if branches is not None:
+                    branches.append((np.inf, np.eye(3), np.zeros(3)))
                 continue
             for _ in range(5):                               # Gauss-Newton on the 6 distance constraints
                 A = np.stack([2 * L[:, 0] * b[0] + L[:, 1] * b[1] + L[:, 3] * b[2] + L[:, 6] * b[3],
@@ -234,6 +238,8 @@ def epnp(p3, p2, cam, solver="lapack"):
             du = uc + fu * cam_pts[:, 0] / cam_pts[:, 2] - p2[:, 0]
             dvv = vc + fv * cam_pts[:, 1] / cam_pts[:, 2] - p2[:, 1]
             err = np.sqrt(du * du + dvv * dvv).mean()
+        if branches is not None:
+            branches.append((err if np.isfinite(err) else np.inf, R, t))
         if np.isfinite(err) and err < best[0]:
             best = (err, R, t)
     return best
@@ -249,12 +255,15 @@ def _inliers(p3, p2, cam, R, t, th2):
 
 
 def pose_recovery_ransac_pnp(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, prob=0, iterations=150,
-                             reproj_error=2.0, solver="lapack"):
+                             reproj_error=2.0, solver="lapack", return_branches=False):
     """utils/pose_recovery.py:68-105 -> (rot (3,3) f64, tvecs (3,1) f64, inliers_ratio float, success bool).
-    `prob` is the problem's index in its batch (it seeds the sampling sequence, as in the batched HIP launch)."""
+    `prob` is the problem's index in its batch (it seeds the sampling sequence, as in the batched HIP launch).
+    return_branches: a fifth element, the refit's three beta-branch candidates [(err, R, t)] * 3 ([] on failure)."""
     fail = (np.eye(3), np.array([[0.0], [0.0], [1.0]]), 0.0, False)
     p3, p2 = gather_valid(tar_pts_2d, src_pts_3d, tem_pose, tar_pts, src_pts)
     n = len(p3)
+    if return_branches:
+        fail = fail + ([],)
     if n < SAMPLE:
         return fail
     K = np.asarray(K, np.float32).astype(np.float64)
@@ -272,10 +281,12 @@ def pose_recovery_ransac_pnp(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_p
     if best_c < SAMPLE:
         return fail
     use = _inliers(p3, p2, cam, best[0], best[1], th2)
-    err, R, t = epnp(p3[use], p2[use], cam, solver)
+    branches = []
+    err, R, t = epnp(p3[use], p2[use], cam, solver, branches)
     if not np.isfinite(err):
         R, t = best
-    return R, t.reshape(3, 1), best_c / n, True
+    res = (R, t.reshape(3, 1), best_c / n, True)
+    return res + (branches,) if return_branches else res
 
 
 def reprojection_gap(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, pose_a, pose_b):

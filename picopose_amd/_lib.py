@@ -126,6 +126,7 @@ def lib():
         L.pp_corr_lookup_nhwc_ex.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
         L.pp_corr_lookup_nhwc_hl.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
         L.pp_pnp_ransac.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]
+        L.pp_pnp_ransac_debug.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
         L.pp_train_keypoints_workspace_bytes.restype = sz
         L.pp_train_keypoints_workspace_bytes.argtypes = [i32]
         L.pp_train_keypoints.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32] + [vp] * 10 + [i32, vp, vp, vp, sz, vp]

@@ -307,8 +307,10 @@ __device__ inline void block_sum(const PointSet<MODE>& ps, double (&vals)[CNT]) 
 // vectors in LDS; PHASE 2 (ONE THREAD per hypothesis, 64 per wave) repeats the cheap preparation — bit for bit the same
 // control points — picks the vectors up and does the scalar algebra (three beta initialisations, Gauss-Newton, Horn
 // alignment), which a group would execute sixteen times over.
+// dbg (MODE 1 only, may be null): the three beta-branch candidates of this solve, [3][13] = R (9), t (3), mean reprojection
+// error (1e300: the branch produced no pose) — what pp_pnp_ransac_debug returns for the refit.
 template <int MODE, int PHASE = 0>
-__device__ double epnp(const PointSet<MODE>& ps, const Cam& cam, double (&R)[9], double (&t)[3]) {
+__device__ double epnp(const PointSet<MODE>& ps, const Cam& cam, double (&R)[9], double (&t)[3], double* dbg = nullptr) {
     const int gk = threadIdx.x & (GL - 1);   // lane of the solver group
     // ---- control points: centroid + principal directions
     double a4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -465,6 +467,9 @@ _Pragma("unroll")
     }
     // ---- three beta initialisations, Gauss-Newton, pose, keep the least reprojection error
     double best_err = 1e300;
+    if (MODE == 1 && dbg && threadIdx.x == 0) {
+        for (int k = 0; k < 39; ++k) dbg[k] = k % 13 == 12 ? 1e300 : 0.0;
+    }
     for (int approx = 0; approx < 3; ++approx) {
         double b[4] = {0, 0, 0, 0};
         if (approx == 0) {  // betas10 columns B11 B12 B13 B14
@@ -565,6 +570,11 @@ _Pragma("unroll")
         })
         block_sum<MODE, 1>(ps, er);
         const double err = er[0] / n;
+        if (MODE == 1 && dbg && threadIdx.x == 0) {
+            for (int k = 0; k < 9; ++k) dbg[approx * 13 + k] = Rc[k];
+            for (int k = 0; k < 3; ++k) dbg[approx * 13 + 9 + k] = tc[k];
+            dbg[approx * 13 + 12] = err == err ? err : 1e300;
+        }
         if (err == err && err < best_err) {
             best_err = err;
 #pragma unroll
@@ -589,7 +599,8 @@ __global__ __launch_bounds__(NT) void pnp_ransac_kernel(const float* __restrict_
                                                         const int64_t* __restrict__ tar_pts, const int64_t* __restrict__ src_pts,
                                                         int H, int W, int N, int iters, float thresh, double* __restrict__ rot,
                                                         double* __restrict__ tvec, double* __restrict__ ratio,
-                                                        int32_t* __restrict__ ok, int32_t* __restrict__ npts) {
+                                                        int32_t* __restrict__ ok, int32_t* __restrict__ npts,
+                                                        double* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* p3 = (float*)smem;                      // [MAXP][3]
     float* p2 = p3 + 3 * MAXP;                     // [MAXP][2]
@@ -642,6 +653,8 @@ __global__ __launch_bounds__(NT) void pnp_ransac_kernel(const float* __restrict_
     if (tid == 0) npts[prob] = np;
     auto fail = [&]() {
         if (tid == 0) {
+            if (dbg)
+                for (int k = 0; k < 40; ++k) dbg[(size_t)prob * 40 + k] = k == 39 ? -1.0 : k % 13 == 12 ? 1e300 : 0.0;
             for (int k = 0; k < 9; ++k) rot[(size_t)prob * 9 + k] = (k % 4 == 0) ? 1.0 : 0.0;
             tvec[(size_t)prob * 3] = 0.0; tvec[(size_t)prob * 3 + 1] = 0.0; tvec[(size_t)prob * 3 + 2] = 1.0;
             ratio[prob] = 0.0;
@@ -756,9 +769,13 @@ __global__ __launch_bounds__(NT) void pnp_ransac_kernel(const float* __restrict_
     // ---- refit on the inlier set (all threads cooperate, identical small algebra in every thread)
     PointSet<1> ps = {p3, p2, nullptr, use, np, red, nullptr};
     double R[9], t[3];
-    const double e = epnp<1>(ps, cam, R, t);
+    const double e = epnp<1>(ps, cam, R, t, dbg ? dbg + (size_t)prob * 40 : nullptr);
     if (tid == 0) {
         const bool good = e < 1e299;
+        if (dbg) {   // the branch the refit kept: the first one of least error (-1: none, the RANSAC winner is returned)
+            double* d = dbg + (size_t)prob * 40;
+            d[39] = !good ? -1.0 : d[12] == e ? 0.0 : d[25] == e ? 1.0 : 2.0;
+        }
         const double* M = hyp + best_h * 12;
         for (int k = 0; k < 9; ++k) rot[(size_t)prob * 9 + k] = good ? R[k] : M[k];
         for (int k = 0; k < 3; ++k) tvec[(size_t)prob * 3 + k] = good ? t[k] : M[9 + k];
@@ -769,12 +786,10 @@ __global__ __launch_bounds__(NT) void pnp_ransac_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" {
-
-int pp_pnp_ransac(const float* tar_pts_2d, const float* src_pts_3d, const float* K, const float* tem_pose,
-                  const int64_t* tar_pts, const int64_t* src_pts, int P, int H, int W, int N, int iterations,
-                  float reproj_threshold, double* rot, double* tvec, double* inlier_ratio, int32_t* success,
-                  int32_t* num_points, void* stream) {
+static int pnp_launch(const float* tar_pts_2d, const float* src_pts_3d, const float* K, const float* tem_pose,
+                      const int64_t* tar_pts, const int64_t* src_pts, int P, int H, int W, int N, int iterations,
+                      float reproj_threshold, double* rot, double* tvec, double* inlier_ratio, int32_t* success,
+                      int32_t* num_points, double* dbg, void* stream) {
     if (!tar_pts_2d || !src_pts_3d || !K || !tem_pose || !tar_pts || !src_pts || !rot || !tvec || !inlier_ratio ||
         !success || !num_points)
         return PP_EINVAL;
@@ -789,8 +804,27 @@ int pp_pnp_ransac(const float* tar_pts_2d, const float* src_pts_3d, const float*
     }
     hipLaunchKernelGGL(pnp_ransac_kernel, dim3(P), dim3(NT), smem, (hipStream_t)stream, tar_pts_2d, src_pts_3d, K,
                        tem_pose, tar_pts, src_pts, H, W, N, iterations, reproj_threshold, rot, tvec, inlier_ratio,
-                       success, num_points);
+                       success, num_points, dbg);
     return pp_last_launch();
+}
+
+extern "C" {
+
+int pp_pnp_ransac(const float* tar_pts_2d, const float* src_pts_3d, const float* K, const float* tem_pose,
+                  const int64_t* tar_pts, const int64_t* src_pts, int P, int H, int W, int N, int iterations,
+                  float reproj_threshold, double* rot, double* tvec, double* inlier_ratio, int32_t* success,
+                  int32_t* num_points, void* stream) {
+    return pnp_launch(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, P, H, W, N, iterations, reproj_threshold, rot, tvec,
+                      inlier_ratio, success, num_points, nullptr, stream);
+}
+
+int pp_pnp_ransac_debug(const float* tar_pts_2d, const float* src_pts_3d, const float* K, const float* tem_pose,
+                        const int64_t* tar_pts, const int64_t* src_pts, int P, int H, int W, int N, int iterations,
+                        float reproj_threshold, double* rot, double* tvec, double* inlier_ratio, int32_t* success,
+                        int32_t* num_points, double* refit_branches, void* stream) {
+    if (!refit_branches) return PP_EINVAL;
+    return pnp_launch(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, P, H, W, N, iterations, reproj_threshold, rot, tvec,
+                      inlier_ratio, success, num_points, refit_branches, stream);
 }
 
 }  // extern "C"

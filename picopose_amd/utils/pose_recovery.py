@@ -24,9 +24,10 @@ def pose_recovery_2d_prediction(query_M, query_K, pred_Ms, template_K, template_
     return out
 
 
-def pnp_launch(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations=150, reproj_error=2.0):
+def pnp_launch(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations=150, reproj_error=2.0, branches=False):
     """Enqueue the batched PnP/RANSAC kernel; returns DEVICE tensors (rot (P,3,3) f64, tvec (P,3) f64, ratio (P) f64,
-    ok (P) i32, npts (P) i32 = correspondences each problem received) without synchronising."""
+    ok (P) i32, npts (P) i32 = correspondences each problem received) without synchronising.  branches=True: a sixth tensor
+    (P,40) f64, the refit's three beta-branch candidates [R, t, error] and the index of the one kept (pp_pnp_ransac_debug)."""
     t2, s3, Kd, pose = _lib.dev_f32(tar_pts_2d, src_pts_3d, K, tem_pose)
     tp, sp = tar_pts.contiguous().long(), src_pts.contiguous().long()
     P, _, H, W = t2.shape
@@ -37,11 +38,32 @@ def pnp_launch(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations
     ratio = torch.empty(P, dtype=torch.float64, device=dev)
     ok = torch.empty(P, dtype=torch.int32, device=dev)
     npts = torch.empty(P, dtype=torch.int32, device=dev)
+    if branches:
+        dbg = torch.empty(P, 40, dtype=torch.float64, device=dev)
+        rc = _lib.lib().pp_pnp_ransac_debug(t2.data_ptr(), s3.data_ptr(), Kd.data_ptr(), pose.data_ptr(), tp.data_ptr(), sp.data_ptr(),
+                                            P, H, W, N, int(iterations), float(reproj_error), rot.data_ptr(), tvec.data_ptr(),
+                                            ratio.data_ptr(), ok.data_ptr(), npts.data_ptr(), dbg.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pp_pnp_ransac_debug")
+        return rot, tvec, ratio, ok, npts, dbg
     rc = _lib.lib().pp_pnp_ransac(t2.data_ptr(), s3.data_ptr(), Kd.data_ptr(), pose.data_ptr(), tp.data_ptr(), sp.data_ptr(),
                                   P, H, W, N, int(iterations), float(reproj_error), rot.data_ptr(), tvec.data_ptr(),
                                   ratio.data_ptr(), ok.data_ptr(), npts.data_ptr(), _lib.stream_ptr())
     _lib.check(rc, "pp_pnp_ransac")
     return rot, tvec, ratio, ok, npts
+
+
+def refit_branches(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations=150, reproj_error=2.0):
+    """Parity instrument (tests): the batched kernel's result plus, per problem, the three beta-branch candidates of its final
+    refit -> rot (P,3,3), tvec (P,3,1), ratio (P), ok (P), branches: list (P) of ([(err, R (3,3), t (3,))] * 3, kept index)."""
+    rot, tvec, ratio, ok, npts, dbg = pnp_launch(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations, reproj_error,
+                                                 branches=True)
+    d = dbg.cpu().numpy()
+    out = []
+    for p in range(d.shape[0]):
+        cand = [(float(d[p, 13 * a + 12]) if d[p, 13 * a + 12] < 1e299 else float("inf"), d[p, 13 * a:13 * a + 9].reshape(3, 3).copy(),
+                 d[p, 13 * a + 9:13 * a + 12].copy()) for a in range(3)]
+        out.append((cand, int(d[p, 39])))
+    return rot.cpu().numpy(), tvec.cpu().numpy()[:, :, None], ratio.cpu().numpy(), ok.cpu().numpy() != 0, out
 
 
 def pose_recovery_ransac_pnp_batched(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations=150,

@@ -261,6 +261,11 @@ def _check_hip_vs_reference(z, tag, B, hyp, ref, outs, flow, cert):
     return total_bad
 
 
+# a20, branch by branch (see the test below): candidate poses of the kernel's refit against the LAPACK oracle's same-index candidates
+PNP_BRANCH_TOL = 1e-6      # |dR|, |dt| (metres) per candidate
+PNP_TIE_REL = 1e-9         # the kept index must be equal unless the oracle's two best mean reprojection errors are this close
+
+
 @gpu
 @pytest.mark.parametrize("tag", CAL_CASES)
 def test_hip_forward_vs_reference_calibrated(golden_dir, tag):
@@ -277,34 +282,64 @@ def test_hip_forward_vs_reference_calibrated(golden_dir, tag):
     # same lists (same sampling sequence, problem id h*B+b) in its solver-INDEPENDENT form: solver="lapack" (eigh / svd / lstsq —
     # nothing of the kernel's Jacobi sequences).  On the round-3 synthetic object (8 cm of relief on the optical axis, the
     # dataset's layout of real_pts2d, tests/netcfg.py) nearly every correspondence is an inlier of the true motion, so the
-    # RANSAC winner does not depend on how a 5-point sample's 2-dimensional null space is resolved: consensus within 1 % of the
-    # points (measured: identical), t within 5 mm, R within 1.5e-2 (measured <= 3.2 mm / 6.8e-3: the scatter of EPnP's own choice between
-    # its null-space solutions on the refit, profiles/r03/pnp_e2e_agreement.txt);
+    # RANSAC winner does not depend on how a 5-point sample's 2-dimensional null space is resolved: the consensus sets are
+    # IDENTICAL.  The refit on that set is EPnP's choice among three candidate poses (beta initialisations with N = 1 / 2 / 3
+    # null-space vectors), by least mean reprojection error.  Round 3 compared only the chosen poses (0.6-3.2 mm apart where the
+    # two solvers kept different candidates of nearly equal error) under a 5 mm bar that a real arithmetic difference in one
+    # branch would have passed.  Now: pp_pnp_ransac_debug returns all three candidates and the comparison is
+    # BRANCH BY BRANCH — every candidate pose within PNP_BRANCH_TOL of the oracle's same-index candidate, the kept index equal
+    # whenever the oracle's two best errors are more than PNP_TIE_REL apart, and the returned pose = the kept candidate;
     # (b) the chain: PnP on the HIP net's own lists (a few threshold slots may differ): the same consensus within 2 %.
+    from picopose_amd.pipeline import pnp_inputs
+    from picopose_amd.utils.pose_recovery import refit_branches
+
     ref_outs = [dict(outs[h], pred_tar_pts=torch.from_numpy(ref[h]["pred_tar_pts"]).cuda(),
                      pred_src_pts=torch.from_numpy(ref[h]["pred_src_pts"]).cuda()) for h in range(hyp)]
     rrot, rtvec, rratio, rok, rnpts = pnp_for_outputs(ref_outs, dev["real_K"], return_npts=True)
-    worst = [0.0, 0.0, 0.0]
+    brot, btvec, bratio, bok, branches = refit_branches(*pnp_inputs(ref_outs, dev["real_K"]))
+    assert np.array_equal(brot.reshape(rrot.shape), rrot) and np.array_equal(btvec.reshape(rtvec.shape), rtvec)   # same kernel, same bits
+    worst = {"dt": 0.0, "dR": 0.0, "derr": 0.0, "chosen_dt": 0.0}
+    kept_differs, ties = 0, 0
     for h in range(hyp):
         for b in range(B):
             t2 = ep["real_pts2d"][b].permute(2, 1, 0).numpy()
             sel = int(np.argmax([np.array_equal(ep["tem_pose"][b, n].numpy(), ref[h]["tem_pose"][b]) for n in range(N)]))
             s3 = ep["tem_pts3d"][b, sel].permute(2, 0, 1).numpy()
-            orot, otvec, oratio, ook = opnp.pose_recovery_ransac_pnp(t2, s3, ep["real_K"][b].numpy(), ref[h]["tem_pose"][b],
-                                                                     ref[h]["pred_tar_pts"][b], ref[h]["pred_src_pts"][b], prob=h * B + b,
-                                                                     solver="lapack")
+            orot, otvec, oratio, ook, obr = opnp.pose_recovery_ransac_pnp(t2, s3, ep["real_K"][b].numpy(), ref[h]["tem_pose"][b],
+                                                                          ref[h]["pred_tar_pts"][b], ref[h]["pred_src_pts"][b],
+                                                                          prob=h * B + b, solver="lapack", return_branches=True)
             n = int(rnpts[h, b])
             assert ook and rok[h, b] and n == int(_valid(ref[h]["pred_tar_pts"][b:b + 1])[0])
-            worst = [max(worst[0], abs(oratio - rratio[h, b])), max(worst[1], float(np.abs(otvec - rtvec[h, b]).max())),
-                     max(worst[2], float(np.abs(orot - rrot[h, b]).max()))]
             assert rratio[h, b] > 0.8, (h, b, rratio[h, b])
-            assert abs(oratio - rratio[h, b]) <= 0.01, (h, b, oratio * n, rratio[h, b] * n)
-            assert np.abs(otvec - rtvec[h, b]).max() < 5e-3 and np.abs(orot - rrot[h, b]).max() < 1.5e-2, (h, b, otvec.ravel(), rtvec[h, b].ravel())
+            assert round(oratio * n) == round(rratio[h, b] * n), (h, b, oratio * n, rratio[h, b] * n)      # identical consensus
+            cand, kept = branches[h * B + b]
+            assert len(obr) == 3 and kept in (0, 1, 2)
+            for a in range(3):
+                (ke, kR, kt), (oe, oR, ot) = cand[a], obr[a]
+                assert np.isfinite(ke) == np.isfinite(oe), (h, b, a, ke, oe)
+                if not np.isfinite(ke):
+                    continue
+                worst["dt"] = max(worst["dt"], float(np.abs(kt - ot).max()))
+                worst["dR"] = max(worst["dR"], float(np.abs(kR - oR).max()))
+                worst["derr"] = max(worst["derr"], abs(ke - oe))
+                assert np.abs(kt - ot).max() <= PNP_BRANCH_TOL and np.abs(kR - oR).max() <= PNP_BRANCH_TOL, (h, b, a, kt, ot)
+                assert abs(ke - oe) <= PNP_BRANCH_TOL * 1e3, (h, b, a, ke, oe)        # px: |d err| <= f * |d pose| / z
+            oerr = sorted(e for e, _, _ in obr)
+            okept = int(np.argmin([e for e, _, _ in obr]))
+            tie = oerr[1] - oerr[0] <= PNP_TIE_REL * oerr[0]
+            ties += tie
+            kept_differs += kept != okept
+            assert kept == okept or tie, (h, b, kept, okept, oerr)
+            # the returned pose is the kept candidate, and the oracle's candidate of THAT index is the same pose
+            assert np.array_equal(rrot[h, b], cand[kept][1]) and np.array_equal(rtvec[h, b, :, 0], cand[kept][2])
+            worst["chosen_dt"] = max(worst["chosen_dt"], float(np.abs(otvec - rtvec[h, b]).max()))
             assert abs(ratio[h, b] - rratio[h, b]) < 0.02
             # and it is the pose stage 2 predicted, refined: same ballpark
             assert np.abs(tvec[h, b, :, 0] - ref[h]["pred_poses"][b, :3, 3]).max() < 0.05
-    print(f"PnP {tag}: HIP kernel vs solver-independent oracle on the reference's key-points: max |consensus ratio diff| {worst[0]:.4f}, "
-          f"max |dt| {worst[1]:.2e} m, max |dR| {worst[2]:.2e}; inlier ratios {rratio.min():.3f}..{rratio.max():.3f}")
+    print(f"PnP {tag}: HIP kernel vs solver-independent oracle on the reference's key-points, {hyp * B} problems: consensus identical; "
+          f"per beta branch max |dt| {worst['dt']:.2e} m, max |dR| {worst['dR']:.2e}, max |d err| {worst['derr']:.2e} px; kept branch "
+          f"differs in {kept_differs} problems ({ties} with the oracle's two best errors within {PNP_TIE_REL:g} relative); chosen poses "
+          f"max |dt| {worst['chosen_dt']:.2e} m; inlier ratios {rratio.min():.3f}..{rratio.max():.3f}")
 
 
 @gpu

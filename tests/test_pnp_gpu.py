@@ -135,3 +135,41 @@ def test_statistical_characterisation_against_ground_truth_and_oracle():
             if noise <= 0.3:
                 assert r["pose_found"] >= 0.55 and r["rot_deg_p50"] < 0.3, (tag, r)
         assert r["oracle_success_agrees"] >= 0.66, (tag, r)
+
+
+@gpu
+def test_refit_branches_agree_with_the_lapack_oracle_branch_by_branch():
+    """pp_pnp_ransac_debug: the three candidate poses of the final EPnP refit (beta initialisations with N = 1 / 2 / 3 null-space
+    vectors) against the solver-independent oracle's (numpy eigh / svd / lstsq) candidates of the same index, on problems whose
+    consensus set both implementations agree on (clean data with planted outliers, mild noise without outliers).  A difference
+    between the RETURNED poses of two correct EPnP implementations can be a different choice between candidates of nearly equal
+    error; a difference inside one branch would be an arithmetic defect — this test separates the two."""
+    from oracle import pnp as op
+    from picopose_amd.utils.pose_recovery import refit_branches
+
+    rng = np.random.default_rng(11)
+    probs = [_problem(rng, 300), _problem(rng, 800, n_out=240), _problem(rng, 3000, noise=0.3), _problem(rng, 4096, n_out=400, noise=0.0),
+             _problem(rng, 1200, noise=0.2), _problem(rng, 3)]
+    st = lambda k: torch.from_numpy(np.stack([p[k] for p in probs])).cuda()  # noqa: E731
+    rot, tvec, ratio, ok, branches = refit_branches(st("tar2d"), st("src3d"), st("K"), st("pose"), st("tar_pts"), st("src_pts"))
+    compared = 0
+    for i, p in enumerate(probs):
+        r, t, ra, success, obr = op.pose_recovery_ransac_pnp(p["tar2d"], p["src3d"], p["K"], p["pose"], p["tar_pts"], p["src_pts"], prob=i,
+                                                             return_branches=True)
+        cand, kept = branches[i]
+        if not success:
+            assert not ok[i] and kept == -1 and obr == [] and all(not np.isfinite(e) for e, _, _ in cand)
+            continue
+        n = int((p["tar_pts"][:, 0] != -1).sum())
+        assert round(ratio[i] * n) == round(ra * n), (i, ratio[i] * n, ra * n)       # same consensus: the refits see the same points
+        for a in range(3):
+            (ke, kR, kt), (oe, oR, ot) = cand[a], obr[a]
+            assert np.isfinite(ke) == np.isfinite(oe), (i, a)
+            if np.isfinite(ke):
+                assert np.abs(kR - oR).max() <= 1e-6 and np.abs(kt - ot).max() <= 1e-6 and abs(ke - oe) <= 1e-6 * max(1.0, oe), (i, a, kt, ot)
+                compared += 1
+        errs = [e for e, _, _ in obr]
+        if sorted(errs)[1] - min(errs) > 1e-9 * min(errs) + 1e-12:
+            assert kept == int(np.argmin(errs)), (i, kept, errs)
+        assert np.array_equal(rot[i], cand[kept][1]) and np.array_equal(tvec[i, :, 0], cand[kept][2])
+    assert compared >= 12
