@@ -446,6 +446,11 @@ int pp_groupnorm_backward_nhwc(const float* x, const float* gamma, const float* 
 int pp_softmax_backward_rows(const float* p, const float* dp, long long rows, int n, float* ds, void* stream);
 /* gradient of pp_xent_diag_rows's mean: dlogits[i][j] = upstream[0] * scale / n * (softmax_j(scale * logits[i]) - [i == j]) */
 int pp_xent_diag_backward(const float* logits, int n, int ld, float scale, const float* upstream, float* dlogits, void* stream);
+/* dst[index[i]][0..C) += src[i][0..C) for i = 0 .. n-1 — the backward of a row gather (torch.gather under autograd,
+ * utils/torch_utils.py:257-283 as used by InfoNCE, utils/loss_utils.py:163-175).  `index` may repeat (several key-points in one
+ * feature-grid cell): their rows are added in ascending i, no atomics, so the result does not depend on the launch.  dst (rows, C)
+ * contiguous, zeroed or holding a sum to extend; every index must be a valid row of dst. */
+int pp_scatter_add_rows(const float* src, const int64_t* index, int n, int C, float* dst, void* stream);
 /* F.normalize backward for the rows x[index[i] * row_stride ...] (index NULL: row i): dx (rows, C) contiguous */
 int pp_normalize_rows_backward(const float* x, long long row_stride, const int64_t* index, const float* dq, int rows, int C, float eps,
                                float* dx, void* stream);

@@ -618,13 +618,15 @@ def gen_train_forward_edge():
 GRAD_SAMPLES = 65536   # entries kept of a gradient tensor larger than this (evenly strided over the flattened tensor)
 
 
-def gen_train_grads():
+def gen_train_grads(name="train_grads"):
     """The reference's OWN gradients for the first backward slice (picopose_amd/autograd.py): `Net.forward_train` in train mode
     under autograd on CPU (ViT-S, B = 2, the batch of train_forward.npz), then
       * d(loss_2d_trans + loss_scale + loss_inplane) / d(every parameter of affine_regressor)   (utils/loss_utils.py:177-186),
       * d(loss_info) / d(every parameter of the last ViT block)                                 (utils/loss_utils.py:144-175)
     by torch.autograd.grad.  Tensors above GRAD_SAMPLES entries are stored as an evenly strided sample of the flattened gradient
-    plus its full L2 norm (affine_regressor.fc1.weight alone is 67 MB)."""
+    plus its full L2 norm (affine_regressor.fc1.weight alone is 67 MB).
+    name = "train_grads_dup": the batch of tests/netcfg.train_kwargs("train_grads_dup") (real crop = the smaller view: repeated rows
+    in the InfoNCE gather of the real tokens) and ONE group, d(loss_info) / d(every parameter of dinov2) — keys gradi/..."""
     _ref()
     sys.path.insert(0, os.path.join(REF, "model"))
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -636,14 +638,15 @@ def gen_train_grads():
     from oracle.weights import AFFINE_CALIBRATION, HEAD_CALIBRATION, PROJ_BN_GAIN, apply_head_calibration, seeded_state_dict
 
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-    from netcfg import make_train_end_points, train_case
+    from netcfg import make_train_end_points, train_case, train_kwargs
 
-    B, seed, edit = train_case("train_forward")
+    dup = name == "train_grads_dup"
+    B, seed, edit = train_case("train_grads_dup" if dup else "train_forward")
     vit, wseed = "dinov2_vits14", 4
     net = ref_picopose.Net(_cfg(vit)).train()
     cal = dict(HEAD_CALIBRATION[vit], affine=AFFINE_CALIBRATION, proj_bn=PROJ_BN_GAIN)
     net.load_state_dict(apply_head_calibration(seeded_state_dict(net.state_dict(), wseed), cal))
-    ep = edit(make_train_end_points(B, seed))
+    ep = edit(make_train_end_points(B, seed, **train_kwargs(name)))
     drawn = {}
     orig = ref_picopose.aug_gtM_noise
 
@@ -677,25 +680,42 @@ def gen_train_grads():
                          res["loss_info"] + res["loss_2d_trans"] + res["loss_scale"] + res["loss_inplane"])
     # the full training step: d(Loss()(end_points)["loss"]) / d(EVERY parameter) — keys grad3/...
     groups["full"] = (list(net.named_parameters()), total)
+    if dup:
+        with torch.no_grad():   # how many real-token rows of the InfoNCE gather repeat (utils/loss_utils.py:150-160: cell = trunc(pt / 64 * 16))
+            kp = net.compute_keypoint_data({k: v.clone() for k, v in ep.items()})
+        # nearest 64 -> 16 sampling keeps every 4th key-point; its cell is trunc(pt * 16 / 64)  (pts are in 64-grid units)
+        cells = []
+        for b in range(B):
+            t = kp["tar_pts"][b].reshape(64, 64, 2)[::4, ::4].reshape(-1, 2)
+            cells.append((t[t[:, 0] != -1] * (16 / 64)).long())
+        repeats = [int(len(c) - len(torch.unique(c[:, 1] * 16 + c[:, 0]))) for c in cells]
+        print("InfoNCE rows per pair", [len(c) for c in cells], "of which repeats of an earlier cell", repeats)
+        out["infonce_rows"], out["infonce_repeats"] = np.array([len(c) for c in cells]), np.array(repeats)
+        assert min(repeats) > 10
+        groups = {"vit_info": ([(n, p) for n, p in net.named_parameters() if n.startswith("feature_extractor.dinov2.")], res["loss_info"])}
     for gname, (params, loss) in groups.items():
         grads = torch.autograd.grad(loss, [p for _, p in params], retain_graph=True, allow_unused=True)
-        prefix = {"vit_all": "grad2", "full": "grad3"}.get(gname, "grad")
+        prefix = {"vit_all": "grad2", "full": "grad3", "vit_info": "gradi"}.get(gname, "grad")
         for (n, p), g in zip(params, grads):
             out[f"{prefix}used/{n}"] = np.bool_(g is not None)
             g = torch.zeros_like(p) if g is None else g
             flat = g.detach().reshape(-1)
-            stride = max(1, -(-flat.numel() // {"grad": GRAD_SAMPLES, "grad2": GRAD_SAMPLES // 16, "grad3": GRAD_SAMPLES // 32}[prefix]))   # (176 / 380 tensors)
+            stride = max(1, -(-flat.numel() // {"grad": GRAD_SAMPLES, "grad2": GRAD_SAMPLES // 16, "grad3": GRAD_SAMPLES // 32, "gradi": GRAD_SAMPLES // 16}[prefix]))   # (176 / 380 tensors)
             out[f"{prefix}/{n}"] = flat[::stride].numpy()
             out[f"{prefix}norm/{n}"] = np.float64(flat.double().norm())
             print(gname, n, tuple(p.shape), "stride", stride, "norm %.4g" % float(flat.double().norm()))
-    np.savez_compressed(os.path.join(OUT, "train_grads.npz"), **out)
-    print("training-gradient fixture written")
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("training-gradient fixture written:", name)
+
+
+def gen_train_grads_dup():
+    gen_train_grads("train_grads_dup")
 
 
 GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry, "nets": gen_nets, "e2e": gen_e2e,
               "e2e_calibrated": gen_e2e_calibrated, "vit_wide": gen_vit_wide, "state_dict": gen_state_dict,
               "preprocess": gen_preprocess, "run_test": gen_run_test, "train_forward": gen_train_forward, "train_forward_edge": gen_train_forward_edge, "e2e_calibrated_vitl": gen_e2e_calibrated_vitl,
-              "train_grads": gen_train_grads}
+              "train_grads": gen_train_grads, "train_grads_dup": gen_train_grads_dup}
 
 
 if __name__ == "__main__":

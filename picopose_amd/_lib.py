@@ -149,6 +149,7 @@ def lib():
         L.pp_softmax_backward_rows.argtypes = [vp, vp, ll, i32, vp, vp]
         L.pp_xent_diag_backward.argtypes = [vp, i32, i32, f32, vp, vp, vp]
         L.pp_normalize_rows_backward.argtypes = [vp, ll, vp, vp, i32, i32, f32, vp, vp]
+        L.pp_scatter_add_rows.argtypes = [vp, vp, i32, i32, vp, vp]
         L.pp_im2col_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
         L.pp_col2im_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
         L.pp_simvol_backward.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]

@@ -1,4 +1,4 @@
-"""First backward slice of the training path.
+"""The backward of the training path: the reference's whole training step under autograd.
 
 `torch.autograd.Function` wrappers whose forward AND backward run on libpicopose_hip.so: the matrix products are pp_gemm
 launches (dgrad = dz @ W, wgrad = dz^T @ x through ops.bmm_nn), the row-wise adjoints are the kernels of csrc/pp_backward.hip.
@@ -135,9 +135,11 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, act, owner=None):
-        # a parameter itself: its operand form is cached per version; a matrix derived from the parameter `owner` (reshaped,
-        # re-packed): split every step with the scale read back one step earlier; otherwise transient (one host wait)
-        cache = True if w.is_leaf else ((owner, "lin") if owner is not None else False)
+        # a parameter itself: its operand form is cached per (address, version); a matrix derived from the parameter `owner`
+        # (reshaped, re-packed): split every step with the scale read back one step earlier; otherwise transient (one host wait).
+        # `is_leaf` is not the test: a matrix derived from a FROZEN parameter is a leaf too, and caching a fresh tensor every step
+        # would pin it and its operand copy in the cache for good
+        cache = True if isinstance(w, torch.nn.Parameter) else ((owner, "lin") if owner is not None else False)
         x, w = _f32c(x), _f32c(w)
         z = ops.linear(x, w, b, cache_weight=cache)
         ctx.act = ACT[act]
@@ -331,8 +333,11 @@ class _InfoNCE(torch.autograd.Function):
             dx = torch.empty(n, C, dtype=torch.float32, device=q.device)
             _lib.check(L.pp_normalize_rows_backward(_p(tok), C, _p(rows_), _p(dn), n, C, 1e-12, _p(dx), _lib.stream_ptr()),
                        "pp_normalize_rows_backward")
+            # the backward of the row gather is a scatter-ADD: the template-side rows are distinct grid cells, but the real-image
+            # rows are re-projected points quantised to the 16x16 feature grid (utils/loss_utils.py:150-160) and several key-points
+            # can share a cell (more than half of them when the real crop is the smaller view).  Fixed summation order, no atomics.
             g = torch.zeros(tok.numel() // C, C, dtype=torch.float32, device=q.device)
-            g.index_copy_(0, rows_, dx)        # the key-point rows are distinct (one per grid cell): a copy, not a sum
+            _lib.check(L.pp_scatter_add_rows(_p(dx), _p(rows_), n, C, _p(g), _lib.stream_ptr()), "pp_scatter_add_rows")
             out.append(g.view_as(tok))
         return out[0], out[1], None, None, None
 

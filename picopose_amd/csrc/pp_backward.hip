@@ -217,6 +217,31 @@ __global__ __launch_bounds__(256) void normalize_backward_kernel(const float* __
     for (int c = lane; c < C; c += 64) dx[(size_t)row * C + c] = (dr[c] - (xr[c] / nrm) * d) / nrm;
 }
 
+// dst[index[i]] += src[i] for i = 0 .. n-1, duplicates in `index` allowed, WITHOUT atomics: the wave of source row i checks whether an
+// earlier source row has the same destination (then that row's wave does the work) and otherwise adds up, in ascending i, every
+// source row of this destination — torch.gather's backward (utils/torch_utils.py:257-283 under autograd) with a fixed summation
+// order.  O(n^2 / 64) index compares per wave: n is a few thousand key-points.
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, const long long* __restrict__ index, int n, int C,
+                                                               float* __restrict__ dst) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const long long row = index[i];
+    bool earlier = false;
+    for (int j = lane; j < i; j += 64) earlier |= index[j] == row;
+    if (__ballot(earlier)) return;                                   // not the first source row of this destination (wave-uniform)
+    float* d = dst + row * (long long)C;
+    for (int c = lane; c < C; c += 64) d[c] += src[(size_t)i * C + c];
+    for (int j0 = i + 1; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        unsigned long long hit = __ballot(j < n && index[j] == row);
+        while (hit) {                                                 // ascending j
+            const int k = __ffsll((long long)hit) - 1;
+            hit &= hit - 1;
+            for (int c = lane; c < C; c += 64) d[c] += src[(size_t)(j0 + k) * C + c];
+        }
+    }
+}
+
 // im2col of an NHWC image for a k x k / stride s / pad p convolution: col[(b, oy, ox)][(ky, kx, ci)]
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, int H, int W, int C, int k, int s, int p, int Ho, int Wo,
                                                      long long total, float* __restrict__ col) {
@@ -377,6 +402,12 @@ int pp_normalize_rows_backward(const float* x, long long row_stride, const int64
     if (!x || !dq || !dx || rows <= 0 || C <= 0) return PP_EINVAL;
     hipLaunchKernelGGL(normalize_backward_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, row_stride, (const long long*)index, dq,
                        rows, C, eps, dx);
+    return pp_last_launch();
+}
+
+int pp_scatter_add_rows(const float* src, const int64_t* index, int n, int C, float* dst, void* stream) {
+    if (!src || !index || !dst || n <= 0 || C <= 0) return PP_EINVAL;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, (const long long*)index, n, C, dst);
     return pp_last_launch();
 }
 

@@ -122,8 +122,8 @@ def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=Non
 
 def allreduce_gradients(parameters, group=None, bucket_bytes=25 << 20):
     """The gradient averaging of DistributedDataParallel (utils/lite.py / run_train.py:109-130 train with strategy='ddp') for the
-    parameters that carry a `.grad` — today the backward slice of picopose_amd/autograd.py: the affine regressor and the last ViT
-    block.  Gradients are packed into flat buckets of <= bucket_bytes in parameter order (every rank builds the same buckets: the
+    parameters that carry a `.grad` — with the default scope of picopose_amd/autograd.py ("full") every parameter the reference
+    trains: the ViT, the affine regressor, the DPT head and the flow decoder (338 tensors at ViT-S).  Gradients are packed into flat buckets of <= bucket_bytes in parameter order (every rank builds the same buckets: the
     set of parameters with a gradient is the same on all ranks), each bucket is ONE all-reduce (RCCL over xGMI: a ring per bucket,
     per-link bound — 25 MB buckets keep the ring's latency term below 1 % of its transfer time at ~50 GB/s per link), then divided
     by the world size and copied back.  Returns the number of buckets.  Call after loss.backward(), before optimizer.step()."""

@@ -88,8 +88,12 @@ class Packed(nn.Module):
         return super()._load_from_state_dict(*a, **k)
 
     def _signatures(self):
-        """(address, version) of every parameter / of every buffer the packings are derived from: an in-place update between
-        two calls (`param.data.copy_`, an optimizer step, an EMA) changes the version, a re-allocation the address."""
+        """(address, version) of every parameter / of every buffer the packings are derived from: an in-place update of the
+        tensor ITSELF between two calls (`with torch.no_grad(): p.copy_(..)` / `p.mul_(..)`, a torch optimizer step) changes the
+        version, a re-allocation the address.  NOT seen: writes through `p.data` (`p.data.copy_`, `p.data.mul_`: typical EMA /
+        weight-surgery code) — `.data` is a view with its OWN version counter, so neither number moves.  Code that writes
+        through `.data` must call `invalidate_packed()` (on the module, or `Net.invalidate_packed()` for all of them)
+        afterwards; tests/test_abi.py pins both behaviours."""
         sig = lambda ts: tuple((t.data_ptr(), t._version) for t in ts)  # noqa: E731
         return sig(self.parameters()), sig(self.buffers())
 
@@ -104,9 +108,13 @@ class Packed(nn.Module):
 
     def invalidate_packed(self):
         """Drop the derived copies of the weights explicitly (they are also dropped by .to() / load_state_dict and whenever a
-        parameter's or buffer's version counter or address has changed since they were built)."""
+        parameter's or buffer's version counter or address has changed since they were built — which a write through `.data`
+        does not do: call this after one)."""
+        from .. import ops
+
         self._pack_cache = self._pack_train_cache = None
         self._pack_psig = self._pack_bsig = None
+        ops.drop_split_cache()          # the pre-split operand copies are keyed the same way
 
     def packed(self, for_training=False):
         """The eval packing.  for_training: the caller reads only entries that do not fold a BatchNorm, so a packing whose

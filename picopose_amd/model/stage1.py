@@ -99,10 +99,13 @@ class FeatureExtractor(Packed):
         """Transposed matrix (N, w0 h0) of the bicubic resampling above (None when the grid is the stored one): the same
         F.interpolate call applied to the N basis images — a constant of the input size, built once; the backward of the position
         embedding is one GEMM with it (picopose_amd/autograd._InterpPos)."""
-        pk = self.packed()
-        key = ("wt", w0, h0)
+        # geometry only — it does not depend on the weights, so it lives outside the packing (which every optimizer step
+        # drops): keyed on the grid and the device
+        v = self.dinov2
+        cache = self.__dict__.setdefault("_pos_wt_cache", {})
+        key = (v.pos_embed.shape[1] - 1, w0, h0, str(v.pos_embed.device))
+        pk = {"pos": cache}
         if key not in pk["pos"]:
-            v = self.dinov2
             N = v.pos_embed.shape[1] - 1
             if w0 * h0 == N:
                 pk["pos"][key] = None

@@ -78,6 +78,13 @@ def split_weight(w, cache=True):
     return hit[0], hit[1]
 
 
+def drop_split_cache():
+    """Forget every cached operand copy of a weight (Packed.invalidate_packed: after a write through `param.data`, which the
+    (address, version) keys cannot see)."""
+    _split_cache.clear()
+    _tracked_scale.clear()
+
+
 _tracked_scale = {}   # (id(parameter), tag) -> [scale (host float), pending (pinned tensor, event) | None, weakref to the parameter]
 
 

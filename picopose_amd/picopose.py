@@ -39,6 +39,16 @@ class Net(nn.Module):
         self.last_stage3 = None
         self.train_backward = True   # True / "full" | "vit+stage2" | "slice1" | False: what trains under autograd (picopose_amd/autograd.py)
 
+    def invalidate_packed(self):
+        """Drop every derived copy of the weights (packed / BatchNorm-folded / pre-split) in every sub-module.  Needed only after
+        a write THROUGH `param.data` (EMA / weight-surgery code): such a write moves neither the parameter's version counter nor
+        its address, which is what the caches watch (model/common.py Packed._signatures)."""
+        from .model.common import Packed
+
+        for m in self.modules():
+            if isinstance(m, Packed):
+                m.invalidate_packed()
+
     # model/picopose.py:52-70 — pick hypothesis k's template for every crop (pure indexing)
     def select_template_data(self, end_points, pred_id_src, k):
         idx = pred_id_src[:, k]

@@ -1,6 +1,8 @@
 """Host mirror of the reference's utils/loss_utils.py (training forward): same function names and
 return values; the per-pixel / per-row work runs in libpicopose_hip.so (csrc/pp_train.hip, the GEMM engine for the InfoNCE
-logits), the B-sized scalar algebra in torch.  Forward values only: the returned tensors carry no autograd graph."""
+logits), the B-sized scalar algebra in torch.  Called under `torch.no_grad()` these return forward values; in a live training step
+`Net.forward_train` routes the same quantities through picopose_amd/autograd.py (infonce, flow_level_losses, ...), whose Functions
+carry the graph — `Loss()(end_points)["loss"].backward()` is then the reference's training step."""
 import torch
 import torch.nn as nn
 

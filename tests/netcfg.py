@@ -115,12 +115,12 @@ def euler_pose(ax, ay, az, t):
     return P.float()
 
 
-def make_train_end_points(B, seed, poses=None):
+def make_train_end_points(B, seed, poses=None, scales=(2.0, 1.5)):
     """Synthetic TRAINING batch (provider/training_dataset.py:152-167 layout): one template per real crop, both views of
     the same planar object, so the key-point sampler finds correspondences.  N(0,1) crops, full-size depth images of the
     plane, disk masks (the real one with a rectangular bite), BOP intrinsics, crops centred on the projected object centre
-    (template scale 1.5, real scale 2).  poses = (real_pose, tem_pose) (B,4,4) each overrides the seeded ones (fixtures
-    carry the poses they were generated with)."""
+    (template scale 1.5, real scale 2 — `scales` = (real, template)).  poses = (real_pose, tem_pose) (B,4,4) each overrides the
+    seeded ones (fixtures carry the poses they were generated with)."""
     import torch
 
     g = torch.Generator().manual_seed(seed)
@@ -136,7 +136,7 @@ def make_train_end_points(B, seed, poses=None):
         real, tem = poses
     ep["real_pose"], ep["tem_pose"] = real, tem
     ep["real_K"] = ep["tem_K"] = K[None].repeat(B, 1, 1)
-    for name, pose, s in (("real", real, 2.0), ("tem", tem, 1.5)):
+    for name, pose, s in (("real", real, scales[0]), ("tem", tem, scales[1])):
         c = (K @ pose[:, :3, 3:4])[:, :, 0]
         c = c[:, :2] / c[:, 2:]                                     # projected object centre (image pixels)
         M = torch.zeros(B, 3, 3)
@@ -161,4 +161,11 @@ def train_case(name):
         ep["real_mask"][1] = 0
         return ep
 
-    return {"train_forward": (2, 51, lambda ep: ep), "train_forward_edge": (3, 52, edge)}[name]
+    return {"train_forward": (2, 51, lambda ep: ep), "train_forward_edge": (3, 52, edge), "train_grads_dup": (2, 53, lambda ep: ep)}[name]
+
+
+def train_kwargs(name):
+    """Extra arguments of make_train_end_points per fixture.  "train_grads_dup": the two crop scales swapped, so the REAL crop is the
+    smaller view — several template key-points then re-project into one cell of the real image's 16x16 feature grid and the
+    InfoNCE rows of the real tokens repeat (the backward of that gather is a scatter-ADD)."""
+    return {"train_grads_dup": {"scales": (1.5, 2.0)}}.get(name, {})

@@ -107,8 +107,10 @@ def test_pack_cache_is_dropped_when_a_checkpoint_loads_through_the_top_level_net
 
 def test_pack_cache_follows_in_place_parameter_updates():
     """the packed / BN-folded copies are derived from the parameters; an in-place update between two forwards
-    (`param.data.copy_`, an optimizer step, an EMA) must not leave them stale.  The cache records every source tensor's
-    (address, version) and rebuilds on a mismatch; a BatchNorm buffer update re-folds the eval packing only."""
+    (an optimizer step, `with torch.no_grad(): p.mul_()`) must not leave them stale.  The cache records every source tensor's
+    (address, version) and rebuilds on a mismatch; a BatchNorm buffer update re-folds the eval packing only.
+    ADVICE r03: a write through `p.data` moves NEITHER number (`.data` is a view with its own version counter) — that case is
+    the caller's: `Net.invalidate_packed()` after it.  Both behaviours are pinned here."""
     import os
     import sys
 
@@ -136,6 +138,15 @@ def test_pack_cache_follows_in_place_parameter_updates():
     assert third is not second and not torch.equal(third["proj0"], second["proj0"])
     fd.invalidate_packed()
     assert fd._pack_cache is None and torch.equal(fd.packed()["proj0"], third["proj0"])
+    # a write through .data: invisible to (address, version) — documented — and picked up after Net.invalidate_packed()
+    w = getattr(fd.proj[0], "0").weight
+    v0, a0 = w._version, w.data_ptr()
+    w.data.mul_(0.5)
+    assert (w._version, w.data_ptr()) == (v0, a0)
+    assert torch.equal(fd.packed()["proj0"], third["proj0"])                  # stale, as documented
+    net.invalidate_packed()
+    assert all(m._pack_cache is None for m in net.modules() if hasattr(m, "_pack_cache"))
+    assert not torch.equal(fd.packed()["proj0"], third["proj0"])
 
 
 @pytest.mark.gpu

@@ -165,14 +165,15 @@ def test_training_forward_matches_the_reference_run(golden_dir, engine_precision
 
 
 # ---- the first backward slice (picopose_amd/autograd.py) against the REFERENCE's own autograd ------------------------------------
-def _load_grad_fixture(golden_dir):
+def _load_grad_fixture(golden_dir, name="train_grads"):
+    from netcfg import train_kwargs
     from oracle.weights import apply_head_calibration, seeded_state_dict
 
-    z = np.load(os.path.join(golden_dir, "train_grads.npz"))
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
     B, seed, wseed = (int(v) for v in z["meta"])
     cal = {"flow": [tuple(r) for r in z["cal_flow"]], "cert": [tuple(r) for r in z["cal_cert"]], "proj_bn": float(z["cal_proj_bn"]),
            "affine": {h: (float(z[f"cal_affine_{h}"][0]), tuple(z[f"cal_affine_{h}"][1:])) for h in ("translation", "scale", "inplane")}}
-    ep = make_train_end_points(B, seed, poses=(torch.from_numpy(z["real_pose"]), torch.from_numpy(z["tem_pose"])))
+    ep = make_train_end_points(B, seed, poses=(torch.from_numpy(z["real_pose"]), torch.from_numpy(z["tem_pose"])), **train_kwargs(name))
     return z, ep, (lambda template: apply_head_calibration(seeded_state_dict(template, wseed), cal))
 
 
@@ -288,6 +289,81 @@ def test_wide_backward_matches_the_reference_autograd(golden_dir, precision):
     assert n_checked == 29 + 12 * 14 + 4     # affine regressor, 12 blocks, patch_embed.proj.{weight,bias} + cls_token + pos_embed
     assert report[0][0] <= TOL, report[:3]
     assert max(b for _, b, _ in report) <= TOL
+
+
+@gpu
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_infonce_backward_with_repeated_real_cells_matches_the_reference_autograd(golden_dir, precision):
+    """the InfoNCE rows of the REAL tokens are re-projected key-points quantised to the 16x16 feature grid
+    (utils/loss_utils.py:156-165), so several key-points can share a cell and the backward of the reference's `gather`
+    (utils/torch_utils.py:257-283) is a scatter-ADD.  The fixtures of round 3 (real crop = the larger view) have no repeated row,
+    so an `index_copy_` passed them.  tests/golden/train_grads_dup.npz = the reference's autograd of loss_info on a batch whose
+    real crop is the SMALLER view (24 / 34 of 121 / 123 rows repeat an earlier cell): d(loss_info) / d(every dinov2 parameter);
+    and the scatter is reproducible bit for bit (fixed summation order, no atomics)."""
+    from picopose_amd import ops
+    from picopose_amd.picopose import Net
+
+    z, ep, weights = _load_grad_fixture(golden_dir, "train_grads_dup")
+    assert int(z["infonce_repeats"].min()) > 10
+    old = ops.PRECISION
+    ops.PRECISION = precision
+    grads = []
+    try:
+        for rep in range(2):
+            net = Net(small_cfg())
+            net.load_state_dict(weights(net.state_dict()))
+            net = net.cuda().train()
+            net.train_backward = "vit+stage2"
+            res = net.forward_train(_cuda(ep), pred_Ms=torch.from_numpy(z["pred_Ms"]).cuda())
+            assert abs(float(res["loss_info"]) - float(z["loss_info"])) <= 1e-3 * float(z["loss_info"])
+            res["loss_info"].backward()
+            grads.append({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+    finally:
+        ops.PRECISION = old
+    assert all(torch.equal(grads[0][n], grads[1][n]) for n in grads[0]) and grads[0].keys() == grads[1].keys()
+    report = []
+    for name, p in net.named_parameters():
+        if not name.startswith("feature_extractor.dinov2."):
+            assert p.grad is None, name
+            continue
+        if not bool(z[f"gradiused/{name}"]):
+            assert p.grad is None, name
+            continue
+        ref = torch.from_numpy(z[f"gradi/{name}"])
+        flat = p.grad.detach().reshape(-1).cpu()
+        got = flat[::max(1, -(-flat.numel() // 4096))]
+        assert got.shape == ref.shape, name
+        nref = float(z[f"gradinorm/{name}"])
+        report.append((float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-30), abs(float(flat.double().norm()) - nref) / max(nref, 1e-30), name))
+    report.sort(reverse=True)
+    print(f"InfoNCE backward with repeated rows [{precision}]: {len(report)} tensors, worst max|err| / max|grad| = {report[0][0]:.2e}, worst norm "
+          f"error {max(b for _, b, _ in report):.2e}")
+    assert len(report) == 12 * 14 + 4
+    assert report[0][0] <= 3e-4 and max(b for _, b, _ in report) <= 3e-4, report[:3]
+
+
+@gpu
+def test_scatter_add_rows_sums_repeated_destinations_in_a_fixed_order():
+    from picopose_amd import _lib
+
+    g = torch.Generator().manual_seed(5)
+    n, C, R = 700, 384, 90
+    src = torch.randn(n, C, generator=g)
+    idx = torch.randint(0, R, (n,), generator=g)
+    idx[:5] = 89
+    ref = torch.zeros(R, C, dtype=torch.float64).index_add_(0, idx, src.double())
+    outs = []
+    for _ in range(2):
+        dst = torch.zeros(R, C, device="cuda")
+        _lib.check(_lib.lib().pp_scatter_add_rows(src.cuda().data_ptr(), idx.cuda().data_ptr(), n, C, dst.data_ptr(), _lib.stream_ptr()), "pp_scatter_add_rows")
+        outs.append(dst.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0].double() - ref).abs().max()) <= 1e-5
+    # sequential fp32 sums in ascending source order, exactly
+    seq = torch.zeros(R, C)
+    for i in range(n):
+        seq[idx[i]] += src[i]
+    assert torch.equal(outs[0], seq)
 
 
 @gpu
