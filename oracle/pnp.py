@@ -152,6 +152,20 @@ def _hestenes12(G):
     return (g * g).sum(axis=0), v
 
 
+def _canonical_signs(v):
+    """Columns of v (principal axes of the model points) with a solver-independent sign: the component of largest magnitude
+    (lowest index among equals) is positive.  EPnP's estimate is NOT invariant to the side of the centroid a control point is
+    put on — on noisy data the two choices give poses ~1 mm apart at equal reprojection error — and an eigen-solver's sign is an
+    accident of its rotation sequence, so kernel (csrc/pp_pnp.hip) and oracle fix it the same way.  (OpenCV takes the sign its
+    SVD returns; unknowable here.)"""
+    v = np.array(v, np.float64)
+    for k in range(v.shape[1]):
+        i = int(np.argmax(np.abs(v[:, k])))
+        if v[i, k] < 0:
+            v[:, k] = -v[:, k]
+    return v
+
+
 def epnp(p3, p2, cam, solver="lapack", branches=None):
     """EPnP on the given points: returns (mean reprojection error, R (3,3), t (3,)); error = inf if no solution.
     branches: a list that receives, per beta initialisation (N = 1 / 2 / 3), the candidate (err, R, t) — err = inf where the
@@ -169,6 +183,7 @@ def epnp(p3, p2, cam, solver="lapack", branches=None):
         v = vr.T
     else:
         w, v = np.linalg.eigh(q.T @ q)                      # ascending
+    v = _canonical_signs(v)
     cws = [c0]
     for k in range(3):                                       # largest first
         cws.append(c0 + np.sqrt(max(w[2 - k], 0.0) / n) * v[:, 2 - k])

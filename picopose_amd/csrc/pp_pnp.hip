@@ -329,6 +329,16 @@ _Pragma("unroll")
     {
         double c3[3][3] = {{a6[0], a6[1], a6[2]}, {a6[1], a6[3], a6[4]}, {a6[2], a6[4], a6[5]}}, w[3], v[3][3];
         eig3_sym(c3, w, v);
+        // Solver-independent sign of each principal axis: its component of largest magnitude (lowest index among equals) is
+        // positive.  EPnP's estimate depends on which side of the centroid a control point lies (on noisy data the two choices
+        // give poses ~1 mm apart at equal reprojection error), and the sign a Jacobi sequence leaves is an accident of its
+        // rotations — with a fixed convention this kernel and a LAPACK-based EPnP (oracle/pnp.py) agree to solver accuracy.
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double a0 = fabs(v[k][0]), a1 = fabs(v[k][1]), a2 = fabs(v[k][2]);
+            const double lead = (a0 >= a1 && a0 >= a2) ? v[k][0] : (a1 >= a2 ? v[k][1] : v[k][2]);
+            if (lead < 0) { v[k][0] = -v[k][0]; v[k][1] = -v[k][1]; v[k][2] = -v[k][2]; }
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {  // largest first, as the SVD ordering of OpenCV's EPnP
             const double kk = sqrt(fmax(w[2 - k], 0.0) / n);
