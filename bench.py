@@ -249,19 +249,25 @@ def gemm_per_kernel(L, cap=8192):
     from picopose_amd import _lib
 
     shape, ms, fl, cnt = (ctypes.c_int * (6 * cap))(), (ctypes.c_float * cap)(), (ctypes.c_double * cap)(), ctypes.c_int()
-    _lib.check(L.pp_prof_gemm_records(cap, shape, ms, fl, ctypes.byref(cnt)), "pp_prof_gemm_records")
+    by = (ctypes.c_double * cap)()
+    _lib.check(L.pp_prof_gemm_records2(cap, shape, ms, fl, by, ctypes.byref(cnt)), "pp_prof_gemm_records2")
     agg = {}
     for i in range(cnt.value):
         M, N, K, ck, cfg, kind = (shape[6 * i + k] for k in range(6))
         name = CFG_KERNEL.get(cfg, f"cfg {cfg}") if kind == 0 else "gemm_f16x3_kernel / gemm_kernel (operands split on the fly or fp32 MFMA)"
         key = (name, "conv" if ck else "dense")
-        a_ = agg.setdefault(key, {"kernel": name, "a_operand": key[1], "launches": 0, "ms": 0.0, "algorithmic_flops": 0.0})
+        # rocprof_key: what tools/profile_set.py derives from a rocprofv3 kernel name (tile + A-operand kind), so the PMC passes
+        # join this table without guessing layer shapes
+        a_ = agg.setdefault(key, {"kernel": name, "a_operand": key[1], "rocprof_key": f"u{cfg}:{key[1]}" if kind == 0 else "other_gemm",
+                                  "launches": 0, "ms": 0.0, "algorithmic_flops": 0.0, "algorithmic_bytes": 0.0})
         a_["launches"] += 1
         a_["ms"] += ms[i]
         a_["algorithmic_flops"] += fl[i]
+        a_["algorithmic_bytes"] += by[i]
     out = sorted(agg.values(), key=lambda r: -r["ms"])
     for r in out:
         r["useful_tflops"] = r["algorithmic_flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else None
+        r["algorithmic_gbs"] = r["algorithmic_bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else None
     return out
 
 
@@ -315,6 +321,9 @@ def main():
     ap.add_argument("--shard", default="auto", choices=["auto", "crops", "templates"],
                     help="N > 1: what is sharded over the ranks. auto = crops for weak scaling (independent replicas, no data-path "
                          "collective), templates for strong scaling (configs[3] / [4]: template-sharded bank + all-gathers)")
+    ap.add_argument("--tune-file", default=None,
+                    help="the GEMM autotuner's table (pp_gemm_tune_load / _save): loaded before the first step if the file exists, "
+                         "written after the run otherwise — every pass of a profiling set then runs identical launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the untimed --mode exact comparison leg")
     a = ap.parse_args()
@@ -357,6 +366,13 @@ def main():
     s1_mode = "exact" if a.mode == "exact" else "fast"       # stage 1's own switch (fp16 MFMA + exact re-evaluation of near-ties | fp32 MFMA)
     from picopose_amd.utils import matching as hm
 
+    tune = None
+    if a.tune_file:
+        tune = {"file": os.path.relpath(os.path.abspath(a.tune_file), ROOT), "loaded": 0}
+        if os.path.exists(a.tune_file):
+            tune["loaded"] = _lib.lib().pp_gemm_tune_load(os.path.abspath(a.tune_file).encode())
+            if tune["loaded"] < 0:
+                raise SystemExit(f"--tune-file {a.tune_file}: unreadable")
     kind, Bl, N, vit, desc = WORKLOADS[a.workload]
     C = VIT[vit][0]
     B, Bl, a.scaling = batch_plan(Bl, world, a.scaling, a.global_batch)
@@ -681,7 +697,10 @@ def main():
                 "traffic_measured_in_this_run": False,
                 "per_kernel": gemm.get("per_kernel"),
                 "per_kernel_note": "every GEMM / conv launch of the event pass grouped by kernel: frac_algorithmic of a kernel = "
-                                   "algorithmic_flops / ms / peak; its executed fraction = 3 x that for the f16x3 kernels",
+                                   "algorithmic_flops / ms / peak; its executed fraction = 3 x that for the f16x3 kernels; algorithmic_bytes = "
+                                   "A (a convolution: its input image, not the im2col) + B + outputs + residuals, each element once in the "
+                                   "format the launch reads / writes (pp_prof_gemm_records2) — profiles/*/pmc_step*.json divide the PMC "
+                                   "FETCH + WRITE bytes of the same kernel by it (traffic_ratio)",
                 "launches_per_step": n, "kernel_ms_per_step": msum, "avg_launch_ms": msum / n,
                 "algorithmic_flops_per_step": fl, "mfma_flops_per_step": mult * fl,
                 "useful_tflops": fl / (msum * 1e-3) / 1e12, "share_of_step": msum / ms,
@@ -717,6 +736,14 @@ def main():
                                                        "(|activation| < 16376, picopose_amd/ops.py CHECK_SATURATION); a hit aborts the bench"}
             if exact is not None:
                 line["exact_mode"] = exact
+        if tune is not None:
+            tune["entries"] = L.pp_gemm_tune_entries()
+            if not tune["loaded"]:
+                tune["saved"] = L.pp_gemm_tune_save(os.path.abspath(a.tune_file).encode())
+            tune["note"] = ("problem shape -> tile configuration of the GEMM engine; loaded: every launch of this run used the file's "
+                            "choice (shapes missing from it were tuned in this run)" if tune["loaded"] else
+                            "tuned in this run and written for the other passes of the measurement set")
+            line["autotune"] = tune
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_full(N, vit, sd) if kind == "full" else cpu_baseline_stage1(N, C)
         print(json.dumps(line), flush=True)

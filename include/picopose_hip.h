@@ -58,6 +58,19 @@ int pp_prof_gemm_collect(double* ms, double* flops, int* launches);
  * shape[6 i ..] = {M, N, K, conv kernel size (0: dense), tile configuration the launch used (PP_GEMM_FORCE_CFG numbering),
  * kind (0 = both operands pre-split, 1 = other)}, ms[i] its duration, flops[i] = 2 M N K batch. */
 int pp_prof_gemm_records(int max_records, int* shape, float* ms, double* flops, int* count);
+/* ... plus bytes[i] = the launch's ALGORITHMIC bytes: every element of A (a convolution: of its input image, not of the im2col),
+ * B, the output(s) and the residual(s) once, in the format the launch reads / writes them (4 B fp32; 4 B per element of a 2-term
+ * operand, 2 B of a 1-term one) — what a per-kernel traffic ratio (PMC FETCH + WRITE over this) is taken against. */
+int pp_prof_gemm_records2(int max_records, int* shape, float* ms, double* flops, double* bytes, int* count);
+/* The contraction engine's autotuner (pp_gemm: per problem shape the fastest tile configuration, measured once per process) as a
+ * table that can be written and read back, so that separate processes — the passes of one profiling set, a serving fleet — run the
+ * SAME configuration per shape: pp_gemm_tune_save writes "key cfg" lines and returns the entry count, pp_gemm_tune_load merges a
+ * file into the table (shapes it lacks are still tuned on first use) and returns the entries read (PP_EINVAL: unreadable);
+ * the environment variable PP_GEMM_TUNE_FILE loads a file before the first pp_gemm call.  Results do not depend on the table
+ * (every configuration accumulates in the same order), only speed does. */
+int pp_gemm_tune_save(const char* path);
+int pp_gemm_tune_load(const char* path);
+int pp_gemm_tune_entries(void);
 
 /* ------------------------------------------------------------------------- *
  * Stage 1: template matching — utils/matching.py:29-69 (matching_templates)

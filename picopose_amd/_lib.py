@@ -76,6 +76,10 @@ def lib():
         L.pp_prof_gemm_enable.argtypes = [i32]
         L.pp_prof_gemm_collect.argtypes = [c.POINTER(c.c_double), c.POINTER(c.c_double), c.POINTER(i32)]
         L.pp_prof_gemm_records.argtypes = [i32, c.POINTER(i32), c.POINTER(f32), c.POINTER(c.c_double), c.POINTER(i32)]
+        L.pp_prof_gemm_records2.argtypes = [i32, c.POINTER(i32), c.POINTER(f32), c.POINTER(c.c_double), c.POINTER(c.c_double), c.POINTER(i32)]
+        L.pp_gemm_tune_save.argtypes = [c.c_char_p]
+        L.pp_gemm_tune_load.argtypes = [c.c_char_p]
+        L.pp_gemm_tune_entries.argtypes = []
         L.pp_stage1_workspace_bytes.argtypes = [i32, i32, i32, c.POINTER(sz)]
         L.pp_stage1_scores.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, vp, vp]
         L.pp_stage1_scores_ex.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, vp, vp]

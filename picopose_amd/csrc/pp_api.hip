@@ -58,16 +58,19 @@ int pp_prof_gemm_enable(int max_records) {
     for (int i = 0; i < p.capacity * 2; ++i) (void)hipEventDestroy(p.ev[i]);
     delete[] p.ev;
     delete[] p.flops;
+    delete[] p.bytes;
     delete[] p.kind;
     delete[] p.shape;
     p.shape = nullptr;
     p.ev = nullptr;
     p.flops = nullptr;
+    p.bytes = nullptr;
     p.kind = nullptr;
     p.capacity = p.count = 0;
     if (max_records <= 0) return PP_OK;
     p.ev = new hipEvent_t[2 * max_records];
     p.flops = new double[max_records];
+    p.bytes = new double[max_records];
     p.kind = new int[max_records];
     p.shape = new int[max_records][5];
     for (int i = 0; i < 2 * max_records; ++i)
@@ -100,7 +103,12 @@ int pp_prof_gemm_collect(double* ms, double* flops, int* launches) {
     return PP_OK;
 }
 
+int pp_prof_gemm_records2(int max_records, int* shape, float* ms, double* flops, double* bytes, int* count);
 int pp_prof_gemm_records(int max_records, int* shape, float* ms, double* flops, int* count) {
+    return pp_prof_gemm_records2(max_records, shape, ms, flops, nullptr, count);
+}
+
+int pp_prof_gemm_records2(int max_records, int* shape, float* ms, double* flops, double* bytes, int* count) {
     PpGemmProf& p = g_gemm_prof;
     if (!shape || !ms || !flops || !count || max_records < 0) return PP_EINVAL;
     const int n = p.count < max_records ? p.count : max_records;
@@ -110,6 +118,7 @@ int pp_prof_gemm_records(int max_records, int* shape, float* ms, double* flops, 
         for (int k = 0; k < 5; ++k) shape[6 * i + k] = p.shape[i][k];
         shape[6 * i + 5] = p.kind[i];
         flops[i] = p.flops[i];
+        if (bytes) bytes[i] = p.bytes[i];
     }
     *count = n;
     return PP_OK;

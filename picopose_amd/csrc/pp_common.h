@@ -83,6 +83,7 @@ struct PpProfScope {
 struct PpGemmProf {
     hipEvent_t* ev = nullptr;
     double* flops = nullptr;
+    double* bytes = nullptr;    // algorithmic bytes of the launch: A + B + C (+ residuals) in the formats actually used
     int* kind = nullptr;
     int (*shape)[5] = nullptr;  // M, N, K, conv kernel size, chosen configuration (PP_GEMM_TRACE dump)
     int capacity = 0;
