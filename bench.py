@@ -248,17 +248,24 @@ def gemm_per_kernel(L, cap=8192):
     the f16x3 kernels, 1 x in the fp32-MFMA ones)."""
     from picopose_amd import _lib
 
-    shape, ms, fl, cnt = (ctypes.c_int * (6 * cap))(), (ctypes.c_float * cap)(), (ctypes.c_double * cap)(), ctypes.c_int()
+    shape, ms, fl, cnt = (ctypes.c_int * (8 * cap))(), (ctypes.c_float * cap)(), (ctypes.c_double * cap)(), ctypes.c_int()
     by = (ctypes.c_double * cap)()
     _lib.check(L.pp_prof_gemm_records2(cap, shape, ms, fl, by, ctypes.byref(cnt)), "pp_prof_gemm_records2")
     agg = {}
     for i in range(cnt.value):
-        M, N, K, ck, cfg, kind = (shape[6 * i + k] for k in range(6))
+        M, N, K, ck, cfg, kind, amode = (shape[8 * i + k] for k in range(7))
         name = CFG_KERNEL.get(cfg, f"cfg {cfg}") if kind == 0 else "gemm_f16x3_kernel / gemm_kernel (operands split on the fly or fp32 MFMA)"
-        key = (name, "conv" if ck else "dense")
-        # rocprof_key: what tools/profile_set.py derives from a rocprofv3 kernel name (tile + A-operand kind), so the PMC passes
-        # join this table without guessing layer shapes
-        a_ = agg.setdefault(key, {"kernel": name, "a_operand": key[1], "rocprof_key": f"u{cfg}:{key[1]}" if kind == 0 else "other_gemm",
+        key = (name, ("dense", "conv, channel-slice-major K", "conv, natural K order")[amode] if kind == 0 else ("conv" if ck else "dense"))
+        # rocprof_key: what tools/profile_set.py derives from a rocprofv3 kernel name (tile + A-delivery MODE template argument), so
+        # the PMC passes join this table without guessing layer shapes
+        rkey = f"u{cfg}:m{amode}"
+        if kind != 0:     # the kernels on fp32 operands: gemm_f16x3_kernel<NJ, OCC, .> (split on the fly) / gemm_kernel<VEC4, NJ, OCC> (fp32 MFMA)
+            vec4, onfly = bool(amode & 1), bool(amode & 2)
+            nj_occ = ((1, 4) if cfg == 2 else (2, 2) if cfg == 0 else (2, 3)) if (onfly or vec4) else ((1, 2) if cfg == 2 else (2, 2))
+            rkey = f"g{'x' if onfly else 'f'}:{nj_occ[0]}:{nj_occ[1]}"
+            name = f"gemm_f16x3_kernel<{nj_occ[0]}, {nj_occ[1]}, .> (fp32 operands split on the fly)" if onfly else f"gemm_kernel<{str(vec4).lower()}, {nj_occ[0]}, {nj_occ[1]}> (v_mfma_f32_32x32x2_f32)"
+            key = (name, "conv" if ck else "dense")
+        a_ = agg.setdefault(key, {"kernel": name, "a_operand": key[1], "rocprof_key": rkey,
                                   "launches": 0, "ms": 0.0, "algorithmic_flops": 0.0, "algorithmic_bytes": 0.0})
         a_["launches"] += 1
         a_["ms"] += ms[i]

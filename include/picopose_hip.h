@@ -58,7 +58,8 @@ int pp_prof_gemm_collect(double* ms, double* flops, int* launches);
  * shape[6 i ..] = {M, N, K, conv kernel size (0: dense), tile configuration the launch used (PP_GEMM_FORCE_CFG numbering),
  * kind (0 = both operands pre-split, 1 = other)}, ms[i] its duration, flops[i] = 2 M N K batch. */
 int pp_prof_gemm_records(int max_records, int* shape, float* ms, double* flops, int* count);
-/* ... plus bytes[i] = the launch's ALGORITHMIC bytes: every element of A (a convolution: of its input image, not of the im2col),
+/* The same with 8 ints per record — shape[8 i ..] = {M, N, K, conv kernel size, cfg, kind, A-delivery mode of the pre-split kernel
+ * (0 dense, 1 convolution in channel-slice-major K order, 2 natural order), 0} — plus bytes[i] = the launch's ALGORITHMIC bytes: every element of A (a convolution: of its input image, not of the im2col),
  * B, the output(s) and the residual(s) once, in the format the launch reads / writes them (4 B fp32; 4 B per element of a 2-term
  * operand, 2 B of a 1-term one) — what a per-kernel traffic ratio (PMC FETCH + WRITE over this) is taken against. */
 int pp_prof_gemm_records2(int max_records, int* shape, float* ms, double* flops, double* bytes, int* count);

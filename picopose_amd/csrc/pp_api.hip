@@ -72,7 +72,7 @@ int pp_prof_gemm_enable(int max_records) {
     p.flops = new double[max_records];
     p.bytes = new double[max_records];
     p.kind = new int[max_records];
-    p.shape = new int[max_records][5];
+    p.shape = new int[max_records][6];
     for (int i = 0; i < 2 * max_records; ++i)
         if (hipEventCreate(&p.ev[i]) != hipSuccess) return PP_ELAUNCH;
     p.capacity = max_records;
@@ -115,10 +115,15 @@ int pp_prof_gemm_records2(int max_records, int* shape, float* ms, double* flops,
     for (int i = 0; i < n; ++i) {
         if (hipEventSynchronize(p.ev[2 * i + 1]) != hipSuccess) return PP_ELAUNCH;
         if (hipEventElapsedTime(&ms[i], p.ev[2 * i], p.ev[2 * i + 1]) != hipSuccess) return PP_ELAUNCH;
-        for (int k = 0; k < 5; ++k) shape[6 * i + k] = p.shape[i][k];
-        shape[6 * i + 5] = p.kind[i];
+        const int st = bytes ? 8 : 6;      // records2: {M, N, K, conv kernel size, cfg, kind, A-delivery mode, 0}
+        for (int k = 0; k < 5; ++k) shape[st * i + k] = p.shape[i][k];
+        shape[st * i + 5] = p.kind[i];
         flops[i] = p.flops[i];
-        if (bytes) bytes[i] = p.bytes[i];
+        if (bytes) {
+            bytes[i] = p.bytes[i];
+            shape[st * i + 6] = p.shape[i][5];
+            shape[st * i + 7] = 0;
+        }
     }
     *count = n;
     return PP_OK;

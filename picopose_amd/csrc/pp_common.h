@@ -85,7 +85,7 @@ struct PpGemmProf {
     double* flops = nullptr;
     double* bytes = nullptr;    // algorithmic bytes of the launch: A + B + C (+ residuals) in the formats actually used
     int* kind = nullptr;
-    int (*shape)[5] = nullptr;  // M, N, K, conv kernel size, chosen configuration (PP_GEMM_TRACE dump)
+    int (*shape)[6] = nullptr;  // M, N, K, conv kernel size, chosen configuration (PP_GEMM_TRACE dump), A-delivery mode (0 dense, 1 / 2 conv)
     int capacity = 0;
     int count = 0;
 };

@@ -1148,7 +1148,9 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         gp->shape[gp->count][1] = d.N;
         gp->shape[gp->count][2] = d.K;
         gp->shape[gp->count][3] = d.conv_kh;
-        gp->shape[gp->count][4] = asplit ? u_cfg(cfg) : cfg;
+        gp->shape[gp->count][4] = asplit ? ((!pp_gemm_u_vec_ok(d) && u_cfg(cfg) != 2) ? 0 : u_cfg(cfg)) : cfg;   // (element-wise epilogue: the small tiles)
+        // pre-split kernels: the A-delivery mode; the others: 8 + (vector loads) + 2 (f16x3 on the fly) — bench.py names the instantiation
+        gp->shape[gp->count][5] = asplit ? (u_cfg(cfg) == 6 ? 1 : pp_gemm_u_mode(d, terms)) : 8 + (vec ? 1 : 0) + (split ? 2 : 0);
         gp->count++;
     }
     return finish();

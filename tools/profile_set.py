@@ -23,11 +23,15 @@ def short(n):
 def key_of(n):
     m = re.search(r"pp_gemm_u_kernel<TileCfg<(\d+), (\d+),[^>]*>, (\d), (\d), (true|false)>", n)
     if m:
-        return f"u{TILE_CFG[(int(m.group(1)), int(m.group(2)))]}:{'dense' if m.group(3) == '0' else 'conv'}"
+        return f"u{TILE_CFG[(int(m.group(1)), int(m.group(2)))]}:m{m.group(3)}"
     if "pp_gemm_uh_kernel" in n:
-        return "u6:conv"
-    if "gemm_f16x3_kernel" in n or re.search(r"\bgemm_kernel<", n):
-        return "other_gemm"
+        return "u6:m1"
+    m = re.search(r"gemm_f16x3_kernel<(\d), (\d), (true|false)>", n)
+    if m:
+        return f"gx:{m.group(1)}:{m.group(2)}"
+    m = re.search(r"\bgemm_kernel<(true|false), (\d), (\d)>", n)
+    if m:
+        return f"gf:{m.group(2)}:{m.group(3)}"
     return None
 
 
@@ -63,7 +67,11 @@ for cdir, names in (("mfma", ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ
                 sys.exit(f"pass {cdir}/{cname}: {n} ran {c} times, the trace pass saw {int(table[n]['launches'])} — the passes differ")
 bench = json.loads(open(f"{root}/bench.json").read().strip().splitlines()[-1])
 roof = bench.get("roofline", {})
-pk = {r["rocprof_key"]: r for r in roof.get("per_kernel") or []}
+pk = {}
+for r in roof.get("per_kernel") or []:       # (conv / dense launches of one instantiation are one rocprof kernel: summed)
+    e = pk.setdefault(r["rocprof_key"], {"algorithmic_flops": 0.0, "algorithmic_bytes": 0.0, "launches": 0})
+    for k in e:
+        e[k] += r[k]
 out, used = [], collections.Counter()
 for n, t in table.items():
     k = key_of(n)
@@ -76,7 +84,7 @@ for n, t in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
            "mfma_busy": t["SQ_VALU_MFMA_BUSY_CYCLES"] / act if act else None, "mfma_insts": t["SQ_INSTS_MFMA"],
            "fetch_bytes": fetch, "write_bytes": write, "hbm_side_gbs": (fetch + write) / (t["ms"] * 1e-3) / 1e9 if t["ms"] else None}
     k = key_of(n)
-    # several instantiations (VEC true / false, MODE 1 / 2) share one bench key: the bench entry is attributed by launch share
+    # the VEC true / false instantiations of a tile share one bench key: the bench entry is attributed by launch share
     if k in pk and used[k]:
         share = t["launches"] / used[k]
         b = pk[k]
@@ -90,7 +98,7 @@ tot_busy = sum(t["SQ_VALU_MFMA_BUSY_CYCLES"] for t in table.values())
 
 
 def is_vit(n):   # the ViT path: dense (MODE 0) engine kernels, attention, LayerNorm, token assembly
-    return (key_of(n) or "").endswith(":dense") or any(s in n for s in ("attn_", "layernorm_kernel", "assemble_tokens"))
+    return (key_of(n) or "").endswith(":m0") or any(s in n for s in ("attn_", "layernorm_kernel", "assemble_tokens"))
 
 
 va = sum(t["GRBM_GUI_ACTIVE"] for n, t in table.items() if is_vit(n))
