@@ -331,14 +331,31 @@ def main():
     ap.add_argument("--tune-file", default=None,
                     help="the GEMM autotuner's table (pp_gemm_tune_load / _save): loaded before the first step if the file exists, "
                          "written after the run otherwise — every pass of a profiling set then runs identical launches")
+    ap.add_argument("--emulate-world", type=int, default=None,
+                    help="8-GPU preflight on ONE GPU in ONE process: run rank 0's share of a --scaling strong job of this many ranks "
+                         "(its crops, its template slice, every launch at the real shard shapes) with the collectives replaced by local "
+                         "copies of the same sizes; reports phases_ms and the rank's peak memory.  Not a measurement of the exchange.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the untimed --mode exact comparison leg")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("PP_BENCH_REHEARSE") != "1":
+        # (counting devices does not initialise the GPU on this image; a rank that asked for a GPU the node lacks would otherwise
+        # fail later with an opaque HIP error — or worse, several ranks would silently share one card)
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but this node shows {have} GPU(s).  One process per GPU is the product's "
+                             f"configuration; to REHEARSE the {a.gpus}-rank code path on fewer GPUs set PP_BENCH_REHEARSE=1 (all ranks on "
+                             f"cuda:0 over gloo, at most 6 ranks per card on this pool) or use --emulate-world {a.gpus} (one process).")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))      # child job; this process never touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    emulate = a.emulate_world
+    if emulate is not None:
+        if a.gpus != 1 or world != 1 or emulate < 2:
+            raise SystemExit("--emulate-world G (G >= 2) runs in ONE process: use it with --gpus 1")
+        a.scaling = "strong"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start the ranks with torch.distributed.run --nproc-per-node {a.gpus} "
@@ -354,7 +371,42 @@ def main():
                   "configuration of the product (one process per GPU; DESIGN.md section 6) and not a measurement", file=sys.stderr, flush=True)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    if emulate is not None:
+        # rank 0 of a world of `emulate` ranks, in this one process: picopose_amd.dist sees a stand-in for torch.distributed whose
+        # collectives are local copies of the same shapes (an all-gather of x = x written world times)
+        import picopose_amd.dist as pdist
+
+        class _Work:
+            def wait(self):
+                return None
+
+        class _LocalDist:
+            ReduceOp = torch.distributed.ReduceOp
+
+            @staticmethod
+            def get_rank(group=None):
+                return 0
+
+            @staticmethod
+            def get_world_size(group=None):
+                return emulate
+
+            @staticmethod
+            def is_available():
+                return True
+
+            @staticmethod
+            def is_initialized():
+                return True
+
+            @staticmethod
+            def all_gather_into_tensor(out, inp, group=None, async_op=False):
+                out.view(emulate, *inp.shape).copy_(inp.unsqueeze(0).expand(emulate, *inp.shape))
+                return _Work() if async_op else None
+
+        pdist.dist = _LocalDist
+        world = emulate
+    distributed = world > 1 and emulate is None
     backend = "none"
     if distributed:
         import torch.distributed as dist
@@ -387,7 +439,7 @@ def main():
         a.shard = "templates" if a.scaling == "strong" else "crops"
     if a.scaling == "strong" and a.shard != "templates":
         raise SystemExit("--scaling strong shards the template bank (configs[3] / [4]): --shard templates")
-    sharded = distributed and a.shard == "templates"       # the template-sharded forward of picopose_amd/dist.py
+    sharded = (distributed or emulate is not None) and a.shard == "templates"       # the template-sharded forward of picopose_amd/dist.py
     lo, hi = shard_bounds(N, world, rank) if sharded else (0, N)
     n_local = hi - lo
     Bq = B if sharded else Bl                               # crops whose scores this rank computes
@@ -624,10 +676,11 @@ def main():
                          "pnp_translation_median_abs_m": float(np.median(abs(xtvec - tvec)[both])) if both.any() else None,
                          "note": "compared on the (crop, hypothesis) pairs for which both modes picked the same template"}}
 
+    peak_mem = torch.cuda.max_memory_allocated(dev)
     if distributed:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, float(peak_mem)], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, peak_mem = float(t[0].item()), int(t[1].item())
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -642,9 +695,11 @@ def main():
         line = {
             "metric": f"image-crops/sec (224x224, {N} templates)" + ("" if kind == "full" else ", stage-1 template matching only")
                       + (", extended template bank (SURVEY 8f row 1: template ViT/DPT precomputed)" if cached else ""),
-            "value": B / (dt / a.steps), "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": (Bl if emulate is not None else B) / (dt / a.steps), "unit": "crops/s", "n_gpus": 1 if emulate is not None else world,
+            "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "ms_per_step_median_hip_events": step_ms[len(step_ms) // 2],
             "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None,
+            "peak_memory_gib_per_rank": peak_mem / 2 ** 30,
             "dtype": {"fast": "f32 tensors; networks: f32 operands split into 2 f16 terms (22 bits) on f16 MFMA with f32 accumulate; stage-1 "
                               "contraction: f16 MFMA operands, f32 accumulate, exact f32 re-evaluation of near-ties; PnP f64",
                       "exact": "f32 (fp32 MFMA everywhere; PnP f64)",
@@ -743,6 +798,12 @@ def main():
                                                        "(|activation| < 16376, picopose_amd/ops.py CHECK_SATURATION); a hit aborts the bench"}
             if exact is not None:
                 line["exact_mode"] = exact
+        if emulate is not None:
+            line["emulated_world"] = {
+                "world": emulate, "rank": 0, "crops_of_this_rank": Bl, "templates_of_this_rank": n_local, "global_batch": B,
+                "note": f"8-GPU preflight: rank 0's share of `bench.py --gpus {emulate} --scaling strong` run in ONE process on ONE GPU — every "
+                        "kernel launch at the real shard shapes, the collectives replaced by local copies of the same sizes (no RCCL, no "
+                        "xGMI: `exchange` in phases_ms is NOT a measurement).  `value` = this ONE rank's crops per second, not the job's."}
         if tune is not None:
             tune["entries"] = L.pp_gemm_tune_entries()
             if not tune["loaded"]:

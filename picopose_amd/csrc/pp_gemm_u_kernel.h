@@ -506,6 +506,13 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             if (!VEC) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         }
     } else {
+#ifdef PP_STUDY_STAGGER   // (timing study builds only: four phase groups of workgroups, offset by PP_STUDY_STAGGER x 10 ns each)
+    {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait_ = (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned long long)(PP_STUDY_STAGGER);
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait_) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     PP_U_SETUP(first)
 #pragma unroll
     for (int s = 0; s < (SPREAD ? S - 1 : S); ++s) PP_U_FETCH(s)
@@ -576,6 +583,15 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             ++since_epi;
 #ifndef PP_STUDY_NOBAR   // (timing study builds only)
             __builtin_amdgcn_s_barrier();
+#endif
+#ifdef PP_STUDY_SPREADST   // (timing study builds only, with PP_STUDY_NOEPI: a tile's 32 KB of stores per wave spread over its first K tiles)
+            if (kt < 16 && d.C_hl) {
+                // (bounded descriptor: the last tile row reaches past M — those stores are dropped by the range check)
+                const __amdgpu_buffer_rsrc_t Hs = __builtin_amdgcn_make_buffer_rsrc((void*)d.C_hl, 0, (int)((long long)d.M * d.ldc_h * EB), 0x00020000);
+                const unsigned so_ = (unsigned)(((tile * 8 + w) * 32 + kt * 2) * 1024 + lane * 16);
+                pp_bstore(Hs, __builtin_bit_cast(f4, fa1.x[0][0]), so_);
+                pp_bstore(Hs, __builtin_bit_cast(f4, fa1.x[1][0]), so_ + 1024u);
+            }
 #endif
             if (B3E) {
                 a_fill = cur;

@@ -5,6 +5,8 @@ ResidualConvUnit :40-95), flow_decoder.py:9-94, raft_decoder.py:14-53,56-161,251
 utils/corr_lookup.py:69-134.  Eval BatchNorms are folded into their convolutions; the correlation
 pyramid is never materialised (ops.corr_lookup); channel concatenations are written in place into
 one (B,H,W,640) buffer by the producing kernels."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -147,6 +149,10 @@ def _motion_encoder(levels, radius):
     return m
 
 
+# One launch for the first layers of the flow and certainty heads; PP_FUSE_XHEADS=0 keeps two launches (A/B).
+FUSE_XHEADS = os.environ.get("PP_FUSE_XHEADS", "1") != "0"
+
+
 def _xhead(cin, kind):
     m = Holder()
     m.layers = seq((0, _cm(cin, 512, 3)), (1, _cm(512, 256, 3)))
@@ -187,6 +193,12 @@ class FlowDecoder(Packed):
                 for idx, sub in head.layers.named_children():
                     pk[f"{name}{l}_{idx}"] = ops.pack_conv_weight(sub.conv.weight.float())
                 pk[f"{name}{l}_p"] = ops.pack_conv_weight(head.predict_layer.weight.float())
+            # the two heads' first layers read the SAME 640-channel operand (flow_decoder.py:58-72): one launch with the filters
+            # concatenated along N (1024 columns) stages every A tile once for both; their successors read their halves of the
+            # hidden operand as channel slices (FUSE_XHEADS)
+            pk[f"x{l}_0"] = torch.cat([pk[f"fp{l}_0"], pk[f"mp{l}_0"]]).contiguous()
+            pk[f"x{l}_0_b"] = torch.cat([getattr(self.flow_pred[l].layers, "0").conv.bias.float(),
+                                         getattr(self.mask_pred[l].layers, "0").conv.bias.float()]).contiguous()
         return pk
 
     def _pack_train(self):
@@ -263,12 +275,19 @@ class FlowDecoder(Packed):
                 ops.warp(fq, flow, out=X[..., 256:512])                 # feature_sample (flow_decoder.py:49-56)
                 Xs = ops.split_image(X)    # both heads read the same operand: split once; hidden maps stay operand-only
             fp, mp = self.flow_pred[l], self.mask_pred[l]
-            h = ops.conv2d(Xs, pk[f"fp{l}_0"], getattr(fp.layers, "0").conv.bias, 3, pad=1, act="relu", out_split=True)
-            h = ops.conv2d(h, pk[f"fp{l}_1"], getattr(fp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True)
-            flow = ops.conv2d(h, pk[f"fp{l}_p"], fp.predict_layer.bias, 3, pad=1, residual=flow)      # flow + delta
-            h = ops.conv2d(Xs, pk[f"mp{l}_0"], getattr(mp.layers, "0").conv.bias, 3, pad=1, act="relu", out_split=True)
-            h = ops.conv2d(h, pk[f"mp{l}_1"], getattr(mp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True)
-            cert = ops.conv2d(h, pk[f"mp{l}_p"], mp.predict_layer.bias, 1, residual=cert)             # certainty + delta
+            if FUSE_XHEADS and isinstance(Xs, ops.Split):
+                hx = ops.conv2d(Xs, pk[f"x{l}_0"], pk[f"x{l}_0_b"], 3, pad=1, act="relu", out_split=True)      # (rows, 512 | 512)
+                h = ops.conv2d(hx, pk[f"fp{l}_1"], getattr(fp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True, in_cols=(0, 512))
+                flow = ops.conv2d(h, pk[f"fp{l}_p"], fp.predict_layer.bias, 3, pad=1, residual=flow)      # flow + delta
+                h = ops.conv2d(hx, pk[f"mp{l}_1"], getattr(mp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True, in_cols=(512, 512))
+                cert = ops.conv2d(h, pk[f"mp{l}_p"], mp.predict_layer.bias, 1, residual=cert)             # certainty + delta
+            else:
+                h = ops.conv2d(Xs, pk[f"fp{l}_0"], getattr(fp.layers, "0").conv.bias, 3, pad=1, act="relu", out_split=True)
+                h = ops.conv2d(h, pk[f"fp{l}_1"], getattr(fp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True)
+                flow = ops.conv2d(h, pk[f"fp{l}_p"], fp.predict_layer.bias, 3, pad=1, residual=flow)      # flow + delta
+                h = ops.conv2d(Xs, pk[f"mp{l}_0"], getattr(mp.layers, "0").conv.bias, 3, pad=1, act="relu", out_split=True)
+                h = ops.conv2d(h, pk[f"mp{l}_1"], getattr(mp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True)
+                cert = ops.conv2d(h, pk[f"mp{l}_p"], mp.predict_layer.bias, 1, residual=cert)             # certainty + delta
             flows.append(flow)
             certs.append(cert)
             if l != self.num_levels - 1:

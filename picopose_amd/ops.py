@@ -371,7 +371,7 @@ def split_image(x, relu=False):
 
 
 def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residual=None, out=None, cin=None,
-           residual2=None, out_split=False, split_relu=False, also_split=None, hl_into=None, cache_weight=True):
+           residual2=None, out_split=False, split_relu=False, also_split=None, hl_into=None, cache_weight=True, in_cols=None):
     """NHWC convolution. x (B,H,W,Cx) (channel-contiguous, may be a channel slice: cin <= Cx stride) or a Split
     carrying .image (a pre-split operand: no split pass, the producer has already applied any input ReLU),
     wp (Cout, k*k*cin) from pack_conv_weight.  out may be a channel slice of a wider NHWC buffer.
@@ -381,9 +381,17 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     `._hl_relu` (a Split) for a following convolution, both written by this epilogue.
     hl_into = (Split over (B*Ho*Wo, Ctot), col0): write the result as operand columns col0.. of that shared Split
     (channel concatenation of operands; Cout % 8 == 0, col0 % 8 == 0) — and, if `out` is given, as fp32 there too;
-    returns `out` (None without it)."""
+    returns `out` (None without it).
+    in_cols = (col0, c) with a Split input: the convolution reads operand columns col0 .. col0 + c of the wider Split (a channel
+    slice of a shared operand: two layers fused along N hand their halves to their successors without a copy)."""
     xs = x if isinstance(x, Split) else None
-    if xs is not None:
+    a_ptr = None
+    if xs is not None and in_cols is not None:
+        col0, cin = in_cols
+        (B, H, W), Cx = xs.image, xs.shape[1]
+        assert not relu_in and col0 % 8 == 0 and cin % 8 == 0 and col0 + cin <= Cx and hl_into is None
+        a_ptr, ld_in = xs.col_ptr(col0), Cx
+    elif xs is not None:
         (B, H, W), Cx = xs.image, xs.shape[1]
         assert not relu_in and cin in (None, Cx)
         ld_in = Cx
@@ -398,7 +406,7 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     Ho = (H + 2 * pad - ksize) // stride + 1
     Wo = (W + 2 * pad - ksize) // stride + 1
     dev = xs.device if xs is not None else x.device
-    if (xs is not None and xs.terms == 2 and Cout <= 2 and ksize in (1, 3) and stride == 1 and pad == ksize // 2 and act is None and out is None
+    if (xs is not None and a_ptr is None and xs.terms == 2 and Cout <= 2 and ksize in (1, 3) and stride == 1 and pad == ksize // 2 and act is None and out is None
             and not out_split and also_split is None and hl_into is None and residual2 is None and Cx % 32 == 0 and W in (16, 32, 64)
             and H % (256 // W) == 0 and wp.dtype == torch.float32 and wp.is_contiguous()
             and (residual is None or (residual.is_contiguous() and tuple(residual.shape) == (B, H, W, Cout)))
@@ -452,8 +460,9 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     if presplit:
         assert "B_hl" in wargs
         hl = xs.hl if xs is not None else split_activation(x, B, H * W, cin, x.stride(0), ld_in, relu=relu_in)  # once, not per tap / column tile
-        _run(_desc(A_hl=_p(hl), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual),
-                   residual2=_p(residual2), conv_bstride=H * W * cin, M=B * Ho * Wo, N=Cout, K=ksize * ksize * cin, lda=cin,
+        ld_a = ld_in if a_ptr is not None else cin
+        _run(_desc(A_hl=a_ptr if a_ptr is not None else _p(hl), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual),
+                   residual2=_p(residual2), conv_bstride=H * W * ld_a, M=B * Ho * Wo, N=Cout, K=ksize * ksize * cin, lda=ld_a,
                    ldb=wp.shape[1], ldc=ldc, act=ACT[act], conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride,
                    conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo, **wargs, **sargs),
              written=(extra if extra is not None else ret) if sargs else None)

@@ -131,6 +131,35 @@ def test_offset_regressor_vs_reference_golden(golden_dir):
 
 
 @gpu
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+def test_fused_xhead_first_layers_equal_two_launches(golden_dir, monkeypatch, precision):
+    """The flow and certainty heads' first layers (conv 3x3 640 -> 512 each, flow_decoder.py:58-72) run as ONE launch with the
+    filters concatenated along N, their successors read channel slices of the shared hidden operand (stage3.FUSE_XHEADS): same
+    flows and certainties as two launches.  Bit for bit when the two filters' operand scales (a power of two per weight tensor,
+    from its max) coincide with the concatenated tensor's — the case for these weights and for any pair of equally initialised /
+    trained heads; otherwise equal up to fp16 subnormals of the lo terms (stated bound 1e-6 of the tensor's max)."""
+    from picopose_amd import ops
+    from picopose_amd.model import stage3
+
+    z, t = _golden(golden_dir)
+    monkeypatch.setattr(ops, "PRECISION", precision)
+    outs = []
+    for fuse in (True, False):
+        monkeypatch.setattr(stage3, "FUSE_XHEADS", fuse)
+        orr = stage3.OffsetRegressor(small_cfg().stage3)
+        orr.load_state_dict(seeded_state_dict(orr.state_dict(), int(z["s3/seed"])))
+        orr = orr.cuda().eval()
+        g = torch.Generator().manual_seed(5)
+        ft = [0.5 * torch.randn(3, 384, 16, 16, generator=g).cuda() for _ in range(4)]
+        fr = [0.5 * torch.randn(3, 384, 16, 16, generator=g).cuda() for _ in range(4)]
+        fl, ce = orr(ft, fr, (0.5 + torch.randn(3, 2, 16, 16, generator=g)).cuda(), (torch.rand(3, 1, 16, 16, generator=g) > 0.3).float().cuda())
+        outs.append([x.cpu() for x in fl + ce])
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    print("fused vs two launches, bit-equal tensors:", sum(int(torch.equal(a, b)) for a, b in zip(*outs)), "of", len(outs[0]))
+
+
+@gpu
 @pytest.mark.parametrize("vit", ["dinov2_vitb14", "dinov2_vitl14"])
 @pytest.mark.parametrize("force", [None, "4", "5", "7", "8"])
 def test_feature_extractor_vs_reference_golden_vitb_vitl(golden_dir, monkeypatch, vit, force):

@@ -71,11 +71,18 @@ def test_bench_gpus_n_launches_its_own_ranks():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PP_BENCH_REHEARSE")}
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        # more ranks than GPUs, no rehearsal flag: refused with a clear message before anything is launched
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=120)
+        assert r.returncode != 0 and "--gpus 2 but this node shows" in r.stdout.decode() and "PP_BENCH_REHEARSE=1" in r.stdout.decode()
+        env["PP_BENCH_REHEARSE"] = "1"      # the rehearsal flag lets the launcher start its ranks on fewer GPUs
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = r.stdout.decode()
-    import torch
 
     if not torch.cuda.is_available():
         assert r.returncode != 0
