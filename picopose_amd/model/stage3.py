@@ -149,8 +149,12 @@ def _motion_encoder(levels, radius):
     return m
 
 
-# One launch for the first layers of the flow and certainty heads; PP_FUSE_XHEADS=0 keeps two launches (A/B).
-FUSE_XHEADS = os.environ.get("PP_FUSE_XHEADS", "1") != "0"
+# One launch for the first layers of the flow and certainty heads: PP_FUSE_XHEADS=1.  Off by default: measured
+# neutral (A/B on one box, 3 + 3 runs: 398.3 / 398.4 / 398.1 crops/s with two launches, 398.0 / 397.5 / 397.6 fused —
+# profiles/r04/ab_xheads.txt: the 256x256 convolution kernel is power-limited, its A tiles already come from L2), and the shared
+# 1024-column hidden operand doubles the row pitch the successors address with 32-bit byte offsets (4 GB: 160 images of 64x64 fit,
+# the 320 of a configs[4] share do not — the fused path then falls back to two launches).
+FUSE_XHEADS = os.environ.get("PP_FUSE_XHEADS", "0") == "1"
 
 
 def _xhead(cin, kind):
@@ -275,7 +279,7 @@ class FlowDecoder(Packed):
                 ops.warp(fq, flow, out=X[..., 256:512])                 # feature_sample (flow_decoder.py:49-56)
                 Xs = ops.split_image(X)    # both heads read the same operand: split once; hidden maps stay operand-only
             fp, mp = self.flow_pred[l], self.mask_pred[l]
-            if FUSE_XHEADS and isinstance(Xs, ops.Split):
+            if FUSE_XHEADS and isinstance(Xs, ops.Split) and B * H * W * 1024 * 2 * Xs.terms < 0xFFFFFF00:
                 hx = ops.conv2d(Xs, pk[f"x{l}_0"], pk[f"x{l}_0_b"], 3, pad=1, act="relu", out_split=True)      # (rows, 512 | 512)
                 h = ops.conv2d(hx, pk[f"fp{l}_1"], getattr(fp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True, in_cols=(0, 512))
                 flow = ops.conv2d(h, pk[f"fp{l}_p"], fp.predict_layer.bias, 3, pad=1, residual=flow)      # flow + delta
