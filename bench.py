@@ -325,6 +325,9 @@ def main():
     ap.add_argument("--global-batch", type=int, default=None, help="strong scaling with this global batch (implies --scaling strong)")
     ap.add_argument("--sync-loop", action="store_true", help="the host reads every step's poses before it launches the next step "
                                                              "(rounds 1-2; default now: a serving loop, one step of read latency)")
+    ap.add_argument("--pnp-stream", default="side", choices=["side", "same"],
+                    help="serving loop: a batch's PnP/RANSAC launch + D2H on a side stream (it waits for the batch's forward, then runs beside "
+                         "the NEXT batch's forward) or on the forward's own stream (rounds 1-3)")
     ap.add_argument("--shard", default="auto", choices=["auto", "crops", "templates"],
                     help="N > 1: what is sharded over the ranks. auto = crops for weak scaling (independent replicas, no data-path "
                          "collective), templates for strong scaling (configs[3] / [4]: template-sharded bank + all-gathers)")
@@ -502,9 +505,11 @@ def main():
         from picopose_amd.pipeline import pnp_collect, pnp_for_outputs_async
         pinned = [torch.empty(5 * Bl, 15, dtype=torch.float64, pin_memory=True) for _ in range(2)]
 
+        pnp_stream = torch.cuda.Stream(device=dev) if a.pnp_stream == "side" else None
+
         def step_launch(i):
             outs = forward()
-            return pnp_for_outputs_async(outs, ep["real_K"], host=pinned[i % 2])
+            return pnp_for_outputs_async(outs, ep["real_K"], host=pinned[i % 2], stream=pnp_stream)
 
     if kind == "stage1":   # a step is ~1 ms: without ~0.3 s of load first, the timed steps run while the clocks still ramp
         t_ramp = time.perf_counter()
@@ -708,7 +713,9 @@ def main():
                               "PnP f64"}[a.mode],
             "data": "synthetic",
             "loop": ("every timed step = forward + PnP/RANSAC launch + asynchronous D2H of its poses; the host reads step i's poses after "
-                     "launching step i + 1 (serving loop), the last step's before the closing synchronisation" if kind != "stage1" and not a.sync_loop else
+                     "launching step i + 1 (serving loop), the last step's before the closing synchronisation"
+                     + ("; PnP + D2H of a step on a side stream (after that step's forward, beside the next step's)" if a.pnp_stream == "side" else "")
+                     if kind != "stage1" and not a.sync_loop else
                      "every timed step = forward + PnP/RANSAC + D2H of its poses, read by the host before the next step is launched" if kind != "stage1" else
                      "every timed step = one matching call, results left on the device"),
             "config": {"workload": f"{a.workload}: {desc}", "global_batch": B, "crops_per_rank": Bl, "templates": N,

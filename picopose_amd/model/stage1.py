@@ -127,8 +127,11 @@ class FeatureExtractor(Packed):
         return pk["pos"][key]
 
     # ---- forward -------------------------------------------------------------------------
-    def forward_tokens(self, x, last_block_fn=None, all_blocks=False, embed_fn=None):
+    def forward_tokens(self, x, last_block_fn=None, all_blocks=False, embed_fn=None, level_out=None):
         """(B,3,H,W) -> list of token tensors (B, 1+hw, C) at the taken blocks (cls row first).
+        level_out = (buffers, row0): the taken blocks' outputs are written as images row0 .. row0 + B of the caller's
+        (Btot * T, C) fp32 buffers (one per taken level) — the query pass and the template pass of a forward then leave their
+        levels in ONE tensor per level, which the DPT head reads as one batch (Net.forward_test).
         last_block_fn(block, xs, B, T, heads, hd) -> xs': computes the LAST block (all_blocks: every block) instead of the fused
         engine path — the training slices run them under autograd (picopose_amd/autograd.last_block_forward); embed_fn(self, x) ->
         token rows (B*T, C): the embedding under autograd (autograd.embed_tokens)."""
@@ -162,7 +165,10 @@ class FeatureExtractor(Packed):
             xs = ops.linear(o, blk.attn.proj.weight, blk.attn.proj.bias, gamma=blk.ls1.gamma, residual=xs)
             h = ops.layernorm(xs, blk.norm2.weight, blk.norm2.bias, 1e-6, out_split=True)
             f = ops.linear(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act="gelu", out_split=True)
-            xs = ops.linear(f, blk.mlp.fc2.weight, blk.mlp.fc2.bias, gamma=blk.ls2.gamma, residual=xs)
+            dst = None
+            if level_out is not None and i in self.blocks_to_take:
+                dst = level_out[0][self.blocks_to_take.index(i)][level_out[1] * T:(level_out[1] + B) * T]
+            xs = ops.linear(f, blk.mlp.fc2.weight, blk.mlp.fc2.bias, gamma=blk.ls2.gamma, residual=xs, out=dst)
             if i in self.blocks_to_take:
                 outs.append(xs.view(B, T, C))
         return outs, (h0, w0)

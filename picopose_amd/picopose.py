@@ -7,6 +7,8 @@ Same constructor (`Net(cfg)` with cfg.stage1/2/3), same sub-module names (identi
 libpicopose_hip.so.  In training mode `model(end_points)` is the reference's forward_train (:114-137): it returns
 `end_points` with the ten `loss*` entries, under autograd (picopose_amd/autograd.py: `loss.backward()` is the reference's training
 step — SURVEY.md 8f rank 4; `Net.train_backward` narrows or switches off the graph)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -21,6 +23,22 @@ from .utils.loss_utils import compute_stage_two_loss, flow_level_losses, infonce
 from .utils.matching import matching_features_similarity, matching_templates
 from .utils.pose_recovery import pose_recovery_2d_prediction
 from .utils.torch_utils import calc_pred_Ms
+
+
+# One pass of the DPT head over [selected templates ; query crops] instead of one pass each (PP_BATCH_DPT=0: two passes, A/B)
+BATCH_DPT = os.environ.get("PP_BATCH_DPT", "1") != "0"
+
+
+def _image_rows(p, b0, b1):
+    """Images b0 .. b1 of an NHWC map, with its attached operand form (`._hl`, model/stage3.py) cut the same way."""
+    q = p[b0:b1]
+    hl = getattr(p, "_hl", None)
+    if hl is not None:
+        hw = p.shape[1] * p.shape[2]
+        s = ops.Split(hl.hl[b0 * hw:b1 * hw], hl.terms)
+        s.image = (b1 - b0, p.shape[1], p.shape[2])
+        q._hl = s
+    return q
 
 
 class Net(nn.Module):
@@ -87,12 +105,13 @@ class Net(nn.Module):
         fe = self.feature_extractor
         real_tok, (h0, w0) = real[0], real[1]
         real_dpt = real[2] if len(real) > 2 else None
+        levels = real[3] if len(real) > 3 else None     # shared level buffers: templates first, then the query crops (forward_test)
         output = {"tem_pose": end_points["tem_pose"]}
         output["tar_pts_2d"] = end_points["real_pts2d"].permute(0, 3, 2, 1)
         output["src_pts_3d"] = end_points["tem_pts3d"].permute(0, 3, 1, 2)
         # stage 1: template features
         if tem_cached is None:
-            tem_tok, _ = fe.forward_tokens(end_points["tem_rgb"])
+            tem_tok, _ = fe.forward_tokens(end_points["tem_rgb"], level_out=None if levels is None else (levels, 0))
             tem_last = ops.tokens_to_nchw(tem_tok[-1], 1, h0, w0)
         else:
             tem_last, tem_dpt = tem_cached
@@ -108,10 +127,18 @@ class Net(nn.Module):
         init_flow, init_certainty = compute_init_correspondences(pred_Ms, end_points["tem_mask"])
         as_img = lambda t: t[:, 1:].unflatten(1, (h0, w0))  # noqa: E731  (B,h0,w0,C) view, batch stride (1+h0*w0)*C
         orr = self.offset_regressor
-        if real_dpt is None:
-            real_dpt = orr.dpt_head.forward_nhwc([as_img(t) for t in real_tok])
-        if tem_cached is None:
-            tem_dpt = orr.dpt_head.forward_nhwc([as_img(t) for t in tem_tok])
+        if levels is not None and real_dpt is None and tem_cached is None:
+            # ONE pass of the DPT head over [templates ; query crops] (the same weights; a row of a GEMM does not depend on the
+            # other rows, so every map keeps the bits two passes give it): larger launches, half as many of them
+            T = h0 * w0 + 1
+            nT, nR = tem_tok[0].shape[0], levels[0].shape[0] // T - tem_tok[0].shape[0]
+            both = orr.dpt_head.forward_nhwc([as_img(lv.view(-1, T, lv.shape[1])) for lv in levels])
+            tem_dpt, real_dpt = [_image_rows(p_, 0, nT) for p_ in both], [_image_rows(p_, nT, nT + nR) for p_ in both]
+        else:
+            if real_dpt is None:
+                real_dpt = orr.dpt_head.forward_nhwc([as_img(t) for t in real_tok])
+            if tem_cached is None:
+                tem_dpt = orr.dpt_head.forward_nhwc([as_img(t) for t in tem_tok])
         flows, certs = orr.flow_decoder.forward_nhwc(tem_dpt, real_dpt, ops.to_nhwc(init_flow), ops.to_nhwc(init_certainty))
         if self.keep_stage3:
             self.last_stage3 = (flows[-1], certs[-1])
@@ -140,6 +167,7 @@ class Net(nn.Module):
         # launches that fill the 256 CUs evenly.
         real_tok, hw = real[0], real[1]
         real_dpt = real[2] if len(real) > 2 and real[2] is not None else None
+        levels = real[3] if len(real) > 3 else None
         B = pred_id_src.shape[0]
         idx = pred_id_src.t().reshape(-1)
         rows = torch.arange(B, device=idx.device).repeat(hyp)
@@ -152,18 +180,31 @@ class Net(nn.Module):
         for key in ("real_pts2d", "real_K", "real_M", "real_mask", "real_pose"):
             sel[key] = rep(end_points[key])
         # (with the query-side DPT maps at hand only the last token level is read again: for the stage-2 similarity)
-        toks = [rep(t) for t in real_tok] if real_dpt is None else [None] * (len(real_tok) - 1) + [rep(real_tok[-1])]
+        toks = ([rep(t) for t in real_tok] if real_dpt is None and levels is None
+                else [None] * (len(real_tok) - 1) + [rep(real_tok[-1])])
         # (the query-side DPT maps go in un-repeated: the flow decoder projects them once and tiles the projection)
-        out = self.forward_test_hyp(sel, (toks, hw, real_dpt),
+        out = self.forward_test_hyp(sel, (toks, hw, real_dpt, levels if cache is None else None),
                                     cached(rows, idx))
         return [{key: v[k * B:(k + 1) * B] for key, v in out.items()} for k in range(hyp)]
 
     # model/picopose.py:97-112
     def forward_test(self, end_points, hyp=5):
         with torch.no_grad():
-            real_tok, (h0, w0) = self.feature_extractor.forward_tokens(end_points["real_rgb"])
-            real_dpt = self.offset_regressor.dpt_head.forward_nhwc([t[:, 1:].unflatten(1, (h0, w0)) for t in real_tok])
-            real = (real_tok, (h0, w0), real_dpt)
+            fe = self.feature_extractor
+            levels = None
+            if BATCH_DPT and self.batch_hypotheses and end_points.get("template_cache") is None:
+                # the four feature levels of the hyp * B selected templates and of the B query crops share one buffer per level
+                # (templates first): the DPT head then runs ONCE over both (forward_test_hyp)
+                B, _, H, W = end_points["real_rgb"].shape
+                T = (H // fe.patch_size) * (W // fe.patch_size) + 1
+                levels = [torch.empty((hyp + 1) * B * T, fe.num_features, dtype=torch.float32, device=end_points["real_rgb"].device)
+                          for _ in fe.blocks_to_take]
+                real_tok, (h0, w0) = fe.forward_tokens(end_points["real_rgb"], level_out=(levels, hyp * B))
+                real = (real_tok, (h0, w0), None, levels)
+            else:
+                real_tok, (h0, w0) = fe.forward_tokens(end_points["real_rgb"])
+                real_dpt = self.offset_regressor.dpt_head.forward_nhwc([t[:, 1:].unflatten(1, (h0, w0)) for t in real_tok])
+                real = (real_tok, (h0, w0), real_dpt)
             # matching.py normalises the bank itself; the reference's extra F.normalize of the whole bank
             # (picopose.py:99) is idempotent up to rounding and is not materialised here
             pred_score_src, pred_id_src = matching_templates(

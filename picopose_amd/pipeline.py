@@ -26,11 +26,12 @@ def pnp_for_outputs(outputs, real_K, return_npts=False):
     return out + (res[4].reshape(hyp, B),) if return_npts else out
 
 
-def pnp_for_outputs_async(outputs, real_K, host=None):
-    """pnp_for_outputs without the host wait -> handle; `pnp_collect(handle, hyp, B)` reads it (one batch later in a serving loop)."""
+def pnp_for_outputs_async(outputs, real_K, host=None, stream=None):
+    """pnp_for_outputs without the host wait -> handle; `pnp_collect(handle, hyp, B)` reads it (one batch later in a serving loop).
+    stream: run the PnP launch and the copy on this side stream, beside the next batch's forward (pose_recovery_ransac_pnp_batched_async)."""
     from .utils.pose_recovery import pose_recovery_ransac_pnp_batched_async
 
-    return pose_recovery_ransac_pnp_batched_async(*pnp_inputs(outputs, real_K), host=host)
+    return pose_recovery_ransac_pnp_batched_async(*pnp_inputs(outputs, real_K), host=host, stream=stream)
 
 
 def pnp_collect(handle, hyp, B):

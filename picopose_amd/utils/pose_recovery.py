@@ -98,18 +98,27 @@ class PnPHandle:
 
 
 def pose_recovery_ransac_pnp_batched_async(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations=150, reproj_error=2.0,
-                                           host=None):
+                                           host=None, stream=None):
     """pose_recovery_ransac_pnp_batched without the host wait: the launch and ONE asynchronous device->host copy (P x 15 doubles
     into a pinned buffer, `host` to reuse one) are enqueued on the current stream; `.result()` of the returned handle waits for
-    them.  A serving loop launches batch i + 1 before it reads batch i's poses, so the GPU never waits for the host."""
-    rot, tvec, ratio, ok, npts = pnp_launch(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations, reproj_error)
-    P = rot.shape[0]
-    packed = torch.cat([rot.reshape(P, 9), tvec, ratio[:, None], ok.double()[:, None], npts.double()[:, None]], dim=1)
-    if host is None or tuple(host.shape) != (P, 15):
-        host = torch.empty(P, 15, dtype=torch.float64, pin_memory=True)
-    host.copy_(packed, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
+    them.  A serving loop launches batch i + 1 before it reads batch i's poses, so the GPU never waits for the host.
+    stream: a side torch.cuda.Stream for the PnP launch and the copy (it first waits for the current stream, i.e. for the forward
+    that produced the inputs): the batch's PnP — one 512-thread workgroup per problem, latency-bound fp64 work on 160 of the
+    256 CUs — then runs beside the NEXT batch's forward instead of in front of it."""
+    inputs = (tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts)
+    if stream is not None:
+        stream.wait_stream(torch.cuda.current_stream())
+        for t in inputs:
+            t.record_stream(stream)      # (the caching allocator must not hand these blocks out while the side stream reads them)
+    with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+        rot, tvec, ratio, ok, npts = pnp_launch(*inputs, iterations, reproj_error)
+        P = rot.shape[0]
+        packed = torch.cat([rot.reshape(P, 9), tvec, ratio[:, None], ok.double()[:, None], npts.double()[:, None]], dim=1)
+        if host is None or tuple(host.shape) != (P, 15):
+            host = torch.empty(P, 15, dtype=torch.float64, pin_memory=True)
+        host.copy_(packed, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
     return PnPHandle(host, ev, P)
 
 
