@@ -86,6 +86,7 @@ def lib():
         L.pp_topk.argtypes = [vp, i32, i32, i32, vp, vp, vp]
         L.pp_stage1_match.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz,
                                       vp, vp, vp, vp, vp]
+        L.pp_stage1_match_ex.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, vp, vp, vp, vp]
         L.pp_similarity_volume.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
         L.pp_calc_pred_Ms.argtypes = [vp, vp, vp, vp, vp, vp, i32, f32, vp, vp]
         L.pp_pose_recovery_2d.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp]

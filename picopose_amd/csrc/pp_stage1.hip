@@ -68,6 +68,7 @@ struct S1Ws {
     float* simt0;   // (B*N, 256) sim[t,0]
     float* colmax;  // (B*N, 256) column maxima over t > 0
     float* sim0s;   // (B*N, 256) sim[0,s]
+    int* counters;  // (B) resolve workgroups of a crop that have written their sim_avg (fused resolve + top-k)
     size_t total;
 };
 
@@ -87,6 +88,7 @@ __host__ S1Ws carve(void* base, int B, int N, int C) {
     w.simt0 = (float*)take(BN * P * 4);
     w.colmax = (float*)take(BN * P * 4);
     w.sim0s = (float*)take(BN * P * 4);
+    w.counters = (int*)take((size_t)B * 4);
     w.total = off;
     return w;
 }
@@ -153,6 +155,67 @@ __global__ __launch_bounds__(256) void s1_qpack(const float* __restrict__ query,
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {  // 8 consecutive channels -> one 16-byte A-fragment piece
+        h8 pk;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pk[j] = (_Float16)v[g * 8 + j];
+        const int kh = g >> 1, hh = g & 1;
+        const size_t off = ((((size_t)b * KT + ks) * 2 + kh) * 8 + tb) * 512 + (tl + 32 * hh) * 8;
+        *(h8*)(qh + off) = pk;
+    }
+}
+
+// s1_qprep = s1_qnorm + s1_qpack in ONE launch for small problems (BASELINE configs[1]: 8 crops, C = 384 — there the two
+// launches and the gap between them were 12 of the call's 70 us): every (crop, 32-channel slice) workgroup recomputes the
+// crop's 256 patch norms itself (the crop's C x 256 floats come from L2; B C^2 32 bytes in total, so only for small B C^2)
+// in EXACTLY s1_qnorm's summation order — 16 partial sums over the channels of one residue class mod 16, ascending, then
+// their sum in class order — so `denom` and everything packed from it keep their bits.  Block (0, 0) also zeroes the
+// per-crop arrival counters of the fused resolve + top-k (pp_stage1_match).
+__global__ __launch_bounds__(256) void s1_qprep(const float* __restrict__ query, const float* __restrict__ mask, int mh, int mw, int C,
+                                                float* __restrict__ denom, float* __restrict__ m16g, _Float16* __restrict__ qh,
+                                                float* __restrict__ qf, int* __restrict__ counters, int ncounters) {
+    const int b = blockIdx.x, ks = blockIdx.y, t = threadIdx.x;
+    if (b == 0 && ks == 0 && counters)
+        for (int j = t; j < ncounters; j += 256) counters[j] = 0;
+    const float* qc = query + (size_t)b * C * P + t;
+    float ss[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ss[j] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 16) {      // channel c0 + j belongs to class j: ascending within every class
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = qc[(size_t)(c0 + j) * P];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ss[j] = fmaf(v[j], v[j], ss[j]);
+    }
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tot += ss[j];
+    const float d = fmaxf(sqrtf(tot), 1e-12f);
+    const int py = t >> 4, px = t & 15;
+    const float sy = (float)mh / 16.0f, sx = (float)mw / 16.0f;
+    int iy = (int)floorf((float)py * sy), ix = (int)floorf((float)px * sx);
+    iy = iy < mh - 1 ? iy : mh - 1;
+    ix = ix < mw - 1 ? ix : mw - 1;
+    const float m = mask[((size_t)b * mh + iy) * mw + ix];
+    if (ks == 0) {
+        denom[b * P + t] = d;
+        m16g[b * P + t] = m;
+    }
+    // the pack of s1_qpack
+    const int KT = C >> 5;
+    const float* q = query + ((size_t)b * C + ks * 32) * P + t;
+    float* qo = qf + ((size_t)b * C + ks * 32) * P + t;
+    const int tb = t >> 5, tl = t & 31;
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) v[j] = q[(size_t)j * P];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        v[j] = (v[j] / d) * m;
+        qo[(size_t)j * P] = v[j];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
         h8 pk;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pk[j] = (_Float16)v[g * 8 + j];
@@ -737,6 +800,75 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void s1_main(const XT* __
 #undef Q_DESC
 }
 
+// torch.topk(sim_avg, k, dim=1) (matching.py:68): descending score, NaN sorts above every
+// number (as torch does), ties -> lower template id.
+__device__ __forceinline__ bool topk_better(float v, int j, float bv, int bi) {
+    if (bi < 0) return true;
+    const bool vn = v != v, bn_ = bv != bv;
+    if (vn != bn_) return vn;
+    if (!vn && v != bv) return v > bv;
+    return j < bi;
+}
+
+// one crop's row by one 256-thread workgroup; sc: N floats followed by N taken flags (LDS).  COHERENT: the row was written by
+// other workgroups of THIS launch (the fused resolve + top-k): read it with agent-scope atomic loads
+template <bool COHERENT>
+__device__ __forceinline__ void topk_block(const float* __restrict__ row, int N, int k, float* __restrict__ out_score,
+                                           int64_t* __restrict__ out_index, float* sc, float* wv, int* wi) {
+    unsigned char* taken = (unsigned char*)(sc + N);
+    const int tid = threadIdx.x;
+    for (int j = tid; j < N; j += 256) {
+        sc[j] = COHERENT ? __hip_atomic_load(row + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : row[j];
+        taken[j] = 0;
+    }
+    __syncthreads();
+    for (int it = 0; it < k; ++it) {
+        float bv = 0.f;
+        int bi = -1;
+        for (int j = tid; j < N; j += 256)
+            if (!taken[j] && topk_better(sc[j], j, bv, bi)) {
+                bv = sc[j];
+                bi = j;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (oi >= 0 && topk_better(ov, oi, bv, bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            wv[tid >> 6] = bv;
+            wi[tid >> 6] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int q = 1; q < 4; ++q)
+                if (wi[q] >= 0 && topk_better(wv[q], wi[q], bv, bi)) {
+                    bv = wv[q];
+                    bi = wi[q];
+                }
+            out_score[it] = bv;
+            out_index[it] = bi;
+            taken[bi] = 1;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_rows(const float* __restrict__ scores, int N, int k,
+                                                 float* __restrict__ out_score,
+                                                 int64_t* __restrict__ out_index) {
+    extern __shared__ float sc[];
+    __shared__ float wv[4];
+    __shared__ int wi[4];
+    const int b = blockIdx.x;
+    topk_block<false>(scores + (size_t)b * N, N, k, out_score + (size_t)b * k, out_index + (size_t)b * k, sc, wv, wi);
+}
+
+
 // ---------------------------------------------------------------------------
 // s1_resolve: per (b,n) — FAST mode's exact re-evaluation of near-tie decisions, then
 // sim_avg (matching.py:53-66).
@@ -760,7 +892,8 @@ __global__ __launch_bounds__(256) void s1_resolve(const XT* __restrict__ bank,
                                                   const float* __restrict__ colmax,
                                                   const float* __restrict__ sim0s,
                                                   float* __restrict__ sim_avg,
-                                                  int32_t* __restrict__ stats) {
+                                                  int32_t* __restrict__ stats, int topk_k, int* __restrict__ counters,
+                                                  float* __restrict__ out_score, int64_t* __restrict__ out_index) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* L = (float*)smem;  // [10][C]: q[:,t], x[:,0], x[:,c..c+3], x[:,c+32..c+35]
     __shared__ int nent;
@@ -906,69 +1039,31 @@ __global__ __launch_bounds__(256) void s1_resolve(const XT* __restrict__ bank,
         wred[4 + (i >> 6)] = ms;
     }
     __syncthreads();
+    __shared__ int last_of_crop;
     if (i == 0) {
         const float tot = (wred[0] + wred[1]) + (wred[2] + wred[3]);
         const float mt = (wred[4] + wred[5]) + (wred[6] + wred[7]);
-        sim_avg[bn] = mt > 0.f ? tot / 256.0f : 0.f;
+        const float v = mt > 0.f ? tot / 256.0f : 0.f;
+        if (topk_k > 0) {
+            // fused top-k (pp_stage1_match): the workgroup that arrives LAST for its crop ranks the crop's N scores.  The score is
+            // published with an agent-scope store, the arrival is an agent-scope acq_rel add (MI355X_MICROARCH.md, "Valid forms":
+            // agent atomics on both sides), the last arriver reads the row with agent-scope loads — the per-XCD L2s are not
+            // coherent with each other for plain accesses.  The counter returns to zero for the next call.
+            __hip_atomic_store(sim_avg + bn, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int ticket = __hip_atomic_fetch_add(counters + b, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            last_of_crop = ticket == N - 1 ? 1 : 0;
+            if (ticket == N - 1) __hip_atomic_store(counters + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            sim_avg[bn] = v;
+        }
     }
-}
-
-// torch.topk(sim_avg, k, dim=1) (matching.py:68): descending score, NaN sorts above every
-// number (as torch does), ties -> lower template id.
-__device__ __forceinline__ bool topk_better(float v, int j, float bv, int bi) {
-    if (bi < 0) return true;
-    const bool vn = v != v, bn_ = bv != bv;
-    if (vn != bn_) return vn;
-    if (!vn && v != bv) return v > bv;
-    return j < bi;
-}
-
-__global__ __launch_bounds__(256) void topk_rows(const float* __restrict__ scores, int N, int k,
-                                                 float* __restrict__ out_score,
-                                                 int64_t* __restrict__ out_index) {
-    extern __shared__ float sc[];  // N floats followed by N taken flags
-    unsigned char* taken = (unsigned char*)(sc + N);
-    __shared__ float wv[4];
-    __shared__ int wi[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int j = tid; j < N; j += 256) {
-        sc[j] = scores[(size_t)b * N + j];
-        taken[j] = 0;
-    }
-    __syncthreads();
-    for (int it = 0; it < k; ++it) {
-        float bv = 0.f;
-        int bi = -1;
-        for (int j = tid; j < N; j += 256)
-            if (!taken[j] && topk_better(sc[j], j, bv, bi)) {
-                bv = sc[j];
-                bi = j;
-            }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o);
-            const int oi = __shfl_xor(bi, o);
-            if (oi >= 0 && topk_better(ov, oi, bv, bi)) {
-                bv = ov;
-                bi = oi;
-            }
-        }
-        if ((tid & 63) == 0) {
-            wv[tid >> 6] = bv;
-            wi[tid >> 6] = bi;
-        }
+    if (topk_k > 0) {
         __syncthreads();
-        if (tid == 0) {
-            for (int q = 1; q < 4; ++q)
-                if (wi[q] >= 0 && topk_better(wv[q], wi[q], bv, bi)) {
-                    bv = wv[q];
-                    bi = wi[q];
-                }
-            out_score[(size_t)b * k + it] = bv;
-            out_index[(size_t)b * k + it] = bi;
-            taken[bi] = 1;
+        if (last_of_crop) {
+            __shared__ float twv[4];
+            __shared__ int twi[4];
+            topk_block<true>(sim_avg + (size_t)b * N, N, topk_k, out_score + (size_t)b * topk_k, out_index + (size_t)b * topk_k, L, twv, twi);
         }
-        __syncthreads();
     }
 }
 
@@ -984,9 +1079,11 @@ int pp_stage1_workspace_bytes(int B, int N, int C, size_t* bytes) {
     return PP_OK;
 }
 
-int pp_stage1_scores_ex(const void* bank_, int bank_dtype, const float* query, const float* mask, int mask_h,
-                        int mask_w, int B, int N, int C, int mode, float eps, void* workspace,
-                        size_t workspace_bytes, float* sim_avg, int32_t* stats, void* stream_) {
+// topk_k > 0: the fused form of pp_stage1_match — the last resolve workgroup of a crop ranks the crop's scores (out_score / out_index)
+static int stage1_run(const void* bank_, int bank_dtype, const float* query, const float* mask, int mask_h,
+                      int mask_w, int B, int N, int C, int mode, float eps, void* workspace,
+                      size_t workspace_bytes, float* sim_avg, int32_t* stats, int topk_k, float* out_score, int64_t* out_index,
+                      void* stream_) {
     const float* bank = (const float*)bank_;
     const _Float16* bank16 = (const _Float16*)bank_;
     const bool f16 = bank_dtype == PP_BANK_F16;
@@ -1005,15 +1102,24 @@ int pp_stage1_scores_ex(const void* bank_, int bank_dtype, const float* query, c
     // sigma ~ sqrt(2) * 2.8e-4 / sqrt(C) for unit vectors with spread-out energy
     if (eps <= 0.f) eps = 3.2e-3f / sqrtf((float)C);
 
-    hipLaunchKernelGGL(s1_qnorm, dim3(B, 4), dim3(1024), 0, stream, query, mask, mask_h, mask_w, C,
-                       w.denom, w.m16);
-    hipLaunchKernelGGL(s1_qpack, dim3(B, C / 32), dim3(256), 0, stream, query, w.denom, w.m16, C,
-                       w.qh, w.qf);
-    // persistent workgroups: 8 waves / whole templates / one per CU, or (PP_S1_WAVES=4) 4 waves / template
-    // halves / two per CU
-    const char* nw_env = getenv("PP_S1_WAVES");  // read per call: the tests run both shapes in one process
-    const int nw = !f16 && nw_env && atoi(nw_env) == 4 ? 4 : 8;   // (the fp16 bank runs the 8-wave shape only)
     const int cus = pp_cu_count();
+    // small problems (B C^2 32 bytes of L2 re-reads <= 64 MB: BASELINE configs[1]): the query pre-pack as ONE launch
+    if ((long long)B * C * C * 32 <= (64LL << 20)) {
+        hipLaunchKernelGGL(s1_qprep, dim3(B, C / 32), dim3(256), 0, stream, query, mask, mask_h, mask_w, C, w.denom, w.m16, w.qh,
+                           w.qf, topk_k > 0 ? w.counters : nullptr, B);
+    } else {
+        hipLaunchKernelGGL(s1_qnorm, dim3(B, 4), dim3(1024), 0, stream, query, mask, mask_h, mask_w, C,
+                           w.denom, w.m16);
+        hipLaunchKernelGGL(s1_qpack, dim3(B, C / 32), dim3(256), 0, stream, query, w.denom, w.m16, C,
+                           w.qh, w.qf);
+        if (topk_k > 0) PP_CHECK_HIP(hipMemsetAsync(w.counters, 0, (size_t)B * sizeof(int), stream));
+    }
+    // persistent workgroups: 8 waves / whole templates / one per CU, or 4 waves / template halves / two per CU.  The 4-wave
+    // shape issues twice the query copies (9 % slower per byte when the chip is full) but halves the work item: with fewer than
+    // two items per CU (configs[1]: 336 items on 256 CUs) the tail round is shorter (36.4 vs 39.3 us).  PP_S1_WAVES=4|8 pins one.
+    const char* nw_env = getenv("PP_S1_WAVES");  // read per call: the tests run both shapes in one process
+    const int nw_auto = B * N < 2 * cus ? 4 : 8;
+    const int nw = f16 ? 8 : (nw_env ? (atoi(nw_env) == 4 ? 4 : 8) : nw_auto);   // (the fp16 bank runs the 8-wave shape only)
     static signed char lds_state[PP_MAX_DEVICES];   // > 64 KB of dynamic LDS needs the opt-in, per device
     signed char& lds_ok = lds_state[pp_cur_device()];
     if (lds_ok == 0) {
@@ -1058,12 +1164,32 @@ int pp_stage1_scores_ex(const void* bank_, int bank_dtype, const float* query, c
     if (f16)
         hipLaunchKernelGGL(s1_resolve<_Float16>, dim3(B * N), dim3(256), (size_t)10 * C * sizeof(float), stream,
                            bank16, w.qf, w.m16, N, C, mode == PP_MATCH_FAST ? 1 : 0, eps, w.rowrec,
-                           w.simt0, w.colmax, w.sim0s, sim_avg, stats);
+                           w.simt0, w.colmax, w.sim0s, sim_avg, stats, topk_k, w.counters, out_score, out_index);
     else
         hipLaunchKernelGGL(s1_resolve<float>, dim3(B * N), dim3(256), (size_t)10 * C * sizeof(float), stream,
                            bank, w.qf, w.m16, N, C, mode == PP_MATCH_FAST ? 1 : 0, eps, w.rowrec,
-                           w.simt0, w.colmax, w.sim0s, sim_avg, stats);
+                           w.simt0, w.colmax, w.sim0s, sim_avg, stats, topk_k, w.counters, out_score, out_index);
     return pp_last_launch();
+}
+
+int pp_stage1_scores_ex(const void* bank, int bank_dtype, const float* query, const float* mask, int mask_h,
+                        int mask_w, int B, int N, int C, int mode, float eps, void* workspace,
+                        size_t workspace_bytes, float* sim_avg, int32_t* stats, void* stream) {
+    return stage1_run(bank, bank_dtype, query, mask, mask_h, mask_w, B, N, C, mode, eps, workspace, workspace_bytes, sim_avg, stats, 0,
+                      nullptr, nullptr, stream);
+}
+
+int pp_stage1_match_ex(const void* bank, int bank_dtype, const float* query, const float* mask, int mask_h,
+                       int mask_w, int B, int N, int C, int k, int mode, float eps, void* workspace,
+                       size_t workspace_bytes, float* sim_avg, float* out_score, int64_t* out_index,
+                       int32_t* stats, void* stream) {
+    if (!out_score || !out_index || k <= 0 || k > N || N > 12288) return PP_EINVAL;
+    // the last resolve workgroup of a crop ranks its scores in the 40 C bytes of LDS it owns; otherwise a top-k launch follows
+    const bool fused = (long long)N * 5 <= 40LL * C;
+    int rc = stage1_run(bank, bank_dtype, query, mask, mask_h, mask_w, B, N, C, mode, eps, workspace, workspace_bytes, sim_avg, stats,
+                        fused ? k : 0, out_score, out_index, stream);
+    if (rc != PP_OK || fused) return rc;
+    return pp_topk(sim_avg, B, N, k, out_score, out_index, stream);
 }
 
 int pp_stage1_scores(const float* bank, const float* query, const float* mask, int mask_h,
@@ -1086,10 +1212,8 @@ int pp_stage1_match(const float* bank, const float* query, const float* mask, in
                     int mask_w, int B, int N, int C, int k, int mode, float eps, void* workspace,
                     size_t workspace_bytes, float* sim_avg, float* out_score, int64_t* out_index,
                     int32_t* stats, void* stream) {
-    int rc = pp_stage1_scores(bank, query, mask, mask_h, mask_w, B, N, C, mode, eps, workspace,
-                              workspace_bytes, sim_avg, stats, stream);
-    if (rc != PP_OK) return rc;
-    return pp_topk(sim_avg, B, N, k, out_score, out_index, stream);
+    return pp_stage1_match_ex(bank, PP_BANK_F32, query, mask, mask_h, mask_w, B, N, C, k, mode, eps, workspace, workspace_bytes, sim_avg,
+                              out_score, out_index, stats, stream);
 }
 
 }  // extern "C"

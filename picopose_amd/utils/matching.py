@@ -87,8 +87,23 @@ def matching_templates(src_feats, tar_feat, src_masks, tar_mask, topk=5, mode=No
     `src_masks` is accepted and unused, exactly as in the reference.
     Returns (pred_score_src (B,topk) f32, pred_id_src (B,topk) i64).
     """
-    sim_avg = template_scores(src_feats, tar_feat, tar_mask, mode=mode)
-    return topk_templates(sim_avg, topk)
+    B, N, C = _check_inputs(src_feats, tar_feat, tar_mask)
+    if topk > N:
+        raise RuntimeError(f"selected index k out of range: topk={topk} > N={N}")
+    half = src_feats.dtype == torch.float16
+    bank = src_feats.contiguous() if half else src_feats.contiguous().float()
+    query, mask = tar_feat.contiguous().float(), tar_mask.contiguous().float()
+    ws, nbytes = _workspace(B, N, C, bank.device)
+    sim_avg = torch.empty(B, N, dtype=torch.float32, device=bank.device)
+    score = torch.empty(B, topk, dtype=torch.float32, device=bank.device)
+    index = torch.empty(B, topk, dtype=torch.int64, device=bank.device)
+    # scores + top-k as one ABI call (pp_stage1_match_ex: the last resolve workgroup of a crop ranks its scores)
+    rc = _lib.lib().pp_stage1_match_ex(
+        bank.data_ptr(), _lib.PP_BANK_F16 if half else _lib.PP_BANK_F32, query.data_ptr(), mask.data_ptr(), mask.shape[1],
+        mask.shape[2], B, N, C, int(topk), _MODES[mode or DEFAULT_MODE], 0.0, ws.data_ptr(), nbytes, sim_avg.data_ptr(),
+        score.data_ptr(), index.data_ptr(), None, _stream_ptr())
+    _lib.check(rc, "pp_stage1_match_ex")
+    return score, index
 
 
 def matching_features_similarity(src_feat, tar_feat, src_mask, tar_mask):

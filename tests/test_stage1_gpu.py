@@ -290,3 +290,25 @@ def test_half_precision_bank_full_size_and_golden(golden_dir):
         margin = om.decision_margins(bank.float(), query, mask)
         safe = margin > 1e-5
         assert (got - ref).abs()[safe].max().item() <= 1e-5 if safe.any() else True
+
+
+@gpu
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("B,N,C,half", [(8, 42, 384, False), (1, 4, 384, False), (5, 9, 768, False), (32, 162, 768, False), (3, 70, 1024, True)])
+def test_one_pass_match_equals_scores_then_topk(B, N, C, half, mode):
+    """matching_templates runs as ONE ABI call (pp_stage1_match_ex): small problems pre-pack the query in one launch (s1_qprep
+    recomputes the patch norms per workgroup in s1_qnorm's summation order) and the LAST resolve workgroup of a crop ranks the
+    crop's scores (agent-scope arrival counter) — no top-k launch.  The ids and scores must equal template_scores followed by
+    topk_templates (two query-pack launches, separate top-k launch) bit for bit, on every repeat (the arrival order of the resolve
+    workgroups differs from run to run), with the workspace reused between calls (the counters return to zero)."""
+    from picopose_amd.utils import matching as hm
+
+    bank, query, m = _inputs(B, N, C, 77 + B)
+    bank, query, m = (bank.cuda().half() if half else bank.cuda()), query.cuda(), m.cuda()
+    k = min(5, N)
+    sim = hm.template_scores(bank, query, m, mode=mode)
+    rs, ri = hm.topk_templates(sim, k)
+    for rep in range(8):
+        s, i = hm.matching_templates(bank, query, None, m, topk=k, mode=mode)
+        assert torch.equal(i, ri) and torch.equal(s, rs), (rep, i, ri)
+    torch.cuda.synchronize()
