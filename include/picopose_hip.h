@@ -117,10 +117,11 @@ int pp_stage1_match(const float* bank, const float* query, const float* mask,
                     float eps, void* workspace, size_t workspace_bytes,
                     float* sim_avg, float* out_score, int64_t* out_index,
                     int32_t* stats, void* stream);
-/* pp_stage1_match with the bank's storage type as an argument, as ONE pass: when the crop's N scores fit the resolve kernel's LDS
- * (5 N <= 40 C bytes — every BASELINE config) the LAST resolve workgroup of a crop to finish ranks the crop's scores itself
- * (agent-scope arrival counter in the workspace), so no separate top-k launch follows; small problems (B C^2 <= 2 M) also
- * pre-pack the query in one launch instead of two.  Same results as pp_stage1_scores_ex + pp_topk, bit for bit. */
+/* pp_stage1_match with the bank's storage type as an argument: one ABI call for scores + top-k.  Small problems
+ * (B C^2 <= 2 M: BASELINE configs[1]) pre-pack the query in one launch instead of two; N <= 1024 ranks with one wave per crop.
+ * (PP_S1_FUSE_TOPK=1: the last resolve workgroup of a crop ranks its scores itself through an agent-scope arrival counter in
+ * the workspace — measured slower than the second launch, kept as a switch.)  Same results as pp_stage1_scores_ex + pp_topk,
+ * bit for bit. */
 int pp_stage1_match_ex(const void* bank, int bank_dtype, const float* query, const float* mask,
                        int mask_h, int mask_w, int B, int N, int C, int k, int mode,
                        float eps, void* workspace, size_t workspace_bytes, float* sim_avg,

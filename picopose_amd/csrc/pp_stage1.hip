@@ -858,6 +858,46 @@ __device__ __forceinline__ void topk_block(const float* __restrict__ row, int N,
     }
 }
 
+// N <= 1024: one WAVE per crop — every lane keeps its N / 64 scores in registers, an iteration is one local scan + one wave
+// reduction, no barrier (the 256-thread form above spends 5.8 us on 8 rows of 42: five rounds of barriers on one workgroup)
+__global__ __launch_bounds__(256) void topk_rows_small(const float* __restrict__ scores, int B, int N, int k,
+                                                       float* __restrict__ out_score, int64_t* __restrict__ out_index) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    float v[16];
+    unsigned taken = 0u;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int j = lane + 64 * q;
+        v[q] = j < N ? scores[(size_t)b * N + j] : 0.f;
+        if (j >= N) taken |= 1u << q;
+    }
+    for (int it = 0; it < k; ++it) {
+        float bv = 0.f;
+        int bi = -1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (!((taken >> q) & 1u) && topk_better(v[q], lane + 64 * q, bv, bi)) {
+                bv = v[q];
+                bi = lane + 64 * q;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (oi >= 0 && topk_better(ov, oi, bv, bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            out_score[(size_t)b * k + it] = bv;
+            out_index[(size_t)b * k + it] = bi;
+        }
+        if (bi >= 0 && (bi & 63) == lane) taken |= 1u << (bi >> 6);
+    }
+}
+
 __global__ __launch_bounds__(256) void topk_rows(const float* __restrict__ scores, int N, int k,
                                                  float* __restrict__ out_score,
                                                  int64_t* __restrict__ out_index) {
@@ -1184,8 +1224,12 @@ int pp_stage1_match_ex(const void* bank, int bank_dtype, const float* query, con
                        size_t workspace_bytes, float* sim_avg, float* out_score, int64_t* out_index,
                        int32_t* stats, void* stream) {
     if (!out_score || !out_index || k <= 0 || k > N || N > 12288) return PP_EINVAL;
-    // the last resolve workgroup of a crop ranks its scores in the 40 C bytes of LDS it owns; otherwise a top-k launch follows
-    const bool fused = (long long)N * 5 <= 40LL * C;
+    // The last resolve workgroup of a crop CAN rank its scores itself (s1_resolve's topk_k argument, 5 N <= 40 C bytes of LDS):
+    // measured slower than a second launch at BASELINE configs[1] — the agent-scope release / acquire of every resolve workgroup
+    // (buffer_wbl2 + buffer_inv, ~3.5 us each, MI355X_MICROARCH.md) and the serial ranking at the end of the kernel cost 12 us
+    // against the 7.7 us of a top-k launch and its gap (profiles/r04/stage1_small.txt).  PP_S1_FUSE_TOPK=1 switches it on.
+    static const bool fuse_env = [] { const char* e = getenv("PP_S1_FUSE_TOPK"); return e && e[0] == '1'; }();
+    const bool fused = fuse_env && (long long)N * 5 <= 40LL * C;
     int rc = stage1_run(bank, bank_dtype, query, mask, mask_h, mask_w, B, N, C, mode, eps, workspace, workspace_bytes, sim_avg, stats,
                         fused ? k : 0, out_score, out_index, stream);
     if (rc != PP_OK || fused) return rc;
@@ -1203,8 +1247,11 @@ int pp_topk(const float* scores, int B, int N, int k, float* out_score, int64_t*
             void* stream_) {
     if (!scores || !out_score || !out_index) return PP_EINVAL;
     if (B <= 0 || N <= 0 || k <= 0 || k > N || N > 12288) return PP_EINVAL;
-    hipLaunchKernelGGL(topk_rows, dim3(B), dim3(256), N * 5, (hipStream_t)stream_,
-                       scores, N, k, out_score, out_index);
+    if (N <= 1024)
+        hipLaunchKernelGGL(topk_rows_small, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream_, scores, B, N, k, out_score, out_index);
+    else
+        hipLaunchKernelGGL(topk_rows, dim3(B), dim3(256), N * 5, (hipStream_t)stream_,
+                           scores, N, k, out_score, out_index);
     return pp_last_launch();
 }
 

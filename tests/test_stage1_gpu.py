@@ -312,3 +312,20 @@ def test_one_pass_match_equals_scores_then_topk(B, N, C, half, mode):
         s, i = hm.matching_templates(bank, query, None, m, topk=k, mode=mode)
         assert torch.equal(i, ri) and torch.equal(s, rs), (rep, i, ri)
     torch.cuda.synchronize()
+
+
+@gpu
+def test_one_pass_match_with_the_top_k_inside_the_resolve_kernel(monkeypatch):
+    """PP_S1_FUSE_TOPK=1 (off by default: slower): the arrival-counter form gives the same ids and scores, repeat after repeat."""
+    import subprocess
+    import sys
+
+    code = ("import torch; from picopose_amd.utils import matching as hm; g = torch.Generator().manual_seed(5); "
+            "bank = torch.randn(8, 42, 384, 16, 16, generator=g).cuda(); q = torch.randn(8, 384, 16, 16, generator=g).cuda(); "
+            "m = (torch.rand(8, 224, 224, generator=g) < 0.7).float().cuda(); sim = hm.template_scores(bank, q, m); rs, ri = hm.topk_templates(sim, 5); "
+            "ok = all(torch.equal(hm.matching_templates(bank, q, None, m, topk=5)[1], ri) for _ in range(20)); print('FUSED OK' if ok else 'FUSED DIFFERS')")
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PP_S1_FUSE_TOPK="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and "FUSED OK" in r.stdout.decode(), r.stdout.decode()[-1500:]
