@@ -117,11 +117,12 @@ int pp_stage1_match(const float* bank, const float* query, const float* mask,
                     float eps, void* workspace, size_t workspace_bytes,
                     float* sim_avg, float* out_score, int64_t* out_index,
                     int32_t* stats, void* stream);
-/* pp_stage1_match with the bank's storage type as an argument: one ABI call for scores + top-k.  Small problems
- * (B C^2 <= 2 M: BASELINE configs[1]) pre-pack the query in one launch instead of two; N <= 1024 ranks with one wave per crop.
- * (PP_S1_FUSE_TOPK=1: the last resolve workgroup of a crop ranks its scores itself through an agent-scope arrival counter in
- * the workspace — measured slower than the second launch, kept as a switch.)  Same results as pp_stage1_scores_ex + pp_topk,
- * bit for bit. */
+/* pp_stage1_match with the bank's storage type as an argument: one ABI call for scores + top-k (the host mirror's
+ * matching_templates).  With fewer than two (crop, template) items per CU the main kernel runs its 4-wave shape on template
+ * halves (shorter tail round: BASELINE configs[1] 73.2 -> 68.7 us per call).  Three launch fusions were built, measured SLOWER at
+ * configs[1] and are off by default (profiles/r04/stage1_small.txt): PP_S1_QPREP=1 (query pre-pack as one launch),
+ * PP_S1_TOPK_SMALL=1 (one wave per crop), PP_S1_FUSE_TOPK=1 (the last resolve workgroup of a crop ranks its scores through an
+ * agent-scope arrival counter).  Same results as pp_stage1_scores_ex + pp_topk, bit for bit, in every form. */
 int pp_stage1_match_ex(const void* bank, int bank_dtype, const float* query, const float* mask,
                        int mask_h, int mask_w, int B, int N, int C, int k, int mode,
                        float eps, void* workspace, size_t workspace_bytes, float* sim_avg,

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void s1_qpack(const float* __restrict__ query,
 }
 
 // s1_qprep = s1_qnorm + s1_qpack in ONE launch for small problems (BASELINE configs[1]: 8 crops, C = 384 — there the two
-// launches and the gap between them were 12 of the call's 70 us): every (crop, 32-channel slice) workgroup recomputes the
+// launches and the gap between them were 12 of the call's 70 us; tried in round 4, measured slower, kept behind PP_S1_QPREP=1): every (crop, 32-channel slice) workgroup recomputes the
 // crop's 256 patch norms itself (the crop's C x 256 floats come from L2; B C^2 32 bytes in total, so only for small B C^2)
 // in EXACTLY s1_qnorm's summation order — 16 partial sums over the channels of one residue class mod 16, ascending, then
 // their sum in class order — so `denom` and everything packed from it keep their bits.  Block (0, 0) also zeroes the
@@ -1144,7 +1144,10 @@ static int stage1_run(const void* bank_, int bank_dtype, const float* query, con
 
     const int cus = pp_cu_count();
     // small problems (B C^2 32 bytes of L2 re-reads <= 64 MB: BASELINE configs[1]): the query pre-pack as ONE launch
-    if ((long long)B * C * C * 32 <= (64LL << 20)) {
+    // (measured SLOWER than the two launches at configs[1] — 71.0 vs 68.7 us per call, A/B on one box, profiles/r04/stage1_small.txt:
+    // the norms recomputed per workgroup cost more than the launch they save — so off unless PP_S1_QPREP=1)
+    static const bool qprep_on = [] { const char* e = getenv("PP_S1_QPREP"); return e && e[0] == '1'; }();
+    if (qprep_on && (long long)B * C * C * 32 <= (64LL << 20)) {
         hipLaunchKernelGGL(s1_qprep, dim3(B, C / 32), dim3(256), 0, stream, query, mask, mask_h, mask_w, C, w.denom, w.m16, w.qh,
                            w.qf, topk_k > 0 ? w.counters : nullptr, B);
     } else {
@@ -1247,7 +1250,10 @@ int pp_topk(const float* scores, int B, int N, int k, float* out_score, int64_t*
             void* stream_) {
     if (!scores || !out_score || !out_index) return PP_EINVAL;
     if (B <= 0 || N <= 0 || k <= 0 || k > N || N > 12288) return PP_EINVAL;
-    if (N <= 1024)
+    // (one wave per crop: measured 0.8 us SLOWER per call than the 256-thread form at configs[1] — both sit on the ~6 us floor
+    // of a dependent tiny launch; off unless PP_S1_TOPK_SMALL=1)
+    static const bool small_on = [] { const char* e = getenv("PP_S1_TOPK_SMALL"); return e && e[0] == '1'; }();
+    if (small_on && N <= 1024)
         hipLaunchKernelGGL(topk_rows_small, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream_, scores, B, N, k, out_score, out_index);
     else
         hipLaunchKernelGGL(topk_rows, dim3(B), dim3(256), N * 5, (hipStream_t)stream_,

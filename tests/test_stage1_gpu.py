@@ -296,11 +296,9 @@ def test_half_precision_bank_full_size_and_golden(golden_dir):
 @pytest.mark.parametrize("mode", ["exact", "fast"])
 @pytest.mark.parametrize("B,N,C,half", [(8, 42, 384, False), (1, 4, 384, False), (5, 9, 768, False), (32, 162, 768, False), (3, 70, 1024, True)])
 def test_one_pass_match_equals_scores_then_topk(B, N, C, half, mode):
-    """matching_templates runs as ONE ABI call (pp_stage1_match_ex): small problems pre-pack the query in one launch (s1_qprep
-    recomputes the patch norms per workgroup in s1_qnorm's summation order) and the LAST resolve workgroup of a crop ranks the
-    crop's scores (agent-scope arrival counter) — no top-k launch.  The ids and scores must equal template_scores followed by
-    topk_templates (two query-pack launches, separate top-k launch) bit for bit, on every repeat (the arrival order of the resolve
-    workgroups differs from run to run), with the workspace reused between calls (the counters return to zero)."""
+    """matching_templates runs as ONE ABI call (pp_stage1_match_ex; with fewer than two items per CU on the 4-wave workgroup
+    shape).  The ids and scores must equal template_scores followed by topk_templates bit for bit, on every repeat, with the
+    workspace reused between calls."""
     from picopose_amd.utils import matching as hm
 
     bank, query, m = _inputs(B, N, C, 77 + B)
@@ -315,8 +313,9 @@ def test_one_pass_match_equals_scores_then_topk(B, N, C, half, mode):
 
 
 @gpu
-def test_one_pass_match_with_the_top_k_inside_the_resolve_kernel(monkeypatch):
-    """PP_S1_FUSE_TOPK=1 (off by default: slower): the arrival-counter form gives the same ids and scores, repeat after repeat."""
+def test_one_pass_match_with_the_optional_launch_fusions(monkeypatch):
+    """PP_S1_FUSE_TOPK=1 PP_S1_QPREP=1 PP_S1_TOPK_SMALL=1 (all off by default: measured slower, profiles/r04/stage1_small.txt): the
+    arrival-counter top-k, the one-launch query pre-pack and the one-wave top-k give the same ids and scores, repeat after repeat."""
     import subprocess
     import sys
 
@@ -327,5 +326,5 @@ def test_one_pass_match_with_the_top_k_inside_the_resolve_kernel(monkeypatch):
     import os
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PP_S1_FUSE_TOPK="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PP_S1_FUSE_TOPK="1", PP_S1_QPREP="1", PP_S1_TOPK_SMALL="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and "FUSED OK" in r.stdout.decode(), r.stdout.decode()[-1500:]
