@@ -228,6 +228,8 @@ typedef struct PpGemmDesc {
     void* C_hl;            /* optional: ALSO (or, with C == NULL, only) write the output as an hl operand */
     int ldc_h;             /* [M][ldc_h] for the next GEMM (no pixel shuffle, no batch); ldc_h % 8 == 0  */
     int c_relu;            /* C_hl holds split(max(out, 0)): the consumer's input ReLU folded in        */
+    const float* alpha_dev;  /* optional DEVICE scalars: alpha is multiplied by alpha_dev[0] (and alpha_dev2[0]) when the kernel   */
+    const float* alpha_dev2; /* runs — the inverse range scales of backward operands, chosen on the device (pp_pow2_scale_ws)      */
 } PpGemmDesc;
 
 int pp_gemm(const PpGemmDesc* desc, void* stream);
@@ -242,6 +244,20 @@ int pp_split_activation(const float* x, long long batch_stride, int B, int P, in
  * group: a multiple of 8 columns into the row): the channel concatenation of operands without an fp32 concat buffer. */
 int pp_split_activation_ld(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu,
                            void* hl, int ld_h, void* stream);
+/* Backward-product operands (picopose_amd/autograd.py): gradients span 1e-9 .. 1, so an operand is multiplied by a power of two chosen
+ * on the DEVICE from its max before it is split, and the product is scaled back through PpGemmDesc.alpha_dev — no host sync, and
+ * (round 4) no separate scaling / transposing passes:
+ *   pp_pow2_scale_ws   scale2[0] = 2^k with max|2^k x| in [512, 1024), scale2[1] = 2^-k; partials: >= 1024 floats of scratch
+ *                      (two launches: per-workgroup maxima, one fold — no atomics, no init launch);
+ *   pp_split_scaled_t  x (rows, C) fp32 with row pitch ld -> contiguous operand (rows, C) of scale[0] * x;
+ *   pp_split_transpose_t  x (rows, cols) fp32 with row pitch ld -> contiguous operand (cols, rows) of scale[0] * x^T (scale NULL = 1;
+ *                      rows % 8 == 0): the K-major operands of dW = dz^T x in ONE pass instead of scale copy + transposed copy + split. */
+int pp_pow2_scale_ws(const float* x, long long n, float* scale2, float* partials, void* stream);
+int pp_split_scaled_t(const float* x, long long rows, int ld, int C, const float* scale, void* out, int terms, void* stream);
+int pp_split_transpose_t(const float* x, long long rows, int cols, int ld, const float* scale, void* out, int terms, void* stream);
+/* The K-major im2col of an NHWC image (pp_im2col_t_nhwc below) written straight as the engine operand: (ksize^2 C) operand rows with
+ * K = B Ho Wo pixels (a multiple of 8) — the B operand of a convolution's weight gradient dW = dz^T colT without the fp32 matrix. */
+int pp_im2col_t_operand(const float* x, int B, int H, int W, int C, int ksize, int stride, int pad, void* out, int terms, void* stream);
 /* Second half of a split-K linear layer (a few rows against a long K — stage 2's fc1, affine_regressor.py:77: 160 x 16384 x
  * 1024 fills 8 workgroups as one GEMM): part (S, M, N) fp32 = the S K-slices' products from one batched pp_gemm;
  * out[m, n] = act(sum_s part[s, m, n] + bias[n]), slices added in index order. */

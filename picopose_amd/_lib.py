@@ -38,6 +38,7 @@ class PpGemmDesc(ctypes.Structure):
         ("prec", ctypes.c_int), ("B_hl", ctypes.c_void_p), ("b_scale", ctypes.c_float), ("A_hl", ctypes.c_void_p),
         ("a_hl_bytes", ctypes.c_longlong), ("b_hl_bytes", ctypes.c_longlong),
         ("C_hl", ctypes.c_void_p), ("ldc_h", ctypes.c_int), ("c_relu", ctypes.c_int),
+        ("alpha_dev", ctypes.c_void_p), ("alpha_dev2", ctypes.c_void_p),
     ]
 
 
@@ -160,6 +161,10 @@ def lib():
         L.pp_simvol_backward.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
         L.pp_im2col_t_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
         L.pp_pow2_scale.argtypes = [vp, ll, vp, vp]
+        L.pp_pow2_scale_ws.argtypes = [vp, ll, vp, vp, vp]
+        L.pp_split_scaled_t.argtypes = [vp, ll, i32, i32, vp, vp, i32, vp]
+        L.pp_split_transpose_t.argtypes = [vp, ll, i32, i32, vp, vp, i32, vp]
+        L.pp_im2col_t_operand.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
         L.pp_split_with_scale_t.argtypes = [vp, ll, i32, vp, vp, vp]
         L.pp_batchnorm_train_backward_workspace_bytes.restype = sz
         L.pp_batchnorm_train_backward_workspace_bytes.argtypes = [ll, i32]

@@ -58,9 +58,9 @@ def _pow2_scale(t):
     4 x as two fp16 terms (full 22 bits only above ~3e-5) — backward products are taken on range-normalised copies and scaled
     back, exactly (powers of two).  One reduction on the device (pp_pow2_scale), no host sync; the scale never enters a value
     except through rounding."""
-    s2 = torch.empty(2, dtype=torch.float32, device=t.device)
-    _lib.check(_lib.lib().pp_pow2_scale(_p(t), t.numel(), _p(s2), _lib.stream_ptr()), "pp_pow2_scale")
-    return s2
+    buf = torch.empty(2 + 1024, dtype=torch.float32, device=t.device)      # (scale, inverse | per-workgroup maxima)
+    _lib.check(_lib.lib().pp_pow2_scale_ws(_p(t), t.numel(), _p(buf), _p(buf[2:]), _lib.stream_ptr()), "pp_pow2_scale_ws")
+    return buf[:2]
 
 
 def _ranged(t, on=True):
@@ -82,6 +82,30 @@ def _unscale(out, sa, sb, target=None):
         target.copy_(out)
         return target
     return out
+
+
+def _scale_of(t, on=True):
+    """Device scale pair of a backward operand WITHOUT a scaled copy (None: fp32 engine, or a forward quantity that is in range as
+    it is) — for the products whose operands are split with the scale applied (ops.split_scaled / split_transposed)."""
+    return None if (ops.PRECISION == "f32" or not on) else _pow2_scale(t.contiguous() if not t.is_contiguous() else t)
+
+
+def _inv(*scales):
+    return [s[1:2] for s in scales if s is not None]
+
+
+def _mm_tn(a, b, ra=True, rb=True, sa=None):
+    """a^T @ b for a (R, M), b (R, N) — the weight-gradient form (R = the rows of the batch is the K axis).  On the pre-split engine both
+    operands are produced K-major in ONE pass each (scale applied, transposed, split: ops.split_transposed) and the inverse scales ride
+    in the launch (alpha_dev): no scaled copy, no transposed copy, no unscale pass.  sa: the scale pair of `a` if the caller has it."""
+    R, M = a.shape
+    N = b.shape[1]
+    tiles = -(-M // 128) * -(-N // 128)
+    if ops.operands_ok(M, N, R) and tiles > 24 and a.stride(1) == 1 and b.stride(1) == 1:
+        sa = sa if sa is not None else _scale_of(a, ra)
+        sb = _scale_of(b, rb)
+        return ops.matmul_operands(ops.split_transposed(a, sa), ops.split_transposed(b, sb), alpha_dev=_inv(sa, sb))
+    return _mm(a.t().contiguous(), b, ra=ra, rb=rb)
 
 
 def bmm_nn_b(a, b, out=None, alpha=1.0, ra=True, rb=True):
@@ -121,10 +145,11 @@ def _mm(a, b, alpha=1.0, out=None, ra=True, rb=True):
         r = torch.empty(M, N, dtype=torch.float32, device=a.device)
         _lib.check(_lib.lib().pp_sum_slices(_p(part), S, M, N, None, 0, _p(r), _lib.stream_ptr()), "pp_sum_slices")
         return _unscale(r, sa, sb, out)
-    if ops.PRECISION == "f16x3" and alpha == 1.0 and K % 8 == 0 and M >= 64 and N >= 64 and M * N * K >= 1 << 24:
-        a2, sa = _ranged(a, ra)
-        b2, sb = _ranged(b, rb)
-        return _unscale(ops.matmul_nt_presplit(a2.contiguous(), b2.t().contiguous()), sa, sb, out)
+    if alpha == 1.0 and ops.operands_ok(M, N, K) and M * N * K >= 1 << 24 and a.stride(1) == 1 and b.stride(1) == 1:
+        # both operands split with their range scale applied (b: transposed in the same pass), the inverse scales in the launch
+        sa, sb = _scale_of(a, ra), _scale_of(b, rb)
+        A = ops.split_scaled(a, sa) if sa is not None else ops.Split(ops.split_activation(a, 1, M, K, 0, a.stride(0)))
+        return ops.matmul_operands(A, ops.split_transposed(b, sb), alpha_dev=_inv(sa, sb), out=out)
     r = bmm_nn_b(a[None, None], b[None, None], None if out is None else out[None, None], alpha=alpha, ra=ra, rb=rb)
     return r[0, 0]
 
@@ -162,7 +187,7 @@ class _Linear(torch.autograd.Function):
         else:
             dz = dy
         dx = _mm(dz, w, rb=False) if ctx.needs_input_grad[0] else None                       # (weights / activations: forward quantities)
-        dw = _mm(dz.t().contiguous(), x, rb=False) if ctx.needs_input_grad[1] else None
+        dw = _mm_tn(dz, x, rb=False) if ctx.needs_input_grad[1] else None
         db = colsum(dz) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None
 
@@ -719,25 +744,45 @@ class _Conv2d(torch.autograd.Function):
             g = torch.empty_like(dz)
             _lib.check(_lib.lib().pp_act_backward(_p(y), _p(dz), dz.numel(), ACT[act], _p(g), _lib.stream_ptr()), "pp_act_backward")
             dz = g                                                        # relu'(z) = [y > 0]
-        dzs, s = _ranged(dz)                                              # the gradient operand of both products
+        rows = B * H * W
+        s = _scale_of(dz)                                                 # the gradient operand of both products: ONE scale
+        fused = s is not None and Cout % 8 == 0 and rows % 8 == 0 and rows * Cout < 2 ** 30
+        dzs = None
+        if not fused:
+            dzs, s = _ranged(dz)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wf = w.flip(2, 3).permute(1, 0, 2, 3)                         # (Cin, Cout, k, k): dx = conv(dz, flipped weights)
             if Cx > Cin:
                 wf = torch.cat([wf, wf.new_zeros(Cx - Cin, Cout, k, k)], dim=0)
-            dx = ops.conv2d(dzs, ops.pack_conv_weight(wf.contiguous()), None, k, pad=k // 2, cache_weight=(ctx.owner, "flip"))
-            dx = _unscale(dx, s, None)
-        if ctx.needs_input_grad[1]:
-            rows = B * H * W
-            colT = torch.empty(k * k * Cx, rows, dtype=torch.float32, device=x.device)
-            _lib.check(_lib.lib().pp_im2col_t_nhwc(_p(x), B, H, W, Cx, k, 1, k // 2, _p(colT), _lib.stream_ptr()), "pp_im2col_t_nhwc")
-            dzt = dzs.view(rows, Cout).t().contiguous()                   # (Cout, rows)
-            tiles = -(-Cout // 128) * -(-(k * k * Cx) // 128)
-            if ops.PRECISION == "f16x3" and Cout >= 64 and tiles > 24 and rows % 8 == 0:
-                dwp = ops.matmul_nt_presplit(dzt, colT)                   # x is a forward activation: in range as it is
+            wfp = ops.pack_conv_weight(wf.contiguous())
+            if fused:     # dz split with its range scale applied (no scaled copy), the inverse scale inside the launch (no unscale pass)
+                dz_op = ops.split_scaled(dz.view(rows, Cout), s)
+                dz_op.image = (B, H, W)
+                dx = ops.conv2d(dz_op, wfp, None, k, pad=k // 2, cache_weight=(ctx.owner, "flip"), alpha_dev=_inv(s))
             else:
-                dwp = _mm_kmajor(dzt, colT)
-            dwp = _unscale(dwp, s, None)                                  # (Cout, k k Cx)
+                dx = ops.conv2d(dzs, wfp, None, k, pad=k // 2, cache_weight=(ctx.owner, "flip"))
+                dx = _unscale(dx, s, None)
+        if ctx.needs_input_grad[1]:
+            tiles = -(-Cout // 128) * -(-(k * k * Cx) // 128)
+            if fused and tiles > 24 and ops.operands_ok(Cout, k * k * Cx, rows):
+                # dz^T as the K-major A operand in one pass (scale, transpose, split); the K-major im2col of x straight as the B
+                # operand (x is a forward activation: in range as it is) — no fp32 im2col matrix, no split pass over it
+                A = ops.split_transposed(dz.view(rows, Cout), s)
+                Bt = ops.Split.empty(k * k * Cx, rows, x.device)
+                _lib.check(_lib.lib().pp_im2col_t_operand(_p(x), B, H, W, Cx, k, 1, k // 2, _p(Bt.hl), Bt.terms, _lib.stream_ptr()), "pp_im2col_t_operand")
+                dwp = ops.matmul_operands(A, Bt, alpha_dev=_inv(s))
+            else:
+                colT = torch.empty(k * k * Cx, rows, dtype=torch.float32, device=x.device)
+                _lib.check(_lib.lib().pp_im2col_t_nhwc(_p(x), B, H, W, Cx, k, 1, k // 2, _p(colT), _lib.stream_ptr()), "pp_im2col_t_nhwc")
+                if dzs is None:
+                    dzs = _ew(1, dz, s[0:1], 1)
+                dzt = dzs.view(rows, Cout).t().contiguous()                   # (Cout, rows)
+                if ops.PRECISION == "f16x3" and Cout >= 64 and tiles > 24 and rows % 8 == 0:
+                    dwp = ops.matmul_nt_presplit(dzt, colT)                   # x is a forward activation: in range as it is
+                else:
+                    dwp = _mm_kmajor(dzt, colT)
+                dwp = _unscale(dwp, s, None)                                  # (Cout, k k Cx)
             dw = dwp.view(Cout, k, k, Cx)[..., :Cin].permute(0, 3, 1, 2).contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             db = colsum(dz.view(-1, Cout))

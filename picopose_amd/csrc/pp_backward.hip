@@ -13,6 +13,7 @@
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -35,6 +36,46 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     float s = 0.f;
     for (int k = 0; k < slabs; ++k) s += part[(size_t)k * cols + c];
     out[c] = s;
+}
+
+// the same with 16-byte loads: a thread owns 4 consecutive columns and one of 4 row lanes of its slab (rows rl, rl + 4, ... with
+// four rows in flight), the row lanes are added in lane order through LDS.  cols % 4 == 0, ld % 4 == 0, 16-byte aligned x.
+__global__ __launch_bounds__(256) void colsum_part4_kernel(const float* __restrict__ x, long long rows, int cols, int ld, int per, float* __restrict__ part) {
+    __shared__ f4 red[4][64];
+    const int q = threadIdx.x & 63, rl = threadIdx.x >> 6, c = (blockIdx.x * 64 + q) * 4;
+    const long long r0 = (long long)per * blockIdx.y, r1 = r0 + per < rows ? r0 + per : rows;
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+        long long r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            const f4 a = *(const f4*)(x + r * ld + c), b = *(const f4*)(x + (r + 4) * ld + c);
+            const f4 e = *(const f4*)(x + (r + 8) * ld + c), g = *(const f4*)(x + (r + 12) * ld + c);
+            s += a;
+            s += b;
+            s += e;
+            s += g;
+        }
+        for (; r < r1; r += 4) s += *(const f4*)(x + r * ld + c);
+    }
+    red[rl][q] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        const f4 t = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+        *(f4*)(part + (size_t)blockIdx.y * cols + c) = t;
+    }
+}
+
+// fold of the slabs with four slab lanes per column (slabs sl, sl + 4, ... each, then the lanes in order): the one-thread-per-column
+// form above walks up to 512 dependent-latency loads on a single workgroup when the matrix is 256 columns wide
+__global__ __launch_bounds__(256) void colsum_final4_kernel(const float* __restrict__ part, int slabs, int cols, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int q = threadIdx.x & 63, sl = threadIdx.x >> 6, c = blockIdx.x * 64 + q;
+    float s = 0.f;
+    if (c < cols)
+        for (int k = sl; k < slabs; k += 4) s += part[(size_t)k * cols + c];
+    red[sl][q] = s;
+    __syncthreads();
+    if (sl == 0 && c < cols) out[c] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
 }
 
 __device__ __forceinline__ float act_fwd(float z, int act) {
@@ -337,17 +378,127 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__
     }
 }
 
+// x (rows, cols) fp32, row stride ld -> the engine operand of s x^T: `cols` operand rows with K = rows (hl: [cols][rows / 8][2][8]
+// halfs; h: [cols][rows]), s = scale[0] (a device scalar, null = 1) x the operand scale 4.  One pass instead of three (scale copy,
+// transposed copy, split) for the K-major operands of the backward products (dW = dz^T x: both dz and x are read "down the rows").
+// A 64 (rows) x 32 (cols) tile goes through LDS; a thread then owns 8 consecutive rows of one column = one 32-byte operand group.
+template <int TERMS>
+__global__ __launch_bounds__(256) void split_transpose_kernel(const float* __restrict__ x, long long rows, int cols, int ld, const float* __restrict__ scale,
+                                                              _Float16* __restrict__ out) {
+    __shared__ float tile[64][33];
+    const long long r0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8
+    const float s = (scale ? scale[0] : 1.f) * PP_A_SCALE;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long r = r0 + ty + 8 * j;
+        tile[ty + 8 * j][tx] = (r < rows && c0 + tx < cols) ? x[r * ld + c0 + tx] * s : 0.f;
+    }
+    __syncthreads();
+    const int c = threadIdx.x >> 3, g = threadIdx.x & 7;       // column of the tile, group of 8 rows
+    if (c0 + c < cols && r0 + 8 * g < rows) {                  // (rows % 8 == 0: a group is in or out as a whole)
+        h8 hh, ll;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = tile[8 * g + k][c];
+            const _Float16 h = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+            hh[k] = h;
+            ll[k] = (_Float16)fminf(fmaxf(v - (float)h, -65504.f), 65504.f);
+        }
+        _Float16* o = out + ((long long)(c0 + c) * rows + r0 + 8 * g) * TERMS;
+        *(h8*)o = hh;
+        if (TERMS == 2) *(h8*)(o + 8) = ll;
+    }
+}
+
+// im2col_t_kernel writing the ENGINE OPERAND of colT directly (operand row = (tap, channel), K = the pixels of the batch, groups of 8
+// pixels): the fp32 K-major matrix (k k C x rows x 4 bytes: 15 GB for the 640-channel decoder input at 64 x 64 x 160) is never
+// stored or re-read by a split pass.  A 64 (pixels) x 32 (channels) tile per tap goes through LDS.
+template <int TERMS>
+__global__ __launch_bounds__(256) void im2col_t_operand_kernel(const float* __restrict__ x, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo,
+                                                               long long rows, _Float16* __restrict__ out) {
+    __shared__ float tile[64][33];
+    const int tap = blockIdx.z, ky = tap / k, kx = tap - ky * k;
+    const long long r0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long row = r0 + ty + 8 * j;
+        const int c = c0 + tx;
+        float v = 0.f;
+        if (row < rows && c < C) {
+            const int ox = (int)(row % Wo), oy = (int)((row / Wo) % Ho);
+            const long long b = row / ((long long)Wo * Ho);
+            const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((b * H + iy) * W + ix) * C + c] * PP_A_SCALE;
+        }
+        tile[ty + 8 * j][tx] = v;
+    }
+    __syncthreads();
+    const int c = threadIdx.x >> 3, g = threadIdx.x & 7;
+    if (c0 + c < C && r0 + 8 * g < rows) {
+        h8 hh, ll;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float v = tile[8 * g + q][c];
+            const _Float16 h = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+            hh[q] = h;
+            ll[q] = (_Float16)fminf(fmaxf(v - (float)h, -65504.f), 65504.f);
+        }
+        _Float16* o = out + (((long long)tap * C + c0 + c) * rows + r0 + 8 * g) * TERMS;
+        *(h8*)o = hh;
+        if (TERMS == 2) *(h8*)(o + 8) = ll;
+    }
+}
+
 extern "C" {
 
-size_t pp_colsum_workspace_bytes(long long rows, int cols) {
-    const int slabs = rows < 64 ? 1 : (rows < 4096 ? 16 : 128);
-    return (size_t)slabs * cols * sizeof(float);
+int pp_im2col_t_operand(const float* x, int B, int H, int W, int C, int ksize, int stride, int pad, void* out, int terms, void* stream) {
+    if (!x || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || (terms != 1 && terms != 2) || ((uintptr_t)out & 15) != 0)
+        return PP_EINVAL;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const long long rows = (long long)B * Ho * Wo;
+    if (rows % 8 != 0 || (C + 31) / 32 > 65535 || ksize * ksize > 65535) return PP_EINVAL;
+    const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((C + 31) / 32), (unsigned)(ksize * ksize));
+    if (terms == 2)
+        hipLaunchKernelGGL(im2col_t_operand_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, C, ksize, stride, pad, Ho, Wo, rows, (_Float16*)out);
+    else
+        hipLaunchKernelGGL(im2col_t_operand_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, C, ksize, stride, pad, Ho, Wo, rows, (_Float16*)out);
+    return pp_last_launch();
 }
+
+int pp_split_transpose_t(const float* x, long long rows, int cols, int ld, const float* scale, void* out, int terms, void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0 || ld < cols || rows % 8 != 0 || (terms != 1 && terms != 2) || ((uintptr_t)out & 15) != 0) return PP_EINVAL;
+    const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((cols + 31) / 32));
+    if (grid.y > 65535) return PP_EINVAL;
+    if (terms == 2) hipLaunchKernelGGL(split_transpose_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, scale, (_Float16*)out);
+    else hipLaunchKernelGGL(split_transpose_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, scale, (_Float16*)out);
+    return pp_last_launch();
+}
+
+// slabs of at least 64 rows, enough of them to fill the chip whatever the width (a 256-column matrix is ONE column block: the
+// slab count is all its parallelism), at most 2048; a function of the shape only, so the summation order is fixed
+static int colsum_slabs(long long rows, int cols) {
+    if (rows < 64) return 1;
+    const long long want = 2048 / ((cols + 255) / 256) + 1, cap = rows / 64;
+    long long s = want < cap ? want : cap;
+    return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
+}
+
+size_t pp_colsum_workspace_bytes(long long rows, int cols) { return (size_t)colsum_slabs(rows, cols) * cols * sizeof(float); }
 
 int pp_colsum(const float* x, long long rows, int cols, int ld, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !out || !workspace || rows <= 0 || cols <= 0 || ld < cols) return PP_EINVAL;
-    const int slabs = rows < 64 ? 1 : (rows < 4096 ? 16 : 128);
+    const int slabs = colsum_slabs(rows, cols);
     if (workspace_bytes < (size_t)slabs * cols * sizeof(float)) return PP_EWORKSPACE;
+    if (cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0) {
+        const int per = (int)((rows + slabs - 1) / slabs);
+        hipLaunchKernelGGL(colsum_part4_kernel, dim3((cols + 255) / 256, slabs), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, per, (float*)workspace);
+        hipLaunchKernelGGL(colsum_final4_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, slabs, cols, out);
+        return pp_last_launch();
+    }
     hipLaunchKernelGGL(colsum_part_kernel, dim3((cols + 255) / 256, slabs), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, (float*)workspace);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, slabs, cols, out);
     return pp_last_launch();

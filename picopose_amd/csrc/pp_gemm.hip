@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(const PpGemmDesc d) {
     }
 
     // ---- epilogue: out = residual + residual2 + gamma * act(alpha * acc + bias)
+    const float alpha_ = pp_alpha(d);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + wc * 32 * NJ + j * 32 + l31;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(const PpGemmDesc d) {
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (m >= d.M) continue;
-                float v = act_apply(acc[i][j][e] * d.alpha + bias, d.act) * gamma;
+                float v = act_apply(acc[i][j][e] * alpha_ + bias, d.act) * gamma;
                 epilogue_store(d, C, R, R2, m, n, v);
             }
     }
@@ -508,6 +509,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const PpGemmDesc d
             for (int r = 0; r < 16; ++r) acc[i][j][r] *= descale;
 
     // ---- epilogue: out = residual + residual2 + gamma * act(alpha * acc + bias)
+    const float alpha_ = pp_alpha(d);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + wc * 32 * NJ + j * 32 + l31;
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16x3_kernel(const PpGemmDesc d
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (m >= d.M) continue;
-                float v = act_apply(acc[i][j][e] * d.alpha + bias, d.act) * gamma;
+                float v = act_apply(acc[i][j][e] * alpha_ + bias, d.act) * gamma;
                 epilogue_store(d, C, R, R2, m, n, v);
             }
     }
@@ -818,6 +820,44 @@ __global__ void absmax_finish_kernel(float* __restrict__ scale, int with_inverse
     if (with_inverse) scale[1] = ldexpf(1.f, -e);
 }
 
+// two launches, no atomics, 16-byte loads: every workgroup leaves its maximum in partial[blockIdx.x], one workgroup folds them
+__global__ __launch_bounds__(256) void absmax_part_kernel(const float* __restrict__ w, long long n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float m = 0.f;
+    const long long n4 = ((uintptr_t)w & 15) == 0 ? n >> 2 : 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f4 v = ((const f4*)w)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));   // (fmaxf drops a NaN operand)
+}
+
+__global__ __launch_bounds__(256) void absmax_fold_kernel(const float* __restrict__ partial, int np, float* __restrict__ scale, int with_inverse, int emax) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) m = fmaxf(m, partial[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        int e = 0;
+        if (m > 0.f && m < INFINITY) {
+            (void)frexpf(m, &e);
+            e = 10 - e;
+        }
+        e = e > emax ? emax : (e < -emax ? -emax : e);
+        scale[0] = ldexpf(1.f, e);
+        if (with_inverse) scale[1] = ldexpf(1.f, -e);
+    }
+}
+
 static void launch_pow2_scale(const float* w, long long n, float* scale, int with_inverse, int emax, hipStream_t st) {
     hipLaunchKernelGGL(absmax_init_kernel, dim3(1), dim3(1), 0, st, scale);
     const int grid = (int)((n + 2047) / 2048 < 1024 ? (n + 2047) / 2048 : 1024);
@@ -870,6 +910,48 @@ int pp_split_with_scale_t(const float* w, long long n, int terms, const float* s
 int pp_pow2_scale(const float* x, long long n, float* scale2, void* stream) {
     if (!x || !scale2 || n <= 0) return PP_EINVAL;
     launch_pow2_scale(x, n, scale2, 1, 100, (hipStream_t)stream);
+    return pp_last_launch();
+}
+
+int pp_pow2_scale_ws(const float* x, long long n, float* scale2, float* partials, void* stream) {
+    if (!x || !scale2 || !partials || n <= 0) return PP_EINVAL;
+    const int grid = (int)((n + 8191) / 8192 < 1024 ? (n + 8191) / 8192 : 1024);
+    hipLaunchKernelGGL(absmax_part_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, partials);
+    hipLaunchKernelGGL(absmax_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, grid, scale2, 1, 100);
+    return pp_last_launch();
+}
+
+// split_act_kernel with a device-side scale: the operand of s x (s = scale[0], a power of two chosen on the device from max|x|)
+__global__ __launch_bounds__(256) void split_act_scaled_kernel(const float* __restrict__ x, long long rows, int ld, int C, const float* __restrict__ scale,
+                                                               _Float16* __restrict__ hl, int terms) {
+    const int c8n = C >> 3;
+    const long long total8 = rows * c8n;
+    const float s = scale[0] * A_SCALE;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+        const long long row = i / c8n;
+        const int c = (int)(i - row * c8n) * 8;
+        const float* xp = x + row * ld + c;
+        const f4 v0 = *(const f4*)xp, v1 = *(const f4*)(xp + 4);
+        h4 h0, l0, h1, l1;
+        split_f16x4(v0, s, h0, l0);
+        split_f16x4(v1, s, h1, l1);
+        _Float16* o = hl + (row * C + c) * terms;
+        *(h4*)o = h0;
+        *(h4*)(o + 4) = h1;
+        if (terms == 2) {
+            *(h4*)(o + 8) = l0;
+            *(h4*)(o + 12) = l1;
+        }
+    }
+}
+
+int pp_split_scaled_t(const float* x, long long rows, int ld, int C, const float* scale, void* hl, int terms, void* stream) {
+    if (!x || !hl || !scale || rows <= 0 || C <= 0 || C % 8 != 0 || ld % 4 != 0 || ld < C || ((uintptr_t)x & 15) != 0 || ((uintptr_t)hl & 15) != 0 ||
+        (terms != 1 && terms != 2))
+        return PP_EINVAL;
+    const long long total8 = rows * (C / 8);
+    const int grid = (int)((total8 + 255) / 256 < 8192 ? (total8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split_act_scaled_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, rows, ld, C, scale, (_Float16*)hl, terms);
     return pp_last_launch();
 }
 
@@ -945,7 +1027,8 @@ int pp_split_activation(const float* x, long long batch_stride, int B, int P, in
 }
 
 int pp_gemm(const PpGemmDesc* desc, void* stream) {
-    if (!desc || (!desc->A && !desc->A_hl) || !desc->B || (!desc->C && !desc->C_hl)) return PP_EINVAL;
+    // (B may be NULL when BOTH operands arrive pre-split: products of two transient operands, picopose_amd/ops.matmul_operands)
+    if (!desc || (!desc->A && !desc->A_hl) || (!desc->B && !(desc->A_hl && desc->B_hl)) || (!desc->C && !desc->C_hl)) return PP_EINVAL;
     {   // operand output: rows of ldc_h elements holding the N columns (pixel-shuffle stores: the N / r^2 channels of a pixel)
         const int r2 = desc->shuffle_r > 0 ? desc->shuffle_r * desc->shuffle_r : 1;
         if (desc->C_hl && (desc->ldc_h < desc->N / r2 || desc->ldc_h % 8 != 0 || desc->batch0 * desc->batch1 != 1 ||

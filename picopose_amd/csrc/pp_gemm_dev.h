@@ -36,6 +36,14 @@ __device__ __forceinline__ float erf_rational(float z) {
     return zc * p * __builtin_amdgcn_rcpf(q);
 }
 
+// alpha of a launch: the host scalar times the optional device scalars (the inverse range scales of backward operands)
+__device__ __forceinline__ float pp_alpha(const PpGemmDesc& d) {
+    float a = d.alpha;
+    if (d.alpha_dev) a *= d.alpha_dev[0];
+    if (d.alpha_dev2) a *= d.alpha_dev2[0];
+    return a;
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case PP_ACT_RELU: return v > 0.f ? v : 0.f;

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
         };
         int cur = 0, nxt = 1;
         int since_epi = S;
-        const float descale = d.alpha / (PP_A_SCALE * d.b_scale);
+        const float descale = pp_alpha(d) / (PP_A_SCALE * d.b_scale);
         // one K tile: MFMAs from set FC; fragments of the next K tile (stage nxt) into FN; pieces of K tile + S into stage cur
         // (a macro: through a nested lambda the two sets stayed in scratch memory)
 #define PP_U_KTILE_PREF(FC, FN)                                                                                          \
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
     load_b(fb0, 0, 0);
     int cur = 0, nxt = S > 1 ? 1 : 0;
     int bcur = 0, bnxt = 1;             // B3: the B ring's cursors (three stages); otherwise the B operand shares cur / nxt
-    const float descale = d.alpha / (PP_A_SCALE * d.b_scale);
+    const float descale = pp_alpha(d) / (PP_A_SCALE * d.b_scale);
     // The vector epilogue issues a fixed number of VMEM operations per wave, whatever the tile (rows / columns out of range
     // are out-of-range offsets, not skipped instructions): at least one 16-byte store per 4 accumulator registers.
     constexpr int EPI_ST = MI * NJ;
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_uh_kernel(const PpGemmDesc d, 
     load_a(fa0, 0, -1, 0);
     load_b(fb0, 0, 0);
     int cur = 0;
-    const float descale = d.alpha / (PP_A_SCALE * d.b_scale);
+    const float descale = pp_alpha(d) / (PP_A_SCALE * d.b_scale);
     for (int tile = first; tile < chunk1; tile += nxw) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)

@@ -280,6 +280,46 @@ def linear(x, weight, bias=None, act=None, gamma=None, residual=None, out=None, 
     return ret
 
 
+def split_scaled(x2d, s2):
+    """x2d (rows, C) fp32 (row pitch free, C % 8 == 0) -> Split of s2[0] * x2d: the range-normalised operand of a backward product in ONE
+    pass (the scale is a device scalar from autograd._pow2_scale; no scaled fp32 copy is made)."""
+    rows, C = x2d.shape
+    assert x2d.stride(1) == 1
+    sp = Split.empty(rows, C, x2d.device)
+    _lib.check(_lib.lib().pp_split_scaled_t(_p(x2d), rows, x2d.stride(0), C, _p(s2), _p(sp.hl), sp.terms, _lib.stream_ptr()), "pp_split_scaled_t")
+    return sp
+
+
+def split_transposed(x2d, s2=None):
+    """x2d (rows, cols) fp32 (row pitch free; rows % 8 == 0) -> Split (cols, rows) of s2[0] * x2d^T (s2 None: 1): the K-major operands of
+    dW = dz^T x without a transposed fp32 copy."""
+    rows, cols = x2d.shape
+    assert x2d.stride(1) == 1 and rows % 8 == 0
+    sp = Split.empty(cols, rows, x2d.device)
+    _lib.check(_lib.lib().pp_split_transpose_t(_p(x2d), rows, cols, x2d.stride(0), _p(s2), _p(sp.hl), sp.terms, _lib.stream_ptr()),
+               "pp_split_transpose_t")
+    return sp
+
+
+def operands_ok(M, N, K):
+    """Shapes the pre-split engine takes for a product of two transient operands (32-bit byte offsets into either operand)."""
+    return presplit() and PRECISION == "f16x3" and M >= 64 and N >= 64 and K % 8 == 0 and M * K < 2 ** 30 and N * K < 2 ** 30
+
+
+def matmul_operands(A, Bt, alpha_dev=(), out=None):
+    """A (M,K) @ Bt (N,K)^T for two Splits (activation scale): fp32 (M,N).  alpha_dev: up to two device scalars the result is
+    multiplied by inside the launch (PpGemmDesc.alpha_dev: the inverse range scales of the operands)."""
+    (M, K), (N, K2) = A.shape, Bt.shape
+    assert K == K2
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    assert out.stride(1) == 1
+    ad = list(alpha_dev) + [None, None]
+    _run(_desc(A_hl=_p(A.hl), B_hl=_p(Bt.hl), b_scale=4.0, C=_p(out), M=M, N=N, K=K, lda=K, ldb=K, ldc=out.stride(0), prec=_PREC[PRECISION],
+               alpha_dev=_p(ad[0]), alpha_dev2=_p(ad[1]), _keep=(A.hl, Bt.hl)))
+    return out
+
+
 def matmul_nt_presplit(a, bt):
     """a (M,K) @ bt (N,K)^T with BOTH operands split as activations (scale PP_A_SCALE) — the pre-split engine for products of two
     transient matrices (the backward GEMMs of picopose_amd/autograd.py: their operands are range-normalised first).  Unlike
@@ -371,7 +411,8 @@ def split_image(x, relu=False):
 
 
 def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residual=None, out=None, cin=None,
-           residual2=None, out_split=False, split_relu=False, also_split=None, hl_into=None, cache_weight=True, in_cols=None):
+           residual2=None, out_split=False, split_relu=False, also_split=None, hl_into=None, cache_weight=True, in_cols=None,
+           alpha_dev=()):
     """NHWC convolution. x (B,H,W,Cx) (channel-contiguous, may be a channel slice: cin <= Cx stride) or a Split
     carrying .image (a pre-split operand: no split pass, the producer has already applied any input ReLU),
     wp (Cout, k*k*cin) from pack_conv_weight.  out may be a channel slice of a wider NHWC buffer.
@@ -383,7 +424,9 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     (channel concatenation of operands; Cout % 8 == 0, col0 % 8 == 0) — and, if `out` is given, as fp32 there too;
     returns `out` (None without it).
     in_cols = (col0, c) with a Split input: the convolution reads operand columns col0 .. col0 + c of the wider Split (a channel
-    slice of a shared operand: two layers fused along N hand their halves to their successors without a copy)."""
+    slice of a shared operand: two layers fused along N hand their halves to their successors without a copy).
+    alpha_dev: up to two device scalars the accumulated product is multiplied by inside the launch (PpGemmDesc.alpha_dev: the inverse
+    range scale of a backward operand) — pre-split path only."""
     xs = x if isinstance(x, Split) else None
     a_ptr = None
     if xs is not None and in_cols is not None:
@@ -461,12 +504,15 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
         assert "B_hl" in wargs
         hl = xs.hl if xs is not None else split_activation(x, B, H * W, cin, x.stride(0), ld_in, relu=relu_in)  # once, not per tap / column tile
         ld_a = ld_in if a_ptr is not None else cin
+        ad = list(alpha_dev) + [None, None]
+        aargs = dict(alpha_dev=_p(ad[0]), alpha_dev2=_p(ad[1]))
         _run(_desc(A_hl=a_ptr if a_ptr is not None else _p(hl), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual),
                    residual2=_p(residual2), conv_bstride=H * W * ld_a, M=B * Ho * Wo, N=Cout, K=ksize * ksize * cin, lda=ld_a,
                    ldb=wp.shape[1], ldc=ldc, act=ACT[act], conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride,
-                   conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo, **wargs, **sargs),
+                   conv_pad=pad, conv_h=H, conv_w=W, conv_ho=Ho, conv_wo=Wo, **wargs, **sargs, **aargs),
              written=(extra if extra is not None else ret) if sargs else None)
         return ret
+    assert not alpha_dev
     _run(_desc(A=_p(x), B=_p(wp), C=_p(out), bias=_p(bias), residual=_p(residual), residual2=_p(residual2),
                conv_bstride=x.stride(0), M=B * Ho * Wo, N=Cout,
                K=ksize * ksize * cin, lda=ld_in, ldb=wp.shape[1], ldc=ldc, act=ACT[act], relu_in=int(relu_in),
