@@ -528,6 +528,15 @@ int pp_warp_backward_nhwc(const float* feat, const float* flow, const float* dy,
 int pp_corr_lookup_backward_nhwc(const float* f1, const float* const* f2_levels, const float* flow, const float* dout, int B, int H, int W,
                                  int C, int levels, int radius, int ld_flow, int ld_dout, float* df1, float* const* df2_levels, float* dflow,
                                  void* stream);
+/* The deterministic forms of the two scatter adjoints: the scattered sums (dfeat; df2 per level) accumulate in 64-bit FIXED POINT
+ * (2^-40 units, integer atomics: the same bits whatever order the workgroups arrive in) into caller-zeroed long long buffers of the
+ * same element counts; pp_fixed_to_float turns them into the fp32 gradients.  df1 / dflow are written directly as before. */
+int pp_warp_backward_nhwc_fixed(const float* feat, const float* flow, const float* dy, int B, int H, int W, int C, int ld_flow,
+                                long long* dfeat_acc, float* dflow, void* stream);
+int pp_corr_lookup_backward_nhwc_fixed(const float* f1, const float* const* f2_levels, const float* flow, const float* dout, int B, int H,
+                                       int W, int C, int levels, int radius, int ld_flow, int ld_dout, float* df1,
+                                       long long* const* df2_acc_levels, float* dflow, void* stream);
+int pp_fixed_to_float(const long long* acc, long long n, float* out, void* stream);
 /* adjoint of pp_flow_loss_sums for one level: g_flow[0] = upstream * flow_weight / (count + eps), g_cert[0] = upstream * mask_weight /
  * (B H W) (device scalars) -> dflow (B,H,W,2), dcertainty (B,H,W) */
 int pp_flow_loss_backward(const float* flow, const float* certainty, const float* tar_pts, int B, int H, int W, float max_flow,

@@ -173,6 +173,9 @@ def lib():
         L.pp_avgpool2_backward_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
         L.pp_warp_backward_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
         L.pp_corr_lookup_backward_nhwc.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+        L.pp_warp_backward_nhwc_fixed.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+        L.pp_corr_lookup_backward_nhwc_fixed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+        L.pp_fixed_to_float.argtypes = [vp, ll, vp, vp]
         L.pp_flow_loss_backward.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
         _lib = L
     return _lib

@@ -26,6 +26,10 @@ import torch
 from . import _lib, ops
 
 ACT = ops.ACT
+# True: the two scatter adjoints (feature warp, correlation lookup) accumulate in 64-bit fixed point with integer atomics — gradients
+# repeat bit for bit from run to run (the reference offers deterministic training through seeding); False: fp32 atomics, faster,
+# last-bit differences between runs (tests/test_train_gpu.py::test_deterministic_option_repeats_bit_for_bit).
+DETERMINISTIC = False
 
 
 def _p(t):
@@ -604,6 +608,12 @@ def resize(x, Ho, Wo, mul=1.0):
     return _Resize.apply(x, Ho, Wo, mul)
 
 
+def _fixed_to_float(acc):
+    out = torch.empty(acc.shape, dtype=torch.float32, device=acc.device)
+    _lib.check(_lib.lib().pp_fixed_to_float(_p(acc), acc.numel(), _p(out), _lib.stream_ptr()), "pp_fixed_to_float")
+    return out
+
+
 class _Warp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, flow):
@@ -615,8 +625,13 @@ class _Warp(torch.autograd.Function):
     def backward(ctx, dy):
         feat, flow = ctx.saved_tensors
         B, H, W, C = feat.shape
-        dfeat = torch.zeros_like(feat)
         dflow = torch.empty(B, H, W, 2, dtype=torch.float32, device=feat.device)
+        if DETERMINISTIC:
+            acc = torch.zeros(feat.shape, dtype=torch.int64, device=feat.device)
+            _lib.check(_lib.lib().pp_warp_backward_nhwc_fixed(_p(feat), _p(flow), _p(_f32c(dy)), B, H, W, C, flow.shape[-1], _p(acc), _p(dflow),
+                                                              _lib.stream_ptr()), "pp_warp_backward_nhwc_fixed")
+            return _fixed_to_float(acc), dflow
+        dfeat = torch.zeros_like(feat)
         _lib.check(_lib.lib().pp_warp_backward_nhwc(_p(feat), _p(flow), _p(_f32c(dy)), B, H, W, C, flow.shape[-1], _p(dfeat), _p(dflow),
                                                     _lib.stream_ptr()), "pp_warp_backward_nhwc")
         return dfeat, dflow
@@ -644,14 +659,22 @@ class _CorrLookup(torch.autograd.Function):
         pyr = [f2]
         for _ in range(levels - 1):
             pyr.append(ops.avgpool2(pyr[-1]))
-        dpyr = [torch.zeros_like(t) for t in pyr]
         df1 = torch.empty_like(f1)
         dflow = torch.empty(B, H, W, 2, dtype=torch.float32, device=f1.device)
         arr = ctypes.c_void_p * 3
         fl = arr(*[_p(t) for t in pyr] + [None] * (3 - levels))
-        dl = arr(*[_p(t) for t in dpyr] + [None] * (3 - levels))
-        _lib.check(_lib.lib().pp_corr_lookup_backward_nhwc(_p(f1), fl, _p(flow), _p(dout), B, H, W, C, levels, r, flow.shape[-1], dout.shape[-1],
-                                                           _p(df1), dl, _p(dflow), _lib.stream_ptr()), "pp_corr_lookup_backward_nhwc")
+        if DETERMINISTIC:
+            accs = [torch.zeros(t.shape, dtype=torch.int64, device=t.device) for t in pyr]
+            dl = arr(*[_p(t) for t in accs] + [None] * (3 - levels))
+            _lib.check(_lib.lib().pp_corr_lookup_backward_nhwc_fixed(_p(f1), fl, _p(flow), _p(dout), B, H, W, C, levels, r, flow.shape[-1],
+                                                                     dout.shape[-1], _p(df1), dl, _p(dflow), _lib.stream_ptr()),
+                       "pp_corr_lookup_backward_nhwc_fixed")
+            dpyr = [_fixed_to_float(a) for a in accs]
+        else:
+            dpyr = [torch.zeros_like(t) for t in pyr]
+            dl = arr(*[_p(t) for t in dpyr] + [None] * (3 - levels))
+            _lib.check(_lib.lib().pp_corr_lookup_backward_nhwc(_p(f1), fl, _p(flow), _p(dout), B, H, W, C, levels, r, flow.shape[-1], dout.shape[-1],
+                                                               _p(df1), dl, _p(dflow), _lib.stream_ptr()), "pp_corr_lookup_backward_nhwc")
         for l in range(levels - 1, 0, -1):       # the pooling chain's adjoint, coarse to fine
             t = dpyr[l - 1]
             _lib.check(_lib.lib().pp_avgpool2_backward_nhwc(_p(dpyr[l]), B, t.shape[1], t.shape[2], C, 1, _p(t), _lib.stream_ptr()),

@@ -1,7 +1,9 @@
 // First backward slice of the training path (utils/lite.py:33-49 calls loss.backward() on the sum of the
 // `loss*` entries of model/picopose.py:114-137): the row-wise / element-wise pieces whose matrix products run on the GEMM engine
-// (picopose_amd/autograd.py: dgrad = dz W, wgrad = dz^T x as pp_gemm launches).  Everything here is deterministic: reductions
-// run in a fixed order (no atomics), so a gradient does not depend on the launch configuration.
+// (picopose_amd/autograd.py: dgrad = dz W, wgrad = dz^T x as pp_gemm launches).  Everything IN THIS FILE is deterministic: reductions
+// run in a fixed order (no atomics), so a gradient does not depend on the launch configuration.  (The two scatter adjoints of
+// pp_backward3.hip — feature warp, correlation lookup — use fp32 atomics by default and 64-bit fixed-point integer atomics with
+// autograd.DETERMINISTIC = True; only then is the whole backward bit-reproducible.)
 //   scope: InfoNCE (utils/loss_utils.py:144-175) -> the last ViT block (layers/block.py:82-107, attention.py:49-62, mlp.py:35-41,
 //   layer_scale.py:27-28, nn.LayerNorm) and the stage-2 losses (:177-186) -> AffineRegressor (model/stage2/affine_regressor.py).
 #include <hip/hip_runtime.h>

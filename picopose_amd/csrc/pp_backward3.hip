@@ -177,11 +177,29 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Scatter accumulation of the two sampling adjoints.  FIXED = false: fp32 atomicAdd — fast, but the sum depends on the order the
+// workgroups arrive in, so two runs differ in the last bits.  FIXED = true (the deterministic option, autograd.DETERMINISTIC): the
+// contribution is rounded to a 64-bit fixed-point number (2^-40 units: 9e-13 absolute resolution, |sum| < 8e6) and added with an
+// INTEGER atomic — integer addition is associative and commutative exactly, so the result is the same bits in any order; a second
+// pass turns the accumulators into floats (pp_fixed_to_float).
+constexpr float FX_SCALE = 1099511627776.f;          // 2^40
+template <bool FIXED>
+__device__ __forceinline__ void scatter_add(void* base, size_t idx, float v) {
+    if (FIXED) atomicAdd((unsigned long long*)base + idx, (unsigned long long)__float2ll_rn(v * FX_SCALE));
+    else atomicAdd((float*)base + idx, v);
+}
+
+__global__ __launch_bounds__(256) void fixed_to_float_kernel(const long long* __restrict__ acc, long long n, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = (float)((double)acc[i] * (1.0 / 1099511627776.0));
+}
+
 // ---------------------------------------------------------------------------------------------------------- feature warp
 // adjoint of warp_kernel: out[p] = bilinear(feat, p + flow[p]), zeros padding.  One wave per pixel, lanes over channels.
+template <bool FIXED>
 __global__ __launch_bounds__(256) void warp_backward_kernel(const float* __restrict__ feat, const float* __restrict__ flow,
                                                             const float* __restrict__ dy, int H, int W, int C, int ld_flow,
-                                                            float* __restrict__ dfeat, float* __restrict__ dflow) {
+                                                            void* __restrict__ dfeat, float* __restrict__ dflow) {
     const int b = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= H * W) return;
     const int y = p / W, x = p - y * W;
@@ -204,10 +222,10 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(const float* __restr
         const float t11 = vy1 && vx1 ? feat[base + ((size_t)yb * W + xb) * C + c] : 0.f;
         gx = fmaf(d, (t01 - t00) * wy0 + (t11 - t10) * wy1, gx);
         gy = fmaf(d, (t10 - t00) * wx0 + (t11 - t01) * wx1, gy);
-        if (vy0 && vx0) atomicAdd(dfeat + base + ((size_t)ya * W + xa) * C + c, d * (wx0 * wy0));
-        if (vy0 && vx1) atomicAdd(dfeat + base + ((size_t)ya * W + xb) * C + c, d * (wx1 * wy0));
-        if (vy1 && vx0) atomicAdd(dfeat + base + ((size_t)yb * W + xa) * C + c, d * (wx0 * wy1));
-        if (vy1 && vx1) atomicAdd(dfeat + base + ((size_t)yb * W + xb) * C + c, d * (wx1 * wy1));
+        if (vy0 && vx0) scatter_add<FIXED>(dfeat, base + ((size_t)ya * W + xa) * C + c, d * (wx0 * wy0));
+        if (vy0 && vx1) scatter_add<FIXED>(dfeat, base + ((size_t)ya * W + xb) * C + c, d * (wx1 * wy0));
+        if (vy1 && vx0) scatter_add<FIXED>(dfeat, base + ((size_t)yb * W + xa) * C + c, d * (wx0 * wy1));
+        if (vy1 && vx1) scatter_add<FIXED>(dfeat, base + ((size_t)yb * W + xb) * C + c, d * (wx1 * wy1));
     }
     gx = wave_sum(gx);
     gy = wave_sum(gy);
@@ -223,12 +241,13 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(const float* __restr
 // One wave per pixel: the (2r+2)^2 table positions per level are visited one after the other, lanes over channels.
 constexpr int CLB_MAXL = 3, CLB_TW = 8;   // levels, table width for r <= 3
 
+template <bool FIXED>
 __global__ __launch_bounds__(256) void corr_lookup_backward_kernel(const float* __restrict__ f1, const float* __restrict__ f2l0,
                                                                    const float* __restrict__ f2l1, const float* __restrict__ f2l2,
                                                                    const float* __restrict__ flow, const float* __restrict__ dout, int H,
                                                                    int W, int C, int L, int r, int ld_flow, int ld_dout, float inv_sqrt_c,
-                                                                   float* __restrict__ df1, float* __restrict__ df2l0,
-                                                                   float* __restrict__ df2l1, float* __restrict__ df2l2,
+                                                                   float* __restrict__ df1, void* __restrict__ df2l0,
+                                                                   void* __restrict__ df2l1, void* __restrict__ df2l2,
                                                                    float* __restrict__ dflow) {
     __shared__ float dtab_s[4][CLB_MAXL * CLB_TW * CLB_TW];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(256) void corr_lookup_backward_kernel(const float* 
         const int bx = (int)floorf(cx) - r, by = (int)floorf(cy) - r;
         const float wx1 = cx - floorf(cx), wy1 = cy - floorf(cy), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
         const float* f2 = l == 0 ? f2l0 : (l == 1 ? f2l1 : f2l2);
-        float* df2 = l == 0 ? df2l0 : (l == 1 ? df2l1 : df2l2);
+        void* df2 = l == 0 ? df2l0 : (l == 1 ? df2l1 : df2l2);
         const size_t lb = (size_t)b * Hl * Wl * C;
         // dtab[dy][dx] = sum over the outputs (a, b) whose four corners include (dy, dx)
         for (int i = lane; i < tw * tw; i += 64) {
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(256) void corr_lookup_backward_kernel(const float* 
             const int qx = bx + dx_, qy = by + dy_;
             if (!(qx >= 0 && qx < Wl && qy >= 0 && qy < Hl)) continue;   // (wave-uniform)
             const float* qv = f2 + lb + ((size_t)qy * Wl + qx) * C;
-            float* dq = df2 + lb + ((size_t)qy * Wl + qx) * C;
+            const size_t dq = lb + ((size_t)qy * Wl + qx) * C;
             const float dt = dtab[l * CLB_TW * CLB_TW + i] * inv_sqrt_c;
             float dot = 0.f;
 #pragma unroll
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(256) void corr_lookup_backward_kernel(const float* 
                     const float u = a[c], v = qv[c];
                     dot = fmaf(u, v, dot);
                     acc1[k] = fmaf(dt, v, acc1[k]);
-                    if (dt != 0.f) atomicAdd(dq + c, dt * u);
+                    if (dt != 0.f) scatter_add<FIXED>(df2, dq + c, dt * u);
                 }
             }
             const float val = wave_sum(dot) * inv_sqrt_c;
@@ -397,27 +416,67 @@ int pp_avgpool2_backward_nhwc(const float* dy, int B, int H, int W, int C, int a
     return pp_last_launch();
 }
 
+int pp_fixed_to_float(const long long* acc, long long n, float* out, void* stream) {
+    if (!acc || !out || n <= 0) return PP_EINVAL;
+    hipLaunchKernelGGL(fixed_to_float_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, acc, n, out);
+    return pp_last_launch();
+}
+
+static int warp_backward(const float* feat, const float* flow, const float* dy, int B, int H, int W, int C, int ld_flow, void* dfeat,
+                         float* dflow, bool fixed, void* stream) {
+    if (!feat || !flow || !dy || !dfeat || !dflow || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld_flow < 2) return PP_EINVAL;
+    if (fixed)
+        hipLaunchKernelGGL(warp_backward_kernel<true>, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, flow, dy, H, W, C, ld_flow,
+                           dfeat, dflow);
+    else
+        hipLaunchKernelGGL(warp_backward_kernel<false>, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, flow, dy, H, W, C, ld_flow,
+                           dfeat, dflow);
+    return pp_last_launch();
+}
+
 int pp_warp_backward_nhwc(const float* feat, const float* flow, const float* dy, int B, int H, int W, int C, int ld_flow, float* dfeat,
                           float* dflow, void* stream) {
-    if (!feat || !flow || !dy || !dfeat || !dflow || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld_flow < 2) return PP_EINVAL;
-    hipLaunchKernelGGL(warp_backward_kernel, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, feat, flow, dy, H, W, C, ld_flow, dfeat,
-                       dflow);
+    return warp_backward(feat, flow, dy, B, H, W, C, ld_flow, dfeat, dflow, false, stream);
+}
+
+int pp_warp_backward_nhwc_fixed(const float* feat, const float* flow, const float* dy, int B, int H, int W, int C, int ld_flow,
+                                long long* dfeat_acc, float* dflow, void* stream) {
+    return warp_backward(feat, flow, dy, B, H, W, C, ld_flow, dfeat_acc, dflow, true, stream);
+}
+
+static int corr_lookup_backward(const float* f1, const float* const* f2_levels, const float* flow, const float* dout, int B, int H, int W,
+                                int C, int levels, int radius, int ld_flow, int ld_dout, float* df1, void* const* df2_levels, float* dflow,
+                                bool fixed, void* stream) {
+    if (!f1 || !f2_levels || !flow || !dout || !df1 || !df2_levels || !dflow || B <= 0 || H <= 0 || W <= 0) return PP_EINVAL;
+    if (levels < 1 || levels > CLB_MAXL || radius < 0 || 2 * radius + 2 > CLB_TW || C <= 0 || C > 256 || ld_flow < 2) return PP_EINVAL;
+    if (ld_dout < levels * (2 * radius + 1) * (2 * radius + 1)) return PP_EINVAL;
+    for (int l = 0; l < levels; ++l)
+        if (!f2_levels[l] || !df2_levels[l]) return PP_EINVAL;
+    if (fixed)
+        hipLaunchKernelGGL(corr_lookup_backward_kernel<true>, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, f1, f2_levels[0],
+                           levels > 1 ? f2_levels[1] : nullptr, levels > 2 ? f2_levels[2] : nullptr, flow, dout, H, W, C, levels, radius, ld_flow,
+                           ld_dout, 1.0f / sqrtf((float)C), df1, df2_levels[0], levels > 1 ? df2_levels[1] : nullptr,
+                           levels > 2 ? df2_levels[2] : nullptr, dflow);
+    else
+        hipLaunchKernelGGL(corr_lookup_backward_kernel<false>, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, f1, f2_levels[0],
+                           levels > 1 ? f2_levels[1] : nullptr, levels > 2 ? f2_levels[2] : nullptr, flow, dout, H, W, C, levels, radius, ld_flow,
+                           ld_dout, 1.0f / sqrtf((float)C), df1, df2_levels[0], levels > 1 ? df2_levels[1] : nullptr,
+                           levels > 2 ? df2_levels[2] : nullptr, dflow);
     return pp_last_launch();
 }
 
 int pp_corr_lookup_backward_nhwc(const float* f1, const float* const* f2_levels, const float* flow, const float* dout, int B, int H, int W,
                                  int C, int levels, int radius, int ld_flow, int ld_dout, float* df1, float* const* df2_levels, float* dflow,
                                  void* stream) {
-    if (!f1 || !f2_levels || !flow || !dout || !df1 || !df2_levels || !dflow || B <= 0 || H <= 0 || W <= 0) return PP_EINVAL;
-    if (levels < 1 || levels > CLB_MAXL || radius < 0 || 2 * radius + 2 > CLB_TW || C <= 0 || C > 256 || ld_flow < 2) return PP_EINVAL;
-    if (ld_dout < levels * (2 * radius + 1) * (2 * radius + 1)) return PP_EINVAL;
-    for (int l = 0; l < levels; ++l)
-        if (!f2_levels[l] || !df2_levels[l]) return PP_EINVAL;
-    hipLaunchKernelGGL(corr_lookup_backward_kernel, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, f1, f2_levels[0],
-                       levels > 1 ? f2_levels[1] : nullptr, levels > 2 ? f2_levels[2] : nullptr, flow, dout, H, W, C, levels, radius, ld_flow,
-                       ld_dout, 1.0f / sqrtf((float)C), df1, df2_levels[0], levels > 1 ? df2_levels[1] : nullptr,
-                       levels > 2 ? df2_levels[2] : nullptr, dflow);
-    return pp_last_launch();
+    return corr_lookup_backward(f1, f2_levels, flow, dout, B, H, W, C, levels, radius, ld_flow, ld_dout, df1, (void* const*)df2_levels, dflow, false,
+                                stream);
+}
+
+int pp_corr_lookup_backward_nhwc_fixed(const float* f1, const float* const* f2_levels, const float* flow, const float* dout, int B, int H, int W,
+                                       int C, int levels, int radius, int ld_flow, int ld_dout, float* df1, long long* const* df2_acc_levels,
+                                       float* dflow, void* stream) {
+    return corr_lookup_backward(f1, f2_levels, flow, dout, B, H, W, C, levels, radius, ld_flow, ld_dout, df1, (void* const*)df2_acc_levels, dflow, true,
+                                stream);
 }
 
 int pp_flow_loss_backward(const float* flow, const float* certainty, const float* tar_pts, int B, int H, int W, float max_flow,

@@ -151,3 +151,81 @@ def allreduce_gradients(parameters, group=None, bucket_bytes=25 << 20):
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
     return len(buckets)
+
+
+class GradientBuckets:
+    """The gradient averaging of DistributedDataParallel WITH its overlap (utils/lite.py:33-49 / run_train.py:109-118 train through
+    Lightning DDP, which all-reduces a bucket as soon as its gradients exist, while backward continues): `allreduce_gradients` above
+    runs after `backward()` has returned; this class issues every bucket's all-reduce from autograd's own hooks.
+
+        buckets = GradientBuckets([p for p in net.parameters() if p.requires_grad and <p trains>])   # once
+        loss.backward()            # hooks: a bucket whose last gradient has just been accumulated is packed and all-reduced (async)
+        buckets.finish()           # wait, divide by the world size, copy back into the .grad tensors; re-arm for the next step
+        optimizer.step()
+
+    Buckets are filled in REVERSE parameter order (gradients arrive roughly output-to-input), <= bucket_bytes each (25 MB: the
+    ring's latency term stays below 1 % of its transfer time at ~50 GB/s per xGMI link).  Every parameter handed in must receive a
+    gradient in every step (a bucket waits for all of its members: pass the parameters that train — INTEGRATION.md section 6 — as
+    a trainer passes them to its optimizer).  Single process / no process group: the hooks do nothing and finish() returns 0."""
+
+    def __init__(self, parameters, group=None, bucket_bytes=25 << 20):
+        self.group = group
+        self.params = [p for p in parameters if p.requires_grad]
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(self.params):
+            nb = p.numel() * p.element_size()
+            if cur and size + nb > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nb
+        if cur:
+            self.buckets.append(cur)
+        self._where = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self._left = [len(b) for b in self.buckets]
+        self._inflight = {}
+        self.launched_in_backward = 0
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _hook(self, p):
+        i = self._where[id(p)]
+        self._left[i] -= 1
+        if self._left[i] == 0 and self._active():
+            flat = torch.cat([q.grad.reshape(-1) for q in self.buckets[i]])
+            self._inflight[i] = (flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.launched_in_backward += 1
+
+    def finish(self):
+        """Call after backward(): waits for the buckets in flight (and reduces, synchronously, any bucket whose hooks did not all
+        fire — a parameter without a gradient this step), averages and writes the gradients back.  Returns the number of buckets."""
+        n = 0
+        if self._active():
+            world = dist.get_world_size(self.group)
+            for i, b in enumerate(self.buckets):
+                if i in self._inflight:
+                    flat, work = self._inflight.pop(i)
+                    work.wait()
+                else:
+                    have = [q for q in b if q.grad is not None]
+                    if not have:
+                        continue
+                    flat = torch.cat([q.grad.reshape(-1) for q in have])
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                    b = have
+                flat.div_(world)
+                off = 0
+                for q in b:
+                    q.grad.copy_(flat[off:off + q.numel()].view_as(q.grad))
+                    off += q.numel()
+                n += 1
+        self._left = [len(b) for b in self.buckets]
+        self._inflight.clear()
+        return n
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

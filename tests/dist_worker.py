@@ -62,6 +62,30 @@ def main():
     ok = ok and nb >= 3 and frozen.grad is None
     for k, p in zip(names, params):
         ok = ok and torch.allclose(p.grad, torch.from_numpy(z[k]) * 1.5, rtol=1e-6, atol=1e-12)
+    # ... and the OVERLAPPED form (GradientBuckets): a small network under real autograd, rank-dependent inputs; every bucket's
+    # all-reduce is issued from a gradient hook during backward(), the result is the mean of the two ranks' gradients
+    from picopose_amd.dist import GradientBuckets
+
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 8))
+    xs = [torch.randn(16, 40, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    want = []
+    for r in range(world):
+        net.zero_grad(set_to_none=True)
+        net(xs[r]).square().sum().backward()
+        want.append([p.grad.clone() for p in net.parameters()])
+    mean = [sum(g) / world for g in zip(*want)]
+    net.zero_grad(set_to_none=True)
+    gb = GradientBuckets(list(net.parameters()), bucket_bytes=1 << 13)
+    for step in range(2):                       # twice: the buckets re-arm
+        net.zero_grad(set_to_none=True)
+        net(xs[rank]).square().sum().backward()
+        launched = gb.launched_in_backward
+        nb2 = gb.finish()
+        ok = ok and nb2 == len(gb.buckets) >= 3 and launched == (step + 1) * len(gb.buckets)      # every bucket went out DURING backward
+        for p, m in zip(net.parameters(), mean):
+            ok = ok and torch.allclose(p.grad, m, rtol=1e-5, atol=1e-7)
+    gb.remove()
     print(f"RANK{rank} {'OK' if ok else 'MISMATCH'}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

@@ -46,12 +46,15 @@ def main():
         torch.cuda.synchronize()
         return net
 
+    turn = dist.new_group(backend="gloo") if world > 1 else None    # its own queue: independent of the gradient collectives' order
+
     def in_turn(fn):
         out = None
         for q in range(world):                      # one rank at a time on the card
             if q == rank:
                 out = fn()
-            dist.barrier()
+            if turn is not None:
+                dist.barrier(group=turn)
         return out
 
     local = in_turn(lambda: {r: grads_of(r) for r in range(world)})          # every rank's gradients, recomputed here
@@ -72,6 +75,30 @@ def main():
         Loss()(ddp(ep))["loss"].backward()
         torch.cuda.synchronize()
         nb = 3
+    elif os.environ.get("PP_DDP") == "buckets":
+        # the OVERLAPPED form (picopose_amd.dist.GradientBuckets): every bucket's all-reduce is issued by a gradient hook while
+        # backward is still running; the ranks still take turns on the card (a rank's buckets wait for its peer's), then finish()
+        import numpy as np
+
+        from picopose_amd.dist import GradientBuckets
+
+        mine = Net(small_cfg())
+        mine.load_state_dict(calibrated_state_dict(mine.state_dict(), 4, "dinov2_vits14"))
+        mine = mine.cuda().train()
+        trains = {n for n, p in local[rank].named_parameters() if p.grad is not None}
+        gb = GradientBuckets([p for n, p in mine.named_parameters() if n in trains], bucket_bytes=4 << 20)
+
+        def step():
+            ep = {k: v.cuda() for k, v in make_train_end_points(2, 100 + rank).items()}
+            np.random.seed(700 + rank)
+            torch.manual_seed(900 + rank)
+            Loss()(mine(ep))["loss"].backward()
+            torch.cuda.synchronize()
+
+        in_turn(step)
+        launched = gb.launched_in_backward
+        nb = gb.finish()
+        assert launched == nb == len(gb.buckets), (launched, nb, len(gb.buckets))
     else:
         mine = in_turn(lambda: grads_of(rank))                               # the copy that is all-reduced
         nb = allreduce_gradients(list(mine.parameters()), bucket_bytes=4 << 20)
