@@ -391,7 +391,11 @@ def test_deterministic_option_repeats_bit_for_bit(golden_dir, monkeypatch):
     assert a.keys() == b.keys() == c.keys() and len(a) >= 330
     differ = [n for n in a if not torch.equal(a[n], b[n])]
     assert not differ, differ[:5]
-    worst = max(float((a[n] - c[n]).abs().max()) / max(float(c[n].abs().max()), 1e-30) for n in a if float(c[n].abs().max()) > 1e-12)
+    # (the bias tensors in front of a training-mode BatchNorm have an analytically zero gradient: rounding noise on both sides — left
+    # out by the reference's own norm, as in test_full_backward_matches_the_reference_autograd)
+    live = [n for n in a if float(z[f"grad3norm/{n}"]) > 1e-6]
+    assert len(live) >= 300
+    worst = max(float((a[n] - c[n]).abs().max()) / float(c[n].abs().max()) for n in live)
     print(f"deterministic option: {len(a)} gradient tensors bit-equal over two runs; vs fp32-atomic gradients max|diff| / max|grad| = {worst:.2e}")
     assert worst <= 5e-4
 
