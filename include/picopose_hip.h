@@ -299,6 +299,14 @@ int pp_attention_ex(const float* qkv, int B, int T, int heads, int head_dim, flo
  * wrote (PpGemmDesc.C_hl): no split work inside the kernel; bit-identical to pp_attention_ex on the fp32 qkv. */
 int pp_attention_hl(const void* qkv_hl, int B, int T, int heads, int head_dim, float scale, float* out, void* out_hl,
                     void* stream);
+/* Training forward of the same attention (PP_PREC_F16X3): out as above plus lse2 (B*heads, T), the base-2 log-sum-exp of every
+ * query's scaled scores — all pp_attention_backward needs; the T x T probabilities are never stored. */
+int pp_attention_train(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, float* lse2, void* stream);
+/* Adjoint of attention.py:49-62 (what torch.autograd derives for the reference): dqkv (B*T, 3*heads*64) from qkv, the forward's out
+ * and lse2, and dout (B*T, heads*64).  gpair = device (2^k, 2^-k) with max|dout| 2^k in [512, 1024) (pp_pow2_scale_ws); Dws = B*heads*T
+ * floats of scratch.  Scores and probabilities are recomputed tile by tile; two kernels (dq | dk, dv), no atomics: bit-reproducible. */
+int pp_attention_backward(const float* qkv, const float* out, const float* dout, const float* lse2, const float* gpair, int B, int T,
+                          int heads, int head_dim, float scale, float* Dws, float* dqkv, void* stream);
 
 /* nn.LayerNorm(C, eps) over rows of a [rows][C] matrix. */
 int pp_layernorm(const float* x, const float* gamma, const float* beta, int rows, int C, float eps,

@@ -113,6 +113,8 @@ def lib():
         L.pp_attention_split.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, vp]
         L.pp_attention_ex.argtypes = [vp, i32, i32, i32, i32, f32, i32, vp, vp, vp]
         L.pp_attention_hl.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, vp]
+        L.pp_attention_train.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, vp]
+        L.pp_attention_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]
         L.pp_layernorm.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp]
         L.pp_layernorm_split.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp]
         L.pp_softmax_rows.argtypes = [vp, i32, i32, i32, vp]

@@ -21,6 +21,8 @@ Backward products run on range-normalised operands (`_ranged`: gradients span 1e
 only above ~3e-5): each operand is scaled by a power of two chosen on the device from its max, the product is scaled back — exact.
 Parity: tests/test_train_gpu.py compares these gradients with the reference's own autograd on CPU (tests/golden/train_grads.npz).
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -238,26 +240,48 @@ class _ScaleResidual(torch.autograd.Function):
         return _ew(1, dy, gamma, t.shape[1]), colsum(_ew(0, dy, t)), dy
 
 
+FUSED_ATTENTION = os.environ.get("PP_FUSED_ATTENTION", "1") != "0"
+
+
 class _Attention(torch.autograd.Function):
-    """softmax((q hd^-1/2) k^T) v per head on the qkv rows (B*T, 3*heads*hd) (layers/attention.py:49-62), unfused so that the
-    probabilities are kept: S and the three products are batched pp_gemm launches, soft-max rows / their adjoint row kernels."""
+    """softmax((q hd^-1/2) k^T) v per head on the qkv rows (B*T, 3*heads*hd) (layers/attention.py:49-62).  f16x3 engine: the fused
+    kernel forward (pp_attention_train keeps the log-sum-exp per query) and the recomputing adjoint (pp_attention_backward): the T x T
+    probabilities are never stored.  fp32 engine (or FUSED_ATTENTION off, head_dim != 64): unfused — S and the three products are batched
+    pp_gemm launches, soft-max rows / their adjoint row kernels, the probabilities kept."""
 
     @staticmethod
     def forward(ctx, qkv, B, T, heads, hd):
         qkv = _f32c(qkv)
+        ctx.dims = (B, T, heads, hd)
+        ctx.fused = FUSED_ATTENTION and ops.PRECISION == "f16x3" and hd == 64
+        if ctx.fused:
+            out = torch.empty(B * T, heads * hd, dtype=torch.float32, device=qkv.device)
+            lse = torch.empty(B * heads, T, dtype=torch.float32, device=qkv.device)
+            _lib.check(_lib.lib().pp_attention_train(_p(qkv), B, T, heads, hd, float(hd) ** -0.5, _p(out), _p(lse), _lib.stream_ptr()),
+                       "pp_attention_train")
+            ctx.save_for_backward(qkv, out, lse)
+            return out
         v5 = qkv.view(B, T, 3, heads, hd)
         q, k, v = (v5[:, :, i].permute(0, 2, 1, 3) for i in range(3))                # (B, heads, T, hd) strided views
         P = ops.softmax_rows_(ops.bmm_nt(q, k, alpha=float(hd) ** -0.5))             # (B, heads, T, T)
         out = torch.empty(B, T, heads, hd, dtype=torch.float32, device=qkv.device)
         ops.bmm_nn(P, v, out.permute(0, 2, 1, 3))
         ctx.save_for_backward(qkv, P)
-        ctx.dims = (B, T, heads, hd)
         return out.view(B * T, heads * hd)
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, P = ctx.saved_tensors
         B, T, heads, hd = ctx.dims
+        if ctx.fused:
+            qkv, out, lse = ctx.saved_tensors
+            dout = _f32c(dout)
+            g = _pow2_scale(dout)
+            dqkv = torch.empty_like(qkv)
+            ws = torch.empty(B * heads * T, dtype=torch.float32, device=qkv.device)
+            _lib.check(_lib.lib().pp_attention_backward(_p(qkv), _p(out), _p(dout), _p(lse), _p(g), B, T, heads, hd, float(hd) ** -0.5,
+                                                        _p(ws), _p(dqkv), _lib.stream_ptr()), "pp_attention_backward")
+            return dqkv, None, None, None, None
+        qkv, P = ctx.saved_tensors
         v5 = qkv.view(B, T, 3, heads, hd)
         q, k, v = (v5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         dO = _f32c(dout).view(B, T, heads, hd).permute(0, 2, 1, 3)

@@ -167,7 +167,8 @@ __device__ __forceinline__ int vt_slot(int key) {  // key (0..31) of a chunk -> 
 // (ops.PRECISION = "f16", BASELINE configs[4]); the lo-term registers / LDS planes / MFMAs compile away.
 template <bool HLIN, int TERMS = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_f16x3_kernel(const void* __restrict__ qkv_any, int T, int heads, float scale,
-                                                         float* __restrict__ out, _Float16* __restrict__ out_hl) {
+                                                         float* __restrict__ out, _Float16* __restrict__ out_hl,
+                                                         float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Kh = (_Float16*)smem;            // [KC][KHLD]
     _Float16* Kl = Kh + KC * KHLD;
@@ -425,6 +426,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
         }
     }
+    // (training) the base-2 log-sum-exp of the query's scaled scores: all the adjoint needs to recompute its probabilities
+    if (lse && q < T && lh == 0) lse[((size_t)b * heads + h) * T + q] = mrun + __builtin_amdgcn_logf(lrun);
     // output through LDS: O^T registers (lane = query) -> rows of 64 floats per query, written as full lines
     __syncthreads();
     float* Os = (float*)smem + w * 32 * OLD;
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 extern "C" {
 
 static int attention_launch(const void* qkv, bool hl_in, int B, int T, int heads, int head_dim, float scale, int prec, float* out,
-                            void* out_hl, void* stream, int terms = 2) {
+                            void* out_hl, void* stream, int terms = 2, float* lse = nullptr) {
     if (!qkv || (!out && !out_hl) || B <= 0 || T <= 0 || heads <= 0 || (hl_in && prec != PP_PREC_F16X3)) return PP_EINVAL;
     if (terms == 1 && !hl_in) return PP_EINVAL;
     if (head_dim != HD || ((uintptr_t)qkv % 16) != 0) return PP_EINVAL;
@@ -495,13 +498,13 @@ static int attention_launch(const void* qkv, bool hl_in, int B, int T, int heads
         const size_t kv = (size_t)(2 * KC * KHLD + 2 * KC * VLD) * sizeof(_Float16), os = (size_t)wpb * 32 * OLD * sizeof(float);
         if (hl_in && terms == 1)
             hipLaunchKernelGGL((attn_f16x3_kernel<true, 1>), dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
-                               (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl);
+                               (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl, lse);
         else if (hl_in)
             hipLaunchKernelGGL(attn_f16x3_kernel<true>, dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
-                               (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl);
+                               (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl, lse);
         else
             hipLaunchKernelGGL(attn_f16x3_kernel<false>, dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
-                               (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl);
+                               (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl, lse);
     } else {
         hipLaunchKernelGGL(attn_kernel, dim3((T + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, (const float*)qkv, T, heads,
                            scale, out, (_Float16*)out_hl);
@@ -536,6 +539,11 @@ int pp_attention_t(const void* qkv_operand, int terms, int B, int T, int heads, 
                    void* stream) {
     if (((uintptr_t)qkv_operand % 16) != 0 || (terms != 1 && terms != 2)) return PP_EINVAL;
     return attention_launch(qkv_operand, true, B, T, heads, head_dim, scale, PP_PREC_F16X3, out, out_operand, stream, terms);
+}
+
+int pp_attention_train(const float* qkv, int B, int T, int heads, int head_dim, float scale, float* out, float* lse2, void* stream) {
+    if (!out || !lse2) return PP_EINVAL;
+    return attention_launch(qkv, false, B, T, heads, head_dim, scale, PP_PREC_F16X3, out, nullptr, stream, 2, lse2);
 }
 
 }  // extern "C"

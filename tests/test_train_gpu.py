@@ -521,6 +521,53 @@ def test_backward_kernels_against_torch_autograd():
 
 
 @gpu
+@pytest.mark.parametrize("B,T,heads,qk_gain,dout_gain", [(2, 257, 12, 1.0, 1.0), (3, 37, 3, 1.0, 1e-7), (1, 1, 2, 1.0, 1.0), (2, 64, 6, 4.0, 30.0),
+                                                         (2, 33, 1, 0.05, 1.0), (1, 300, 2, 2.5, 1e-3)])
+def test_fused_attention_forward_and_adjoint_against_float64(B, T, heads, qk_gain, dout_gain):
+    """pp_attention_train / pp_attention_backward (csrc/pp_attn_bwd.hip: scores and probabilities recomputed, nothing T x T stored) against
+    torch's float64 autograd of layers/attention.py:49-62: ragged T (one query tile with one row at 257), peaked soft-maxes (qk_gain 4:
+    rows with one probability ~1 and the rest down to 1e-30 — the per-tile ranges of dS), tiny and large output gradients.
+    Stated tolerance 1e-5 of each tensor's max (the f16x3 products' 2^-22 over T-long sums); two runs are bit-equal (no atomics)."""
+    from picopose_amd import autograd as ag
+    from picopose_amd import ops
+
+    hd = 64
+    assert ag.FUSED_ATTENTION and ops.PRECISION == "f16x3"
+    g = torch.Generator().manual_seed(100 + T)
+    qkv = torch.randn(B * T, 3 * heads * hd, generator=g)
+    qkv[:, :2 * heads * hd] *= qk_gain
+    w = torch.randn(B * T, heads * hd, generator=g) * dout_gain
+    w[::3] *= 1e-3                                              # rows of very different gradient size
+
+    def ref(x):
+        q, k, v = x.view(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        return (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * T, heads * hd)
+
+    xr = qkv.double().requires_grad_(True)
+    yr = ref(xr)
+    (yr * w.double()).sum().backward()
+    runs = []
+    for _ in range(2):
+        x = qkv.clone().cuda().requires_grad_(True)
+        y = ag._Attention.apply(x, B, T, heads, hd)
+        (y * w.cuda()).sum().backward()
+        runs.append((y.detach().cpu(), x.grad.cpu()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    y, dx = runs[0]
+    assert torch.isfinite(dx).all()
+    ey = float((y.double() - yr.detach()).abs().max() / yr.detach().abs().max())
+    print(f"T={T}: out {ey:.2e}")
+    assert ey <= 1e-5
+    C = heads * hd
+    for i, nm in enumerate("qkv"):
+        a, b = dx[:, i * C:(i + 1) * C].double(), xr.grad[:, i * C:(i + 1) * C]
+        den = b.abs().max() if float(b.abs().max()) > 0 else xr.grad.abs().max()      # (T = 1: dq = dk = 0 exactly)
+        e = float((a - b).abs().max() / den)
+        print(f"  d{nm} {e:.2e} of max {float(b.abs().max()):.3e}")
+        assert e <= 1e-5, (nm, e)
+
+
+@gpu
 def test_stage3_adjoint_kernels_against_torch_autograd():
     """The adjoints of csrc/pp_backward3.hip one by one against torch's autograd on CPU (fp32): BatchNorm in training mode (+ReLU),
     bilinear resize (align_corners), ConvTranspose(kernel = stride), the feature warp, the fused correlation pyramid + lookup (against
