@@ -230,6 +230,11 @@ typedef struct PpGemmDesc {
     int c_relu;            /* C_hl holds split(max(out, 0)): the consumer's input ReLU folded in        */
     const float* alpha_dev;  /* optional DEVICE scalars: alpha is multiplied by alpha_dev[0] (and alpha_dev2[0]) when the kernel   */
     const float* alpha_dev2; /* runs — the inverse range scales of backward operands, chosen on the device (pp_pow2_scale_ws)      */
+    /* K slices (weight gradients: few output tiles over a very long K leave most CUs idle).  ksplit = S > 1, both operands pre-split,
+     * dense, M % 256 == 0, K % (64 S) == 0: C holds S*M rows — rows s*M .. of it receive the product over k in [s K/S, (s+1) K/S)
+     * (one launch of S * tiles work items); add the S slices in index order (pp_sum_slices).  No bias / activation / residual.  */
+    int ksplit;
+    int ks_rows;             /* filled in by pp_gemm (the rows of one slice)                                                       */
 } PpGemmDesc;
 
 int pp_gemm(const PpGemmDesc* desc, void* stream);
@@ -255,6 +260,9 @@ int pp_split_activation_ld(const float* x, long long batch_stride, int B, int P,
 int pp_pow2_scale_ws(const float* x, long long n, float* scale2, float* partials, void* stream);
 int pp_split_scaled_t(const float* x, long long rows, int ld, int C, const float* scale, void* out, int terms, void* stream);
 int pp_split_transpose_t(const float* x, long long rows, int cols, int ld, const float* scale, void* out, int terms, void* stream);
+/* ... with an operand row pitch ld_out >= rows (% 8 == 0), the k in [rows, ld_out) zero: K padded to a multiple of the K slices */
+int pp_split_transpose_ld(const float* x, long long rows, int cols, int ld, const float* scale, void* out, long long ld_out, int terms,
+                          void* stream);
 /* The K-major im2col of an NHWC image (pp_im2col_t_nhwc below) written straight as the engine operand: (ksize^2 C) operand rows with
  * K = B Ho Wo pixels (a multiple of 8) — the B operand of a convolution's weight gradient dW = dz^T colT without the fp32 matrix. */
 int pp_im2col_t_operand(const float* x, int B, int H, int W, int C, int ksize, int stride, int pad, void* out, int terms, void* stream);

@@ -39,6 +39,7 @@ class PpGemmDesc(ctypes.Structure):
         ("a_hl_bytes", ctypes.c_longlong), ("b_hl_bytes", ctypes.c_longlong),
         ("C_hl", ctypes.c_void_p), ("ldc_h", ctypes.c_int), ("c_relu", ctypes.c_int),
         ("alpha_dev", ctypes.c_void_p), ("alpha_dev2", ctypes.c_void_p),
+        ("ksplit", ctypes.c_int), ("ks_rows", ctypes.c_int),
     ]
 
 
@@ -166,6 +167,7 @@ def lib():
         L.pp_pow2_scale_ws.argtypes = [vp, ll, vp, vp, vp]
         L.pp_split_scaled_t.argtypes = [vp, ll, i32, i32, vp, vp, i32, vp]
         L.pp_split_transpose_t.argtypes = [vp, ll, i32, i32, vp, vp, i32, vp]
+        L.pp_split_transpose_ld.argtypes = [vp, ll, i32, i32, vp, vp, ll, i32, vp]
         L.pp_im2col_t_operand.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
         L.pp_split_with_scale_t.argtypes = [vp, ll, i32, vp, vp, vp]
         L.pp_batchnorm_train_backward_workspace_bytes.restype = sz

@@ -107,10 +107,18 @@ def _mm_tn(a, b, ra=True, rb=True, sa=None):
     R, M = a.shape
     N = b.shape[1]
     tiles = -(-M // 128) * -(-N // 128)
-    if ops.operands_ok(M, N, R) and tiles > 24 and a.stride(1) == 1 and b.stride(1) == 1:
-        sa = sa if sa is not None else _scale_of(a, ra)
-        sb = _scale_of(b, rb)
-        return ops.matmul_operands(ops.split_transposed(a, sa), ops.split_transposed(b, sb), alpha_dev=_inv(sa, sb))
+    if ops.operands_ok(M, N, R) and a.stride(1) == 1 and b.stride(1) == 1:
+        # few output tiles over the long K: K slices inside ONE engine launch (ops.ksplit_choice: a function of the shape; the slice's
+        # rows must be whole tiles — M % 256 — so a product with only N % 256 == 0 is taken transposed)
+        swap = M % 256 != 0 and N % 256 == 0
+        S, kp = ops.ksplit_choice(N, M, R) if swap else ops.ksplit_choice(M, N, R)
+        if (tiles > 24 or S > 1) and max(M, N) * kp < 2 ** 30:
+            sa = sa if sa is not None else _scale_of(a, ra)
+            sb = _scale_of(b, rb)
+            A, Bt = ops.split_transposed(a, sa, k_pad=kp), ops.split_transposed(b, sb, k_pad=kp)
+            if swap:
+                return ops.matmul_operands(Bt, A, alpha_dev=_inv(sa, sb), ksplit=S).t().contiguous()
+            return ops.matmul_operands(A, Bt, alpha_dev=_inv(sa, sb), ksplit=S)
     return _mm(a.t().contiguous(), b, ra=ra, rb=rb)
 
 
@@ -818,7 +826,10 @@ class _Conv2d(torch.autograd.Function):
                 A = ops.split_transposed(dz.view(rows, Cout), s)
                 Bt = ops.Split.empty(k * k * Cx, rows, x.device)
                 _lib.check(_lib.lib().pp_im2col_t_operand(_p(x), B, H, W, Cx, k, 1, k // 2, _p(Bt.hl), Bt.terms, _lib.stream_ptr()), "pp_im2col_t_operand")
-                dwp = ops.matmul_operands(A, Bt, alpha_dev=_inv(s))
+                if Cout % 256 != 0 and (k * k * Cx) % 256 == 0:     # K slices need whole tile rows per slice: take the product transposed
+                    dwp = ops.matmul_operands(Bt, A, alpha_dev=_inv(s), ksplit=ops.ksplit_choice(k * k * Cx, Cout, rows, can_pad=False)[0]).t().contiguous()
+                else:
+                    dwp = ops.matmul_operands(A, Bt, alpha_dev=_inv(s), ksplit=ops.ksplit_choice(Cout, k * k * Cx, rows, can_pad=False)[0])
             else:
                 colT = torch.empty(k * k * Cx, rows, dtype=torch.float32, device=x.device)
                 _lib.check(_lib.lib().pp_im2col_t_nhwc(_p(x), B, H, W, Cx, k, 1, k // 2, _p(colT), _lib.stream_ptr()), "pp_im2col_t_nhwc")

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__
 // A 64 (rows) x 32 (cols) tile goes through LDS; a thread then owns 8 consecutive rows of one column = one 32-byte operand group.
 template <int TERMS>
 __global__ __launch_bounds__(256) void split_transpose_kernel(const float* __restrict__ x, long long rows, int cols, int ld, const float* __restrict__ scale,
-                                                              _Float16* __restrict__ out) {
+                                                              _Float16* __restrict__ out, long long ld_out) {
     __shared__ float tile[64][33];
     const long long r0 = (long long)blockIdx.x * 64;
     const int c0 = blockIdx.y * 32;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const float* __res
     }
     __syncthreads();
     const int c = threadIdx.x >> 3, g = threadIdx.x & 7;       // column of the tile, group of 8 rows
-    if (c0 + c < cols && r0 + 8 * g < rows) {                  // (rows % 8 == 0: a group is in or out as a whole)
+    if (c0 + c < cols && r0 + 8 * g < ld_out) {                // (rows % 8 == 0: a group is in or out as a whole; [rows, ld_out) is zeros)
         h8 hh, ll;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const float* __res
             hh[k] = h;
             ll[k] = (_Float16)fminf(fmaxf(v - (float)h, -65504.f), 65504.f);
         }
-        _Float16* o = out + ((long long)(c0 + c) * rows + r0 + 8 * g) * TERMS;
+        _Float16* o = out + ((long long)(c0 + c) * ld_out + r0 + 8 * g) * TERMS;
         *(h8*)o = hh;
         if (TERMS == 2) *(h8*)(o + 8) = ll;
     }
@@ -471,13 +471,20 @@ int pp_im2col_t_operand(const float* x, int B, int H, int W, int C, int ksize, i
     return pp_last_launch();
 }
 
-int pp_split_transpose_t(const float* x, long long rows, int cols, int ld, const float* scale, void* out, int terms, void* stream) {
-    if (!x || !out || rows <= 0 || cols <= 0 || ld < cols || rows % 8 != 0 || (terms != 1 && terms != 2) || ((uintptr_t)out & 15) != 0) return PP_EINVAL;
-    const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((cols + 31) / 32));
+int pp_split_transpose_ld(const float* x, long long rows, int cols, int ld, const float* scale, void* out, long long ld_out, int terms,
+                          void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0 || ld < cols || rows % 8 != 0 || ld_out < rows || ld_out % 8 != 0 || (terms != 1 && terms != 2) ||
+        ((uintptr_t)out & 15) != 0)
+        return PP_EINVAL;
+    const dim3 grid((unsigned)((ld_out + 63) / 64), (unsigned)((cols + 31) / 32));
     if (grid.y > 65535) return PP_EINVAL;
-    if (terms == 2) hipLaunchKernelGGL(split_transpose_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, scale, (_Float16*)out);
-    else hipLaunchKernelGGL(split_transpose_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, scale, (_Float16*)out);
+    if (terms == 2) hipLaunchKernelGGL(split_transpose_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, scale, (_Float16*)out, ld_out);
+    else hipLaunchKernelGGL(split_transpose_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, scale, (_Float16*)out, ld_out);
     return pp_last_launch();
+}
+
+int pp_split_transpose_t(const float* x, long long rows, int cols, int ld, const float* scale, void* out, int terms, void* stream) {
+    return pp_split_transpose_ld(x, rows, cols, ld, scale, out, rows, terms, stream);
 }
 
 // slabs of at least 64 rows, enough of them to fill the chip whatever the width (a 256-column matrix is ONE column block: the

@@ -1084,6 +1084,15 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         d.a_hl_bytes = a_elems * eb;
         d.b_hl_bytes = b_elems * eb;
     }
+    d.ks_rows = 0;
+    if (d.ksplit > 1) {   // K slices as extra tile rows (include/picopose_hip.h): from here on d is the launch's view, M = S rows-blocks of K / S
+        if (!asplit || d.conv_kh != 0 || d.M % 256 != 0 || d.K % (64 * d.ksplit) != 0 || d.bias || d.gamma || d.residual || d.residual2 ||
+            d.act != 0 || d.C_hl || d.shuffle_r != 0 || !d.C || (long long)d.M * d.ksplit >= (1LL << 31))
+            return PP_EINVAL;
+        d.ks_rows = d.M;
+        d.M *= d.ksplit;
+        d.K /= d.ksplit;
+    }
     if (d.B_hl && (d.b_kn || d.ldb % 8 != 0 || d.K % 8 != 0 || z != 1 || !(d.b_scale > 0.f))) return PP_EINVAL;
     if (d.B_hl && !split && !f16) d.B_hl = nullptr;  // unaligned layer: the fp32 kernel reads d.B
     // Tile configurations ("cfg", PP_GEMM_FORCE_CFG numbering).  Both operands pre-split (pp_gemm_u_kernel.h): 0 = 128x128 tile, two

@@ -67,13 +67,14 @@ __device__ __forceinline__ f32x4 pp_mfma16(const h8 a, const h8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// MODE 0: dense A; 1: convolution, channel-slice-major K order (Cin a multiple of the K tile); 2: convolution, natural K order
+// MODE 0: dense A (3: dense, K slices as extra tile rows — PpGemmDesc.ksplit); 1: convolution, channel-slice-major K order (Cin a multiple of the K tile); 2: convolution, natural K order
 // (any Cin % 8 == 0: the 8 k of a lane's chunk share a tap)
 // VEC: the epilogue's vector conditions hold (pp_gemm_u_vec_ok, checked on the host: N % 8 == 0, aligned rows); the
 // element-wise epilogue lives in its own instantiations (both in one kernel cost 100 registers and spills in the 256-wide tiles)
 template <class T, int MODE, int TERMS, bool VEC>
 __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpGemmDesc d, int gx, int gy) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (it cannot instantiate the LDS-DMA builtins)
+    constexpr bool DENSE = MODE == 0 || MODE == 3, KS = MODE == 3;   // MODE 3: dense with K slices (PpGemmDesc.ksplit)
     constexpr int NW = T::NW, PA = T::PA, PB = T::PB, S = T::S, MI = T::MI, NJ = T::NJ, NIP = MI / 2, NJH = NJ / 2;
     constexpr int KT = 64 / TERMS;       // k per K tile (one 128-byte row segment)
     constexpr int EB = 2 * TERMS;        // operand bytes per element
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
     // range check looks at voffset alone: MODE 1 moves the base back by the largest negative window offset (pad rows + pad
     // pixels) so that every voffset is >= 0; past the end of the workgroup's tile list the descriptor has zero records.
     const long long abias = MODE == 1 ? ((long long)d.conv_pad * d.conv_w + d.conv_pad) * d.lda : 0;   // elements
-    const bool ktail = MODE == 0 && d.K % KT != 0;
+    const bool ktail = DENSE && d.K % KT != 0;
     unsigned tmask = 0u;   // MODE 0, K % KT != 0: all-ones in the lanes whose chunk of the current K tile lies past K
 
     // ---- fetch side: addressing state of the tile the DMA stream is in
@@ -127,8 +128,12 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             const int m = m0_ + (j * NW + w) * 8 + lr;                                                               \
             const bool ok = m < d.M;                                                                                 \
             long long base = ok ? (long long)m * d.lda : 0;                                                          \
+            if (KS && ok) { /* K slices: tile rows s M .. are slice s of the real rows (d.K = its length) */ \
+                const int sl = m0_ / d.ks_rows;                                                                      \
+                base = (long long)(m - sl * d.ks_rows) * d.lda + (long long)sl * d.K;                                \
+            }                                                                                                        \
             unsigned mask = ok ? 1u : 0u;                                                                            \
-            if (MODE != 0) {                                                                                         \
+            if (!DENSE) {                                                                                         \
                 mask = 0u;                                                                                           \
                 int oy = 0, ox = 0;                                                                                  \
                 if (ok) {                                                                                            \
@@ -153,13 +158,14 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             }                                                                                                        \
             /* MODE 0: an invalid row is an out-of-range offset; MODE 1: offsets relative to the biased base (>= 0), amask = the */ \
             /* INVALID taps (one v_bfe_i32 turns the tap's bit into the all-ones mask); MODE 2: as computed              */ \
-            abyte[j] = MODE == 0 ? (ok ? (unsigned)(base * EB) + cbyte : 0xFFFFFFFFu)                                \
+            abyte[j] = DENSE ? (ok ? (unsigned)(base * EB) + cbyte : 0xFFFFFFFFu)                                \
                                  : (unsigned)((base + (MODE == 1 ? abias : 0)) * EB) + cbyte;                        \
             amask[j] = MODE == 1 ? ~mask : mask;                                                                     \
         }                                                                                                            \
         _Pragma("unroll") for (int j = 0; j < PB; ++j) {                                                             \
             const int nb = n0_ + pp_wperm((j * NW + w) * 8 + lr);   /* LDS weight rows are permuted: pp_gemm_dev.h */  \
-            bbyte[j] = nb < d.N ? (unsigned)((long long)nb * d.ldb * EB) + cbyte : 0xFFFFFFFFu;                      \
+            const long long koff_ = KS ? (long long)(m0_ / d.ks_rows) * d.K : 0;          \
+            bbyte[j] = nb < d.N ? (unsigned)(((long long)nb * d.ldb + koff_) * EB) + cbyte : 0xFFFFFFFFu;            \
         }                                                                                                            \
         fkt = 0;                                                                                                     \
         ctap = cky = ckx = cci = 0;                                                                                  \
@@ -198,8 +204,8 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
         } else {
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)((const char*)d.A_hl - abias * EB), 0, ftile < chunk1 ? (int)(d.a_hl_bytes + abias * EB) : 0, 0x00020000);
-            const unsigned v = MODE == 0 ? abyte[j] | tmask : abyte[j] | (unsigned)__builtin_amdgcn_sbfe((int)amask[j], (unsigned)ctap, 1u);
-            const int so = MODE == 0 ? fkt * 128 : ((cky * d.conv_w + ckx) * d.lda + cci) * EB;
+            const unsigned v = DENSE ? abyte[j] | tmask : abyte[j] | (unsigned)__builtin_amdgcn_sbfe((int)amask[j], (unsigned)ctap, 1u);
+            const int so = DENSE ? fkt * 128 : ((cky * d.conv_w + ckx) * d.lda + cci) * EB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, PP_STUDY_OFF(v), so, 0, 0);
         }
     };
@@ -212,8 +218,8 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
             __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, dst, 16, PP_STUDY_OFF(off_b2(j)), 0, 0, 0);
         } else {
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)d.B_hl, 0, ftile < chunk1 ? (int)d.b_hl_bytes : 0, 0x00020000);
-            const unsigned v = MODE == 0 ? bbyte[j] | tmask : bbyte[j];
-            const int so = MODE == 0 ? fkt * 128 : (ctap * d.conv_cin + cci) * EB;
+            const unsigned v = DENSE ? bbyte[j] | tmask : bbyte[j];
+            const int so = DENSE ? fkt * 128 : (ctap * d.conv_cin + cci) * EB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, PP_STUDY_OFF(v), so, 0, 0);
         }
     };
@@ -989,6 +995,10 @@ template <class T, int TERMS, bool VEC>
 static int pp_u_launch_tile(const PpGemmDesc& d, int mode, int slots, hipStream_t st) {
     if (mode == 0) return pp_u_launch_one<T, 0, TERMS, VEC>(d, slots, st);
     if (mode == 1) return pp_u_launch_one<T, 1, TERMS, VEC>(d, slots, st);
+    if (mode == 3) {   // K slices: the hl format with the vector epilogue only (weight gradients of the training step)
+        if constexpr (TERMS == 2 && VEC) return pp_u_launch_one<T, 3, TERMS, VEC>(d, slots, st);
+        else return PP_EINVAL;
+    }
     return pp_u_launch_one<T, 2, TERMS, VEC>(d, slots, st);
 }
 

@@ -6,7 +6,7 @@ int pp_gemm_u_launch_t2(const PpGemmDesc& d, int tile, int mode, bool vec, int c
 
 int pp_gemm_u_mode(const PpGemmDesc& d, int terms) {
     const int kt = 64 / terms;
-    if (d.conv_kh == 0) return 0;
+    if (d.conv_kh == 0) return d.ks_rows > 0 ? 3 : 0;
     return (d.conv_cin % kt == 0 && d.conv_kh * d.conv_kw <= 32) ? 1 : 2;
 }
 

@@ -290,15 +290,39 @@ def split_scaled(x2d, s2):
     return sp
 
 
-def split_transposed(x2d, s2=None):
+def split_transposed(x2d, s2=None, k_pad=None):
     """x2d (rows, cols) fp32 (row pitch free; rows % 8 == 0) -> Split (cols, rows) of s2[0] * x2d^T (s2 None: 1): the K-major operands of
-    dW = dz^T x without a transposed fp32 copy."""
+    dW = dz^T x without a transposed fp32 copy.  k_pad >= rows (% 8 == 0): Split (cols, k_pad), the k past `rows` zero (K slices)."""
     rows, cols = x2d.shape
     assert x2d.stride(1) == 1 and rows % 8 == 0
-    sp = Split.empty(cols, rows, x2d.device)
-    _lib.check(_lib.lib().pp_split_transpose_t(_p(x2d), rows, cols, x2d.stride(0), _p(s2), _p(sp.hl), sp.terms, _lib.stream_ptr()),
-               "pp_split_transpose_t")
+    k_pad = rows if k_pad is None else k_pad
+    sp = Split.empty(cols, k_pad, x2d.device)
+    _lib.check(_lib.lib().pp_split_transpose_ld(_p(x2d), rows, cols, x2d.stride(0), _p(s2), _p(sp.hl), k_pad, sp.terms, _lib.stream_ptr()),
+               "pp_split_transpose_ld")
     return sp
+
+
+KSPLIT = os.environ.get("PP_KSPLIT", "1") != "0"
+
+
+def ksplit_choice(M, N, K, can_pad=True):
+    """(S, K_pad) for a product of two K-major operands with few output tiles over a long K (weight gradients): S K-slices run as S x tiles
+    work items of ONE engine launch (PpGemmDesc.ksplit), K padded with zeros to a multiple of 64 S when the producer can
+    (can_pad).  Chosen from the shape only (a cost model in units of k per work item: rounds over the 256 CUs x (slice length + a
+    tile's fixed cost)), so the summation order is a function of the shape.  S = 1: no slices."""
+    if not KSPLIT or M % 256 != 0:
+        return 1, K
+    t = -(-M // 256) * -(-N // 256)
+    base = -(-t // 256) * (K + 512)
+    best = (base, 1, K)
+    for S in range(2, 65):
+        kp = -(-K // (64 * S)) * 64 * S
+        if (kp != K and not can_pad) or kp // S < 256 or S * M * N * 4 > (1 << 28):
+            continue
+        cost = -(-S * t // 256) * (kp // S + 512)
+        if cost < best[0]:
+            best = (cost, S, kp)
+    return (best[1], best[2]) if best[0] <= 0.8 * base else (1, K)      # the partial sums have to be paid for: 20 % at least
 
 
 def operands_ok(M, N, K):
@@ -306,15 +330,25 @@ def operands_ok(M, N, K):
     return presplit() and PRECISION == "f16x3" and M >= 64 and N >= 64 and K % 8 == 0 and M * K < 2 ** 30 and N * K < 2 ** 30
 
 
-def matmul_operands(A, Bt, alpha_dev=(), out=None):
+def matmul_operands(A, Bt, alpha_dev=(), out=None, ksplit=1):
     """A (M,K) @ Bt (N,K)^T for two Splits (activation scale): fp32 (M,N).  alpha_dev: up to two device scalars the result is
-    multiplied by inside the launch (PpGemmDesc.alpha_dev: the inverse range scales of the operands)."""
+    multiplied by inside the launch (PpGemmDesc.alpha_dev: the inverse range scales of the operands).  ksplit = S > 1: the S K-slices
+    as one launch into (S, M, N), added in index order (K % (64 S) == 0, M % 256 == 0: ksplit_choice)."""
     (M, K), (N, K2) = A.shape, Bt.shape
     assert K == K2
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=A.device)
     assert out.stride(1) == 1
     ad = list(alpha_dev) + [None, None]
+    if ksplit > 1:
+        part = torch.empty(ksplit, M, N, dtype=torch.float32, device=A.device)
+        _run(_desc(A_hl=_p(A.hl), B_hl=_p(Bt.hl), b_scale=4.0, C=_p(part), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, prec=_PREC[PRECISION],
+                   alpha_dev=_p(ad[0]), alpha_dev2=_p(ad[1]), ksplit=ksplit, _keep=(A.hl, Bt.hl, part)))
+        tgt = out if out.is_contiguous() else torch.empty(M, N, dtype=torch.float32, device=A.device)
+        _lib.check(_lib.lib().pp_sum_slices(_p(part), ksplit, M, N, None, 0, _p(tgt), _lib.stream_ptr()), "pp_sum_slices")
+        if tgt is not out:
+            out.copy_(tgt)
+        return out
     _run(_desc(A_hl=_p(A.hl), B_hl=_p(Bt.hl), b_scale=4.0, C=_p(out), M=M, N=N, K=K, lda=K, ldb=K, ldc=out.stride(0), prec=_PREC[PRECISION],
                alpha_dev=_p(ad[0]), alpha_dev2=_p(ad[1]), _keep=(A.hl, Bt.hl)))
     return out

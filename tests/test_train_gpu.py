@@ -568,6 +568,37 @@ def test_fused_attention_forward_and_adjoint_against_float64(B, T, heads, qk_gai
 
 
 @gpu
+@pytest.mark.parametrize("R,M,N", [(8224, 768, 768), (8224, 3072, 768), (32768, 256, 2304), (16384, 192, 2304), (4104, 256, 256), (8224, 768, 200), (8224, 192, 200)])
+def test_weight_gradient_products_with_k_slices_against_float64(R, M, N):
+    """dW = dz^T x (autograd._mm_tn) when the output has few tiles and K = the rows of the batch is long: the K slices run as extra tile rows
+    of ONE engine launch (PpGemmDesc.ksplit, K padded with zeros to a multiple of the slices) and are added in index order.  Against float64
+    (1e-5 of the result's max: 2^-22 products over K-long sums), equal to the unsliced launch within fp32 summation order, and the same
+    bits on every run.  (16384, 192, 2304): M is not a multiple of 256, the product is taken transposed; (8224, 192, 200): no slices possible."""
+    from picopose_amd import autograd as ag
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(R + M)
+    a = (torch.randn(R, M, generator=g) * 1e-4).cuda()            # a gradient: range-normalised on the way in
+    b = torch.randn(R, N, generator=g).cuda()
+    swap = M % 256 != 0 and N % 256 == 0
+    S, kp = ops.ksplit_choice(N, M, R) if swap else ops.ksplit_choice(M, N, R)
+    print(f"R={R} M={M} N={N}: S={S} K padded to {kp}")
+    assert (S > 1) == (M % 256 == 0 or N % 256 == 0)
+    want = a.double().t() @ b.double()
+    got = ag._mm_tn(a, b, rb=False)
+    assert torch.equal(got, ag._mm_tn(a, b, rb=False))
+    e = float((got.double() - want).abs().max() / want.abs().max())
+    print(f"  vs float64 {e:.2e}")
+    assert e <= 1e-5
+    try:
+        ops.KSPLIT = False
+        plain = ag._mm_tn(a, b, rb=False)
+    finally:
+        ops.KSPLIT = True
+    assert float((got - plain).abs().max() / want.abs().max()) <= 5e-6
+
+
+@gpu
 def test_stage3_adjoint_kernels_against_torch_autograd():
     """The adjoints of csrc/pp_backward3.hip one by one against torch's autograd on CPU (fp32): BatchNorm in training mode (+ReLU),
     bilinear resize (align_corners), ConvTranspose(kernel = stride), the feature warp, the fused correlation pyramid + lookup (against
