@@ -26,6 +26,7 @@ from .utils.torch_utils import calc_pred_Ms
 
 
 # One pass of the DPT head over [selected templates ; query crops] instead of one pass each (PP_BATCH_DPT=0: two passes, A/B)
+BATCH_VIT_TRAIN = os.environ.get("PP_BATCH_VIT_TRAIN", "1") != "0"
 BATCH_DPT = os.environ.get("PP_BATCH_DPT", "1") != "0"
 
 
@@ -241,8 +242,16 @@ class Net(nn.Module):
             kp = self.compute_keypoint_data(end_points)
         with torch.set_grad_enabled(live):
             kw = dict(last_block_fn=ag.last_block_forward if live else None, all_blocks=wide, embed_fn=ag.embed_tokens if wide else None)
-            real_tok, (h0, w0) = fe.forward_tokens(end_points["real_rgb"], **kw)
-            tem_tok, _ = fe.forward_tokens(end_points["tem_rgb"], **kw)
+            if BATCH_VIT_TRAIN and end_points["real_rgb"].shape == end_points["tem_rgb"].shape:
+                # ONE pass over [real ; template] crops: the ViT has no batch statistics and a GEMM row does not depend on the other rows,
+                # so every token keeps its bits; twice the rows per launch fill the engine's tile rounds better (8 224 rows are 1.55
+                # rounds of 256 x 256 tiles on the N = 3072 layers, 16 448 are 3.05) and the weight gradients are one product each
+                nb = end_points["real_rgb"].shape[0]
+                both, (h0, w0) = fe.forward_tokens(torch.cat([end_points["real_rgb"], end_points["tem_rgb"]]), **kw)
+                real_tok, tem_tok = [t[:nb] for t in both], [t[nb:] for t in both]
+            else:
+                real_tok, (h0, w0) = fe.forward_tokens(end_points["real_rgb"], **kw)
+                tem_tok, _ = fe.forward_tokens(end_points["tem_rgb"], **kw)
             if live:
                 s_rows, t_rows = infonce_index_rows(tem_tok[-1].shape, kp["src_pts"], kp["tar_pts"])
                 end_points["loss_info"] = (ag.infonce(tem_tok[-1], real_tok[-1], s_rows, t_rows) if s_rows.numel() else
