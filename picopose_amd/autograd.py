@@ -820,16 +820,19 @@ class _Conv2d(torch.autograd.Function):
                 dx = _unscale(dx, s, None)
         if ctx.needs_input_grad[1]:
             tiles = -(-Cout // 128) * -(-(k * k * Cx) // 128)
-            if fused and tiles > 24 and ops.operands_ok(Cout, k * k * Cx, rows):
+            kk = k * k * Cx
+            swap = Cout % 256 != 0 and kk % 256 == 0      # K slices need whole tile rows per slice: take the product transposed
+            S = ops.ksplit_choice(kk, Cout, rows, can_pad=False)[0] if swap else ops.ksplit_choice(Cout, kk, rows, can_pad=False)[0]
+            if fused and (tiles > 24 or S > 1) and ops.operands_ok(Cout, kk, rows) and Cx % 4 == 0:
                 # dz^T as the K-major A operand in one pass (scale, transpose, split); the K-major im2col of x straight as the B
                 # operand (x is a forward activation: in range as it is) — no fp32 im2col matrix, no split pass over it
                 A = ops.split_transposed(dz.view(rows, Cout), s)
-                Bt = ops.Split.empty(k * k * Cx, rows, x.device)
+                Bt = ops.Split.empty(kk, rows, x.device)
                 _lib.check(_lib.lib().pp_im2col_t_operand(_p(x), B, H, W, Cx, k, 1, k // 2, _p(Bt.hl), Bt.terms, _lib.stream_ptr()), "pp_im2col_t_operand")
-                if Cout % 256 != 0 and (k * k * Cx) % 256 == 0:     # K slices need whole tile rows per slice: take the product transposed
-                    dwp = ops.matmul_operands(Bt, A, alpha_dev=_inv(s), ksplit=ops.ksplit_choice(k * k * Cx, Cout, rows, can_pad=False)[0]).t().contiguous()
+                if swap:
+                    dwp = ops.matmul_operands(Bt, A, alpha_dev=_inv(s), ksplit=S).t().contiguous()
                 else:
-                    dwp = ops.matmul_operands(A, Bt, alpha_dev=_inv(s), ksplit=ops.ksplit_choice(Cout, k * k * Cx, rows, can_pad=False)[0])
+                    dwp = ops.matmul_operands(A, Bt, alpha_dev=_inv(s), ksplit=S)
             else:
                 colT = torch.empty(k * k * Cx, rows, dtype=torch.float32, device=x.device)
                 _lib.check(_lib.lib().pp_im2col_t_nhwc(_p(x), B, H, W, Cx, k, 1, k // 2, _p(colT), _lib.stream_ptr()), "pp_im2col_t_nhwc")

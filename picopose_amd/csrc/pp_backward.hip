@@ -419,55 +419,76 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const float* __res
 // stored or re-read by a split pass.  A 64 (pixels) x 32 (channels) tile per tap goes through LDS.
 template <int TERMS>
 __global__ __launch_bounds__(256) void im2col_t_operand_kernel(const float* __restrict__ x, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo,
-                                                               long long rows, _Float16* __restrict__ out) {
+                                                               int rows, _Float16* __restrict__ out) {
+    // a block = 64 pixels x 32 channels for ALL taps: the pixel decomposition (three divisions per pixel) is done once, the taps re-read
+    // the same input rows out of L1 / L2; float4 loads along the channels (C % 4 == 0)
     __shared__ float tile[64][33];
-    const int tap = blockIdx.z, ky = tap / k, kx = tap - ky * k;
-    const long long r0 = (long long)blockIdx.x * 64;
-    const int c0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 32;
+    const int lp = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const bool cv = c0 + c4 < C;
+    int iy0[2], ix0[2];
+    long long xb[2];
+    bool ok[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const long long row = r0 + ty + 8 * j;
-        const int c = c0 + tx;
-        float v = 0.f;
-        if (row < rows && c < C) {
-            const int ox = (int)(row % Wo), oy = (int)((row / Wo) % Ho);
-            const long long b = row / ((long long)Wo * Ho);
-            const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((b * H + iy) * W + ix) * C + c] * PP_A_SCALE;
-        }
-        tile[ty + 8 * j][tx] = v;
+    for (int j = 0; j < 2; ++j) {
+        const unsigned row = (unsigned)(r0 + lp + 32 * j);
+        ok[j] = cv && row < (unsigned)rows;
+        const unsigned per = (unsigned)(Ho * Wo), b = row / per, rem = row - b * per, oy = rem / (unsigned)Wo, ox = rem - oy * (unsigned)Wo;
+        iy0[j] = (int)oy * stride - pad;
+        ix0[j] = (int)ox * stride - pad;
+        xb[j] = (long long)b * H * W * C + c0 + c4;
     }
-    __syncthreads();
-    const int c = threadIdx.x >> 3, g = threadIdx.x & 7;
-    if (c0 + c < C && r0 + 8 * g < rows) {
-        h8 hh, ll;
+    const int wc = threadIdx.x >> 3, g = threadIdx.x & 7;
+    const bool wv = c0 + wc < C && r0 + 8 * g < rows;
+    int ky = 0, kx = 0;
+    for (int tap = 0; tap < k * k; ++tap) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float v = tile[8 * g + q][c];
-            const _Float16 h = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-            hh[q] = h;
-            ll[q] = (_Float16)fminf(fmaxf(v - (float)h, -65504.f), 65504.f);
+        for (int j = 0; j < 2; ++j) {
+            const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[j] && iy >= 0 && iy < H && ix >= 0 && ix < W) v = *(const float4*)(x + xb[j] + ((long long)iy * W + ix) * C);
+            float* t = &tile[lp + 32 * j][c4];
+            t[0] = v.x * PP_A_SCALE;
+            t[1] = v.y * PP_A_SCALE;
+            t[2] = v.z * PP_A_SCALE;
+            t[3] = v.w * PP_A_SCALE;
         }
-        _Float16* o = out + (((long long)tap * C + c0 + c) * rows + r0 + 8 * g) * TERMS;
-        *(h8*)o = hh;
-        if (TERMS == 2) *(h8*)(o + 8) = ll;
+        __syncthreads();
+        if (wv) {
+            h8 hh, ll;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float v = tile[8 * g + q][wc];
+                const _Float16 h = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+                hh[q] = h;
+                ll[q] = (_Float16)fminf(fmaxf(v - (float)h, -65504.f), 65504.f);
+            }
+            _Float16* o = out + (((long long)tap * C + c0 + wc) * rows + r0 + 8 * g) * TERMS;
+            *(h8*)o = hh;
+            if (TERMS == 2) *(h8*)(o + 8) = ll;
+        }
+        __syncthreads();
+        if (++kx == k) {
+            kx = 0;
+            ++ky;
+        }
     }
 }
 
 extern "C" {
 
 int pp_im2col_t_operand(const float* x, int B, int H, int W, int C, int ksize, int stride, int pad, void* out, int terms, void* stream) {
-    if (!x || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || (terms != 1 && terms != 2) || ((uintptr_t)out & 15) != 0)
+    if (!x || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || ksize <= 0 || stride <= 0 || pad < 0 || (terms != 1 && terms != 2) ||
+        ((uintptr_t)out & 15) != 0 || ((uintptr_t)x & 15) != 0)
         return PP_EINVAL;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const long long rows = (long long)B * Ho * Wo;
-    if (rows % 8 != 0 || (C + 31) / 32 > 65535 || ksize * ksize > 65535) return PP_EINVAL;
-    const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((C + 31) / 32), (unsigned)(ksize * ksize));
+    if (rows % 8 != 0 || rows >= (1LL << 31) - 64 || (C + 31) / 32 > 65535) return PP_EINVAL;
+    const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((C + 31) / 32));
     if (terms == 2)
-        hipLaunchKernelGGL(im2col_t_operand_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, C, ksize, stride, pad, Ho, Wo, rows, (_Float16*)out);
+        hipLaunchKernelGGL(im2col_t_operand_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, C, ksize, stride, pad, Ho, Wo, (int)rows, (_Float16*)out);
     else
-        hipLaunchKernelGGL(im2col_t_operand_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, C, ksize, stride, pad, Ho, Wo, rows, (_Float16*)out);
+        hipLaunchKernelGGL(im2col_t_operand_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, C, ksize, stride, pad, Ho, Wo, (int)rows, (_Float16*)out);
     return pp_last_launch();
 }
 

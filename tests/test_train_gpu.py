@@ -599,6 +599,24 @@ def test_weight_gradient_products_with_k_slices_against_float64(R, M, N):
 
 
 @gpu
+@pytest.mark.parametrize("B,H,W,C,k", [(2, 16, 16, 64, 3), (3, 8, 24, 40, 3), (1, 16, 8, 128, 7), (2, 8, 8, 36, 1)])
+def test_k_major_im2col_operand_equals_the_split_of_the_unfolded_map(B, H, W, C, k):
+    """pp_im2col_t_operand (the B operand of a convolution's weight gradient: rows (tap, channel), K = the pixels of the batch, written
+    in the engine's operand format) against torch's unfold of the same map, transposed and split by pp_split_transpose_t: bit-equal."""
+    from picopose_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(B * H + C)
+    x = torch.randn(B, H, W, C, generator=g).cuda()
+    rows = B * H * W
+    got = ops.Split.empty(k * k * C, rows, x.device)
+    _lib.check(_lib.lib().pp_im2col_t_operand(x.data_ptr(), B, H, W, C, k, 1, k // 2, got.hl.data_ptr(), got.terms, _lib.stream_ptr()), "pp_im2col_t_operand")
+    col = F.unfold(x.permute(0, 3, 1, 2), k, padding=k // 2)                    # (B, C k k, H W), channel-major rows
+    col = col.view(B, C, k * k, H * W).permute(0, 3, 2, 1).reshape(rows, k * k * C).contiguous()   # (pixels, (tap, channel))
+    want = ops.split_transposed(col)
+    assert torch.equal(got.hl, want.hl)
+
+
+@gpu
 def test_stage3_adjoint_kernels_against_torch_autograd():
     """The adjoints of csrc/pp_backward3.hip one by one against torch's autograd on CPU (fp32): BatchNorm in training mode (+ReLU),
     bilinear resize (align_corners), ConvTranspose(kernel = stride), the feature warp, the fused correlation pyramid + lookup (against
