@@ -352,31 +352,41 @@ __global__ void simvol_backward_kernel(const float* __restrict__ out, const floa
 // dW = dz^T col (its K axis is the rows of the batch).  A 32 x 32 (pixels x channels) tile per tap goes through LDS so that both the
 // reads (channels contiguous) and the writes (rows contiguous) are coalesced.
 __global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__ x, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo,
-                                                       long long rows, float* __restrict__ colT) {
+                                                       int rows, float* __restrict__ colT) {
+    // a block = 32 pixels x 32 channels for ALL taps (the pixel decomposition is done once, in 32-bit arithmetic)
     __shared__ float tile[32][33];
-    const int tap = blockIdx.z, ky = tap / k, kx = tap - ky * k;
-    const long long r0 = (long long)blockIdx.x * 32;
-    const int c0 = blockIdx.y * 32;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    int iy0[4], ix0[4];
+    long long xb[4];
+    bool ok[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const long long row = r0 + ty + 8 * j;
-        const int c = c0 + tx;
-        float v = 0.f;
-        if (row < rows && c < C) {
-            const int ox = (int)(row % Wo), oy = (int)((row / Wo) % Ho);
-            const long long b = row / ((long long)Wo * Ho);
-            const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((b * H + iy) * W + ix) * C + c];
-        }
-        tile[ty + 8 * j][tx] = v;
+        const unsigned row = (unsigned)(r0 + ty + 8 * j);
+        ok[j] = row < (unsigned)rows && c0 + tx < C;
+        const unsigned per = (unsigned)(Ho * Wo), b = row / per, rem = row - b * per, oy = rem / (unsigned)Wo, ox = rem - oy * (unsigned)Wo;
+        iy0[j] = (int)oy * stride - pad;
+        ix0[j] = (int)ox * stride - pad;
+        xb[j] = (long long)b * H * W * C + c0 + tx;
     }
-    __syncthreads();
+    int ky = 0, kx = 0;
+    for (int tap = 0; tap < k * k; ++tap) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = c0 + ty + 8 * j;
-        const long long row = r0 + tx;
-        if (row < rows && c < C) colT[((long long)tap * C + c) * rows + row] = tile[tx][ty + 8 * j];
+        for (int j = 0; j < 4; ++j) {
+            const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+            tile[ty + 8 * j][tx] = (ok[j] && iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[xb[j] + ((long long)iy * W + ix) * C] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + ty + 8 * j;
+            if (r0 + tx < rows && c < C) colT[((long long)tap * C + c) * rows + r0 + tx] = tile[tx][ty + 8 * j];
+        }
+        __syncthreads();
+        if (++kx == k) {
+            kx = 0;
+            ++ky;
+        }
     }
 }
 
@@ -612,9 +622,9 @@ int pp_im2col_t_nhwc(const float* x, int B, int H, int W, int C, int ksize, int 
     if (!x || !colT || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0 || stride <= 0 || pad < 0) return PP_EINVAL;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const long long rows = (long long)B * Ho * Wo;
-    if (rows <= 0 || (rows + 31) / 32 > 0x7FFFFFFFLL || ksize * ksize > 65535) return PP_EINVAL;
-    hipLaunchKernelGGL(im2col_t_kernel, dim3((unsigned)((rows + 31) / 32), (C + 31) / 32, ksize * ksize), dim3(256), 0, (hipStream_t)stream, x, H, W, C,
-                       ksize, stride, pad, Ho, Wo, rows, colT);
+    if (rows <= 0 || rows >= (1LL << 31) - 32) return PP_EINVAL;
+    hipLaunchKernelGGL(im2col_t_kernel, dim3((unsigned)((rows + 31) / 32), (C + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, H, W, C, ksize, stride,
+                       pad, Ho, Wo, (int)rows, colT);
     return pp_last_launch();
 }
 

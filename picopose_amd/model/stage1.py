@@ -123,7 +123,15 @@ class FeatureExtractor(Packed):
         key = (w0, h0)
         if key not in pk["pos"]:
             with torch.no_grad():
-                pk["pos"][key] = self._pos_embed(w0, h0).contiguous()
+                wt = self._pos_wt(w0, h0) if self.training else None
+                if wt is not None:
+                    # training: every optimizer step drops the packing, and torch's bicubic kernel takes 1.7 ms for this small map —
+                    # the same resampling as ONE product with the cached matrix (16 non-zero weights per output cell: the values
+                    # differ from F.interpolate's by the summation order of those 16 terms)
+                    pe = self.dinov2.pos_embed.float()[0]
+                    pk["pos"][key] = torch.cat([pe[:1], wt.t() @ pe[1:]], dim=0).contiguous()
+                else:
+                    pk["pos"][key] = self._pos_embed(w0, h0).contiguous()
         return pk["pos"][key]
 
     # ---- forward -------------------------------------------------------------------------
