@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
 }
 
 // ---- dK, dV: a wave = 32 keys (lane = key column), the workgroup's waves share the staged Q / dO chunks --------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                            const float* __restrict__ lse2, const float* __restrict__ Dg,
                                                            const float* __restrict__ gpair, int T, int heads, float scale,
                                                            float* __restrict__ dqkv) {
