@@ -800,12 +800,21 @@ class _Conv2d(torch.autograd.Function):
             _lib.check(_lib.lib().pp_act_backward(_p(y), _p(dz), dz.numel(), ACT[act], _p(g), _lib.stream_ptr()), "pp_act_backward")
             dz = g                                                        # relu'(z) = [y > 0]
         rows = B * H * W
+        db = colsum(dz.view(-1, Cout)) if has_bias and ctx.needs_input_grad[2] else None
+        Cout0 = Cout
+        if Cout % 8 != 0 and Cout >= 64 and ops.PRECISION == "f16x3":
+            # (the motion encoder's 126-channel convolution: its dz and weights zero-padded to 128 channels take the engine in both
+            # backward products instead of the on-the-fly kernel; the pad rows of dW are dropped)
+            padc = -Cout % 8
+            dz = torch.nn.functional.pad(dz, (0, padc))
+            w = torch.cat([w, w.new_zeros(padc, Cin, k, k)], dim=0)
+            Cout += padc
         s = _scale_of(dz)                                                 # the gradient operand of both products: ONE scale
         fused = s is not None and Cout % 8 == 0 and rows % 8 == 0 and rows * Cout < 2 ** 30
         dzs = None
         if not fused:
             dzs, s = _ranged(dz)
-        dx = dw = db = None
+        dx = dw = None
         if ctx.needs_input_grad[0]:
             wf = w.flip(2, 3).permute(1, 0, 2, 3)                         # (Cin, Cout, k, k): dx = conv(dz, flipped weights)
             if Cx > Cin:
@@ -844,9 +853,7 @@ class _Conv2d(torch.autograd.Function):
                 else:
                     dwp = _mm_kmajor(dzt, colT)
                 dwp = _unscale(dwp, s, None)                                  # (Cout, k k Cx)
-            dw = dwp.view(Cout, k, k, Cx)[..., :Cin].permute(0, 3, 1, 2).contiguous()
-        if has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dz.view(-1, Cout))
+            dw = dwp.view(Cout, k, k, Cx)[:Cout0, ..., :Cin].permute(0, 3, 1, 2).contiguous()
         return dx, dw, db, None, None
 
 

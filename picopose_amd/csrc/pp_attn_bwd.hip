@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_bwd_d_kernel(const float* __restrict
 }
 
 // ---- dQ: a wave = 32 queries (lane = query column), the workgroup's waves share the staged K / V chunks -------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                           const float* __restrict__ lse2, const float* __restrict__ Dg,
                                                           const float* __restrict__ gpair, int T, int heads, float scale,
                                                           float* __restrict__ dqkv) {

@@ -67,17 +67,31 @@ __global__ __launch_bounds__(256) void colsum_part4_kernel(const float* __restri
     }
 }
 
-// fold of the slabs with four slab lanes per column (slabs sl, sl + 4, ... each, then the lanes in order): the one-thread-per-column
-// form above walks up to 512 dependent-latency loads on a single workgroup when the matrix is 256 columns wide
+// fold of the slabs with SIXTEEN slab lanes per column (slabs sl, sl + 16, ... each with eight loads in flight, then the lanes in
+// order): a workgroup = 16 columns.  (One thread per column walks up to 512 dependent-latency loads; four lanes still took 17 us.)
 __global__ __launch_bounds__(256) void colsum_final4_kernel(const float* __restrict__ part, int slabs, int cols, float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int q = threadIdx.x & 63, sl = threadIdx.x >> 6, c = blockIdx.x * 64 + q;
+    __shared__ float red[16][17];
+    const int q = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + q;
     float s = 0.f;
-    if (c < cols)
-        for (int k = sl; k < slabs; k += 4) s += part[(size_t)k * cols + c];
+    if (c < cols) {
+        int k = sl;
+        for (; k + 112 < slabs; k += 128) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + 16 * j) * cols + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; k < slabs; k += 16) s += part[(size_t)k * cols + c];
+    }
     red[sl][q] = s;
     __syncthreads();
-    if (sl == 0 && c < cols) out[c] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+    if (sl == 0 && c < cols) {
+        float t = red[0][q];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) t += red[j][q];
+        out[c] = t;
+    }
 }
 
 __device__ __forceinline__ float act_fwd(float z, int act) {
@@ -536,7 +550,7 @@ int pp_colsum(const float* x, long long rows, int cols, int ld, float* out, void
     if (cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0) {
         const int per = (int)((rows + slabs - 1) / slabs);
         hipLaunchKernelGGL(colsum_part4_kernel, dim3((cols + 255) / 256, slabs), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, per, (float*)workspace);
-        hipLaunchKernelGGL(colsum_final4_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, slabs, cols, out);
+        hipLaunchKernelGGL(colsum_final4_kernel, dim3((cols + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, slabs, cols, out);
         return pp_last_launch();
     }
     hipLaunchKernelGGL(colsum_part_kernel, dim3((cols + 255) / 256, slabs), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, (float*)workspace);

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(const float* __restr
 // One wave per pixel: the (2r+2)^2 table positions per level are visited one after the other, lanes over channels.
 constexpr int CLB_MAXL = 3, CLB_TW = 8;   // levels, table width for r <= 3
 
-template <bool FIXED>
+template <bool FIXED, bool SCATTER = true>
 __global__ __launch_bounds__(256) void corr_lookup_backward_kernel(const float* __restrict__ f1, const float* __restrict__ f2l0,
                                                                    const float* __restrict__ f2l1, const float* __restrict__ f2l2,
                                                                    const float* __restrict__ flow, const float* __restrict__ dout, int H,
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void corr_lookup_backward_kernel(const float* 
                     const float u = a[c], v = qv[c];
                     dot = fmaf(u, v, dot);
                     acc1[k] = fmaf(dt, v, acc1[k]);
-                    if (dt != 0.f) scatter_add<FIXED>(df2, dq + c, dt * u);
+                    if (SCATTER && dt != 0.f) scatter_add<FIXED>(df2, dq + c, dt * u);
                 }
             }
             const float val = wave_sum(dot) * inv_sqrt_c;
@@ -339,6 +339,118 @@ __global__ __launch_bounds__(256) void corr_lookup_backward_kernel(const float* 
     if (lane == 0) {
         dflow[((size_t)b * H * W + p) * 2] = dfx;
         dflow[((size_t)b * H * W + p) * 2 + 1] = dfy;
+    }
+}
+
+// The df2 half of the adjoint above with 6 x fewer global atomics (the per-pixel kernel issues one per (pixel, table position, channel):
+// 1.2 G per level at 64 x 64 x 32 images x 256 channels — the L2 takes about one atomic per channel and clock: 2.5 ms per level whatever
+// the flow).  A workgroup (16 waves) owns a 4 x 4 pixel patch and 128 channels.  The 16 windows of a level overlap (smooth flow: a
+// (tw + 3)^2 union against 16 tw^2 visits): each pixel's wave writes its table dt[p, .] into column p of a small LDS matrix D (cells of
+// a (tw + 4)^2 frame anchored at the patch's second pixel x 16 pixels; plain stores — a pixel's positions are distinct cells), then
+// T = D F1 (cells x 128 channels, 16 terms each) is evaluated in registers — thread = (channel, every 8th cell) — and every non-zero
+// entry leaves as ONE global atomic.  A position outside the frame (a flow that tears the patch apart) falls back to the direct
+// atomics.  (LDS float atomics into a cells x channels table were tried first: slower than the kernel they replace.)  fp32,
+// order-dependent in the last bits like that kernel (the deterministic option keeps the per-pixel fixed-point kernel).
+constexpr int CS_CH = 128, CS_CELLS = (CLB_TW + 4) * (CLB_TW + 4);
+
+__global__ __launch_bounds__(1024) void corr_lookup_scatter_kernel(const float* __restrict__ f1, const float* __restrict__ flow,
+                                                                   const float* __restrict__ dout, int H, int W, int C, int L, int r, int ld_flow,
+                                                                   int ld_dout, float inv_sqrt_c, float* __restrict__ df2l0,
+                                                                   float* __restrict__ df2l1, float* __restrict__ df2l2) {
+    __shared__ __attribute__((aligned(16))) float D[CS_CELLS][16];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y, ch0 = blockIdx.z * CS_CH;
+    const int pw = W >> 2, px0 = (blockIdx.x % pw) * 4, py0 = (blockIdx.x / pw) * 4;
+    const int tw = 2 * r + 2, win = 2 * r + 1, twd = tw + 4, ncell = twd * twd;
+    const int mc = threadIdx.x & (CS_CH - 1), mg = threadIdx.x >> 7;     // matrix phase: channel, cell group (8)
+    float fk[16];                                                        // f1 of the patch's 16 pixels at this thread's channel
+#pragma unroll
+    for (int k = 0; k < 16; ++k) fk[k] = f1[((size_t)b * H * W + (size_t)(py0 + (k >> 2)) * W + px0 + (k & 3)) * C + ch0 + mc];
+    const int x = px0 + (wv & 3), y = py0 + (wv >> 2), p = y * W + x;    // pixel phase: this wave's pixel
+    const float* fl = flow + ((size_t)b * H * W + p) * ld_flow;
+    const float* g = dout + ((size_t)b * H * W + p) * ld_dout;
+    const float gx0 = (float)x + fl[0], gy0 = (float)y + fl[1];
+    const float* fa = flow + ((size_t)b * H * W + (size_t)(py0 + 1) * W + px0 + 1) * ld_flow;
+    const float agx = (float)(px0 + 1) + fa[0], agy = (float)(py0 + 1) + fa[1];
+    for (int l = 0; l < L; ++l) {
+        const int Hl = H >> l, Wl = W >> l;
+        const float sc = (float)(1 << l);
+        float* df2 = l == 0 ? df2l0 : (l == 1 ? df2l1 : df2l2);
+        const size_t lb = (size_t)b * Hl * Wl * C;
+        for (int i = threadIdx.x; i < ncell * 16; i += 1024) (&D[0][0])[i] = 0.f;
+        int ax, ay;   // anchor: the window base of pixel (px0 + 1, py0 + 1), two positions up and left
+        {
+            const float rx = roundtrip(agx / sc, Wl), ry = roundtrip(agy / sc, Hl);
+            const float cx = fminf(fmaxf(rx, -(float)(r + 2)), (float)(Wl + r + 1)), cy = fminf(fmaxf(ry, -(float)(r + 2)), (float)(Hl + r + 1));
+            ax = (int)floorf(cx) - r - 2;
+            ay = (int)floorf(cy) - r - 2;
+        }
+        __syncthreads();
+        {
+            const float rx = roundtrip(gx0 / sc, Wl), ry = roundtrip(gy0 / sc, Hl);
+            const float cx = fminf(fmaxf(rx, -(float)(r + 2)), (float)(Wl + r + 1)), cy = fminf(fmaxf(ry, -(float)(r + 2)), (float)(Hl + r + 1));
+            const int bx = (int)floorf(cx) - r, by = (int)floorf(cy) - r;
+            const float wx1 = cx - floorf(cx), wy1 = cy - floorf(cy), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+            float dt = 0.f;
+            int qx = 0, qy = 0;
+            bool far = false;
+            if (lane < tw * tw) {      // lane = table position; dt as in corr_lookup_backward_kernel
+                const int dy_ = lane / tw, dx_ = lane - dy_ * tw;
+                float s = 0.f;
+#pragma unroll
+                for (int cy_ = 0; cy_ < 2; ++cy_)
+#pragma unroll
+                    for (int cx_ = 0; cx_ < 2; ++cx_) {
+                        const int bi = dy_ - cy_, ai = dx_ - cx_;
+                        if (ai >= 0 && ai < win && bi >= 0 && bi < win)
+                            s = fmaf(g[l * win * win + ai * win + bi], (cx_ ? wx1 : wx0) * (cy_ ? wy1 : wy0), s);
+                    }
+                qx = bx + dx_;
+                qy = by + dy_;
+                dt = (qx >= 0 && qx < Wl && qy >= 0 && qy < Hl) ? s * inv_sqrt_c : 0.f;
+                const int lx = qx - ax, ly = qy - ay;
+                if (dt != 0.f) {
+                    if (lx >= 0 && lx < twd && ly >= 0 && ly < twd) D[ly * twd + lx][wv] = dt;
+                    else far = true;
+                }
+            }
+            unsigned long long m = __ballot(far);
+            while (m) {                // positions outside the frame: direct atomics, all lanes over the channels
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float dts = __shfl(dt, src);
+                const int sx = __shfl(qx, src), sy = __shfl(qy, src);
+                const float* a = f1 + ((size_t)b * H * W + p) * C + ch0;
+                float* t = df2 + lb + ((size_t)sy * Wl + sx) * C + ch0;
+                atomicAdd(t + lane, dts * a[lane]);
+                atomicAdd(t + lane + 64, dts * a[lane + 64]);
+            }
+        }
+        __syncthreads();
+        for (int cell = mg; cell < ncell; cell += 8) {
+            const f4 d0 = *(const f4*)&D[cell][0], d1 = *(const f4*)&D[cell][4], d2 = *(const f4*)&D[cell][8], d3 = *(const f4*)&D[cell][12];
+            float acc = d0.x * fk[0];
+            acc = fmaf(d0.y, fk[1], acc);
+            acc = fmaf(d0.z, fk[2], acc);
+            acc = fmaf(d0.w, fk[3], acc);
+            acc = fmaf(d1.x, fk[4], acc);
+            acc = fmaf(d1.y, fk[5], acc);
+            acc = fmaf(d1.z, fk[6], acc);
+            acc = fmaf(d1.w, fk[7], acc);
+            acc = fmaf(d2.x, fk[8], acc);
+            acc = fmaf(d2.y, fk[9], acc);
+            acc = fmaf(d2.z, fk[10], acc);
+            acc = fmaf(d2.w, fk[11], acc);
+            acc = fmaf(d3.x, fk[12], acc);
+            acc = fmaf(d3.y, fk[13], acc);
+            acc = fmaf(d3.z, fk[14], acc);
+            acc = fmaf(d3.w, fk[15], acc);
+            if (acc != 0.f) {          // (a non-zero cell is inside the map: only such positions are stored)
+                const int qx = ax + cell % twd, qy = ay + cell / twd;
+                atomicAdd(df2 + lb + ((size_t)qy * Wl + qx) * C + ch0 + mc, acc);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -457,7 +569,16 @@ static int corr_lookup_backward(const float* f1, const float* const* f2_levels, 
                            levels > 1 ? f2_levels[1] : nullptr, levels > 2 ? f2_levels[2] : nullptr, flow, dout, H, W, C, levels, radius, ld_flow,
                            ld_dout, 1.0f / sqrtf((float)C), df1, df2_levels[0], levels > 1 ? df2_levels[1] : nullptr,
                            levels > 2 ? df2_levels[2] : nullptr, dflow);
-    else
+    else if (H % 4 == 0 && W % 4 == 0 && C % CS_CH == 0 && !getenv("PP_CORR_SCATTER_PER_PIXEL")) {
+        // values / df1 / dflow per pixel without the scatter, df2 by patches through an LDS table (corr_lookup_scatter_kernel)
+        hipLaunchKernelGGL((corr_lookup_backward_kernel<false, false>), dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, f1, f2_levels[0],
+                           levels > 1 ? f2_levels[1] : nullptr, levels > 2 ? f2_levels[2] : nullptr, flow, dout, H, W, C, levels, radius, ld_flow,
+                           ld_dout, 1.0f / sqrtf((float)C), df1, df2_levels[0], levels > 1 ? df2_levels[1] : nullptr,
+                           levels > 2 ? df2_levels[2] : nullptr, dflow);
+        hipLaunchKernelGGL(corr_lookup_scatter_kernel, dim3((H / 4) * (W / 4), B, C / CS_CH), dim3(1024), 0, (hipStream_t)stream, f1, flow, dout, H, W,
+                           C, levels, radius, ld_flow, ld_dout, 1.0f / sqrtf((float)C), (float*)df2_levels[0],
+                           levels > 1 ? (float*)df2_levels[1] : nullptr, levels > 2 ? (float*)df2_levels[2] : nullptr);
+    } else
         hipLaunchKernelGGL(corr_lookup_backward_kernel<false>, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, f1, f2_levels[0],
                            levels > 1 ? f2_levels[1] : nullptr, levels > 2 ? f2_levels[2] : nullptr, flow, dout, H, W, C, levels, radius, ld_flow,
                            ld_dout, 1.0f / sqrtf((float)C), df1, df2_levels[0], levels > 1 ? df2_levels[1] : nullptr,
