@@ -350,13 +350,15 @@ __global__ __launch_bounds__(256) void corr_lookup_backward_kernel(const float* 
 // T = D F1 (cells x 128 channels, 16 terms each) is evaluated in registers — thread = (channel, every 8th cell) — and every non-zero
 // entry leaves as ONE global atomic.  A position outside the frame (a flow that tears the patch apart) falls back to the direct
 // atomics.  (LDS float atomics into a cells x channels table were tried first: slower than the kernel they replace.)  fp32,
-// order-dependent in the last bits like that kernel (the deterministic option keeps the per-pixel fixed-point kernel).
+// order-dependent in the last bits like that kernel; FIXED: T's entries are evaluated in a fixed order and added as 64-bit fixed point
+// with integer atomics — the same bits on every run (the deterministic option).
 constexpr int CS_CH = 128, CS_CELLS = (CLB_TW + 4) * (CLB_TW + 4);
 
+template <bool FIXED>
 __global__ __launch_bounds__(1024) void corr_lookup_scatter_kernel(const float* __restrict__ f1, const float* __restrict__ flow,
                                                                    const float* __restrict__ dout, int H, int W, int C, int L, int r, int ld_flow,
-                                                                   int ld_dout, float inv_sqrt_c, float* __restrict__ df2l0,
-                                                                   float* __restrict__ df2l1, float* __restrict__ df2l2) {
+                                                                   int ld_dout, float inv_sqrt_c, void* __restrict__ df2l0,
+                                                                   void* __restrict__ df2l1, void* __restrict__ df2l2) {
     __shared__ __attribute__((aligned(16))) float D[CS_CELLS][16];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y, ch0 = blockIdx.z * CS_CH;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(1024) void corr_lookup_scatter_kernel(const float* 
     for (int l = 0; l < L; ++l) {
         const int Hl = H >> l, Wl = W >> l;
         const float sc = (float)(1 << l);
-        float* df2 = l == 0 ? df2l0 : (l == 1 ? df2l1 : df2l2);
+        void* df2 = l == 0 ? df2l0 : (l == 1 ? df2l1 : df2l2);
         const size_t lb = (size_t)b * Hl * Wl * C;
         for (int i = threadIdx.x; i < ncell * 16; i += 1024) (&D[0][0])[i] = 0.f;
         int ax, ay;   // anchor: the window base of pixel (px0 + 1, py0 + 1), two positions up and left
@@ -421,9 +423,9 @@ __global__ __launch_bounds__(1024) void corr_lookup_scatter_kernel(const float* 
                 const float dts = __shfl(dt, src);
                 const int sx = __shfl(qx, src), sy = __shfl(qy, src);
                 const float* a = f1 + ((size_t)b * H * W + p) * C + ch0;
-                float* t = df2 + lb + ((size_t)sy * Wl + sx) * C + ch0;
-                atomicAdd(t + lane, dts * a[lane]);
-                atomicAdd(t + lane + 64, dts * a[lane + 64]);
+                const size_t t = lb + ((size_t)sy * Wl + sx) * C + ch0;
+                scatter_add<FIXED>(df2, t + lane, dts * a[lane]);
+                scatter_add<FIXED>(df2, t + lane + 64, dts * a[lane + 64]);
             }
         }
         __syncthreads();
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(1024) void corr_lookup_scatter_kernel(const float* 
             acc = fmaf(d3.w, fk[15], acc);
             if (acc != 0.f) {          // (a non-zero cell is inside the map: only such positions are stored)
                 const int qx = ax + cell % twd, qy = ay + cell / twd;
-                atomicAdd(df2 + lb + ((size_t)qy * Wl + qx) * C + ch0 + mc, acc);
+                scatter_add<FIXED>(df2, lb + ((size_t)qy * Wl + qx) * C + ch0 + mc, acc);
             }
         }
         __syncthreads();
@@ -564,25 +566,32 @@ static int corr_lookup_backward(const float* f1, const float* const* f2_levels, 
     if (ld_dout < levels * (2 * radius + 1) * (2 * radius + 1)) return PP_EINVAL;
     for (int l = 0; l < levels; ++l)
         if (!f2_levels[l] || !df2_levels[l]) return PP_EINVAL;
-    if (fixed)
-        hipLaunchKernelGGL(corr_lookup_backward_kernel<true>, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, f1, f2_levels[0],
-                           levels > 1 ? f2_levels[1] : nullptr, levels > 2 ? f2_levels[2] : nullptr, flow, dout, H, W, C, levels, radius, ld_flow,
-                           ld_dout, 1.0f / sqrtf((float)C), df1, df2_levels[0], levels > 1 ? df2_levels[1] : nullptr,
-                           levels > 2 ? df2_levels[2] : nullptr, dflow);
-    else if (H % 4 == 0 && W % 4 == 0 && C % CS_CH == 0 && !getenv("PP_CORR_SCATTER_PER_PIXEL")) {
-        // values / df1 / dflow per pixel without the scatter, df2 by patches through an LDS table (corr_lookup_scatter_kernel)
-        hipLaunchKernelGGL((corr_lookup_backward_kernel<false, false>), dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, f1, f2_levels[0],
-                           levels > 1 ? f2_levels[1] : nullptr, levels > 2 ? f2_levels[2] : nullptr, flow, dout, H, W, C, levels, radius, ld_flow,
-                           ld_dout, 1.0f / sqrtf((float)C), df1, df2_levels[0], levels > 1 ? df2_levels[1] : nullptr,
-                           levels > 2 ? df2_levels[2] : nullptr, dflow);
-        hipLaunchKernelGGL(corr_lookup_scatter_kernel, dim3((H / 4) * (W / 4), B, C / CS_CH), dim3(1024), 0, (hipStream_t)stream, f1, flow, dout, H, W,
-                           C, levels, radius, ld_flow, ld_dout, 1.0f / sqrtf((float)C), (float*)df2_levels[0],
-                           levels > 1 ? (float*)df2_levels[1] : nullptr, levels > 2 ? (float*)df2_levels[2] : nullptr);
-    } else
-        hipLaunchKernelGGL(corr_lookup_backward_kernel<false>, dim3((H * W + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, f1, f2_levels[0],
-                           levels > 1 ? f2_levels[1] : nullptr, levels > 2 ? f2_levels[2] : nullptr, flow, dout, H, W, C, levels, radius, ld_flow,
-                           ld_dout, 1.0f / sqrtf((float)C), df1, df2_levels[0], levels > 1 ? df2_levels[1] : nullptr,
-                           levels > 2 ? df2_levels[2] : nullptr, dflow);
+    const dim3 pgrid((H * W + 3) / 4, B);
+    const float isc = 1.0f / sqrtf((float)C);
+    const float *f20 = f2_levels[0], *f21 = levels > 1 ? f2_levels[1] : nullptr, *f22 = levels > 2 ? f2_levels[2] : nullptr;
+    void *d0 = df2_levels[0], *d1 = levels > 1 ? df2_levels[1] : nullptr, *d2 = levels > 2 ? df2_levels[2] : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (H % 4 == 0 && W % 4 == 0 && C % CS_CH == 0 && !getenv("PP_CORR_SCATTER_PER_PIXEL")) {
+        // values / df1 / dflow per pixel without the scatter, df2 by patches (corr_lookup_scatter_kernel)
+        const dim3 sgrid((H / 4) * (W / 4), B, C / CS_CH);
+        if (fixed) {
+            hipLaunchKernelGGL((corr_lookup_backward_kernel<true, false>), pgrid, dim3(256), 0, st, f1, f20, f21, f22, flow, dout, H, W, C, levels, radius,
+                               ld_flow, ld_dout, isc, df1, d0, d1, d2, dflow);
+            hipLaunchKernelGGL(corr_lookup_scatter_kernel<true>, sgrid, dim3(1024), 0, st, f1, flow, dout, H, W, C, levels, radius, ld_flow, ld_dout, isc, d0,
+                               d1, d2);
+        } else {
+            hipLaunchKernelGGL((corr_lookup_backward_kernel<false, false>), pgrid, dim3(256), 0, st, f1, f20, f21, f22, flow, dout, H, W, C, levels, radius,
+                               ld_flow, ld_dout, isc, df1, d0, d1, d2, dflow);
+            hipLaunchKernelGGL(corr_lookup_scatter_kernel<false>, sgrid, dim3(1024), 0, st, f1, flow, dout, H, W, C, levels, radius, ld_flow, ld_dout, isc, d0,
+                               d1, d2);
+        }
+    } else if (fixed) {
+        hipLaunchKernelGGL(corr_lookup_backward_kernel<true>, pgrid, dim3(256), 0, st, f1, f20, f21, f22, flow, dout, H, W, C, levels, radius, ld_flow, ld_dout,
+                           isc, df1, d0, d1, d2, dflow);
+    } else {
+        hipLaunchKernelGGL(corr_lookup_backward_kernel<false>, pgrid, dim3(256), 0, st, f1, f20, f21, f22, flow, dout, H, W, C, levels, radius, ld_flow, ld_dout,
+                           isc, df1, d0, d1, d2, dflow);
+    }
     return pp_last_launch();
 }
 

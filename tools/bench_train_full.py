@@ -1,5 +1,5 @@
 """The full training step (scope "full": forward_train under autograd, Loss, backward, SGD) at B pairs, ViT-B: wall time per step, when
-the host had finished launching it, peak memory.  usage: bench_train_full.py [B=32] [steps=6]   (PP_TRAIN_MARK=1: a tiny marker kernel
+the host had finished launching it, peak memory.  usage: bench_train_full.py [B=32] [steps=6]   (PP_DETERMINISTIC=1: autograd.DETERMINISTIC; PP_TRAIN_MARK=1: a tiny marker kernel
 — torch.zeros(1) — before every step, so a kernel trace can be cut into steps)"""
 import os
 import sys
@@ -14,10 +14,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from netcfg import make_train_end_points  # noqa: E402
 
+from picopose_amd import autograd as _ag  # noqa: E402
 from picopose_amd.picopose import Net  # noqa: E402
 from picopose_amd.utils.loss_utils import Loss  # noqa: E402
 from picopose_amd.utils.seeding import calibrated_state_dict  # noqa: E402
 
+_ag.DETERMINISTIC = os.environ.get("PP_DETERMINISTIC", "0") == "1"     # the bit-reproducible scatter adjoints (autograd.DETERMINISTIC)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 vit = "dinov2_vitb14"
