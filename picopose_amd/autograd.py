@@ -1,15 +1,16 @@
 """The backward of the training path: the reference's whole training step under autograd.
 
 `torch.autograd.Function` wrappers whose forward AND backward run on libpicopose_hip.so: the matrix products are pp_gemm
-launches (dgrad = dz @ W, wgrad = dz^T @ x through ops.bmm_nn), the row-wise adjoints are the kernels of csrc/pp_backward.hip.
-torch keeps the graph, allocates tensors, makes the transposed / gathered copies and sums the gradients of a tensor that is used
-twice (the residual stream, the two ViT passes over shared weights: autograd's own accumulation) — nothing else on the gradient
-path is torch arithmetic.
+launches on the pre-split engine (dgrad = dz @ W; wgrad = dz^T @ x with both operands produced K-major in one pass and, when the
+output has few tiles, the K slices of PpGemmDesc.ksplit), attention is fused in both directions (csrc/pp_attn_bwd.hip), the
+row-wise and sampling adjoints are the kernels of csrc/pp_backward.hip / pp_backward3.hip.  torch keeps the graph, allocates
+tensors and sums the gradients of a tensor that is used twice (the residual stream, the taken ViT levels: autograd's own
+accumulation) — nothing else on the gradient path is torch arithmetic.
 
 Scope (exactly the parameters that receive a gradient from `Net.forward_train`), by `Net.train_backward`:
   * "full" (= True, the default): the reference's training step — all ten losses under autograd, every parameter the reference
       trains receives its gradient: the ViT (blocks, patch / cls / position embeddings), `affine_regressor`, the DPT head and the
-      flow decoder (stage 3 in training mode, unfused: im2col + engine GEMM convolutions, training-mode BatchNorm, align_corners
+      flow decoder (stage 3 in training mode, layer by layer: implicit-GEMM convolutions in all three directions, training-mode BatchNorm, align_corners
       resize, ConvTranspose, feature warp, the fused correlation pyramid + lookup, flow / certainty losses — adjoints in
       csrc/pp_backward3.hip);
   * "vit+stage2": only the stage-1 and stage-2 losses (InfoNCE, utils/loss_utils.py:144-175; the three stage-2 losses, :177-186,
