@@ -694,8 +694,20 @@ def main():
         achieved = kbytes / (kern_ms * 1e-3) / 1e9
         prof_dir = next((d for d in ("r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_traffic_stage1.json"))), "r01")
         traffic = traffic_src = None  # HBM bytes per launch from a separate PMC pass (tools/pmc.sh): same kernel, same shape
+        # the committed measurement set of this mode and workload, if any (tools/profile_set.sh: kernel trace, MFMA-busy, FETCH_SIZE and
+        # WRITE_SIZE passes on identical launches — the autotuner table is pinned — joined per kernel in per_kernel.json)
+        pset = pset_src = None
+        for rdir in ("r04",):
+            f = os.path.join(ROOT, "profiles", rdir, a.mode, "per_kernel.json")
+            if world == 1 and emulate is None and not cached and os.path.exists(f):
+                cand = json.load(open(f))
+                if cand.get("summary", {}).get("config", {}).get("workload", "").split(":")[0] == a.workload:
+                    pset, pset_src = cand, os.path.relpath(f, ROOT)
         pmc = os.path.join(ROOT, "profiles", prof_dir, "pmc_traffic_stage1.json")
-        if world == 1 and a.mode == "fast" and (B, N, C, bpe) == (32, 162, 768, 4) and os.path.exists(pmc):
+        if pset is not None and any("s1_main" in k["kernel"] for k in pset["kernels"]):
+            k1 = next(k for k in pset["kernels"] if "s1_main" in k["kernel"])
+            traffic, traffic_src = (k1["fetch_bytes"] + k1["write_bytes"]) / k1["launches"], pset_src
+        elif world == 1 and a.mode == "fast" and (B, N, C, bpe) == (32, 162, 768, 4) and os.path.exists(pmc):
             traffic, traffic_src = json.load(open(pmc))["hbm_bytes_per_launch"], os.path.relpath(pmc, ROOT)
         line = {
             "metric": f"image-crops/sec (224x224, {N} templates)" + ("" if kind == "full" else ", stage-1 template matching only")
@@ -742,14 +754,19 @@ def main():
         s1_roof["mfma"] = {"achieved": s1_flops / (kern_ms * 1e-3) / 1e12, "peak": s1_peak, "unit": "TFLOP/s",
                            "frac": s1_flops / (kern_ms * 1e-3) / 1e12 / s1_peak, "flops_per_launch": s1_flops,
                            "intensity_flop_per_byte": s1_flops / kbytes}
-        if kind == "full" and gemm and gemm["launches"][0] > 0:
-            k = 1 if a.mode == "exact" else 0     # fast / fp16: the pre-split kernel; exact: the fp32-MFMA kernel
+        k = 1 if a.mode == "exact" else 0     # fast / fp16: the pre-split kernel; exact: the fp32-MFMA kernel
+        if kind == "full" and gemm and gemm["launches"][k] > 0:
             mult, peak = {"fast": (3, MFMA_F16_PEAK_TF), "fp16": (1, MFMA_F16_PEAK_TF), "exact": (1, MFMA_F32_PEAK_TF)}[a.mode]
             n, msum, fl = gemm["launches"][k], gemm["ms"][k], gemm["flops"][k]
             ach = mult * fl / (msum * 1e-3) / 1e12
             g_traffic = g_src = None   # HBM bytes of these kernels over one step, from separate PMC passes (tools/pmc_step.sh)
             pmc_step = os.path.join(ROOT, "profiles", prof_dir, "pmc_step.json")
-            if world == 1 and a.mode == "fast" and a.workload == "full_b32_n162_vitb" and os.path.exists(pmc_step):
+            if pset is not None:      # FETCH + WRITE of the kernels this object describes, summed over one step
+                tag = "gemm_kernel<" if a.mode == "exact" else "pp_gemm_u"
+                sel = [kk for kk in pset["kernels"] if tag in kk["kernel"] and kk.get("fetch_bytes") is not None]
+                if sel:
+                    g_traffic, g_src = sum(kk["fetch_bytes"] + kk["write_bytes"] for kk in sel), pset_src
+            elif world == 1 and a.mode == "fast" and a.workload == "full_b32_n162_vitb" and os.path.exists(pmc_step):
                 g_traffic, g_src = json.load(open(pmc_step)).get("gemm_f16x3_hbm_bytes_per_step"), os.path.relpath(pmc_step, ROOT)
             line["roofline"] = {
                 "bound": "mfma",
