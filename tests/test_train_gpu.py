@@ -702,6 +702,74 @@ def test_stage3_adjoint_kernels_against_torch_autograd():
 
 
 @gpu
+@pytest.mark.parametrize("H,C,flow_sigma", [(16, 128, 0.3), (16, 256, 1.5), (8, 128, 6.0), (12, 128, 1.0)])
+def test_correlation_lookup_adjoint_by_patches_against_float64_and_the_per_pixel_kernel(H, C, flow_sigma, monkeypatch):
+    """The df2 half of the correlation-lookup adjoint scattered by 4 x 4 pixel patches (corr_lookup_scatter_kernel: taken when H, W are
+    multiples of 4 and C of 128 — the flow decoder's maps) against torch's float64 autograd of the oracle's materialised pyramid +
+    grid_sample, and against the per-pixel kernel it replaces (PP_CORR_SCATTER_PER_PIXEL=1).  Smooth flows (every position inside the
+    patch's frame), rough ones (sigma 1.5: some outside — the direct-atomic fallback) and flows that tear the patch apart and leave the
+    map (sigma 6).  1e-5 of the largest gradient (measured 1.3e-6: fp32 sums); both kernels agree to 2e-6 (measured 2.8e-7).  With the
+    deterministic option the patch kernel repeats bit for bit."""
+    from oracle import nets as onets
+    from picopose_amd import autograd as ag
+
+    levels, r = 3, 2
+    ncorr = levels * (2 * r + 1) ** 2
+    cp = -(-ncorr // 8) * 8
+    g = torch.Generator().manual_seed(H + C)
+    f1, f2 = torch.randn(2, H, H, C, generator=g), torch.randn(2, H, H, C, generator=g)
+    flow = torch.randn(2, H, H, 2, generator=g) * flow_sigma + torch.tensor([0.7, -1.2])
+    w = torch.randn(2, H, H, ncorr, generator=g)
+
+    def run_hip():
+        a = [t.clone().cuda().requires_grad_(True) for t in (f1, f2, flow)]
+        y = ag._CorrLookup.apply(*a, levels, r, cp)[..., :ncorr]
+        (y * w.cuda()).sum().backward()
+        return [t.grad.cpu() for t in a]
+
+    b = [t.double().requires_grad_(True) for t in (f1, f2, flow)]
+    yb = onets.corr_lookup(b[0].permute(0, 3, 1, 2), b[1].permute(0, 3, 1, 2), b[2].permute(0, 3, 1, 2), levels, r).permute(0, 2, 3, 1)
+    (yb * w.double()).sum().backward()
+    got = run_hip()
+    monkeypatch.setenv("PP_CORR_SCATTER_PER_PIXEL", "1")
+    old = run_hip()
+    monkeypatch.delenv("PP_CORR_SCATTER_PER_PIXEL")
+    for name, u, o, v in zip(("df1", "df2", "dflow"), got, old, b):
+        scale = float(v.grad.abs().max())
+        e, d = float((u.double() - v.grad).abs().max()) / scale, float((u - o).abs().max()) / scale
+        print(f"H={H} C={C} sigma={flow_sigma}: {name} vs float64 {e:.1e}, vs per-pixel kernel {d:.1e}")
+        assert e <= 1e-5 and d <= 2e-6, (name, e, d)
+    monkeypatch.setattr(ag, "DETERMINISTIC", True)
+    d1, d2 = run_hip(), run_hip()
+    assert all(torch.equal(x, y) for x, y in zip(d1, d2))
+    assert float((d1[1].double() - b[1].grad).abs().max()) <= 1e-5 * float(b[1].grad.abs().max())
+
+
+@gpu
+@pytest.mark.parametrize("B,H,Cin,Cout,k", [(2, 32, 64, 256, 3), (2, 32, 256, 192, 3), (1, 64, 32, 126, 3), (2, 16, 16, 512, 7)])
+def test_convolution_backward_with_k_slices_against_float64(B, H, Cin, Cout, k):
+    """_Conv2d's three directions at sizes whose weight gradient takes the K slices (Cout a multiple of 256), the transposed product
+    (Cout = 192, k k Cin a multiple of 256), the 126-channel layer padded to 128 in its backward, and a 7 x 7 kernel — against torch's
+    float64 autograd of F.conv2d: 1e-5 of each gradient's maximum (measured 3.5e-6 at worst)."""
+    from picopose_amd import autograd as ag
+
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x, wt, bias = torch.randn(B, H, H, Cin, generator=g), torch.randn(Cout, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5, torch.randn(Cout, generator=g)
+    up = torch.randn(B, H, H, Cout, generator=g) * 1e-3
+    a = [t.clone().cuda().requires_grad_(True) for t in (x, wt, bias)]
+    ya = ag._Conv2d.apply(a[0], a[1], a[2], k, None)
+    (ya * up.cuda()).sum().backward()
+    b = [t.double().requires_grad_(True) for t in (x, wt, bias)]
+    yb = F.conv2d(b[0].permute(0, 3, 1, 2), b[1], b[2], padding=k // 2).permute(0, 2, 3, 1)
+    (yb * up.double()).sum().backward()
+    assert float((ya.detach().cpu().double() - yb.detach()).abs().max()) <= 1e-5 * float(yb.detach().abs().max())
+    for name, u, v in zip(("dx", "dw", "db"), a, b):
+        e = float((u.grad.cpu().double() - v.grad).abs().max() / v.grad.abs().max())
+        print(f"Cin={Cin} Cout={Cout} k={k}: {name} {e:.1e}")
+        assert e <= 1e-5, (name, e)
+
+
+@gpu
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
 def test_full_backward_matches_the_reference_autograd(golden_dir, precision):
     """Scope "full" (the default): `Loss()(net(end_points))["loss"].backward()` is the reference's training step.  With the noisy
