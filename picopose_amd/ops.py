@@ -310,7 +310,7 @@ def ksplit_choice(M, N, K, can_pad=True):
     work items of ONE engine launch (PpGemmDesc.ksplit), K padded with zeros to a multiple of 64 S when the producer can
     (can_pad).  Chosen from the shape only (a cost model in units of k per work item: rounds over the 256 CUs x (slice length + a
     tile's fixed cost)), so the summation order is a function of the shape.  S = 1: no slices."""
-    if not KSPLIT or M % 256 != 0:
+    if not KSPLIT or M % 256 != 0 or N % 8 != 0 or PRECISION != "f16x3":     # (the sliced kernel exists for the hl format and the vector epilogue)
         return 1, K
     t = -(-M // 256) * -(-N // 256)
     base = -(-t // 256) * (K + 512)
