@@ -168,18 +168,23 @@ __device__ __forceinline__ int vt_slot(int key) {  // key (0..31) of a chunk -> 
 template <bool HLIN, int TERMS = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_f16x3_kernel(const void* __restrict__ qkv_any, int T, int heads, float scale,
                                                          float* __restrict__ out, _Float16* __restrict__ out_hl,
-                                                         float* __restrict__ lse) {
+                                                         float* __restrict__ lse, int ntx, int npairs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Kh = (_Float16*)smem;            // [KC][KHLD]
     _Float16* Kl = Kh + KC * KHLD;
     _Float16* Vh = Kl + KC * KHLD;             // [KC key slots][VLD]: row = k-slot of the key, d contiguous
     _Float16* Vl = Vh + KC * VLD;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.y / heads, h = blockIdx.y % heads;
+    // 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the ntx workgroups of one (image, head)
+    // — which stage the SAME K / V chunks — take ids of one residue mod 8: id = xcd + 8 (ntx (pair / 8) + tile), pair = 8 (..) + xcd.
+    // (On a (tile, pair) grid the three workgroups of a pair sat on three XCDs: FETCH 2.3 x the qkv bytes.)
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3, bx = jj % ntx, pair = (jj / ntx) * 8 + xcd;
+    if (pair >= npairs) return;
+    const int b = pair / heads, h = pair % heads;
     const int C3 = 3 * heads * HD;
     const float* base = (const float*)qkv_any + (size_t)b * T * C3 + h * HD;            // fp32 input
     const _Float16* hbase = (const _Float16*)qkv_any + ((size_t)b * T * C3 + h * HD) * TERMS;  // operand input (h*HD % 8 == 0)
-    const int q = (blockIdx.x * (nthr >> 6) + w) * 32 + l31;
+    const int q = (bx * (nthr >> 6) + w) * 32 + l31;
     const int qc = q < T ? q : T - 1;
 
     // Q fragments: step s holds d = 16 s + 8 lh .. + 7 of query l31 (unscaled: the scores are scaled after the MFMAs)
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave reads only what it wrote itself
     const int qr = lane >> 1, half = lane & 1;
-    const int qo = (blockIdx.x * (nthr >> 6) + w) * 32 + qr;
+    const int qo = (bx * (nthr >> 6) + w) * 32 + qr;
     if (qo < T) {
         const size_t obase = ((size_t)b * T + qo) * (heads * HD) + h * HD + 32 * half;
         const float* src = Os + qr * OLD + 32 * half;
@@ -496,15 +501,17 @@ static int attention_launch(const void* qkv, bool hl_in, int B, int T, int heads
             }
         }
         const size_t kv = (size_t)(2 * KC * KHLD + 2 * KC * VLD) * sizeof(_Float16), os = (size_t)wpb * 32 * OLD * sizeof(float);
+        const int ntx = (tiles + wpb - 1) / wpb, npairs = B * heads;
+        const dim3 grid((unsigned)(ntx * ((npairs + 7) / 8) * 8));
         if (hl_in && terms == 1)
-            hipLaunchKernelGGL((attn_f16x3_kernel<true, 1>), dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
-                               (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl, lse);
+            hipLaunchKernelGGL((attn_f16x3_kernel<true, 1>), grid, dim3(64 * wpb), kv > os ? kv : os, (hipStream_t)stream, qkv, T, heads, scale, out,
+                               (_Float16*)out_hl, lse, ntx, npairs);
         else if (hl_in)
-            hipLaunchKernelGGL(attn_f16x3_kernel<true>, dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
-                               (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl, lse);
+            hipLaunchKernelGGL(attn_f16x3_kernel<true>, grid, dim3(64 * wpb), kv > os ? kv : os, (hipStream_t)stream, qkv, T, heads, scale, out,
+                               (_Float16*)out_hl, lse, ntx, npairs);
         else
-            hipLaunchKernelGGL(attn_f16x3_kernel<false>, dim3((tiles + wpb - 1) / wpb, B * heads), dim3(64 * wpb), kv > os ? kv : os,
-                               (hipStream_t)stream, qkv, T, heads, scale, out, (_Float16*)out_hl, lse);
+            hipLaunchKernelGGL(attn_f16x3_kernel<false>, grid, dim3(64 * wpb), kv > os ? kv : os, (hipStream_t)stream, qkv, T, heads, scale, out,
+                               (_Float16*)out_hl, lse, ntx, npairs);
     } else {
         hipLaunchKernelGGL(attn_kernel, dim3((T + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, (const float*)qkv, T, heads,
                            scale, out, (_Float16*)out_hl);

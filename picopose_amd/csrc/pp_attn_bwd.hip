@@ -207,16 +207,19 @@ __global__ __launch_bounds__(256) void attn_bwd_d_kernel(const float* __restrict
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                           const float* __restrict__ lse2, const float* __restrict__ Dg,
                                                           const float* __restrict__ gpair, int T, int heads, float scale,
-                                                          float* __restrict__ dqkv) {
+                                                          float* __restrict__ dqkv, int ntx, int npairs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Kr = (_Float16*)smem;               // K chunk, row-major planes   [2][KC][RLD]
     _Float16* Kt = Kr + 2 * ROW_TILE;             // K chunk, slot-major planes  [2][KC][TLD]
     _Float16* Vr = Kt + 2 * SLOT_TILE;            // V chunk, row-major planes
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.y / heads, h = blockIdx.y % heads;
+    // XCD-aware 1-D grid as in pp_attn.hip: the workgroups of one (image, head) share an XCD (and its L2 copy of K / V)
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3, bx = jj % ntx, pair = (jj / ntx) * 8 + xcd;
+    if (pair >= npairs) return;
+    const int b = pair / heads, h = pair % heads;
     const int C1 = heads * HD, C3 = 3 * C1;
     const float* base = qkv + (size_t)b * T * C3 + h * HD;
-    const int q0 = (blockIdx.x * (nthr >> 6) + w) * 32, q = q0 + l31, qc = q < T ? q : T - 1;
+    const int q0 = (bx * (nthr >> 6) + w) * 32, q = q0 + l31, qc = q < T ? q : T - 1;
     const float g = gpair[0], ginv = gpair[1];
 
     h8 qh[4], ql[4], doh[4], dol[4];
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                            const float* __restrict__ lse2, const float* __restrict__ Dg,
                                                            const float* __restrict__ gpair, int T, int heads, float scale,
-                                                           float* __restrict__ dqkv) {
+                                                           float* __restrict__ dqkv, int ntx, int npairs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Qr = (_Float16*)smem;               // Q chunk row-major / slot-major, dO chunk row-major / slot-major
     _Float16* Qt = Qr + 2 * ROW_TILE;
@@ -273,11 +276,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* Ls = (float*)(Gt + 2 * SLOT_TILE);     // [KC] lse of the chunk's queries (+inf past T), then [KC] their D
     float* Ds = Ls + KC;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.y / heads, h = blockIdx.y % heads;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3, bx = jj % ntx, pair = (jj / ntx) * 8 + xcd;
+    if (pair >= npairs) return;
+    const int b = pair / heads, h = pair % heads;
     const int C1 = heads * HD, C3 = 3 * C1;
     const float* base = qkv + (size_t)b * T * C3 + h * HD;
     const float* dbase = dout + (size_t)b * T * C1 + h * HD;
-    const int key0 = (blockIdx.x * (nthr >> 6) + w) * 32, key = key0 + l31, kc = key < T ? key : T - 1;
+    const int key0 = (bx * (nthr >> 6) + w) * 32, key = key0 + l31, kc = key < T ? key : T - 1;
     const float g = gpair[0], ginv = gpair[1];
 
     h8 kh[4], kl[4], vh[4], vl[4];
@@ -339,7 +344,7 @@ extern "C" int pp_attention_backward(const float* qkv, const float* out, const f
                                      int T, int heads, int head_dim, float scale, float* Dws, float* dqkv, void* stream) {
     if (!qkv || !out || !dout || !lse2 || !gpair || !Dws || !dqkv || B <= 0 || T <= 0 || heads <= 0 || head_dim != HD) return PP_EINVAL;
     if (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) % 16 != 0) return PP_EINVAL;
-    if ((long)B * heads > 65535L) return PP_EINVAL;
+    if ((long)B * heads * ((T + 63) / 64) > 0x7FFFFFF0L) return PP_EINVAL;
     const long items = (long)B * T * heads;
     hipLaunchKernelGGL(attn_bwd_d_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, (hipStream_t)stream, out, dout, gpair, B, T,
                        heads, Dws);
@@ -355,10 +360,11 @@ extern "C" int pp_attention_backward(const float* qkv, const float* out, const f
     const size_t os = (size_t)wpb * 32 * OLD * sizeof(float);
     const size_t s_dq = (size_t)(4 * ROW_TILE + 2 * SLOT_TILE) * sizeof(_Float16);
     const size_t s_kv = (size_t)(4 * ROW_TILE + 4 * SLOT_TILE) * sizeof(_Float16) + 2 * KC * sizeof(float);
-    const dim3 grid((tiles + wpb - 1) / wpb, B * heads);
+    const int ntx = (tiles + wpb - 1) / wpb, npairs = B * heads;
+    const dim3 grid((unsigned)(ntx * ((npairs + 7) / 8) * 8));
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(64 * wpb), s_dq > os ? s_dq : os, (hipStream_t)stream, qkv, dout, lse2, Dws, gpair, T,
-                       heads, scale, dqkv);
+                       heads, scale, dqkv, ntx, npairs);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(64 * wpb), s_kv > os ? s_kv : os, (hipStream_t)stream, qkv, dout, lse2, Dws, gpair, T,
-                       heads, scale, dqkv);
+                       heads, scale, dqkv, ntx, npairs);
     return pp_last_launch();
 }
