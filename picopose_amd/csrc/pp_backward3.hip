@@ -20,17 +20,36 @@ inline int grid_for(long long n) { return (int)((n + 255) / 256 < 16384 ? (n + 2
 //   g = dy [y > 0],  dgamma = sum g xhat,  dbeta = sum g,  dx = gamma rstd (g - mean(g) - xhat mean(g xhat))
 constexpr int BNB_ROWS = 256;
 
+// (both partial kernels: a workgroup = BNB_ROWS rows; a thread owns 4 consecutive channels (16-byte loads) and one of 4 row lanes —
+// rows rl, rl + 4, ... —, the row lanes are added in lane order through LDS: the sums keep a fixed order.  C % 4 == 0.)
 __global__ __launch_bounds__(256) void bnb_stats_kernel(const float* __restrict__ x, int rows, int C, double* __restrict__ part) {
+    __shared__ double red[4][64][8];
     const int r0 = blockIdx.x * BNB_ROWS, r1 = min(rows, r0 + BNB_ROWS);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double s = 0.0, q = 0.0;
-        for (int r = r0; r < r1; ++r) {
-            const double v = (double)x[(size_t)r * C + c];
-            s += v;
-            q = fma(v, v, q);
+    const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    for (int cb = 0; cb < C; cb += 256) {
+        const int c = cb + 4 * q;
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, qq[4] = {0.0, 0.0, 0.0, 0.0};
+        if (c < C)
+            for (int r = r0 + rl; r < r1; r += 4) {
+                const f4 v = *(const f4*)(x + (size_t)r * C + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double d = (double)v[i];
+                    s[i] += d;
+                    qq[i] = fma(d, d, qq[i]);
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[rl][q][2 * i] = s[i];
+            red[rl][q][2 * i + 1] = qq[i];
         }
-        part[((size_t)blockIdx.x * C + c) * 2] = s;
-        part[((size_t)blockIdx.x * C + c) * 2 + 1] = q;
+        __syncthreads();
+        if (rl == 0 && c < C)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                part[((size_t)blockIdx.x * C + c + (i >> 1)) * 2 + (i & 1)] = ((red[0][q][i] + red[1][q][i]) + red[2][q][i]) + red[3][q][i];
+        __syncthreads();
     }
 }
 
@@ -53,19 +72,37 @@ __global__ __launch_bounds__(256) void bnb_stats_finish_kernel(const double* __r
 __global__ __launch_bounds__(256) void bnb_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, int rows, int C, int relu, double* __restrict__ part) {
+    __shared__ double red[4][64][8];
     const int r0 = blockIdx.x * BNB_ROWS, r1 = min(rows, r0 + BNB_ROWS);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float m = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
-        double s = 0.0, q = 0.0;
-        for (int r = r0; r < r1; ++r) {
-            const float xh = (x[(size_t)r * C + c] - m) * rs;
-            float g = dy[(size_t)r * C + c];
-            if (relu && !(fmaf(xh, ga, be) > 0.f)) g = 0.f;
-            s += (double)g;
-            q = fma((double)g, (double)xh, q);
+    const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    for (int cb = 0; cb < C; cb += 256) {
+        const int c = cb + 4 * q;
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, qq[4] = {0.0, 0.0, 0.0, 0.0};
+        if (c < C) {
+            const f4 m = *(const f4*)(mean + c), rs = *(const f4*)(rstd + c), ga = *(const f4*)(gamma + c), be = *(const f4*)(beta + c);
+            for (int r = r0 + rl; r < r1; r += 4) {
+                const f4 xv = *(const f4*)(x + (size_t)r * C + c), gv = *(const f4*)(dy + (size_t)r * C + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xh = (xv[i] - m[i]) * rs[i];
+                    float g = gv[i];
+                    if (relu && !(fmaf(xh, ga[i], be[i]) > 0.f)) g = 0.f;
+                    s[i] += (double)g;
+                    qq[i] = fma((double)g, (double)xh, qq[i]);
+                }
+            }
         }
-        part[((size_t)blockIdx.x * C + c) * 2] = s;
-        part[((size_t)blockIdx.x * C + c) * 2 + 1] = q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[rl][q][2 * i] = s[i];
+            red[rl][q][2 * i + 1] = qq[i];
+        }
+        __syncthreads();
+        if (rl == 0 && c < C)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                part[((size_t)blockIdx.x * C + c + (i >> 1)) * 2 + (i & 1)] = ((red[0][q][i] + red[1][q][i]) + red[2][q][i]) + red[3][q][i];
+        __syncthreads();
     }
 }
 
@@ -499,7 +536,8 @@ size_t pp_batchnorm_train_backward_workspace_bytes(long long rows, int C) {
 
 int pp_batchnorm_train_backward(const float* x, const float* gamma, const float* beta, const float* dy, long long rows, int C, float eps,
                                 int relu, float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!x || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0) return PP_EINVAL;
+    if (!x || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0 || C % 4 != 0) return PP_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)beta) & 15) != 0) return PP_EINVAL;
     if (workspace_bytes < pp_batchnorm_train_backward_workspace_bytes(rows, C)) return PP_EWORKSPACE;
     const int nblk = (int)((rows + BNB_ROWS - 1) / BNB_ROWS);
     double* part = (double*)workspace;

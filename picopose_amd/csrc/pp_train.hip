@@ -148,17 +148,36 @@ __global__ __launch_bounds__(256) void keypoint_visibility_kernel(const int2* __
 // ---------------------------------------------------------------------------
 constexpr int BN_ROWS = 256;   // rows per statistics workgroup
 
+// a workgroup = BN_ROWS rows; a thread owns 4 consecutive channels (16-byte loads) and one of 4 row lanes (rows rl, rl + 4, ...), the
+// row lanes are added in lane order through LDS (fixed order).  C % 4 == 0.
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int rows, int C, double* __restrict__ part) {
+    __shared__ double red[4][64][8];
     const int r0 = blockIdx.x * BN_ROWS, r1 = min(rows, r0 + BN_ROWS);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double s = 0.0, q = 0.0;
-        for (int r = r0; r < r1; ++r) {
-            const double v = (double)x[(size_t)r * C + c];
-            s += v;
-            q = fma(v, v, q);
+    const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    for (int cb = 0; cb < C; cb += 256) {
+        const int c = cb + 4 * q;
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, qq[4] = {0.0, 0.0, 0.0, 0.0};
+        if (c < C)
+            for (int r = r0 + rl; r < r1; r += 4) {
+                const f4 v = *(const f4*)(x + (size_t)r * C + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double d = (double)v[i];
+                    s[i] += d;
+                    qq[i] = fma(d, d, qq[i]);
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[rl][q][2 * i] = s[i];
+            red[rl][q][2 * i + 1] = qq[i];
         }
-        part[((size_t)blockIdx.x * C + c) * 2] = s;
-        part[((size_t)blockIdx.x * C + c) * 2 + 1] = q;
+        __syncthreads();
+        if (rl == 0 && c < C)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                part[((size_t)blockIdx.x * C + c + (i >> 1)) * 2 + (i & 1)] = ((red[0][q][i] + red[1][q][i]) + red[2][q][i]) + red[3][q][i];
+        __syncthreads();
     }
 }
 
