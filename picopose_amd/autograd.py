@@ -863,7 +863,7 @@ def _mm_kmajor(a, bt):
     M, K = a.shape
     N = bt.shape[0]
     tiles = -(-M // 128) * -(-N // 128)
-    S = 64 if tiles <= 8 else 16
+    S = 64 if (tiles <= 8 or (tiles <= 24 and K >= 65536)) else 16      # (a function of the shape: the order of the sums is fixed)
     while S > 1 and (K % S or (K // S) % 8):
         S //= 2
     kc = K // S

@@ -51,6 +51,6 @@ for i in range(cnt.value):
     a[2] += fl[i]
 tot = sum(a[1] for a in agg.values())
 print(f"{cnt.value} GEMM launches, {tot:.1f} ms in one full training step (B = {B}, {vit})")
-for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("PP_TRACE_TOP", "28"))]:
     M, N, K, ck, kind = key
     print(f"  {a[1]:7.2f} ms  x{a[0]:3d}  M={M:7d} N={N:5d} K={K:7d} {'conv' if ck else 'dense'} {'engine' if kind == 0 else 'fly/fp32'}  {a[2] / max(a[1], 1e-9) / 1e9:7.1f} useful TFLOP/s")
