@@ -241,6 +241,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream);
 /* Split n fp32 weights (rows of a multiple of 8 elements) once at load time into an hl buffer of 2n halfs:
  * scale[0] = 2^k with max|scale*w| in [512,1024) (device float), hi = f16(scale*w), lo = f16(scale*w - hi). */
 int pp_split_f16x3(const float* w, long long n, void* hl, float* scale, void* stream);
+/* The same split with the scale left ON THE DEVICE: scale2[0] = 2^k, scale2[1] = 2^-k (pass scale2 + 1 as PpGemmDesc.alpha_dev with
+ * b_scale = 1: no host read-back — the training step re-splits every parameter after every optimizer step); partials: 1024 floats of
+ * scratch; two launches. */
+int pp_split_weights_ws(const float* w, long long n, int terms, void* out, float* scale2, float* partials, void* stream);
 /* Split an activation tensor x (B, P, C) fp32 (batch / row strides in floats, channels contiguous, C % 8 == 0)
  * once into a contiguous hl buffer (B*P rows, ld = C) for PP_PREC_F16X3 (activation scale 4; optional ReLU first). */
 int pp_split_activation(const float* x, long long batch_stride, int B, int P, int row_stride, int C, int relu,

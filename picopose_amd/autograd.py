@@ -179,7 +179,7 @@ class _Linear(torch.autograd.Function):
         # (reshaped, re-packed): split every step with the scale read back one step earlier; otherwise transient (one host wait).
         # `is_leaf` is not the test: a matrix derived from a FROZEN parameter is a leaf too, and caching a fresh tensor every step
         # would pin it and its operand copy in the cache for good
-        cache = True if isinstance(w, torch.nn.Parameter) else ((owner, "lin") if owner is not None else False)
+        cache = ("dev" if (w.requires_grad and DEVICE_WEIGHT_SCALE) else True) if isinstance(w, torch.nn.Parameter) else ((owner, "lin") if owner is not None else False)
         x, w = _f32c(x), _f32c(w)
         z = ops.linear(x, w, b, cache_weight=cache)
         ctx.act = ACT[act]
@@ -250,6 +250,9 @@ class _ScaleResidual(torch.autograd.Function):
 
 
 FUSED_ATTENTION = os.environ.get("PP_FUSED_ATTENTION", "1") != "0"
+# trained parameters are re-split after every optimizer step: their power-of-two scale stays on the device (ops.split_weight_dev) instead of
+# being read back by the host (one wait per parameter and step)
+DEVICE_WEIGHT_SCALE = os.environ.get("PP_DEVICE_WEIGHT_SCALE", "1") != "0"
 
 
 class _Attention(torch.autograd.Function):

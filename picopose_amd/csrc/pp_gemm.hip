@@ -886,6 +886,48 @@ __global__ void split_f16x3_kernel(const float* __restrict__ w, long long n, con
     }
 }
 
+// pp_split_weights_ws: the fold of absmax_part_kernel's maxima inside the split launch (every workgroup folds the <= 1024 partial
+// maxima itself, workgroup 0 leaves the scale pair) — two launches per weight instead of four, nothing read back by the host
+__global__ __launch_bounds__(256) void split_fold_kernel(const float* __restrict__ w, long long n, const float* __restrict__ partial, int np, int emax,
+                                                         float* __restrict__ scale2, _Float16* __restrict__ hl, int terms) {
+    __shared__ float red[4];
+    __shared__ float s_sh;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) m = fmaxf(m, partial[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        int e = 0;
+        if (m > 0.f && m < INFINITY) {
+            (void)frexpf(m, &e);
+            e = 10 - e;
+        }
+        e = e > emax ? emax : (e < -emax ? -emax : e);
+        s_sh = ldexpf(1.f, e);
+        if (blockIdx.x == 0) {
+            scale2[0] = ldexpf(1.f, e);
+            scale2[1] = ldexpf(1.f, -e);
+        }
+    }
+    __syncthreads();
+    const float s = s_sh;
+    if (terms == 1) {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+            hl[i] = (_Float16)fminf(fmaxf(w[i] * s, -65504.f), 65504.f);
+        return;
+    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = w[i] * s;
+        const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+        _Float16* p = hl + ((i >> 3) << 4) + (i & 7);
+        p[0] = h;
+        p[8] = (_Float16)(x - (float)h);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -895,6 +937,15 @@ int pp_split_weights_t(const float* w, long long n, int terms, void* out, float*
     launch_pow2_scale(w, n, scale, 0, 30, (hipStream_t)stream);
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(split_f16x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, n, scale, (_Float16*)out, terms);
+    return pp_last_launch();
+}
+
+int pp_split_weights_ws(const float* w, long long n, int terms, void* out, float* scale2, float* partials, void* stream) {
+    if (!w || !out || !scale2 || !partials || n <= 0 || n % 8 != 0 || (terms != 1 && terms != 2)) return PP_EINVAL;
+    const int gp = (int)((n + 8191) / 8192 < 1024 ? (n + 8191) / 8192 : 1024);
+    hipLaunchKernelGGL(absmax_part_kernel, dim3(gp), dim3(256), 0, (hipStream_t)stream, w, n, partials);
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(split_fold_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, n, (const float*)partials, gp, 30, scale2, (_Float16*)out, terms);
     return pp_last_launch();
 }
 

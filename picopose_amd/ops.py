@@ -78,6 +78,25 @@ def split_weight(w, cache=True):
     return hit[0], hit[1]
 
 
+def split_weight_dev(w):
+    """(hl, scale2) of a trained PARAMETER with its power-of-two scale left on the device (scale2 = [2^k, 2^-k]): no host wait.  The
+    training step re-splits every parameter after every optimizer step; `split_weight` reads each scale back (197 host waits per step at
+    ViT-B, the GPU idling while the host catches up) — here the launch takes 2^-k through PpGemmDesc.alpha_dev with b_scale = 1
+    (exact: powers of two).  Remembered per (address, version) like `split_weight`."""
+    t = terms()
+    key = (w.data_ptr(), w._version, tuple(w.shape), t, "dev")
+    hit = _split_cache.get(key)
+    if hit is None:
+        assert w.is_contiguous()
+        hl = torch.empty(w.shape[0], t * w.shape[1], dtype=torch.float16, device=w.device)
+        buf = torch.empty(2 + 1024, dtype=torch.float32, device=w.device)
+        _lib.check(_lib.lib().pp_split_weights_ws(_p(w), w.numel(), t, _p(hl), _p(buf), _p(buf[2:]), _lib.stream_ptr()), "pp_split_weights_ws")
+        if len(_split_cache) > 4096:
+            _split_cache.clear()
+        hit = _split_cache[key] = (hl, buf[:2], w)
+    return hit[0], hit[1]
+
+
 def drop_split_cache():
     """Forget every cached operand copy of a weight (Packed.invalidate_packed: after a write through `param.data`, which the
     (address, version) keys cannot see)."""
@@ -196,11 +215,15 @@ def _can_presplit(x, K, C, *strides):
 
 def _weight_args(w, K, cache=True):
     """desc fields for a weight operand under the current precision (pre-split operand when it is aligned).
-    cache: True (a parameter: remembered per version) | False (transient: split now, one host wait for its scale) |
-    (owner, tag) (derived from the parameter `owner` every step: split_weight_tracked, no host wait)."""
+    cache: True (a parameter: remembered per version, scale read back once) | "dev" (a TRAINED parameter: remembered per version, scale
+    left on the device) | False (transient: split now, one host wait for its scale) | (owner, tag) (derived from the parameter `owner`
+    every step: split_weight_tracked, no host wait)."""
     if isinstance(cache, tuple) and os.environ.get("PP_TRACK_SCALE", "1") == "0":
         cache = False                      # (A/B switch: the scale of every derived weight read back at once, one host wait each)
     if presplit() and K % 8 == 0 and w.data_ptr() % 16 == 0:
+        if cache == "dev":                 # a trained parameter: scale on the device, taken by the launch through alpha_dev
+            hl, s2 = split_weight_dev(w)
+            return dict(prec=_PREC[PRECISION], B_hl=_p(hl), b_scale=1.0, alpha_dev=_p(s2[1:2]), _hl=(hl, s2))
         hl, scale = split_weight_tracked(w, *cache) if isinstance(cache, tuple) else split_weight(w, cache)
         return dict(prec=_PREC[PRECISION], B_hl=_p(hl), b_scale=scale, _hl=hl)
     return dict(prec=_fly_prec())

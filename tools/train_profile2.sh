@@ -26,5 +26,5 @@ for r in seg:
     k = cat(r["Kernel_Name"]); t[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); c[k] += 1
 tot = sum(t.values()); span = int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])
 print(f"one step under the profiler: {len(seg)} launches, kernel time {tot / 1e6:.1f} ms, span {span / 1e6:.1f} ms")
-for k, v in t.most_common(26): print(f"{v / 1e6:8.2f} ms {v / tot * 100:5.1f}%  x{c[k]:5d}  {k}")
+for k, v in t.most_common(int(__import__("os").environ.get("PP_PROF_TOP", "26"))): print(f"{v / 1e6:8.2f} ms {v / tot * 100:5.1f}%  x{c[k]:5d}  {k}")
 PY
