@@ -58,3 +58,13 @@ rows = rows[2:]
 med = lambda k: sorted(r[k] for r in rows)[len(rows) // 2]  # noqa: E731
 print(f"training step {vit} B={B} scope=full: {med(3):.1f} ms per step ({B / med(3) * 1e3:.1f} pairs/s); host: forward launched at {med(0):.1f} ms, "
       f"backward at {med(1):.1f}, optimizer at {med(2):.1f}; peak memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB; loss {float(tot.detach()):.4f}", flush=True)
+# the same steps back to back, ONE synchronisation at the end (a training loop that does not read the loss every step): the host runs ahead
+# of the GPU, so the forward's launch time is hidden behind the previous step's backward
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(steps):
+    Loss()(net(dict(ep)))["loss"].backward()
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+torch.cuda.synchronize()
+print(f"  {steps} steps back to back, one synchronisation: {1e3 * (time.perf_counter() - t0) / steps:.1f} ms per step", flush=True)

@@ -3,7 +3,7 @@
 # trace of one step (cut at the marker fills) grouped by category: kernel time, launch count.
 B=${1:-32}
 root=$GRAFT_REPO_ROOT
-python3 $root/tools/bench_train_full.py $B 6 2>/dev/null | tail -1
+python3 $root/tools/bench_train_full.py $B 6 2>/dev/null | tail -2
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_train2
 PP_TRAIN_MARK=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_train2 -- python3 $root/tools/bench_train_full.py $B 5 > /tmp/prof_train2.log 2>&1
