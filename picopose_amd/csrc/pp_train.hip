@@ -181,18 +181,55 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
+// fold of the per-workgroup partial sums (s, q) of one channel with 16 slab lanes (slabs sl, sl + 16, ..., eight loads in flight, then the
+// lanes in order — a fixed order): a workgroup = 16 channels.  (One thread per channel walked up to 512 dependent loads: 27 us per launch.)
+__device__ __forceinline__ bool bn_fold16(const double* __restrict__ part, int nblk, int C, int& c, double& s, double& q) {
+    __shared__ double red[16][16][2];
+    const int ql = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    c = blockIdx.x * 16 + ql;
+    double ss = 0.0, qq = 0.0;
+    if (c < C) {
+        int k = sl;
+        for (; k + 112 < nblk; k += 128) {
+            double a[8], b[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a[j] = part[((size_t)(k + 16 * j) * C + c) * 2];
+                b[j] = part[((size_t)(k + 16 * j) * C + c) * 2 + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ss += a[j];
+                qq += b[j];
+            }
+        }
+        for (; k < nblk; k += 16) {
+            ss += part[((size_t)k * C + c) * 2];
+            qq += part[((size_t)k * C + c) * 2 + 1];
+        }
+    }
+    red[sl][ql][0] = ss;
+    red[sl][ql][1] = qq;
+    __syncthreads();
+    if (sl != 0 || c >= C) return false;
+    s = red[0][ql][0];
+    q = red[0][ql][1];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+        s += red[j][ql][0];
+        q += red[j][ql][1];
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(256) void bn_finish_kernel(const double* __restrict__ part, int nblk, int rows, int C,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         float momentum, float* __restrict__ running_mean,
                                                         float* __restrict__ running_var, float* __restrict__ scale,
                                                         float* __restrict__ shift) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-        s += part[((size_t)k * C + c) * 2];
-        q += part[((size_t)k * C + c) * 2 + 1];
-    }
+    int c;
+    double s, q;
+    if (!bn_fold16(part, nblk, C, c, s, q)) return;
     const double mean = s / rows;
     double var = q / rows - mean * mean;
     var = var > 0.0 ? var : 0.0;
@@ -349,7 +386,7 @@ int pp_batchnorm_train(const float* x, const float* gamma, const float* beta, in
     float* shift = scale + C;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_partial_kernel, dim3(nblk), dim3(256), 0, st, x, rows, C, part);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, rows, C, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, nblk, rows, C, gamma, beta, eps, momentum,
                        running_mean, running_var, scale, shift);
     const long long n4 = (long long)rows * C / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, scale, shift, residual, residual2, n4, C,
