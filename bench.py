@@ -242,6 +242,10 @@ CFG_KERNEL = {0: "pp_gemm_u_kernel<128x128, 4 waves, 2-stage ring, 2 workgroups/
               6: "pp_gemm_uh_kernel (256x256, row-shared A delivery of 3x3 convolutions)"}
 
 
+F_CFG_KERNEL = {3: "pp_gemm_f_kernel<128x128, 4 waves, fp32 MFMA, 2 workgroups/CU>", 4: "pp_gemm_f_kernel<256x128, 8 waves, fp32 MFMA>",
+                5: "pp_gemm_f_kernel<256x256, 8 waves, fp32 MFMA>", 6: "pp_gemm_f_kernel<128x64, 4 waves, fp32 MFMA, 2 workgroups/CU>"}
+
+
 def gemm_per_kernel(L, cap=8192):
     """Per-kernel view of the GEMM launches the event pass recorded: [{kernel, cfg, conv, launches, ms, algorithmic_flops,
     useful_tflops}] — every per-kernel roofline fraction can be recomputed from it (executed MFMA flops = 3 x algorithmic in
@@ -259,7 +263,12 @@ def gemm_per_kernel(L, cap=8192):
         # rocprof_key: what tools/profile_set.py derives from a rocprofv3 kernel name (tile + A-delivery MODE template argument), so
         # the PMC passes join this table without guessing layer shapes
         rkey = f"u{cfg}:m{amode}"
-        if kind != 0:     # the kernels on fp32 operands: gemm_f16x3_kernel<NJ, OCC, .> (split on the fly) / gemm_kernel<VEC4, NJ, OCC> (fp32 MFMA)
+        if kind != 0 and amode >= 16:     # the fp32 engine (pp_gemm_f.hip): pp_gemm_f_kernel<FTile<BM, BN, ..>, MODE> on v_mfma_f32_32x32x2_f32
+            fm = amode - 16
+            name = F_CFG_KERNEL.get(cfg, f"pp_gemm_f_kernel cfg {cfg}")
+            key = (name, ("dense", "conv, channel-slice-major K", "conv, natural K order")[fm])
+            rkey = f"f{cfg}:m{fm}"
+        elif kind != 0:     # the kernels on fp32 operands: gemm_f16x3_kernel<NJ, OCC, .> (split on the fly) / gemm_kernel<VEC4, NJ, OCC> (fp32 MFMA)
             vec4, onfly = bool(amode & 1), bool(amode & 2)
             nj_occ = ((1, 4) if cfg == 2 else (2, 2) if cfg == 0 else (2, 3)) if (onfly or vec4) else ((1, 2) if cfg == 2 else (2, 2))
             rkey = f"g{'x' if onfly else 'f'}:{nj_occ[0]}:{nj_occ[1]}"
@@ -665,7 +674,7 @@ def main():
             exact = {"value": Bl / x_dt, "unit": "crops/s", "ms_per_step": x_dt * 1e3, "steps": x_steps,
                      "ms_per_step_median_hip_events": x_ms[len(x_ms) // 2],
                      "dtype": "f32 (v_mfma_f32_32x32x2_f32 in every kernel, exact-fp32 stage 1; PnP f64)",
-                     "roofline": {"bound": "mfma", "kernel": "gemm_kernel (v_mfma_f32_32x32x2_f32), all GEMM / conv launches of one step",
+                     "roofline": {"bound": "mfma", "kernel": "pp_gemm_f_kernel (fp32 engine, v_mfma_f32_32x32x2_f32) + round-1 gemm_kernel, all GEMM / conv launches of one step",
                                   "achieved": xk_fl / (xk_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                   "frac": xk_fl / (xk_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "launches_per_step": xg_n[0] + xg_n[1],
                                   "kernel_ms_per_step": xk_ms, "algorithmic_flops_per_step": xk_fl, "per_kernel": x_per_kernel,
@@ -697,9 +706,9 @@ def main():
         # the committed measurement set of this mode and workload, if any (tools/profile_set.sh: kernel trace, MFMA-busy, FETCH_SIZE and
         # WRITE_SIZE passes on identical launches — the autotuner table is pinned — joined per kernel in per_kernel.json)
         pset = pset_src = None
-        for rdir in ("r04",):
+        for rdir in ("r05", "r04"):
             f = os.path.join(ROOT, "profiles", rdir, a.mode, "per_kernel.json")
-            if world == 1 and emulate is None and not cached and os.path.exists(f):
+            if pset is None and world == 1 and emulate is None and not cached and os.path.exists(f):
                 cand = json.load(open(f))
                 if cand.get("summary", {}).get("config", {}).get("workload", "").split(":")[0] == a.workload:
                     pset, pset_src = cand, os.path.relpath(f, ROOT)
@@ -762,8 +771,8 @@ def main():
             g_traffic = g_src = None   # HBM bytes of these kernels over one step, from separate PMC passes (tools/pmc_step.sh)
             pmc_step = os.path.join(ROOT, "profiles", prof_dir, "pmc_step.json")
             if pset is not None:      # FETCH + WRITE of the kernels this object describes, summed over one step
-                tag = "gemm_kernel<" if a.mode == "exact" else "pp_gemm_u"
-                sel = [kk for kk in pset["kernels"] if tag in kk["kernel"] and kk.get("fetch_bytes") is not None]
+                tags = ("gemm_kernel<", "pp_gemm_f_kernel") if a.mode == "exact" else ("pp_gemm_u",)
+                sel = [kk for kk in pset["kernels"] if any(t in kk["kernel"] for t in tags) and kk.get("fetch_bytes") is not None]
                 if sel:
                     g_traffic, g_src = sum(kk["fetch_bytes"] + kk["write_bytes"] for kk in sel), pset_src
             elif world == 1 and a.mode == "fast" and a.workload == "full_b32_n162_vitb" and os.path.exists(pmc_step):
@@ -773,7 +782,9 @@ def main():
                 "kernel": "pp_gemm_u_kernel / pp_gemm_uh_kernel, all tile instantiations (GEMM / implicit-im2col conv, persistent, LDS-DMA ring; both operands "
                           "pre-split into 2 fp16 terms; 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)" if a.mode == "fast" else
                           ("pp_gemm_u_kernel / pp_gemm_uh_kernel, h operand format (plain fp16 operands, 1 x v_mfma_f32_16x16x32_f16 per product, "
-                           "fp32 accumulate)" if a.mode == "fp16" else "gemm_kernel (v_mfma_f32_32x32x2_f32)"),
+                           "fp32 accumulate)" if a.mode == "fp16" else
+                           "pp_gemm_f_kernel, all tile instantiations (fp32 operands, GEMM / implicit-im2col conv, persistent, LDS-DMA ring, "
+                           "v_mfma_f32_32x32x2_f32) + the round-1 gemm_kernel on batched / unaligned shapes"),
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "frac_algorithmic": fl / (msum * 1e-3) / 1e12 / peak,
                 "frac_note": "frac = EXECUTED MFMA flops (3 fp16 MFMA products per fp32-grade product) / time / fp16 dense peak; "
@@ -792,6 +803,14 @@ def main():
                 "useful_tflops": fl / (msum * 1e-3) / 1e12, "share_of_step": msum / ms,
                 "timing": "HIP events on the launch stream around every launch of one extra, untimed step",
             }
+            # scalars the driver's record keeps (it drops lists and long strings): the kernel with the most time in the step
+            pk = gemm.get("per_kernel") or []
+            if pk:
+                dom = pk[0]
+                line["roofline"].update({
+                    "dominant_kernel": (dom["kernel"] + " | " + dom["a_operand"])[:120], "dominant_launches": dom["launches"], "dominant_ms": dom["ms"],
+                    "dominant_useful_tflops": dom["useful_tflops"], "dominant_frac_algorithmic": dom["useful_tflops"] / peak,
+                    "dominant_frac_executed": mult * dom["useful_tflops"] / peak})
             line["roofline_stage1"] = s1_roof
         else:
             line["roofline"] = s1_roof
@@ -822,6 +841,9 @@ def main():
                                                        "(|activation| < 16376, picopose_amd/ops.py CHECK_SATURATION); a hit aborts the bench"}
             if exact is not None:
                 line["exact_mode"] = exact
+                line["exact_value"] = exact["value"]                 # scalars: the strictly like-for-like (all-fp32) number
+                line["exact_ms_per_step"] = exact["ms_per_step"]
+                line["exact_roofline_frac"] = exact["roofline"]["frac"]
         if emulate is not None:
             line["emulated_world"] = {
                 "world": emulate, "rank": 0, "crops_of_this_rank": Bl, "templates_of_this_rank": n_local, "global_batch": B,

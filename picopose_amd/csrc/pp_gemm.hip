@@ -1151,6 +1151,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     // 6 = 256x256 with row-shared A delivery (3x3 convolutions); 7 / 8 (the former two / three-workgroups-per-CU K-16 kernels) are
     // aliases of 0.  All of them persistent (a launch with fewer tiles than slots is one tile per workgroup) and bit-identical
     // in their results.  fp32 operands (split on the fly, or fp32 MFMA): 0 / 1 = 128x128 at 2 / 3 workgroups per CU, 2 = 128x64.
+    // fp32 operands on aligned shapes: the fp32 engine (pp_gemm_f.hip; configurations 3 = 128x128, 4 = 256x128, 5 = 256x256, 6 = 128x64
+    // — every one of them accumulates in the same order).  The round-1 gemm_kernel keeps batched products, B [K][N], unaligned rows.
+    static const bool f_engine_on = [] { const char* e = getenv("PP_F32_ENGINE"); return !(e && e[0] == '0'); }();
+    const bool fvec = f_engine_on && !asplit && !split && vec && z == 1 && pp_gemm_f_ok(d);
     const bool h_shape = asplit && pp_gemm_uh_shape_ok(d, terms) && pp_gemm_u_vec_ok(d);
     auto u_cfg = [&](int cfg) {   // canonical pre-split configuration
         if (cfg == 3) cfg = 4;
@@ -1165,6 +1169,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             cfg = u_cfg(cfg);
             if (cfg == 6) launch_rc = pp_gemm_uh_launch(d, terms, cus, st);
             else launch_rc = pp_gemm_u_launch(d, cfg == 5 ? PP_U_256x256 : cfg == 4 ? PP_U_256x128 : cfg == 2 ? PP_U_128x64 : PP_U_128x128, terms, cus, st);
+            return;
+        }
+        if (fvec && cfg >= 3) {
+            launch_rc = pp_gemm_f_launch(d, cfg == 5 ? PP_U_256x256 : cfg == 4 ? PP_U_256x128 : cfg == 3 ? PP_U_128x128 : PP_U_128x64, cus, st);
             return;
         }
         const bool narrow = cfg == 2;
@@ -1194,17 +1202,17 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     // Which block tile / occupancy is fastest depends on how the tile count fills the CUs (wave quantisation)
     // and on K; it is measured once per problem shape (timed launches of the same GEMM — idempotent
     // unless the output aliases a residual) and remembered.  PP_GEMM_AUTOTUNE=0 keeps the static choice.
-    int cfg = d.N <= 64 ? 2 : 0;
+    int cfg = fvec ? (d.N <= 64 ? 6 : 3) : (d.N <= 64 ? 2 : 0);
     if (const char* f = getenv("PP_GEMM_FORCE_CFG")) {  // tests: pin one kernel configuration
         const int fc = atoi(f);
-        if (fc >= 0 && fc <= 8 && (asplit || fc <= 2)) {
+        if (fc >= 0 && fc <= 8 && (asplit || fc <= 2 || (fvec && fc <= 6))) {
             launch(fc);
             return finish();
         }
     }
     const bool alias = d.C != nullptr && (d.residual == d.C || d.residual2 == d.C);  // (C is null for operand-only outputs)
     static const bool tune = [] { const char* e = getenv("PP_GEMM_AUTOTUNE"); return !(e && e[0] == '0'); }();
-    if (tune && !alias && d.N > 64) {
+    if (tune && !alias && (d.N > 64 || fvec)) {
         std::mutex& mu = g_tune_mu;
         std::unordered_map<std::string, int>& best = g_tune_best;
         static const bool env_loaded = [] {
@@ -1217,7 +1225,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         (void)env_loaded;
         char key[160];
         snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%lld.%d.%d.%d.%d.%d.%d", d.M, d.N, d.K, (int)vec, d.b_kn, z, d.conv_kh,
-                 d.conv_cin, d.conv_stride, d.conv_h, d.shuffle_r, (int)split + 2 * (d.B_hl != nullptr) + 4 * (int)asplit + 8 * (int)f16);
+                 d.conv_cin, d.conv_stride, d.conv_h, d.shuffle_r, (int)split + 2 * (d.B_hl != nullptr) + 4 * (int)asplit + 8 * (int)f16 + 16 * (int)fvec);
         std::lock_guard<std::mutex> lock(mu);
         auto it = best.find(key);
         if (it == best.end()) {
@@ -1235,6 +1243,12 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                 if (t4 >= cus / 2) cands[nc++] = 4;
                 if (t5 >= cus / 2 && d.N > 128) cands[nc++] = 5;
                 if (t5 >= cus / 2 && d.N > 128 && h_shape) cands[nc++] = 6;
+            } else if (fvec) {
+                const long long t4 = (long long)((d.M + 255) / 256) * ((d.N + 127) / 128), t5 = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256);
+                cands[nc++] = 6;
+                if (d.N > 64) cands[nc++] = 3;
+                if (t4 >= cus / 2 && d.N > 64) cands[nc++] = 4;
+                if (t5 >= cus / 2 && d.N > 128) cands[nc++] = 5;
             } else {
                 for (int c = 0; c < (vec ? 3 : 2); ++c) cands[nc++] = vec ? c : (c == 0 ? 0 : 2);
             }
@@ -1286,14 +1300,15 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             gp->bytes[gp->count] = (double)z * (a_el * ea + (double)d.N * d.K * ew + (d.C ? mn * 4.0 : 0.0) + (d.C_hl ? mn * eb : 0.0) +
                                                (d.residual ? mn * 4.0 : 0.0) + (d.residual2 ? mn * 4.0 : 0.0));
         }
-        gp->kind[gp->count] = asplit ? 0 : 1;
+        gp->kind[gp->count] = asplit ? 0 : 1;   // (pp_prof_gemm_collect: two classes; the fp32 engine is told apart by its mode field, 16 + MODE)
         gp->shape[gp->count][0] = d.M;
         gp->shape[gp->count][1] = d.N;
         gp->shape[gp->count][2] = d.K;
         gp->shape[gp->count][3] = d.conv_kh;
         gp->shape[gp->count][4] = asplit ? ((!pp_gemm_u_vec_ok(d) && u_cfg(cfg) != 2) ? 0 : u_cfg(cfg)) : cfg;   // (element-wise epilogue: the small tiles)
         // pre-split kernels: the A-delivery mode; the others: 8 + (vector loads) + 2 (f16x3 on the fly) — bench.py names the instantiation
-        gp->shape[gp->count][5] = asplit ? (u_cfg(cfg) == 6 ? 1 : pp_gemm_u_mode(d, terms)) : 8 + (vec ? 1 : 0) + (split ? 2 : 0);
+        gp->shape[gp->count][5] = asplit ? (u_cfg(cfg) == 6 ? 1 : pp_gemm_u_mode(d, terms))
+                                         : (fvec && cfg >= 3 ? 16 + pp_gemm_f_mode(d) : 8 + (vec ? 1 : 0) + (split ? 2 : 0));
         gp->count++;
     }
     return finish();

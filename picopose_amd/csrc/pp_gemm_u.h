@@ -18,4 +18,9 @@ int pp_gemm_u_launch(const PpGemmDesc& d, int tile, int terms, int cus, hipStrea
 bool pp_gemm_uh_shape_ok(const PpGemmDesc& d, int terms);
 bool pp_gemm_u_vec_ok(const PpGemmDesc& d);
 int pp_gemm_uh_launch(const PpGemmDesc& d, int terms, int cus, hipStream_t st);
+// The fp32-operand engine (pp_gemm_f.hip: LDS-DMA ring + v_mfma_f32_32x32x2_f32, the same tile ids): eligibility test (fills the
+// operand extents a_hl_bytes / b_hl_bytes), A-delivery mode (0 dense, 1 / 2 convolution) and launch
+bool pp_gemm_f_ok(PpGemmDesc& d);
+int pp_gemm_f_mode(const PpGemmDesc& d);
+int pp_gemm_f_launch(const PpGemmDesc& d, int tile, int cus, hipStream_t st);
 #endif

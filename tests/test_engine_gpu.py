@@ -282,6 +282,64 @@ def test_fused_operand_planes_equal_separate_split(engine_precision):
 
 
 @gpu
+@pytest.mark.parametrize("cfg", ["3", "4", "5", "6"])
+def test_fp32_engine_kernels_pinned(monkeypatch, engine_precision, cfg):
+    """The fp32 engine (csrc/pp_gemm_f.hip: LDS-DMA ring + v_mfma_f32_32x32x2_f32; configurations 3 = 128x128, 4 = 256x128,
+    5 = 256x256, 6 = 128x64) pinned on shapes with row / column / K tails, padded and strided taps, Cin that is not a multiple of
+    the K tile, residuals and the pixel-shuffle store — the cases of the pre-split kernels' pinned tests, in `f32` mode."""
+    if engine_precision != "f32":
+        pytest.skip("the fp32 engine serves ops.PRECISION = 'f32'")
+    _pinned_big_kernel_cases(monkeypatch, cfg)
+
+
+@gpu
+def test_fp32_engine_agrees_bitwise_across_tile_configurations_and_with_the_round1_kernel(monkeypatch, engine_precision):
+    """Every tile configuration of the fp32 engine accumulates an output element in the same order, so its value does not depend on
+    the autotuner's choice (what lets `Net` batch hypotheses in exact mode too).  Dense products also reproduce the round-1
+    gemm_kernel (configuration 0: same K tiles, same pairs per MFMA) bit for bit; convolutions with Cin % 32 == 0 walk K
+    channel-slice-major here and are compared with a tolerance.  Also: ReLU on the A operand, two residuals, LayerScale, strided rows."""
+    if engine_precision != "f32":
+        pytest.skip("the fp32 engine serves ops.PRECISION = 'f32'")
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(10)
+    x, w, b = torch.randn(700, 768, generator=g).cuda(), (torch.randn(384, 768, generator=g) / 27).cuda(), torch.randn(384, generator=g).cuda()
+    gam, res = torch.randn(384, generator=g).cuda(), torch.randn(700, 384, generator=g).cuda()
+    xi = torch.randn(2, 24, 24, 64, generator=g).cuda()
+    wc = ops.pack_conv_weight((torch.randn(256, 64, 3, 3, generator=g) / 24).cuda())
+    xo = torch.randn(3, 20, 20, 72, generator=g).cuda()                                       # Cin % 32 != 0: natural K order
+    wo = ops.pack_conv_weight((torch.randn(136, 72, 3, 3, generator=g) / 25).cuda())
+    r1, r2 = torch.randn(2, 24, 24, 256, generator=g).cuda(), torch.randn(2, 24, 24, 256, generator=g).cuda()
+    x2, w2 = torch.randn(1300, 396, generator=g).cuda(), (torch.randn(200, 396, generator=g) / 20).cuda()   # K % 32 == 12, row / column tails
+    wide = torch.randn(700, 1000, generator=g).cuda()
+    xs = wide[:, 8:8 + 768]                                                                    # strided rows (16-byte aligned start)
+
+    def run():
+        return (ops.linear(x, w, b, act="gelu"), ops.linear(x, w, b, gamma=gam, residual=res), ops.linear(x2, w2, None),
+                ops.linear(xs, w, b, act="leaky01"),
+                ops.conv2d(xi, wc, None, 3, pad=1, act="relu", relu_in=True, residual=r1, residual2=r2),
+                ops.conv2d(xo, wo, None, 3, pad=1))
+
+    outs = {}
+    for cfg in ("0", "3", "4", "5", "6"):
+        monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
+        outs[cfg] = run()
+    for cfg in ("4", "5", "6"):
+        for a, b_ in zip(outs[cfg], outs["3"]):
+            assert torch.equal(a, b_), cfg
+    for k in (0, 2, 3):                      # dense: the round-1 kernel's bits
+        assert torch.equal(outs["3"][k], outs["0"][k]), k
+    _close(outs["3"][1], outs["0"][1], 1e-6)  # (LayerScale + residual: one fma here, a product and a sum there)
+    assert torch.equal(outs["3"][5], outs["0"][5])       # natural K order: the same chain as the round-1 kernel
+    _close(outs["3"][4], outs["0"][4], 2e-6)
+    ref = F.gelu(F.linear(x.cpu(), w.cpu(), b.cpu()))
+    _close(outs["3"][0], ref)
+    _close(outs["3"][1], res.cpu() + gam.cpu() * F.linear(x.cpu(), w.cpu(), b.cpu()))
+    _close(outs["3"][2], x2.cpu() @ w2.cpu().t())
+    _close(outs["3"][3], F.leaky_relu(F.linear(xs.cpu(), w.cpu(), b.cpu()), 0.1))
+
+
+@gpu
 def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, engine_precision):
     """The three pre-split kernels (128x128, 128x64, 256x128 LDS-DMA) walk K in the same order and accumulate the
     same way, so the value of an output element does not depend on which one the autotuner picks for a shape —

@@ -13,6 +13,10 @@ import bench  # noqa: E402
 from picopose_amd import _lib  # noqa: E402
 from picopose_amd.picopose import Net  # noqa: E402
 
+from picopose_amd import ops  # noqa: E402
+
+if os.environ.get("PP_TRACE_MODE"):     # "f32" (exact) / "f16x3" (default) / "f16"
+    ops.PRECISION = os.environ["PP_TRACE_MODE"]
 dev = torch.device("cuda", 0)
 vit, Bl, N = "dinov2_vitb14", 32, 162
 net = Net(bench.make_cfg(vit))
@@ -37,6 +41,6 @@ for i in range(cnt.value):
     a[0] += 1; a[1] += ms[i]; a[2] += fl[i]
 tot = sum(a[1] for a in agg.values())
 print(f"{cnt.value} launches, {tot:.1f} ms")
-for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
     M, Nn, K, ck, cf, kind = key
     print(f"  {a[1]:7.3f} ms x{a[0]:3d}  M={M:7d} N={Nn:5d} K={K:6d} {'conv ' if ck else 'dense'} cfg={cf} {'engine' if kind == 0 else 'fly'}  {a[2] / max(a[1], 1e-9) / 1e9:6.1f} TF/s useful")
