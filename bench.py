@@ -66,6 +66,9 @@ WORKLOADS = {
     "full_cached_b32_n162_vitb": ("full_cached", 32, 162, "dinov2_vitb14",
                                   "configs[2] with the EXTENDED template bank (template-side DPT maps precomputed too, SURVEY 8f row 1)"),
     "full_b8_n42_vitl": ("full", 8, 42, "dinov2_vitl14", "batch 8, 42 templates, ViT-L/14 (config/base.yaml backbone), stage1+2+3 + PnP/RANSAC, hyp 5"),
+    # config/base.yaml, the reference's ONLY configuration: ViT-L/14, 162 templates, hyp 5, test batch 4 — and the same network at batch 32
+    "full_b4_n162_vitl": ("full", 4, 162, "dinov2_vitl14", "config/base.yaml: ViT-L/14, 162 templates, hyp 5, test batch 4 (run_test.py:102), stage1+2+3 + PnP/RANSAC"),
+    "full_b32_n162_vitl": ("full", 32, 162, "dinov2_vitl14", "config/base.yaml's network at batch 32: ViT-L/14, 162 templates, hyp 5, stage1+2+3 + PnP/RANSAC"),
     "stage1_b32_n162_c768": ("stage1", 32, 162, "dinov2_vitb14", "configs[2] stage-1 shape: matching_templates only"),
     "stage1_b8_n42_c384": ("stage1", 8, 42, "dinov2_vits14", "configs[1]: batch 8, 42 templates, ViT-S/14, stage-1 matching only"),
     "stage1_b32_n162_c1024": ("stage1", 32, 162, "dinov2_vitl14", "base.yaml shape (ViT-L/14), stage-1 matching only"),
@@ -242,6 +245,52 @@ CFG_KERNEL = {0: "pp_gemm_u_kernel<128x128, 4 waves, 2-stage ring, 2 workgroups/
               6: "pp_gemm_uh_kernel (256x256, row-shared A delivery of 3x3 convolutions)"}
 
 
+def latency_leg(dev, s1_mode, images=10, n_det=8, bs=4, N=162, vit="dinov2_vitl14", n_obj=2, hyp=5):
+    """What the reference itself measures (run_test.py:141-216: `end = time.time()` ... `image_time = time.time() - end`, mean seconds per
+    test image) at its own configuration (config/base.yaml: ViT-L/14, 162 templates, hyp 5, test batch 4): one test image = `n_det`
+    detections walked in chunks of `bs` by picopose_amd.pipeline.infer_image — per chunk the gather of the detections' object banks
+    (`templates_data[key][obj_idx].contiguous()`), Net.forward, PnP/RANSAC of its bs * hyp problems, D2H, hypothesis ranking on the host.
+    Wall clock per image after a device synchronisation, like the reference; synthetic detections of `n_obj` objects (seg_time = 0).
+    The template feature bank is computed once outside, in chunks of `bs` renders (run_test.py:120-134)."""
+    from picopose_amd.picopose import Net
+    from picopose_amd.pipeline import infer_image
+
+    net = Net(make_cfg(vit))
+    seeded_weights(net, 4, vit)
+    net = net.to(dev).eval()
+    net.match_mode = s1_mode
+    tem = make_end_points(n_obj, N, dev, 300)
+    templates_data = {k: v for k, v in tem.items() if k.startswith("tem_")}
+    with torch.no_grad():
+        templates_data["template_feature"] = torch.stack([torch.cat([net.feature_extractor(tem["tem_rgb"][o, s0:s0 + bs])[-1] for s0 in range(0, N, bs)])
+                                                          for o in range(n_obj)])
+    g = torch.Generator().manual_seed(7)
+    times, disp = [], None
+    for i in range(images + 2):
+        det = make_end_points(n_det, 1, dev, 400 + i)
+        data = {k: v[None] for k, v in det.items() if k.startswith("real_")}
+        data["obj_idx"] = torch.randint(0, n_obj, (1, n_det, 1), generator=g).to(dev)
+        data["score"] = torch.rand(1, n_det, generator=g).to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            preds = infer_image(net, data, templates_data, hyp=hyp, bs=bs)
+        dt = time.perf_counter() - t0
+        assert len(preds) == n_det and len(preds[0]) == hyp
+        if i >= 2:            # (two warm-up images: autotuner, allocator)
+            times.append(dt * 1e3)
+    times.sort()
+    med = times[len(times) // 2]
+    del net, templates_data, tem
+    torch.cuda.empty_cache()
+    return {"what": "wall-clock per test image as run_test.py:142-188 takes it (synchronise, then chunks of bs detections: bank gather + forward + "
+                    "PnP/RANSAC + D2H + ranking), seg_time excluded",
+            "config": f"config/base.yaml: {vit}, {N} templates, hyp {hyp}, test batch {bs}; {n_det} detections per image of {n_obj} objects",
+            "ms_per_image": med, "ms_per_image_min": times[0], "ms_per_image_max": times[-1], "images": len(times),
+            "detections_per_image": n_det, "chunk": bs, "ms_per_chunk": med / (-(-n_det // bs)), "crops_per_s": n_det / (med * 1e-3),
+            "seconds_per_image": med * 1e-3}
+
+
 F_CFG_KERNEL = {3: "pp_gemm_f_kernel<128x128, 4 waves, fp32 MFMA, 2 workgroups/CU>", 4: "pp_gemm_f_kernel<256x128, 8 waves, fp32 MFMA>",
                 5: "pp_gemm_f_kernel<256x256, 8 waves, fp32 MFMA>", 6: "pp_gemm_f_kernel<128x64, 4 waves, fp32 MFMA, 2 workgroups/CU>"}
 
@@ -349,6 +398,8 @@ def main():
                          "copies of the same sizes; reports phases_ms and the rank's peak memory.  Not a measurement of the exchange.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the untimed --mode exact comparison leg")
+    ap.add_argument("--no-latency-leg", action="store_true",
+                    help="skip the per-image latency leg (the reference's own measurement: ViT-L/14, 162 templates, hyp 5, chunks of 4 detections)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("PP_BENCH_REHEARSE") != "1":
@@ -858,6 +909,10 @@ def main():
                             "choice (shapes missing from it were tuned in this run)" if tune["loaded"] else
                             "tuned in this run and written for the other passes of the measurement set")
             line["autotune"] = tune
+        if world == 1 and emulate is None and kind == "full" and not a.no_latency_leg:
+            ops.PRECISION = {"fast": "f16x3", "exact": "f32", "fp16": "f16"}[a.mode]
+            line["latency"] = latency_leg(dev, s1_mode)
+            line["latency_ms_per_image"] = line["latency"]["ms_per_image"]
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_full(N, vit, sd) if kind == "full" else cpu_baseline_stage1(N, C)
         print(json.dumps(line), flush=True)

@@ -712,10 +712,83 @@ def gen_train_grads_dup():
     gen_train_grads("train_grads_dup")
 
 
+def gen_train_grads_f64():
+    """The SAME training step as train_grads.npz (same weights, batch and augmentation draw: `pred_Ms` is taken from that fixture) with the
+    reference evaluated in FLOAT64 — module in .double(), inputs in double, default dtype float64, and the reference's explicit `.float()`
+    casts widened for the duration of this run — then d(Loss) / d(every parameter), stored as grad3f64/<name> at the strides of grad3/<name>.
+    It is the arbiter for gradient tensors too ill-conditioned for an fp32-vs-fp32 bar (the DPT fusion blocks between
+    batch-statistics BatchNorms): tests/test_train_gpu.py asserts |HIP - f64| <= 2 |reference-fp32 - f64| + 1e-7 max|grad| for them."""
+    _ref()
+    sys.path.insert(0, os.path.join(REF, "model"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import ref_shims
+
+    ref_shims.install()
+    import picopose as ref_picopose
+
+    from oracle.weights import AFFINE_CALIBRATION, HEAD_CALIBRATION, PROJ_BN_GAIN, apply_head_calibration, seeded_state_dict
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from netcfg import make_train_end_points, train_case, train_kwargs
+
+    src = os.path.join(OUT, "train_grads.npz")     # (a regeneration into a scratch directory reads the committed fp32 fixture)
+    if not os.path.exists(src):
+        src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "train_grads.npz")
+    f32 = np.load(src)
+    B, seed, edit = train_case("train_forward")
+    vit, wseed = "dinov2_vits14", 4
+    net = ref_picopose.Net(_cfg(vit)).train()
+    cal = dict(HEAD_CALIBRATION[vit], affine=AFFINE_CALIBRATION, proj_bn=PROJ_BN_GAIN)
+    net.load_state_dict(apply_head_calibration(seeded_state_dict(net.state_dict(), wseed), cal))   # the fp32 weights, then widened
+    net = net.double()
+    ep = edit(make_train_end_points(B, seed, **train_kwargs("train_grads")))
+    ep = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in ep.items()}
+    orig_aug, orig_float, orig_dtype = ref_picopose.aug_gtM_noise, torch.Tensor.float, torch.get_default_dtype()
+    ref_picopose.aug_gtM_noise = lambda end_points: torch.from_numpy(f32["pred_Ms"]).double()
+    torch.Tensor.float = lambda self, *a, **k: self.double()
+    torch.set_default_dtype(torch.float64)
+    try:
+        np.random.seed(1000 + seed)
+        torch.manual_seed(2000 + seed)
+        res = net(ep)
+        from utils.loss_utils import Loss
+
+        total = Loss()(res)["loss"]
+        params = list(net.named_parameters())
+        grads = torch.autograd.grad(total, [p for _, p in params], allow_unused=True)
+    finally:
+        ref_picopose.aug_gtM_noise, torch.Tensor.float = orig_aug, orig_float
+        torch.set_default_dtype(orig_dtype)
+    assert total.dtype == torch.float64
+    out = {"meta": np.array([B, seed, wseed], dtype=np.int64), "total_loss": total.detach().numpy(),
+           "total_loss_f32_reference": f32["total_loss"]}
+    print("total loss f64 %.9f   fp32 reference %.9f" % (float(total), float(f32["total_loss"])))
+    for k in [k for k in res if "loss" in k]:
+        out[k] = res[k].detach().numpy()
+    worst = (0.0, "")
+    for (n, p), g in zip(params, grads):
+        out[f"grad3f64used/{n}"] = np.bool_(g is not None)
+        assert bool(out[f"grad3f64used/{n}"]) == bool(f32[f"grad3used/{n}"]), n
+        g = torch.zeros_like(p) if g is None else g
+        flat = g.detach().reshape(-1)
+        stride = max(1, -(-flat.numel() // (GRAD_SAMPLES // 32)))
+        out[f"grad3f64/{n}"] = flat[::stride].numpy()
+        out[f"grad3f64norm/{n}"] = np.float64(flat.norm())
+        ref32 = f32[f"grad3/{n}"]
+        assert ref32.shape == out[f"grad3f64/{n}"].shape, n
+        d = float(np.abs(ref32 - out[f"grad3f64/{n}"]).max()) / max(float(np.abs(out[f"grad3f64/{n}"]).max()), 1e-30)
+        if bool(f32[f"grad3used/{n}"]) and d > worst[0]:
+            worst = (d, n)
+    print("fp32 reference against float64, worst tensor: %.3g of its maximum (%s)" % worst)
+    np.savez_compressed(os.path.join(OUT, "train_grads_f64.npz"), **out)
+    print("training-gradient fixture written: train_grads_f64")
+
+
 GENERATORS = {"stage1": gen_stage1, "geometry": gen_geometry, "nets": gen_nets, "e2e": gen_e2e,
               "e2e_calibrated": gen_e2e_calibrated, "vit_wide": gen_vit_wide, "state_dict": gen_state_dict,
               "preprocess": gen_preprocess, "run_test": gen_run_test, "train_forward": gen_train_forward, "train_forward_edge": gen_train_forward_edge, "e2e_calibrated_vitl": gen_e2e_calibrated_vitl,
-              "train_grads": gen_train_grads, "train_grads_dup": gen_train_grads_dup}
+              "train_grads": gen_train_grads, "train_grads_dup": gen_train_grads_dup,
+              "train_grads_f64": gen_train_grads_f64}
 
 
 if __name__ == "__main__":

@@ -21,6 +21,9 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 // 1.5e-6 absolute over |x| <= 10).  13 FMAs + v_rcp_f32 instead of libm's branchy erff (~50 instructions, 15 % of the
 // fc1 GEMM of a ViT block).
 __device__ __forceinline__ float erf_rational(float z) {
+#ifdef PP_STUDY_EXACT_ERF   // (accuracy study builds only: libm's erff in every GELU epilogue — profiles/r05/grad_f64.txt)
+    return erff(z);
+#endif
     const float zc = fminf(fmaxf(z, -3.925f), 3.925f), t = zc * zc;
     float p = 2.086927816e-06f, q = 3.855828442e-05f;
     p = fmaf(p, t, 2.864863205e-04f);

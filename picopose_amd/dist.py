@@ -120,6 +120,130 @@ def sharded_forward(net, local_end_points, local_bank, n_total, hyp=5, group=Non
         return outs
 
 
+class LocalWorld:
+    """A one-process stand-in for `torch.distributed` that runs ALL ranks of a sharded job: every rank is a thread, and a collective is
+    a REAL exchange between them (an all-gather returns every rank's contribution, not copies of the caller's).  It exists so that the
+    real shard shapes of BASELINE configs[3] — 8 ranks, 4 crops and 21 / 20 templates each — run through `sharded_forward` on a one-GPU
+    box (tests/test_dist_gpu.py) and so that `bench.py --emulate-world` has the same semantics as the multi-process job; the RCCL hop
+    itself is the one thing it does not exercise.
+
+    Ranks take TURNS: a thread computes only while it holds the run token and hands it over when it waits for a collective, so between two
+    collectives a rank's launches are never interleaved with another rank's (the model keeps per-shape scratch buffers, and one process per
+    GPU is the product's configuration).  All ranks enqueue on the same HIP stream, whose order makes a producer's writes visible to the
+    ranks that copy them after the rendezvous.
+
+        world = LocalWorld(8)
+        with world.installed():                       # picopose_amd.dist.dist -> this object
+            outs = world.run(lambda rank: sharded_forward(net, ep[rank], bank[rank], N))
+    """
+    ReduceOp = dist.ReduceOp
+
+    class _Work:
+        def __init__(self, world, seq, out, shape):
+            self.world, self.seq, self.out, self.shape, self.done = world, seq, out, shape, False
+
+        def wait(self):
+            if self.done:
+                return None
+            w = self.world
+            w._token.release()               # hand the card to the next rank while this one waits for the others
+            try:
+                w._barrier.wait()
+            finally:
+                w._token.acquire()
+            parts = w._slots[self.seq]
+            self.out.view(w.world, *self.shape).copy_(torch.stack([parts[r] for r in range(w.world)]))
+            w._taken[self.seq] = w._taken.get(self.seq, 0) + 1
+            if w._taken[self.seq] == w.world:    # every rank has its copy: drop the contributions
+                del w._slots[self.seq], w._taken[self.seq]
+            self.done = True
+            return None
+
+    def __init__(self, world):
+        import threading
+
+        self.world = int(world)
+        self._tls = threading.local()
+        self._token = threading.Lock()
+        self._barrier = threading.Barrier(self.world)
+        self._slots, self._taken = {}, {}
+
+    # ---- the subset of torch.distributed this module uses
+    def get_rank(self, group=None):
+        return self._tls.rank
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def is_available(self):
+        return True
+
+    def is_initialized(self):
+        return True
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        seq = self._tls.seq                  # the n-th collective of a rank meets the n-th collective of every other rank
+        self._tls.seq += 1
+        assert out.numel() == self.world * inp.numel(), (tuple(out.shape), tuple(inp.shape))
+        self._slots.setdefault(seq, {})[self._tls.rank] = inp
+        work = LocalWorld._Work(self, seq, out, tuple(inp.shape))
+        if async_op:
+            return work
+        work.wait()
+        return None
+
+    def barrier(self, group=None):
+        self._token.release()
+        try:
+            self._barrier.wait()
+        finally:
+            self._token.acquire()
+
+    # ---- driver
+    def installed(self):
+        """Context manager: this module's `dist` is the stand-in inside, torch.distributed again outside."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            g = globals()
+            old = g["dist"]
+            g["dist"] = self
+            try:
+                yield self
+            finally:
+                g["dist"] = old
+        return cm()
+
+    def run(self, fn):
+        """fn(rank) on every rank (one thread each, taking turns); returns [fn(0), ..., fn(world - 1)] or re-raises a rank's exception."""
+        import threading
+
+        results, errors = [None] * self.world, [None] * self.world
+
+        def body(rank):
+            self._tls.rank, self._tls.seq = rank, 0
+            self._token.acquire()
+            try:
+                results[rank] = fn(rank)
+            except BaseException as e:      # noqa: BLE001  (re-raised in the caller; the others must not wait for this rank)
+                errors[rank] = e
+                self._barrier.abort()
+            finally:
+                self._token.release()
+
+        threads = [threading.Thread(target=body, args=(r,), name=f"rank{r}") for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        first = next((e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)), None) or \
+            next((e for e in errors if e is not None), None)
+        if first is not None:
+            raise first
+        return results
+
+
 def allreduce_gradients(parameters, group=None, bucket_bytes=25 << 20):
     """The gradient averaging of DistributedDataParallel (utils/lite.py / run_train.py:109-130 train with strategy='ddp') for the
     parameters that carry a `.grad` — with the default scope of picopose_amd/autograd.py ("full") every parameter the reference

@@ -40,3 +40,41 @@ def test_sharded_matching_world2_gloo():
     out = r.stdout.decode()
     assert r.returncode == 0, out[-2000:]
     assert "RANK0 OK" in out and "RANK1 OK" in out, out[-2000:]
+
+
+def test_local_world_eight_ranks_at_the_configs3_shard_layout():
+    """picopose_amd.dist.LocalWorld (every rank a thread of ONE process, collectives real exchanges) at the shard layout of BASELINE
+    configs[3]: world 8, global batch 32, 162 templates -> 4 crops + 21 / 20 templates per rank (narrow C: the oracle scores on CPU).
+    Every rank gets the full-bank result of its own crops from `sharded_forward`, and `sharded_matching_templates` the global one."""
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import picopose_amd.dist as pd
+    from oracle import matching as om
+
+    torch.set_num_threads(4)
+    world, bl, N, C, hyp = 8, 4, 162, 8, 5
+    g = torch.Generator().manual_seed(11)
+    Bt = world * bl
+    bank = torch.randn(Bt, N, C, 16, 16, generator=g)
+    rgb = torch.randn(Bt, C, 16, 16, generator=g)
+    mask = (torch.rand(Bt, 224, 224, generator=g) < 0.7).float()
+    score = lambda b, q, m: om.template_scores(b, q, m)            # noqa: E731
+    topk = lambda sc, k: torch.topk(sc, k, dim=1)                  # noqa: E731
+
+    def body(rank):
+        lo, hi = pd.shard_bounds(N, world, rank)
+        own = slice(rank * bl, (rank + 1) * bl)
+        ids = pd.sharded_forward(None, {"real_rgb": rgb[own], "real_mask": mask[own]}, bank[:, lo:hi].contiguous(), N, hyp=hyp,
+                                 features_fn=lambda x: ("state", x), scores_fn=score, topk_fn=topk, tail_fn=lambda e, i, real: i)
+        s, i = pd.sharded_matching_templates(bank[:, lo:hi].contiguous(), rgb, mask, N, topk=hyp, score_fn=score, topk_fn=topk)
+        return ids, s, i
+
+    lw = pd.LocalWorld(world)
+    with lw.installed():
+        outs = lw.run(body)
+    assert pd.dist is torch.distributed
+    ws, wi = om.matching_templates(bank, rgb, None, mask, topk=hyp)
+    for rank, (ids, s, i) in enumerate(outs):
+        assert torch.equal(ids, wi[rank * bl:(rank + 1) * bl]), rank
+        assert torch.equal(i, wi) and float((s - ws).abs().max()) <= 1e-6, rank

@@ -26,7 +26,7 @@ FAST = {"stage1": ["stage1_matching_templates.npz", "stage2_similarity.npz"], "g
         "state_dict": ["state_dict_names.json"], "preprocess": ["preprocess_boxes.npz"], "run_test": ["run_test_rows.json"],
         "train_forward": ["train_forward.npz"], "train_forward_edge": ["train_forward_edge.npz"], "vit_wide": ["vit_wide.npz"],
         "e2e": ["e2e.npz"], "train_grads_dup": ["train_grads_dup.npz"]}
-SLOW = {"e2e_calibrated": ["e2e_calibrated.npz"], "train_grads": ["train_grads.npz"]}
+SLOW = {"e2e_calibrated": ["e2e_calibrated.npz"], "train_grads": ["train_grads.npz"], "train_grads_f64": ["train_grads_f64.npz"]}
 
 
 def _cal_table(vit):

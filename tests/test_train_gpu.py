@@ -799,14 +799,14 @@ def test_full_backward_matches_the_reference_autograd(golden_dir, precision):
         tot.backward()
     finally:
         ops.PRECISION = old
-    # Bars: max|err| / max|grad| <= 3e-3 per tensor (measured 2.6e-4 .. 4.7e-4 f16x3 / 1.1e-3 f32), the tensor's L2 norm within 3e-4 (8e-5).
+    # Bars: max|err| / max|grad| <= 3e-3 per tensor against the reference's fp32 autograd, the tensor's L2 norm within 3e-4.
     # The DPT head's FUSION BLOCKS (scratch.refinenet*: convolutions between batch-statistics BatchNorms on 2 x 16 x 16 .. 64 x 64 samples,
-    # gradients of 3e-7 .. 7e-5 against the model's largest 3.6) are ill-conditioned in the forward values: a 3e-7 RELATIVE random
-    # perturbation of the attention outputs — below the 1e-6 by which any two fp32 evaluations of a soft-max differ, the reference's
-    # included — moves single entries by 1.7e-3 of the tensor's maximum, 1e-5 by 3.8e-3 (profiles/r04/grad_sensitivity.txt; the
-    # norms stay within 8e-5).  Their bar is 1e-2; measured 3.9e-3 with the fused attention forward, 2.6e-4 with the unfused one,
-    # whose operation order is torch's.
-    TOL, TOL_SMALL = 3e-3, 1e-2
+    # gradients of 3e-7 .. 7e-5 against the model's largest 3.6) carried a restated 1e-2 bar in round 4 (3.9e-3 measured with the fused
+    # attention forward).  Round 5 settles them against a FLOAT64 evaluation of the reference (train_grads_f64.npz, oracle/gen_golden.py
+    # gen_train_grads_f64): every tensor's distance to float64 is reported beside the fp32 reference's own, and the fusion blocks are
+    # held to F64_BAR of their maximum against float64 — the arbiter — instead of to a looser bar against another fp32 evaluation.
+    z64 = np.load(os.path.join(golden_dir, "train_grads_f64.npz"))
+    TOL, F64_BAR = 3e-3, 5e-3
     report, n_checked, n_zero = [], 0, 0
     gmax = max(float(z[k]) for k in z.files if k.startswith("grad3norm/"))
     for name, p in net.named_parameters():
@@ -831,16 +831,24 @@ def test_full_backward_matches_the_reference_autograd(golden_dir, precision):
             assert float(flat.double().norm()) < bar, (name, float(flat.double().norm()), bar)
             n_zero += 1
             continue
-        report.append((float((got - ref).abs().max()) / scale, abs(float(flat.double().norm()) - nref) / max(nref, 1e-30), name, ".scratch.refinenet" in name))
+        ref64 = torch.from_numpy(z64[f"grad3f64/{name}"])
+        d_hip64 = float((got.double() - ref64).abs().max()) / scale
+        d_ref64 = float((ref.double() - ref64).abs().max()) / scale
+        report.append((float((got - ref).abs().max()) / scale, abs(float(flat.double().norm()) - nref) / max(nref, 1e-30), name, ".scratch.refinenet" in name,
+                       d_hip64, d_ref64))
         n_checked += 1
     report.sort(reverse=True)
     print(f"({n_zero} bias tensors with an analytically zero gradient: noise below 1e-3 of their weight's gradient / 1e-6 of the largest gradient on both sides)")
     short = lambda n: n.replace("feature_extractor.dinov2.", "vit.").replace("offset_regressor.", "")   # noqa: E731
     print(f"full backward [{precision}]: {n_checked} parameter tensors, worst max|err| / max|grad| = {report[0][0]:.2e}, worst norm error "
-          f"{max(b for _, b, _, _ in report):.2e}; worst eight:", [(f"{a:.1e}", f"{b:.1e}", short(n), "fusion block" if sm else "") for a, b, n, sm in report[:8]])
+          f"{max(r[1] for r in report):.2e}; worst eight:", [(f"{r[0]:.1e}", f"{r[1]:.1e}", short(r[2]), "fusion block" if r[3] else "") for r in report[:8]])
+    by64 = sorted(report, key=lambda r: -r[4])
+    print(f"against float64 [{precision}]: worst |HIP - f64| / max|grad| = {by64[0][4]:.2e} (the fp32 reference's own worst: {max(r[5] for r in report):.2e}); "
+          "worst eight (HIP-f64, ref32-f64, tensor):", [(f"{r[4]:.1e}", f"{r[5]:.1e}", short(r[2])) for r in by64[:8]])
     assert n_checked + n_zero == 338 and n_zero <= 40
-    assert all(a <= (TOL_SMALL if sm else TOL) for a, _, _, sm in report), [r for r in report if r[0] > (TOL_SMALL if r[3] else TOL)][:3]
-    assert max(b for _, b, _, _ in report) <= 3e-4     # (the L2 norms of the gradient tensors)
+    assert all(r[0] <= TOL for r in report if not r[3]), [r for r in report if r[0] > TOL and not r[3]][:3]
+    assert all(r[4] <= F64_BAR for r in report), [r for r in by64 if r[4] > F64_BAR][:3]       # every tensor, the fusion blocks included
+    assert max(r[1] for r in report) <= 3e-4     # (the L2 norms of the gradient tensors)
 
 
 @gpu
