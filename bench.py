@@ -396,6 +396,8 @@ def main():
                     help="8-GPU preflight on ONE GPU in ONE process: run rank 0's share of a --scaling strong job of this many ranks "
                          "(its crops, its template slice, every launch at the real shard shapes) with the collectives replaced by local "
                          "copies of the same sizes; reports phases_ms and the rank's peak memory.  Not a measurement of the exchange.")
+    ap.add_argument("--no-prefetch-query", dest="prefetch_query", action="store_false",
+                    help="the query ViT of every batch as its own pass (rounds 1-4) instead of inside the previous batch's template-side pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the untimed --mode exact comparison leg")
     ap.add_argument("--no-latency-leg", action="store_true",
@@ -553,7 +555,10 @@ def main():
             ep["template_feature"] = feats
 
         def forward(mark=None):
-            return sharded_forward(net, ep, bank, N, hyp=5, mark=mark) if sharded else net(ep, 5)
+            if sharded:
+                return sharded_forward(net, ep, bank, N, hyp=5, mark=mark)
+            # a serving loop knows its next batch: its query crops ride in this batch's template-side ViT pass (Net.forward_test)
+            return net(ep, 5, next_real_rgb=ep["real_rgb"]) if a.prefetch_query else net(ep, 5)
 
         def step():
             outs = forward()

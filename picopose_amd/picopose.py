@@ -28,6 +28,16 @@ from .utils.torch_utils import calc_pred_Ms
 # One pass of the DPT head over [selected templates ; query crops] instead of one pass each (PP_BATCH_DPT=0: two passes, A/B)
 BATCH_VIT_TRAIN = os.environ.get("PP_BATCH_VIT_TRAIN", "1") != "0"
 BATCH_DPT = os.environ.get("PP_BATCH_DPT", "1") != "0"
+# The NEXT batch's query ViT inside this batch's template-side ViT pass (Net.forward(..., next_real_rgb=...); PP_PREFETCH_QUERY=0: off, A/B)
+PREFETCH_QUERY = os.environ.get("PP_PREFETCH_QUERY", "1") != "0"
+
+
+def _tensor_key(t, fe=None):
+    """Identity of a tensor's contents as far as the host can tell: storage address, shape, version counter — and, for the query stash of
+    Net.forward_test, what its levels were computed WITH: the engine's arithmetic mode and the feature extractor's weights (the
+    signature model/common.Packed watches; a write through `.data` needs Net.invalidate_packed(), which also drops the stash)."""
+    key = (t.data_ptr(), tuple(t.shape), t._version, ops.PRECISION)
+    return key if fe is None else key + (fe._signatures()[0],)
 
 
 def _image_rows(p, b0, b1):
@@ -67,6 +77,7 @@ class Net(nn.Module):
         for m in self.modules():
             if isinstance(m, Packed):
                 m.invalidate_packed()
+        self._query_stash = None
 
     # model/picopose.py:52-70 — pick hypothesis k's template for every crop (pure indexing)
     def select_template_data(self, end_points, pred_id_src, k):
@@ -111,7 +122,17 @@ class Net(nn.Module):
         output["tar_pts_2d"] = end_points["real_pts2d"].permute(0, 3, 2, 1)
         output["src_pts_3d"] = end_points["tem_pts3d"].permute(0, 3, 1, 2)
         # stage 1: template features
-        if tem_cached is None:
+        pre = real[4] if len(real) > 4 else None        # (level buffers with room in front, the NEXT batch's query crops): forward_test
+        if tem_cached is None and pre is not None and levels is not None:
+            # the next batch's query ViT rides in this batch's template pass: rows [next queries ; templates] of one launch per layer
+            # (a GEMM row does not depend on the other rows: every token keeps its bits); its four levels stay behind as the stash
+            alloc, nxt = pre
+            Bn, T = nxt.shape[0], h0 * w0 + 1
+            both, _ = fe.forward_tokens(torch.cat([nxt, end_points["tem_rgb"]]), level_out=(alloc, 0))
+            tem_tok = [t[Bn:] for t in both]
+            self._query_stash = (_tensor_key(nxt, fe), [a[:Bn * T] for a in alloc], (h0, w0))
+            tem_last = ops.tokens_to_nchw(tem_tok[-1], 1, h0, w0)
+        elif tem_cached is None:
             tem_tok, _ = fe.forward_tokens(end_points["tem_rgb"], level_out=None if levels is None else (levels, 0))
             tem_last = ops.tokens_to_nchw(tem_tok[-1], 1, h0, w0)
         else:
@@ -184,24 +205,38 @@ class Net(nn.Module):
         toks = ([rep(t) for t in real_tok] if real_dpt is None and levels is None
                 else [None] * (len(real_tok) - 1) + [rep(real_tok[-1])])
         # (the query-side DPT maps go in un-repeated: the flow decoder projects them once and tiles the projection)
-        out = self.forward_test_hyp(sel, (toks, hw, real_dpt, levels if cache is None else None),
+        out = self.forward_test_hyp(sel, (toks, hw, real_dpt, levels if cache is None else None, real[4] if len(real) > 4 and cache is None else None),
                                     cached(rows, idx))
         return [{key: v[k * B:(k + 1) * B] for key, v in out.items()} for k in range(hyp)]
 
     # model/picopose.py:97-112
-    def forward_test(self, end_points, hyp=5):
+    def forward_test(self, end_points, hyp=5, next_real_rgb=None):
+        """next_real_rgb: the query crops of the batch this forward will be called with NEXT (a serving loop, the mini-batches of a test
+        image: picopose_amd/pipeline.infer_image).  Their ViT pass does not depend on this batch, so it runs as extra rows of this batch's
+        template-side ViT launches ((hyp + 1) B images per launch instead of hyp B and, separately, B at a fifth of the rows and two thirds
+        of the tile fill), and the next call finds its query levels stashed — same bits with or without (tests/test_e2e.py)."""
         with torch.no_grad():
             fe = self.feature_extractor
             levels = None
+            stash, self._query_stash = getattr(self, "_query_stash", None), None
             if BATCH_DPT and self.batch_hypotheses and end_points.get("template_cache") is None:
                 # the four feature levels of the hyp * B selected templates and of the B query crops share one buffer per level
                 # (templates first): the DPT head then runs ONCE over both (forward_test_hyp)
                 B, _, H, W = end_points["real_rgb"].shape
                 T = (H // fe.patch_size) * (W // fe.patch_size) + 1
-                levels = [torch.empty((hyp + 1) * B * T, fe.num_features, dtype=torch.float32, device=end_points["real_rgb"].device)
-                          for _ in fe.blocks_to_take]
-                real_tok, (h0, w0) = fe.forward_tokens(end_points["real_rgb"], level_out=(levels, hyp * B))
-                real = (real_tok, (h0, w0), None, levels)
+                pre_ok = PREFETCH_QUERY and next_real_rgb is not None and tuple(next_real_rgb.shape[1:]) == (3, H, W) and next_real_rgb.is_contiguous()
+                Bn = next_real_rgb.shape[0] if pre_ok else 0
+                alloc = [torch.empty((Bn + (hyp + 1) * B) * T, fe.num_features, dtype=torch.float32, device=end_points["real_rgb"].device)
+                         for _ in fe.blocks_to_take]
+                levels = [a_[Bn * T:] for a_ in alloc]           # [templates ; query crops]; the Bn images in front: the next batch's queries
+                if stash is not None and stash[0] == _tensor_key(end_points["real_rgb"], fe) and stash[1][0].shape[0] == B * T:
+                    (h0, w0) = stash[2]
+                    for lv, st in zip(levels, stash[1]):        # computed inside the previous batch's template pass
+                        lv[hyp * B * T:].copy_(st)
+                    real_tok = [lv[hyp * B * T:].view(B, T, -1) for lv in levels]
+                else:
+                    real_tok, (h0, w0) = fe.forward_tokens(end_points["real_rgb"], level_out=(levels, hyp * B))
+                real = (real_tok, (h0, w0), None, levels, (alloc, next_real_rgb) if Bn else None)
             else:
                 real_tok, (h0, w0) = fe.forward_tokens(end_points["real_rgb"])
                 real_dpt = self.offset_regressor.dpt_head.forward_nhwc([t[:, 1:].unflatten(1, (h0, w0)) for t in real_tok])
@@ -295,7 +330,7 @@ class Net(nn.Module):
                 self.last_stage3 = (flows[-1], certs[-1])
         return end_points
 
-    def forward(self, end_points, hyp=5):
+    def forward(self, end_points, hyp=5, next_real_rgb=None):
         if self.training:
             return self.forward_train(end_points)
-        return self.forward_test(end_points, hyp)
+        return self.forward_test(end_points, hyp, next_real_rgb=next_real_rgb)

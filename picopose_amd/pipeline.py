@@ -39,14 +39,8 @@ def pnp_collect(handle, hyp, B):
     return rot.reshape(hyp, B, 3, 3), tvec.reshape(hyp, B, 3, 1), ratio.reshape(hyp, B), ok.reshape(hyp, B)
 
 
-def infer_batch(net, end_points, hyp=5, pnp_fn=None):
-    """-> per-instance pose hypotheses sorted by inlier ratio (run_test.py:168-186):
-    list over instances of list over hypotheses of dict(R (3,3), t (3,), inliers_ratio, pnp_success).
-    pnp_fn(outputs, real_K) -> (rot (hyp,B,3,3), tvec (hyp,B,3,1), ratio (hyp,B), ok (hyp,B)) replaces the batched HIP
-    PnP (tests of the loop semantics inject canned answers)."""
-    outputs = net(end_points, hyp)
-    rot, tvec, ratio, ok = (pnp_fn or pnp_for_outputs)(outputs, end_points["real_K"])
-    stage2 = np.stack([o["pred_poses"].cpu().numpy() for o in outputs])            # (hyp,B,4,4) float32
+def _rank_hypotheses(stage2, rot, tvec, ratio, ok, hyp):
+    """run_test.py:168-186 for one mini-batch: per instance the hypotheses sorted by inlier ratio, stage-2 pose where PnP failed."""
     B = stage2.shape[1]
     results = []
     for b in range(B):
@@ -62,16 +56,31 @@ def infer_batch(net, end_points, hyp=5, pnp_fn=None):
     return results
 
 
-def infer_image(net, data, templates_data, hyp=5, bs=16, pnp_fn=None):
+def infer_batch(net, end_points, hyp=5, pnp_fn=None):
+    """-> per-instance pose hypotheses sorted by inlier ratio (run_test.py:168-186):
+    list over instances of list over hypotheses of dict(R (3,3), t (3,), inliers_ratio, pnp_success).
+    pnp_fn(outputs, real_K) -> (rot (hyp,B,3,3), tvec (hyp,B,3,1), ratio (hyp,B), ok (hyp,B)) replaces the batched HIP
+    PnP (tests of the loop semantics inject canned answers)."""
+    outputs = net(end_points, hyp)
+    rot, tvec, ratio, ok = (pnp_fn or pnp_for_outputs)(outputs, end_points["real_K"])
+    stage2 = np.stack([o["pred_poses"].cpu().numpy() for o in outputs])            # (hyp,B,4,4) float32
+    return _rank_hypotheses(stage2, rot, tvec, ratio, ok, hyp)
+
+
+def infer_image(net, data, templates_data, hyp=5, bs=16, pnp_fn=None, pipelined=True):
     """One test image exactly as run_test.py:141-188 walks it: `data` holds the image's instances on dim 1
     (data[key][0] = (n_instance, ...), plus 'obj_idx'), `templates_data[key]` the per-object template bank
     ((n_objects, N, ...), including 'template_feature' and, optionally, an extended bank under 'template_cache').
     Instances are processed in mini-batches of `bs`; returns preds_image: per instance the hypotheses sorted by
-    inlier ratio, each {'R_stage_3' (9,), 't_stage_3' (3,) in mm, 'inliers_ratio'} (run_test.py:181-186)."""
+    inlier ratio, each {'R_stage_3' (9,), 't_stage_3' (3,) in mm, 'inliers_ratio'} (run_test.py:181-186).
+    pipelined (default; HIP PnP only): the mini-batches of an image are independent, so mini-batch j + 1's forward is launched
+    BEFORE the host waits for mini-batch j's PnP results (its PnP launch + device->host copy are already enqueued behind its forward) —
+    the card does not idle while the host ranks hypotheses; same results, same order.  pipelined=False: the reference's strictly
+    sequential walk (every mini-batch ends with a host wait)."""
     n_instance = data["score"].shape[1]
     preds_image = []
-    for start in range(0, n_instance, bs):
-        end = min(start + bs, n_instance)
+
+    def inputs_of(start, end):
         obj_idx = data["obj_idx"][0][start:end].reshape(-1)
         inputs = {k: v[0][start:end].contiguous() for k, v in data.items() if v[0].dim() > 0}
         for k, v in templates_data.items():
@@ -79,10 +88,43 @@ def infer_image(net, data, templates_data, hyp=5, bs=16, pnp_fn=None):
                 inputs[k] = {"obj_index": obj_idx, "dpt": v["dpt"]}
             else:
                 inputs[k] = v[obj_idx].contiguous()
-        for hyps in infer_batch(net, inputs, hyp, pnp_fn=pnp_fn):
+        return inputs
+
+    def emit(batch_results):
+        for hyps in batch_results:
             preds_image.append([{"R_stage_3": np.asarray(h["R"]).reshape(9), "t_stage_3": np.asarray(h["t"]).reshape(3) * 1000,
                                  "inliers_ratio": h["inliers_ratio"]} for h in hyps])
+
+    if pnp_fn is not None or not pipelined:
+        for start in range(0, n_instance, bs):
+            emit(infer_batch(net, inputs_of(start, min(start + bs, n_instance)), hyp, pnp_fn=pnp_fn))
+        return preds_image
+    pending = None      # (PnP handle, pinned stage-2 poses, their event, batch size) of the mini-batch in flight
+    starts = list(range(0, n_instance, bs))
+    for j, start in enumerate(starts):
+        inputs = inputs_of(start, min(start + bs, n_instance))
+        # the next mini-batch's query crops ride in this one's template-side ViT pass (Net.forward_test): same bits, fuller launches
+        nxt = data["real_rgb"][0][starts[j + 1]:min(starts[j + 1] + bs, n_instance)].contiguous() if j + 1 < len(starts) else None
+        outputs = net(inputs, hyp, next_real_rgb=nxt) if nxt is not None else net(inputs, hyp)
+        handle = pnp_for_outputs_async(outputs, inputs["real_K"])
+        s2 = torch.stack([o["pred_poses"] for o in outputs])                        # (hyp,B,4,4) float32
+        s2_host = torch.empty(s2.shape, dtype=s2.dtype, pin_memory=True)
+        s2_host.copy_(s2, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        if pending is not None:
+            emit(_collect(pending, hyp))
+        pending = (handle, s2_host, ev, s2.shape[1])
+    if pending is not None:
+        emit(_collect(pending, hyp))
     return preds_image
+
+
+def _collect(pending, hyp):
+    handle, s2_host, ev, B = pending
+    rot, tvec, ratio, ok = pnp_collect(handle, hyp, B)
+    ev.synchronize()
+    return _rank_hypotheses(s2_host.numpy(), rot, tvec, ratio, ok, hyp)
 
 
 def bop_csv_lines(scene_id, img_id, obj_ids, scores, preds_image, image_time):

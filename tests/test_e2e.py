@@ -81,9 +81,6 @@ def test_hip_forward_vs_reference(golden_dir, tag):
     assert np.abs(dev["template_feature"][:, :, ::16, 3, 5].cpu().numpy() - z[f"{tag}/template_feature_probe"]).max() < 2e-3
     outs = net(dev, hyp)
     assert isinstance(outs, list) and len(outs) == hyp
-    # oracle run for the margins of the discontinuous outputs
-    ep["template_feature"] = dev["template_feature"].cpu()
-    _, aux = on.net_forward_test(sd, ep, hyp, HEADS, TAKE)
     total_bad = 0
     for h in range(hyp):
         o = {k: v.cpu().numpy() for k, v in outs[h].items()}
@@ -91,11 +88,13 @@ def test_hip_forward_vs_reference(golden_dir, tag):
         assert np.array_equal(o["tem_pose"], ref[h]["tem_pose"])                        # template ids: exact
         assert np.array_equal(o["tar_pts_2d"], ref[h]["tar_pts_2d"]) and np.array_equal(o["src_pts_3d"], ref[h]["src_pts_3d"])
         assert np.abs(o["pred_poses"] - ref[h]["pred_poses"]).max() <= 1e-4             # north_star tolerance
-        # (plain random weights: flows of +-1500 px and logits of +-100 — fp32 reassociation alone moves them by 1e-4 of that;
-        # the calibrated fixtures below carry the tight bar)
-        total_bad += _keypoint_mismatch_is_explained(o["pred_tar_pts"], o["pred_src_pts"], ref[h]["pred_tar_pts"],
-                                                     ref[h]["pred_src_pts"], aux["flow"][h].numpy(), aux["cert"][h].numpy(), rel=5e-4)
-    assert total_bad <= 0.002 * hyp * B * 4096
+        # Key-point lists on THESE fixtures (plain random weights: flows of +-1500 px, logits of +-100 — nearly every slot is the -1
+        # padding, and fp32 reassociation moves the flows by 1e-4 of their range) are compared slot by slot WITHOUT a margin argument:
+        # >= 99.8 % of the 4096 slots bit-equal.  The bar that means something — every mismatch explained by a flow within 2e-5 of a
+        # pixel boundary or a logit within 2e-5 of zero — is carried by the calibrated fixtures (test_hip_forward_vs_reference_calibrated).
+        same = (o["pred_tar_pts"] == ref[h]["pred_tar_pts"]).all(-1) & (o["pred_src_pts"] == ref[h]["pred_src_pts"]).all(-1)
+        total_bad += int((~same).sum())
+    assert total_bad <= 0.002 * hyp * B * 4096, total_bad
 
 
 @gpu
@@ -123,6 +122,54 @@ def test_extended_template_cache_gives_identical_outputs(batched):
             assert torch.equal(got[h][k], ref[h][k]), (h, k)
     # the bank feature of precompute_templates is the reference's bank (run_test.py:130-131)
     assert torch.equal(banks[0]["feature"], net.feature_extractor(dev["tem_rgb"][0])[-1])
+
+
+@gpu
+def test_query_prefetch_inside_the_template_pass_keeps_every_bit():
+    """Net.forward(ep, hyp, next_real_rgb=...) runs the NEXT batch's query ViT as extra rows of this batch's template-side ViT pass and
+    the next call picks the stashed levels up: every output of both calls equals the plain forward's, bit for bit — also when the next
+    batch has another size, when the stash does not belong to the batch that follows (ignored), and after a change of the arithmetic mode."""
+    from picopose_amd import ops
+    from picopose_amd.picopose import Net
+
+    net = Net(small_cfg())
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 9))
+    net = net.cuda().eval()
+    hyp, N = 3, 5
+    eps = []
+    for B, seed in ((2, 61), (3, 62), (2, 63)):
+        d = {k: v.cuda() for k, v in make_end_points(B, N, seed).items()}
+        d["template_feature"] = torch.stack([net.feature_extractor(d["tem_rgb"][b])[-1] for b in range(B)])
+        eps.append(d)
+    plain = [net(d, hyp) for d in eps]
+    assert getattr(net, "_query_stash", None) is None
+
+    def same(a, b):
+        for h in range(hyp):
+            assert set(a[h]) == set(b[h])
+            for k in a[h]:
+                assert torch.equal(a[h][k], b[h][k]), (h, k)
+
+    got0 = net(eps[0], hyp, next_real_rgb=eps[1]["real_rgb"])
+    assert net._query_stash is not None and net._query_stash[1][0].shape[0] == 3 * 257
+    got1 = net(eps[1], hyp, next_real_rgb=eps[2]["real_rgb"])          # uses the stash, leaves one for batch 2
+    got2 = net(eps[2], hyp)                                            # uses the stash, leaves none
+    assert net._query_stash is None
+    same(got0, plain[0]); same(got1, plain[1]); same(got2, plain[2])   # noqa: E702
+    # a stash that does not belong to the batch that follows is ignored
+    net(eps[0], hyp, next_real_rgb=eps[1]["real_rgb"])
+    same(net(eps[2], hyp), plain[2])
+    # ... and so is one computed in another arithmetic mode
+    net(eps[0], hyp, next_real_rgb=eps[1]["real_rgb"])
+    old = ops.PRECISION
+    ops.PRECISION = "f32"
+    try:
+        exact_plain = net(eps[1], hyp)
+        assert net._query_stash is None
+        net(eps[0], hyp, next_real_rgb=eps[1]["real_rgb"])
+        same(net(eps[1], hyp), exact_plain)
+    finally:
+        ops.PRECISION = old
 
 
 @gpu
@@ -154,6 +201,10 @@ def test_infer_image_walks_instances_like_run_test():
         for g, r in zip(got, ref):
             assert np.allclose(g["R_stage_3"], np.asarray(r["R"]).reshape(9), atol=1e-6)
             assert np.allclose(g["t_stage_3"], np.asarray(r["t"]).reshape(3) * 1000, atol=1e-3)
+    # the reference's strictly sequential walk (a host wait per mini-batch) returns the pipelined walk's results, bit for bit
+    for got, ref in zip(infer_image(net, data, tem, hyp=hyp, bs=2, pipelined=False), preds):
+        for g, r in zip(got, ref):
+            assert np.array_equal(g["R_stage_3"], r["R_stage_3"]) and np.array_equal(g["t_stage_3"], r["t_stage_3"]) and g["inliers_ratio"] == r["inliers_ratio"]
     # extended bank: identical poses
     tem["template_cache"] = {"dpt": [torch.stack([b["dpt"][k] for b in banks]) for k in range(3)]}
     for got, ref in zip(infer_image(net, data, tem, hyp=hyp, bs=2), preds):
