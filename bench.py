@@ -398,6 +398,9 @@ def main():
                          "copies of the same sizes; reports phases_ms and the rank's peak memory.  Not a measurement of the exchange.")
     ap.add_argument("--no-prefetch-query", dest="prefetch_query", action="store_false",
                     help="the query ViT of every batch as its own pass (rounds 1-4) instead of inside the previous batch's template-side pass")
+    ap.add_argument("--graph", action="store_true",
+                    help="stage-1 workloads: replay the five kernels of a matching call as ONE HIP graph (picopose_amd.utils.matching.MatchingGraph) "
+                         "instead of launching them one by one — measured no faster on this runtime (profiles/r05/stage1_small.txt): off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the untimed --mode exact comparison leg")
     ap.add_argument("--no-latency-leg", action="store_true",
@@ -520,9 +523,13 @@ def main():
         mask = disk_mask(Bq, dev)
         bank = torch.randn(Bq, n_local, C, 16, 16, device=dev, generator=torch.Generator(device=dev).manual_seed(1 + rank)).to(bank_dtype)
 
+        graphed = hm.MatchingGraph(bank, query, mask, topk=5, mode=s1_mode) if (a.graph and not sharded) else None
+
         def step():
             if sharded:
                 return sharded_matching_templates(bank, query, mask, N, topk=5, mode=s1_mode)
+            if graphed is not None:     # the call's five launches replayed as one HIP graph (fixed buffers: a resident bank)
+                return graphed()
             return hm.matching_templates(bank, query, None, mask, topk=5, mode=s1_mode)
     else:
         from picopose_amd.picopose import Net
@@ -588,7 +595,8 @@ def main():
     L = _lib.lib()
     # stage-1 workloads: the roofline kernel IS the step, so its launch is bracketed by HIP events inside the timed steps
     # (on the launch stream); full path: the event brackets go into extra, untimed steps after the timed region
-    if kind == "stage1":
+    s1_graphed = kind == "stage1" and a.graph and not sharded      # (a replayed graph does not pass the library's event hooks)
+    if kind == "stage1" and not s1_graphed:
         _lib.check(L.pp_prof_enable(a.steps), "pp_prof_enable")
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     if distributed:
@@ -622,7 +630,14 @@ def main():
         return sum(buf[i] for i in range(cnt.value)) / max(cnt.value, 1)
 
     gemm = pnp = exact = phases = None
-    if kind == "stage1":
+    if kind == "stage1" and s1_graphed:     # the kernel's own time: the same launches outside the graph, after the timed region
+        n_ev = min(a.steps, 64)
+        _lib.check(L.pp_prof_enable(n_ev), "pp_prof_enable")
+        for _ in range(n_ev):
+            hm.matching_templates(bank, query, None, mask, topk=5, mode=s1_mode)
+        torch.cuda.synchronize()
+        kern_ms = collect_stage1(n_ev)
+    elif kind == "stage1":
         kern_ms = collect_stage1(a.steps)
     else:
         _lib.check(L.pp_prof_enable(3), "pp_prof_enable")       # 3 untimed steps with events around the stage-1 launch
@@ -794,7 +809,8 @@ def main():
                      + ("; PnP + D2H of a step on a side stream (after that step's forward, beside the next step's)" if a.pnp_stream == "side" else "")
                      if kind != "stage1" and not a.sync_loop else
                      "every timed step = forward + PnP/RANSAC + D2H of its poses, read by the host before the next step is launched" if kind != "stage1" else
-                     "every timed step = one matching call, results left on the device"),
+                     "every timed step = one matching call, results left on the device"
+                     + ("; the call's five launches replayed as ONE HIP graph (MatchingGraph: fixed buffers)" if (kind == "stage1" and a.graph and not sharded) else "")),
             "config": {"workload": f"{a.workload}: {desc}", "global_batch": B, "crops_per_rank": Bl, "templates": N,
                        "templates_per_rank": n_local, "backbone": vit, "channels": C,
                        "hypotheses": 5, "mode": a.mode, "bank_dtype": "f16" if bpe == 2 else "f32",
@@ -810,7 +826,8 @@ def main():
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                    "traffic_source": traffic_src, "traffic_measured_in_this_run": False, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kbytes,
                    "timing": "HIP events on the launch stream around this launch, " +
-                             ("inside the timed steps" if kind == "stage1" else "3 extra untimed steps after the timed region")}
+                             ("inside the timed steps" if kind == "stage1" and not s1_graphed else
+                              "the same launches outside the graph, after the timed region" if kind == "stage1" else "3 extra untimed steps after the timed region")}
         # the other roof of the same launch: the 256 x 256 x C contraction per (crop, template) on the matrix cores
         # (fast mode: one fp16 MFMA term; exact mode: fp32 MFMA).  With an fp16-stored bank the intensity is 2 C 256^2 / (2 C 256)
         # = 256 flop/B against a ridge of 2500 / 8 = 312: the kernel then sits between both roofs and this reading is the binding one.

@@ -524,9 +524,10 @@ __global__ __launch_bounds__(1024) void corr_lookup_scatter_kernel(const float* 
             acc = fmaf(d3.y, fk[13], acc);
             acc = fmaf(d3.z, fk[14], acc);
             acc = fmaf(d3.w, fk[15], acc);
-            if (acc != 0.f) {          // (a non-zero cell is inside the map: only such positions are stored)
+            if (acc != 0.f) {          // (with finite data a non-zero cell is inside the map: only such positions are stored)
                 const int qx = ax + cell % twd, qy = ay + cell / twd;
-                scatter_add<FIXED>(df2, lb + ((size_t)qy * Wl + qx) * C + ch0 + mc, acc);
+                // ... but 0 * inf = NaN != 0 for a cell that was never stored (a diverged run): the range is checked, not inferred
+                if (qx >= 0 && qx < Wl && qy >= 0 && qy < Hl) scatter_add<FIXED>(df2, lb + ((size_t)qy * Wl + qx) * C + ch0 + mc, acc);
             }
         }
         __syncthreads();

@@ -1145,7 +1145,12 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         d.K /= d.ksplit;
     }
     if (d.B_hl && (d.b_kn || d.ldb % 8 != 0 || d.K % 8 != 0 || z != 1 || !(d.b_scale > 0.f))) return PP_EINVAL;
-    if (d.B_hl && !split && !f16) d.B_hl = nullptr;  // unaligned layer: the fp32 kernel reads d.B
+    if (d.B_hl && !split && !f16) {                  // unaligned layer: the fp32 kernel reads d.B
+        // ... whose epilogue knows nothing of a weight scale handed over as a device scalar (ops._weight_args cache="dev": b_scale = 1,
+        // alpha_dev = 2^-k for weights pre-multiplied by 2^k): refusing beats a result that is off by 2^-k without an error
+        if (d.alpha_dev || d.alpha_dev2) return PP_EINVAL;
+        d.B_hl = nullptr;
+    }
     // Tile configurations ("cfg", PP_GEMM_FORCE_CFG numbering).  Both operands pre-split (pp_gemm_u_kernel.h): 0 = 128x128 tile, two
     // workgroups per CU; 2 = 128x64, two per CU; 4 = 256x128 (3, the former one-shot launch of it, is an alias); 5 = 256x256;
     // 6 = 256x256 with row-shared A delivery (3x3 convolutions); 7 / 8 (the former two / three-workgroups-per-CU K-16 kernels) are

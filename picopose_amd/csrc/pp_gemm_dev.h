@@ -68,19 +68,20 @@ __device__ __forceinline__ int pp_swz_key(int r) { return (((r >> 2) & 1) * 3) |
 // ~4 tile rows x 8 tile columns: each A row slice and each B column slice missed in L2 serves 8 resp. 4 tiles (row-major
 // order over a wide N would be 1.3 rows x 24 columns: the B operand streams from the Infinity Cache all the time —
 // 29 % L2 misses on the fc1 GEMM).  For gx <= 8 this is plain row-major.  A bijection of [0, gx*gy).
-__device__ __forceinline__ void pp_tile_rc(int t, int gx, int gy, int& r, int& c) {
-    const int ncg = (gx + 7) >> 3, band = 4 * gx;
+// (gw tile columns per group, br tile rows per band: 8 / 4 for the pre-split kernels; the fp32 engine passes its own, pp_gemm_f.hip)
+__device__ __forceinline__ void pp_tile_rc_g(int t, int gx, int gy, int gw, int br_, int& r, int& c) {
+    const int ncg = (gx + gw - 1) / gw, band = br_ * gx;
     const int rg = t / band;
     int u = t - rg * band;
-    int br = gy - 4 * rg;
-    br = br > 4 ? 4 : br;  // (the last band may be short; the bands before it are full, so rg is right)
+    int br = gy - br_ * rg;
+    br = br > br_ ? br_ : br;  // (the last band may be short; the bands before it are full, so rg is right)
     const int wq = gx / ncg, wrem = gx - wq * ncg;  // the first wrem groups have wq + 1 columns
     int c0 = 0;
     r = c = 0;
     for (int g = 0; g < ncg; ++g) {
         const int wg = wq + (g < wrem ? 1 : 0), cnt = br * wg;
         if (u < cnt) {
-            r = 4 * rg + u / wg;
+            r = br_ * rg + u / wg;
             c = c0 + u % wg;
             return;
         }
@@ -88,6 +89,7 @@ __device__ __forceinline__ void pp_tile_rc(int t, int gx, int gy, int& r, int& c
         c0 += wg;
     }
 }
+__device__ __forceinline__ void pp_tile_rc(int t, int gx, int gy, int& r, int& c) { pp_tile_rc_g(t, gx, gy, 8, 4, r, c); }
 
 // Operand formats of the pre-split kernels (PpGemmDesc.prec):
 //   PP_PREC_F16X3 "hl": fp16 [rows][ld/8][2][8] — per 8 consecutive k the 8 hi terms then the 8 lo terms of 4 x (32 bytes);

@@ -28,10 +28,16 @@
 // not depend on the configuration the autotuner picks (tests/test_engine_gpu.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "pp_gemm_dev.h"
 #include "pp_gemm_u.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_f;
+// cache policy of the result stores (buffer instruction aux bits: 2 = nt).  Measured with nt: FETCH_SIZE of the ViT linears -2 %, time
+// unchanged (gpurun_out/nt_study.txt) — a band's 4 MB of results are not what evicts the shared operand lines; left at the default.
+#ifndef PP_F_STORE_AUX
+#define PP_F_STORE_AUX 0
+#endif
 
 template <int BM_, int BN_, int WM_, int WN_, int OCC_>
 struct FTile {
@@ -43,6 +49,11 @@ struct FTile {
     static constexpr int A_F = BM_ * 32, B_F = BN_ * 32;     // floats per operand per stage (128-byte rows)
     static constexpr int STAGE = A_F + B_F;
     static constexpr int LDS_BYTES = 2 * STAGE * 4;
+    // the walk over the output tiles (pp_tile_rc_g): bands of BR tile rows, inside a band groups of GW tile columns.  An XCD has
+    // 32 CUs x OCC tiles in flight = BR x GW; the weights (7 - 13 MB per ViT linear in fp32) do not fit its 4 MB L2 and are
+    // streamed from the Infinity Cache once per BAND, so bands are 1024 rows whatever the tile (128-row tiles with 4-row bands
+    // re-read them 80 times over M = 41 120: 2.3 x the algorithmic bytes of those launches, profiles/r05/exact)
+    static constexpr int BR = 1024 / BM_, GW = 32 * OCC_ / BR;
     static_assert(NW % 4 == 0, "the swizzle key of a DMA lane must not depend on the piece");
     static_assert(BM_ % (8 * NW) == 0 && BN_ % (8 * NW) == 0, "DMA pieces are 8 rows per wave instruction");
     static_assert(PA + PB <= 16, "pieces are spread over the 4 MI NJ MFMAs of one quad");
@@ -240,7 +251,7 @@ __device__ __forceinline__ void epilogue_f32_rows(const PpGemmDesc& d, float alp
                     if (GELU) v = 0.5f * v * (1.0f + erf_rational(v * 0.70710678118654752440f));
                     else v = fmaxf(v, v * slope);
                     v = fmaf(v, gam[j], rc[4 * gg + t][j]) + r2[t][j];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), Cr, colv[j], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), Cr, colv[j], 0, PP_F_STORE_AUX);
                 }
             }
         }
@@ -257,7 +268,7 @@ __device__ __forceinline__ void epilogue_f32(const PpGemmDesc& d, float alpha, f
 // MODE 0: dense A; 1: convolution, channel-slice-major K order (Cin % 32 == 0, <= 32 taps); 2: convolution, natural K order
 // (any Cin % 4 == 0: the 4 k of a lane's chunk share a tap)
 template <class T, int MODE>
-__global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_f_kernel(const PpGemmDesc d, int gx, int gy) {
+__global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_f_kernel(const PpGemmDesc d, int gx, int gy, int walk) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (it cannot instantiate the LDS-DMA builtins)
     constexpr bool DENSE = MODE == 0;
     constexpr int NW = T::NW, PA = T::PA, PB = T::PB, MI = T::MI, NJ = T::NJ, NP = PA + PB;
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_f_kernel(const PpG
 #define PP_F_SETUP(TILE)                                                                                             \
     {                                                                                                                \
         int tr_, tc_;                                                                                                \
-        pp_tile_rc((TILE), gx, gy, tr_, tc_);                                                                        \
+        pp_tile_rc_g((TILE), gx, gy, walk & 255, walk >> 8, tr_, tc_);                                                                        \
         const int m0_ = tr_ * T::BM, n0_ = tc_ * T::BN;                                                              \
         _Pragma("unroll") for (int j = 0; j < PA; ++j) {                                                             \
             const int m = m0_ + (j * NW + w) * 8 + lr;                                                               \
@@ -537,7 +548,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_f_kernel(const PpG
             cur ^= 1;
         }
         int tr, tc;
-        pp_tile_rc(tile, gx, gy, tr, tc);
+        pp_tile_rc_g(tile, gx, gy, walk & 255, walk >> 8, tr, tc);
 #ifdef PP_STUDY_F_NOEPI   // (timing study builds only: the K loop alone; one store keeps the accumulators alive)
         {
             f32x16 keep = acc[0][0];
@@ -578,7 +589,9 @@ static int pp_f_launch_one(const PpGemmDesc& d, int slots, hipStream_t st) {
     const int gx = (d.N + T::BN - 1) / T::BN, gy = (d.M + T::BM - 1) / T::BM;
     const int nt = gx * gy;
     const int g = nt < slots ? (nt + 7) / 8 * 8 : slots / 8 * 8;
-    hipLaunchKernelGGL((pp_gemm_f_kernel<T, MODE>), dim3(g), dim3(T::NW * 64), T::LDS_BYTES, st, d, gx, gy);
+    static const int walk_env = [] { const char* e = getenv("PP_F_WALK"); return e ? atoi(e) : 0; }();   // (study: rows << 8 | columns)
+    const int walk = walk_env > 0 ? walk_env : (T::BR << 8 | T::GW);
+    hipLaunchKernelGGL((pp_gemm_f_kernel<T, MODE>), dim3(g), dim3(T::NW * 64), T::LDS_BYTES, st, d, gx, gy, walk);
     return PP_OK;
 }
 

@@ -290,7 +290,12 @@ class GradientBuckets:
     Buckets are filled in REVERSE parameter order (gradients arrive roughly output-to-input), <= bucket_bytes each (25 MB: the
     ring's latency term stays below 1 % of its transfer time at ~50 GB/s per xGMI link).  Every parameter handed in must receive a
     gradient in every step (a bucket waits for all of its members: pass the parameters that train — INTEGRATION.md section 6 — as
-    a trainer passes them to its optimizer).  Single process / no process group: the hooks do nothing and finish() returns 0."""
+    a trainer passes them to its optimizer).  Single process / no process group: the hooks do nothing and finish() returns 0.
+    Contract, as for DistributedDataParallel without find_unused_parameters: the SET of parameters that receive a gradient is the same
+    on every rank in a step.  A rank-dependent set makes the ranks issue different collectives from their hooks — by the time finish()
+    runs they are already queued, so it cannot be turned into an error after the fact (gloo aborts on the size mismatch, RCCL hangs);
+    use `allreduce_gradients` after backward() for models with data-dependent unused parameters.  What IS detected: a second
+    backward() before finish() (gradient accumulation), which would silently average only the first micro-batch — it raises."""
 
     def __init__(self, parameters, group=None, bucket_bytes=25 << 20):
         self.group = group
@@ -317,6 +322,11 @@ class GradientBuckets:
     def _hook(self, p):
         i = self._where[id(p)]
         self._left[i] -= 1
+        if self._left[i] < 0:
+            # a SECOND backward() before finish() (gradient accumulation over micro-batches): the bucket was already reduced with the first
+            # micro-batch's gradients and finish() would write that mean over the accumulated .grad — silently wrong gradients
+            raise RuntimeError("GradientBuckets: a parameter received a second gradient before finish() — one backward() per finish(); "
+                               "for gradient accumulation call allreduce_gradients() after the last micro-batch instead")
         if self._left[i] == 0 and self._active():
             flat = torch.cat([q.grad.reshape(-1) for q in self.buckets[i]])
             self._inflight[i] = (flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

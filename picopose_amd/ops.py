@@ -65,16 +65,20 @@ def split_weight(w, cache=True):
         scale = torch.empty(1, dtype=torch.float32, device=w.device)
         _lib.check(_lib.lib().pp_split_weights_t(_p(w), w.numel(), t, _p(hl), _p(scale), _lib.stream_ptr()), "pp_split_weights_t")
         return hl, float(scale.item())
-    key = (w.data_ptr(), w._version, tuple(w.shape), t)
+    # keyed by the tensor's ADDRESS (+ shape, format); the version lives in the value: an optimizer step bumps the version, and the entry
+    # of the old version — which can never be hit again — is overwritten in place instead of piling up (~4 bytes per
+    # parameter per step of dead device memory until the wholesale clear)
+    key = (w.data_ptr(), tuple(w.shape), t)
     hit = _split_cache.get(key)
-    if hit is None:
+    if hit is None or hit[3] != w._version:
         assert w.is_contiguous()
-        hl = torch.empty(w.shape[0], t * w.shape[1], dtype=torch.float16, device=w.device)
+        hl = hit[0] if hit is not None and hit[0].shape == (w.shape[0], t * w.shape[1]) else \
+            torch.empty(w.shape[0], t * w.shape[1], dtype=torch.float16, device=w.device)
         scale = torch.empty(1, dtype=torch.float32, device=w.device)
         _lib.check(_lib.lib().pp_split_weights_t(_p(w), w.numel(), t, _p(hl), _p(scale), _lib.stream_ptr()), "pp_split_weights_t")
-        if len(_split_cache) > 4096:
+        if len(_split_cache) > 4096:       # (last resort: thousands of distinct live weight tensors)
             _split_cache.clear()
-        hit = _split_cache[key] = (hl, float(scale.item()), w)  # keep w alive so its address is not reused
+        hit = _split_cache[key] = (hl, float(scale.item()), w, w._version)  # keep w alive so its address is not reused
     return hit[0], hit[1]
 
 
@@ -84,16 +88,19 @@ def split_weight_dev(w):
     ViT-B, the GPU idling while the host catches up) — here the launch takes 2^-k through PpGemmDesc.alpha_dev with b_scale = 1
     (exact: powers of two).  Remembered per (address, version) like `split_weight`."""
     t = terms()
-    key = (w.data_ptr(), w._version, tuple(w.shape), t, "dev")
+    key = (w.data_ptr(), tuple(w.shape), t, "dev")
     hit = _split_cache.get(key)
-    if hit is None:
+    if hit is None or hit[3] != w._version:      # (a new version re-splits INTO the previous version's buffers: nothing accumulates)
         assert w.is_contiguous()
-        hl = torch.empty(w.shape[0], t * w.shape[1], dtype=torch.float16, device=w.device)
-        buf = torch.empty(2 + 1024, dtype=torch.float32, device=w.device)
+        if hit is not None and hit[0].shape == (w.shape[0], t * w.shape[1]):
+            hl, buf = hit[0], hit[4]
+        else:
+            hl = torch.empty(w.shape[0], t * w.shape[1], dtype=torch.float16, device=w.device)
+            buf = torch.empty(2 + 1024, dtype=torch.float32, device=w.device)
         _lib.check(_lib.lib().pp_split_weights_ws(_p(w), w.numel(), t, _p(hl), _p(buf), _p(buf[2:]), _lib.stream_ptr()), "pp_split_weights_ws")
         if len(_split_cache) > 4096:
             _split_cache.clear()
-        hit = _split_cache[key] = (hl, buf[:2], w)
+        hit = _split_cache[key] = (hl, buf[:2], w, w._version, buf)
     return hit[0], hit[1]
 
 
@@ -240,6 +247,8 @@ def _fly_args(wargs):
     weights cannot be used there) or hl weights (f16x3)."""
     if PRECISION == "f16":
         return dict(prec=1)
+    if "alpha_dev" in wargs:     # device-scaled weights (cache="dev") belong to the pre-split kernels: these launches read the fp32 weights
+        return dict(prec=_fly_prec())
     return wargs
 
 

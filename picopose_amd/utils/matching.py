@@ -106,6 +106,36 @@ def matching_templates(src_feats, tar_feat, src_masks, tar_mask, topk=5, mode=No
     return score, index
 
 
+class MatchingGraph:
+    """`matching_templates` on FIXED buffers as ONE HIP graph: the five launches of a call (query norms, query pre-pack, the fused
+    similarity kernel, the near-tie resolve, top-k) are captured once and replayed — at BASELINE configs[1] (batch 8, 42 templates,
+    ViT-S) a call is five dependent 5-40 us kernels and the host's launch gaps are a fifth of it (profiles/r05/stage1_small.txt).
+    A serving loop with a resident bank has fixed shapes and addresses; the caller refreshes `tar_feat` / `tar_mask` / the bank IN
+    PLACE between replays (the graph reads the same addresses).  `__call__()` -> (pred_score_src, pred_id_src), the tensors the
+    capture wrote (overwritten by the next replay).  Same kernels, same arguments: bit-identical to `matching_templates`."""
+
+    def __init__(self, src_feats, tar_feat, tar_mask, topk=5, mode=None):
+        _check_inputs(src_feats, tar_feat, tar_mask)
+        for t in (src_feats, tar_feat, tar_mask):
+            if not t.is_contiguous():
+                raise _lib.PicoPoseHipError("MatchingGraph reads its inputs in place: they must be contiguous")
+        if src_feats.dtype not in (torch.float16, torch.float32) or tar_feat.dtype != torch.float32 or tar_mask.dtype != torch.float32:
+            raise _lib.PicoPoseHipError("MatchingGraph reads its inputs in place: fp32 query / mask, fp32 or fp16 bank")
+        self.inputs = (src_feats, tar_feat, tar_mask)
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):       # (first use outside the capture: per-device kernel attributes, the allocator's pool)
+            matching_templates(src_feats, tar_feat, None, tar_mask, topk=topk, mode=mode)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(self.graph):
+            self.score, self.index = matching_templates(src_feats, tar_feat, None, tar_mask, topk=topk, mode=mode)
+
+    def __call__(self):
+        self.graph.replay()
+        return self.score, self.index
+
+
 def matching_features_similarity(src_feat, tar_feat, src_mask, tar_mask):
     """Drop-in for reference utils/matching.py:6-26 (`tar_mask` is unused there as well).
 

@@ -85,6 +85,15 @@ def main():
         ok = ok and nb2 == len(gb.buckets) >= 3 and launched == (step + 1) * len(gb.buckets)      # every bucket went out DURING backward
         for p, m in zip(net.parameters(), mean):
             ok = ok and torch.allclose(p.grad, m, rtol=1e-5, atol=1e-7)
+    # a second backward() before finish() (gradient accumulation) is refused instead of silently averaging the first micro-batch only
+    net.zero_grad(set_to_none=True)
+    net(xs[rank]).square().sum().backward()
+    try:
+        net(xs[rank]).square().sum().backward()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "one backward() per finish()" in str(e)
+    gb.finish()
     gb.remove()
     print(f"RANK{rank} {'OK' if ok else 'MISMATCH'}", flush=True)
     dist.destroy_process_group()

@@ -328,3 +328,27 @@ def test_one_pass_match_with_the_optional_launch_fusions(monkeypatch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PP_S1_FUSE_TOPK="1", PP_S1_QPREP="1", PP_S1_TOPK_SMALL="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and "FUSED OK" in r.stdout.decode(), r.stdout.decode()[-1500:]
+
+
+@gpu
+def test_matching_graph_replay_equals_the_eager_call():
+    """picopose_amd.utils.matching.MatchingGraph: the five launches of a call captured in ONE HIP graph; a replay returns the eager
+    call's scores and ids bit for bit, also after the query and the mask were refreshed IN PLACE (BASELINE configs[1] shape)."""
+    import torch
+
+    from picopose_amd.utils import matching as hm
+
+    B, N, C = 8, 42, 384
+    g = torch.Generator(device="cuda").manual_seed(5)
+    bank = torch.randn(B, N, C, 16, 16, device="cuda", generator=g)
+    query = torch.randn(B, C, 16, 16, device="cuda", generator=g)
+    mask = (torch.rand(B, 224, 224, device="cuda", generator=g) < 0.7).float()
+    mg = hm.MatchingGraph(bank, query, mask, topk=5)
+    s, i = mg()
+    ws, wi = hm.matching_templates(bank, query, None, mask, topk=5)
+    assert torch.equal(i, wi) and torch.equal(s, ws)
+    query.copy_(torch.randn(B, C, 16, 16, device="cuda", generator=g))
+    mask.copy_((torch.rand(B, 224, 224, device="cuda", generator=g) < 0.5).float())
+    s, i = mg()
+    ws, wi = hm.matching_templates(bank, query, None, mask, topk=5)
+    assert torch.equal(i, wi) and torch.equal(s, ws)
