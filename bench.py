@@ -47,6 +47,7 @@ import sys
 import time
 import types
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -291,6 +292,61 @@ def latency_leg(dev, s1_mode, images=10, n_det=8, bs=4, N=162, vit="dinov2_vitl1
             "seconds_per_image": med * 1e-3}
 
 
+def train_step_leg(dev, pairs=32, vit="dinov2_vitb14", steps=5):
+    """SURVEY 8f row 4 in the driver's line: the FULL training step (Net.forward in train mode under autograd — key-point ground truth,
+    both ViT passes, ten losses, BatchNorm on batch statistics — Loss, backward of every parameter the reference trains, SGD) at `pairs`
+    real/template pairs, ViT-B/14, f16x3 engine; after the headline's timed region, `steps` steps timed one by one behind two warm-up
+    steps.  grad_norm_checksum = sum over the parameter tensors of the L2 norm of their gradient after the FIRST step (float64 on the
+    host): it moves when a gradient moves; tests/test_train_gpu.py compares all 338 tensors with the reference's autograd at ViT-S."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from netcfg import make_train_end_points
+
+    from picopose_amd import ops
+    from picopose_amd.picopose import Net
+    from picopose_amd.utils.loss_utils import Loss
+    from picopose_amd.utils.seeding import calibrated_state_dict
+
+    old = ops.PRECISION
+    ops.PRECISION = "f16x3"
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    base_bytes = torch.cuda.memory_allocated(dev)       # (the headline's model and inputs are still resident: reported memory is the step's own)
+    try:
+        net = Net(make_cfg(vit))
+        net.load_state_dict(calibrated_state_dict(net.state_dict(), 4, vit))
+        net = net.to(dev).train()
+        ep = {k: v.to(dev) for k, v in make_train_end_points(pairs, 11).items()}
+        np.random.seed(0)
+        torch.manual_seed(0)
+        opt, times, checksum, n_grads, loss0 = None, [], None, 0, None
+        for i in range(steps + 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tot = Loss()(net(dict(ep)))["loss"]
+            tot.backward()
+            if opt is None:
+                grads = [p.grad for p in net.parameters() if p.grad is not None]
+                checksum, n_grads, loss0 = float(sum(g.double().norm() for g in grads)), len(grads), float(tot.detach())
+                opt = torch.optim.SGD([p for p in net.parameters() if p.grad is not None], lr=1e-6)
+                t0 = None
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            if t0 is not None and i >= 2:
+                times.append((time.perf_counter() - t0) * 1e3)
+        times.sort()
+        return {"what": "full training step (forward_train under autograd + Loss + backward of every trained parameter + SGD), wall clock per "
+                        "step with a synchronisation, after the headline's timed region",
+                "config": f"{vit}, {pairs} real/template pairs, f16x3 engine, scope full", "ms_per_step": times[len(times) // 2],
+                "ms_per_step_min": times[0], "steps": len(times), "pairs_per_s": pairs / (times[len(times) // 2] * 1e-3),
+                "peak_memory_gib": (torch.cuda.max_memory_allocated(dev) - base_bytes) / 2 ** 30, "gradient_tensors": n_grads,
+                "grad_norm_checksum": checksum, "loss_first_step": loss0}
+    finally:
+        ops.PRECISION = old
+        torch.cuda.empty_cache()
+
+
 F_CFG_KERNEL = {3: "pp_gemm_f_kernel<128x128, 4 waves, fp32 MFMA, 2 workgroups/CU>", 4: "pp_gemm_f_kernel<256x128, 8 waves, fp32 MFMA>",
                 5: "pp_gemm_f_kernel<256x256, 8 waves, fp32 MFMA>", 6: "pp_gemm_f_kernel<128x64, 4 waves, fp32 MFMA, 2 workgroups/CU>"}
 
@@ -403,6 +459,7 @@ def main():
                          "instead of launching them one by one — measured no faster on this runtime (profiles/r05/stage1_small.txt): off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the untimed --mode exact comparison leg")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the training-step extra (default workload, fast mode only)")
     ap.add_argument("--no-latency-leg", action="store_true",
                     help="skip the per-image latency leg (the reference's own measurement: ViT-L/14, 162 templates, hyp 5, chunks of 4 detections)")
     a = ap.parse_args()
@@ -935,6 +992,9 @@ def main():
             ops.PRECISION = {"fast": "f16x3", "exact": "f32", "fp16": "f16"}[a.mode]
             line["latency"] = latency_leg(dev, s1_mode)
             line["latency_ms_per_image"] = line["latency"]["ms_per_image"]
+        if world == 1 and emulate is None and kind == "full" and a.workload == "full_b32_n162_vitb" and a.mode == "fast" and not a.no_train_leg:
+            line["train_step"] = train_step_leg(dev)
+            line["train_step_ms"] = line["train_step"]["ms_per_step"]
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_full(N, vit, sd) if kind == "full" else cpu_baseline_stage1(N, C)
         print(json.dumps(line), flush=True)

@@ -14,9 +14,9 @@ shift
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/set_$tag
 mkdir -p $out
-args="--steps 1 --warmup 1 --no-cpu-baseline --no-exact-leg --no-latency-leg --tune-file $out/tune.txt $@"
+args="--steps 1 --warmup 1 --no-cpu-baseline --no-exact-leg --no-latency-leg --no-train-leg --tune-file $out/tune.txt $@"
 cd /tmp && export TMPDIR=/tmp
-python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-exact-leg --no-latency-leg --tune-file $out/tune.txt "$@" > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
+python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-exact-leg --no-latency-leg --no-train-leg --tune-file $out/tune.txt "$@" > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
 echo "0/4 bench + tune table: $(wc -l < $out/tune.txt) shapes"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py $args > $out/bench_trace.json 2> $out/bench_trace.err || exit 1
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
