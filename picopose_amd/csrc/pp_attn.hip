@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/picopose_hip.h"
 #include "pp_common.h"
 
@@ -165,16 +166,35 @@ __device__ __forceinline__ int vt_slot(int key) {  // key (0..31) of a chunk -> 
 // K / V chunks are 16-byte copies); otherwise fp32 qkv, split while staging.  Both give the same bits.
 // TERMS = 1 (HLIN only): the h operand format (plain fp16 q, k, v, probabilities) — one MFMA per product
 // (ops.PRECISION = "f16", BASELINE configs[4]); the lo-term registers / LDS planes / MFMAs compile away.
-template <bool HLIN, int TERMS = 2>
+// RING = S > 0 (operand input only, WPB = waves per workgroup as a template argument): the K / V chunks go global -> LDS by LDS-DMA
+// (`buffer_load_dwordx4 ... lds`) into a ring of S stages, S - 1 chunks ahead, with ONE barrier per chunk and no staging registers —
+// round 4's study builds put a quarter of the kernel into the latency of the register-staged fetch (one chunk ahead, two barriers
+// per chunk).  A chunk row is the 64 d of a key as the operand format stores them (hl: 16 chunks of 16 bytes, hi / lo groups
+// alternating; h: 8 chunks); the LDS image has NO row padding (a DMA writes lane-linearly) — bank conflicts are removed by an XOR
+// key on the chunk position instead, applied to the per-lane SOURCE address: K rows (read by ds_read_b128, lane = key) key(r) = r & 15
+// (hl) / r >> 1 & 7 (h); V rows (read by ds_read_b64_tr_b16, four consecutive slots per half-wave) key(r) = (r & 1) | (r >> 1 & 1) << 3
+// (hl) / (r >> 1 & 1) << 2 (h).  V rows are the key SLOTS of the second product (vt_slot), also by source addressing.
+template <int TERMS>
+struct RingGeom {
+    static constexpr int ROWH = 64 * TERMS;                  // halfs per chunk row (128 / 256 bytes)
+    static constexpr int CPR = ROWH / 8;                     // 16-byte chunks per row
+    static constexpr int RPP = 64 / CPR;                     // rows per DMA piece (1 KB per wave instruction)
+    static constexpr int NPT = KC / RPP;                     // pieces per tensor and chunk
+    static constexpr int STAGE_H = 2 * KC * ROWH;            // halfs per stage: K rows then V rows
+};
+
+template <bool HLIN, int TERMS = 2, int RING = 0, int WPB = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_f16x3_kernel(const void* __restrict__ qkv_any, int T, int heads, float scale,
                                                          float* __restrict__ out, _Float16* __restrict__ out_hl,
                                                          float* __restrict__ lse, int ntx, int npairs) {
+    static_assert(RING == 0 || (HLIN && WPB >= 1 && WPB <= 4), "the LDS-DMA ring copies operand rows");
+    using RG = RingGeom<TERMS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Kh = (_Float16*)smem;            // [KC][KHLD]
     _Float16* Kl = Kh + KC * KHLD;
     _Float16* Vh = Kl + KC * KHLD;             // [KC key slots][VLD]: row = k-slot of the key, d contiguous
     _Float16* Vl = Vh + KC * VLD;
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = RING ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, l31 = lane & 31, lh = lane >> 5;
     // 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the ntx workgroups of one (image, head)
     // — which stage the SAME K / V chunks — take ids of one residue mod 8: id = xcd + 8 (ntx (pair / 8) + tile), pair = 8 (..) + xcd.
     // (On a (tile, pair) grid the three workgroups of a pair sat on three XCDs: FETCH 2.3 x the qkv bytes.)
@@ -295,6 +315,160 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
         }
     };
+    // ---- LDS-DMA ring (RING > 0): addressing of this lane's pieces.  Piece p of a chunk: tensor p / NPT (0 = K, 1 = V), LDS rows
+    // (p % NPT) RPP .. + RPP - 1; lane L fills chunk position L % CPR of row L / CPR.  Wave w issues pieces w, w + WPB, ... — NPW per chunk,
+    // wrapping past the last piece (a duplicate copy of the same bytes to the same place) so that every wave's count is the same constant.
+    constexpr int NPW = RING ? (2 * RG::NPT + (WPB > 0 ? WPB : 1) - 1) / (WPB > 0 ? WPB : 1) : 1;
+    unsigned poff[NPW];            // byte offset of the piece's source chunk relative to (key 0 of the chunk, this head's q column 0)
+    int prow[NPW];                 // key of the chunk (0 .. 31) the lane copies
+    const __amdgpu_buffer_rsrc_t Hr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)hbase, 0, RING ? (int)(((size_t)(T - 1) * C3 + 2 * heads * HD + HD) * 2 * TERMS) : 0, 0x00020000);
+    if (RING) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int p = (w + (WPB > 0 ? WPB : 1) * i) % (2 * RG::NPT), isv = p / RG::NPT;
+            const int rho = (p % RG::NPT) * RG::RPP + lane / RG::CPR, pos = lane % RG::CPR;
+            int key, xk;
+            if (isv) {     // LDS row rho = key slot: the key whose vt_slot is rho; V chunk key
+                const int r16 = rho & 15;
+                key = (rho & 16) | (((r16 >> 2) & 1) << 3) | ((r16 >> 3) << 2) | (r16 & 3);
+                xk = TERMS == 2 ? ((rho & 1) | (((rho >> 1) & 1) << 3)) : (((rho >> 1) & 1) << 2);
+            } else {
+                key = rho;
+                xk = TERMS == 2 ? (rho & 15) : ((rho >> 1) & 7);
+            }
+            prow[i] = key;
+            poff[i] = (unsigned)(((size_t)key * C3 + (size_t)(1 + isv) * heads * HD) * 2 * TERMS + (unsigned)((pos ^ xk) * 16));
+        }
+    }
+    // pieces [i0, i1) of chunk k0 into `stage` (the chunk loop spreads a chunk's pieces over its six MFMA groups: an LDS-DMA instruction
+    // costs the issuing wave 60-180 cycles, and the waves of a workgroup leave the barrier together)
+    auto ring_pieces = [&](int k0, int stage, int i0, int i1) __attribute__((always_inline)) {
+        _Float16* st = (_Float16*)smem + stage * RG::STAGE_H;
+        const unsigned kbytes = (unsigned)((size_t)k0 * C3 * 2 * TERMS);
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            if (i < i0 || i >= i1) continue;
+            const int p = (w + (WPB > 0 ? WPB : 1) * i) % (2 * RG::NPT);
+            const unsigned off = (k0 + prow[i] < Tm) ? poff[i] + kbytes : 0xFFFFFFFFu;      // keys past the chunked range: zeros, no traffic
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Hr, (__attribute__((address_space(3))) void*)(st + p * 512), 16, off, 0, 0, 0);
+        }
+    };
+    auto ring_issue = [&](int k0, int stage) __attribute__((always_inline)) { ring_pieces(k0, stage, 0, NPW); };
+    // slot g of 6 (four S-product steps, two P V steps) carries pieces [g NPW / 6, (g + 1) NPW / 6)
+    auto ring_slot = [&](int k0, int stage, int g) __attribute__((always_inline)) {
+        if ((g * NPW) / 6 != ((g + 1) * NPW) / 6) {
+            __builtin_amdgcn_sched_barrier(0);
+            ring_pieces(k0, stage, (g * NPW) / 6, ((g + 1) * NPW) / 6);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (RING > 0) {
+        const int nch = (Tm + KC - 1) / KC;
+#pragma unroll
+        for (int c = 0; c < RING - 1; ++c) ring_issue(c * KC, c);
+        int stage = 0, fill = RING - 1;
+        // K fragment / V fragment addressing (halfs, inside a stage)
+        const int kx = TERMS == 2 ? (l31 & 15) : ((l31 >> 1) & 7);
+        for (int c = 0; c < nch; ++c) {
+            const int k0 = c * KC;
+            // chunk c has landed: this wave's pieces (counted wait: the pieces of the S - 2 younger chunks may fly), every wave's
+            // (barrier) — and every wave is done with chunk c - 1, whose stage now takes chunk c + S - 1
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * NPW) : "memory");
+            __syncthreads();
+            const int kn = k0 + (RING - 1) * KC;      // the chunk whose pieces go out during this one
+            const _Float16* Kst = (const _Float16*)smem + stage * RG::STAGE_H;
+            const _Float16* Vst = Kst + KC * RG::ROWH;
+            f32x16 sacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ch = TERMS == 2 ? 2 * (2 * s + lh) : 2 * s + lh;
+                const h8 kh = *(const h8*)(Kst + l31 * RG::ROWH + ((ch ^ kx) * 8));
+                if (TERMS == 2) {
+                    const h8 kl = *(const h8*)(Kst + l31 * RG::ROWH + (((ch + 1) ^ kx) * 8));
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
+                }
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
+                ring_slot(kn, fill, s);
+            }
+            float mx = -INFINITY;
+            if (k0 + KC <= Tm) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    sacc[e] *= S_DESCALE;
+                    mx = fmaxf(mx, sacc[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    sacc[e] = key < Tm ? sacc[e] * S_DESCALE : -INFINITY;
+                    mx = fmaxf(mx, sacc[e]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun, mx);
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+            float ls = 0.f;
+            h8 ph[2], pl[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pe = __builtin_amdgcn_exp2f(sacc[e] - mnew);
+                ls += pe;
+                const float x = pe * P_SCALE;
+                const _Float16 hh = (_Float16)x;
+                ph[e >> 3][e & 7] = hh;
+                pl[e >> 3][e & 7] = (_Float16)(x - (float)hh);
+            }
+            ls += __shfl_xor(ls, 32);
+            lrun = lrun * alpha + ls;
+            mrun = mnew;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                o0[e] *= alpha;
+                o1[e] *= alpha;
+            }
+            // V^T fragments by transposing reads from the [slot][d chunks] image: lane (d = l31 [+32], lh) gets slots 16 s + 8 lh .. + 7
+            auto vfrag = [&](int term, int s, int dhalf) __attribute__((always_inline)) -> h8 {
+                const int col = 32 * dhalf + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                const int row = 16 * s + 8 * lh + ((lane & 15) >> 2);
+                const int ch = TERMS == 2 ? 2 * (col >> 3) + term : (col >> 3);
+                auto at = [&](int r) __attribute__((always_inline)) -> const _Float16* {
+                    const int xv = TERMS == 2 ? ((r & 1) | (((r >> 1) & 1) << 3)) : (((r >> 1) & 1) << 2);
+                    return Vst + r * RG::ROWH + ((ch ^ xv) * 8) + (col & 7);
+                };
+                const fp16x4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)at(row));
+                const fp16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)at(row + 4));
+                h8 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r[e] = (_Float16)lo4[e];
+                    r[4 + e] = (_Float16)hi4[e];
+                }
+                return r;
+            };
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const h8 v0h = vfrag(0, s, 0), v1h = vfrag(0, s, 1);
+                if (TERMS == 2) {
+                    const h8 v0l = vfrag(1, s, 0), v1l = vfrag(1, s, 1);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph[s], o0, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl[s], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph[s], o1, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl[s], o1, 0, 0, 0);
+                }
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph[s], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph[s], o1, 0, 0, 0);
+                ring_slot(kn, fill, 4 + s);
+            }
+            fill = stage;
+            stage = stage + 1 == RING ? 0 : stage + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the zero-filling pieces of the chunks past the end: no DMA may target LDS below)
+    } else {
     if (Tm > 0) fetch(0);
     for (int k0 = 0; k0 < Tm; k0 += KC) {
         __syncthreads();                       // the previous chunk has been read by every wave
@@ -380,6 +554,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph[s], o1, 0, 0, 0);
         }
     }
+    }   // (RING == 0)
     // ---- tail keys on the VALU: one online-soft-max step per key with exact fp32 products of the operands' values
     // (hi + lo is exact in fp32).  Lane (l31, lh) holds dims 16 s + 8 lh + i of its query; its accumulator register e
     // holds O^T[d = (e & 3) + 8 (e >> 2) + 4 lh (+ 32)][query l31].
@@ -503,6 +678,41 @@ static int attention_launch(const void* qkv, bool hl_in, int B, int T, int heads
         const size_t kv = (size_t)(2 * KC * KHLD + 2 * KC * VLD) * sizeof(_Float16), os = (size_t)wpb * 32 * OLD * sizeof(float);
         const int ntx = (tiles + wpb - 1) / wpb, npairs = B * heads;
         const dim3 grid((unsigned)(ntx * ((npairs + 7) / 8) * 8));
+        // operand input: the K / V chunks through an LDS-DMA ring (PP_ATTN_RING = 0: the register-staged kernel of rounds 2-4, 2 | 3: stages)
+        const char* ring_s = getenv("PP_ATTN_RING");       // (read per call: the tests compare the variants in one process)
+        const int ring_env = ring_s ? atoi(ring_s) : 3;
+        const size_t img_bytes = ((size_t)(T - 1) * 3 * heads * HD + 3 * heads * HD) * 2 * terms;      // (32-bit offsets inside an image's rows)
+        if (hl_in && (ring_env == 2 || ring_env == 3) && lse == nullptr && img_bytes < 0x7FFFFFFFull) {
+            const size_t ring = (size_t)ring_env * RingGeom<2>::STAGE_H * sizeof(_Float16) * terms / 2;
+            const size_t lds = ring > os ? ring : os;
+#define PP_ATTN_RING_LAUNCH(TERMS_, S_, W_)                                                                                        \
+    {                                                                                                                              \
+        static signed char st_[PP_MAX_DEVICES];                                                                                    \
+        signed char& ok_ = st_[pp_cur_device()];                                                                                   \
+        if (ok_ == 0)                                                                                                              \
+            ok_ = hipFuncSetAttribute((const void*)attn_f16x3_kernel<true, TERMS_, S_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)(S_ * RingGeom<TERMS_>::STAGE_H * sizeof(_Float16) > 4 * 32 * OLD * sizeof(float)               \
+                                                ? S_ * RingGeom<TERMS_>::STAGE_H * sizeof(_Float16)                                  \
+                                                : 4 * 32 * OLD * sizeof(float))) == hipSuccess ? 1 : -1;                            \
+        if (ok_ < 0) return PP_ELAUNCH;                                                                                            \
+        hipLaunchKernelGGL((attn_f16x3_kernel<true, TERMS_, S_, W_>), grid, dim3(64 * W_), lds, (hipStream_t)stream, qkv, T, heads, scale, out, \
+                           (_Float16*)out_hl, lse, ntx, npairs);                                                                   \
+    }
+#define PP_ATTN_RING_W(TERMS_, S_)                                  \
+    switch (wpb) {                                                  \
+        case 2: PP_ATTN_RING_LAUNCH(TERMS_, S_, 2) break;           \
+        case 3: PP_ATTN_RING_LAUNCH(TERMS_, S_, 3) break;           \
+        default: PP_ATTN_RING_LAUNCH(TERMS_, S_, 4) break;          \
+    }
+            if (terms == 1) {
+                if (ring_env == 2) PP_ATTN_RING_W(1, 2) else PP_ATTN_RING_W(1, 3)
+            } else {
+                if (ring_env == 2) PP_ATTN_RING_W(2, 2) else PP_ATTN_RING_W(2, 3)
+            }
+#undef PP_ATTN_RING_W
+#undef PP_ATTN_RING_LAUNCH
+            return pp_last_launch();
+        }
         if (hl_in && terms == 1)
             hipLaunchKernelGGL((attn_f16x3_kernel<true, 1>), grid, dim3(64 * wpb), kv > os ? kv : os, (hipStream_t)stream, qkv, T, heads, scale, out,
                                (_Float16*)out_hl, lse, ntx, npairs);

@@ -432,6 +432,36 @@ def test_attention_shapes_and_operand_input(B, T, heads, engine_precision):
 
 
 @gpu
+@pytest.mark.parametrize("B,T,heads", [(2, 257, 12), (3, 100, 6), (1, 300, 3), (2, 33, 2), (1, 1025, 2), (5, 1, 1)])
+def test_attention_lds_dma_ring_equals_the_register_staged_kernel(monkeypatch, B, T, heads, engine_precision):
+    """The fused attention on operand input stages its K / V chunks through an LDS-DMA ring of three (PP_ATTN_RING=3, default) or two
+    stages; the register-staged kernel of rounds 2-4 (PP_ATTN_RING=0) computes the same products in the same order: bit-identical
+    outputs in both operand formats, fp32 and operand outputs, for token counts with full chunks, a masked last chunk and VALU tail keys."""
+    if engine_precision == "f32":
+        pytest.skip("operand input exists in the f16x3 / f16 modes only")
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(31)
+    hd = 64
+    qkv = (torch.randn(B * T, 3 * heads * hd, generator=g) * 2).cuda()
+    w = torch.eye(3 * heads * hd).cuda()
+    sp = ops.linear(qkv, w, None, out_split=True)        # the operand the qkv GEMM epilogue writes
+    assert isinstance(sp, ops.Split)
+    outs = {}
+    for ring in ("0", "3", "2"):
+        monkeypatch.setenv("PP_ATTN_RING", ring)
+        o32 = ops.attention(sp, B, T, heads, hd)
+        osp = ops.attention(sp, B, T, heads, hd, out_split=True)
+        outs[ring] = (o32, osp.hl)
+    for ring in ("3", "2"):
+        assert torch.equal(outs[ring][0], outs["0"][0]), ring
+        assert torch.equal(outs[ring][1], outs["0"][1]), ring
+    q, k, v = (qkv.cpu().view(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)[i] for i in range(3))
+    ref = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1) @ v
+    _close(outs["3"][0].view(B, T, heads, hd).permute(0, 2, 1, 3), ref, 5e-4 if engine_precision == "f16x3" else TOL_F16)
+
+
+@gpu
 def test_saturation_check_raises_instead_of_returning_clipped_operands():
     """The f16x3 operand format holds |x| < 16376; ops.CHECK_SATURATION turns a silent clip into an error."""
     from picopose_amd import _lib, ops
