@@ -183,11 +183,16 @@ struct RingGeom {
     static constexpr int STAGE_H = 2 * KC * ROWH;            // halfs per stage: K rows then V rows
 };
 
+// RING = 8 with WPB = 9 ("resident"): T = 257 .. 260 — one workgroup of NINE waves per (image, head), one wave per query tile; all eight
+// 32-key chunks of K and V are copied ONCE (128 KB of LDS in the hl format, every piece issued before the first product), each chunk
+// has ONE barrier when it is first read and the stages are never refilled: the deepest prefetch the ring can have, a third of the
+// K / V copies (three workgroups per pair staged the same chunks before), and 2 304 workgroups on 256 CUs are nine full rounds.
 template <bool HLIN, int TERMS = 2, int RING = 0, int WPB = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_f16x3_kernel(const void* __restrict__ qkv_any, int T, int heads, float scale,
+__global__ __launch_bounds__(WPB > 4 ? 64 * WPB : 256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_f16x3_kernel(const void* __restrict__ qkv_any, int T, int heads, float scale,
                                                          float* __restrict__ out, _Float16* __restrict__ out_hl,
                                                          float* __restrict__ lse, int ntx, int npairs) {
-    static_assert(RING == 0 || (HLIN && WPB >= 1 && WPB <= 4), "the LDS-DMA ring copies operand rows");
+    static_assert(RING == 0 || (HLIN && WPB >= 1 && (WPB <= 4 || (WPB == 9 && RING == 8))), "the LDS-DMA ring copies operand rows");
+    constexpr bool RESIDENT = RING == 8 && WPB == 9;
     using RG = RingGeom<TERMS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Kh = (_Float16*)smem;            // [KC][KHLD]
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if constexpr (RING > 0) {
         const int nch = (Tm + KC - 1) / KC;
 #pragma unroll
-        for (int c = 0; c < RING - 1; ++c) ring_issue(c * KC, c);
+        for (int c = 0; c < (RESIDENT ? RING : RING - 1); ++c) ring_issue(c * KC, c);
         int stage = 0, fill = RING - 1;
         // K fragment / V fragment addressing (halfs, inside a stage)
         const int kx = TERMS == 2 ? (l31 & 15) : ((l31 >> 1) & 7);
@@ -374,9 +379,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const int k0 = c * KC;
             // chunk c has landed: this wave's pieces (counted wait: the pieces of the S - 2 younger chunks may fly), every wave's
             // (barrier) — and every wave is done with chunk c - 1, whose stage now takes chunk c + S - 1
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * NPW) : "memory");
+            if constexpr (RESIDENT) {      // chunk c of 8 issued up front: the 7 - c younger chunks' pieces may fly
+                switch (c) {
+                    case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * NPW) : "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NPW) : "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NPW) : "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPW) : "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NPW) : "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory"); break;
+                    case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * NPW) : "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * NPW) : "memory");
+            }
             __syncthreads();
-            const int kn = k0 + (RING - 1) * KC;      // the chunk whose pieces go out during this one
+            // the pieces of chunk c + S - 1, back to back: spread over the chunk's six MFMA groups (ring_slot, kept for A/B under
+            // PP_ATTN_SPREAD builds) they cost MORE — 264 against 236 us at 192 images: the sched_barriers that pin them also pin the
+            // fragment reads behind the MFMAs they feed
+#ifndef PP_ATTN_SPREAD
+            if constexpr (!RESIDENT) ring_issue(k0 + (RING - 1) * KC, fill);
+#endif
+            const int kn = k0 + (RING - 1) * KC;
+            (void)kn;
             const _Float16* Kst = (const _Float16*)smem + stage * RG::STAGE_H;
             const _Float16* Vst = Kst + KC * RG::ROWH;
             f32x16 sacc;
@@ -392,7 +417,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
                 }
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
+#ifdef PP_ATTN_SPREAD
                 ring_slot(kn, fill, s);
+#endif
             }
             float mx = -INFINITY;
             if (k0 + KC <= Tm) {
@@ -462,7 +489,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph[s], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph[s], o1, 0, 0, 0);
+#ifdef PP_ATTN_SPREAD
                 ring_slot(kn, fill, 4 + s);
+#endif
             }
             fill = stage;
             stage = stage + 1 == RING ? 0 : stage + 1;
@@ -680,8 +709,31 @@ static int attention_launch(const void* qkv, bool hl_in, int B, int T, int heads
         const dim3 grid((unsigned)(ntx * ((npairs + 7) / 8) * 8));
         // operand input: the K / V chunks through an LDS-DMA ring (PP_ATTN_RING = 0: the register-staged kernel of rounds 2-4, 2 | 3: stages)
         const char* ring_s = getenv("PP_ATTN_RING");       // (read per call: the tests compare the variants in one process)
-        const int ring_env = ring_s ? atoi(ring_s) : 3;
+        const int ring_env = ring_s ? atoi(ring_s) : 2;      // (two stages: three cost a workgroup per CU — 258 vs 236 vs 252 us staged)
         const size_t img_bytes = ((size_t)(T - 1) * 3 * heads * HD + 3 * heads * HD) * 2 * terms;      // (32-bit offsets inside an image's rows)
+        const int tail_n = (T % KC) <= 4 ? T % KC : 0;
+        if (hl_in && ring_env > 0 && ring_env != 1 && getenv("PP_ATTN_RESIDENT") != nullptr && lse == nullptr && img_bytes < 0x7FFFFFFFull && tiles == 9 &&
+            T - tail_n == 8 * KC) {
+            // T = 257 .. 260: all of K / V of an (image, head) resident in LDS, nine waves per workgroup (see the kernel).  MEASURED SLOWER —
+            // 334 us against 252 (staged) / 243-248 (two-stage ring) at 192 images: nine waves per CU instead of twelve on a kernel whose
+            // time is the soft-max's vector work (MFMA-busy 0.21), and nothing overlaps a workgroup's load phase — opt-in (PP_ATTN_RESIDENT=1)
+            const dim3 grid9((unsigned)(((npairs + 7) / 8) * 8));
+#define PP_ATTN_RES_LAUNCH(TERMS_)                                                                                                  \
+    {                                                                                                                              \
+        constexpr int lds_ = 8 * RingGeom<TERMS_>::STAGE_H * (int)sizeof(_Float16) > 9 * 32 * OLD * (int)sizeof(float)             \
+                                 ? 8 * RingGeom<TERMS_>::STAGE_H * (int)sizeof(_Float16) : 9 * 32 * OLD * (int)sizeof(float);      \
+        static signed char st_[PP_MAX_DEVICES];                                                                                    \
+        signed char& ok_ = st_[pp_cur_device()];                                                                                   \
+        if (ok_ == 0)                                                                                                              \
+            ok_ = hipFuncSetAttribute((const void*)attn_f16x3_kernel<true, TERMS_, 8, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_) == hipSuccess ? 1 : -1; \
+        if (ok_ < 0) return PP_ELAUNCH;                                                                                            \
+        hipLaunchKernelGGL((attn_f16x3_kernel<true, TERMS_, 8, 9>), grid9, dim3(64 * 9), lds_, (hipStream_t)stream, qkv, T, heads, scale, out, \
+                           (_Float16*)out_hl, lse, 1, npairs);                                                                     \
+    }
+            if (terms == 1) PP_ATTN_RES_LAUNCH(1) else PP_ATTN_RES_LAUNCH(2)
+#undef PP_ATTN_RES_LAUNCH
+            return pp_last_launch();
+        }
         if (hl_in && (ring_env == 2 || ring_env == 3) && lse == nullptr && img_bytes < 0x7FFFFFFFull) {
             const size_t ring = (size_t)ring_env * RingGeom<2>::STAGE_H * sizeof(_Float16) * terms / 2;
             const size_t lds = ring > os ? ring : os;

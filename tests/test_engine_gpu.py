@@ -448,12 +448,15 @@ def test_attention_lds_dma_ring_equals_the_register_staged_kernel(monkeypatch, B
     sp = ops.linear(qkv, w, None, out_split=True)        # the operand the qkv GEMM epilogue writes
     assert isinstance(sp, ops.Split)
     outs = {}
-    for ring in ("0", "3", "2"):
-        monkeypatch.setenv("PP_ATTN_RING", ring)
+    for ring in ("0", "3", "2", "res"):
+        monkeypatch.setenv("PP_ATTN_RING", "2" if ring == "res" else ring)
+        if ring == "res":        # T = 257 .. 260: the nine-wave variant with all of K / V resident in LDS (opt-in; other T: the ring)
+            monkeypatch.setenv("PP_ATTN_RESIDENT", "1")
         o32 = ops.attention(sp, B, T, heads, hd)
         osp = ops.attention(sp, B, T, heads, hd, out_split=True)
         outs[ring] = (o32, osp.hl)
-    for ring in ("3", "2"):
+    monkeypatch.delenv("PP_ATTN_RESIDENT")
+    for ring in ("3", "2", "res"):
         assert torch.equal(outs[ring][0], outs["0"][0]), ring
         assert torch.equal(outs[ring][1], outs["0"][1]), ring
     q, k, v = (qkv.cpu().view(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)[i] for i in range(3))
