@@ -275,7 +275,11 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 // HLIN: f1 / f2 arrive as the engine's hl operand (fp16 [rows][2 ld]: per 8 channels 8 hi then 8 lo terms — what the
 // producing convolution's epilogue writes): staging is 16-byte copies, no split arithmetic (it was as long as the MFMAs of a
 // chunk).  Same bits either way: the split of a value does not depend on who performs it.
-template <bool HLIN>
+// EXACT (fp32 input only; ops.PRECISION = "f32" / bench.py --mode exact): the chunk is staged as fp32 (a 128-byte row is 32 floats
+// instead of 32 hi + 32 lo halfs) and S is accumulated by v_mfma_f32_32x32x2_f32 — exact fp32 products, a k-ordered fma chain per
+// entry like the lane-per-position kernel's, 5.3 x the matrix time of the f16x3 form but a third less than that kernel's 108 row
+// streams per pixel (9.6 -> measured below, profiles/r05/exact).
+template <bool HLIN, bool EXACT = false>
 __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const void* __restrict__ f1v, int ld_f1, int f2_batch,
                                                                   const void* __restrict__ f2l0, const void* __restrict__ f2l1,
                                                                   const void* __restrict__ f2l2, const float* __restrict__ flow,
@@ -367,6 +371,10 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const void* __
             };
             // LDS rows hold the chunk in hl order: per 8 channels 8 hi then 8 lo halfs (fp32 input: split here)
             auto put = [&](float* rowp, f4 v) __attribute__((always_inline)) {
+                if (EXACT) {
+                    *(f4*)(rowp + 4 * part) = v;
+                    return;
+                }
                 if (HLIN) {
                     *(f4*)((_Float16*)rowp + 8 * part) = v;
                     return;
@@ -394,6 +402,27 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const void* __
                 for (int i = 0; i < 8; ++i) put(Bs + (row0 + 32 * i) * CKP, rb[i]);
                 __syncthreads();
                 if (kc + 2 < nk) load_chunk(kc + 2, ra, rb);    // in flight under two chunks of MFMAs
+                if constexpr (EXACT) {
+                    // lane (l31, lh) feeds row / column l31 with channels 16 lh + 4 q .. + 3: MFMA e of quad q multiplies the pair
+                    // (4 q + e, 16 + 4 q + e) — the order of the fp32 engine (csrc/pp_gemm_f.hip)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f4 af[2], bf[2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            af[i] = *(const f4*)(As + (i * 32 + l31) * CKP + 16 * lh + 4 * q);
+                            bf[i] = *(const f4*)(Bs + (wv * 64 + i * 32 + l31) * CKP + 16 * lh + 4 * q);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                    }
+                    return;
+                }
                 // lane (l31, lh) feeds row / column l31 with channels 16 q + 8 lh .. + 7 of the chunk in k-step q
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -431,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const void* __
 #pragma unroll
                     for (int e = 0; e < 16; ++e)            // accumulator (e, lane): row (e/4)*8 + lh*4 + e%4, column l31
                         S[(i * 32 + (e >> 2) * 8 + lh * 4 + (e & 3)) * CSP + wv * 64 + j * 32 + l31] =
-                            acc[i][j][e] * (inv_sqrt_c / (PP_A_SCALE * PP_A_SCALE));
+                            acc[i][j][e] * (EXACT ? inv_sqrt_c : inv_sqrt_c / (PP_A_SCALE * PP_A_SCALE));
             __syncthreads();
             // ---- blend the 25 samples of every pixel whose neighbourhood lies in the region
             for (int idx = tid; idx < CM * win * win; idx += 256) {
@@ -686,18 +715,22 @@ int pp_avgpool2_nhwc(const float* in, int B, int H, int W, int C, float* out, vo
 
 static int corr_tiled_launch(bool hl, const void* f1, int ld_f1, const void* f2_l0, const void* f2_l1, const void* f2_l2, int f2_batch,
                              const float* flow, int B, int H, int W, int C, int levels, int radius, int ld_flow, float* out, int ld_out,
-                             void* stream) {
+                             void* stream, bool exact = false) {
     // matrix-core version: one workgroup per 8 x 8 pixel tile
     const size_t lds = (size_t)(CM * CSP > (CM + CN) * CKP ? CM * CSP : (CM + CN) * CKP) * sizeof(float);
     static signed char attr[PP_MAX_DEVICES];
     signed char& ok = attr[pp_cur_device()];
     if (ok == 0)
         ok = hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                     hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess
+                     hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess
                  ? 1 : -1;
     if (ok < 0) return PP_ELAUNCH;
     const dim3 grid((unsigned)((H / CT) * (W / CT) * B));
-    if (hl)
+    if (exact)
+        hipLaunchKernelGGL((corr_lookup_mfma_kernel<false, true>), grid, dim3(256), lds, (hipStream_t)stream, f1, ld_f1, f2_batch, f2_l0, f2_l1, f2_l2,
+                           flow, B, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out, ld_out);
+    else if (hl)
         hipLaunchKernelGGL(corr_lookup_mfma_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, f1, ld_f1, f2_batch, f2_l0, f2_l1, f2_l2,
                            flow, B, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out, ld_out);
     else
@@ -718,12 +751,13 @@ int pp_corr_lookup_nhwc_ex(const float* f1, int ld_f1, const float* f2_l0, const
     const int win = 2 * radius + 1;
     if (ld_out < levels * win * win) return PP_EINVAL;
     const char* te = getenv("PP_CORR_TILED");   // read per call: the tests run both kernels in one process
-    const bool tiled = prec == PP_PREC_F16X3 && !(te && te[0] == '0');   // PP_PREC_F32: exact fp32 fmas, always
+    const bool tiled = !(te && te[0] == '0');   // (PP_PREC_F32: the tiled kernel on exact fp32 MFMAs — every product and sum fp32)
     // every pyramid level the tiled kernel reads goes through 16-byte vector loads: a misaligned one falls back (as the hl entry
     // point below rejects it) instead of faulting
     const bool aligned = (((uintptr_t)f2_l0 | (levels > 1 ? (uintptr_t)f2_l1 : 0) | (levels > 2 ? (uintptr_t)f2_l2 : 0)) % 16) == 0;
     if (tiled && H % CT == 0 && W % CT == 0 && C % CK == 0 && aligned)   // (PP_CORR_TILED=0 keeps the lane-per-position kernel)
-        return corr_tiled_launch(false, f1, ld_f1, f2_l0, f2_l1, f2_l2, f2_batch, flow, B, H, W, C, levels, radius, ld_flow, out, ld_out, stream);
+        return corr_tiled_launch(false, f1, ld_f1, f2_l0, f2_l1, f2_l2, f2_batch, flow, B, H, W, C, levels, radius, ld_flow, out, ld_out, stream,
+                                 prec == PP_PREC_F32);
     const size_t smem = (size_t)4 * (C + MAXL * TW * TW) * sizeof(float);
     hipLaunchKernelGGL(corr_lookup_kernel, dim3((H * W + 3) / 4, B), dim3(256), smem, (hipStream_t)stream, f1, ld_f1,
                        f2_batch, f2_l0, f2_l1, f2_l2, flow, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out,

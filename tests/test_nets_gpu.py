@@ -224,3 +224,33 @@ def test_tiled_corr_lookup_equals_the_lane_per_position_kernel(monkeypatch, H, l
         f2s = ops.Split(ops.split_activation(f2, 2, H * H, C, H * H * C, C))
         from_operands = ops.corr_lookup(f1, f2, flow, levels, 2, c_pad=pad, f1_hl=(wide, 32), f2_hl=f2s)
         assert torch.equal(from_operands, tiled)
+
+
+@gpu
+@pytest.mark.parametrize("H,levels,scale", [(16, 1, 1.0), (32, 2, 3.0), (64, 3, 0.7), (64, 3, 40.0)])
+def test_exact_mode_tiled_corr_lookup_on_fp32_matrix_cores(monkeypatch, H, levels, scale):
+    """ops.PRECISION = "f32" (bench.py --mode exact): the tiled correlation lookup with fp32 chunks and v_mfma_f32_32x32x2_f32 (round 5)
+    against the lane-per-position fp32 kernel it replaces in that mode (PP_CORR_TILED=0) and the CPU oracle — smooth, noisy and
+    out-of-image flows, a shared query map, padded output channels.  Both are fp32 fma chains over the channels (in different orders)."""
+    from picopose_amd import ops
+
+    monkeypatch.setattr(ops, "PRECISION", "f32")
+    g = torch.Generator().manual_seed(H * 10 + levels + 1)
+    B, C = 4, 64
+    f1 = torch.randn(B, H, H, C, generator=g).cuda()
+    f2 = torch.randn(2, H, H, C, generator=g).cuda()
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(H, dtype=torch.float32), indexing="ij")
+    smooth = torch.stack([0.15 * xx - 0.1 * yy + 1.3, 0.1 * xx + 0.2 * yy - 2.1], dim=-1)[None].repeat(B, 1, 1, 1)
+    flow = (smooth + scale * torch.randn(B, H, H, 2, generator=g)).cuda()
+    pad = -(-(levels * 25) // 8) * 8
+    tiled = ops.corr_lookup(f1, f2, flow, levels, 2, c_pad=pad)
+    monkeypatch.setenv("PP_CORR_TILED", "0")
+    lane = ops.corr_lookup(f1, f2, flow, levels, 2, c_pad=pad)
+    monkeypatch.delenv("PP_CORR_TILED")
+    ref = on.corr_lookup(f1.cpu().permute(0, 3, 1, 2), f2.cpu().repeat(2, 1, 1, 1).permute(0, 3, 1, 2), flow.cpu().permute(0, 3, 1, 2), levels, 2)
+    ref = ref.permute(0, 2, 3, 1)
+    n = levels * 25
+    bar = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((tiled[..., :n].cpu() - ref).abs().max()) <= bar
+    assert float((tiled[..., :n] - lane[..., :n]).abs().max()) <= bar
+    assert torch.equal(tiled[..., n:], torch.zeros_like(tiled[..., n:]))
