@@ -408,6 +408,11 @@ int pp_corr_lookup_nhwc_ex(const float* f1, int ld_f1, const float* f2_l0, const
  * at least the accuracy of the f16x3 engine, independent of the batch size. */
 int pp_conv_narrow_hl(const void* x_hl, int ld_x, int B, int H, int W, int C, const float* weight, const float* bias, int ksize,
                       int n_out, const float* residual, float* out, void* stream);
+/* The same layers on the fp32 NHWC map itself (x: (B,H,W) pixels with rows of ld_x floats, ld_x % 4 == 0, 16-byte aligned; images
+ * contiguous) — the strict-fp32 mode's form (PP_PREC_F32 networks: raft_decoder.py:287-289 in the reference's own arithmetic):
+ * every product and sum fp32, taps walked in the engine's k order. */
+int pp_conv_narrow_f32(const float* x, int ld_x, int B, int H, int W, int C, const float* weight, const float* bias, int ksize,
+                       int n_out, const float* residual, float* out, void* stream);
 
 /* The tiled lookup on operands the producers already hold in the engine's hl format (fp16 [pixels][2 ld]: per 8 channels
  * the 8 hi then the 8 lo terms; include "hl" above): f1_hl with rows of ld_f1 channels (a column block of a wider operand

@@ -100,6 +100,7 @@ def lib():
         L.pp_split_activation.argtypes = [vp, c.c_longlong, i32, i32, i32, i32, i32, vp, vp]
         L.pp_split_activation_ld.argtypes = [vp, c.c_longlong, i32, i32, i32, i32, i32, vp, i32, vp]
         L.pp_conv_narrow_hl.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]
+        L.pp_conv_narrow_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]
         L.pp_split_weights_t.argtypes = [vp, c.c_longlong, i32, vp, vp, vp]
         L.pp_split_weights_ws.argtypes = [vp, c.c_longlong, i32, vp, vp, vp, vp]
         L.pp_split_activation_t.argtypes = [vp, c.c_longlong, i32, i32, i32, i32, i32, vp, i32, i32, vp]

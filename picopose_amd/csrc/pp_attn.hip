@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
 #pragma unroll
         for (int p = 0; p < 32; p += 4) {
             const f4 v = *(const f4*)(qp + p);
-            qr[p] = v.x * scale; qr[p + 1] = v.y * scale; qr[p + 2] = v.z * scale; qr[p + 3] = v.w * scale;
+            const float sc2 = scale * 1.44269504088896340736f;
+            qr[p] = v.x * sc2; qr[p + 1] = v.y * sc2; qr[p + 2] = v.z * sc2; qr[p + 3] = v.w * sc2;
         }
     }
     f32x16 o0, o1;  // O^T: rows d (0..31 / 32..63), column = query (lane)
@@ -77,21 +78,28 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qr[p4 + 2], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qr[p4 + 3], s, 0, 0, 0);
         }
-        // register e of this lane = key k0 + (e&3) + 8(e>>2) + 4 lh, query l31; mask keys past T
+        // register e of this lane = key k0 + (e&3) + 8(e>>2) + 4 lh, query l31; mask keys past T (only the last chunk has any)
         float mx = -INFINITY;
+        if (k0 + KC <= T) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            s[e] = key < T ? s[e] : -INFINITY;
-            mx = fmaxf(mx, s[e]);
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                s[e] = key < T ? s[e] : -INFINITY;
+                mx = fmaxf(mx, s[e]);
+            }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mnew = fmaxf(mrun, mx);
-        const float alpha = expf(mrun - mnew);  // 0 for the first chunk (mrun = -inf)
+        // the scores live in the base-2 domain (q was scaled by scale * log2 e): an exponential is ONE v_exp_f32 instead of libm's
+        // ~20-instruction expf — on fp32 MFMAs every vector instruction is taken from the matrix pipe's issue slots (csrc/pp_gemm_f.hip)
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);  // 0 for the first chunk (mrun = -inf)
         float ls = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            s[e] = expf(s[e] - mnew);
+            s[e] = __builtin_amdgcn_exp2f(s[e] - mnew);
             ls += s[e];
         }
         ls += __shfl_xor(ls, 32);

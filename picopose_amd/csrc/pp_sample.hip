@@ -578,7 +578,9 @@ __global__ __launch_bounds__(256) void depth_points_kernel(const float* __restri
 // fp32 value / 4, the weights are the layer's fp32 filters (scalar loads: the index is uniform), fp32 fma accumulation.
 constexpr int NRW_PITCH = 144;   // bytes per staged pixel: 128 + 16 (conflict-free 16-byte reads along a row of pixels)
 
-template <int KS, int NOUT>
+// F32IN (round 5, ops.PRECISION = "f32"): the input is the fp32 NHWC map itself (ldx floats per pixel; a 32-channel slice of a pixel is
+// the same 128 bytes), every product and sum fp32 — the exact-mode form of the same layers (they ran as GEMMs padded from 2 columns to 64).
+template <int KS, int NOUT, bool F32IN = false>
 __global__ __launch_bounds__(256) void conv_narrow_kernel(const _Float16* __restrict__ x, int ldx, int H, int W, int C,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           const float* __restrict__ residual, float* __restrict__ out) {
@@ -607,7 +609,8 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const _Float16* __rest
             const unsigned m = 0u - (unsigned)((tid + 256 * j < npiece) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W));
             const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
             typedef unsigned u4n __attribute__((ext_vector_type(4)));
-            const u4n raw = *(const u4n*)(x + (((size_t)b * H + iyc) * W + ixc) * (size_t)(2 * ldx) + 2 * c0 + 8 * piece) & m;
+            const u4n raw = (F32IN ? *(const u4n*)((const float*)x + (((size_t)b * H + iyc) * W + ixc) * (size_t)ldx + c0 + 4 * piece)
+                                   : *(const u4n*)(x + (((size_t)b * H + iyc) * W + ixc) * (size_t)(2 * ldx) + 2 * c0 + 8 * piece)) & m;
             pre[j] = __builtin_bit_cast(float4, raw);
         }
     };
@@ -627,6 +630,17 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const _Float16* __rest
             for (int dx = 0; dx < KS; ++dx) {
                 const unsigned char* p = nsm + (size_t)((ty + dy) * PW + tx + dx) * NRW_PITCH;
                 const float* wt = w + (dy * KS + dx) * C + c0;
+                if constexpr (F32IN) {
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const f4 xv = *(const f4*)(p + 16 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int n = 0; n < NOUT; ++n) acc[n] = fmaf(xv[e], wt[n * K + 4 * g + e], acc[n]);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     typedef _Float16 h8v __attribute__((ext_vector_type(8)));
@@ -643,7 +657,7 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const _Float16* __rest
     const size_t o = (((size_t)b * H + y0 + ty) * W + tx) * NOUT;
 #pragma unroll
     for (int n = 0; n < NOUT; ++n) {
-        float v = acc[n] * (1.0f / PP_A_SCALE) + (bias ? bias[n] : 0.f);
+        float v = (F32IN ? acc[n] : acc[n] * (1.0f / PP_A_SCALE)) + (bias ? bias[n] : 0.f);
         if (residual) v += residual[o + n];
         out[o + n] = v;
     }
@@ -736,6 +750,25 @@ static int corr_tiled_launch(bool hl, const void* f1, int ld_f1, const void* f2_
     else
         hipLaunchKernelGGL(corr_lookup_mfma_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, f1, ld_f1, f2_batch, f2_l0, f2_l1, f2_l2,
                            flow, B, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out, ld_out);
+    return pp_last_launch();
+}
+
+int pp_conv_narrow_f32(const float* x, int ld_x, int B, int H, int W, int C, const float* weight, const float* bias, int ksize,
+                       int n_out, const float* residual, float* out, void* stream) {
+    if (!x || !weight || !out || B <= 0 || H <= 0 || C <= 0 || C % 32 != 0 || ld_x < C || ld_x % 4 != 0) return PP_EINVAL;
+    if ((W != 16 && W != 32 && W != 64) || H % (256 / W) != 0 || (ksize != 1 && ksize != 3) || (n_out != 1 && n_out != 2)) return PP_EINVAL;
+    if (((uintptr_t)x % 16) != 0) return PP_EINVAL;
+    const int TH = 256 / W, R = ksize / 2;
+    const size_t lds = (size_t)(TH + 2 * R) * (W + 2 * R) * NRW_PITCH;
+    const dim3 grid((unsigned)(B * (H / TH)));
+    hipStream_t st = (hipStream_t)stream;
+#define NRW_LAUNCH(KS_, N_)                                                                                                                  \
+    hipLaunchKernelGGL((conv_narrow_kernel<KS_, N_, true>), grid, dim3(256), lds, st, (const _Float16*)x, ld_x, H, W, C, weight, bias, residual, out)
+    if (ksize == 3 && n_out == 2) NRW_LAUNCH(3, 2);
+    else if (ksize == 3) NRW_LAUNCH(3, 1);
+    else if (n_out == 2) NRW_LAUNCH(1, 2);
+    else NRW_LAUNCH(1, 1);
+#undef NRW_LAUNCH
     return pp_last_launch();
 }
 

@@ -526,6 +526,16 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
         _lib.check(_lib.lib().pp_conv_narrow_hl(_p(xs.hl), Cx, B, H, W, Cx, _p(wp), _p(bias), ksize, Cout, _p(residual), _p(out),
                                                 _lib.stream_ptr()), "pp_conv_narrow_hl")
         return out
+    if (xs is None and PRECISION == "f32" and Cout <= 2 and ksize in (1, 3) and stride == 1 and pad == ksize // 2 and act is None and out is None
+            and not relu_in and residual2 is None and cin == Cx and Cx % 32 == 0 and W in (16, 32, 64) and H % (256 // W) == 0
+            and ld_in % 4 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) == H * W * ld_in and wp.dtype == torch.float32 and wp.is_contiguous()
+            and (residual is None or (residual.is_contiguous() and tuple(residual.shape) == (B, H, W, Cout)))
+            and os.environ.get("PP_CONV_NARROW", "1") != "0"):
+        # the same predict layers in the strict-fp32 mode: a direct fp32 convolution on the NHWC map (pp_conv_narrow_f32)
+        out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().pp_conv_narrow_f32(_p(x), ld_in, B, H, W, Cx, _p(wp), _p(bias), ksize, Cout, _p(residual), _p(out),
+                                                 _lib.stream_ptr()), "pp_conv_narrow_f32")
+        return out
     wargs = _weight_args(wp, ksize * ksize * cin, cache_weight)   # (cache_weight=False: a transient packed weight of the training graph)
     presplit = xs is not None or ("B_hl" in wargs and (Cout > 64 or ksize > 1)
                                   and _can_presplit(x, ksize * ksize * cin, cin, ld_in, x.stride(0)) and B * H * W * cin < 2 ** 30)

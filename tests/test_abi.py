@@ -43,6 +43,7 @@ def test_argument_validation_needs_no_gpu():
     assert L.pp_xent_diag_rows(None, 4, 4, 10.0, None, None) == -1
     assert L.pp_flow_loss_blocks() > 0 and L.pp_flow_loss_sums(None, None, None, 2, 16, 16, 400.0, None, None) == -1
     assert L.pp_conv_narrow_hl(None, 256, 1, 64, 64, 256, None, None, 3, 2, None, None, None) == -1
+    assert L.pp_conv_narrow_f32(None, 256, 1, 64, 64, 256, None, None, 3, 2, None, None, None) == -1
     assert L.pp_corr_lookup_nhwc_hl(None, 256, None, None, None, 1, None, 1, 64, 64, 256, 3, 2, 2, None, 80, None) == -1
     assert L.pp_hl_patch_columns(None, 2, 2, 10, None, 640, 638, None) == -1
     assert L.pp_sum_slices(None, 32, 160, 1024, None, 3, None, None) == -1

@@ -372,8 +372,6 @@ def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, 
 def test_narrow_output_convolution(monkeypatch, k, nout, hw, B, engine_precision):
     """The one- / two-channel predict layers on an operand input (pp_conv_narrow_hl) against torch and against the GEMM
     route they replace (PP_CONV_NARROW=0), with bias and a residual, image borders and every band of rows."""
-    if engine_precision == "f32":
-        pytest.skip("operand inputs exist in f16x3 mode only")
     from picopose_amd import ops
 
     g = torch.Generator().manual_seed(k * 100 + hw + nout)
@@ -381,7 +379,8 @@ def test_narrow_output_convolution(monkeypatch, k, nout, hw, B, engine_precision
     x = torch.randn(B, hw, hw, C, generator=g)
     w = torch.randn(nout, C, k, k, generator=g) / (C * k * k) ** 0.5
     b, res = torch.randn(nout, generator=g), torch.randn(B, hw, hw, nout, generator=g)
-    xs = ops.split_image(x.cuda())
+    # f32 mode: the fp32 map itself (pp_conv_narrow_f32); f16x3 / f16: the operand its producer wrote (pp_conv_narrow_hl)
+    xs = x.cuda() if engine_precision == "f32" else ops.split_image(x.cuda())
     wp = ops.pack_conv_weight(w.cuda())
     got = ops.conv2d(xs, wp, b.cuda(), k, pad=k // 2, residual=res.cuda())
     monkeypatch.setenv("PP_CONV_NARROW", "0")
