@@ -348,7 +348,8 @@ def train_step_leg(dev, pairs=32, vit="dinov2_vitb14", steps=5):
 
 
 F_CFG_KERNEL = {3: "pp_gemm_f_kernel<128x128, 4 waves, fp32 MFMA, 2 workgroups/CU>", 4: "pp_gemm_f_kernel<256x128, 8 waves, fp32 MFMA>",
-                5: "pp_gemm_f_kernel<256x256, 8 waves, fp32 MFMA>", 6: "pp_gemm_f_kernel<128x64, 4 waves, fp32 MFMA, 2 workgroups/CU>"}
+                5: "pp_gemm_f_kernel<256x256, 8 waves, fp32 MFMA>", 6: "pp_gemm_f_kernel<128x64, 4 waves, fp32 MFMA, 2 workgroups/CU>",
+                7: "pp_gemm_f_kernel<256x192, 8 waves, fp32 MFMA>"}
 
 
 def gemm_per_kernel(L, cap=8192):

@@ -1177,7 +1177,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             return;
         }
         if (fvec && cfg >= 3) {
-            launch_rc = pp_gemm_f_launch(d, cfg == 5 ? PP_U_256x256 : cfg == 4 ? PP_U_256x128 : cfg == 3 ? PP_U_128x128 : PP_U_128x64, cus, st);
+            launch_rc = pp_gemm_f_launch(d, cfg == 7 ? PP_F_256x192 : cfg == 5 ? PP_U_256x256 : cfg == 4 ? PP_U_256x128 : cfg == 3 ? PP_U_128x128 : PP_U_128x64, cus, st);
             return;
         }
         const bool narrow = cfg == 2;
@@ -1210,7 +1210,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     int cfg = fvec ? (d.N <= 64 ? 6 : 3) : (d.N <= 64 ? 2 : 0);
     if (const char* f = getenv("PP_GEMM_FORCE_CFG")) {  // tests: pin one kernel configuration
         const int fc = atoi(f);
-        if (fc >= 0 && fc <= 8 && (asplit || fc <= 2 || (fvec && fc <= 6))) {
+        if (fc >= 0 && fc <= 8 && (asplit || fc <= 2 || (fvec && fc <= 7))) {
             launch(fc);
             return finish();
         }
@@ -1254,6 +1254,8 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                 if (d.N > 64) cands[nc++] = 3;
                 if (t4 >= cus / 2 && d.N > 64) cands[nc++] = 4;
                 if (t5 >= cus / 2 && d.N > 128) cands[nc++] = 5;
+                // 256x192: layers whose N wastes less of a 192-wide tile than of a 128-wide one (the decoder's 192-channel maps)
+                if ((d.N + 191) / 192 * 192 - d.N < (d.N + 127) / 128 * 128 - d.N && (long long)((d.M + 255) / 256) * ((d.N + 191) / 192) >= cus / 2) cands[nc++] = 7;
             } else {
                 for (int c = 0; c < (vec ? 3 : 2); ++c) cands[nc++] = vec ? c : (c == 0 ? 0 : 2);
             }

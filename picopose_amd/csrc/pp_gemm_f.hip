@@ -578,6 +578,7 @@ typedef FTile<256, 256, 2, 4, 1> F256x256;   // 8 waves, 128x64 each, 2 x 64 KB 
 typedef FTile<256, 128, 4, 2, 1> F256x128;   // 8 waves, 64x64 each, 2 x 48 KB ring
 typedef FTile<128, 128, 2, 2, 2> F128x128;   // 4 waves, 64x64 each, 2 x 32 KB ring: two workgroups per CU
 typedef FTile<128, 64, 2, 2, 2> F128x64;     // 4 waves, 64x32 each, 2 x 24 KB ring: two workgroups per CU
+typedef FTile<256, 192, 4, 2, 1> F256x192;   // 8 waves, 64x96 each, 2 x 56 KB ring: layers whose N is a multiple of 192 (the decoder's 192-channel maps)
 
 template <class T, int MODE>
 static int pp_f_launch_one(const PpGemmDesc& d, int slots, hipStream_t st) {
@@ -639,6 +640,7 @@ int pp_gemm_f_launch(const PpGemmDesc& d, int tile, int cus, hipStream_t st) {
         case PP_U_256x128: return pp_f_launch_tile<F256x128>(d, mode, cus, st);
         case PP_U_128x128: return pp_f_launch_tile<F128x128>(d, mode, 2 * cus, st);
         case PP_U_128x64: return pp_f_launch_tile<F128x64>(d, mode, 2 * cus, st);
+        case PP_F_256x192: return mode == 2 ? pp_f_launch_tile<F256x128>(d, mode, cus, st) : pp_f_launch_tile<F256x192>(d, mode, cus, st);
         default: return PP_EINVAL;
     }
 }

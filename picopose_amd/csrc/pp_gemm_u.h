@@ -5,7 +5,7 @@
 #include "../../include/picopose_hip.h"
 
 // block tiles the kernel is instantiated for
-enum { PP_U_128x64 = 0, PP_U_128x128 = 1, PP_U_256x128 = 2, PP_U_256x256 = 3 };
+enum { PP_U_128x64 = 0, PP_U_128x128 = 1, PP_U_256x128 = 2, PP_U_256x256 = 3, PP_F_256x192 = 4 /* fp32 engine only */ };
 
 // A-delivery mode the kernel will use for this problem: 0 dense, 1 convolution in channel-slice-major K order, 2 natural order
 int pp_gemm_u_mode(const PpGemmDesc& d, int terms);

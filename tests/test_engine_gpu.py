@@ -282,7 +282,7 @@ def test_fused_operand_planes_equal_separate_split(engine_precision):
 
 
 @gpu
-@pytest.mark.parametrize("cfg", ["3", "4", "5", "6"])
+@pytest.mark.parametrize("cfg", ["3", "4", "5", "6", "7"])
 def test_fp32_engine_kernels_pinned(monkeypatch, engine_precision, cfg):
     """The fp32 engine (csrc/pp_gemm_f.hip: LDS-DMA ring + v_mfma_f32_32x32x2_f32; configurations 3 = 128x128, 4 = 256x128,
     5 = 256x256, 6 = 128x64) pinned on shapes with row / column / K tails, padded and strided taps, Cin that is not a multiple of
@@ -321,10 +321,10 @@ def test_fp32_engine_agrees_bitwise_across_tile_configurations_and_with_the_roun
                 ops.conv2d(xo, wo, None, 3, pad=1))
 
     outs = {}
-    for cfg in ("0", "3", "4", "5", "6"):
+    for cfg in ("0", "3", "4", "5", "6", "7"):
         monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
         outs[cfg] = run()
-    for cfg in ("4", "5", "6"):
+    for cfg in ("4", "5", "6", "7"):
         for a, b_ in zip(outs[cfg], outs["3"]):
             assert torch.equal(a, b_), cfg
     for k in (0, 2, 3):                      # dense: the round-1 kernel's bits

@@ -28,7 +28,7 @@ def key_of(n):
         return "u6:m1"
     m = re.search(r"pp_gemm_f_kernel<FTile<(\d+), (\d+),[^>]*>, (\d)>", n)
     if m:   # the fp32 engine (pp_gemm_f.hip): configurations 3 = 128x128, 4 = 256x128, 5 = 256x256, 6 = 128x64
-        return f"f{ {(128, 128): 3, (256, 128): 4, (256, 256): 5, (128, 64): 6}[(int(m.group(1)), int(m.group(2)))] }:m{m.group(3)}"
+        return f"f{ {(128, 128): 3, (256, 128): 4, (256, 256): 5, (128, 64): 6, (256, 192): 7}[(int(m.group(1)), int(m.group(2)))] }:m{m.group(3)}"
     m = re.search(r"gemm_f16x3_kernel<(\d), (\d), (true|false)>", n)
     if m:
         return f"gx:{m.group(1)}:{m.group(2)}"
