@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "pp_gemm_dev.h"
 #include "pp_gemm_u.h"
 
@@ -477,6 +478,37 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_f_kernel(const PpG
                 for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
     };
 
+    // one quad's MFMAs with (issue: a wave-uniform flag — ONE path for the accumulators, small scalar branches around the pieces) the NP
+    // DMA pieces of the fetch cursor's K tile spread between them, into `stage`
+    auto mma_q_issue = [&](const FS& f, int stage, bool issue) __attribute__((always_inline)) {
+        constexpr int NM = 4 * MI * NJ;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int s_ = (e * MI + i) * NJ + j;
+                    if ((s_ * NP) / NM != ((s_ + 1) * NP) / NM) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (issue) {
+#pragma unroll
+                            for (int q = (s_ * NP) / NM; q < ((s_ + 1) * NP) / NM; ++q) piece(stage, q);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
+                }
+    };
+    // (measured, round 5: staggering the two waves of a SIMD bought the dense layers + 1.5 % on the 256x256 tile and cost the
+    // convolutions 3 - 6 % — the operand streams of the dense layers are not what holds their K loop back; off unless -DPP_F_STAGGER)
+#ifdef PP_F_STAGGER
+    const bool late = NW == 8 && w >= 4;
+#else
+    constexpr bool late = false;
+#endif
+    bool late_pending = false;
+
     PP_F_SETUP(first)
     PP_F_FETCH(0)
     PP_F_FETCH(1)
@@ -503,7 +535,11 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_f_kernel(const PpG
         for (int kt = 0; kt < nk; ++kt) {
             load_q(f1, cur, 1);
             relu_a(f0);
-            mma_q(f0);
+            // (LATE waves: the pieces of the K tile the other half issued in the previous last quad go out here — see below)
+            const bool issue0 = late && late_pending;
+            if (issue0) PP_F_KTILE()
+            mma_q_issue(f0, cur ^ 1, issue0);
+            if (issue0) PP_F_ADVANCE()
             __builtin_amdgcn_sched_barrier(0);
             load_q(f0, cur, 2);
             relu_a(f1);
@@ -521,29 +557,18 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_f_kernel(const PpG
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
 #endif
-            PP_F_KTILE()
             relu_a(f1);
             load_q(f0, cur ^ 1, 0);
-            // last quad | DMA pieces of K tile kt + 2 pinned between its MFMAs (hipcc would issue them back to back)
-            {
-                constexpr int NM = 4 * MI * NJ;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-                            const int s = (e * MI + i) * NJ + j;
-                            if ((s * NP) / NM != ((s + 1) * NP) / NM) {
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int q = (s * NP) / NM; q < ((s + 1) * NP) / NM; ++q) piece(cur, q);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.a[i][e], f1.b[j][e], acc[i][j], 0, 0, 0);
-                        }
-            }
-            PP_F_ADVANCE()
+            // last quad | DMA pieces of K tile kt + 2 pinned between its MFMAs (hipcc would issue them back to back).  In an 8-wave
+            // workgroup the two waves of a SIMD leave the barrier together; when the operands stream from beyond the L2 (dense layers)
+            // an LDS-DMA instruction waits for a slot in the memory pipeline and blocks its wave's MFMAs behind it — both waves of the
+            // SIMD at once.  So only waves 0-3 issue here; waves 4-7 ("late") issue theirs one quad later, in the first quad of the
+            // next K tile (the stage is free since this barrier and is not read before the next one): one wave of every SIMD always
+            // has MFMAs to issue.
+            if (!late) PP_F_KTILE()
+            mma_q_issue(f1, cur, !late);
+            if (!late) PP_F_ADVANCE()
+            late_pending = late;
             __builtin_amdgcn_sched_barrier(0);
             cur ^= 1;
         }
