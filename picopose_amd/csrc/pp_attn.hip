@@ -255,7 +255,47 @@ __global__ __launch_bounds__(WPB > 4 ? 64 * WPB : 256) __attribute__((amdgpu_wav
     const float* vp = base + 2 * heads * HD;
     // scores are kept in the base-2 domain (scaled by log2 e): the soft-max exponentials are single v_exp_f32 instructions
     const float S_DESCALE = scale * 1.44269504088896340736f / (PP_A_SCALE * PP_A_SCALE);
-    constexpr float O_RESCALE = 1.0f / (PP_A_SCALE * P_SCALE);
+    // (lrun is kept in the units of the probability operand, 1024 p: see SOFTMAX_STEP)
+    constexpr float O_RESCALE = 1.0f / PP_A_SCALE;
+    // One online-soft-max step on the score tile `sacc` (raw MFMA sums, keys k0 ..): the kernel's time is this vector work (MFMA-busy 0.21),
+    // so it is cut to the bone (round 5, ~210 -> ~150 vector instructions per chunk):
+    //   * the maximum is taken on the RAW sums (the scale is positive) and the scale rides in the exponential's argument — one fma per
+    //     score instead of a multiply and a subtract;
+    //   * the probability operand is 1024 p: the factor is an addend of the same fma (exp2(x + 10)), and the running sum `lrun` is kept
+    //     in those units (the final division and the log-sum-exp take the 2^10 out) — no multiply per probability;
+    //   * the accumulators are rescaled only when some query's maximum moved in this chunk (wave-uniform test): after the first
+    //     chunks it rarely does.
+#define SOFTMAX_STEP(K0)                                                                                          \
+    float mx = -INFINITY;                                                                                         \
+    if ((K0) + KC > Tm) { /* (uniform) the last, partial chunk: keys past the chunked range are masked */       \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                          \
+            const int key = (K0) + (e & 3) + 8 * (e >> 2) + 4 * lh;                                               \
+            sacc[e] = key < Tm ? sacc[e] : -INFINITY;                                                             \
+        }                                                                                                         \
+    }                                                                                                             \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[e]);                                       \
+    mx = fmaxf(mx, __shfl_xor(mx, 32));                                                                           \
+    const float mnew = fmaxf(mrun, mx * S_DESCALE);                                                               \
+    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);                                                      \
+    const float shift = 10.0f - mnew;                                                                             \
+    float ls = 0.f;                                                                                               \
+    h8 ph[2], pl[2];                                                                                              \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                              \
+        const float x = __builtin_amdgcn_exp2f(fmaf(sacc[e], S_DESCALE, shift)); /* 1024 p <= 1024 */             \
+        ls += x;                                                                                                  \
+        const _Float16 hh = (_Float16)x;                                                                          \
+        ph[e >> 3][e & 7] = hh;                                                                                   \
+        pl[e >> 3][e & 7] = (_Float16)(x - (float)hh);                                                            \
+    }                                                                                                             \
+    ls += __shfl_xor(ls, 32);                                                                                     \
+    lrun = lrun * alpha + ls;                                                                                     \
+    mrun = mnew;                                                                                                  \
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {                                                        \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                          \
+            o0[e] *= alpha;                                                                                       \
+            o1[e] *= alpha;                                                                                       \
+        }                                                                                                         \
+    }
 
     // Keys are consumed in chunks of KC = 32 through LDS; a tail of up to TAILMAX keys (T = 257 = 8 x 32 + 1: the chunk
     // loop would spend a ninth pass, 11 % of the kernel, on ONE key) is folded in afterwards on the VALU.
@@ -429,43 +469,7 @@ __global__ __launch_bounds__(WPB > 4 ? 64 * WPB : 256) __attribute__((amdgpu_wav
                 ring_slot(kn, fill, s);
 #endif
             }
-            float mx = -INFINITY;
-            if (k0 + KC <= Tm) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    sacc[e] *= S_DESCALE;
-                    mx = fmaxf(mx, sacc[e]);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    sacc[e] = key < Tm ? sacc[e] * S_DESCALE : -INFINITY;
-                    mx = fmaxf(mx, sacc[e]);
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun, mx);
-            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-            float ls = 0.f;
-            h8 ph[2], pl[2];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pe = __builtin_amdgcn_exp2f(sacc[e] - mnew);
-                ls += pe;
-                const float x = pe * P_SCALE;
-                const _Float16 hh = (_Float16)x;
-                ph[e >> 3][e & 7] = hh;
-                pl[e >> 3][e & 7] = (_Float16)(x - (float)hh);
-            }
-            ls += __shfl_xor(ls, 32);
-            lrun = lrun * alpha + ls;
-            mrun = mnew;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                o0[e] *= alpha;
-                o1[e] *= alpha;
-            }
+            SOFTMAX_STEP(k0)
             // V^T fragments by transposing reads from the [slot][d chunks] image: lane (d = l31 [+32], lh) gets slots 16 s + 8 lh .. + 7
             auto vfrag = [&](int term, int s, int dhalf) __attribute__((always_inline)) -> h8 {
                 const int col = 32 * dhalf + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -525,43 +529,7 @@ __global__ __launch_bounds__(WPB > 4 ? 64 * WPB : 256) __attribute__((amdgpu_wav
             }
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
         }
-        float mx = -INFINITY;
-        if (k0 + KC <= Tm) {   // (uniform) a full chunk — every chunk when T - tail is a multiple of 32, as for T = 257: no key masks
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                sacc[e] *= S_DESCALE;
-                mx = fmaxf(mx, sacc[e]);
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                sacc[e] = key < Tm ? sacc[e] * S_DESCALE : -INFINITY;
-                mx = fmaxf(mx, sacc[e]);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mnew = fmaxf(mrun, mx);
-        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-        float ls = 0.f;
-        h8 ph[2], pl[2];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float pe = __builtin_amdgcn_exp2f(sacc[e] - mnew);
-            ls += pe;
-            const float x = pe * P_SCALE;  // <= 1024: no saturation needed
-            const _Float16 hh = (_Float16)x;
-            ph[e >> 3][e & 7] = hh;
-            pl[e >> 3][e & 7] = (_Float16)(x - (float)hh);
-        }
-        ls += __shfl_xor(ls, 32);
-        lrun = lrun * alpha + ls;
-        mrun = mnew;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            o0[e] *= alpha;
-            o1[e] *= alpha;
-        }
+        SOFTMAX_STEP(k0)
         // V^T fragments by transposing reads from the [slot][d] tile: lane (d = l31 [+32], lh) gets slots 16 s + 8 lh .. + 7
         auto vfrag = [&](const _Float16* V, int s, int dhalf) __attribute__((always_inline)) -> h8 {
             const int col = 32 * dhalf + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -631,10 +599,9 @@ __global__ __launch_bounds__(WPB > 4 ? 64 * WPB : 256) __attribute__((amdgpu_wav
             dot += __shfl_xor(dot, 32);
             const float sv = dot * S_DESCALE;
             const float mnew = fmaxf(mrun, sv);
-            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew), pe = __builtin_amdgcn_exp2f(sv - mnew);
-            lrun = lrun * alpha + pe;
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew), pw = __builtin_amdgcn_exp2f(sv - mnew + 10.0f);   // 1024 p: the MFMA path's units
+            lrun = lrun * alpha + pw;
             mrun = mnew;
-            const float pw = pe * P_SCALE;     // the units of the MFMA path: (4 v) (1024 p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int dd = (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -644,7 +611,7 @@ __global__ __launch_bounds__(WPB > 4 ? 64 * WPB : 256) __attribute__((amdgpu_wav
         }
     }
     // (training) the base-2 log-sum-exp of the query's scaled scores: all the adjoint needs to recompute its probabilities
-    if (lse && q < T && lh == 0) lse[((size_t)b * heads + h) * T + q] = mrun + __builtin_amdgcn_logf(lrun);
+    if (lse && q < T && lh == 0) lse[((size_t)b * heads + h) * T + q] = mrun + __builtin_amdgcn_logf(lrun) - 10.0f;   // (lrun counts 1024 p)
     // output through LDS: O^T registers (lane = query) -> rows of 64 floats per query, written as full lines
     __syncthreads();
     float* Os = (float*)smem + w * 32 * OLD;
