@@ -67,7 +67,7 @@ def infer_batch(net, end_points, hyp=5, pnp_fn=None):
     return _rank_hypotheses(stage2, rot, tvec, ratio, ok, hyp)
 
 
-def infer_image(net, data, templates_data, hyp=5, bs=16, pnp_fn=None, pipelined=True):
+def infer_image(net, data, templates_data, hyp=5, bs=16, pnp_fn=None, pipelined=True, next_data=None):
     """One test image exactly as run_test.py:141-188 walks it: `data` holds the image's instances on dim 1
     (data[key][0] = (n_instance, ...), plus 'obj_idx'), `templates_data[key]` the per-object template bank
     ((n_objects, N, ...), including 'template_feature' and, optionally, an extended bank under 'template_cache').
@@ -76,7 +76,9 @@ def infer_image(net, data, templates_data, hyp=5, bs=16, pnp_fn=None, pipelined=
     pipelined (default; HIP PnP only): the mini-batches of an image are independent, so mini-batch j + 1's forward is launched
     BEFORE the host waits for mini-batch j's PnP results (its PnP launch + device->host copy are already enqueued behind its forward) —
     the card does not idle while the host ranks hypotheses; same results, same order.  pipelined=False: the reference's strictly
-    sequential walk (every mini-batch ends with a host wait)."""
+    sequential walk (every mini-batch ends with a host wait).
+    next_data: the NEXT test image's `data` (an evaluator's loader has it one iteration ahead): the query crops of its first mini-batch
+    ride in this image's last forward, as the mini-batches of one image do among themselves — same results."""
     n_instance = data["score"].shape[1]
     preds_image = []
 
@@ -104,7 +106,12 @@ def infer_image(net, data, templates_data, hyp=5, bs=16, pnp_fn=None, pipelined=
     for j, start in enumerate(starts):
         inputs = inputs_of(start, min(start + bs, n_instance))
         # the next mini-batch's query crops ride in this one's template-side ViT pass (Net.forward_test): same bits, fuller launches
-        nxt = data["real_rgb"][0][starts[j + 1]:min(starts[j + 1] + bs, n_instance)].contiguous() if j + 1 < len(starts) else None
+        if j + 1 < len(starts):
+            nxt = data["real_rgb"][0][starts[j + 1]:min(starts[j + 1] + bs, n_instance)].contiguous()
+        elif next_data is not None and next_data["score"].shape[1] > 0:
+            nxt = next_data["real_rgb"][0][0:min(bs, next_data["score"].shape[1])].contiguous()
+        else:
+            nxt = None
         outputs = net(inputs, hyp, next_real_rgb=nxt) if nxt is not None else net(inputs, hyp)
         handle = pnp_for_outputs_async(outputs, inputs["real_K"])
         s2 = torch.stack([o["pred_poses"] for o in outputs])                        # (hyp,B,4,4) float32

@@ -205,6 +205,20 @@ def test_infer_image_walks_instances_like_run_test():
     for got, ref in zip(infer_image(net, data, tem, hyp=hyp, bs=2, pipelined=False), preds):
         for g, r in zip(got, ref):
             assert np.array_equal(g["R_stage_3"], r["R_stage_3"]) and np.array_equal(g["t_stage_3"], r["t_stage_3"]) and g["inliers_ratio"] == r["inliers_ratio"]
+    # the loader's NEXT image handed over (next_data): its first mini-batch's query ViT rides in this image's last forward — same bits for both
+    inst2 = {k: v.cuda() for k, v in make_end_points(2, 1, 73).items() if k.startswith("real_")}
+    data2 = {k: v[None] for k, v in inst2.items()}
+    data2["obj_idx"] = torch.tensor([[0, 1]], device="cuda")
+    data2["score"] = torch.tensor([[0.6, 0.5]], device="cuda")
+    plain2 = infer_image(net, data2, tem, hyp=hyp, bs=2)
+    ahead1 = infer_image(net, data, tem, hyp=hyp, bs=2, next_data=data2)
+    assert net._query_stash is not None
+    ahead2 = infer_image(net, data2, tem, hyp=hyp, bs=2)
+    assert net._query_stash is None
+    for a_, b_ in ((ahead1, preds), (ahead2, plain2)):
+        for got, ref in zip(a_, b_):
+            for g, r in zip(got, ref):
+                assert np.array_equal(g["R_stage_3"], r["R_stage_3"]) and np.array_equal(g["t_stage_3"], r["t_stage_3"])
     # extended bank: identical poses
     tem["template_cache"] = {"dpt": [torch.stack([b["dpt"][k] for b in banks]) for k in range(3)]}
     for got, ref in zip(infer_image(net, data, tem, hyp=hyp, bs=2), preds):
