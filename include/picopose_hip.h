@@ -414,6 +414,19 @@ int pp_conv_narrow_hl(const void* x_hl, int ld_x, int B, int H, int W, int C, co
 int pp_conv_narrow_f32(const float* x, int ld_x, int B, int H, int W, int C, const float* weight, const float* bias, int ksize,
                        int n_out, const float* residual, float* out, void* stream);
 
+/* Winograd F(2x2, 3x3) for the 3x3 / stride 1 / padding 1 convolutions of the strict-fp32 mode (raft_decoder.py:251-289, dpt.py:72-95 in
+ * the reference's own arithmetic; csrc/pp_winograd.hip): 16 dense products Y_xi (P, Cout) = U_xi (P, Cin) V_xi (Cout, Cin)^T over the
+ * P = B H W / 4 output tiles run through pp_gemm (PP_PREC_F32, dense); these are the three fp32 transforms around them.
+ *   pp_winograd_input_f32   x: NHWC image (B, H, W) with rows of ld_x floats (C of them read; H, W even, C % 4 == 0, 16-byte aligned,
+ *                           images batch_stride floats apart), relu != 0: max(x, 0) first (ResidualConvUnit)  ->  U (16, P, C)
+ *   pp_winograd_weight_f32  w: (Cout, 9 Cin) in the engine's k order (tap-major, then channel), rows of ldw floats  ->  V (16, Cout, Cin)
+ *   pp_winograd_output_f32  Y (16, P, Cout)  ->  out (B, H, W) with rows of ldc floats: A^T Y A + bias, act (none / ReLU / LeakyReLU),
+ *                           + residual + residual2 (laid out like out) */
+int pp_winograd_input_f32(const float* x, int ld_x, long long batch_stride, int B, int H, int W, int C, int relu, float* U, void* stream);
+int pp_winograd_weight_f32(const float* w, int Cout, int Cin, int ldw, float* V, void* stream);
+int pp_winograd_output_f32(const float* Y, int B, int H, int W, int Cout, const float* bias, int act, const float* residual,
+                           const float* residual2, float* out, int ldc, void* stream);
+
 /* The tiled lookup on operands the producers already hold in the engine's hl format (fp16 [pixels][2 ld]: per 8 channels
  * the 8 hi then the 8 lo terms; include "hl" above): f1_hl with rows of ld_f1 channels (a column block of a wider operand
  * is fine), f2_hl_l{0,1,2} contiguous (f2_batch, H >> l, W >> l, C).  H, W multiples of 8 and C of 32 (else PP_EINVAL: use

@@ -108,6 +108,7 @@ def drop_split_cache():
     """Forget every cached operand copy of a weight (Packed.invalidate_packed: after a write through `param.data`, which the
     (address, version) keys cannot see)."""
     _split_cache.clear()
+    _wino_cache.clear()
     _tracked_scale.clear()
 
 
@@ -536,6 +537,11 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
         _lib.check(_lib.lib().pp_conv_narrow_f32(_p(x), ld_in, B, H, W, Cx, _p(wp), _p(bias), ksize, Cout, _p(residual), _p(out),
                                                  _lib.stream_ptr()), "pp_conv_narrow_f32")
         return out
+    if (xs is None and PRECISION == "f32" and WINOGRAD and ksize == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0
+            and cin % 4 == 0 and Cout >= 32 and act in (None, "none", "relu", "leaky01") and B * H * W >= WINOGRAD_MIN_PIXELS
+            and ld_in % 4 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and wp.dtype == torch.float32 and wp.is_contiguous()
+            and hl_into is None and cache_weight is True and not torch.is_grad_enabled()):     # (out_split / also_split: f16x3-engine hints, ignored in this mode)
+        return _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, residual, residual2, out)
     wargs = _weight_args(wp, ksize * ksize * cin, cache_weight)   # (cache_weight=False: a transient packed weight of the training graph)
     presplit = xs is not None or ("B_hl" in wargs and (Cout > 64 or ksize > 1)
                                   and _can_presplit(x, ksize * ksize * cin, cin, ld_in, x.stride(0)) and B * H * W * cin < 2 ** 30)
@@ -595,6 +601,52 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
                conv_kh=ksize, conv_kw=ksize, conv_cin=cin, conv_stride=stride, conv_pad=pad, conv_h=H, conv_w=W,
                conv_ho=Ho, conv_wo=Wo, **_fly_args(wargs)))
     return ret
+
+
+# Winograd F(2x2, 3x3) for the large 3x3 convolutions of the strict-fp32 mode (csrc/pp_winograd.hip): 2.25 x fewer fp32 multiplications on
+# matrix-bound layers.  PP_WINOGRAD=0 keeps the direct implicit-GEMM convolution; layers below WINOGRAD_MIN_PIXELS output pixels stay direct
+# (sixteen small products do not fill the chip).
+WINOGRAD = os.environ.get("PP_WINOGRAD", "1") != "0"
+WINOGRAD_MIN_PIXELS = int(os.environ.get("PP_WINOGRAD_MIN_PIXELS", str(128 * 1024)))
+_wino_cache = {}
+
+
+def winograd_weight(wp, cin):
+    """V (16, Cout, Cin) = G g G^T of a packed 3x3 weight (Cout, 9 Cin): once per tensor version (keyed like the split caches)."""
+    key = (wp.data_ptr(), tuple(wp.shape), "wino")
+    hit = _wino_cache.get(key)
+    if hit is None or hit[2] != wp._version:
+        Cout = wp.shape[0]
+        V = hit[0] if hit is not None else torch.empty(16, Cout, cin, dtype=torch.float32, device=wp.device)
+        _lib.check(_lib.lib().pp_winograd_weight_f32(_p(wp), Cout, cin, wp.shape[1], _p(V), _lib.stream_ptr()), "pp_winograd_weight_f32")
+        if len(_wino_cache) > 1024:
+            _wino_cache.clear()
+        hit = _wino_cache[key] = (V, wp, wp._version)
+    return hit[0]
+
+
+def _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, residual, residual2, out):
+    """3x3 / stride 1 / pad 1 on an fp32 NHWC map (a channel slice is fine) by Winograd F(2x2, 3x3): input transform, 16 dense fp32
+    products on the engine, output transform with bias / activation / residuals.  Everything fp32."""
+    dev = x.device
+    P = B * (H // 2) * (W // 2)
+    L = _lib.lib()
+    V = winograd_weight(wp, cin)
+    U = torch.empty(16, P, cin, dtype=torch.float32, device=dev)
+    _lib.check(L.pp_winograd_input_f32(_p(x), ld_in, x.stride(0), B, H, W, cin, int(relu_in), _p(U), _lib.stream_ptr()), "pp_winograd_input_f32")
+    Y = torch.empty(16, P, Cout, dtype=torch.float32, device=dev)
+    for xi in range(16):
+        _run(_desc(A=_p(U[xi]), B=_p(V[xi]), C=_p(Y[xi]), M=P, N=Cout, K=cin, lda=cin, ldb=cin, ldc=Cout, prec=0))
+    if out is None:
+        out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=dev)
+    ldc = out.stride(2)
+    assert out.stride(3) == 1 and out.stride(1) == W * ldc and out.stride(0) == H * W * ldc
+    for r_ in (residual, residual2):
+        if r_ is not None:
+            assert r_.stride() == out.stride()
+    _lib.check(L.pp_winograd_output_f32(_p(Y), B, H, W, Cout, _p(bias), ACT[act], _p(residual), _p(residual2), _p(out), ldc, _lib.stream_ptr()),
+               "pp_winograd_output_f32")
+    return out
 
 
 def conv_transpose2d(x, wp, bias_tiled, r, out_split=False):

@@ -340,6 +340,59 @@ def test_fp32_engine_agrees_bitwise_across_tile_configurations_and_with_the_roun
 
 
 @gpu
+@pytest.mark.parametrize("B,cin,cout,hw", [(3, 64, 96, 32), (2, 640, 512, 16), (1, 256, 126, 64), (5, 32, 32, 8)])
+def test_winograd_3x3_of_the_strict_fp32_mode(monkeypatch, engine_precision, B, cin, cout, hw):
+    """ops.PRECISION = "f32": the large 3x3 / stride 1 / pad 1 convolutions run as Winograd F(2x2, 3x3) (csrc/pp_winograd.hip: input
+    transform, 16 dense fp32 products on the engine, output transform) — against float64 torch and against the direct implicit-GEMM
+    convolution it replaces (ops.WINOGRAD = False), with bias, ReLU, ReLU on the input, two residuals, a channel-slice input, a
+    channel-slice output and a channel count that is not a multiple of 4.  Error against float64 within 3 x the direct convolution's."""
+    if engine_precision != "f32":
+        pytest.skip("Winograd serves ops.PRECISION = 'f32'")
+    from picopose_amd import ops
+
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_PIXELS", 0)
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout)
+    x = torch.randn(B, hw, hw, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    r1, r2 = torch.randn(B, hw, hw, cout, generator=g), torch.randn(B, hw, hw, cout, generator=g)
+    wp = ops.pack_conv_weight(w.cuda())
+    wide_in = torch.zeros(B, hw, hw, cin + 24)
+    wide_in[..., 8:8 + cin] = x
+    wide_in = wide_in.cuda()
+    xd, wd = x.permute(0, 3, 1, 2).double(), w.double()
+
+    def both(fn):
+        monkeypatch.setattr(ops, "WINOGRAD", True)
+        a = fn()
+        monkeypatch.setattr(ops, "WINOGRAD", False)
+        d = fn()
+        monkeypatch.setattr(ops, "WINOGRAD", True)
+        return a, d
+
+    cases = [
+        (lambda: ops.conv2d(x.cuda(), wp, b.cuda(), 3, pad=1, act="relu"),
+         F.relu(F.conv2d(xd, wd, b.double(), padding=1))),
+        (lambda: ops.conv2d(wide_in[..., 8:8 + cin], wp, None, 3, pad=1, relu_in=True, residual=r1.cuda(), residual2=r2.cuda()),
+         F.conv2d(F.relu(xd), wd, None, padding=1) + r1.permute(0, 3, 1, 2).double() + r2.permute(0, 3, 1, 2).double()),
+    ]
+    for fn, ref in cases:
+        got, direct = both(fn)
+        ref = ref.permute(0, 2, 3, 1)
+        scale = float(ref.abs().max())
+        e_w, e_d = float((got.cpu().double() - ref).abs().max()) / scale, float((direct.cpu().double() - ref).abs().max()) / scale
+        assert e_w <= max(3 * e_d, 2e-6), (e_w, e_d)
+        assert e_w <= 2e-5
+    # a channel-slice output of a wider NHWC buffer
+    if cout % 4 == 0:
+        buf = torch.zeros(B, hw, hw, cout + 40, device="cuda")
+        ops.conv2d(x.cuda(), wp, b.cuda(), 3, pad=1, out=buf[..., 16:16 + cout])
+        ref = F.conv2d(xd, wd, b.double(), padding=1).permute(0, 2, 3, 1)
+        assert float((buf[..., 16:16 + cout].cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        assert not buf[..., :16].any() and not buf[..., 16 + cout:].any()
+
+
+@gpu
 def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, engine_precision):
     """The three pre-split kernels (128x128, 128x64, 256x128 LDS-DMA) walk K in the same order and accumulate the
     same way, so the value of an output element does not depend on which one the autotuner picks for a shape —
