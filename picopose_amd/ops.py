@@ -494,6 +494,10 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     slice of a shared operand: two layers fused along N hand their halves to their successors without a copy).
     alpha_dev: up to two device scalars the accumulated product is multiplied by inside the launch (PpGemmDesc.alpha_dev: the inverse
     range scale of a backward operand) — pre-split path only."""
+    if isinstance(x, WinoInput):      # the shared Winograd input of several 3x3 convolutions (strict-fp32 mode)
+        B, H, W, Cx = x.geom
+        assert ksize == 3 and stride == 1 and pad == 1 and cin in (None, Cx) and wp.shape[1] == 9 * Cx and hl_into is None
+        return _conv3x3_winograd(x, wp, bias, B, H, W, Cx, Cx, wp.shape[0], act, relu_in, residual, residual2, out)
     xs = x if isinstance(x, Split) else None
     a_ptr = None
     if xs is not None and in_cols is not None:
@@ -537,10 +541,9 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
         _lib.check(_lib.lib().pp_conv_narrow_f32(_p(x), ld_in, B, H, W, Cx, _p(wp), _p(bias), ksize, Cout, _p(residual), _p(out),
                                                  _lib.stream_ptr()), "pp_conv_narrow_f32")
         return out
-    if (xs is None and PRECISION == "f32" and WINOGRAD and ksize == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0
-            and cin % 4 == 0 and Cout >= 32 and act in (None, "none", "relu", "leaky01") and B * H * W >= WINOGRAD_MIN_PIXELS
-            and ld_in % 4 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and wp.dtype == torch.float32 and wp.is_contiguous()
-            and hl_into is None and cache_weight is True and not torch.is_grad_enabled()):     # (out_split / also_split: f16x3-engine hints, ignored in this mode)
+    if (xs is None and ksize == 3 and stride == 1 and pad == 1 and Cout >= 32 and act in (None, "none", "relu", "leaky01")
+            and _winograd_ok(B, H, W, cin, ld_in, x) and wp.dtype == torch.float32 and wp.is_contiguous()
+            and hl_into is None and cache_weight is True):     # (out_split / also_split: f16x3-engine hints, ignored in this mode)
         return _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, residual, residual2, out)
     wargs = _weight_args(wp, ksize * ksize * cin, cache_weight)   # (cache_weight=False: a transient packed weight of the training graph)
     presplit = xs is not None or ("B_hl" in wargs and (Cout > 64 or ksize > 1)
@@ -625,15 +628,48 @@ def winograd_weight(wp, cin):
     return hit[0]
 
 
+class WinoInput:
+    """The Winograd input transform U (16, P, C) of an fp32 NHWC map, made once for SEVERAL 3x3 convolutions that read the same map (the
+    two heads of the flow decoder read one 640-channel input: raft_decoder.py:251-289) — `ops.winograd_shared(x)`; `conv2d` takes it in
+    place of `x`.  The caller guarantees that the map is not rewritten between the transform and its last use."""
+    __slots__ = ("U", "geom", "relu")
+
+    def __init__(self, U, geom, relu):
+        self.U, self.geom, self.relu = U, geom, relu
+
+
+def _winograd_ok(B, H, W, cin, ld_in, x):
+    return (PRECISION == "f32" and WINOGRAD and H % 2 == 0 and W % 2 == 0 and cin % 4 == 0 and B * H * W >= WINOGRAD_MIN_PIXELS
+            and ld_in % 4 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and not torch.is_grad_enabled())
+
+
+def winograd_shared(x, relu=False):
+    """x (B,H,W,C) fp32 NHWC (channel-contiguous) -> WinoInput when the strict-fp32 mode would run its 3x3 convolutions by Winograd
+    (otherwise x itself): the input transform of a map that several convolutions read, done once."""
+    if isinstance(x, (Split, WinoInput)) or x.dim() != 4:
+        return x
+    B, H, W, C = x.shape
+    if not (x.stride(3) == 1 and x.stride(1) == W * x.stride(2) and _winograd_ok(B, H, W, C, x.stride(2), x)):
+        return x
+    U = torch.empty(16, B * (H // 2) * (W // 2), C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().pp_winograd_input_f32(_p(x), x.stride(2), x.stride(0), B, H, W, C, int(relu), _p(U), _lib.stream_ptr()),
+               "pp_winograd_input_f32")
+    return WinoInput(U, (B, H, W, C), bool(relu))
+
+
 def _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, residual, residual2, out):
     """3x3 / stride 1 / pad 1 on an fp32 NHWC map (a channel slice is fine) by Winograd F(2x2, 3x3): input transform, 16 dense fp32
-    products on the engine, output transform with bias / activation / residuals.  Everything fp32."""
-    dev = x.device
+    products on the engine, output transform with bias / activation / residuals.  Everything fp32.  x: the map, or its WinoInput."""
     P = B * (H // 2) * (W // 2)
     L = _lib.lib()
     V = winograd_weight(wp, cin)
-    U = torch.empty(16, P, cin, dtype=torch.float32, device=dev)
-    _lib.check(L.pp_winograd_input_f32(_p(x), ld_in, x.stride(0), B, H, W, cin, int(relu_in), _p(U), _lib.stream_ptr()), "pp_winograd_input_f32")
+    if isinstance(x, WinoInput):
+        assert x.geom == (B, H, W, cin) and x.relu == bool(relu_in)
+        U, dev = x.U, x.U.device
+    else:
+        dev = x.device
+        U = torch.empty(16, P, cin, dtype=torch.float32, device=dev)
+        _lib.check(L.pp_winograd_input_f32(_p(x), ld_in, x.stride(0), B, H, W, cin, int(relu_in), _p(U), _lib.stream_ptr()), "pp_winograd_input_f32")
     Y = torch.empty(16, P, Cout, dtype=torch.float32, device=dev)
     for xi in range(16):
         _run(_desc(A=_p(U[xi]), B=_p(V[xi]), C=_p(Y[xi]), M=P, N=Cout, K=cin, lda=cin, ldb=cin, ldc=Cout, prec=0))
