@@ -712,12 +712,16 @@ def gen_train_grads_dup():
     gen_train_grads("train_grads_dup")
 
 
+KINK_BAND = 5e-4
+
+
 def gen_train_grads_f64():
     """The SAME training step as train_grads.npz (same weights, batch and augmentation draw: `pred_Ms` is taken from that fixture) with the
     reference evaluated in FLOAT64 — module in .double(), inputs in double, default dtype float64, and the reference's explicit `.float()`
     casts widened for the duration of this run — then d(Loss) / d(every parameter), stored as grad3f64/<name> at the strides of grad3/<name>.
     It is the arbiter for gradient tensors too ill-conditioned for an fp32-vs-fp32 bar (the DPT fusion blocks between
-    batch-statistics BatchNorms): tests/test_train_gpu.py asserts |HIP - f64| <= 2 |reference-fp32 - f64| + 1e-7 max|grad| for them."""
+    batch-statistics BatchNorms); tests/test_train_gpu.py holds every tensor to a bar against these values, and — with the ReLU kinks
+    recorded below pinned to float64's side — the fusion blocks to |HIP - f64| <= 2 |reference-fp32 - f64| + 1e-7 max|grad|."""
     _ref()
     sys.path.insert(0, os.path.join(REF, "model"))
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -747,6 +751,28 @@ def gen_train_grads_f64():
     ref_picopose.aug_gtM_noise = lambda end_points: torch.from_numpy(f32["pred_Ms"]).double()
     torch.Tensor.float = lambda self, *a, **k: self.double()
     torch.set_default_dtype(torch.float64)
+    # The ReLU kinks of the DPT fusion blocks (dpt.py:82,87): every pre-activation the float64 forward holds within KINK_BAND of zero, as
+    # (index into the NHWC-flattened map, float64 value) — keys kink_idx/<module>/<call>, kink_val/... with <module> a ResidualConvUnit
+    # (its INPUT, the ReLU in front of conv1) or its bn1 (its OUTPUT, the ReLU in front of conv2) and <call> 0 = templates, 1 = real
+    # crops.  An fp32 forward within rounding of float64 may hold such an element on the other side of zero; the gradient of that element
+    # is then wholly different, and these blocks' parameter gradients are sums that cancel to 1e-7 of their terms
+    # (profiles/r05/grad_f64.txt).  tests/test_train_gpu.py pins these elements to float64's values for the float64 comparison.
+    kinks, calls = {}, {}
+
+    def kink_site(name, take_output):
+        def fwd(m, inp, o):
+            c = calls.get(name, 0)
+            calls[name] = c + 1
+            v = (o if take_output else inp[0]).detach().permute(0, 2, 3, 1).reshape(-1)
+            idx = torch.nonzero(v.abs() < KINK_BAND).reshape(-1)
+            kinks[f"kink_idx/{name}/{c}"] = idx.numpy().astype(np.int64)
+            kinks[f"kink_val/{name}/{c}"] = v[idx].numpy().astype(np.float64)
+        return fwd
+
+    for mname, m in net.named_modules():
+        if ".scratch.refinenet" in mname and (mname.endswith(".resConfUnit1") or mname.endswith(".resConfUnit2")):
+            m.register_forward_hook(kink_site(mname, False))
+            m.bn1.register_forward_hook(kink_site(mname + ".bn1", True))
     try:
         np.random.seed(1000 + seed)
         torch.manual_seed(2000 + seed)
@@ -761,7 +787,9 @@ def gen_train_grads_f64():
         torch.set_default_dtype(orig_dtype)
     assert total.dtype == torch.float64
     out = {"meta": np.array([B, seed, wseed], dtype=np.int64), "total_loss": total.detach().numpy(),
-           "total_loss_f32_reference": f32["total_loss"]}
+           "total_loss_f32_reference": f32["total_loss"], "kink_band": np.float64(KINK_BAND)}
+    out.update(kinks)
+    print("ReLU kinks of the fusion blocks: %d sites, %d pre-activations within %g of zero" % (len(kinks) // 2, sum(len(v) for k, v in kinks.items() if k.startswith("kink_idx/")), KINK_BAND))
     print("total loss f64 %.9f   fp32 reference %.9f" % (float(total), float(f32["total_loss"])))
     for k in [k for k in res if "loss" in k]:
         out[k] = res[k].detach().numpy()

@@ -851,6 +851,94 @@ def test_full_backward_matches_the_reference_autograd(golden_dir, precision):
     assert max(r[1] for r in report) <= 3e-4     # (the L2 norms of the gradient tensors)
 
 
+class _PinKinks(torch.autograd.Function):
+    """TEST-ONLY: y = x with the listed elements (NHWC-flat indices) overwritten by the float64 forward's values; the gradient passes through.
+    It puts every pre-activation float64 holds within 5e-4 of a ReLU's kink on float64's SIDE of it (the values move by < 1e-3 of the map's
+    rms): the gradient of a ReLU network is discontinuous exactly there, so no bar against float64 tighter than one element's own
+    gradient can be asked of ANY fp32 forward without it."""
+
+    @staticmethod
+    def forward(ctx, x, idx, val):
+        y = x.clone()
+        y.view(-1)[idx] = val
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None
+
+
+@gpu
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_fusion_block_gradients_against_float64_with_the_relu_kinks_pinned(golden_dir, precision, monkeypatch):
+    """What limits `test_full_backward_matches_the_reference_autograd` to 5e-3 against float64 on the DPT fusion blocks, isolated
+    (profiles/r05/grad_f64.txt, tools/grad_nodes_hip.py): ONE pre-activation of 524 288 in a block — float64 holds it at 1.6e-5 on a map of
+    rms 8.9, this build's fp32 forward 1e-5 on the other side of zero (the reference's own fp32 forward flips another one) — whose gradient
+    (1.5e-9) is then wholly different, on parameter gradients whose sums cancel to 3e-7.  Here the same step runs with the pre-activations
+    that float64 holds within 5e-4 of a ReLU kink of the fusion blocks (train_grads_f64.npz kink_idx / kink_val, 1 313 of 9.4 M elements)
+    pinned to float64's values, and the relation VERDICT r04 asked for is asserted on every fusion-block tensor:
+        |HIP - f64| <= 2 |reference-fp32 - f64| + KINK_FLOOR max|grad|,
+    KINK_FLOOR = 1e-5 on the fp32 engine (measured: worst tensor 1.6e-5 against the reference's own 1.4e-5 — 4.7e-3 without the pins; the
+    floor is used by tensors the reference holds to 1e-6: 6.4e-6 measured) and 3e-4 on the f16x3 engine (22-bit operands: 1.2e-4 measured,
+    3.9e-3 without the pins)."""
+    from picopose_amd import autograd as A
+    from picopose_amd import ops
+    from picopose_amd.picopose import Net
+    from picopose_amd.utils.loss_utils import Loss
+
+    z, ep, weights = _load_grad_fixture(golden_dir)
+    z64 = np.load(os.path.join(golden_dir, "train_grads_f64.npz"))
+    net = Net(small_cfg())
+    net.load_state_dict(weights(net.state_dict()))
+    net = net.cuda().train()
+    mods = {id(m): n for n, m in net.named_modules()}
+    calls, pinned, moved = {}, [0], [0]
+
+    def pin(t, site):
+        idx = torch.from_numpy(z64[f"kink_idx/{site}"]).cuda()
+        val = torch.from_numpy(z64[f"kink_val/{site}"]).float().cuda()
+        if idx.numel() == 0:
+            return t
+        assert idx.max() < t.numel()
+        pinned[0] += idx.numel()
+        moved[0] += int(((t.detach().reshape(-1)[idx] > 0) != (val > 0)).sum())
+        return _PinKinks.apply(t, idx, val)
+
+    def rcu(u, x, extra=None):                    # picopose_amd.autograd._rcu with the two ReLU inputs pinned (and bn1's ReLU un-fused for it)
+        name = mods[id(u)]
+        c = calls.get(name, 0)
+        calls[name] = c + 1
+        x = pin(x, f"{name}/{c}")
+        h = A.conv2d(A._Act.apply(x, "relu"), u.conv1.weight, u.conv1.bias, 3, pad=1)
+        h = A._Act.apply(pin(A.batchnorm_train(h, u.bn1, relu=False), f"{name}.bn1/{c}"), "relu")
+        h = A.conv2d(h, u.conv2.weight, u.conv2.bias, 3, pad=1)
+        h = A.add(A.batchnorm_train(h, u.bn2), x)
+        return h if extra is None else A.add(h, extra)
+
+    monkeypatch.setattr(A, "_rcu", rcu)
+    monkeypatch.setattr(ops, "PRECISION", precision)
+    res = net.forward_train(_cuda(ep), pred_Ms=torch.from_numpy(z["pred_Ms"]).cuda())
+    Loss()(res)["loss"].backward()
+    assert pinned[0] == sum(len(z64[k]) for k in z64.files if k.startswith("kink_idx/")) and len(calls) == 5
+    KINK_FLOOR, report = {"f32": 1e-5, "f16x3": 3e-4}[precision], []
+    for name, p in net.named_parameters():
+        if ".scratch.refinenet" not in name or not bool(z[f"grad3used/{name}"]):
+            continue
+        ref, ref64 = torch.from_numpy(z[f"grad3/{name}"]), torch.from_numpy(z64[f"grad3f64/{name}"])
+        sib = name[:-4] + "weight" if name.endswith(".bias") else None
+        if sib is not None and float(z[f"grad3norm/{name}"]) < 1e-4 * float(z[f"grad3norm/{sib}"]):
+            continue                                                  # (analytically zero gradients: see the test above)
+        flat = p.grad.detach().reshape(-1).cpu()
+        got = flat[:: max(1, -(-flat.numel() // 2048))]
+        scale = float(ref64.abs().max())
+        report.append((float((got.double() - ref64).abs().max()) / scale, float((ref.double() - ref64).abs().max()) / scale, name))
+    report.sort(reverse=True)
+    print(f"fusion blocks, kinks pinned [{precision}]: {pinned[0]} elements pinned, {moved[0]} of them were on the other side of zero; {len(report)} tensors; "
+          "worst (HIP-f64, ref32-f64, tensor):", [(f"{r[0]:.1e}", f"{r[1]:.1e}", r[2].replace("offset_regressor.dpt_head.scratch.", "")) for r in report[:6]])
+    bad = [r for r in report if r[0] > 2 * r[1] + KINK_FLOOR]
+    assert not bad, bad[:4]
+
+
 @gpu
 def test_full_backward_directional_derivative_at_vitb_width(monkeypatch):
     """A size-independent property of the whole backward at the configs[2] width (ViT-B/14, 4 pairs), against an INDEPENDENT
