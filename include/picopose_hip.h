@@ -235,6 +235,11 @@ typedef struct PpGemmDesc {
      * (one launch of S * tiles work items); add the S slices in index order (pp_sum_slices).  No bias / activation / residual.  */
     int ksplit;
     int ks_rows;             /* filled in by pp_gemm (the rows of one slice)                                                       */
+    /* filled in by pp_gemm — a batch of fp32 products whose A and C blocks lie one behind the other (a_bs0 = M lda, c_bs0 = M ldc,
+     * batch1 = 1, M % 256 == 0, no residual: the sixteen products of a Winograd convolution) runs as ONE persistent launch of the fp32
+     * engine over batch0 * M rows; row tile r reads the weights of group r BM / grp_rows, grp_b_bytes further on.                     */
+    int grp_rows;
+    long long grp_b_bytes;
 } PpGemmDesc;
 
 int pp_gemm(const PpGemmDesc* desc, void* stream);

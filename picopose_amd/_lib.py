@@ -39,7 +39,7 @@ class PpGemmDesc(ctypes.Structure):
         ("a_hl_bytes", ctypes.c_longlong), ("b_hl_bytes", ctypes.c_longlong),
         ("C_hl", ctypes.c_void_p), ("ldc_h", ctypes.c_int), ("c_relu", ctypes.c_int),
         ("alpha_dev", ctypes.c_void_p), ("alpha_dev2", ctypes.c_void_p),
-        ("ksplit", ctypes.c_int), ("ks_rows", ctypes.c_int),
+        ("ksplit", ctypes.c_int), ("ks_rows", ctypes.c_int), ("grp_rows", ctypes.c_int), ("grp_b_bytes", ctypes.c_longlong),
     ]
 
 

@@ -1111,6 +1111,26 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         fprintf(stderr, "[pp_gemm] scalar path: M=%d N=%d K=%d lda=%d ldb=%d conv=%dx%d cin=%d b_kn=%d batch=%d A%%16=%d B%%16=%d\n", d.M, d.N, d.K, d.lda,
                 d.ldb, d.conv_kh, d.conv_kw, d.conv_cin, d.b_kn, d.batch0 * d.batch1, (int)((uintptr_t)d.A % 16), (int)((uintptr_t)d.B % 16));
     const int cus = pp_cu_count();   // cached per device (two runtime calls per GEMM launch otherwise)
+    static const bool f_engine_on = [] { const char* e = getenv("PP_F32_ENGINE"); return !(e && e[0] == '0'); }();
+    static const bool f_group_on = [] { const char* e = getenv("PP_F32_GROUPED"); return !(e && e[0] == '0'); }();
+    d.grp_rows = 0;
+    d.grp_b_bytes = 0;
+    // A batch of fp32 products with A and C blocks one behind the other (the sixteen products of a Winograd convolution): ONE persistent
+    // launch of the fp32 engine over all the row tiles — a row tile lies inside one group (M % 256 == 0) and reads that group's weights.
+    if (f_engine_on && f_group_on && d.prec == PP_PREC_F32 && d.batch0 > 1 && d.batch1 == 1 && vec && !d.A_hl && d.conv_kh == 0 && !d.b_kn &&
+        d.shuffle_r == 0 && !d.residual && !d.residual2 && d.ksplit <= 1 && d.M % 256 == 0 && d.a_bs0 == (long long)d.M * d.lda &&
+        d.c_bs0 == (long long)d.M * d.ldc && (long long)d.M * d.batch0 < (1LL << 31) && d.b_bs0 >= 0) {
+        PpGemmDesc g = d;
+        g.M = d.M * d.batch0;
+        g.batch0 = 1;
+        const long long extra_b = (long long)(d.batch0 - 1) * d.b_bs0 * 4;
+        if (pp_gemm_f_ok(g) && g.b_hl_bytes + extra_b < 0xFFFFFF00LL) {
+            g.b_hl_bytes += extra_b;
+            g.grp_rows = d.M;
+            g.grp_b_bytes = d.b_bs0 * 4;
+            d = g;
+        }
+    }
     const long long rows = (d.M + BM - 1) / BM, z = (long long)d.batch0 * d.batch1;
     hipStream_t st = (hipStream_t)stream;
     const bool f16 = d.prec == PP_PREC_F16;          // plain fp16 operands: pre-split kernels only
@@ -1158,8 +1178,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     // in their results.  fp32 operands (split on the fly, or fp32 MFMA): 0 / 1 = 128x128 at 2 / 3 workgroups per CU, 2 = 128x64.
     // fp32 operands on aligned shapes: the fp32 engine (pp_gemm_f.hip; configurations 3 = 128x128, 4 = 256x128, 5 = 256x256, 6 = 128x64
     // — every one of them accumulates in the same order).  The round-1 gemm_kernel keeps batched products, B [K][N], unaligned rows.
-    static const bool f_engine_on = [] { const char* e = getenv("PP_F32_ENGINE"); return !(e && e[0] == '0'); }();
-    const bool fvec = f_engine_on && !asplit && !split && vec && z == 1 && pp_gemm_f_ok(d);
+    const bool fvec = f_engine_on && !asplit && !split && vec && z == 1 && (d.grp_rows != 0 || pp_gemm_f_ok(d));
     const bool h_shape = asplit && pp_gemm_uh_shape_ok(d, terms) && pp_gemm_u_vec_ok(d);
     auto u_cfg = [&](int cfg) {   // canonical pre-split configuration
         if (cfg == 3) cfg = 4;
@@ -1304,7 +1323,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             const double a_el = d.conv_kh != 0 ? (double)((d.M + per - 1) / per) * d.conv_h * d.conv_w * d.conv_cin   // the image, not its im2col
                                                : (double)d.M * d.K;
             const double mn = (double)d.M * d.N;
-            gp->bytes[gp->count] = (double)z * (a_el * ea + (double)d.N * d.K * ew + (d.C ? mn * 4.0 : 0.0) + (d.C_hl ? mn * eb : 0.0) +
+            gp->bytes[gp->count] = (double)z * (a_el * ea + (double)d.N * d.K * ew * (d.grp_rows ? d.M / d.grp_rows : 1) + (d.C ? mn * 4.0 : 0.0) + (d.C_hl ? mn * eb : 0.0) +
                                                (d.residual ? mn * 4.0 : 0.0) + (d.residual2 ? mn * 4.0 : 0.0));
         }
         gp->kind[gp->count] = asplit ? 0 : 1;   // (pp_prof_gemm_collect: two classes; the fp32 engine is told apart by its mode field, 16 + MODE)

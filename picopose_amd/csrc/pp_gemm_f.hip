@@ -342,9 +342,11 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_f_kernel(const PpG
                              : (unsigned)((base + (MODE == 1 ? abias : 0)) * EB) + cbyte;                            \
             amask[j] = MODE == 1 ? ~mask : mask;                                                                     \
         }                                                                                                            \
+        /* grouped launch (pp_gemm: a batch as extra row tiles): this row tile reads the weights of ITS group */     \
+        const unsigned gofs_ = (DENSE && d.grp_rows != 0) ? (unsigned)(m0_ / d.grp_rows) * (unsigned)d.grp_b_bytes : 0u;   \
         _Pragma("unroll") for (int j = 0; j < PB; ++j) {                                                             \
             const int nb = n0_ + (j * NW + w) * 8 + lr;                                                              \
-            bbyte[j] = nb < d.N ? (unsigned)((long long)nb * d.ldb * EB) + cbyte : 0xFFFFFFFFu;                      \
+            bbyte[j] = nb < d.N ? (unsigned)((long long)nb * d.ldb * EB) + cbyte + gofs_ : 0xFFFFFFFFu;              \
         }                                                                                                            \
         fkt = 0;                                                                                                     \
         ctap = cky = ckx = cci = 0;                                                                                  \

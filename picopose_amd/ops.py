@@ -608,9 +608,10 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
 
 # Winograd F(2x2, 3x3) for the large 3x3 convolutions of the strict-fp32 mode (csrc/pp_winograd.hip): 2.25 x fewer fp32 multiplications on
 # matrix-bound layers.  PP_WINOGRAD=0 keeps the direct implicit-GEMM convolution; layers below WINOGRAD_MIN_PIXELS output pixels stay direct
-# (sixteen small products do not fill the chip).
+# (the sixteen products run as one or two grouped launches of the engine, so 32 K pixels — 2 048 row tiles — already fill the chip; measured at
+# configs[2], ms per exact-mode step: threshold 128 K 181.3, 32 K 177.8, 8 K 177.4).
 WINOGRAD = os.environ.get("PP_WINOGRAD", "1") != "0"
-WINOGRAD_MIN_PIXELS = int(os.environ.get("PP_WINOGRAD_MIN_PIXELS", str(128 * 1024)))
+WINOGRAD_MIN_PIXELS = int(os.environ.get("PP_WINOGRAD_MIN_PIXELS", str(32 * 1024)))
 _wino_cache = {}
 
 
@@ -671,8 +672,13 @@ def _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, resi
         U = torch.empty(16, P, cin, dtype=torch.float32, device=dev)
         _lib.check(L.pp_winograd_input_f32(_p(x), ld_in, x.stride(0), B, H, W, cin, int(relu_in), _p(U), _lib.stream_ptr()), "pp_winograd_input_f32")
     Y = torch.empty(16, P, Cout, dtype=torch.float32, device=dev)
-    for xi in range(16):
-        _run(_desc(A=_p(U[xi]), B=_p(V[xi]), C=_p(Y[xi]), M=P, N=Cout, K=cin, lda=cin, ldb=cin, ldc=Cout, prec=0))
+    # the sixteen products as batches of one pp_gemm call each: the engine runs a batch as ONE persistent launch (row tiles of all its
+    # products, include/picopose_hip.h grp_rows) while the stacked operand / result blocks stay inside its 32-bit byte offsets
+    per = max(1, min(16, (0xF0000000 // (4 * P * max(cin, Cout))))) if P % 256 == 0 else 1    # (a row tile must lie inside one product)
+    for x0 in range(0, 16, per):
+        n = min(per, 16 - x0)
+        _run(_desc(A=_p(U[x0]), B=_p(V[x0]), C=_p(Y[x0]), M=P, N=Cout, K=cin, lda=cin, ldb=cin, ldc=Cout, prec=0, batch0=n,
+                   a_bs0=P * cin, b_bs0=Cout * cin, c_bs0=P * Cout))
     if out is None:
         out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=dev)
     ldc = out.stride(2)

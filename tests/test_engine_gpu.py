@@ -340,6 +340,28 @@ def test_fp32_engine_agrees_bitwise_across_tile_configurations_and_with_the_roun
 
 
 @gpu
+@pytest.mark.parametrize("nb,M,N,K", [(16, 256, 96, 64), (5, 512, 130, 36), (3, 768, 512, 640)])
+def test_fp32_batch_as_one_grouped_launch_equals_the_products_one_by_one(nb, M, N, K):
+    """pp_gemm, prec = PP_PREC_F32, batch0 = nb with the A and C blocks one behind the other (the sixteen products of a Winograd
+    convolution): ONE persistent launch of the fp32 engine whose row tiles read the weights of their own product (include/picopose_hip.h
+    grp_rows / grp_b_bytes) — the same bits as nb separate calls, with a bias and an activation shared by the products, and against float64."""
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(nb * 100 + N)
+    A = torch.randn(nb, M, K, generator=g).cuda()
+    W = (torch.randn(nb, N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    one, many = torch.empty(nb, M, N, device="cuda"), torch.full((nb, M, N), float("nan"), device="cuda")
+    for z in range(nb):
+        ops._run(ops._desc(A=ops._p(A[z]), B=ops._p(W[z]), C=ops._p(one[z]), bias=ops._p(b), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, prec=0, act=ops.ACT["relu"]))
+    ops._run(ops._desc(A=ops._p(A), B=ops._p(W), C=ops._p(many), bias=ops._p(b), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, prec=0, act=ops.ACT["relu"],
+                       batch0=nb, a_bs0=M * K, b_bs0=N * K, c_bs0=M * N))
+    ref = F.relu(torch.einsum("zmk,znk->zmn", A.cpu().double(), W.cpu().double()) + b.cpu().double())
+    assert float((many.cpu().double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert torch.equal(one, many)
+
+
+@gpu
 @pytest.mark.parametrize("B,cin,cout,hw", [(3, 64, 96, 32), (2, 640, 512, 16), (1, 256, 126, 64), (5, 32, 32, 8)])
 def test_winograd_3x3_of_the_strict_fp32_mode(monkeypatch, engine_precision, B, cin, cout, hw):
     """ops.PRECISION = "f32": the large 3x3 / stride 1 / pad 1 convolutions run as Winograd F(2x2, 3x3) (csrc/pp_winograd.hip: input
