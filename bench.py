@@ -266,7 +266,7 @@ def latency_leg(dev, s1_mode, images=10, n_det=8, bs=4, N=162, vit="dinov2_vitl1
         templates_data["template_feature"] = torch.stack([torch.cat([net.feature_extractor(tem["tem_rgb"][o, s0:s0 + bs])[-1] for s0 in range(0, N, bs)])
                                                           for o in range(n_obj)])
     g = torch.Generator().manual_seed(7)
-    times, times_la = [], []
+    times, times_la, times_one = [], [], []
 
     def image(i):
         det = make_end_points(n_det, 1, dev, 400 + i)
@@ -276,22 +276,20 @@ def latency_leg(dev, s1_mode, images=10, n_det=8, bs=4, N=162, vit="dinov2_vitl1
         return data
 
     datas = [image(i) for i in range(images + 3)]
-    # second pass: the loader hands over the NEXT image too (infer_image(next_data=): its first chunk's query crops ride in this image's last forward)
-    for look_ahead in (False, True):
-      for i in range(images + 2):
-        data = datas[i]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            preds = infer_image(net, data, templates_data, hyp=hyp, bs=bs, next_data=datas[i + 1] if look_ahead else None)
-        dt = time.perf_counter() - t0
-        if look_ahead:
-            if i >= 2:
-                times_la.append(dt * 1e3)
-            continue
-        assert len(preds) == n_det and len(preds[0]) == hyp
-        if i >= 2:            # (two warm-up images: autotuner, allocator)
-            times.append(dt * 1e3)
+    # pass 1: the reference's walk.  pass 2: the loader hands over the NEXT image too (infer_image(next_data=): its first chunk's query crops
+    # ride in this image's last forward).  pass 3: the whole image as ONE chunk (test batch = its detections; results do not depend on the batch).
+    for sink, chunk, look_ahead in ((times, bs, False), (times_la, bs, True), (times_one, n_det, False)):
+        for i in range(images + 2):
+            data = datas[i]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                preds = infer_image(net, data, templates_data, hyp=hyp, bs=chunk, next_data=datas[i + 1] if look_ahead else None)
+            dt = time.perf_counter() - t0
+            assert len(preds) == n_det and len(preds[0]) == hyp
+            if i >= 2:            # (two warm-up images: autotuner, allocator)
+                sink.append(dt * 1e3)
+    times_one.sort()
     times.sort()
     times_la.sort()
     med = times[len(times) // 2]
@@ -304,6 +302,9 @@ def latency_leg(dev, s1_mode, images=10, n_det=8, bs=4, N=162, vit="dinov2_vitl1
             "detections_per_image": n_det, "chunk": bs, "ms_per_chunk": med / (-(-n_det // bs)), "crops_per_s": n_det / (med * 1e-3),
             "seconds_per_image": med * 1e-3,
             "ms_per_image_with_next_image_look_ahead": times_la[len(times_la) // 2],
+            "ms_per_image_as_one_chunk": times_one[len(times_one) // 2],
+            "one_chunk_note": f"the same images with test batch = {n_det} (all detections of an image in one forward): the reference's test batch is a "
+                              "memory knob, results do not depend on it (tests/test_e2e.py batch-independence)",
             "look_ahead_note": "the same images with infer_image(next_data=): the loader's next image is known, so its first chunk's query ViT "
                                "rides in this image's last forward (the first chunk of an image otherwise has no predecessor to carry it)"}
 
