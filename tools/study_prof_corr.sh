@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pc
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc -o pc -- python3 $GRAFT_REPO_ROOT/tools/scratch/corr_bwd_levels.py > /tmp/pc.log 2>&1 < /dev/null
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc -o pc -- python3 $GRAFT_REPO_ROOT/tools/study_corr_bwd_levels.py > /tmp/pc.log 2>&1 < /dev/null
 echo "rocprof rc=$?"
 grep -v "simple_timer\|^$" /tmp/pc.log | tail -12
 f=$(find /tmp/pc -name "*kernel_stats.csv" | head -1)
