@@ -820,7 +820,13 @@ def main():
             exact = {"value": Bl / x_dt, "unit": "crops/s", "ms_per_step": x_dt * 1e3, "steps": x_steps,
                      "ms_per_step_median_hip_events": x_ms[len(x_ms) // 2],
                      "dtype": "f32 (v_mfma_f32_32x32x2_f32 in every kernel, exact-fp32 stage 1; PnP f64)",
+                     "winograd": {"on": bool(ops.WINOGRAD), "min_output_pixels": int(ops.WINOGRAD_MIN_PIXELS),
+                                  "note": "3x3 / stride 1 convolutions of at least min_output_pixels run as Winograd F(2x2, 3x3): fp32 transforms around 16 fp32 "
+                                          "products per 2x2 output tile instead of 36 (error within 3x the direct convolution's against float64); "
+                                          "PP_WINOGRAD=0 runs every convolution direct — the like-for-like operation count (227 ms, 140.7 crops/s, profiles/r05)",
+                                  "direct_convolution_equivalent_tflops": Bl * full_gflop_per_crop(N, vit, cached=cached) / x_dt / 1e3},
                      "roofline": {"bound": "mfma", "kernel": "pp_gemm_f_kernel (fp32 engine, v_mfma_f32_32x32x2_f32) + round-1 gemm_kernel, all GEMM / conv launches of one step",
+                                  "flops_note": "EXECUTED fp32 MFMA flops: a Winograd convolution counts its sixteen products, not the direct convolution it replaces",
                                   "achieved": xk_fl / (xk_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                   "frac": xk_fl / (xk_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "launches_per_step": xg_n[0] + xg_n[1],
                                   "kernel_ms_per_step": xk_ms, "algorithmic_flops_per_step": xk_fl, "per_kernel": x_per_kernel,
@@ -979,7 +985,10 @@ def main():
             else:
                 line["mfma"] = {"bound": "mfma", "scope": "whole step, all kernels (the GEMM/conv engine is >85 % of it)",
                                 "engine": "f32: v_mfma_f32_32x32x2_f32", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
-                                "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "gflop_per_crop": full_gflop_per_crop(N, vit, cached=cached)}
+                                "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "gflop_per_crop": full_gflop_per_crop(N, vit, cached=cached),
+                                "note": "DIRECT-convolution-equivalent flops of the step: with Winograd on (ops.WINOGRAD) the large 3x3 convolutions execute "
+                                        "2.25x fewer, so this fraction is not an MFMA utilisation and may exceed 1; `roofline` counts executed flops",
+                                "winograd": bool(ops.WINOGRAD)}
             line["pnp"] = pnp
             if phases is not None:
                 line["phases_ms"] = phases
