@@ -793,6 +793,21 @@ def main():
             torch.cuda.synchronize()
             x_dt = (time.perf_counter() - t1) / x_steps
             x_ms = sorted(xm[i].elapsed_time(xm[i + 1]) for i in range(x_steps))
+            # ... and with every convolution DIRECT (the reference's operation count, ops.WINOGRAD off): 2 warm-up steps, 3 timed
+            xd_dt = None
+            if ops.WINOGRAD:
+                ops.WINOGRAD = False
+                try:
+                    for _ in range(2):
+                        step()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        step()
+                    torch.cuda.synchronize()
+                    xd_dt = (time.perf_counter() - t1) / 3
+                finally:
+                    ops.WINOGRAD = True
             # its own roofline: HIP events around every GEMM launch of one more (untimed) exact step, fp32-MFMA peak
             _lib.check(L.pp_prof_gemm_enable(8192), "pp_prof_gemm_enable")
             forward()
@@ -824,7 +839,9 @@ def main():
                                   "note": "3x3 / stride 1 convolutions of at least min_output_pixels run as Winograd F(2x2, 3x3): fp32 transforms around 16 fp32 "
                                           "products per 2x2 output tile instead of 36 (error within 3x the direct convolution's against float64); "
                                           "PP_WINOGRAD=0 runs every convolution direct — the like-for-like operation count (227 ms, 140.7 crops/s, profiles/r05)",
-                                  "direct_convolution_equivalent_tflops": Bl * full_gflop_per_crop(N, vit, cached=cached) / x_dt / 1e3},
+                                  "direct_convolution_equivalent_tflops": Bl * full_gflop_per_crop(N, vit, cached=cached) / x_dt / 1e3,
+                                  "value_with_every_convolution_direct": None if xd_dt is None else Bl / xd_dt,
+                                  "ms_per_step_with_every_convolution_direct": None if xd_dt is None else xd_dt * 1e3},
                      "roofline": {"bound": "mfma", "kernel": "pp_gemm_f_kernel (fp32 engine, v_mfma_f32_32x32x2_f32) + round-1 gemm_kernel, all GEMM / conv launches of one step",
                                   "flops_note": "EXECUTED fp32 MFMA flops: a Winograd convolution counts its sixteen products, not the direct convolution it replaces",
                                   "achieved": xk_fl / (xk_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
@@ -1001,6 +1018,7 @@ def main():
                 line["exact_value"] = exact["value"]                 # scalars: the strictly like-for-like (all-fp32) number
                 line["exact_ms_per_step"] = exact["ms_per_step"]
                 line["exact_roofline_frac"] = exact["roofline"]["frac"]
+                line["exact_direct_value"] = exact["winograd"]["value_with_every_convolution_direct"]   # (the same leg with ops.WINOGRAD off)
         if emulate is not None:
             line["emulated_world"] = {
                 "world": emulate, "rank": 0, "crops_of_this_rank": Bl, "templates_of_this_rank": n_local, "global_batch": B,
