@@ -90,45 +90,49 @@ def test_torch_ddp_wrapper_around_the_hip_model():
     assert "world=2" in out and "tensors=338" in out, out[-2000:]
 
 
-@gpu
-def test_configs3_real_shard_shapes_eight_ranks_in_one_process():
-    """BASELINE configs[3] at its REAL shard shapes: ViT-B/14, global batch 32, 162 templates, 8 ranks -> 4 crops and 21 / 21 / 20 x 6
-    templates per rank, every rank run by picopose_amd.dist.LocalWorld (a thread per rank in this one process, the all-gathers real
-    exchanges between them — only the RCCL hop itself is not exercised).  For ranks 0, 3 and 7: template ids (through the selected
-    template's pose), stage-2 poses and the key-point lists of `sharded_forward` are BIT-EQUAL to the single-process forward of the same
-    crops against the whole bank (a score depends on one crop and one template; a network row on its own crop), and so are the
-    2-D / 3-D maps the PnP leg reads."""
+def _shard_shapes_in_one_process(world, bl, N, vit, precision, random_bank, sizes_want):
     import torch
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     import picopose_amd.dist as pd
+    from picopose_amd import ops
     from picopose_amd.picopose import Net
 
     dev = torch.device("cuda", 0)
-    world, bl, N, hyp, vit = 8, 4, 162, 5, "dinov2_vitb14"
-    net = Net(bench.make_cfg(vit))
-    bench.seeded_weights(net, 4, vit)
-    net = net.to(dev).eval()
-    ep = bench.make_end_points(world * bl, N, dev, 100)
-    with torch.no_grad():
-        bank = torch.stack([torch.cat([net.feature_extractor(ep["tem_rgb"][b, s:min(s + 54, N)])[-1] for s in range(0, N, 54)])
-                            for b in range(world * bl)])
-        ep["template_feature"] = bank
-        want = net(ep, hyp)                                      # single process, all 32 crops against their whole banks
-    sizes = [pd.shard_bounds(N, world, r)[1] - pd.shard_bounds(N, world, r)[0] for r in range(world)]
-    assert sizes == [21, 21, 20, 20, 20, 20, 20, 20]
+    hyp = 5
+    old = ops.PRECISION
+    ops.PRECISION = precision
+    try:
+        net = Net(bench.make_cfg(vit))
+        bench.seeded_weights(net, 4, vit)
+        net = net.to(dev).eval()
+        ep = bench.make_end_points(world * bl, N, dev, 100)
+        with torch.no_grad():
+            if random_bank:      # (a bank of 32 768 ViT-L maps would take the test's time; stage 1 reads it as data either way)
+                C = net.feature_extractor.dinov2.embed_dim
+                g = torch.Generator(device=dev).manual_seed(5)
+                bank = torch.stack([torch.randn(N, C, 16, 16, device=dev, generator=g).half() for _ in range(world * bl)])
+            else:
+                bank = torch.stack([torch.cat([net.feature_extractor(ep["tem_rgb"][b, s:min(s + 54, N)])[-1] for s in range(0, N, 54)])
+                                    for b in range(world * bl)])
+            ep["template_feature"] = bank
+            want = net(ep, hyp)                                      # single process, all crops against their whole banks
+        sizes = [pd.shard_bounds(N, world, r)[1] - pd.shard_bounds(N, world, r)[0] for r in range(world)]
+        assert sizes == sizes_want
 
-    def body(rank):
-        lo, hi = pd.shard_bounds(N, world, rank)
-        own = slice(rank * bl, (rank + 1) * bl)
-        local = {k: v[own].contiguous() for k, v in ep.items() if k != "template_feature"}
-        return pd.sharded_forward(net, local, bank[:, lo:hi].contiguous(), N, hyp=hyp)
+        def body(rank):
+            lo, hi = pd.shard_bounds(N, world, rank)
+            own = slice(rank * bl, (rank + 1) * bl)
+            local = {k: v[own].contiguous() for k, v in ep.items() if k != "template_feature"}
+            return pd.sharded_forward(net, local, bank[:, lo:hi].contiguous(), N, hyp=hyp)
 
-    lw = pd.LocalWorld(world)
-    with lw.installed():
-        outs = lw.run(body)
-    torch.cuda.synchronize()
+        lw = pd.LocalWorld(world)
+        with lw.installed():
+            outs = lw.run(body)
+        torch.cuda.synchronize()
+    finally:
+        ops.PRECISION = old
     assert pd.dist is torch.distributed
     for rank in (0, 3, 7):
         own = slice(rank * bl, (rank + 1) * bl)
@@ -137,3 +141,23 @@ def test_configs3_real_shard_shapes_eight_ranks_in_one_process():
             for key in ("tem_pose", "pred_poses", "pred_tar_pts", "pred_src_pts", "tar_pts_2d", "src_pts_3d"):
                 g, w = outs[rank][h][key], want[h][key][own]
                 assert g.shape == w.shape and torch.equal(g, w), (rank, h, key, float((g.double() - w.double()).abs().max()))
+
+
+@gpu
+def test_configs3_real_shard_shapes_eight_ranks_in_one_process():
+    """BASELINE configs[3] at its REAL shard shapes: ViT-B/14, global batch 32, 162 templates, 8 ranks -> 4 crops and 21 / 21 / 20 x 6
+    templates per rank, every rank run by picopose_amd.dist.LocalWorld (a thread per rank in this one process, the all-gathers real
+    exchanges between them — only the RCCL hop itself is not exercised).  For ranks 0, 3 and 7: template ids (through the selected
+    template's pose), stage-2 poses and the key-point lists of `sharded_forward` are BIT-EQUAL to the single-process forward of the same
+    crops against the whole bank (a score depends on one crop and one template; a network row on its own crop), and so are the
+    2-D / 3-D maps the PnP leg reads."""
+    _shard_shapes_in_one_process(8, 4, 162, "dinov2_vitb14", "f16x3", False, [21, 21, 20, 20, 20, 20, 20, 20])
+
+
+@gpu
+def test_configs4_real_shard_shapes_eight_ranks_in_one_process():
+    """BASELINE configs[4] at its shard shapes and in its arithmetic: ViT-L/14, global batch 64, 512 templates, fp16 engine mode, fp16
+    feature bank (17 GB), 8 ranks -> 8 crops and 64 templates per rank, again as eight LocalWorld ranks of one process and bit-equal to
+    the single-process forward for ranks 0, 3 and 7 (224 x 224 crops: 256 is not a multiple of the 14-pixel patch; the bank
+    holds random fp16 maps — stage 1 reads it as data)."""
+    _shard_shapes_in_one_process(8, 8, 512, "dinov2_vitl14", "f16", True, [64] * 8)
