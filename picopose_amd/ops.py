@@ -640,8 +640,9 @@ class WinoInput:
 
 
 def _winograd_ok(B, H, W, cin, ld_in, x):
-    return (PRECISION == "f32" and WINOGRAD and H % 2 == 0 and W % 2 == 0 and cin % 4 == 0 and B * H * W >= WINOGRAD_MIN_PIXELS
-            and ld_in % 4 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and not torch.is_grad_enabled())
+    P = B * (H // 2) * (W // 2)      # (P % 256 != 0: the products cannot share a launch — sixteen small launches pay only on larger maps)
+    return (PRECISION == "f32" and WINOGRAD and H % 2 == 0 and W % 2 == 0 and cin % 4 == 0
+            and B * H * W >= (WINOGRAD_MIN_PIXELS if P % 256 == 0 else 4 * WINOGRAD_MIN_PIXELS) and ld_in % 4 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and not torch.is_grad_enabled())
 
 
 def winograd_shared(x, relu=False):
