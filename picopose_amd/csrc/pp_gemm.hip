@@ -1306,7 +1306,11 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             best[key] = bc;
-            return finish();  // the last timed launch already produced the result
+            // the result this call leaves is the CHOSEN configuration's, launched once more behind the timing bursts — not whatever candidate
+            // happened to be timed last (PP_GEMM_TUNE_KEEP_LAST=1: the former behaviour, for the study in tools/study_grad_cfg.py)
+            static const bool keep_last = [] { const char* e = getenv("PP_GEMM_TUNE_KEEP_LAST"); return e && e[0] == '1'; }();
+            if (!keep_last) launch(bc);
+            return finish();
         }
         cfg = it->second;
     }

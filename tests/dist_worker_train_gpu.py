@@ -24,6 +24,10 @@ def main():
     from picopose_amd.utils.loss_utils import Loss
     from picopose_amd.utils.seeding import calibrated_state_dict
 
+    if os.environ.get("PP_DETERMINISTIC") == "1":     # fixed-point scatter adjoints: two computations of a gradient give the same bits
+        from picopose_amd import autograd
+
+        autograd.DETERMINISTIC = True
     backend = os.environ.get("PP_DIST_BACKEND", "gloo")
     torch.cuda.set_device(0)
     if backend == "nccl":
@@ -103,7 +107,7 @@ def main():
         mine = in_turn(lambda: grads_of(rank))                               # the copy that is all-reduced
         nb = allreduce_gradients(list(mine.parameters()), bucket_bytes=4 << 20)
     torch.cuda.synchronize()
-    ok, worst, n = nb >= 3, 0.0, 0
+    ok, worst, n, worst_name = nb >= 3, 0.0, 0, ""
     for (name, p), *cols in zip(mine.named_parameters(), *[local[r].parameters() for r in range(world)]):
         if p.grad is None or all(c.grad is None for c in cols):        # (DDP's reducer leaves zeros in the unused parameters)
             ok = ok and all(c.grad is None for c in cols) and (p.grad is None or float(p.grad.abs().max()) == 0.0)
@@ -112,9 +116,14 @@ def main():
         top = float(want.abs().max())
         n += 1
         if top > 1e-7:                               # (analytically zero gradients hold rounding noise)
-            worst = max(worst, float((p.grad - want).abs().max()) / top)
+            e = float((p.grad - want).abs().max()) / top
+            if e > worst:
+                worst, worst_name = e, name
+            if e > 2e-5 and os.environ.get("PP_DDP_VERBOSE") == "1":
+                d = (p.grad - want).abs()
+                print(f"RANK{rank} off: {name} e={e:.2e} elements off by > 1e-6 top: {int((d > 1e-6 * top).sum())} of {d.numel()}", flush=True)
     ok = ok and n >= 300 and worst <= 2e-5
-    print(f"RANK{rank} {'OK' if ok else 'MISMATCH'} backend={dist.get_backend()} world={world} buckets={nb} tensors={n} worst={worst:.2e}", flush=True)
+    print(f"RANK{rank} {'OK' if ok else 'MISMATCH'} backend={dist.get_backend()} world={world} buckets={nb} tensors={n} worst={worst:.2e} ({worst_name})", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
 
