@@ -960,7 +960,9 @@ def main():
                 "frac_algorithmic": fl / (msum * 1e-3) / 1e12 / peak,
                 "frac_note": "frac = EXECUTED MFMA flops (3 fp16 MFMA products per fp32-grade product) / time / fp16 dense peak; "
                              "frac_algorithmic = 2MNK / time / the same peak (ceiling 1/3 under the 3-term scheme)"
-                             if a.mode == "fast" else "one MFMA product per product: executed = algorithmic (frac = frac_algorithmic)",
+                             if a.mode == "fast" else ("one MFMA product per product: executed = algorithmic (frac = frac_algorithmic)" +
+                                                       ("; a Winograd convolution (ops.WINOGRAD, strict-fp32 mode) counts its sixteen products, not the "
+                                                        "direct convolution it replaces" if a.mode == "exact" and ops.WINOGRAD else "")),
                 "traffic": None if g_traffic is None else g_traffic / n, "traffic_bytes_per_step": g_traffic, "traffic_source": g_src,
                 "traffic_measured_in_this_run": False,
                 "per_kernel": gemm.get("per_kernel"),
