@@ -432,6 +432,30 @@ int pp_winograd_weight_f32(const float* w, int Cout, int Cin, int ldw, float* V,
 int pp_winograd_output_f32(const float* Y, int B, int H, int W, int Cout, const float* bias, int act, const float* residual,
                            const float* residual2, float* out, int ldc, void* stream);
 
+/* Winograd F(4x4, 3x3) on the f16x3 engine (PP_PREC_F16X3; round 6) for the large 3x3 / stride 1 / padding 1 convolutions of the flow
+ * decoder's heads (raft_decoder.py:251-289): 36 dense products Y_xi (P, Cout) = U_xi (P, Cin) V_xi (Cout, Cin)^T over the P = B H W / 16
+ * tiles — four times fewer multiplications than the direct convolution — run by pp_gemm as a batch of pre-split products (A_hl, B_hl,
+ * batch0 = the frequencies of the launch, a_bs0 = P lda, b_bs0 = Cout Cin, c_bs0 = P ldc, alpha = 64: ONE persistent launch).
+ *   pp_winograd4_input_hl    x_hl: hl operand image (B, H, W), rows of ld_x channels (C of them read from the pointer's column on; H, W
+ *                            % 4 == 0, C % 8 == 0); batch_stride in ELEMENTS  ->  U_hl (36, P, C) hl operand of (B^T d B) / 16
+ *   pp_winograd4_weight_f32  w (Cout, 9 Cin) in the engine's k order, rows of ldw floats  ->  V (36, Cout, Cin) fp32 (split it with
+ *                            pp_split_weights_t as ONE matrix of 36 Cout rows)
+ *   pp_winograd4_output      Y (36, P, Cout) fp32  ->  A^T Y A + bias, act (none / ReLU / LeakyReLU): as fp32 NHWC map `out` (rows of ldc
+ *                            floats; + residual + residual2 laid out like out) and / or as hl operand `out_hl` (rows of ld_h channels,
+ *                            the pointer at the first column's group; of max(., 0) with c_relu).  Cout % 4 == 0 (% 8 for out_hl). */
+int pp_winograd4_input_hl(const void* x_hl, int ld_x, long long batch_stride, int B, int H, int W, int C, int relu, void* U_hl, void* stream);
+int pp_winograd4_weight_f32(const float* w, int Cout, int Cin, int ldw, float* V, void* stream);
+int pp_winograd4_output(const float* Y, int B, int H, int W, int Cout, const float* bias, int act, const float* residual, const float* residual2,
+                        float* out, int ldc, void* out_hl, int ld_h, int c_relu, void* stream);
+
+/* Sticky operand-saturation word.  The f16x3 / f16 operand formats clamp at the fp16 range (|4 x| >= 65504): a clamped term is finite but
+ * WRONG.  With a device word registered here, every kernel that writes operand terms ORs bit 0 into it when a term hit the clamp (one
+ * atomic per wave that saw one; nothing when none did) — the host reads the word together with its results (no extra synchronisation)
+ * and raises.  word = NULL switches the reporting off.  Per device (the current one).  block.py:104-106 / layer_scale.py:27-28: trained
+ * DINOv2 residual streams hold a few very large channels. */
+int pp_set_saturation_word(unsigned int* word);
+
+
 /* The tiled lookup on operands the producers already hold in the engine's hl format (fp16 [pixels][2 ld]: per 8 channels
  * the 8 hi then the 8 lo terms; include "hl" above): f1_hl with rows of ld_f1 channels (a column block of a wider operand
  * is fine), f2_hl_l{0,1,2} contiguous (f2_batch, H >> l, W >> l, C).  H, W multiples of 8 and C of 32 (else PP_EINVAL: use

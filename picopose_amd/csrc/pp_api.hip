@@ -17,6 +17,16 @@ const char* pp_strerror(int code) {
 
 int pp_version(void) { return 100; }
 
+}  // extern "C"
+static unsigned* g_sat_word[PP_MAX_DEVICES];
+unsigned* pp_saturation_word() { return g_sat_word[pp_cur_device()]; }
+extern "C" {
+
+int pp_set_saturation_word(unsigned int* word) {
+    g_sat_word[pp_cur_device()] = word;
+    return PP_OK;
+}
+
 // ---- optional in-library timing of the dominant kernel (bench.py's roofline leg) ----------
 }  // extern "C"
 static PpProf g_prof;

@@ -50,6 +50,9 @@ static inline int pp_cu_count() {
     return cus[d];
 }
 
+// device word the operand producers OR bit 0 into when a term hit the fp16 clamp (pp_set_saturation_word; NULL: off)
+unsigned* pp_saturation_word();
+
 static inline int pp_last_launch() { return hipGetLastError() == hipSuccess ? PP_OK : PP_ELAUNCH; }
 
 

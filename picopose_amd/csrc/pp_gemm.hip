@@ -1131,6 +1131,19 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             d = g;
         }
     }
+    // The same for a batch of PRE-SPLIT products (the 36 frequencies of a Winograd F(4x4, 3x3) convolution on the f16x3 engine): A_hl /
+    // C blocks one behind the other, the weights of group g b_bs0 ELEMENTS further on — one persistent launch of pp_gemm_u_kernel.
+    long long grp_extra_b = 0;
+    if (d.A_hl && d.B_hl && d.batch0 > 1 && d.batch1 == 1 && d.conv_kh == 0 && !d.b_kn && d.shuffle_r == 0 && !d.residual && !d.residual2 &&
+        d.ksplit <= 1 && !d.C_hl && d.M % 256 == 0 && d.a_bs0 == (long long)d.M * d.lda && d.c_bs0 == (long long)d.M * d.ldc &&
+        (long long)d.M * d.batch0 < (1LL << 31) && d.b_bs0 >= 0 && d.b_bs0 % 8 == 0) {
+        const int eb_ = d.prec == PP_PREC_F16 ? 2 : 4;
+        grp_extra_b = (long long)(d.batch0 - 1) * d.b_bs0;     // elements
+        d.grp_rows = d.M;
+        d.grp_b_bytes = d.b_bs0 * eb_;
+        d.M *= d.batch0;
+        d.batch0 = 1;
+    }
     const long long rows = (d.M + BM - 1) / BM, z = (long long)d.batch0 * d.batch1;
     hipStream_t st = (hipStream_t)stream;
     const bool f16 = d.prec == PP_PREC_F16;          // plain fp16 operands: pre-split kernels only
@@ -1149,7 +1162,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             ? ((long long)((d.M + (long long)d.conv_ho * d.conv_wo - 1) / ((long long)d.conv_ho * d.conv_wo) - 1) * d.conv_bstride +
                (long long)d.conv_h * d.conv_w * d.lda)
             : (long long)(d.M - 1) * d.lda + d.K;
-        const long long b_elems = (long long)(d.N - 1) * d.ldb + d.K;
+        const long long b_elems = (long long)(d.N - 1) * d.ldb + d.K + grp_extra_b;
         // (32-bit byte offsets; 0xFFFFFFFF is the "reads zero" marker)
         if (a_elems * eb >= 0xFFFFFF00LL || b_elems * eb >= 0xFFFFFF00LL) return PP_EINVAL;
         d.a_hl_bytes = a_elems * eb;
@@ -1195,6 +1208,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             else launch_rc = pp_gemm_u_launch(d, cfg == 5 ? PP_U_256x256 : cfg == 4 ? PP_U_256x128 : cfg == 2 ? PP_U_128x64 : PP_U_128x128, terms, cus, st);
             return;
         }
+        if (fvec && cfg < 3 && d.grp_rows != 0) cfg = 3;   // a grouped batch exists on the engine only (the round-1 kernel would read group 0's weights for every row)
         if (fvec && cfg >= 3) {
             launch_rc = pp_gemm_f_launch(d, cfg == 7 ? PP_F_256x192 : cfg == 5 ? PP_U_256x256 : cfg == 4 ? PP_U_256x128 : cfg == 3 ? PP_U_128x128 : PP_U_128x64, cus, st);
             return;

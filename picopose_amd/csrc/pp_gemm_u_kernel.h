@@ -165,7 +165,9 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
         _Pragma("unroll") for (int j = 0; j < PB; ++j) {                                                             \
             const int nb = n0_ + pp_wperm((j * NW + w) * 8 + lr);   /* LDS weight rows are permuted: pp_gemm_dev.h */  \
             const long long koff_ = KS ? (long long)(m0_ / d.ks_rows) * d.K : 0;          \
-            bbyte[j] = nb < d.N ? (unsigned)(((long long)nb * d.ldb + koff_) * EB) + cbyte : 0xFFFFFFFFu;            \
+            /* grouped launch (the frequencies of a Winograd convolution): the row tile reads the weights of ITS group */ \
+            const unsigned gofs_ = (MODE == 0 && d.grp_rows != 0) ? (unsigned)(m0_ / d.grp_rows) * (unsigned)d.grp_b_bytes : 0u;   \
+            bbyte[j] = nb < d.N ? (unsigned)(((long long)nb * d.ldb + koff_) * EB) + cbyte + gofs_ : 0xFFFFFFFFu;    \
         }                                                                                                            \
         fkt = 0;                                                                                                     \
         ctap = cky = ckx = cci = 0;                                                                                  \

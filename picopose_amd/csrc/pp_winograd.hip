@@ -172,6 +172,226 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Winograd F(4x4, 3x3) on the f16x3 engine (round 6).  The pre-split engine runs the 3x3 convolutions at ~490 useful TFLOP/s
+// (three fp16 MFMAs per product); what is left is fewer products.  F(4x4, 3x3) computes a 4x4 output tile from a 6x6 input tile
+// with 36 products per (input channel, output channel) instead of 144 — FOUR times fewer — and its transformed operands are only
+// 36 / 16 = 2.25 x the map (F(2x2, 3x3): 2.25 x fewer products, operands 4 x the map: on this engine it breaks even):
+//      Y = A^T [ (G g G^T) .* (B^T d B) ] A ,     36 dense products  Y_xi (P, Cout) = U_xi (P, Cin) V_xi (Cout, Cin)^T ,  xi = 6 a + b,
+// over the P = B H W / 16 tiles, run by pp_gemm as grouped launches of pp_gemm_u_kernel (PpGemmDesc.grp_rows).  Transforms:
+//   pp_winograd4_input_hl    x: hl operand image (B, H, W) -> U (36, P, C) hl operand of (B^T d B) / 16  (operand scale 1/16 instead
+//                            of the activations' 4: |B^T d B| <= 100 |d|, so the operand saturates at |d| >= 10 480)
+//   pp_winograd4_weight_f32  w (Cout, 9 Cin) k-order -> V (36, Cout, Cin) fp32 = G g G^T  (then split once like any weight)
+//   pp_winograd4_output      Y (36, P, Cout) fp32 -> A^T Y A + bias, activation; as fp32 map and / or as hl operand (next layer's input)
+// The transforms are fp32 sums; their rounding is what F(4x4) costs: ~1e-5 of the map's maximum per layer against ~4e-7 direct
+// (tools/wino_precision_study.py) — inside every parity bar of the f16x3 mode (2e-4 / 5e-4 of the maximum).
+typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+
+// XCD-contiguous block order: hardware block b runs on XCD b % 8; logical blocks of one XCD are consecutive, so neighbouring tiles
+// (which share input columns / rows) meet in the same L2
+__device__ __forceinline__ long long wino_logical_block() {
+    const unsigned per = gridDim.x >> 3;      // gridDim.x is a multiple of 8
+    return (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+}
+
+// one 1-D input transform B^T (6 -> 6)
+#define PP_W4_BT(d0, d1, d2, d3, d4, d5, t0, t1, t2, t3, t4, t5)          \
+    {                                                                     \
+        const f4 a_ = d4 - 4.f * d2, b_ = d3 - 4.f * d1;                  \
+        const f4 c_ = d4 - d2, e_ = 2.f * (d3 - d1);                      \
+        t0 = 4.f * d0 - 5.f * d2 + d4;                                    \
+        t1 = a_ + b_;                                                     \
+        t2 = a_ - b_;                                                     \
+        t3 = c_ + e_;                                                     \
+        t4 = c_ - e_;                                                     \
+        t5 = 4.f * d1 - 5.f * d3 + d5;                                    \
+    }
+
+__device__ __forceinline__ bool wino_split4(f4 v, hf4& hi, hf4& lo) {
+    bool clamp = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e];
+        clamp |= !(fabsf(x) < 65504.f);
+        const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+        hi[e] = h;
+        lo[e] = (_Float16)fminf(fmaxf(x - (float)h, -65504.f), 65504.f);
+    }
+    return clamp;
+}
+
+// sticky saturation word (include/picopose_hip.h pp_set_saturation_word): one atomic per wave that saw a clamped term
+__device__ __forceinline__ void wino_note_sat(bool clamp, unsigned* sat) {
+    if (sat && __builtin_amdgcn_ballot_w64(clamp) != 0ull && (threadIdx.x & 63) == 0) atomicOr(sat, 1u);
+}
+
+// one thread = one 6x6 tile x 4 consecutive channels; tiles row-major over (B, H/4, W/4)
+__global__ __launch_bounds__(256) void wino4_input_kernel(const _Float16* __restrict__ x, int ld_x, long long bstride, int B, int H, int W, int C,
+                                                          int relu, _Float16* __restrict__ U, unsigned* sat) {
+    const int c4n = C >> 2;
+    const int tw = W >> 2, th = H >> 2;
+    const long long P = (long long)B * th * tw, total = P * c4n;
+    const long long i = wino_logical_block() * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long p = i / c4n;
+    const int c = (int)(i - p * c4n) * 4;
+    const int b = (int)(p / ((long long)th * tw)), r = (int)(p - (long long)b * th * tw), ty = r / tw, tx = r - ty * tw;
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    const int gcol = ((c >> 3) << 4) + (c & 7);     // half index of (c, hi) inside an hl row
+    const _Float16* img = x + b * bstride * 2;
+    f4 t[6][6];   // t = B^T d, built column by column
+#pragma unroll
+    for (int dx = 0; dx < 6; ++dx) {
+        f4 d[6];
+        const int ix = x0 + dx;
+#pragma unroll
+        for (int dy = 0; dy < 6; ++dy) {
+            const int iy = y0 + dy;
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const _Float16* src = img + ((long long)iy * W + ix) * 2 * ld_x + gcol;
+                const hf4 hi = *(const hf4*)src, lo = *(const hf4*)(src + 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (float)hi[e] + (float)lo[e];     // = 4 x, exactly
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            d[dy] = v;
+        }
+        PP_W4_BT(d[0], d[1], d[2], d[3], d[4], d[5], t[0][dx], t[1][dx], t[2][dx], t[3][dx], t[4][dx], t[5][dx])
+    }
+    bool clamp = false;
+    _Float16* dst = U + p * 2 * C + gcol;
+    const long long xi_stride = P * 2 * C;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        f4 u[6];
+        PP_W4_BT(t[a][0], t[a][1], t[a][2], t[a][3], t[a][4], t[a][5], u[0], u[1], u[2], u[3], u[4], u[5])
+#pragma unroll
+        for (int bb = 0; bb < 6; ++bb) {
+            hf4 hi, lo;
+            clamp |= wino_split4(u[bb] * (1.f / 64.f), hi, lo);       // (the 4 x of the source operand) / 64 = (B^T d B) / 16
+            _Float16* o = dst + (long long)(6 * a + bb) * xi_stride;
+            *(hf4*)o = hi;
+            *(hf4*)(o + 8) = lo;
+        }
+    }
+    wino_note_sat(clamp, sat);
+}
+
+// V_xi[co][ci] = (G g G^T)[a][b];  G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
+__global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int ldw, float* __restrict__ V) {
+    const long long total = (long long)Cout * Cin;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int co = (int)(i / Cin), ci = (int)(i - (long long)co * Cin);
+    float g[3][3], t[6][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[(long long)co * ldw + (ky * 3 + kx) * Cin + ci];
+    auto g6 = [](float g0, float g1, float g2, float (&o)[6]) {
+        o[0] = 0.25f * g0;
+        o[1] = (-1.f / 6.f) * ((g0 + g2) + g1);
+        o[2] = (-1.f / 6.f) * ((g0 + g2) - g1);
+        o[3] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+        o[4] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+        o[5] = g2;
+    };
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        float o[6];
+        g6(g[0][kx], g[1][kx], g[2][kx], o);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) t[a][kx] = o[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float o[6];
+        g6(t[a][0], t[a][1], t[a][2], o);
+#pragma unroll
+        for (int bb = 0; bb < 6; ++bb) V[((long long)(6 * a + bb) * Cout + co) * Cin + ci] = o[bb];
+    }
+}
+
+// one 1-D output transform A^T (6 -> 4)
+#define PP_W4_AT(y0, y1, y2, y3, y4, y5, o0, o1, o2, o3)                   \
+    {                                                                      \
+        const f4 s12 = y1 + y2, d12 = y1 - y2, s34 = y3 + y4, d34 = y3 - y4; \
+        o0 = (y0 + s12) + s34;                                             \
+        o1 = d12 + 2.f * d34;                                              \
+        o2 = s12 + 4.f * s34;                                              \
+        o3 = (d12 + 8.f * d34) + y5;                                       \
+    }
+
+// out(4x4) = A^T Y A, + bias, activation, (+ residuals for the fp32 map); fp32 map `out` and / or hl operand `out_hl` (of max(., 0) with
+// c_relu); one thread = one tile x 4 channels
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Y, int B, int H, int W, int Cout, const float* __restrict__ bias,
+                                                           int act, const float* __restrict__ residual, const float* __restrict__ residual2,
+                                                           float* __restrict__ out, int ldc, _Float16* __restrict__ out_hl, int ld_h, int c_relu,
+                                                           unsigned* sat) {
+    const int cn = Cout >> 2;
+    const int tw = W >> 2, th = H >> 2;
+    const long long P = (long long)B * th * tw, total = P * cn;
+    const long long i = wino_logical_block() * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long p = i / cn;
+    const int c = (int)(i - p * cn) * 4;
+    const int b = (int)(p / ((long long)th * tw)), r = (int)(p - (long long)b * th * tw), ty = r / tw, tx = r - ty * tw;
+    const float* src = Y + p * Cout + c;
+    const long long xi_stride = P * Cout;
+    f4 z[4][6];   // z = A^T Y, column by column
+#pragma unroll
+    for (int bb = 0; bb < 6; ++bb) {
+        f4 y[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) y[a] = *(const f4*)(src + (long long)(6 * a + bb) * xi_stride);
+        PP_W4_AT(y[0], y[1], y[2], y[3], y[4], y[5], z[0][bb], z[1][bb], z[2][bb], z[3][bb])
+    }
+    const f4 bv = bias ? *(const f4*)(bias + c) : f4{0.f, 0.f, 0.f, 0.f};
+    const float slope = act == PP_ACT_RELU ? 0.f : (act == PP_ACT_LEAKY01 ? 0.1f : 1.f);
+    const float hfloor = c_relu ? 0.f : -INFINITY;
+    const int gcol = ((c >> 3) << 4) + (c & 7);
+    bool clamp = false;
+#pragma unroll
+    for (int oy = 0; oy < 4; ++oy) {
+        f4 o[4];
+        PP_W4_AT(z[oy][0], z[oy][1], z[oy][2], z[oy][3], z[oy][4], z[oy][5], o[0], o[1], o[2], o[3])
+#pragma unroll
+        for (int ox = 0; ox < 4; ++ox) {
+            const long long row = ((long long)b * H + 4 * ty + oy) * W + 4 * tx + ox;
+            f4 v = o[ox] + bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+            if (out) {
+                f4 w = v;
+                if (residual) w += *(const f4*)(residual + row * ldc + c);
+                if (residual2) w += *(const f4*)(residual2 + row * ldc + c);
+                *(f4*)(out + row * ldc + c) = w;
+                v = w;
+            }
+            if (out_hl) {
+                hf4 hi, lo;
+                f4 x4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x4[e] = fmaxf(v[e] * PP_A_SCALE, hfloor);
+                clamp |= wino_split4(x4, hi, lo);
+                _Float16* o2 = out_hl + row * 2 * ld_h + gcol;
+                *(hf4*)o2 = hi;
+                *(hf4*)(o2 + 8) = lo;
+            }
+        }
+    }
+    wino_note_sat(clamp, sat);
+}
+
+static inline int grid8_of(long long n) {   // blocks of 256 threads, a multiple of 8 (wino_logical_block)
+    const long long g = ((n + 255) / 256 + 7) / 8 * 8;
+    return (int)g;
+}
+
 static inline int grid_of(long long n) {
     const long long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 65535 * 8 ? 65535 * 8 : g));
@@ -207,6 +427,40 @@ int pp_winograd_output_f32(const float* Y, int B, int H, int W, int Cout, const 
     else
         hipLaunchKernelGGL(wino_output_kernel<false>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, Y, B, H, W, Cout, bias, act, residual,
                            residual2, out, ldc);
+    return pp_last_launch();
+}
+
+
+/* ---- F(4x4, 3x3) on the f16x3 engine ---- */
+int pp_winograd4_input_hl(const void* x_hl, int ld_x, long long batch_stride, int B, int H, int W, int C, int relu, void* U_hl, void* stream) {
+    if (!x_hl || !U_hl || B <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3) || C <= 0 || (C & 7) || ld_x < C || (ld_x & 7) || (batch_stride & 7)) return PP_EINVAL;
+    if (((uintptr_t)x_hl & 15) || ((uintptr_t)U_hl & 15)) return PP_EINVAL;
+    const long long total = (long long)B * (H / 4) * (W / 4) * (C / 4);
+    if ((total + 255) / 256 + 8 >= (1LL << 31)) return PP_EINVAL;
+    hipLaunchKernelGGL(wino4_input_kernel, dim3(grid8_of(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_hl, ld_x, batch_stride, B, H, W,
+                       C, relu, (_Float16*)U_hl, pp_saturation_word());
+    return pp_last_launch();
+}
+
+int pp_winograd4_weight_f32(const float* w, int Cout, int Cin, int ldw, float* V, void* stream) {
+    if (!w || !V || Cout <= 0 || Cin <= 0 || ldw < 9 * Cin) return PP_EINVAL;
+    const long long total = (long long)Cout * Cin;
+    hipLaunchKernelGGL(wino4_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, ldw, V);
+    return pp_last_launch();
+}
+
+int pp_winograd4_output(const float* Y, int B, int H, int W, int Cout, const float* bias, int act, const float* residual, const float* residual2,
+                        float* out, int ldc, void* out_hl, int ld_h, int c_relu, void* stream) {
+    if (!Y || (!out && !out_hl) || B <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3) || Cout <= 0 || (Cout & 3)) return PP_EINVAL;
+    if (act != PP_ACT_NONE && act != PP_ACT_RELU && act != PP_ACT_LEAKY01) return PP_EINVAL;
+    if (out && (ldc < Cout || (ldc & 3))) return PP_EINVAL;
+    if (!out && (residual || residual2)) return PP_EINVAL;
+    if (out_hl && ((Cout & 7) || ld_h < Cout || (ld_h & 7))) return PP_EINVAL;
+    if (((uintptr_t)Y | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)residual2 | (uintptr_t)bias | (uintptr_t)out_hl) & 15) return PP_EINVAL;
+    const long long total = (long long)B * (H / 4) * (W / 4) * (Cout / 4);
+    if ((total + 255) / 256 + 8 >= (1LL << 31)) return PP_EINVAL;
+    hipLaunchKernelGGL(wino4_output_kernel, dim3(grid8_of(total)), dim3(256), 0, (hipStream_t)stream, Y, B, H, W, Cout, bias, act, residual, residual2,
+                       out, ldc, (_Float16*)out_hl, ld_h, c_relu, pp_saturation_word());
     return pp_last_launch();
 }
 

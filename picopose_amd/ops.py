@@ -39,6 +39,7 @@ def presplit():
 # of an operand verify its buffer (a host sync per operand: a debugging / test / bench-verification mode, never on in a
 # timed region) and raise instead of returning silently clipped values.
 CHECK_SATURATION = False
+PP_A_SCALE = 4.0              # csrc/pp_common.h: activation operand scale
 saturation_checks = 0        # operands verified since import (bench.py reports it)
 
 
@@ -498,6 +499,10 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
         B, H, W, Cx = x.geom
         assert ksize == 3 and stride == 1 and pad == 1 and cin in (None, Cx) and wp.shape[1] == 9 * Cx and hl_into is None
         return _conv3x3_winograd(x, wp, bias, B, H, W, Cx, Cx, wp.shape[0], act, relu_in, residual, residual2, out)
+    if isinstance(x, WinoInput4):     # the shared F(4x4, 3x3) input of several 3x3 convolutions (f16x3 engine)
+        B, H, W, Cx = x.geom
+        assert ksize == 3 and stride == 1 and pad == 1 and cin in (None, Cx) and wp.shape[1] == 9 * Cx and hl_into is None and not relu_in
+        return _conv3x3_winograd4(x, wp, bias, B, H, W, Cx, wp.shape[0], act, residual, residual2, out, out_split, split_relu, also_split)
     xs = x if isinstance(x, Split) else None
     a_ptr = None
     if xs is not None and in_cols is not None:
@@ -545,6 +550,11 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
             and _winograd_ok(B, H, W, cin, ld_in, x) and wp.dtype == torch.float32 and wp.is_contiguous()
             and hl_into is None and cache_weight is True):     # (out_split / also_split: f16x3-engine hints, ignored in this mode)
         return _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, residual, residual2, out)
+    if (xs is not None and ksize == 3 and stride == 1 and pad == 1 and xs.terms == 2 and hl_into is None and not alpha_dev and cache_weight is True
+            and act in (None, "none", "relu", "leaky01") and wp.dtype == torch.float32 and wp.is_contiguous()
+            and _winograd4_ok(B, H, W, cin, Cout)):
+        src = xs if a_ptr is None else (xs, in_cols[0])
+        return _conv3x3_winograd4(src, wp, bias, B, H, W, cin, Cout, act, residual, residual2, out, out_split, split_relu, also_split)
     wargs = _weight_args(wp, ksize * ksize * cin, cache_weight)   # (cache_weight=False: a transient packed weight of the training graph)
     presplit = xs is not None or ("B_hl" in wargs and (Cout > 64 or ksize > 1)
                                   and _can_presplit(x, ksize * ksize * cin, cin, ld_in, x.stride(0)) and B * H * W * cin < 2 ** 30)
@@ -645,10 +655,16 @@ def _winograd_ok(B, H, W, cin, ld_in, x):
             and B * H * W >= (WINOGRAD_MIN_PIXELS if P % 256 == 0 else 4 * WINOGRAD_MIN_PIXELS) and ld_in % 4 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and not torch.is_grad_enabled())
 
 
-def winograd_shared(x, relu=False):
+def winograd_shared(x, relu=False, cout=None):
     """x (B,H,W,C) fp32 NHWC (channel-contiguous) -> WinoInput when the strict-fp32 mode would run its 3x3 convolutions by Winograd
-    (otherwise x itself): the input transform of a map that several convolutions read, done once."""
-    if isinstance(x, (Split, WinoInput)) or x.dim() != 4:
+    (otherwise x itself): the input transform of a map that several convolutions read, done once.  f16x3 engine: x a Split with .image and
+    cout = the output channels of the convolutions that will read it -> WinoInput4 when F(4x4, 3x3) applies to them (else x itself)."""
+    if isinstance(x, Split) and cout is not None and x.image is not None and x.terms == 2:
+        B, H, W = x.image
+        if not relu and _winograd4_ok(B, H, W, x.shape[1], cout):
+            return WinoInput4(_winograd4_input(x.hl.data_ptr(), x.shape[1], B, H, W, x.shape[1], x.device), (B, H, W, x.shape[1]), x)
+        return x
+    if isinstance(x, (Split, WinoInput, WinoInput4)) or x.dim() != 4:
         return x
     B, H, W, C = x.shape
     if not (x.stride(3) == 1 and x.stride(1) == W * x.stride(2) and _winograd_ok(B, H, W, C, x.stride(2), x)):
@@ -690,6 +706,107 @@ def _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, resi
     _lib.check(L.pp_winograd_output_f32(_p(Y), B, H, W, Cout, _p(bias), ACT[act], _p(residual), _p(residual2), _p(out), ldc, _lib.stream_ptr()),
                "pp_winograd_output_f32")
     return out
+
+
+# Winograd F(4x4, 3x3) on the f16x3 engine (round 6; csrc/pp_winograd.hip): four times fewer products on the wide 3x3 convolutions of the flow
+# decoder's heads (640 -> 512, 512 -> 256: raft_decoder.py:251-289), transformed operands 2.25 x the map.  PP_WINOGRAD4=0 keeps them direct.
+# Which layers: wide enough that the saved MFMAs outweigh the three transform passes (measured per layer: profiles/r06/wino4_layers.txt).
+WINOGRAD4 = os.environ.get("PP_WINOGRAD4", "1") != "0"
+WINOGRAD4_MIN_PIXELS = int(os.environ.get("PP_WINOGRAD4_MIN_PIXELS", str(128 * 1024)))
+WINOGRAD4_MIN_CIN = int(os.environ.get("PP_WINOGRAD4_MIN_CIN", "512"))
+WINOGRAD4_MIN_COUT = int(os.environ.get("PP_WINOGRAD4_MIN_COUT", "256"))
+WINO4_GROUPS_PER_LAUNCH = 36
+WINO4_U_SCALE = 1.0 / 16.0        # operand scale of U = B^T d B (|U| <= 100 |d|): alpha = PP_A_SCALE / WINO4_U_SCALE = 64 undoes it
+
+
+class WinoInput4:
+    """The F(4x4, 3x3) input transform of an operand image — a Split (36 P, C) — made once for SEVERAL convolutions that read the same
+    map (`ops.winograd_shared(Xs, cout=...)`); `conv2d` takes it in place of the Split.  `.src` keeps the source operand alive."""
+    __slots__ = ("U", "geom", "src")
+
+    def __init__(self, U, geom, src):
+        self.U, self.geom, self.src = U, geom, src
+
+
+def _winograd4_ok(B, H, W, cin, cout):
+    P = B * (H // 4) * (W // 4)
+    return (PRECISION == "f16x3" and WINOGRAD4 and H % 4 == 0 and W % 4 == 0 and P % 256 == 0 and cin % 8 == 0 and cout % 8 == 0
+            and cin >= WINOGRAD4_MIN_CIN and cout >= WINOGRAD4_MIN_COUT and B * H * W >= WINOGRAD4_MIN_PIXELS
+            and 36 * P < 2 ** 31 and not torch.is_grad_enabled())
+
+
+def winograd4_weight(wp, cin):
+    """(V (36 Cout, Cin) fp32, its hl operand, power-of-two scale) = G g G^T of a packed 3x3 weight (Cout, 9 Cin), transformed and split
+    once per tensor version (a new version re-uses the buffers; one host sync to read the scale back)."""
+    key = (wp.data_ptr(), tuple(wp.shape), "wino4")
+    hit = _wino_cache.get(key)
+    if hit is None or hit[2] != wp._version:
+        Cout = wp.shape[0]
+        V = hit[0] if hit is not None else torch.empty(36 * Cout, cin, dtype=torch.float32, device=wp.device)
+        hl = hit[3] if hit is not None else torch.empty(36 * Cout, 2 * cin, dtype=torch.float16, device=wp.device)
+        _lib.check(_lib.lib().pp_winograd4_weight_f32(_p(wp), Cout, cin, wp.shape[1], _p(V), _lib.stream_ptr()), "pp_winograd4_weight_f32")
+        scale = torch.empty(1, dtype=torch.float32, device=wp.device)
+        _lib.check(_lib.lib().pp_split_weights_t(_p(V), V.numel(), 2, _p(hl), _p(scale), _lib.stream_ptr()), "pp_split_weights_t")
+        if len(_wino_cache) > 1024:
+            _wino_cache.clear()
+        hit = _wino_cache[key] = (V, wp, wp._version, hl, float(scale.item()))
+    return hit[0], hit[3], hit[4]
+
+
+def _winograd4_input(src_ptr, ld_x, B, H, W, cin, dev):
+    P = B * (H // 4) * (W // 4)
+    U = Split(torch.empty(36 * P, 2 * cin, dtype=torch.float16, device=dev), 2)
+    _lib.check(_lib.lib().pp_winograd4_input_hl(src_ptr, ld_x, H * W * ld_x, B, H, W, cin, 0, _p(U.hl), _lib.stream_ptr()), "pp_winograd4_input_hl")
+    _chk(U.hl, "pp_winograd4_input_hl")
+    return U
+
+
+def _conv3x3_winograd4(x, wp, bias, B, H, W, cin, Cout, act, residual, residual2, out, out_split, split_relu, also_split):
+    """3x3 / stride 1 / pad 1 on an operand image by Winograd F(4x4, 3x3): input transform (operand -> operand), 36 dense products on the
+    pre-split engine as grouped launches, output transform with bias / activation (/ residuals) into an fp32 map and / or the next
+    layer's operand.  x: a Split with .image, (Split, col0) for a channel slice of it, or its WinoInput4."""
+    P = B * (H // 4) * (W // 4)
+    L = _lib.lib()
+    V, vhl, vscale = winograd4_weight(wp, cin)
+    if isinstance(x, WinoInput4):
+        assert x.geom == (B, H, W, cin)
+        U = x.U
+    elif isinstance(x, tuple):
+        U = _winograd4_input(x[0].col_ptr(x[1]), x[0].shape[1], B, H, W, cin, x[0].device)
+    else:
+        U = _winograd4_input(x.hl.data_ptr(), x.shape[1], B, H, W, cin, x.device)
+    dev = U.device
+    Y = torch.empty(36, P, Cout, dtype=torch.float32, device=dev)
+    per = max(1, min(WINO4_GROUPS_PER_LAUNCH, 0xF0000000 // (4 * P * max(cin, Cout))))   # groups per launch: operand / result blocks inside 32-bit byte offsets
+    for x0 in range(0, 36, per):
+        n = min(per, 36 - x0)
+        _run(_desc(A_hl=U.hl.data_ptr() + x0 * P * cin * 4, B=_p(V), B_hl=vhl.data_ptr() + x0 * Cout * cin * 4, b_scale=vscale, C=_p(Y[x0]),
+                   M=P, N=Cout, K=cin, lda=cin, ldb=cin, ldc=Cout, prec=_PREC["f16x3"], batch0=n, a_bs0=P * cin, b_bs0=Cout * cin,
+                   c_bs0=P * Cout, alpha=PP_A_SCALE / WINO4_U_SCALE, _keep=(U, vhl, V)))
+    ret, hl_t, ldc = None, None, 0
+    if out_split and out is None and residual is None and residual2 is None:
+        hl_t = Split.empty(B * H * W, Cout, dev)
+        hl_t.image = (B, H, W)
+        ret, c_relu = hl_t, int(split_relu)
+    else:
+        if out is None:
+            out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=dev)
+        ldc = out.stride(2)
+        assert out.stride(3) == 1 and out.stride(1) == W * ldc and out.stride(0) == H * W * ldc
+        for r_ in (residual, residual2):
+            if r_ is not None:
+                assert r_.stride() == out.stride()
+        ret, c_relu = out, 0
+        if also_split is not None and out.is_contiguous():
+            hl_t = Split.empty(B * H * W, Cout, dev)
+            hl_t.image = (B, H, W)
+            c_relu = int(also_split == "relu")
+            setattr(out, "_hl_relu" if also_split == "relu" else "_hl", hl_t)
+    _lib.check(L.pp_winograd4_output(_p(Y), B, H, W, Cout, _p(bias), ACT[act], _p(residual), _p(residual2), _p(out), ldc,
+                                     _p(hl_t.hl) if hl_t is not None else None, Cout, c_relu, _lib.stream_ptr()), "pp_winograd4_output")
+    if hl_t is not None:
+        _chk(hl_t.hl, "pp_winograd4_output")
+    return ret
 
 
 def conv_transpose2d(x, wp, bias_tiled, r, out_split=False):

@@ -415,6 +415,80 @@ def test_winograd_3x3_of_the_strict_fp32_mode(monkeypatch, engine_precision, B, 
 
 
 @gpu
+@pytest.mark.parametrize("B,cin,cout,hw", [(16, 64, 64, 16), (4, 640, 512, 32), (1, 512, 256, 64), (64, 32, 40, 8)])
+def test_winograd4_3x3_of_the_f16x3_engine(monkeypatch, engine_precision, B, cin, cout, hw):
+    """ops.PRECISION = "f16x3": wide 3x3 / stride 1 / pad 1 convolutions on an operand image run as Winograd F(4x4, 3x3)
+    (csrc/pp_winograd.hip: operand -> operand input transform, 36 dense products on the pre-split engine as grouped launches, output
+    transform) — against float64 torch and against the direct implicit-GEMM convolution it replaces (ops.WINOGRAD4 = False): operand
+    output with the consumer's ReLU folded in, fp32 output with residuals and an attached operand, a channel slice of a wider operand as
+    input, and one input transform shared by two convolutions.  F(4x4)'s fp32 transforms cost ~1e-5 of the maximum per layer
+    (tools/wino_precision_study.py); the bar here is 4e-5, the f16x3 mode's network bars are 2e-4 / 5e-4."""
+    if engine_precision != "f16x3":
+        pytest.skip("F(4x4, 3x3) serves ops.PRECISION = 'f16x3'")
+    from picopose_amd import ops
+
+    for k in ("WINOGRAD4_MIN_PIXELS", "WINOGRAD4_MIN_CIN", "WINOGRAD4_MIN_COUT"):
+        monkeypatch.setattr(ops, k, 0)
+    monkeypatch.setattr(ops, "CHECK_SATURATION", True)
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout)
+    x = torch.randn(B, hw, hw, cin, generator=g) * 3.0
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    r1, r2 = torch.randn(B, hw, hw, cout, generator=g), torch.randn(B, hw, hw, cout, generator=g)
+    wp = ops.pack_conv_weight(w.cuda())
+    xs = ops.split_image(x.cuda())
+    assert isinstance(xs, ops.Split)
+    wide = torch.zeros(B, hw, hw, cin + 24)
+    wide[..., 8:8 + cin] = x
+    wide_s = ops.split_image(wide.cuda())
+    xq = (xs.hl.view(-1, cin // 8, 2, 8).float().sum(2).view(B, hw, hw, cin) / 4).cpu()    # the operand's values (22 bits of x)
+    xd, wd = xq.permute(0, 3, 1, 2).double(), w.double()
+
+    def both(fn):
+        monkeypatch.setattr(ops, "WINOGRAD4", True)
+        a = fn()
+        monkeypatch.setattr(ops, "WINOGRAD4", False)
+        d = fn()
+        monkeypatch.setattr(ops, "WINOGRAD4", True)
+        return a, d
+
+    def as_f32(t):
+        if isinstance(t, ops.Split):
+            return (t.hl.view(-1, t.shape[1] // 8, 2, 8).float().sum(2).view(B, hw, hw, -1) / 4).cpu().double()
+        return t.cpu().double()
+
+    ref_plain = F.conv2d(xd, wd, b.double(), padding=1)
+    cases = [
+        (lambda: ops.conv2d(xs, wp, b.cuda(), 3, pad=1, act="relu", out_split=True, split_relu=True), F.relu(ref_plain)),
+        (lambda: ops.conv2d(xs, wp, b.cuda(), 3, pad=1, act="leaky01", residual=r1.cuda(), residual2=r2.cuda()),
+         F.leaky_relu(ref_plain, 0.1) + r1.permute(0, 3, 1, 2).double() + r2.permute(0, 3, 1, 2).double()),
+        (lambda: ops.conv2d(wide_s, wp, None, 3, pad=1, in_cols=(8, cin)), F.conv2d(xd, wd, None, padding=1)),
+    ]
+    for fn, ref in cases:
+        got, direct = both(fn)
+        ref = ref.permute(0, 2, 3, 1)
+        scale = float(ref.abs().max())
+        e_w, e_d = float((as_f32(got) - ref).abs().max()) / scale, float((as_f32(direct) - ref).abs().max()) / scale
+        assert e_d <= 4e-6, e_d
+        assert e_w <= 4e-5, (e_w, e_d)
+    # fp32 output that also carries its relu'd operand form
+    o = ops.conv2d(xs, wp, b.cuda(), 3, pad=1, also_split="relu")
+    ref = ref_plain.permute(0, 2, 3, 1)
+    assert float((o.cpu().double() - ref).abs().max()) <= 4e-5 * float(ref.abs().max())
+    assert float((as_f32(o._hl_relu) - F.relu(ref)).abs().max()) <= 4e-5 * float(ref.abs().max())
+    # one input transform shared by two convolutions: the same bits as two separate ones
+    w2p = ops.pack_conv_weight((torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda())
+    sh = ops.winograd_shared(xs, cout=cout)
+    assert isinstance(sh, ops.WinoInput4)
+    for wq in (wp, w2p):
+        assert torch.equal(ops.conv2d(sh, wq, b.cuda(), 3, pad=1, act="relu"), ops.conv2d(xs, wq, b.cuda(), 3, pad=1, act="relu"))
+    # a grouped launch cut into several (32-bit byte offsets of the stacked blocks): the same bits
+    one = ops.conv2d(xs, wp, b.cuda(), 3, pad=1)
+    monkeypatch.setattr(ops, "WINO4_GROUPS_PER_LAUNCH", 7)
+    assert torch.equal(ops.conv2d(xs, wp, b.cuda(), 3, pad=1), one)
+
+
+@gpu
 def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, engine_precision):
     """The three pre-split kernels (128x128, 128x64, 256x128 LDS-DMA) walk K in the same order and accumulate the
     same way, so the value of an output element does not depend on which one the autotuner picks for a shape —
