@@ -442,11 +442,14 @@ int pp_winograd_output_f32(const float* Y, int B, int H, int W, int Cout, const 
  *                            pp_split_weights_t as ONE matrix of 36 Cout rows)
  *   pp_winograd4_output      Y (36, P, Cout) fp32  ->  A^T Y A + bias, act (none / ReLU / LeakyReLU): as fp32 NHWC map `out` (rows of ldc
  *                            floats; + residual + residual2 laid out like out) and / or as hl operand `out_hl` (rows of ld_h channels,
- *                            the pointer at the first column's group; of max(., 0) with c_relu).  Cout % 4 == 0 (% 8 for out_hl). */
-int pp_winograd4_input_hl(const void* x_hl, int ld_x, long long batch_stride, int B, int H, int W, int C, int relu, void* U_hl, void* stream);
+ *                            the pointer at the first column's group; of max(., 0) with c_relu).  Cout % 4 == 0 (% 8 for out_hl).
+ * P_pad >= P: the rows of one frequency block of U and Y (P rounded up to a multiple of 256, the engine's row tile, so that a row tile
+ * lies inside one frequency; the pad rows are never read by the output transform). */
+int pp_winograd4_input_hl(const void* x_hl, int ld_x, long long batch_stride, int B, int H, int W, int C, int relu, void* U_hl, long long P_pad,
+                          void* stream);
 int pp_winograd4_weight_f32(const float* w, int Cout, int Cin, int ldw, float* V, void* stream);
 int pp_winograd4_output(const float* Y, int B, int H, int W, int Cout, const float* bias, int act, const float* residual, const float* residual2,
-                        float* out, int ldc, void* out_hl, int ld_h, int c_relu, void* stream);
+                        float* out, int ldc, void* out_hl, int ld_h, int c_relu, long long P_pad, void* stream);
 
 /* Sticky operand-saturation word.  The f16x3 / f16 operand formats clamp at the fp16 range (|4 x| >= 65504): a clamped term is finite but
  * WRONG.  With a device word registered here, every kernel that writes operand terms ORs bit 0 into it when a term hit the clamp (one

@@ -227,7 +227,7 @@ __device__ __forceinline__ void wino_note_sat(bool clamp, unsigned* sat) {
 
 // one thread = one 6x6 tile x 4 consecutive channels; tiles row-major over (B, H/4, W/4)
 __global__ __launch_bounds__(256) void wino4_input_kernel(const _Float16* __restrict__ x, int ld_x, long long bstride, int B, int H, int W, int C,
-                                                          int relu, _Float16* __restrict__ U, unsigned* sat) {
+                                                          int relu, _Float16* __restrict__ U, long long Pp, unsigned* sat) {
     const int c4n = C >> 2;
     const int tw = W >> 2, th = H >> 2;
     const long long P = (long long)B * th * tw, total = P * c4n;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const _Float16* __rest
     }
     bool clamp = false;
     _Float16* dst = U + p * 2 * C + gcol;
-    const long long xi_stride = P * 2 * C;
+    const long long xi_stride = Pp * 2 * C;     // rows per frequency block: P rounded up to the engine's row tile
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         f4 u[6];
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Y, int B, int H, int W, int Cout, const float* __restrict__ bias,
                                                            int act, const float* __restrict__ residual, const float* __restrict__ residual2,
                                                            float* __restrict__ out, int ldc, _Float16* __restrict__ out_hl, int ld_h, int c_relu,
-                                                           unsigned* sat) {
+                                                           long long Pp, unsigned* sat) {
     const int cn = Cout >> 2;
     const int tw = W >> 2, th = H >> 2;
     const long long P = (long long)B * th * tw, total = P * cn;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     const int c = (int)(i - p * cn) * 4;
     const int b = (int)(p / ((long long)th * tw)), r = (int)(p - (long long)b * th * tw), ty = r / tw, tx = r - ty * tw;
     const float* src = Y + p * Cout + c;
-    const long long xi_stride = P * Cout;
+    const long long xi_stride = Pp * Cout;
     f4 z[4][6];   // z = A^T Y, column by column
 #pragma unroll
     for (int bb = 0; bb < 6; ++bb) {
@@ -432,13 +432,14 @@ int pp_winograd_output_f32(const float* Y, int B, int H, int W, int Cout, const 
 
 
 /* ---- F(4x4, 3x3) on the f16x3 engine ---- */
-int pp_winograd4_input_hl(const void* x_hl, int ld_x, long long batch_stride, int B, int H, int W, int C, int relu, void* U_hl, void* stream) {
+int pp_winograd4_input_hl(const void* x_hl, int ld_x, long long batch_stride, int B, int H, int W, int C, int relu, void* U_hl, long long P_pad,
+                          void* stream) {
     if (!x_hl || !U_hl || B <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3) || C <= 0 || (C & 7) || ld_x < C || (ld_x & 7) || (batch_stride & 7)) return PP_EINVAL;
     if (((uintptr_t)x_hl & 15) || ((uintptr_t)U_hl & 15)) return PP_EINVAL;
     const long long total = (long long)B * (H / 4) * (W / 4) * (C / 4);
-    if ((total + 255) / 256 + 8 >= (1LL << 31)) return PP_EINVAL;
+    if ((total + 255) / 256 + 8 >= (1LL << 31) || P_pad < (long long)B * (H / 4) * (W / 4)) return PP_EINVAL;
     hipLaunchKernelGGL(wino4_input_kernel, dim3(grid8_of(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_hl, ld_x, batch_stride, B, H, W,
-                       C, relu, (_Float16*)U_hl, pp_saturation_word());
+                       C, relu, (_Float16*)U_hl, P_pad, pp_saturation_word());
     return pp_last_launch();
 }
 
@@ -450,7 +451,8 @@ int pp_winograd4_weight_f32(const float* w, int Cout, int Cin, int ldw, float* V
 }
 
 int pp_winograd4_output(const float* Y, int B, int H, int W, int Cout, const float* bias, int act, const float* residual, const float* residual2,
-                        float* out, int ldc, void* out_hl, int ld_h, int c_relu, void* stream) {
+                        float* out, int ldc, void* out_hl, int ld_h, int c_relu, long long P_pad, void* stream) {
+    if (P_pad < (long long)B * (H / 4) * (W / 4)) return PP_EINVAL;
     if (!Y || (!out && !out_hl) || B <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3) || Cout <= 0 || (Cout & 3)) return PP_EINVAL;
     if (act != PP_ACT_NONE && act != PP_ACT_RELU && act != PP_ACT_LEAKY01) return PP_EINVAL;
     if (out && (ldc < Cout || (ldc & 3))) return PP_EINVAL;
@@ -460,7 +462,7 @@ int pp_winograd4_output(const float* Y, int B, int H, int W, int Cout, const flo
     const long long total = (long long)B * (H / 4) * (W / 4) * (Cout / 4);
     if ((total + 255) / 256 + 8 >= (1LL << 31)) return PP_EINVAL;
     hipLaunchKernelGGL(wino4_output_kernel, dim3(grid8_of(total)), dim3(256), 0, (hipStream_t)stream, Y, B, H, W, Cout, bias, act, residual, residual2,
-                       out, ldc, (_Float16*)out_hl, ld_h, c_relu, pp_saturation_word());
+                       out, ldc, (_Float16*)out_hl, ld_h, c_relu, P_pad, pp_saturation_word());
     return pp_last_launch();
 }
 

@@ -480,7 +480,7 @@ def split_image(x, relu=False):
 
 def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residual=None, out=None, cin=None,
            residual2=None, out_split=False, split_relu=False, also_split=None, hl_into=None, cache_weight=True, in_cols=None,
-           alpha_dev=()):
+           alpha_dev=(), wino=False):
     """NHWC convolution. x (B,H,W,Cx) (channel-contiguous, may be a channel slice: cin <= Cx stride) or a Split
     carrying .image (a pre-split operand: no split pass, the producer has already applied any input ReLU),
     wp (Cout, k*k*cin) from pack_conv_weight.  out may be a channel slice of a wider NHWC buffer.
@@ -550,7 +550,7 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
             and _winograd_ok(B, H, W, cin, ld_in, x) and wp.dtype == torch.float32 and wp.is_contiguous()
             and hl_into is None and cache_weight is True):     # (out_split / also_split: f16x3-engine hints, ignored in this mode)
         return _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, residual, residual2, out)
-    if (xs is not None and ksize == 3 and stride == 1 and pad == 1 and xs.terms == 2 and hl_into is None and not alpha_dev and cache_weight is True
+    if (wino and xs is not None and ksize == 3 and stride == 1 and pad == 1 and xs.terms == 2 and hl_into is None and not alpha_dev and cache_weight is True
             and act in (None, "none", "relu", "leaky01") and wp.dtype == torch.float32 and wp.is_contiguous()
             and _winograd4_ok(B, H, W, cin, Cout)):
         src = xs if a_ptr is None else (xs, in_cols[0])
@@ -710,11 +710,10 @@ def _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, resi
 
 # Winograd F(4x4, 3x3) on the f16x3 engine (round 6; csrc/pp_winograd.hip): four times fewer products on the wide 3x3 convolutions of the flow
 # decoder's heads (640 -> 512, 512 -> 256: raft_decoder.py:251-289), transformed operands 2.25 x the map.  PP_WINOGRAD4=0 keeps them direct.
-# Which layers: wide enough that the saved MFMAs outweigh the three transform passes (measured per layer: profiles/r06/wino4_layers.txt).
+# Which layers: the caller says so (`conv2d(..., wino=True)` / `winograd_shared(.., cout=)`: the heads' two hidden layers, where the saved
+# MFMAs outweigh the transform passes at every level — per-layer A/B in profiles/r06/wino4_layers.txt); the decision never looks at the
+# batch, so a crop's result does not depend on the batch it is in (test_full_size_forward_is_batch_independent).
 WINOGRAD4 = os.environ.get("PP_WINOGRAD4", "1") != "0"
-WINOGRAD4_MIN_PIXELS = int(os.environ.get("PP_WINOGRAD4_MIN_PIXELS", str(128 * 1024)))
-WINOGRAD4_MIN_CIN = int(os.environ.get("PP_WINOGRAD4_MIN_CIN", "512"))
-WINOGRAD4_MIN_COUT = int(os.environ.get("PP_WINOGRAD4_MIN_COUT", "256"))
 WINO4_GROUPS_PER_LAUNCH = 36
 WINO4_U_SCALE = 1.0 / 16.0        # operand scale of U = B^T d B (|U| <= 100 |d|): alpha = PP_A_SCALE / WINO4_U_SCALE = 64 undoes it
 
@@ -730,9 +729,13 @@ class WinoInput4:
 
 def _winograd4_ok(B, H, W, cin, cout):
     P = B * (H // 4) * (W // 4)
-    return (PRECISION == "f16x3" and WINOGRAD4 and H % 4 == 0 and W % 4 == 0 and P % 256 == 0 and cin % 8 == 0 and cout % 8 == 0
-            and cin >= WINOGRAD4_MIN_CIN and cout >= WINOGRAD4_MIN_COUT and B * H * W >= WINOGRAD4_MIN_PIXELS
-            and 36 * P < 2 ** 31 and not torch.is_grad_enabled())
+    return (PRECISION == "f16x3" and WINOGRAD4 and H % 4 == 0 and W % 4 == 0 and cin % 8 == 0 and cout % 8 == 0
+            and 36 * (P + 255) < 2 ** 31 and not torch.is_grad_enabled())
+
+
+def _wino4_rows(P):
+    """Rows of one frequency block: P tiles rounded up to the engine's row tile (a row tile of the grouped launch lies inside one block)."""
+    return -(-P // 256) * 256
 
 
 def winograd4_weight(wp, cin):
@@ -755,8 +758,10 @@ def winograd4_weight(wp, cin):
 
 def _winograd4_input(src_ptr, ld_x, B, H, W, cin, dev):
     P = B * (H // 4) * (W // 4)
-    U = Split(torch.empty(36 * P, 2 * cin, dtype=torch.float16, device=dev), 2)
-    _lib.check(_lib.lib().pp_winograd4_input_hl(src_ptr, ld_x, H * W * ld_x, B, H, W, cin, 0, _p(U.hl), _lib.stream_ptr()), "pp_winograd4_input_hl")
+    Pp = _wino4_rows(P)
+    # (pad rows: zeros, so that the products of the pad rows are finite — they are never read)
+    U = Split((torch.empty if Pp == P else torch.zeros)(36 * Pp, 2 * cin, dtype=torch.float16, device=dev), 2)
+    _lib.check(_lib.lib().pp_winograd4_input_hl(src_ptr, ld_x, H * W * ld_x, B, H, W, cin, 0, _p(U.hl), Pp, _lib.stream_ptr()), "pp_winograd4_input_hl")
     _chk(U.hl, "pp_winograd4_input_hl")
     return U
 
@@ -776,13 +781,15 @@ def _conv3x3_winograd4(x, wp, bias, B, H, W, cin, Cout, act, residual, residual2
     else:
         U = _winograd4_input(x.hl.data_ptr(), x.shape[1], B, H, W, cin, x.device)
     dev = U.device
-    Y = torch.empty(36, P, Cout, dtype=torch.float32, device=dev)
-    per = max(1, min(WINO4_GROUPS_PER_LAUNCH, 0xF0000000 // (4 * P * max(cin, Cout))))   # groups per launch: operand / result blocks inside 32-bit byte offsets
+    Pp = _wino4_rows(P)
+    assert U.hl.shape[0] == 36 * Pp
+    Y = torch.empty(36, Pp, Cout, dtype=torch.float32, device=dev)
+    per = max(1, min(WINO4_GROUPS_PER_LAUNCH, 0xF0000000 // (4 * Pp * max(cin, Cout))))   # groups per launch: operand / result blocks inside 32-bit byte offsets
     for x0 in range(0, 36, per):
         n = min(per, 36 - x0)
-        _run(_desc(A_hl=U.hl.data_ptr() + x0 * P * cin * 4, B=_p(V), B_hl=vhl.data_ptr() + x0 * Cout * cin * 4, b_scale=vscale, C=_p(Y[x0]),
-                   M=P, N=Cout, K=cin, lda=cin, ldb=cin, ldc=Cout, prec=_PREC["f16x3"], batch0=n, a_bs0=P * cin, b_bs0=Cout * cin,
-                   c_bs0=P * Cout, alpha=PP_A_SCALE / WINO4_U_SCALE, _keep=(U, vhl, V)))
+        _run(_desc(A_hl=U.hl.data_ptr() + x0 * Pp * cin * 4, B=_p(V), B_hl=vhl.data_ptr() + x0 * Cout * cin * 4, b_scale=vscale, C=_p(Y[x0]),
+                   M=Pp, N=Cout, K=cin, lda=cin, ldb=cin, ldc=Cout, prec=_PREC["f16x3"], batch0=n, a_bs0=Pp * cin, b_bs0=Cout * cin,
+                   c_bs0=Pp * Cout, alpha=PP_A_SCALE / WINO4_U_SCALE, _keep=(U, vhl, V)))
     ret, hl_t, ldc = None, None, 0
     if out_split and out is None and residual is None and residual2 is None:
         hl_t = Split.empty(B * H * W, Cout, dev)
@@ -803,7 +810,7 @@ def _conv3x3_winograd4(x, wp, bias, B, H, W, cin, Cout, act, residual, residual2
             c_relu = int(also_split == "relu")
             setattr(out, "_hl_relu" if also_split == "relu" else "_hl", hl_t)
     _lib.check(L.pp_winograd4_output(_p(Y), B, H, W, Cout, _p(bias), ACT[act], _p(residual), _p(residual2), _p(out), ldc,
-                                     _p(hl_t.hl) if hl_t is not None else None, Cout, c_relu, _lib.stream_ptr()), "pp_winograd4_output")
+                                     _p(hl_t.hl) if hl_t is not None else None, Cout, c_relu, Pp, _lib.stream_ptr()), "pp_winograd4_output")
     if hl_t is not None:
         _chk(hl_t.hl, "pp_winograd4_output")
     return ret

@@ -363,6 +363,7 @@ def test_fp32_batch_as_one_grouped_launch_equals_the_products_one_by_one(nb, M, 
 
 @gpu
 @pytest.mark.parametrize("B,cin,cout,hw", [(3, 64, 96, 32), (2, 640, 512, 16), (1, 256, 126, 64), (5, 32, 32, 8)])
+@torch.no_grad()      # (the Winograd paths serve inference: ops._winograd_ok / _winograd4_ok are off under autograd)
 def test_winograd_3x3_of_the_strict_fp32_mode(monkeypatch, engine_precision, B, cin, cout, hw):
     """ops.PRECISION = "f32": the large 3x3 / stride 1 / pad 1 convolutions run as Winograd F(2x2, 3x3) (csrc/pp_winograd.hip: input
     transform, 16 dense fp32 products on the engine, output transform) — against float64 torch and against the direct implicit-GEMM
@@ -403,6 +404,7 @@ def test_winograd_3x3_of_the_strict_fp32_mode(monkeypatch, engine_precision, B, 
         ref = ref.permute(0, 2, 3, 1)
         scale = float(ref.abs().max())
         e_w, e_d = float((got.cpu().double() - ref).abs().max()) / scale, float((direct.cpu().double() - ref).abs().max()) / scale
+        assert not torch.equal(got, direct), "the Winograd path did not run"
         assert e_w <= max(3 * e_d, 2e-6), (e_w, e_d)
         assert e_w <= 2e-5
     # a channel-slice output of a wider NHWC buffer
@@ -415,7 +417,8 @@ def test_winograd_3x3_of_the_strict_fp32_mode(monkeypatch, engine_precision, B, 
 
 
 @gpu
-@pytest.mark.parametrize("B,cin,cout,hw", [(16, 64, 64, 16), (4, 640, 512, 32), (1, 512, 256, 64), (64, 32, 40, 8)])
+@pytest.mark.parametrize("B,cin,cout,hw", [(16, 64, 64, 16), (4, 640, 512, 32), (1, 512, 256, 64), (64, 32, 40, 8), (3, 64, 48, 20)])
+@torch.no_grad()
 def test_winograd4_3x3_of_the_f16x3_engine(monkeypatch, engine_precision, B, cin, cout, hw):
     """ops.PRECISION = "f16x3": wide 3x3 / stride 1 / pad 1 convolutions on an operand image run as Winograd F(4x4, 3x3)
     (csrc/pp_winograd.hip: operand -> operand input transform, 36 dense products on the pre-split engine as grouped launches, output
@@ -427,8 +430,6 @@ def test_winograd4_3x3_of_the_f16x3_engine(monkeypatch, engine_precision, B, cin
         pytest.skip("F(4x4, 3x3) serves ops.PRECISION = 'f16x3'")
     from picopose_amd import ops
 
-    for k in ("WINOGRAD4_MIN_PIXELS", "WINOGRAD4_MIN_CIN", "WINOGRAD4_MIN_COUT"):
-        monkeypatch.setattr(ops, k, 0)
     monkeypatch.setattr(ops, "CHECK_SATURATION", True)
     g = torch.Generator().manual_seed(B * 1000 + cin + cout)
     x = torch.randn(B, hw, hw, cin, generator=g) * 3.0
@@ -459,10 +460,10 @@ def test_winograd4_3x3_of_the_f16x3_engine(monkeypatch, engine_precision, B, cin
 
     ref_plain = F.conv2d(xd, wd, b.double(), padding=1)
     cases = [
-        (lambda: ops.conv2d(xs, wp, b.cuda(), 3, pad=1, act="relu", out_split=True, split_relu=True), F.relu(ref_plain)),
-        (lambda: ops.conv2d(xs, wp, b.cuda(), 3, pad=1, act="leaky01", residual=r1.cuda(), residual2=r2.cuda()),
+        (lambda: ops.conv2d(xs, wp, b.cuda(), 3, pad=1, act="relu", out_split=True, split_relu=True, wino=True), F.relu(ref_plain)),
+        (lambda: ops.conv2d(xs, wp, b.cuda(), 3, pad=1, act="leaky01", residual=r1.cuda(), residual2=r2.cuda(), wino=True),
          F.leaky_relu(ref_plain, 0.1) + r1.permute(0, 3, 1, 2).double() + r2.permute(0, 3, 1, 2).double()),
-        (lambda: ops.conv2d(wide_s, wp, None, 3, pad=1, in_cols=(8, cin)), F.conv2d(xd, wd, None, padding=1)),
+        (lambda: ops.conv2d(wide_s, wp, None, 3, pad=1, in_cols=(8, cin), wino=True), F.conv2d(xd, wd, None, padding=1)),
     ]
     for fn, ref in cases:
         got, direct = both(fn)
@@ -471,8 +472,9 @@ def test_winograd4_3x3_of_the_f16x3_engine(monkeypatch, engine_precision, B, cin
         e_w, e_d = float((as_f32(got) - ref).abs().max()) / scale, float((as_f32(direct) - ref).abs().max()) / scale
         assert e_d <= 4e-6, e_d
         assert e_w <= 4e-5, (e_w, e_d)
+        assert float((as_f32(got) - as_f32(direct)).abs().max()) > 0, "the Winograd path did not run"
     # fp32 output that also carries its relu'd operand form
-    o = ops.conv2d(xs, wp, b.cuda(), 3, pad=1, also_split="relu")
+    o = ops.conv2d(xs, wp, b.cuda(), 3, pad=1, also_split="relu", wino=True)
     ref = ref_plain.permute(0, 2, 3, 1)
     assert float((o.cpu().double() - ref).abs().max()) <= 4e-5 * float(ref.abs().max())
     assert float((as_f32(o._hl_relu) - F.relu(ref)).abs().max()) <= 4e-5 * float(ref.abs().max())
@@ -481,11 +483,15 @@ def test_winograd4_3x3_of_the_f16x3_engine(monkeypatch, engine_precision, B, cin
     sh = ops.winograd_shared(xs, cout=cout)
     assert isinstance(sh, ops.WinoInput4)
     for wq in (wp, w2p):
-        assert torch.equal(ops.conv2d(sh, wq, b.cuda(), 3, pad=1, act="relu"), ops.conv2d(xs, wq, b.cuda(), 3, pad=1, act="relu"))
+        assert torch.equal(ops.conv2d(sh, wq, b.cuda(), 3, pad=1, act="relu"), ops.conv2d(xs, wq, b.cuda(), 3, pad=1, act="relu", wino=True))
     # a grouped launch cut into several (32-bit byte offsets of the stacked blocks): the same bits
-    one = ops.conv2d(xs, wp, b.cuda(), 3, pad=1)
+    one = ops.conv2d(xs, wp, b.cuda(), 3, pad=1, wino=True)
     monkeypatch.setattr(ops, "WINO4_GROUPS_PER_LAUNCH", 7)
-    assert torch.equal(ops.conv2d(xs, wp, b.cuda(), 3, pad=1), one)
+    assert torch.equal(ops.conv2d(xs, wp, b.cuda(), 3, pad=1, wino=True), one)
+    # the result of a crop does not depend on the batch it is in (other row-tile counts, other pad rows)
+    if B > 1:
+        xs1 = ops.split_image(x[B - 1:].cuda())
+        assert torch.equal(ops.conv2d(xs1, wp, b.cuda(), 3, pad=1, wino=True), one[B - 1:])
 
 
 @gpu

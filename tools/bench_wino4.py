@@ -39,8 +39,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
-    for k in ("WINOGRAD4_MIN_PIXELS", "WINOGRAD4_MIN_CIN", "WINOGRAD4_MIN_COUT"):
-        setattr(ops, k, 0)
     g = torch.Generator().manual_seed(0)
     print(f"{'layer':22s} {'direct ms':>10s} {'wino4 ms':>9s} {'in-tx':>7s} {'gemm':>7s} {'out-tx':>7s} {'TF/s direct':>11s} {'TF/s gemm':>9s}  max|diff|/max")
     for name, B, hw, cin, cout in LAYERS:
@@ -49,7 +47,7 @@ def main():
         del x
         wp = ops.pack_conv_weight((torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).cuda())
         bias = torch.randn(cout, generator=g).cuda()
-        run = lambda: ops.conv2d(xs, wp, bias, 3, pad=1, act="relu", out_split=True)  # noqa: E731
+        run = lambda: ops.conv2d(xs, wp, bias, 3, pad=1, act="relu", out_split=True, wino=True)  # noqa: E731
         ops.WINOGRAD4 = False
         d = run()
         t_d = timed(run, a.reps)
@@ -66,7 +64,7 @@ def main():
         hl_t = ops.Split.empty(B * hw * hw, cout, xs.device)
         from picopose_amd import _lib
         t_out = timed(lambda: _lib.check(_lib.lib().pp_winograd4_output(Y.data_ptr(), B, hw, hw, cout, bias.data_ptr(), 1, None, None, None, 0,
-                                                                         hl_t.hl.data_ptr(), cout, 0, _lib.stream_ptr()), "out"), a.reps)
+                                                                         hl_t.hl.data_ptr(), cout, 0, P, _lib.stream_ptr()), "out"), a.reps)
         t_g = t_shared - t_out
         fl = 2.0 * B * hw * hw * cout * 9 * cin
         print(f"{name:22s} {t_d:10.3f} {t_w:9.3f} {t_in:7.3f} {t_g:7.3f} {t_out:7.3f} {fl / t_d / 1e9:11.1f} {fl / 4 / t_g / 1e9:9.1f}  {diff:.1e}", flush=True)
@@ -75,4 +73,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    with torch.no_grad():
+        main()
