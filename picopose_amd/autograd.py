@@ -905,12 +905,19 @@ def _rcu(u, x, extra=None):
 def dpt_head_forward(dpt, feats):
     """DPTHead.forward (dpt.py:252-272) in training mode under autograd: feats = 4 NHWC maps (B,16,16,C) -> [path_4, path_3, path_2]."""
     r, s = dpt.resize_layers, dpt.scratch
-    x = [conv2d(f, dpt.projects[i].weight, dpt.projects[i].bias, 1) for i, f in enumerate(feats)]
-    l1 = _ConvTranspose.apply(x[0], getattr(r, "0").weight, getattr(r, "0").bias, 4)
+    from .model.stage3 import COMPUTE_DEAD_LAYER1
+
+    # (layer_1 / layer_1_rn: only the SHAPE of layer_1_rn is read — dpt.py:263, 270 — and no gradient reaches projects[0], resize_layers[0]
+    # or layer1_rn in the reference either (their .grad stays None): not computed, see DPTHead.forward_nhwc)
+    x = {i: conv2d(feats[i], dpt.projects[i].weight, dpt.projects[i].bias, 1) for i in (range(4) if COMPUTE_DEAD_LAYER1 else range(1, 4))}
+    size1 = (4 * feats[0].shape[1], 4 * feats[0].shape[2])
     l2 = _ConvTranspose.apply(x[1], getattr(r, "1").weight, getattr(r, "1").bias, 2)
     l3 = x[2]
     l4 = conv2d(x[3], getattr(r, "3").weight, getattr(r, "3").bias, 3, stride=2, pad=1)
-    rn = [conv2d(l, getattr(s, f"layer{i + 1}_rn").weight, None, 3, pad=1) for i, l in enumerate((l1, l2, l3, l4))]
+    rn = {i: conv2d(l, getattr(s, f"layer{i + 1}_rn").weight, None, 3, pad=1) for i, l in ((1, l2), (2, l3), (3, l4))}
+    if COMPUTE_DEAD_LAYER1:
+        l1 = _ConvTranspose.apply(x[0], getattr(r, "0").weight, getattr(r, "0").bias, 4)
+        rn[0] = conv2d(l1, s.layer1_rn.weight, None, 3, pad=1)
 
     def fuse(i, size, x0, x1=None):
         f = getattr(s, f"refinenet{i}")
@@ -921,7 +928,7 @@ def dpt_head_forward(dpt, feats):
 
     p4 = fuse(4, rn[2].shape[1:3], rn[3])
     p3 = fuse(3, rn[1].shape[1:3], p4, rn[2])
-    p2 = fuse(2, rn[0].shape[1:3], p3, rn[1])
+    p2 = fuse(2, size1, p3, rn[1])
     dpt.bn_moved()
     return [p4, p3, p2]
 

@@ -225,6 +225,31 @@ __device__ __forceinline__ void wino_note_sat(bool clamp, unsigned* sat) {
     if (sat && __builtin_amdgcn_ballot_w64(clamp) != 0ull && (threadIdx.x & 63) == 0) atomicOr(sat, 1u);
 }
 
+// Lane pairs.  A thread owns 4 channels, an hl group is [8 hi | 8 lo] (32 bytes): lanes 2k / 2k + 1 own channels 0-3 / 4-7 of the SAME group
+// (C % 8 == 0 puts them in one tile).  Instead of two 8-byte accesses per lane (hi[0:4] and lo[0:4], resp. hi[4:8] and lo[4:8]) the even lane
+// moves the 16 bytes of the hi terms and the odd lane the 16 bytes of the lo terms, and the pair trades halves with one DPP quad-permute per
+// dword: half the vector-memory instructions (measured: input transform 3.0 -> TB/s of FETCH + WRITE, profiles/r06/wino4_layers.txt).
+typedef unsigned int wu4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned wino_swap(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }   // lanes 2k <-> 2k + 1
+__device__ __forceinline__ float wino_h2f(unsigned w, int hi16) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(hi16 ? w >> 16 : w & 0xFFFFu)); }
+
+// the lane's 4 channels of the group at `grp` (half index of the group's first hi term) as 4 x = hi + lo (exact)
+__device__ __forceinline__ f4 wino_pair_load(const _Float16* grp, int par) {
+    const wu4 q = *(const wu4*)(grp + par * 8);            // even lane: hi[0:8], odd lane: lo[0:8]
+    const unsigned k0 = par ? q[2] : q[0], k1 = par ? q[3] : q[1];     // own half: hi[0:4] (even) / lo[4:8] (odd)
+    const unsigned r0 = wino_swap(par ? q[0] : q[2]), r1 = wino_swap(par ? q[1] : q[3]);   // the partner's: lo[0:4] / hi[4:8]
+    return f4{wino_h2f(k0, 0) + wino_h2f(r0, 0), wino_h2f(k0, 1) + wino_h2f(r0, 1), wino_h2f(k1, 0) + wino_h2f(r1, 0), wino_h2f(k1, 1) + wino_h2f(r1, 1)};
+}
+
+// store the lane's 4 channels (hi / lo terms) into the group at `grp`: the even lane writes hi[0:8], the odd lane lo[0:8]
+__device__ __forceinline__ void wino_pair_store(_Float16* grp, int par, hf4 hi, hf4 lo) {
+    const unsigned H0 = __builtin_bit_cast(unsigned, __builtin_shufflevector(hi, hi, 0, 1)), H1 = __builtin_bit_cast(unsigned, __builtin_shufflevector(hi, hi, 2, 3));
+    const unsigned L0 = __builtin_bit_cast(unsigned, __builtin_shufflevector(lo, lo, 0, 1)), L1 = __builtin_bit_cast(unsigned, __builtin_shufflevector(lo, lo, 2, 3));
+    const unsigned r0 = wino_swap(par ? H0 : L0), r1 = wino_swap(par ? H1 : L1);    // even receives the partner's hi[4:8], odd the partner's lo[0:4]
+    const wu4 w = {par ? r0 : H0, par ? r1 : H1, par ? L0 : r0, par ? L1 : r1};
+    *(wu4*)(grp + par * 8) = w;
+}
+
 // one thread = one 6x6 tile x 4 consecutive channels; tiles row-major over (B, H/4, W/4)
 __global__ __launch_bounds__(256) void wino4_input_kernel(const _Float16* __restrict__ x, int ld_x, long long bstride, int B, int H, int W, int C,
                                                           int relu, _Float16* __restrict__ U, long long Pp, unsigned* sat) {
@@ -237,7 +262,8 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const _Float16* __rest
     const int c = (int)(i - p * c4n) * 4;
     const int b = (int)(p / ((long long)th * tw)), r = (int)(p - (long long)b * th * tw), ty = r / tw, tx = r - ty * tw;
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
-    const int gcol = ((c >> 3) << 4) + (c & 7);     // half index of (c, hi) inside an hl row
+    const int gcol = (c >> 3) << 4;                 // half index of the channel group (c & ~7, hi) inside an hl row
+    const int par = (c >> 2) & 1;                   // = lane parity (c4n is even): which half of the group's channels this lane owns
     const _Float16* img = x + b * bstride * 2;
     f4 t[6][6];   // t = B^T d, built column by column
 #pragma unroll
@@ -248,12 +274,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const _Float16* __rest
         for (int dy = 0; dy < 6; ++dy) {
             const int iy = y0 + dy;
             f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                const _Float16* src = img + ((long long)iy * W + ix) * 2 * ld_x + gcol;
-                const hf4 hi = *(const hf4*)src, lo = *(const hf4*)(src + 8);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (float)hi[e] + (float)lo[e];     // = 4 x, exactly
-            }
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = wino_pair_load(img + ((long long)iy * W + ix) * 2 * ld_x + gcol, par);   // = 4 x, exactly
             if (relu) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -273,9 +294,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const _Float16* __rest
         for (int bb = 0; bb < 6; ++bb) {
             hf4 hi, lo;
             clamp |= wino_split4(u[bb] * (1.f / 64.f), hi, lo);       // (the 4 x of the source operand) / 64 = (B^T d B) / 16
-            _Float16* o = dst + (long long)(6 * a + bb) * xi_stride;
-            *(hf4*)o = hi;
-            *(hf4*)(o + 8) = lo;
+            wino_pair_store(dst + (long long)(6 * a + bb) * xi_stride, par, hi, lo);
         }
     }
     wino_note_sat(clamp, sat);
@@ -353,7 +372,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     const f4 bv = bias ? *(const f4*)(bias + c) : f4{0.f, 0.f, 0.f, 0.f};
     const float slope = act == PP_ACT_RELU ? 0.f : (act == PP_ACT_LEAKY01 ? 0.1f : 1.f);
     const float hfloor = c_relu ? 0.f : -INFINITY;
-    const int gcol = ((c >> 3) << 4) + (c & 7);
+    const int gcol = (c >> 3) << 4, par = (c >> 2) & 1;     // (operand output: Cout % 8 == 0, lanes 2k / 2k + 1 share a group)
     bool clamp = false;
 #pragma unroll
     for (int oy = 0; oy < 4; ++oy) {
@@ -378,9 +397,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x4[e] = fmaxf(v[e] * PP_A_SCALE, hfloor);
                 clamp |= wino_split4(x4, hi, lo);
-                _Float16* o2 = out_hl + row * 2 * ld_h + gcol;
-                *(hf4*)o2 = hi;
-                *(hf4*)(o2 + 8) = lo;
+                wino_pair_store(out_hl + row * 2 * ld_h + gcol, par, hi, lo);
             }
         }
     }

@@ -15,6 +15,9 @@ from .common import Holder, Packed, bn_p, conv_p, convT_p, fold_bn, seq
 
 
 # ------------------------------------------------------------------------------------------ DPT head
+COMPUTE_DEAD_LAYER1 = os.environ.get("PP_DPT_DEAD_LAYER1", "0") == "1"    # see DPTHead.forward_nhwc
+
+
 def _rcu(c):
     m = Holder()
     m.conv1, m.conv2 = conv_p(c, c, 3), conv_p(c, c, 3)
@@ -114,16 +117,26 @@ class DPTHead(Packed):
         pk, r = self.packed(for_training=train), self.resize_layers
         # (the projected maps feed only their resize layer, the resized maps only their layerK_rn convolution: operand-only
         # outputs on the f16x3 engine — no fp32 store, no split pass)
-        x = [ops.conv2d(f, pk[f"proj{i}"], self.projects[i].bias, 1, out_split=True) for i, f in enumerate(feats)]
-        l1 = ops.conv_transpose2d(x[0], pk["up0"], pk["up0_b"], 4, out_split=True)
+        # The reference computes layer_1 = resize_layers[0](projects[0](.)) and layer_1_rn = layer1_rn(layer_1) but reads only the SHAPE of
+        # layer_1_rn (dpt.py:263, 270; refinenet1, its one consumer, is commented out at :271): three layers — 0.93 TFLOP of the 3x3
+        # convolution at 64 x 64 x 192 images — whose values reach no output, no loss and no BatchNorm buffer.  They are not computed
+        # (COMPUTE_DEAD_LAYER1 = True runs them anyway: the bench's A/B, test_dead_layer1_branch_does_not_reach_any_output).
+        live = range(4) if COMPUTE_DEAD_LAYER1 else range(1, 4)
+        x = {i: ops.conv2d(feats[i], pk[f"proj{i}"], self.projects[i].bias, 1, out_split=True) for i in live}
+        B0, H0, W0, _ = feats[0].shape
+        size1 = (4 * H0, 4 * W0)                               # layer_1_rn.shape[2:]: ConvTranspose2d(kernel = stride = 4), then 3x3 / pad 1
         l2 = ops.conv_transpose2d(x[1], pk["up1"], pk["up1_b"], 2, out_split=True)
         l3 = x[2]
         l4 = ops.conv2d(x[3], pk["down3"], getattr(r, "3").bias, 3, stride=2, pad=1, out_split=True)
         # every layerK_rn output is the input of a ResidualConvUnit (fp32 for its skip, relu'd operand for its conv1)
-        rn = [ops.conv2d(l, pk[f"rn{i + 1}"], None, 3, pad=1, also_split="relu") for i, l in enumerate((l1, l2, l3, l4))]
+        rn = {i: ops.conv2d(l, pk[f"rn{i + 1}"], None, 3, pad=1, also_split="relu") for i, l in ((1, l2), (2, l3), (3, l4))}
+        if COMPUTE_DEAD_LAYER1:
+            l1 = ops.conv_transpose2d(x[0], pk["up0"], pk["up0_b"], 4, out_split=True)
+            rn[0] = ops.conv2d(l1, pk["rn1"], None, 3, pad=1, also_split="relu")
+            assert tuple(rn[0].shape[1:3]) == size1
         p4 = self._fuse(pk, 4, rn[2].shape[1:3], rn[3], train=train)
         p3 = self._fuse(pk, 3, rn[1].shape[1:3], p4, rn[2], train)
-        p2 = self._fuse(pk, 2, rn[0].shape[1:3], p3, rn[1], train)
+        p2 = self._fuse(pk, 2, size1, p3, rn[1], train)
         if train:
             self.bn_moved()              # eval re-folds the running buffers on its next call
         return [p4, p3, p2]

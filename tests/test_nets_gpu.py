@@ -131,6 +131,36 @@ def test_offset_regressor_vs_reference_golden(golden_dir):
 
 
 @gpu
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_dead_layer1_branch_does_not_reach_any_output(golden_dir, monkeypatch, precision):
+    """dpt.py:252-272 computes layer_1 = resize_layers[0](projects[0](x0)) and layer_1_rn = layer1_rn(layer_1) but reads only
+    `layer_1_rn.shape[2:]` (refinenet1 is commented out): the build does not compute the three layers.  With them computed
+    (stage3.COMPUTE_DEAD_LAYER1) every output is bit for bit the same — and the same as with their weights replaced by NaN."""
+    from picopose_amd import ops
+    from picopose_amd.model import stage3
+
+    z, t = _golden(golden_dir)
+    monkeypatch.setattr(ops, "PRECISION", precision)
+    outs = []
+    for dead, poison in ((False, False), (True, False), (False, True)):
+        monkeypatch.setattr(stage3, "COMPUTE_DEAD_LAYER1", dead)
+        orr = stage3.OffsetRegressor(small_cfg().stage3)
+        sd = seeded_state_dict(orr.state_dict(), int(z["s3/seed"]))
+        if poison:
+            for k in sd:
+                if k.startswith(("dpt_head.projects.0.", "dpt_head.resize_layers.0.", "dpt_head.scratch.layer1_rn.")):
+                    sd[k] = torch.full_like(sd[k], float("nan"))
+        orr.load_state_dict(sd)
+        orr = orr.cuda().eval()
+        ft, fr = [t[f"s3/ft{i}"] for i in range(4)], [t[f"s3/fr{i}"] for i in range(4)]
+        fl, ce = orr(ft, fr, t["s3/init_flow"], t["s3/init_cert"])
+        outs.append([x.cpu() for x in orr.dpt_head(ft) + fl + ce])
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
+    assert all(torch.isfinite(a).all() for a in outs[0])
+
+
+@gpu
 @pytest.mark.parametrize("precision", ["f16x3", "f16"])
 def test_fused_xhead_first_layers_equal_two_launches(golden_dir, monkeypatch, precision):
     """The flow and certainty heads' first layers (conv 3x3 640 -> 512 each, flow_decoder.py:58-72) run as ONE launch with the
