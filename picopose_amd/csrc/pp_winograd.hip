@@ -207,17 +207,18 @@ __device__ __forceinline__ long long wino_logical_block() {
         t5 = 4.f * d1 - 5.f * d3 + d5;                                    \
     }
 
-__device__ __forceinline__ bool wino_split4(f4 v, hf4& hi, hf4& lo) {
-    bool clamp = false;
+// split 4 values (already in operand scale) into their hi / lo fp16 terms; `top` keeps the running maximum of |v| — ONE v_max3 per two
+// elements instead of a clamp and a compare per element: a value beyond the fp16 range is converted to +-inf (wrong either way) and is
+// reported through the saturation word by the caller, which tests `top` once
+__device__ __forceinline__ void wino_split4(f4 v, hf4& hi, hf4& lo, float& top) {
+    top = fmaxf(fmaxf(top, fabsf(v[0])), fabsf(v[1]));
+    top = fmaxf(fmaxf(top, fabsf(v[2])), fabsf(v[3]));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float x = v[e];
-        clamp |= !(fabsf(x) < 65504.f);
-        const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+        const _Float16 h = (_Float16)v[e];
         hi[e] = h;
-        lo[e] = (_Float16)fminf(fmaxf(x - (float)h, -65504.f), 65504.f);
+        lo[e] = (_Float16)(v[e] - (float)h);        // |v - h| <= half an ulp of h
     }
-    return clamp;
 }
 
 // sticky saturation word (include/picopose_hip.h pp_set_saturation_word): one atomic per wave that saw a clamped term
@@ -233,12 +234,26 @@ typedef unsigned int wu4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned wino_swap(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }   // lanes 2k <-> 2k + 1
 __device__ __forceinline__ float wino_h2f(unsigned w, int hi16) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(hi16 ? w >> 16 : w & 0xFFFFu)); }
 
-// the lane's 4 channels of the group at `grp` (half index of the group's first hi term) as 4 x = hi + lo (exact)
-__device__ __forceinline__ f4 wino_pair_load(const _Float16* grp, int par) {
-    const wu4 q = *(const wu4*)(grp + par * 8);            // even lane: hi[0:8], odd lane: lo[0:8]
+// the lane's 4 channels out of the 16 bytes `q` it loaded from its group (even lane: hi[0:8], odd lane: lo[0:8]) and the partner's
+// 16 bytes, as 4 x = hi + lo (exact)
+__device__ __forceinline__ f4 wino_pair_unpack(wu4 q, int par) {
     const unsigned k0 = par ? q[2] : q[0], k1 = par ? q[3] : q[1];     // own half: hi[0:4] (even) / lo[4:8] (odd)
     const unsigned r0 = wino_swap(par ? q[0] : q[2]), r1 = wino_swap(par ? q[1] : q[3]);   // the partner's: lo[0:4] / hi[4:8]
     return f4{wino_h2f(k0, 0) + wino_h2f(r0, 0), wino_h2f(k0, 1) + wino_h2f(r0, 1), wino_h2f(k1, 0) + wino_h2f(r1, 0), wino_h2f(k1, 1) + wino_h2f(r1, 1)};
+}
+
+// the 16 bytes a lane stores for its pair's group: the even lane hi[0:8], the odd lane lo[0:8]
+__device__ __forceinline__ wu4 wino_pair_pack(int par, hf4 hi, hf4 lo) {
+    const unsigned H0 = __builtin_bit_cast(unsigned, __builtin_shufflevector(hi, hi, 0, 1)), H1 = __builtin_bit_cast(unsigned, __builtin_shufflevector(hi, hi, 2, 3));
+    const unsigned L0 = __builtin_bit_cast(unsigned, __builtin_shufflevector(lo, lo, 0, 1)), L1 = __builtin_bit_cast(unsigned, __builtin_shufflevector(lo, lo, 2, 3));
+    const unsigned r0 = wino_swap(par ? H0 : L0), r1 = wino_swap(par ? H1 : L1);    // even receives the partner's hi[4:8], odd the partner's lo[0:4]
+    return wu4{par ? r0 : H0, par ? r1 : H1, par ? L0 : r0, par ? L1 : r1};
+}
+
+// descriptor of frequency block xi of a (36, rows, ..) buffer: built from scalars next to its use (no 64-bit per-lane addresses: 36
+// of them cost 72 registers and hipcc spilled)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wino_block_rsrc(const void* base, int xi, unsigned long long block_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + (unsigned long long)xi * block_bytes), 0, (int)(unsigned)block_bytes, 0x00020000);
 }
 
 // store the lane's 4 channels (hi / lo terms) into the group at `grp`: the even lane writes hi[0:8], the odd lane lo[0:8]
@@ -250,9 +265,12 @@ __device__ __forceinline__ void wino_pair_store(_Float16* grp, int par, hf4 hi, 
     *(wu4*)(grp + par * 8) = w;
 }
 
-// one thread = one 6x6 tile x 4 consecutive channels; tiles row-major over (B, H/4, W/4)
-__global__ __launch_bounds__(256) void wino4_input_kernel(const _Float16* __restrict__ x, int ld_x, long long bstride, int B, int H, int W, int C,
-                                                          int relu, _Float16* __restrict__ U, long long Pp, unsigned* sat) {
+// one thread = one 6x6 tile x 4 consecutive channels; tiles row-major over (B, H/4, W/4).  The 36 loads of a tile are bounded buffer
+// loads issued back to back — a pixel outside the image is an out-of-range offset (zeros, no traffic, no branch): with a branch per
+// padded pixel hipcc waited for every load before the next one (39 s_waitcnt, 80 branches) and the kernel ran at 3.0 TB/s.
+template <bool RELU>
+__global__ __launch_bounds__(256, 2) void wino4_input_kernel(const _Float16* __restrict__ x, unsigned x_bytes, int ld_x, long long bstride, int B, int H,
+                                                             int W, int C, _Float16* __restrict__ U, long long Pp, unsigned* sat) {
     const int c4n = C >> 2;
     const int tw = W >> 2, th = H >> 2;
     const long long P = (long long)B * th * tw, total = P * c4n;
@@ -264,18 +282,32 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const _Float16* __rest
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
     const int gcol = (c >> 3) << 4;                 // half index of the channel group (c & ~7, hi) inside an hl row
     const int par = (c >> 2) & 1;                   // = lane parity (c4n is even): which half of the group's channels this lane owns
-    const _Float16* img = x + b * bstride * 2;
+    // address = base' + voffset (per lane: the tile's pixel (-1, -1), or out of range) + soffset (wave-uniform: (dy W + dx) pixels).  The
+    // range check reads voffset alone, so the base is moved back by one row + one pixel and every in-image voffset is >= 0.
+    const unsigned pix = (unsigned)ld_x * 4u;                                      // bytes per pixel row of the operand
+    const unsigned back = (unsigned)(W + 1) * pix;
+    const __amdgpu_buffer_rsrc_t R = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)x - back), 0, (int)(x_bytes + back), 0x00020000);
+    const unsigned v00 = (unsigned)((b * bstride * 2 + gcol + par * 8) * 2) + (unsigned)((y0 + 1) * W + x0 + 1) * pix;
+    bool rok[6], cok[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        rok[k] = (unsigned)(y0 + k) < (unsigned)H;
+        cok[k] = (unsigned)(x0 + k) < (unsigned)W;
+    }
+    wu4 q[6][6];
+#pragma unroll
+    for (int dx = 0; dx < 6; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 6; ++dy)
+            q[dy][dx] = __builtin_amdgcn_raw_buffer_load_b128(R, (rok[dy] && cok[dx]) ? v00 : 0xFFFFFFFFu, (dy * W + dx) * (int)pix, 0);
     f4 t[6][6];   // t = B^T d, built column by column
 #pragma unroll
     for (int dx = 0; dx < 6; ++dx) {
         f4 d[6];
-        const int ix = x0 + dx;
 #pragma unroll
         for (int dy = 0; dy < 6; ++dy) {
-            const int iy = y0 + dy;
-            f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = wino_pair_load(img + ((long long)iy * W + ix) * 2 * ld_x + gcol, par);   // = 4 x, exactly
-            if (relu) {
+            f4 v = wino_pair_unpack(q[dy][dx], par);       // = 4 x, exactly
+            if (RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
@@ -283,9 +315,9 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const _Float16* __rest
         }
         PP_W4_BT(d[0], d[1], d[2], d[3], d[4], d[5], t[0][dx], t[1][dx], t[2][dx], t[3][dx], t[4][dx], t[5][dx])
     }
-    bool clamp = false;
-    _Float16* dst = U + p * 2 * C + gcol;
-    const long long xi_stride = Pp * 2 * C;     // rows per frequency block: P rounded up to the engine's row tile
+    float top = 0.f;
+    const unsigned long long blk = (unsigned long long)Pp * C * 4;     // bytes of one frequency block (Pp = P rounded up to the engine's row tile)
+    const unsigned uoff = (unsigned)((p * 2 * C + gcol + par * 8) * 2);
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         f4 u[6];
@@ -293,11 +325,11 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const _Float16* __rest
 #pragma unroll
         for (int bb = 0; bb < 6; ++bb) {
             hf4 hi, lo;
-            clamp |= wino_split4(u[bb] * (1.f / 64.f), hi, lo);       // (the 4 x of the source operand) / 64 = (B^T d B) / 16
-            wino_pair_store(dst + (long long)(6 * a + bb) * xi_stride, par, hi, lo);
+            wino_split4(u[bb] * (1.f / 64.f), hi, lo, top);       // (the 4 x of the source operand) / 64 = (B^T d B) / 16
+            __builtin_amdgcn_raw_buffer_store_b128(wino_pair_pack(par, hi, lo), wino_block_rsrc(U, 6 * a + bb, blk), uoff, 0, 0);
         }
     }
-    wino_note_sat(clamp, sat);
+    wino_note_sat(!(top < 65504.f), sat);
 }
 
 // V_xi[co][ci] = (G g G^T)[a][b];  G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
@@ -359,21 +391,21 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     const long long p = i / cn;
     const int c = (int)(i - p * cn) * 4;
     const int b = (int)(p / ((long long)th * tw)), r = (int)(p - (long long)b * th * tw), ty = r / tw, tx = r - ty * tw;
-    const float* src = Y + p * Cout + c;
-    const long long xi_stride = Pp * Cout;
+    const unsigned long long blk = (unsigned long long)Pp * Cout * 4;
+    const unsigned yoff = (unsigned)((p * Cout + c) * 4);
     f4 z[4][6];   // z = A^T Y, column by column
 #pragma unroll
     for (int bb = 0; bb < 6; ++bb) {
         f4 y[6];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) y[a] = *(const f4*)(src + (long long)(6 * a + bb) * xi_stride);
+        for (int a = 0; a < 6; ++a) y[a] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wino_block_rsrc(Y, 6 * a + bb, blk), yoff, 0, 0));
         PP_W4_AT(y[0], y[1], y[2], y[3], y[4], y[5], z[0][bb], z[1][bb], z[2][bb], z[3][bb])
     }
     const f4 bv = bias ? *(const f4*)(bias + c) : f4{0.f, 0.f, 0.f, 0.f};
     const float slope = act == PP_ACT_RELU ? 0.f : (act == PP_ACT_LEAKY01 ? 0.1f : 1.f);
     const float hfloor = c_relu ? 0.f : -INFINITY;
     const int gcol = (c >> 3) << 4, par = (c >> 2) & 1;     // (operand output: Cout % 8 == 0, lanes 2k / 2k + 1 share a group)
-    bool clamp = false;
+    float top = 0.f;
 #pragma unroll
     for (int oy = 0; oy < 4; ++oy) {
         f4 o[4];
@@ -396,12 +428,12 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
                 f4 x4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x4[e] = fmaxf(v[e] * PP_A_SCALE, hfloor);
-                clamp |= wino_split4(x4, hi, lo);
+                wino_split4(x4, hi, lo, top);
                 wino_pair_store(out_hl + row * 2 * ld_h + gcol, par, hi, lo);
             }
         }
     }
-    wino_note_sat(clamp, sat);
+    wino_note_sat(!(top < 65504.f), sat);
 }
 
 static inline int grid8_of(long long n) {   // blocks of 256 threads, a multiple of 8 (wino_logical_block)
@@ -455,8 +487,15 @@ int pp_winograd4_input_hl(const void* x_hl, int ld_x, long long batch_stride, in
     if (((uintptr_t)x_hl & 15) || ((uintptr_t)U_hl & 15)) return PP_EINVAL;
     const long long total = (long long)B * (H / 4) * (W / 4) * (C / 4);
     if ((total + 255) / 256 + 8 >= (1LL << 31) || P_pad < (long long)B * (H / 4) * (W / 4)) return PP_EINVAL;
-    hipLaunchKernelGGL(wino4_input_kernel, dim3(grid8_of(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_hl, ld_x, batch_stride, B, H, W,
-                       C, relu, (_Float16*)U_hl, P_pad, pp_saturation_word());
+    // extent of the operand from x_hl on (32-bit byte offsets of the bounded loads; 0xFFFFFFFF is the "reads zero" offset)
+    const long long x_bytes = ((long long)(B - 1) * batch_stride + (long long)(H * W - 1) * ld_x + C) * 4;
+    if (x_bytes + (long long)(W + 1) * ld_x * 4 >= 0xFFFFFF00LL || P_pad * C * 4 >= 0xFFFFFF00LL) return PP_EINVAL;
+    if (relu)
+        hipLaunchKernelGGL(wino4_input_kernel<true>, dim3(grid8_of(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_hl, (unsigned)x_bytes,
+                           ld_x, batch_stride, B, H, W, C, (_Float16*)U_hl, P_pad, pp_saturation_word());
+    else
+        hipLaunchKernelGGL(wino4_input_kernel<false>, dim3(grid8_of(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_hl, (unsigned)x_bytes,
+                           ld_x, batch_stride, B, H, W, C, (_Float16*)U_hl, P_pad, pp_saturation_word());
     return pp_last_launch();
 }
 
@@ -469,7 +508,7 @@ int pp_winograd4_weight_f32(const float* w, int Cout, int Cin, int ldw, float* V
 
 int pp_winograd4_output(const float* Y, int B, int H, int W, int Cout, const float* bias, int act, const float* residual, const float* residual2,
                         float* out, int ldc, void* out_hl, int ld_h, int c_relu, long long P_pad, void* stream) {
-    if (P_pad < (long long)B * (H / 4) * (W / 4)) return PP_EINVAL;
+    if (P_pad < (long long)B * (H / 4) * (W / 4) || P_pad * Cout * 4 >= 0xFFFFFF00LL) return PP_EINVAL;
     if (!Y || (!out && !out_hl) || B <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3) || Cout <= 0 || (Cout & 3)) return PP_EINVAL;
     if (act != PP_ACT_NONE && act != PP_ACT_RELU && act != PP_ACT_LEAKY01) return PP_EINVAL;
     if (out && (ldc < Cout || (ldc & 3))) return PP_EINVAL;

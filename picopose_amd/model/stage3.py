@@ -129,7 +129,9 @@ class DPTHead(Packed):
         l3 = x[2]
         l4 = ops.conv2d(x[3], pk["down3"], getattr(r, "3").bias, 3, stride=2, pad=1, out_split=True)
         # every layerK_rn output is the input of a ResidualConvUnit (fp32 for its skip, relu'd operand for its conv1)
-        rn = {i: ops.conv2d(l, pk[f"rn{i + 1}"], None, 3, pad=1, also_split="relu") for i, l in ((1, l2), (2, l3), (3, l4))}
+        # (layer2_rn 512 -> 256 at 32 x 32 and layer3_rn 1024 -> 256 at 16 x 16: wide enough for F(4x4, 3x3) to pay — 0.93 -> 0.76 ms and
+        # 0.54 -> 0.36 ms at 192 images, profiles/r06/wino4_layers.txt)
+        rn = {i: ops.conv2d(l, pk[f"rn{i + 1}"], None, 3, pad=1, also_split="relu", wino=i in (1, 2)) for i, l in ((1, l2), (2, l3), (3, l4))}
         if COMPUTE_DEAD_LAYER1:
             l1 = ops.conv_transpose2d(x[0], pk["up0"], pk["up0_b"], 4, out_split=True)
             rn[0] = ops.conv2d(l1, pk["rn1"], None, 3, pad=1, also_split="relu")
