@@ -424,6 +424,18 @@ def batch_plan(workload_crops, world, scaling="weak", global_batch=None):
     return workload_crops * world, workload_crops, "weak"
 
 
+def sharded_leg_plan(workload_crops, n_templates, world, rank):
+    """The default N > 1 run's SHARDED leg = BASELINE configs[3] as written: the workload's crops as the GLOBAL batch, cut evenly over the
+    ranks, and the template feature bank cut along the template axis (picopose_amd.dist.shard_bounds).  Returns (crops of this rank,
+    first template, one past the last) or None when the ranks do not divide the batch (the leg is skipped and the line says so)."""
+    from picopose_amd.dist import shard_bounds
+
+    if world < 2 or workload_crops % world != 0 or n_templates < world:
+        return None
+    lo, hi = shard_bounds(n_templates, world, rank)
+    return workload_crops // world, lo, hi
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` from a plain shell: run the N ranks as a child torch.distributed.run job (nothing in
     this process has touched the GPU) and hand back its return code; rank 0 of the child prints the JSON line."""
@@ -470,6 +482,12 @@ def main():
                     help="8-GPU preflight on ONE GPU in ONE process: run rank 0's share of a --scaling strong job of this many ranks "
                          "(its crops, its template slice, every launch at the real shard shapes) with the collectives replaced by local "
                          "copies of the same sizes; reports phases_ms and the rank's peak memory.  Not a measurement of the exchange.")
+    ap.add_argument("--single-batch", action="store_true",
+                    help="every timed step runs the SAME input batch (rounds 1-5); default: two distinct synthetic batches alternate, so the look-ahead "
+                         "(the next batch's query crops inside this batch's template-side ViT pass) prefetches a batch that really differs")
+    ap.add_argument("--no-sharded-leg", action="store_true",
+                    help="N > 1, default (weak) run: skip the extra leg that runs BASELINE configs[3] — global batch = the workload's crops, "
+                         "template-sharded bank, all-gathers over RCCL — after the timed region")
     ap.add_argument("--no-prefetch-query", dest="prefetch_query", action="store_false",
                     help="the query ViT of every batch as its own pass (rounds 1-4) instead of inside the previous batch's template-side pass")
     ap.add_argument("--graph", action="store_true",
@@ -563,6 +581,7 @@ def main():
 
     from picopose_amd import _lib, ops
     from picopose_amd.dist import shard_bounds, sharded_forward, sharded_matching_templates
+    from picopose_amd.model.stage3 import COMPUTE_DEAD_LAYER1 as dead_layer1
 
     ops.PRECISION = {"fast": "f16x3", "exact": "f32", "fp16": "f16"}[a.mode]   # --mode exact: fp32 MFMA in every kernel
     s1_mode = "exact" if a.mode == "exact" else "fast"       # stage 1's own switch (fp16 MFMA + exact re-evaluation of near-ties | fp32 MFMA)
@@ -616,6 +635,10 @@ def main():
         net = net.to(dev).eval()
         net.match_mode = s1_mode
         ep = make_end_points(Bl, N, dev, 100 + rank)                     # this rank's crops + their raw templates
+        # a second, different batch: the timed loop alternates the two, so every step's look-ahead prefetches crops that are NOT the
+        # ones it is working on (--single-batch: one batch, as in rounds 1-5)
+        two_batches = a.prefetch_query and not a.single_batch and not sharded and kind != "full_cached"
+        ep_b = make_end_points(Bl, N, dev, 200 + rank) if two_batches else None
         fe = net.feature_extractor
         # feature bank (outside the timed region, run_test.py:120-134): this rank's template slice of ALL crops.
         # Synthetic stand-in for the other ranks' crops: features of this rank's own renders (same shapes/bytes).
@@ -635,16 +658,22 @@ def main():
             bank = feats.repeat(world, 1, 1, 1, 1).contiguous()
         else:
             ep["template_feature"] = feats
+            if ep_b is not None:
+                with torch.no_grad():
+                    ep_b["template_feature"] = torch.stack([torch.cat([fe(ep_b["tem_rgb"][b, s:min(s + 54, hi)])[-1] for s in range(lo, hi, 54)])
+                                                            for b in range(Bl)]).to(bank_dtype)
+        eps = [ep, ep_b] if ep_b is not None else [ep, ep]
 
-        def forward(mark=None):
+        def forward(mark=None, i=0):
             if sharded:
                 return sharded_forward(net, ep, bank, N, hyp=5, mark=mark)
             # a serving loop knows its next batch: its query crops ride in this batch's template-side ViT pass (Net.forward_test)
-            return net(ep, 5, next_real_rgb=ep["real_rgb"]) if a.prefetch_query else net(ep, 5)
+            cur, nxt = eps[i % 2], eps[(i + 1) % 2]
+            return net(cur, 5, next_real_rgb=nxt["real_rgb"]) if a.prefetch_query else net(cur, 5)
 
-        def step():
-            outs = forward()
-            return outs, pnp_for_outputs(outs, ep["real_K"])            # PnP/RANSAC + D2H of the poses
+        def step(i=0):
+            outs = forward(i=i)
+            return outs, pnp_for_outputs(outs, eps[i % 2]["real_K"])            # PnP/RANSAC + D2H of the poses
 
         # the timed loop is a serving loop: step i + 1 is launched before the host reads step i's poses (asynchronous D2H into
         # two alternating pinned buffers on the same stream), so the GPU does not wait for the host between batches; every
@@ -655,8 +684,8 @@ def main():
         pnp_stream = torch.cuda.Stream(device=dev) if a.pnp_stream == "side" else None
 
         def step_launch(i):
-            outs = forward()
-            return pnp_for_outputs_async(outs, ep["real_K"], host=pinned[i % 2], stream=pnp_stream)
+            outs = forward(i=i)
+            return pnp_for_outputs_async(outs, eps[i % 2]["real_K"], host=pinned[i % 2], stream=pnp_stream)
 
     if kind == "stage1":   # a step is ~1 ms: without ~0.3 s of load first, the timed steps run while the clocks still ramp
         t_ramp = time.perf_counter()
@@ -664,8 +693,8 @@ def main():
             for _ in range(20):
                 out = step()
             torch.cuda.synchronize()
-    for _ in range(a.warmup):
-        out = step()
+    for w_ in range(a.warmup):
+        out = step() if kind == "stage1" else step(w_ + a.warmup % 2)     # (the warm-up ends on batch 1: the timed loop starts on batch 0 with its look-ahead in place)
     torch.cuda.synchronize()
     L = _lib.lib()
     # stage-1 workloads: the roofline kernel IS the step, so its launch is bracketed by HIP events inside the timed steps
@@ -681,8 +710,10 @@ def main():
     marks[0].record()
     pending = None
     for i in range(a.steps):
-        if kind == "stage1" or a.sync_loop:
+        if kind == "stage1":
             out = step()
+        elif a.sync_loop:
+            out = step(i)
         else:
             h = step_launch(i)
             if pending is not None:
@@ -704,7 +735,7 @@ def main():
         _lib.check(L.pp_prof_enable(0), "pp_prof_enable")
         return sum(buf[i] for i in range(cnt.value)) / max(cnt.value, 1)
 
-    gemm = pnp = exact = phases = None
+    gemm = pnp = exact = phases = sharded_leg = None
     if kind == "stage1" and s1_graphed:     # the kernel's own time: the same launches outside the graph, after the timed region
         n_ev = min(a.steps, 64)
         _lib.check(L.pp_prof_enable(n_ev), "pp_prof_enable")
@@ -772,6 +803,58 @@ def main():
         if npts.min() < 5:
             raise SystemExit(f"bench: a PnP problem received {int(npts.min())} correspondences (< the 5-point sample): "
                              "the key-point -> PnP chain is not loaded")
+        sharded_leg = None
+        if distributed and not sharded and not cached and not a.no_sharded_leg:
+            # BASELINE configs[3] as written, as an extra leg of the default N > 1 run: the workload's crops as the GLOBAL batch,
+            # this rank's share of them, the feature bank cut along the template axis (utils/matching.py:29-69 sharded, picopose_amd/dist.py:
+            # all-gathers of query features / masks and of the score slices over RCCL), stages 2-3 + PnP data-parallel on the own crops
+            plan = sharded_leg_plan(WORKLOADS[a.workload][1], N, world, rank)
+            if plan is None:
+                sharded_leg = {"skipped": f"{world} ranks do not divide the workload's {WORKLOADS[a.workload][1]} crops"}
+            else:
+                bl_s, lo_s, hi_s = plan
+                ep_s = {k_: v_[:bl_s] for k_, v_ in ep.items() if k_ != "template_feature"}
+                # (stand-in for the other ranks' crops: this rank's own crops repeated — same shapes and bytes)
+                bank_s = ep["template_feature"][:bl_s, lo_s:hi_s].repeat(world, 1, 1, 1, 1).contiguous()
+
+                def s_forward(mark=None):
+                    return sharded_forward(net, ep_s, bank_s, N, hyp=5, mark=mark)
+
+                for _ in range(2):
+                    pnp_for_outputs(s_forward(), ep_s["real_K"])
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                s_steps = max(3, min(a.steps, 10))
+                ts = time.perf_counter()
+                for _ in range(s_steps):
+                    pnp_for_outputs(s_forward(), ep_s["real_K"])     # forward + PnP/RANSAC + D2H, the poses read every step
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                s_dt = torch.tensor([time.perf_counter() - ts], device=dev, dtype=torch.float64)
+                dist.all_reduce(s_dt, op=dist.ReduceOp.MAX)
+                s_dt = float(s_dt.item()) / s_steps
+                evs = []
+
+                def s_mark(name):
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    evs.append((name, e))
+
+                po = s_forward(s_mark)
+                pnp_for_outputs(po, ep_s["real_K"])
+                s_mark("pnp")
+                torch.cuda.synchronize()
+                d_ = {evs[j + 1][0]: evs[j][1].elapsed_time(evs[j + 1][1]) for j in range(len(evs) - 1)}
+                sharded_leg = {"crops_per_s": WORKLOADS[a.workload][1] / s_dt, "ms_per_step": s_dt * 1e3, "steps": s_steps,
+                               "global_batch": WORKLOADS[a.workload][1], "crops_per_rank": bl_s, "templates_of_rank0": hi_s - lo_s,
+                               "world_size": world, "backend": backend,
+                               "phases_ms": {"features": d_["features"], "exchange_q": d_["exchange_q"], "stage1": d_["stage1"],
+                                             "exchange_s": d_["exchange_s"], "tail": d_["tail"], "pnp": d_["pnp"]},
+                               "note": "configs[3]: global batch = the workload's crops, template-sharded bank + all-gathers; strong-scaling leg "
+                                       "after the weak-scaling timed region; max over ranks; phases = HIP events of rank 0, one extra step"}
+                del bank_s
         if a.mode == "fast" and world == 1 and not a.no_exact_leg:
             # the same step in --mode exact (fp32 MFMA everywhere, exact-fp32 stage 1), untimed leg: its rate and the
             # deviation of the default (f16x3) arithmetic from it on these very inputs
@@ -780,15 +863,15 @@ def main():
                     "cert": net.last_stage3[1].clone(), "tvec": tvec, "rot": rot}
             ops.PRECISION, net.match_mode = "f32", "exact"
             net.keep_stage3 = True
-            for _ in range(2):
-                xo = step()
+            for j_ in range(2):
+                xo = step(j_)
             torch.cuda.synchronize()
-            x_steps = 5
+            x_steps = 5     # (odd: the last step is batch 0, the batch `fast` was computed on)
             xm = [torch.cuda.Event(enable_timing=True) for _ in range(x_steps + 1)]
             t1 = time.perf_counter()
             xm[0].record()
             for i in range(x_steps):
-                xo = step()
+                xo = step(i)
                 xm[i + 1].record()
             torch.cuda.synchronize()
             x_dt = (time.perf_counter() - t1) / x_steps
@@ -798,14 +881,14 @@ def main():
             if ops.WINOGRAD:
                 ops.WINOGRAD = False
                 try:
-                    for _ in range(2):
-                        step()
+                    for j_ in range(2):
+                        step(j_)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    for _ in range(3):
-                        step()
+                    for j_ in range(4):
+                        step(j_)
                     torch.cuda.synchronize()
-                    xd_dt = (time.perf_counter() - t1) / 3
+                    xd_dt = (time.perf_counter() - t1) / 4
                 finally:
                     ops.WINOGRAD = True
             # its own roofline: HIP events around every GEMM launch of one more (untimed) exact step, fp32-MFMA peak
@@ -875,7 +958,7 @@ def main():
         # the committed measurement set of this mode and workload, if any (tools/profile_set.sh: kernel trace, MFMA-busy, FETCH_SIZE and
         # WRITE_SIZE passes on identical launches — the autotuner table is pinned — joined per kernel in per_kernel.json)
         pset = pset_src = None
-        for rdir in ("r05", "r04"):
+        for rdir in ("r06", "r05", "r04"):
             f = os.path.join(ROOT, "profiles", rdir, a.mode, "per_kernel.json")
             if pset is None and world == 1 and emulate is None and not cached and os.path.exists(f):
                 cand = json.load(open(f))
@@ -914,15 +997,20 @@ def main():
                        "hypotheses": 5, "mode": a.mode, "bank_dtype": "f16" if bpe == 2 else "f32",
                        "weights": "seeded random init, prediction heads calibrated (picopose_amd/utils/seeding.py)",
                        "shard": "none" if world == 1 else a.shard,
+                       "prefetch_query": bool(a.prefetch_query) if kind != "stage1" else None,
+                       "input_batches": None if kind == "stage1" else (2 if (kind != "stage1" and ep_b is not None) else 1),
+                       "winograd_f4x4_heads": bool(ops.WINOGRAD4) if a.mode == "fast" else False,
+                       "dpt_layer1_branch": None if kind == "stage1" else
+                       ("computed (PP_DPT_DEAD_LAYER1=1)" if dead_layer1 else "not computed: only its shape is read (dpt.py:263-271)"),
                        "parallelism": "single GPU" if world == 1 else
                        (f"{a.scaling} scaling: {Bl} crops per rank x{world} (global batch {B}); feature bank template-sharded x{world} "
                         f"({n_local} of {N} templates on rank 0) + all-gathers (query features, sampled masks, scores); {backend}" if sharded else
                         f"weak scaling: {Bl} crops per rank x{world} (global batch {B}), each rank its own crops and their banks — independent "
                         f"units, no data-path collective (barrier + max-over-ranks of the timed region only); {backend}")},
         }
-        s1_roof = {"bound": "hbm", "kernel": f"s1_main<{s1_mode}> (stage-1 fused similarity)", "achieved": achieved,
-                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                   "traffic_source": traffic_src, "traffic_measured_in_this_run": False, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kbytes,
+        s1_roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                   "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kbytes, "traffic_measured_in_this_run": False,
+                   "kernel": f"s1_main<{s1_mode}> (stage-1 fused similarity)", "traffic_source": traffic_src,
                    "timing": "HIP events on the launch stream around this launch, " +
                              ("inside the timed steps" if kind == "stage1" and not s1_graphed else
                               "the same launches outside the graph, after the timed region" if kind == "stage1" else "3 extra untimed steps after the timed region")}
@@ -948,42 +1036,42 @@ def main():
                     g_traffic, g_src = sum(kk["fetch_bytes"] + kk["write_bytes"] for kk in sel), pset_src
             elif world == 1 and a.mode == "fast" and a.workload == "full_b32_n162_vitb" and os.path.exists(pmc_step):
                 g_traffic, g_src = json.load(open(pmc_step)).get("gemm_f16x3_hbm_bytes_per_step"), os.path.relpath(pmc_step, ROOT)
-            line["roofline"] = {
-                "bound": "mfma",
-                "kernel": "pp_gemm_u_kernel / pp_gemm_uh_kernel, all tile instantiations (GEMM / implicit-im2col conv, persistent, LDS-DMA ring; both operands "
-                          "pre-split into 2 fp16 terms; 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)" if a.mode == "fast" else
-                          ("pp_gemm_u_kernel / pp_gemm_uh_kernel, h operand format (plain fp16 operands, 1 x v_mfma_f32_16x16x32_f16 per product, "
-                           "fp32 accumulate)" if a.mode == "fp16" else
-                           "pp_gemm_f_kernel, all tile instantiations (fp32 operands, GEMM / implicit-im2col conv, persistent, LDS-DMA ring, "
-                           "v_mfma_f32_32x32x2_f32) + the round-1 gemm_kernel on batched / unaligned shapes"),
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "frac_algorithmic": fl / (msum * 1e-3) / 1e12 / peak,
-                "frac_note": "frac = EXECUTED MFMA flops (3 fp16 MFMA products per fp32-grade product) / time / fp16 dense peak; "
-                             "frac_algorithmic = 2MNK / time / the same peak (ceiling 1/3 under the 3-term scheme)"
-                             if a.mode == "fast" else ("one MFMA product per product: executed = algorithmic (frac = frac_algorithmic)" +
-                                                       ("; a Winograd convolution (ops.WINOGRAD, strict-fp32 mode) counts its sixteen products, not the "
-                                                        "direct convolution it replaces" if a.mode == "exact" and ops.WINOGRAD else "")),
-                "traffic": None if g_traffic is None else g_traffic / n, "traffic_bytes_per_step": g_traffic, "traffic_source": g_src,
-                "traffic_measured_in_this_run": False,
-                "per_kernel": gemm.get("per_kernel"),
-                "per_kernel_note": "every GEMM / conv launch of the event pass grouped by kernel: frac_algorithmic of a kernel = "
-                                   "algorithmic_flops / ms / peak; its executed fraction = 3 x that for the f16x3 kernels; algorithmic_bytes = "
-                                   "A (a convolution: its input image, not the im2col) + B + outputs + residuals, each element once in the "
-                                   "format the launch reads / writes (pp_prof_gemm_records2) — profiles/*/pmc_step*.json divide the PMC "
-                                   "FETCH + WRITE bytes of the same kernel by it (traffic_ratio)",
-                "launches_per_step": n, "kernel_ms_per_step": msum, "avg_launch_ms": msum / n,
-                "algorithmic_flops_per_step": fl, "mfma_flops_per_step": mult * fl,
-                "useful_tflops": fl / (msum * 1e-3) / 1e12, "share_of_step": msum / ms,
-                "timing": "HIP events on the launch stream around every launch of one extra, untimed step",
-            }
-            # scalars the driver's record keeps (it drops lists and long strings): the kernel with the most time in the step
             pk = gemm.get("per_kernel") or []
-            if pk:
-                dom = pk[0]
-                line["roofline"].update({
-                    "dominant_kernel": (dom["kernel"] + " | " + dom["a_operand"])[:120], "dominant_launches": dom["launches"], "dominant_ms": dom["ms"],
-                    "dominant_useful_tflops": dom["useful_tflops"], "dominant_frac_algorithmic": dom["useful_tflops"] / peak,
-                    "dominant_frac_executed": mult * dom["useful_tflops"] / peak})
+            dom = pk[0] if pk else None
+            direct_tf = Bl * full_gflop_per_crop(N, vit, cached=cached) / (dt / a.steps) / 1e3     # direct-convolution-equivalent, whole step
+            # Scalars FIRST (the driver's record keeps the first ~23 keys of this object and drops unknown top-level keys): the contract's six,
+            # then what a reader needs without the rest of the line; every string after them, each <= 100 characters.
+            line["roofline"] = {
+                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "traffic": None if g_traffic is None else g_traffic / n,
+                "frac_algorithmic": fl / (msum * 1e-3) / 1e12 / peak,
+                "dominant_ms": dom["ms"] if dom else None,
+                "dominant_frac_algorithmic": dom["useful_tflops"] / peak if dom else None,
+                "dominant_frac_executed": mult * dom["useful_tflops"] / peak if dom else None,
+                "stage1_hbm_frac": s1_roof["frac"], "stage1_kernel_ms": kern_ms,
+                # world 1: the like-for-like legs of the same run; world > 1: the template-sharded (configs[3]) leg
+                **({"exact_value": None, "exact_direct_value": None, "latency_ms_per_image": None, "train_step_ms": None} if world == 1 else
+                   {"sharded_crops_per_s": (sharded_leg or {}).get("crops_per_s"), "sharded_ms_per_step": (sharded_leg or {}).get("ms_per_step"),
+                    "sharded_exchange_q_ms": ((sharded_leg or {}).get("phases_ms") or {}).get("exchange_q"),
+                    "sharded_exchange_s_ms": ((sharded_leg or {}).get("phases_ms") or {}).get("exchange_s"),
+                    "rccl_world_size": world}),
+                "kernel_ms_per_step": msum, "share_of_step": msum / ms, "launches_per_step": n, "avg_launch_ms": msum / n,
+                "useful_tflops": fl / (msum * 1e-3) / 1e12, "step_direct_conv_equiv_tflops": direct_tf,
+                "dominant_launches": dom["launches"] if dom else None,
+                "algorithmic_flops_per_step": fl, "mfma_flops_per_step": mult * fl,
+                "traffic_bytes_per_step": g_traffic, "traffic_measured_in_this_run": False, "prefetch_query": bool(a.prefetch_query),
+                "dominant_kernel": ((dom["kernel"] + " | " + dom["a_operand"])[:100] if dom else None),
+                "kernel": {"fast": "pp_gemm_u_kernel, all tiles: operands pre-split in 2 f16 terms, 3 MFMAs per product",
+                           "fp16": "pp_gemm_u_kernel, all tiles: plain f16 operands, 1 MFMA per product",
+                           "exact": "pp_gemm_f_kernel (fp32 operands, v_mfma_f32_32x32x2_f32) + round-1 gemm_kernel"}[a.mode],
+                "frac_note": ("frac: executed MFMA flops (3 per product) / time / peak; frac_algorithmic: 2MNK / time / peak" if a.mode == "fast"
+                              else "one MFMA per product: executed = algorithmic"),
+                "flops_note": "2MNK of every launch as executed: a Winograd convolution counts its dense products",
+                "traffic_source": g_src,
+                "timing": "HIP events on the launch stream around every launch of one extra, untimed step",
+                "per_kernel_note": "per kernel: ms, 2MNK, algorithmic bytes (operands + results once); profiles/r06/*/per_kernel.txt",
+                "per_kernel": pk,
+            }
             line["roofline_stage1"] = s1_roof
         else:
             line["roofline"] = s1_roof
@@ -1021,6 +1109,13 @@ def main():
                 line["exact_ms_per_step"] = exact["ms_per_step"]
                 line["exact_roofline_frac"] = exact["roofline"]["frac"]
                 line["exact_direct_value"] = exact["winograd"]["value_with_every_convolution_direct"]   # (the same leg with ops.WINOGRAD off)
+                if "exact_value" in line["roofline"]:
+                    line["roofline"]["exact_value"] = exact["value"]
+                    line["roofline"]["exact_direct_value"] = line["exact_direct_value"]
+            if sharded_leg is not None:
+                line["sharded_leg"] = sharded_leg
+                for k_ in ("crops_per_s", "ms_per_step"):
+                    line["sharded_" + k_] = sharded_leg.get(k_)
         if emulate is not None:
             line["emulated_world"] = {
                 "world": emulate, "rank": 0, "crops_of_this_rank": Bl, "templates_of_this_rank": n_local, "global_batch": B,
@@ -1039,9 +1134,13 @@ def main():
             ops.PRECISION = {"fast": "f16x3", "exact": "f32", "fp16": "f16"}[a.mode]
             line["latency"] = latency_leg(dev, s1_mode)
             line["latency_ms_per_image"] = line["latency"]["ms_per_image"]
+            if "latency_ms_per_image" in line.get("roofline", {}):
+                line["roofline"]["latency_ms_per_image"] = line["latency_ms_per_image"]
         if world == 1 and emulate is None and kind == "full" and a.workload == "full_b32_n162_vitb" and a.mode == "fast" and not a.no_train_leg:
             line["train_step"] = train_step_leg(dev)
             line["train_step_ms"] = line["train_step"]["ms_per_step"]
+            if "train_step_ms" in line.get("roofline", {}):
+                line["roofline"]["train_step_ms"] = line["train_step_ms"]
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_full(N, vit, sd) if kind == "full" else cpu_baseline_stage1(N, C)
         print(json.dumps(line), flush=True)

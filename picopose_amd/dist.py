@@ -124,8 +124,8 @@ class LocalWorld:
     """A one-process stand-in for `torch.distributed` that runs ALL ranks of a sharded job: every rank is a thread, and a collective is
     a REAL exchange between them (an all-gather returns every rank's contribution, not copies of the caller's).  It exists so that the
     real shard shapes of BASELINE configs[3] — 8 ranks, 4 crops and 21 / 20 templates each — run through `sharded_forward` on a one-GPU
-    box (tests/test_dist_gpu.py) and so that `bench.py --emulate-world` has the same semantics as the multi-process job; the RCCL hop
-    itself is the one thing it does not exercise.
+    box (tests/test_dist_gpu.py); the RCCL hop itself is the one thing it does not exercise.  (`bench.py --emulate-world` is a different,
+    cheaper stand-in: ONE rank's share with every all-gather replaced by copies of that rank's own contribution.)
 
     Ranks take TURNS: a thread computes only while it holds the run token and hands it over when it waits for a collective, so between two
     collectives a rank's launches are never interleaved with another rank's (the model keeps per-shape scratch buffers, and one process per
@@ -185,7 +185,9 @@ class LocalWorld:
         seq = self._tls.seq                  # the n-th collective of a rank meets the n-th collective of every other rank
         self._tls.seq += 1
         assert out.numel() == self.world * inp.numel(), (tuple(out.shape), tuple(inp.shape))
-        self._slots.setdefault(seq, {})[self._tls.rank] = inp
+        # deposited as a COPY (stream-ordered, a few KB .. MB): the depositing rank resumes before the others have read its contribution and
+        # may legally overwrite `inp` (the model's scratch buffers are per shape and shared by all rank threads of this process)
+        self._slots.setdefault(seq, {})[self._tls.rank] = inp.clone()
         work = LocalWorld._Work(self, seq, out, tuple(inp.shape))
         if async_op:
             return work
@@ -320,6 +322,8 @@ class GradientBuckets:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
     def _hook(self, p):
+        if not self._active():
+            return       # a single process: nothing is counted, nothing raises — gradient accumulation over several backward() calls works
         i = self._where[id(p)]
         self._left[i] -= 1
         if self._left[i] < 0:
@@ -327,7 +331,7 @@ class GradientBuckets:
             # micro-batch's gradients and finish() would write that mean over the accumulated .grad — silently wrong gradients
             raise RuntimeError("GradientBuckets: a parameter received a second gradient before finish() — one backward() per finish(); "
                                "for gradient accumulation call allreduce_gradients() after the last micro-batch instead")
-        if self._left[i] == 0 and self._active():
+        if self._left[i] == 0:
             flat = torch.cat([q.grad.reshape(-1) for q in self.buckets[i]])
             self._inflight[i] = (flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.launched_in_backward += 1

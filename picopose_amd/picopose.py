@@ -35,7 +35,10 @@ PREFETCH_QUERY = os.environ.get("PP_PREFETCH_QUERY", "1") != "0"
 def _tensor_key(t, fe=None):
     """Identity of a tensor's contents as far as the host can tell: storage address, shape, version counter — and, for the query stash of
     Net.forward_test, what its levels were computed WITH: the engine's arithmetic mode and the feature extractor's weights (the
-    signature model/common.Packed watches; a write through `.data` needs Net.invalidate_packed(), which also drops the stash)."""
+    signature model/common.Packed watches; a write through `.data` needs Net.invalidate_packed(), which also drops the stash).
+    The address identifies the contents only while the tensor is ALIVE (the stash keeps it), and the version counter only sees writes made
+    through torch: a buffer refilled in place by a custom kernel or through DLPack must be passed as a new tensor, or refilled with
+    `copy_`."""
     key = (t.data_ptr(), tuple(t.shape), t._version, ops.PRECISION)
     return key if fe is None else key + (fe._signatures()[0],)
 
@@ -130,7 +133,10 @@ class Net(nn.Module):
             Bn, T = nxt.shape[0], h0 * w0 + 1
             both, _ = fe.forward_tokens(torch.cat([nxt, end_points["tem_rgb"]]), level_out=(alloc, 0))
             tem_tok = [t[Bn:] for t in both]
-            self._query_stash = (_tensor_key(nxt, fe), [a[:Bn * T] for a in alloc], (h0, w0))
+            # the stash: the key of the crops it was computed FROM, copies of its Bn * T rows per level (views would pin the whole `alloc` of
+            # this batch until the next call), and `nxt` itself — held so that its storage cannot be freed and its address handed to another
+            # batch of the same shape, whose key would then match
+            self._query_stash = (_tensor_key(nxt, fe), [a[:Bn * T].clone() for a in alloc], (h0, w0), nxt)
             tem_last = ops.tokens_to_nchw(tem_tok[-1], 1, h0, w0)
         elif tem_cached is None:
             tem_tok, _ = fe.forward_tokens(end_points["tem_rgb"], level_out=None if levels is None else (levels, 0))

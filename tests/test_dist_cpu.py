@@ -78,3 +78,40 @@ def test_local_world_eight_ranks_at_the_configs3_shard_layout():
     for rank, (ids, s, i) in enumerate(outs):
         assert torch.equal(ids, wi[rank * bl:(rank + 1) * bl]), rank
         assert torch.equal(i, wi) and float((s - ws).abs().max()) <= 1e-6, rank
+
+
+def test_local_world_deposits_are_copies_and_single_process_buckets_allow_accumulation():
+    """ LocalWorld.all_gather_into_tensor deposits a COPY of a rank's contribution: the rank that resumes first may overwrite
+    its input buffer (the model's per-shape scratch) before the others have read it.  GradientBuckets in a single process: the hooks do
+    nothing — several backward() calls per finish() (gradient accumulation) work and accumulate."""
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import picopose_amd.dist as pd
+
+    world = 4
+    shared = torch.zeros(3)                       # ONE buffer every rank thread fills with its own value, like a per-shape scratch
+
+    def body(rank):
+        out = torch.empty(world, 3)
+        shared.fill_(float(rank + 1))
+        pd.dist.all_gather_into_tensor(out, shared)
+        shared.fill_(-1.0)                        # legal after a synchronous collective
+        return out
+
+    lw = pd.LocalWorld(world)
+    with lw.installed():
+        outs = lw.run(body)
+    for o in outs:
+        assert torch.equal(o, torch.arange(1.0, world + 1)[:, None].expand(world, 3)), o
+
+    net = torch.nn.Linear(5, 3)
+    gb = pd.GradientBuckets(list(net.parameters()))
+    x = torch.randn(4, 5)
+    for _ in range(3):                            # three micro-batches, one finish(): no error in a single process
+        net(x).sum().backward()
+    assert gb.finish() == 0
+    one = torch.autograd.grad(net(x).sum(), list(net.parameters()))
+    for p, g1 in zip(net.parameters(), one):
+        assert torch.allclose(p.grad, 3 * g1)
+    gb.remove()

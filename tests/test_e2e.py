@@ -159,6 +159,21 @@ def test_query_prefetch_inside_the_template_pass_keeps_every_bit():
     # a stash that does not belong to the batch that follows is ignored
     net(eps[0], hyp, next_real_rgb=eps[1]["real_rgb"])
     same(net(eps[2], hyp), plain[2])
+    # a DISCARDED look-ahead cannot be mistaken for a later batch of the same shape: the stash holds the look-ahead tensor itself, so its
+    # storage stays allocated and a fresh batch cannot receive its address (stale hit -> the OTHER batch's query features)
+    look = eps[1]["real_rgb"].clone()
+    net(eps[0], hyp, next_real_rgb=look)
+    addr = look.data_ptr()
+    assert net._query_stash[3] is look
+    del look                                                      # the serving loop drops the request ...
+    fresh = dict(eps[1], real_rgb=torch.randn_like(eps[1]["real_rgb"]))    # ... and a new batch of the same shape arrives
+    assert fresh["real_rgb"].data_ptr() != addr
+    want = net(fresh, hyp)
+    net(eps[0], hyp, next_real_rgb=eps[1]["real_rgb"].clone())    # (again a discarded look-ahead in front of `fresh`)
+    same(net(fresh, hyp), want)
+    # the stash owns its rows: it does not keep the previous batch's level buffers alive
+    net(eps[0], hyp, next_real_rgb=eps[1]["real_rgb"])
+    assert net._query_stash[1][0]._base is None
     # ... and so is one computed in another arithmetic mode
     net(eps[0], hyp, next_real_rgb=eps[1]["real_rgb"])
     old = ops.PRECISION

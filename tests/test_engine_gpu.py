@@ -406,6 +406,12 @@ def test_winograd_3x3_of_the_strict_fp32_mode(monkeypatch, engine_precision, B, 
         e_w, e_d = float((got.cpu().double() - ref).abs().max()) / scale, float((direct.cpu().double() - ref).abs().max()) / scale
         assert not torch.equal(got, direct), "the Winograd path did not run"
         assert e_w <= max(3 * e_d, 2e-6), (e_w, e_d)
+        # a pinned round-1 configuration (tests / tools pin 0 .. 2) must not send the GROUPED batch to the round-1 kernel, which knows
+        # nothing of groups and would multiply every frequency by frequency 0's weights: same bits as unpinned
+        monkeypatch.setenv("PP_GEMM_FORCE_CFG", "0")
+        pinned = fn()
+        monkeypatch.delenv("PP_GEMM_FORCE_CFG")
+        assert torch.equal(pinned, got)
         assert e_w <= 2e-5
     # a channel-slice output of a wider NHWC buffer
     if cout % 4 == 0:

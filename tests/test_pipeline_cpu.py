@@ -114,6 +114,12 @@ def test_bench_batch_plan_weak_and_strong():
     assert [shard_bounds(162, 8, r)[1] - shard_bounds(162, 8, r)[0] for r in range(8)] == [21, 21, 20, 20, 20, 20, 20, 20]
     with pytest.raises(SystemExit):
         bench.batch_plan(32, 3, "strong")
+    # the SHARDED leg of the default `--gpus N` run (configs[3]: global batch 32, bank cut 21 / 21 / 20 x 6): every rank's plan
+    plans = [bench.sharded_leg_plan(32, 162, 8, r) for r in range(8)]
+    assert [p[0] for p in plans] == [4] * 8 and [p[2] - p[1] for p in plans] == [21, 21, 20, 20, 20, 20, 20, 20]
+    assert plans[0][1] == 0 and plans[-1][2] == 162 and all(plans[r][2] == plans[r + 1][1] for r in range(7))
+    assert bench.sharded_leg_plan(32, 162, 2, 1) == (16, 81, 162) and bench.sharded_leg_plan(32, 162, 4, 0) == (8, 0, 41)
+    assert bench.sharded_leg_plan(32, 162, 1, 0) is None and bench.sharded_leg_plan(32, 162, 3, 0) is None     # one rank / ranks that do not divide the batch
 
 
 def test_compat_import_installs_the_pnp_drop_in(tmp_path):
