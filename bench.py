@@ -679,7 +679,7 @@ def main():
         # two alternating pinned buffers on the same stream), so the GPU does not wait for the host between batches; every
         # step's poses are read, the last ones before the closing synchronisation
         from picopose_amd.pipeline import pnp_collect, pnp_for_outputs_async
-        pinned = [torch.empty(5 * Bl, 15, dtype=torch.float64, pin_memory=True) for _ in range(2)]
+        pinned = [torch.empty(5 * Bl + (1 if ops.SATURATION_FLAG else 0), 15, dtype=torch.float64, pin_memory=True) for _ in range(2)]   # (+ the saturation row)
 
         pnp_stream = torch.cuda.Stream(device=dev) if a.pnp_stream == "side" else None
 

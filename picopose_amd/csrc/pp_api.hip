@@ -18,12 +18,24 @@ const char* pp_strerror(int code) {
 int pp_version(void) { return 100; }
 
 }  // extern "C"
+int pp_sat_set_gemm(unsigned*);
+int pp_sat_set_gemm_u1(unsigned*);
+int pp_sat_set_gemm_u2(unsigned*);
+int pp_sat_set_gemm_uh(unsigned*);
+int pp_sat_set_attn(unsigned*);
+int pp_sat_set_sample(unsigned*);
 static unsigned* g_sat_word[PP_MAX_DEVICES];
 unsigned* pp_saturation_word() { return g_sat_word[pp_cur_device()]; }
 extern "C" {
 
 int pp_set_saturation_word(unsigned int* word) {
-    g_sat_word[pp_cur_device()] = word;
+    // every translation unit with a producer kernel holds its own device-side copy of the pointer (pp_common.h)
+    int (*const setters[])(unsigned*) = {pp_sat_set_gemm, pp_sat_set_gemm_u1, pp_sat_set_gemm_u2, pp_sat_set_gemm_uh, pp_sat_set_attn, pp_sat_set_sample};
+    for (auto f : setters) {
+        const int rc = f(word);
+        if (rc != PP_OK) return rc;
+    }
+    g_sat_word[pp_cur_device()] = word;      // (the Winograd transforms take it as a kernel argument)
     return PP_OK;
 }
 

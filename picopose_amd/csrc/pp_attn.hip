@@ -643,7 +643,7 @@ __global__ __launch_bounds__(WPB > 4 ? 64 * WPB : 256) __attribute__((amdgpu_wav
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     _Float16 a, c;
-                    pp_split_f16(v[i], a, c);
+                    pp_split_f16_chk(v[i], a, c);
                     hh[i] = a;
                     ll[i] = c;
                 }
@@ -660,6 +660,8 @@ __global__ __launch_bounds__(WPB > 4 ? 64 * WPB : 256) __attribute__((amdgpu_wav
 }
 
 }  // namespace
+
+PP_SAT_SETTER(pp_sat_set_attn)
 
 extern "C" {
 

@@ -27,6 +27,32 @@ __device__ __forceinline__ void pp_split_f16(float v, _Float16& hi, _Float16& lo
 // plain-fp16 operand ("h" format, PP_PREC_F16): v -> f16(4 v), saturated like the hi term above
 __device__ __forceinline__ _Float16 pp_to_f16(float v) { return (_Float16)fminf(fmaxf(v * PP_A_SCALE, -65504.f), 65504.f); }
 
+// Sticky saturation word (include/picopose_hip.h pp_set_saturation_word).  A clamped operand term is finite but WRONG; the kernels that
+// WRITE operand buffers (the producers of the inference path: split passes, LayerNorm, attention output, GEMM epilogues, resize, warp,
+// Winograd transforms) report it by OR-ing bit 0 into a device word — an atomic only from a lane that actually saw a clamped term.
+// Every translation unit holds its own copy of the registered pointer (no relocatable device code in this build);
+// pp_set_saturation_word updates all of them (PP_SAT_SETTER below).  nullptr: reporting off.
+static __device__ unsigned* pp_sat_dev_word = nullptr;
+__device__ __forceinline__ void pp_sat_flag(bool bad) {
+    if (bad) {
+        unsigned* w = pp_sat_dev_word;
+        if (w) atomicOr(w, 1u);
+    }
+}
+// the same splits as above for a PRODUCER of an operand buffer: the value beyond the fp16 range is reported
+__device__ __forceinline__ void pp_split_f16_chk(float v, _Float16& hi, _Float16& lo) {
+    pp_sat_flag(!(fabsf(v) * PP_A_SCALE < 65504.f));
+    pp_split_f16(v, hi, lo);
+}
+__device__ __forceinline__ _Float16 pp_to_f16_chk(float v) {
+    pp_sat_flag(!(fabsf(v) * PP_A_SCALE < 65504.f));
+    return pp_to_f16(v);
+}
+#define PP_SAT_SETTER(name)                                                                                                    \
+    int name(unsigned* w) {                                                                                                    \
+        return hipMemcpyToSymbol(HIP_SYMBOL(pp_sat_dev_word), &w, sizeof(w), 0, hipMemcpyHostToDevice) == hipSuccess ? PP_OK : PP_ELAUNCH; \
+    }
+
 // "hl" operand format (include/picopose_hip.h): half index of element (k, term p) inside a row
 __device__ __forceinline__ int pp_hl_col(int k, int p) { return ((k >> 3) << 4) + (p << 3) + (k & 7); }
 

@@ -135,7 +135,7 @@ __device__ __forceinline__ void epilogue_store(const PpGemmDesc& d, float* C, co
     if (C) C[off] = v;
     if (d.C_hl) {
         _Float16 h, l;
-        pp_split_f16(d.c_relu ? fmaxf(v, 0.f) : v, h, l);
+        pp_split_f16_chk(d.c_relu ? fmaxf(v, 0.f) : v, h, l);
         _Float16* hp = (_Float16*)d.C_hl + orow * 2 * d.ldc_h + pp_hl_col(ocol, 0);
         hp[0] = h;
         hp[8] = l;
@@ -312,6 +312,14 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(const PpGemmDesc d) {
 // LDS: hi/lo planes of [rows][32 k] halfs with an 80-byte row stride (conflict-free ds_read_b128).
 // ---------------------------------------------------------------------------
 constexpr float A_SCALE = PP_A_SCALE;  // activation operand scale of the f16x3 engine
+
+// largest magnitude of 8 values (producers of operand buffers: the saturation report, pp_common.h)
+__device__ __forceinline__ float top4(const f4 a, const f4 b) {
+    float t = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fabsf(a[2]));
+    t = fmaxf(fmaxf(t, fabsf(a[3])), fabsf(b[0]));
+    t = fmaxf(fmaxf(t, fabsf(b[1])), fabsf(b[2]));
+    return fmaxf(t, fabsf(b[3]));
+}
 
 template <bool WEIGHT = false>
 __device__ __forceinline__ void split_f16x4(const f4 v, float s, h4& hi, h4& lo) {
@@ -553,6 +561,7 @@ __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict_
             }
         }
         h4 h0, l0, h1, l1;
+        pp_sat_flag(!(top4(v0, v1) * A_SCALE < 65504.f));
         split_f16x4(v0, A_SCALE, h0, l0);
         split_f16x4(v1, A_SCALE, h1, l1);
         _Float16* o = hl + row * ldh + terms * c;
@@ -633,6 +642,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             }
             if (hl) {
                 h4 h0, l0, h1, l1;
+                pp_sat_flag(!(top4(o[0], o[1]) * A_SCALE < 65504.f));
                 split_f16x4(o[0], A_SCALE, h0, l0);
                 split_f16x4(o[1], A_SCALE, h1, l1);
                 _Float16* hp = hl + ((size_t)row * C + gi * 8) * terms;
@@ -663,7 +673,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (y) y[(size_t)row * C + c] = o;
             if (hl) {  // f16x3 operand of the following linear layer
                 _Float16 h, l;
-                pp_split_f16(o, h, l);
+                pp_split_f16_chk(o, h, l);
                 if (terms == 2) {
                     _Float16* hp = hl + (size_t)row * 2 * C + pp_hl_col(c, 0);
                     hp[0] = h;
@@ -1049,7 +1059,7 @@ __global__ __launch_bounds__(256) void hl_patch_kernel(const float* __restrict__
     const long long row = i / c;
     const int j = (int)(i - row * c);
     _Float16 h, l;
-    pp_split_f16(x[row * ld_x + j], h, l);
+    pp_split_f16_chk(x[row * ld_x + j], h, l);
     if (terms == 2) {
         _Float16* hp = hl + row * ldh + pp_hl_col(col0 + j, 0);
         hp[0] = h;
@@ -1076,6 +1086,10 @@ int pp_split_activation(const float* x, long long batch_stride, int B, int P, in
                         void* stream) {
     return pp_split_activation_ld(x, batch_stride, B, P, row_stride, C, relu, hl, C, stream);
 }
+
+}  // extern "C"
+PP_SAT_SETTER(pp_sat_set_gemm)
+extern "C" {
 
 int pp_gemm(const PpGemmDesc* desc, void* stream) {
     // (B may be NULL when BOTH operands arrive pre-split: products of two transient operands, picopose_amd/ops.matmul_operands)

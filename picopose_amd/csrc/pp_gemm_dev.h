@@ -134,8 +134,18 @@ __device__ __forceinline__ f4 pp_bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
 // split 8 values (already in the operand's 4x scale, any input ReLU applied) into the operand group(s) and store them:
 // hl: [8 hi | 8 lo] at byte offset `off`; h: 8 halfs at `off`
 template <int TERMS>
-__device__ __forceinline__ void pp_store_operand8(__amdgpu_buffer_rsrc_t H, const f4 (&x4)[2], unsigned off) {
+__device__ __forceinline__ void pp_store_operand8(__amdgpu_buffer_rsrc_t H, const f4 (&x4)[2], unsigned off, unsigned long long& sbad) {
     h8 hh, ll;
+    // saturation report (pp_common.h): the largest of the 8 magnitudes (v_max3 chain, a short-lived register) against the fp16 range; the
+    // verdict is a wave mask in SCALAR registers — a per-lane running maximum kept across the epilogue cost the 256x256 kernels ~90
+    // spilled registers (they sit at the 256-VGPR limit)
+    {
+        float t = fmaxf(fmaxf(fabsf(x4[0][0]), fabsf(x4[0][1])), fabsf(x4[0][2]));
+        t = fmaxf(fmaxf(t, fabsf(x4[0][3])), fabsf(x4[1][0]));
+        t = fmaxf(fmaxf(t, fabsf(x4[1][1])), fabsf(x4[1][2]));
+        t = fmaxf(t, fabsf(x4[1][3]));
+        sbad |= __builtin_amdgcn_ballot_w64(!(t < 65504.f));
+    }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const float x = x4[c >> 2][c & 3];
@@ -169,6 +179,9 @@ __device__ __forceinline__ void epilogue_wave16(const PpGemmDesc& d, float desca
     const float hfloor = d.c_relu ? 0.f : -INFINITY;              // the consumer's input ReLU folded into the operand
     const bool lin_act = d.act != PP_ACT_GELU && d.act != PP_ACT_TANH;
     const int m0 = mw + l15;
+    // lanes that turned a magnitude beyond the fp16 range into operand terms (rows past M / columns past N are products of zero-filled
+    // operand tiles — bias and activation only — and cannot be what saturates)
+    unsigned long long sbad = 0ull;
     if (!d.C && !d.residual && !d.residual2 && !d.gamma && d.shuffle_r == 0 && d.act != PP_ACT_TANH) {
         const float ds4 = descale * PP_A_SCALE;
 #pragma unroll
@@ -205,10 +218,11 @@ __device__ __forceinline__ void epilogue_wave16(const PpGemmDesc& d, float desca
                         }
                 }
                 const bool ok = ncol && m0 + mi * 16 < d.M;
-                pp_store_operand8<TERMS>(Hr, x, ok ? off : 0xFFFFFFFFu);
+                pp_store_operand8<TERMS>(Hr, x, ok ? off : 0xFFFFFFFFu, sbad);
                 off += 16u * hrow;
             }
         }
+        pp_sat_flag(sbad != 0ull && lane == 0);
         return;
     }
     const __amdgpu_buffer_rsrc_t Cr = pp_rsrc(d.C), Rr = pp_rsrc(d.residual), R2r = pp_rsrc(d.residual2);
@@ -290,7 +304,7 @@ __device__ __forceinline__ void epilogue_wave16(const PpGemmDesc& d, float desca
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) x[h][c] = fmaxf(v[h][c] * PP_A_SCALE, hfloor);
-                pp_store_operand8<TERMS>(Hr, x, ok ? hoff : 0xFFFFFFFFu);
+                pp_store_operand8<TERMS>(Hr, x, ok ? hoff : 0xFFFFFFFFu, sbad);
             }
             coff = ncoff;
             hoff = nhoff;
@@ -302,6 +316,7 @@ __device__ __forceinline__ void epilogue_wave16(const PpGemmDesc& d, float desca
             }
         }
     }
+    if (d.C_hl) pp_sat_flag(sbad != 0ull && lane == 0);
 }
 
 // element-wise form of the same epilogue (N % 8 != 0, unaligned rows, pixel shuffle with odd channel counts)
@@ -341,12 +356,12 @@ __device__ __forceinline__ void epilogue_scalar16(const PpGemmDesc& d, float des
                     const float x = d.c_relu ? fmaxf(v, 0.f) : v;
                     if (TERMS == 2) {
                         _Float16 h, l;
-                        pp_split_f16(x, h, l);
+                        pp_split_f16_chk(x, h, l);
                         _Float16* hp = (_Float16*)d.C_hl + orow * 2 * d.ldc_h + pp_hl_col(ocol, 0);
                         hp[0] = h;
                         hp[8] = l;
                     } else {
-                        ((_Float16*)d.C_hl)[orow * d.ldc_h + ocol] = pp_to_f16(x);
+                        ((_Float16*)d.C_hl)[orow * d.ldc_h + ocol] = pp_to_f16_chk(x);
                     }
                 }
             }

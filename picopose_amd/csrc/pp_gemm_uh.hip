@@ -61,3 +61,4 @@ int pp_gemm_u_launch(const PpGemmDesc& d, int tile, int terms, int cus, hipStrea
     if (!vec && tile != PP_U_128x64) tile = PP_U_128x128;   // the element-wise epilogue exists for the two small tiles
     return terms == 2 ? pp_gemm_u_launch_t2(d, tile, mode, vec, cus, st) : pp_gemm_u_launch_t1(d, tile, mode, vec, cus, st);
 }
+PP_SAT_SETTER(pp_sat_set_gemm_uh)

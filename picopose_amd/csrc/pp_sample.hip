@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
                 for (int k = 0; k < 4; ++k) {
                     const float v = (hy * (hx * a[k] + lx * bq[k]) + ly * (hx * cq[k] + lx * dq[k])) * mul;
                     _Float16 h, l;
-                    pp_split_f16(v, h, l);
+                    pp_split_f16_chk(v, h, l);
                     hh[4 * q + k] = h;
                     ll[4 * q + k] = l;
                 }
@@ -134,10 +134,10 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
         if (HL) {
             typedef _Float16 h4w __attribute__((ext_vector_type(4)));
             _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
-            pp_split_f16(acc.x, h0, l0);
-            pp_split_f16(acc.y, h1, l1);
-            pp_split_f16(acc.z, h2, l2);
-            pp_split_f16(acc.w, h3, l3);
+            pp_split_f16_chk(acc.x, h0, l0);
+            pp_split_f16_chk(acc.y, h1, l1);
+            pp_split_f16_chk(acc.z, h2, l2);
+            pp_split_f16_chk(acc.w, h3, l3);
             if (terms == 2) {
                 _Float16* q = oh + pp_hl_col(c, 0);
                 *(h4w*)q = h4w{h0, h1, h2, h3};
@@ -380,10 +380,10 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const void* __
                     return;
                 }
                 _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
-                pp_split_f16(v.x, h0, l0);
-                pp_split_f16(v.y, h1, l1);
-                pp_split_f16(v.z, h2, l2);
-                pp_split_f16(v.w, h3, l3);
+                pp_split_f16_chk(v.x, h0, l0);
+                pp_split_f16_chk(v.y, h1, l1);
+                pp_split_f16_chk(v.z, h2, l2);
+                pp_split_f16_chk(v.w, h3, l3);
                 const h4_t hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
                 _Float16* g8 = (_Float16*)rowp + 16 * (part >> 1) + 4 * (part & 1);   // channels 4 part .. + 3 of group part / 2
                 *(h4_t*)g8 = hi;
@@ -664,6 +664,8 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const _Float16* __rest
 }
 
 }  // namespace
+
+PP_SAT_SETTER(pp_sat_set_sample)
 
 extern "C" {
 

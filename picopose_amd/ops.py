@@ -43,6 +43,50 @@ PP_A_SCALE = 4.0              # csrc/pp_common.h: activation operand scale
 saturation_checks = 0        # operands verified since import (bench.py reports it)
 
 
+# The default guard (round 6): a STICKY device word.  Every kernel that writes operand terms ORs bit 0 into it when a term hit the fp16 clamp
+# (csrc/pp_common.h pp_sat_flag: an atomic only from a wave that saw one — nothing in a healthy forward); the host reads the word together
+# with a batch's poses (picopose_amd/utils/pose_recovery.py: one more row of the packed device->host copy — no extra synchronisation) and
+# raises instead of returning poses computed from clipped operands.  A caller of the bare `Net.forward` asks with `saturation_raised()`
+# (a 4-byte copy + wait) or reads `saturation_word()` itself.  PP_SAT_FLAG=0 switches the reporting off.
+SATURATION_FLAG = os.environ.get("PP_SAT_FLAG", "1") != "0"
+_sat_words = {}            # device index -> registered int32 tensor (1,)
+
+
+def saturation_word(device=None):
+    """The registered saturation word of `device` (default: the current one): int32 (1,), 0 = no operand term was clamped since the last
+    reset.  Registered with the library on first use; None when the reporting is switched off."""
+    if not SATURATION_FLAG:
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    w = _sat_words.get(idx)
+    if w is None:
+        with torch.cuda.device(idx):
+            w = torch.zeros(1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()      # (the zero is in place before the library's kernels may write the word from another stream)
+            _lib.check(_lib.lib().pp_set_saturation_word(_p(w)), "pp_set_saturation_word")
+        _sat_words[idx] = w
+    return w
+
+
+def saturation_error(what="this forward"):
+    return _lib.PicoPoseHipError(
+        f"an f16x3 / f16 operand saturated in {what}: an activation reached the fp16 range of the engine's operand format (|x| >= 16376; "
+        "Winograd-transformed maps: >= 10480) and was clamped — the results of this batch are wrong.  Run this network with "
+        "ops.PRECISION = 'f32' (bench.py --mode exact); ops.CHECK_SATURATION = True names the layer")
+
+
+def saturation_raised(reset=True, device=None):
+    """True if an operand term was clamped since the last reset (waits for the device: a 4-byte copy)."""
+    w = saturation_word(device)
+    if w is None:
+        return False
+    hit = bool(w.item())
+    if hit and reset:
+        w.zero_()
+    return hit
+
+
 def _chk(hl, what):
     """hl: fp16 operand buffer (or None).  Raises if any element sits at the fp16 clamp (|v| >= 65504) or is not finite."""
     global saturation_checks

@@ -224,6 +224,7 @@ class Net(nn.Module):
         with torch.no_grad():
             fe = self.feature_extractor
             levels = None
+            ops.saturation_word(end_points["real_rgb"].device)      # (registered before the first producer kernel of this device runs)
             stash, self._query_stash = getattr(self, "_query_stash", None), None
             if BATCH_DPT and self.batch_hypotheses and end_points.get("template_cache") is None:
                 # the four feature levels of the hyp * B selected templates and of the B query crops share one buffer per level

@@ -76,10 +76,36 @@ def pose_recovery_ransac_pnp_batched(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pt
     [+ npts (P) int32 with return_npts]."""
     rot, tvec, ratio, ok, npts = pnp_launch(tar_pts_2d, src_pts_3d, K, tem_pose, tar_pts, src_pts, iterations, reproj_error)
     P = rot.shape[0]
-    # one packed device->host copy (P x 14 doubles) instead of four
-    host = torch.cat([rot.reshape(P, 9), tvec, ratio[:, None], ok.double()[:, None], npts.double()[:, None]], dim=1).cpu().numpy()
+    # one packed device->host copy (P x 15 doubles + the saturation row) instead of four
+    host = _with_sat_row(torch.cat([rot.reshape(P, 9), tvec, ratio[:, None], ok.double()[:, None], npts.double()[:, None]], dim=1)).cpu().numpy()
+    host = _check_sat_row(host, P)
     res = (host[:, :9].reshape(P, 3, 3).copy(), host[:, 9:12].reshape(P, 3, 1).copy(), host[:, 12].copy(), host[:, 13] != 0)
     return res + (host[:, 14].astype("int32"),) if return_npts else res
+
+
+def _with_sat_row(packed):
+    """packed (P, 15) f64 on the device + ONE more row whose first entry is the sticky operand-saturation word (picopose_amd/ops.py): the
+    host learns with the poses' own copy — no extra synchronisation — whether the forward that produced them clamped an operand."""
+    from .. import ops
+
+    w = ops.saturation_word(packed.device)
+    if w is None:
+        return packed
+    row = torch.zeros(1, packed.shape[1], dtype=packed.dtype, device=packed.device)
+    row[0, 0] = w[0]
+    return torch.cat([packed, row])
+
+
+def _check_sat_row(host, P):
+    """host (P or P + 1, 15): strips the saturation row; raises (and resets the word) if it is set."""
+    if host.shape[0] == P:
+        return host
+    if host[P, 0] != 0:
+        from .. import ops
+
+        ops.saturation_word().zero_()
+        raise ops.saturation_error("the forward whose poses were just read")
+    return host[:P]
 
 
 class PnPHandle:
@@ -92,7 +118,7 @@ class PnPHandle:
     def result(self, return_npts=False):
         """Wait for the copy and unpack: rot (P,3,3) f64, tvec (P,3,1) f64, inliers_ratio (P) f64, success (P) bool [+ npts]."""
         self.event.synchronize()
-        host, P = self.host.numpy(), self.P
+        host, P = _check_sat_row(self.host.numpy(), self.P), self.P
         res = (host[:, :9].reshape(P, 3, 3).copy(), host[:, 9:12].reshape(P, 3, 1).copy(), host[:, 12].copy(), host[:, 13] != 0)
         return res + (host[:, 14].astype("int32"),) if return_npts else res
 
@@ -113,9 +139,9 @@ def pose_recovery_ransac_pnp_batched_async(tar_pts_2d, src_pts_3d, K, tem_pose, 
     with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
         rot, tvec, ratio, ok, npts = pnp_launch(*inputs, iterations, reproj_error)
         P = rot.shape[0]
-        packed = torch.cat([rot.reshape(P, 9), tvec, ratio[:, None], ok.double()[:, None], npts.double()[:, None]], dim=1)
-        if host is None or tuple(host.shape) != (P, 15):
-            host = torch.empty(P, 15, dtype=torch.float64, pin_memory=True)
+        packed = _with_sat_row(torch.cat([rot.reshape(P, 9), tvec, ratio[:, None], ok.double()[:, None], npts.double()[:, None]], dim=1))
+        if host is None or tuple(host.shape) != tuple(packed.shape):
+            host = torch.empty(tuple(packed.shape), dtype=torch.float64, pin_memory=True)
         host.copy_(packed, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
