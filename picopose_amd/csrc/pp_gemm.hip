@@ -1215,7 +1215,36 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         return cfg;
     };
     int launch_rc = PP_OK;
-    auto launch = [&](int cfg) {
+    // TAIL SPLIT (round 6; configurations 9 = 256x256 + tail, 10 = 256x128 + tail).  A persistent launch of T tiles on S slots takes
+    // ceil(T / S) rounds; the ViT linears at M = 49 344 leave the last round of 256-row tiles 5-50 % filled (fc1: 9.05 rounds -> 10,
+    // proj / fc2: 2.26 -> 3).  The rows of the full rounds run on the big tile, the remaining rows as a second launch on 128x128 tiles
+    // (two workgroups per CU: a short round of quarter-size tiles).  Dense launches only (a row's address is base + m * pitch: the tail is the
+    // same descriptor with shifted pointers); every tile configuration accumulates in the same order, so the split leaves no trace in the bits.
+    const bool split_ok = (asplit || fvec) && d.conv_kh == 0 && d.shuffle_r == 0 && d.ks_rows == 0 && d.grp_rows == 0 && z == 1;
+    auto tail_rows = [&](int big_bm, int big_bn) -> int {   // rows [0, r) on the big tile (whole rounds), [r, M) on the small one; 0: no split
+        if (!split_ok) return 0;
+        const long long gx_ = (d.N + big_bn - 1) / big_bn, gy_ = (d.M + big_bm - 1) / big_bm, tiles_ = gx_ * gy_, full_ = tiles_ / cus;
+        if (full_ < 1 || tiles_ % cus == 0) return 0;
+        const long long r_ = full_ * cus / gx_ * big_bm;
+        return (r_ > 0 && r_ < d.M && d.M - r_ >= 128) ? (int)r_ : 0;
+    };
+    auto shifted = [&](const PpGemmDesc& src, int r0, int rows_) {   // rows [r0, r0 + rows_) of a dense launch as a launch of its own
+        PpGemmDesc t = src;
+        t.M = rows_;
+        const size_t eb_ = f16 ? 2 : 4;
+        if (t.A_hl) t.A_hl = (const char*)src.A_hl + (size_t)r0 * src.lda * eb_;
+        if (t.A) t.A = src.A + (size_t)r0 * src.lda;
+        if (t.C) t.C = src.C + (size_t)r0 * src.ldc;
+        if (t.C_hl) t.C_hl = (char*)src.C_hl + (size_t)r0 * src.ldc_h * eb_;
+        if (t.residual) t.residual = src.residual + (size_t)r0 * src.ldc;
+        if (t.residual2) t.residual2 = src.residual2 + (size_t)r0 * src.ldc;
+        if (asplit) t.a_hl_bytes = ((long long)(rows_ - 1) * src.lda + src.K) * (long long)eb_;
+        else if (fvec) (void)pp_gemm_f_ok(t);      // (recomputes the operand extents of the fp32 engine)
+        return t;
+    };
+    const PpGemmDesc* cur = &d;     // the descriptor `launch` works on
+    auto launch1 = [&](int cfg) {
+        const PpGemmDesc& d = *cur;
         if (asplit) {
             cfg = u_cfg(cfg);
             if (cfg == 6) launch_rc = pp_gemm_uh_launch(d, terms, cus, st);
@@ -1250,6 +1279,25 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             hipLaunchKernelGGL((gemm_kernel<true, 2, 3>), grid, dim3(256), 0, st, d);
         }
     };
+    auto launch = [&](int cfg) {
+        if (cfg == 9 || cfg == 10) {
+            const int big = cfg == 9 ? 5 : 4, r0 = tail_rows(256, cfg == 9 ? 256 : 128);
+            if (r0 == 0 || (big == 5 && d.N <= 128)) {
+                launch1(big);
+                return;
+            }
+            const PpGemmDesc head = shifted(d, 0, r0), tail = shifted(d, r0, d.M - r0);
+            cur = &head;
+            launch1(big);
+            if (launch_rc == PP_OK) {
+                cur = &tail;
+                launch1(asplit ? 0 : 3);        // 128x128, two workgroups per CU (pre-split engine: 0, fp32 engine: 3)
+            }
+            cur = &d;
+            return;
+        }
+        launch1(cfg);
+    };
     auto finish = [&]() { return launch_rc != PP_OK ? launch_rc : pp_last_launch(); };
     // Which block tile / occupancy is fastest depends on how the tile count fills the CUs (wave quantisation)
     // and on K; it is measured once per problem shape (timed launches of the same GEMM — idempotent
@@ -1257,6 +1305,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
     int cfg = fvec ? (d.N <= 64 ? 6 : 3) : (d.N <= 64 ? 2 : 0);
     if (const char* f = getenv("PP_GEMM_FORCE_CFG")) {  // tests: pin one kernel configuration
         const int fc = atoi(f);
+        if ((fc == 9 || fc == 10) && (asplit || fvec)) {
+            launch(fc);
+            return finish();
+        }
         if (fc >= 0 && fc <= 8 && (asplit || fc <= 2 || (fvec && fc <= 7))) {
             launch(fc);
             return finish();
@@ -1286,7 +1338,8 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             PP_CHECK_HIP(hipEventCreate(&e1));
             float bt = 1e30f;
             int bc = 0;
-            int cands[8], nc = 0;
+            int cands[12], nc = 0;
+            static const bool tail_on = [] { const char* e = getenv("PP_GEMM_TAIL_SPLIT"); return !(e && e[0] == '0'); }();
             if (asplit) {
                 // the 128-row tiles always; the 256-row ones for problems that give at least half the chip a tile of theirs
                 const long long t4 = (long long)((d.M + 255) / 256) * ((d.N + 127) / 128), t5 = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256);
@@ -1295,6 +1348,8 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                 if (t4 >= cus / 2) cands[nc++] = 4;
                 if (t5 >= cus / 2 && d.N > 128) cands[nc++] = 5;
                 if (t5 >= cus / 2 && d.N > 128 && h_shape) cands[nc++] = 6;
+                if (tail_on && d.N > 128 && tail_rows(256, 256)) cands[nc++] = 9;
+                if (tail_on && tail_rows(256, 128)) cands[nc++] = 10;
             } else if (fvec) {
                 const long long t4 = (long long)((d.M + 255) / 256) * ((d.N + 127) / 128), t5 = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256);
                 cands[nc++] = 6;
@@ -1303,13 +1358,15 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                 if (t5 >= cus / 2 && d.N > 128) cands[nc++] = 5;
                 // 256x192: layers whose N wastes less of a 192-wide tile than of a 128-wide one (the decoder's 192-channel maps)
                 if ((d.N + 191) / 192 * 192 - d.N < (d.N + 127) / 128 * 128 - d.N && (long long)((d.M + 255) / 256) * ((d.N + 191) / 192) >= cus / 2) cands[nc++] = 7;
+                if (tail_on && d.N > 128 && tail_rows(256, 256)) cands[nc++] = 9;
+                if (tail_on && d.N > 64 && tail_rows(256, 128)) cands[nc++] = 10;
             } else {
                 for (int c = 0; c < (vec ? 3 : 2); ++c) cands[nc++] = vec ? c : (c == 0 ? 0 : 2);
             }
             // Round-robin: every round times one burst of four back-to-back launches of EACH candidate, and a candidate keeps
             // its best burst.  (Timing the candidates one after the other ranked them by the clock the chip happened to hold:
             // the first ones ran on a cool chip, and configurations within ~5-10 % changed places from run to run.)
-            float ms[8];
+            float ms[12];
             for (int i = 0; i < nc; ++i) {
                 ms[i] = 1e30f;
                 launch(cands[i]);  // warm
@@ -1363,11 +1420,14 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
         gp->shape[gp->count][1] = d.N;
         gp->shape[gp->count][2] = d.K;
         gp->shape[gp->count][3] = d.conv_kh;
+        const int cfg_ = cfg;
+        cfg = cfg == 9 ? 5 : cfg == 10 ? 4 : cfg;     // (a tail split is recorded under its big tile; the tail's share of the time rides along)
         gp->shape[gp->count][4] = asplit ? ((!pp_gemm_u_vec_ok(d) && u_cfg(cfg) != 2) ? 0 : u_cfg(cfg)) : cfg;   // (element-wise epilogue: the small tiles)
         // pre-split kernels: the A-delivery mode; the others: 8 + (vector loads) + 2 (f16x3 on the fly) — bench.py names the instantiation
         gp->shape[gp->count][5] = asplit ? (u_cfg(cfg) == 6 ? 1 : pp_gemm_u_mode(d, terms))
                                          : (fvec && cfg >= 3 ? 16 + pp_gemm_f_mode(d) : 8 + (vec ? 1 : 0) + (split ? 2 : 0));
         gp->count++;
+        cfg = cfg_;
     }
     return finish();
 }

@@ -501,6 +501,33 @@ def test_winograd4_3x3_of_the_f16x3_engine(monkeypatch, engine_precision, B, cin
 
 
 @gpu
+def test_tail_split_launches_equal_the_single_launch_bitwise(monkeypatch, engine_precision):
+    """Configurations 9 / 10 of pp_gemm (round 6): the rows of the whole rounds of a persistent launch on the 256x256 / 256x128 tile, the
+    remaining rows as a second launch on 128x128 tiles (the ViT linears at M = 49 344 leave their last round of 256-row tiles 5-50 % filled).
+    Same bits as the single launch — fp32 output with residual and LayerScale, operand output, both engines."""
+    from picopose_amd import ops
+
+    g = torch.Generator().manual_seed(21)
+    M, K, N = 256 * 100 + 77, 256, 768          # 101 x 3 tiles of 256 x 256: one whole round of 256 slots + 47 tiles
+    x = torch.randn(M, K, generator=g).cuda()
+    w, b = (torch.randn(N, K, generator=g) / 16).cuda(), torch.randn(N, generator=g).cuda()
+    gam, res = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    outs = []
+    for cfg in ("5", "9", "10", "4"):
+        monkeypatch.setenv("PP_GEMM_FORCE_CFG", cfg)
+        o = [ops.linear(x, w, b, act="gelu", gamma=gam, residual=res)]
+        if engine_precision != "f32":
+            sp = ops.linear(ops.Split(ops.split_activation(x, 1, M, K, 0, K)), w, b, act="relu", out_split=True)
+            o.append(sp.hl)
+        outs.append(o)
+    for o in outs[1:]:
+        for a_, b_ in zip(o, outs[0]):
+            assert torch.equal(a_, b_)
+    ref = res.cpu() + gam.cpu() * F.gelu(F.linear(x.cpu(), w.cpu(), b.cpu()))
+    _close(outs[0][0], ref)
+
+
+@gpu
 def test_presplit_kernels_agree_bitwise_across_tile_configurations(monkeypatch, engine_precision):
     """The three pre-split kernels (128x128, 128x64, 256x128 LDS-DMA) walk K in the same order and accumulate the
     same way, so the value of an output element does not depend on which one the autotuner picks for a shape —
