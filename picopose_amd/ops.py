@@ -69,7 +69,7 @@ def saturation_word(device=None):
     return w
 
 
-def saturation_error(what="this forward"):
+def saturation_error(what="a forward since the last check"):
     return _lib.PicoPoseHipError(
         f"an f16x3 / f16 operand saturated in {what}: an activation reached the fp16 range of the engine's operand format (|x| >= 16376; "
         "Winograd-transformed maps: >= 10480) and was clamped — the results of this batch are wrong.  Run this network with "

@@ -104,7 +104,7 @@ def _check_sat_row(host, P):
         from .. import ops
 
         ops.saturation_word().zero_()
-        raise ops.saturation_error("the forward whose poses were just read")
+        raise ops.saturation_error("a forward since the saturation word was last read (sticky: normally the forward whose poses were just read)")
     return host[:P]
 
 

@@ -16,3 +16,19 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _fresh_saturation_word(request):
+    """The operand-saturation word (picopose_amd/ops.py) is STICKY and process-wide: a test that drives an engine with out-of-range values
+    (plain random weights, deliberately huge inputs) and never reads its poses would leave it set for the next test that does.  GPU tests
+    start with a clear word; nothing here touches the GPU in the CPU suite."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import torch
+
+        if torch.cuda.is_available():
+            from picopose_amd import ops
+
+            if ops._sat_words:
+                ops.saturation_raised()
+    yield
