@@ -664,14 +664,20 @@ def main():
                                                             for b in range(Bl)]).to(bank_dtype)
         eps = [ep, ep_b] if ep_b is not None else [ep, ep]
 
-        def forward(mark=None, i=0):
+        seq = [0]       # index of the next forward: batch seq % 2, look-ahead = batch (seq + 1) % 2 — EVERY call continues the alternation, so the
+        #               extra (untimed, profiled) steps after the timed region find their query levels stashed like the timed ones
+
+        def forward(mark=None, i=None):
             if sharded:
                 return sharded_forward(net, ep, bank, N, hyp=5, mark=mark)
+            i = seq[0] if i is None else i
+            seq[0] = i + 1
             # a serving loop knows its next batch: its query crops ride in this batch's template-side ViT pass (Net.forward_test)
             cur, nxt = eps[i % 2], eps[(i + 1) % 2]
             return net(cur, 5, next_real_rgb=nxt["real_rgb"]) if a.prefetch_query else net(cur, 5)
 
-        def step(i=0):
+        def step(i=None):
+            i = seq[0] if i is None else i
             outs = forward(i=i)
             return outs, pnp_for_outputs(outs, eps[i % 2]["real_K"])            # PnP/RANSAC + D2H of the poses
 
@@ -695,6 +701,8 @@ def main():
             torch.cuda.synchronize()
     for w_ in range(a.warmup):
         out = step() if kind == "stage1" else step(w_ + a.warmup % 2)     # (the warm-up ends on batch 1: the timed loop starts on batch 0 with its look-ahead in place)
+    if kind != "stage1" and a.warmup == 0 and not sharded:
+        seq[0] = 0
     torch.cuda.synchronize()
     L = _lib.lib()
     # stage-1 workloads: the roofline kernel IS the step, so its launch is bracketed by HIP events inside the timed steps
@@ -754,6 +762,7 @@ def main():
         # one more untimed step with an event pair around every GEMM launch, and around the PnP launch
         _lib.check(L.pp_prof_gemm_enable(8192), "pp_prof_gemm_enable")
         net.keep_stage3 = True
+        fast_idx = seq[0]
         outs = forward()
         net.keep_stage3 = False
         torch.cuda.synchronize()
@@ -787,7 +796,7 @@ def main():
             n0, ops.CHECK_SATURATION = ops.saturation_checks, True
             forward()
             ops.CHECK_SATURATION, sat_checked = False, ops.saturation_checks - n0
-        args = pnp_inputs(outs, ep["real_K"])
+        args = pnp_inputs(outs, eps[fast_idx % 2]["real_K"] if not sharded else ep["real_K"])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         pnp_launch(*args)
         torch.cuda.synchronize()
@@ -795,7 +804,7 @@ def main():
         pnp_launch(*args)
         e1.record()
         torch.cuda.synchronize()
-        rot, tvec, ratio, ok, npts = pnp_for_outputs(outs, ep["real_K"], return_npts=True)
+        rot, tvec, ratio, ok, npts = pnp_for_outputs(outs, eps[fast_idx % 2]["real_K"] if not sharded else ep["real_K"], return_npts=True)
         pnp = {"problems": int(npts.size), "valid_points_mean": float(npts.mean()), "valid_points_min": int(npts.min()),
                "valid_points_max": int(npts.max()), "kernel_ms": e0.elapsed_time(e1), "success_rate": float(ok.mean()),
                "inliers_ratio_mean": float(ratio.mean()), "iterations": 150, "reprojection_px": 2.0,
@@ -864,14 +873,14 @@ def main():
             ops.PRECISION, net.match_mode = "f32", "exact"
             net.keep_stage3 = True
             for j_ in range(2):
-                xo = step(j_)
+                xo = step(fast_idx + 1 + j_)
             torch.cuda.synchronize()
-            x_steps = 5     # (odd: the last step is batch 0, the batch `fast` was computed on)
+            x_steps = 6     # (even, starting one past `fast_idx`: the last step runs the batch `fast` was computed on)
             xm = [torch.cuda.Event(enable_timing=True) for _ in range(x_steps + 1)]
             t1 = time.perf_counter()
             xm[0].record()
             for i in range(x_steps):
-                xo = step(i)
+                xo = step(fast_idx + 1 + i)
                 xm[i + 1].record()
             torch.cuda.synchronize()
             x_dt = (time.perf_counter() - t1) / x_steps
@@ -882,11 +891,11 @@ def main():
                 ops.WINOGRAD = False
                 try:
                     for j_ in range(2):
-                        step(j_)
+                        step()
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
                     for j_ in range(4):
-                        step(j_)
+                        step()
                     torch.cuda.synchronize()
                     xd_dt = (time.perf_counter() - t1) / 4
                 finally:
