@@ -1339,7 +1339,7 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             float bt = 1e30f;
             int bc = 0;
             int cands[12], nc = 0;
-            static const bool tail_on = [] { const char* e = getenv("PP_GEMM_TAIL_SPLIT"); return !(e && e[0] == '0'); }();
+            static const bool tail_on = [] { const char* e = getenv("PP_GEMM_TAIL_SPLIT"); return e && e[0] == '1'; }();   // (opt-in: measured neutral on the step, profiles/r06/README.md)
             if (asplit) {
                 // the 128-row tiles always; the 256-row ones for problems that give at least half the chip a tile of theirs
                 const long long t4 = (long long)((d.M + 255) / 256) * ((d.N + 127) / 128), t5 = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256);

@@ -45,6 +45,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define PP_STUDY_OFF(x) (x)
 #endif
 
+// tile rows per band of the persistent tile walk (pp_tile_rc_g) for the ONE-term (h format) kernels: with 2-byte operands a band of 4 tile rows
+// re-reads the weight columns twice as often per operand byte as the hl kernels do (study switch; profiles/r06/README.md)
+#ifndef PP_U1_BAND_ROWS
+#define PP_U1_BAND_ROWS 4
+#endif
+
 template <int BM_, int BN_, int WM_, int WN_, int S_, int OCC_, int PREF_ = 0, int B3_ = 0>
 struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, S = S_, OCC = OCC_;
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
 #define PP_U_SETUP(TILE)                                                                                             \
     {                                                                                                                \
         int tr_, tc_;                                                                                                \
-        pp_tile_rc((TILE), gx, gy, tr_, tc_);                                                                        \
+        pp_tile_rc_g((TILE), gx, gy, 8, TERMS == 1 ? PP_U1_BAND_ROWS : 4, tr_, tc_);                                                                        \
         const int m0_ = tr_ * T::BM, n0_ = tc_ * T::BN;                                                              \
         _Pragma("unroll") for (int j = 0; j < PA; ++j) {                                                             \
             const int m = m0_ + (j * NW + w) * 8 + lr;                                                               \
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
                 f0 = f1;   // an odd K tile count: the next tile's first fragments move to the set every tile starts from
             }
             int tr, tc;
-            pp_tile_rc(tile, gx, gy, tr, tc);
+            pp_tile_rc_g(tile, gx, gy, 8, TERMS == 1 ? PP_U1_BAND_ROWS : 4, tr, tc);
             const int mw = tr * T::BM + wr * T::TM, nw = tc * T::BN + wc * T::TN;
 #ifdef PP_STUDY_NOEPI
             {
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(T::NW * 64, T::OCC) void pp_gemm_u_kernel(const PpG
         }
         // epilogue of this tile; the ring keeps receiving the next tile meanwhile (fa0 / fb0 already hold its first fragments)
         int tr, tc;
-        pp_tile_rc(tile, gx, gy, tr, tc);
+        pp_tile_rc_g(tile, gx, gy, 8, TERMS == 1 ? PP_U1_BAND_ROWS : 4, tr, tc);
         const int mw = tr * T::BM + wr * T::TM, nw = tc * T::BN + wc * T::TN;
 #ifdef PP_STUDY_NOEPI   // (timing study builds only: the K loop alone; one store keeps the accumulators alive)
         {
@@ -762,7 +768,7 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_uh_kernel(const PpGemmDesc d, 
 #define PP_H_SETUP(TILE)                                                                                             \
     {                                                                                                                \
         int tr_, tc_;                                                                                                \
-        pp_tile_rc((TILE), gx, gy, tr_, tc_);                                                                        \
+        pp_tile_rc_g((TILE), gx, gy, 8, TERMS == 1 ? PP_U1_BAND_ROWS : 4, tr_, tc_);                                                                        \
         const int m0_ = tr_ * H_BM, n0_ = tc_ * H_BN;                                                                \
         abase = (unsigned)((long long)m0_ * d.lda * EB);                                                             \
         bbase = (unsigned)((long long)n0_ * d.ldb * EB);                                                             \
@@ -959,7 +965,7 @@ __global__ __launch_bounds__(512, 1) void pp_gemm_uh_kernel(const PpGemmDesc d, 
 #undef PP_H_STEP
         {
             int tr, tc;
-            pp_tile_rc(tile, gx, gy, tr, tc);
+            pp_tile_rc_g(tile, gx, gy, 8, TERMS == 1 ? PP_U1_BAND_ROWS : 4, tr, tc);
             const int mw = tr * H_BM + wr * 128, nw = tc * H_BN + wc * 64;
             if (VEC) epilogue_wave16<MI, NJ, TERMS>(d, descale, acc, mw, nw, lane);
             else epilogue_scalar16<MI, NJ, TERMS>(d, descale, acc, mw, nw, lane);

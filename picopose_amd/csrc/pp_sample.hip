@@ -379,11 +379,12 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const void* __
                     *(f4*)((_Float16*)rowp + 8 * part) = v;
                     return;
                 }
+                // (staging into LDS, not an operand buffer: the same maps' saturation is reported by the epilogue that wrote their operand form)
                 _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
-                pp_split_f16_chk(v.x, h0, l0);
-                pp_split_f16_chk(v.y, h1, l1);
-                pp_split_f16_chk(v.z, h2, l2);
-                pp_split_f16_chk(v.w, h3, l3);
+                pp_split_f16(v.x, h0, l0);
+                pp_split_f16(v.y, h1, l1);
+                pp_split_f16(v.z, h2, l2);
+                pp_split_f16(v.w, h3, l3);
                 const h4_t hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
                 _Float16* g8 = (_Float16*)rowp + 16 * (part >> 1) + 4 * (part & 1);   // channels 4 part .. + 3 of group part / 2
                 *(h4_t*)g8 = hi;
