@@ -451,6 +451,13 @@ int pp_winograd4_weight_f32(const float* w, int Cout, int Cin, int ldw, float* V
 int pp_winograd4_output(const float* Y, int B, int H, int W, int Cout, const float* bias, int act, const float* residual, const float* residual2,
                         float* out, int ldc, void* out_hl, int ld_h, int c_relu, long long P_pad, void* stream);
 
+/* Output transform of a Winograd F(4x4, 3x3) layer CHAINED into the input transform of the next one (conv 3x3 -> ReLU -> conv 3x3,
+ * raft_decoder.py:251-289): Y (36, P_pad, C) fp32 of the first layer -> U_hl (36, P_pad, C) hl operand of B^T relu'(A^T Y A + bias) B / 16 of the
+ * second, the hidden map never stored; bit-identical to pp_winograd4_output (operand output, c_relu) followed by pp_winograd4_input_hl.
+ * W in {16, 32, 64}, H % 4 == 0, C % 32 == 0; act none / ReLU / LeakyReLU, then (c_relu) the consumer's input ReLU. */
+int pp_winograd4_chain(const float* Y, int B, int H, int W, int C, const float* bias, int act, int c_relu, void* U_hl, long long P_pad,
+                       void* stream);
+
 /* Sticky operand-saturation word.  The f16x3 / f16 operand formats clamp at the fp16 range (|4 x| >= 65504): a clamped term is finite but
  * WRONG.  With a device word registered here, every kernel that writes operand terms ORs bit 0 into it when a term hit the clamp (one
  * atomic per wave that saw one; nothing when none did) — the host reads the word together with its results (no extra synchronisation)

@@ -436,6 +436,124 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     wino_note_sat(!(top < 65504.f), sat);
 }
 
+// ---- output transform of layer k CHAINED into the input transform of layer k + 1 (round 6) ------------------------------------------------
+// The decoder's heads are conv 3x3 -> ReLU -> conv 3x3 (raft_decoder.py:251-289), both by F(4x4, 3x3): the hidden map h = relu(A^T Y0 A + b)
+// would be written as an operand (4 bytes per element) by the output transform and read back by the next input transform.  Here it never
+// reaches HBM: a workgroup owns (image, 32-channel slice) and walks the image's tile rows; half of its threads transform tile row r of Y0
+// into four pixel rows of h — rounded to the operand's 22 bits exactly as the operand store would, so the result is BIT-IDENTICAL to the two
+// separate kernels — in an LDS ring of four tile rows, the other half takes tile row r - 2 (whose one-pixel halo above and below is in the
+// ring by then) through B^T d B and writes U1.  One barrier per tile row.  Bytes per layer pair: Y0 once + U1 once instead of + 2 x h.
+constexpr int CHN_PX = 36;     // floats per staged pixel: 32 channels + 4 (the 16-byte accesses of a tile's pixels fall on different banks)
+// a frequency index the optimiser cannot see through: inside the tile-row loop the 72 buffer descriptors (36 of Y, 36 of U) are loop
+// invariants, and hipcc hoisted all of them — 288 scalar registers, 460 spilled into vector lanes
+__device__ __forceinline__ int wino_opaque(int xi) {
+    int k;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(k) : "s"(xi));
+    return k;
+}
+
+template <int W>
+__global__ __launch_bounds__(2 * (W / 4) * 8) void wino4_chain_kernel(const float* __restrict__ Y, int H, int C, const float* __restrict__ bias,
+                                                                       int act, int c_relu, _Float16* __restrict__ U, long long Pp, unsigned* sat) {
+    constexpr int TW = W / 4, NI = TW * 8;                  // tiles per tile row; work items (tile, channel quad) per tile row
+    constexpr int SLOT = 4 * W * CHN_PX;                    // floats per ring slot (one tile row = 4 pixel rows)
+    extern __shared__ __attribute__((aligned(16))) float chs[];
+    const int th = H >> 2, nsl = C >> 5;
+    const int b = blockIdx.x / nsl, cs = blockIdx.x - b * nsl;
+    const int half = threadIdx.x / NI, it = threadIdx.x - half * NI, tx = it >> 3, q = it & 7;
+    const int c = cs * 32 + 4 * q;                          // first of this thread's 4 channels
+    const unsigned long long blk = (unsigned long long)Pp * C * 4;
+    const f4 bv = bias ? *(const f4*)(bias + c) : f4{0.f, 0.f, 0.f, 0.f};
+    const float slope = act == PP_ACT_RELU ? 0.f : (act == PP_ACT_LEAKY01 ? 0.1f : 1.f);
+    const int gcol = (c >> 3) << 4, par = q & 1;
+    const float hfloor = c_relu ? 0.f : -INFINITY;          // the consumer's input ReLU folded into the operand, as pp_winograd4_output does
+    float top = 0.f;
+    for (int r = 0; r < th + 2; ++r) {
+        if (half == 0 && r < th) {
+            // ---- tile (b, r, tx): h(4x4) = relu'(A^T Y A + bias), as the operand's value 4 h (hi + lo), into ring slot r % 4
+            const long long p = ((long long)b * th + r) * TW + tx;
+            const unsigned yoff = (unsigned)((p * C + c) * 4);
+            f4 z[4][6];
+#pragma unroll
+            for (int bb = 0; bb < 6; ++bb) {
+                f4 y[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) y[a] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wino_block_rsrc(Y, wino_opaque(6 * a + bb), blk), yoff, 0, 0));
+                PP_W4_AT(y[0], y[1], y[2], y[3], y[4], y[5], z[0][bb], z[1][bb], z[2][bb], z[3][bb])
+            }
+            float* slot = chs + (r & 3) * SLOT;
+#pragma unroll
+            for (int oy = 0; oy < 4; ++oy) {
+                f4 o[4];
+                PP_W4_AT(z[oy][0], z[oy][1], z[oy][2], z[oy][3], z[oy][4], z[oy][5], o[0], o[1], o[2], o[3])
+#pragma unroll
+                for (int ox = 0; ox < 4; ++ox) {
+                    f4 v = o[ox] + bv, x4, f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = fmaxf(v[e], v[e] * slope);
+                        x4[e] = fmaxf(v[e] * PP_A_SCALE, hfloor);
+                    }
+                    hf4 hi, lo;
+                    wino_split4(x4, hi, lo, top);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = (float)hi[e] + (float)lo[e];     // what the operand would hold: exact
+                    *(f4*)(slot + ((oy * W) + 4 * tx + ox) * CHN_PX + 4 * q) = f;
+                }
+            }
+        }
+        if (half == 1 && r >= 2) {
+            // ---- tile (b, R = r - 2, tx): U = B^T d B / 64 of the 6x6 pixels around it (rows 4 R - 1 .. 4 R + 4 of h: ring slots R - 1, R, R + 1)
+            const int R = r - 2;
+            f4 t[6][6];
+#pragma unroll
+            for (int dx = 0; dx < 6; ++dx) {
+                f4 d[6];
+                const int px = 4 * tx - 1 + dx;
+#pragma unroll
+                for (int dy = 0; dy < 6; ++dy) {
+                    const int g = 4 * R - 1 + dy;                      // pixel row of the image
+                    // (zero padding: the read runs on a clamped pixel and is masked afterwards — no branch per pixel)
+                    const int gc = min(max(g, 0), H - 1), pc = min(max(px, 0), W - 1);
+                    f4 v = *(const f4*)(chs + ((gc >> 2) & 3) * SLOT + ((gc & 3) * W + pc) * CHN_PX + 4 * q);
+                    if (!(g >= 0 && g < H && px >= 0 && px < W)) v = f4{0.f, 0.f, 0.f, 0.f};
+                    d[dy] = v;
+                }
+                PP_W4_BT(d[0], d[1], d[2], d[3], d[4], d[5], t[0][dx], t[1][dx], t[2][dx], t[3][dx], t[4][dx], t[5][dx])
+            }
+            const long long p = ((long long)b * th + R) * TW + tx;
+            const unsigned uoff = (unsigned)((p * 2 * C + gcol + par * 8) * 2);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                f4 u[6];
+                PP_W4_BT(t[a][0], t[a][1], t[a][2], t[a][3], t[a][4], t[a][5], u[0], u[1], u[2], u[3], u[4], u[5])
+#pragma unroll
+                for (int bb = 0; bb < 6; ++bb) {
+                    hf4 hi, lo;
+                    wino_split4(u[bb] * (1.f / 64.f), hi, lo, top);
+                    __builtin_amdgcn_raw_buffer_store_b128(wino_pair_pack(par, hi, lo), wino_block_rsrc(U, wino_opaque(6 * a + bb), blk), uoff, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    wino_note_sat(!(top < 65504.f), sat);
+}
+
+template <int W>
+static int wino4_chain_launch(const float* Y, int B, int H, int C, const float* bias, int act, int c_relu, void* U, long long Pp, hipStream_t st) {
+    constexpr int threads = 2 * (W / 4) * 8;
+    const size_t lds = (size_t)4 * 4 * W * CHN_PX * sizeof(float);
+    static signed char attr[PP_MAX_DEVICES];
+    signed char& ok = attr[pp_cur_device()];
+    if (ok == 0)
+        ok = hipFuncSetAttribute((const void*)wino4_chain_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
+    if (ok < 0) return PP_ELAUNCH;
+    hipLaunchKernelGGL(wino4_chain_kernel<W>, dim3((unsigned)(B * (C / 32))), dim3(threads), lds, st, Y, H, C, bias, act, c_relu, (_Float16*)U, Pp,
+                       pp_saturation_word());
+    return pp_last_launch();
+}
+
 static inline int grid8_of(long long n) {   // blocks of 256 threads, a multiple of 8 (wino_logical_block)
     const long long g = ((n + 255) / 256 + 7) / 8 * 8;
     return (int)g;
@@ -520,6 +638,18 @@ int pp_winograd4_output(const float* Y, int B, int H, int W, int Cout, const flo
     hipLaunchKernelGGL(wino4_output_kernel, dim3(grid8_of(total)), dim3(256), 0, (hipStream_t)stream, Y, B, H, W, Cout, bias, act, residual, residual2,
                        out, ldc, (_Float16*)out_hl, ld_h, c_relu, P_pad, pp_saturation_word());
     return pp_last_launch();
+}
+
+
+int pp_winograd4_chain(const float* Y, int B, int H, int W, int C, const float* bias, int act, int c_relu, void* U_hl, long long P_pad, void* stream) {
+    if (!Y || !U_hl || B <= 0 || H < 4 || (H & 3) || (W != 16 && W != 32 && W != 64) || C <= 0 || (C & 31)) return PP_EINVAL;
+    if (act != PP_ACT_NONE && act != PP_ACT_RELU && act != PP_ACT_LEAKY01) return PP_EINVAL;
+    if (P_pad < (long long)B * (H / 4) * (W / 4) || P_pad * C * 4 >= 0xFFFFFF00LL || (long long)B * (C / 32) >= (1LL << 31)) return PP_EINVAL;
+    if (((uintptr_t)Y | (uintptr_t)U_hl | (uintptr_t)bias) & 15) return PP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (W == 64) return wino4_chain_launch<64>(Y, B, H, C, bias, act, c_relu, U_hl, P_pad, st);
+    if (W == 32) return wino4_chain_launch<32>(Y, B, H, C, bias, act, c_relu, U_hl, P_pad, st);
+    return wino4_chain_launch<16>(Y, B, H, C, bias, act, c_relu, U_hl, P_pad, st);
 }
 
 }  // extern "C"

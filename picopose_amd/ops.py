@@ -524,7 +524,7 @@ def split_image(x, relu=False):
 
 def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residual=None, out=None, cin=None,
            residual2=None, out_split=False, split_relu=False, also_split=None, hl_into=None, cache_weight=True, in_cols=None,
-           alpha_dev=(), wino=False):
+           alpha_dev=(), wino=False, wino_next=False):
     """NHWC convolution. x (B,H,W,Cx) (channel-contiguous, may be a channel slice: cin <= Cx stride) or a Split
     carrying .image (a pre-split operand: no split pass, the producer has already applied any input ReLU),
     wp (Cout, k*k*cin) from pack_conv_weight.  out may be a channel slice of a wider NHWC buffer.
@@ -546,7 +546,7 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     if isinstance(x, WinoInput4):     # the shared F(4x4, 3x3) input of several 3x3 convolutions (f16x3 engine)
         B, H, W, Cx = x.geom
         assert ksize == 3 and stride == 1 and pad == 1 and cin in (None, Cx) and wp.shape[1] == 9 * Cx and hl_into is None and not relu_in
-        return _conv3x3_winograd4(x, wp, bias, B, H, W, Cx, wp.shape[0], act, residual, residual2, out, out_split, split_relu, also_split)
+        return _conv3x3_winograd4(x, wp, bias, B, H, W, Cx, wp.shape[0], act, residual, residual2, out, out_split, split_relu, also_split, wino_next)
     xs = x if isinstance(x, Split) else None
     a_ptr = None
     if xs is not None and in_cols is not None:
@@ -598,7 +598,7 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
             and act in (None, "none", "relu", "leaky01") and wp.dtype == torch.float32 and wp.is_contiguous()
             and _winograd4_ok(B, H, W, cin, Cout)):
         src = xs if a_ptr is None else (xs, in_cols[0])
-        return _conv3x3_winograd4(src, wp, bias, B, H, W, cin, Cout, act, residual, residual2, out, out_split, split_relu, also_split)
+        return _conv3x3_winograd4(src, wp, bias, B, H, W, cin, Cout, act, residual, residual2, out, out_split, split_relu, also_split, wino_next)
     wargs = _weight_args(wp, ksize * ksize * cin, cache_weight)   # (cache_weight=False: a transient packed weight of the training graph)
     presplit = xs is not None or ("B_hl" in wargs and (Cout > 64 or ksize > 1)
                                   and _can_presplit(x, ksize * ksize * cin, cin, ld_in, x.stride(0)) and B * H * W * cin < 2 ** 30)
@@ -810,7 +810,10 @@ def _winograd4_input(src_ptr, ld_x, B, H, W, cin, dev):
     return U
 
 
-def _conv3x3_winograd4(x, wp, bias, B, H, W, cin, Cout, act, residual, residual2, out, out_split, split_relu, also_split):
+WINO4_CHAIN = os.environ.get("PP_WINOGRAD4_CHAIN", "1") != "0"
+
+
+def _conv3x3_winograd4(x, wp, bias, B, H, W, cin, Cout, act, residual, residual2, out, out_split, split_relu, also_split, chain_next=False):
     """3x3 / stride 1 / pad 1 on an operand image by Winograd F(4x4, 3x3): input transform (operand -> operand), 36 dense products on the
     pre-split engine as grouped launches, output transform with bias / activation (/ residuals) into an fp32 map and / or the next
     layer's operand.  x: a Split with .image, (Split, col0) for a channel slice of it, or its WinoInput4."""
@@ -835,6 +838,13 @@ def _conv3x3_winograd4(x, wp, bias, B, H, W, cin, Cout, act, residual, residual2
                    M=Pp, N=Cout, K=cin, lda=cin, ldb=cin, ldc=Cout, prec=_PREC["f16x3"], batch0=n, a_bs0=Pp * cin, b_bs0=Cout * cin,
                    c_bs0=Pp * Cout, alpha=PP_A_SCALE / WINO4_U_SCALE, _keep=(U, vhl, V)))
     ret, hl_t, ldc = None, None, 0
+    if (chain_next and WINO4_CHAIN and out_split and out is None and residual is None and residual2 is None and W in (16, 32, 64) and Cout % 32 == 0
+            and _winograd4_ok(B, H, W, Cout, Cout)):
+        # the next layer's Winograd input straight from this layer's products: h = act(A^T Y A + bias) lives in LDS only
+        U1 = Split((torch.empty if Pp == P else torch.zeros)(36 * Pp, 2 * Cout, dtype=torch.float16, device=dev), 2)
+        _lib.check(L.pp_winograd4_chain(_p(Y), B, H, W, Cout, _p(bias), ACT[act], int(split_relu), _p(U1.hl), Pp, _lib.stream_ptr()), "pp_winograd4_chain")
+        _chk(U1.hl, "pp_winograd4_chain")
+        return WinoInput4(U1, (B, H, W, Cout), None)
     if out_split and out is None and residual is None and residual2 is None:
         hl_t = Split.empty(B * H * W, Cout, dev)
         hl_t.image = (B, H, W)

@@ -490,6 +490,15 @@ def test_winograd4_3x3_of_the_f16x3_engine(monkeypatch, engine_precision, B, cin
     assert isinstance(sh, ops.WinoInput4)
     for wq in (wp, w2p):
         assert torch.equal(ops.conv2d(sh, wq, b.cuda(), 3, pad=1, act="relu"), ops.conv2d(xs, wq, b.cuda(), 3, pad=1, act="relu", wino=True))
+    # conv -> ReLU -> conv with the first output transform CHAINED into the second input transform (the hidden map never stored): the
+    # same bits as the two separate kernels, with the consumer's ReLU folded in or not
+    w3p = ops.pack_conv_weight((torch.randn(64, cout, 3, 3, generator=g) / (cout * 9) ** 0.5).cuda())
+    for kw in (dict(act="relu"), dict(act="leaky01", split_relu=True), dict(act=None)):
+        ch = ops.conv2d(xs, wp, b.cuda(), 3, pad=1, out_split=True, wino=True, wino_next=True, **kw)
+        assert isinstance(ch, ops.WinoInput4) == (hw in (16, 32, 64) and cout % 32 == 0)
+        sep = ops.conv2d(xs, wp, b.cuda(), 3, pad=1, out_split=True, wino=True, **kw)
+        assert isinstance(sep, ops.Split)
+        assert torch.equal(ops.conv2d(ch, w3p, None, 3, pad=1, wino=True), ops.conv2d(sep, w3p, None, 3, pad=1, wino=True))
     # a grouped launch cut into several (32-bit byte offsets of the stacked blocks): the same bits
     one = ops.conv2d(xs, wp, b.cuda(), 3, pad=1, wino=True)
     monkeypatch.setattr(ops, "WINO4_GROUPS_PER_LAUNCH", 7)

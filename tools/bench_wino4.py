@@ -67,6 +67,13 @@ def main():
                                                                          hl_t.hl.data_ptr(), cout, 0, P, _lib.stream_ptr()), "out"), a.reps)
         t_g = t_shared - t_out
         fl = 2.0 * B * hw * hw * cout * 9 * cin
+        if cout % 32 == 0 and hw in (16, 32, 64):   # the chained output -> input transform against the two separate kernels (next layer: cout -> cout)
+            U1 = ops.Split(torch.empty(36 * P, 2 * cout, dtype=torch.float16, device="cuda"), 2)
+            t_ch = timed(lambda: _lib.check(_lib.lib().pp_winograd4_chain(Y.data_ptr(), B, hw, hw, cout, bias.data_ptr(), 1, 0, U1.hl.data_ptr(), P,
+                                                                          _lib.stream_ptr()), "chain"), a.reps)
+            t_in2 = timed(lambda: ops._winograd4_input(hl_t.hl.data_ptr(), cout, B, hw, hw, cout, xs.device), a.reps)
+            name = f"{name} | out+in {t_out + t_in2:.3f} chained {t_ch:.3f}"
+            del U1
         print(f"{name:22s} {t_d:10.3f} {t_w:9.3f} {t_in:7.3f} {t_g:7.3f} {t_out:7.3f} {fl / t_d / 1e9:11.1f} {fl / 4 / t_g / 1e9:9.1f}  {diff:.1e}", flush=True)
         del xs, sh, Y, hl_t, d, w
         torch.cuda.empty_cache()
