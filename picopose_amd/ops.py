@@ -811,6 +811,7 @@ def _winograd4_input(src_ptr, ld_x, B, H, W, cin, dev):
 
 
 WINO4_CHAIN = os.environ.get("PP_WINOGRAD4_CHAIN", "1") != "0"
+WINO4_CHAIN_WIDTHS = (32, 64)
 
 
 def _conv3x3_winograd4(x, wp, bias, B, H, W, cin, Cout, act, residual, residual2, out, out_split, split_relu, also_split, chain_next=False):
@@ -838,7 +839,8 @@ def _conv3x3_winograd4(x, wp, bias, B, H, W, cin, Cout, act, residual, residual2
                    M=Pp, N=Cout, K=cin, lda=cin, ldb=cin, ldc=Cout, prec=_PREC["f16x3"], batch0=n, a_bs0=Pp * cin, b_bs0=Cout * cin,
                    c_bs0=Pp * Cout, alpha=PP_A_SCALE / WINO4_U_SCALE, _keep=(U, vhl, V)))
     ret, hl_t, ldc = None, None, 0
-    if (chain_next and WINO4_CHAIN and out_split and out is None and residual is None and residual2 is None and W in (16, 32, 64) and Cout % 32 == 0
+    # (W = 16: the chain's one workgroup per (image, slice) is four tile rows long and loses to the two separate kernels, 0.121 vs 0.095 ms)
+    if (chain_next and WINO4_CHAIN and out_split and out is None and residual is None and residual2 is None and W in WINO4_CHAIN_WIDTHS and Cout % 32 == 0
             and _winograd4_ok(B, H, W, Cout, Cout)):
         # the next layer's Winograd input straight from this layer's products: h = act(A^T Y A + bias) lives in LDS only
         U1 = Split((torch.empty if Pp == P else torch.zeros)(36 * Pp, 2 * Cout, dtype=torch.float16, device=dev), 2)

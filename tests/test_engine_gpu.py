@@ -492,6 +492,7 @@ def test_winograd4_3x3_of_the_f16x3_engine(monkeypatch, engine_precision, B, cin
         assert torch.equal(ops.conv2d(sh, wq, b.cuda(), 3, pad=1, act="relu"), ops.conv2d(xs, wq, b.cuda(), 3, pad=1, act="relu", wino=True))
     # conv -> ReLU -> conv with the first output transform CHAINED into the second input transform (the hidden map never stored): the
     # same bits as the two separate kernels, with the consumer's ReLU folded in or not
+    monkeypatch.setattr(ops, "WINO4_CHAIN_WIDTHS", (16, 32, 64))       # (the product chains at 32 and 64 only: at 16 it is slower)
     w3p = ops.pack_conv_weight((torch.randn(64, cout, 3, 3, generator=g) / (cout * 9) ** 0.5).cuda())
     for kw in (dict(act="relu"), dict(act="leaky01", split_relu=True), dict(act=None)):
         ch = ops.conv2d(xs, wp, b.cuda(), 3, pad=1, out_split=True, wino=True, wino_next=True, **kw)
