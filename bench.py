@@ -885,6 +885,7 @@ def main():
             torch.cuda.synchronize()
             x_dt = (time.perf_counter() - t1) / x_steps
             x_ms = sorted(xm[i].elapsed_time(xm[i + 1]) for i in range(x_steps))
+            x_flow, x_cert = net.last_stage3[0].clone(), net.last_stage3[1].clone()     # (of the LAST timed exact step: the batch `fast` ran on)
             # ... and with every convolution DIRECT (the reference's operation count, ops.WINOGRAD off): 2 warm-up steps, 3 timed
             xd_dt = None
             if ops.WINOGRAD:
@@ -943,9 +944,9 @@ def main():
                      "f16x3_vs_exact": {
                          "pairs": int(same.numel()), "pairs_with_same_template": int(same.sum()),
                          "pred_poses_max_abs": float(dpose.max()) if any_same else None,
-                         "flow_max_abs_px": float((net.last_stage3[0] - fast["flow"]).abs()[flat].max()) if any_same else None,
+                         "flow_max_abs_px": float((x_flow - fast["flow"]).abs()[flat].max()) if any_same else None,
                          "flow_max_abs_value": float(fast["flow"].abs().max()),
-                         "certainty_logit_max_abs": float((net.last_stage3[1] - fast["cert"]).abs()[flat].max()) if any_same else None,
+                         "certainty_logit_max_abs": float((x_cert - fast["cert"]).abs()[flat].max()) if any_same else None,
                          "keypoint_slots_equal": float((xtar == fast["tar"]).all(-1)[same].float().mean()) if any_same else None,
                          "pnp_translation_max_abs_m": float(abs(xtvec - tvec)[both].max()) if both.any() else None,
                          "pnp_translation_median_abs_m": float(np.median(abs(xtvec - tvec)[both])) if both.any() else None,
