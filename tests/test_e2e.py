@@ -574,12 +574,33 @@ def test_sticky_saturation_word_is_set_by_every_producer_and_raised_with_the_pos
         "bilinear resize (operand output)": lambda t: ops.resize_bilinear(t.view(2, 16, 16, 256), 32, 32, out_split=True),
         "Winograd convolution (operand output)": lambda t: ops.conv2d(ops.split_image(img), wc * (1.0 if t is x else 4000.0), None, 3, pad=1, out_split=True, wino=True),
         "convolution epilogue (operand output)": lambda t: ops.conv2d(ops.split_image(img), wc * (1.0 if t is x else 4000.0), None, 3, pad=1, out_split=True),
+        # attention: 2 images x 4 heads x 64 (qkv = 768 columns of a (2 * 64, 768) matrix); a huge V entry reaches the output operand
+        "attention (operand output, fp32 qkv)": lambda t: ops.attention(qkv_of(t), 2, 64, 4, 64, out_split=True),
+        "attention (operand output, operand qkv)": lambda t: ops.attention(ops.Split(ops.split_activation(qkv_of(t) * (1.0 if t is x else 0.25), 1, 128, 768, 0, 768)),
+                                                                             2, 64, 4, 64, out_split=True) if t is x else ops.attention(
+            ops.Split(ops.split_activation(qkv_ok_big_v, 1, 128, 768, 0, 768)), 2, 64, 4, 64, out_split=True),
+        "warp (operand columns)": lambda t: ops.warp(t.view(2, 16, 16, 256), flow0, hl_into=(warp_tgt, 0)),
     }
+    qkv_base = torch.randn(128, 768, generator=g).cuda()
+
+    def qkv_of(t):
+        q_ = qkv_base.clone()
+        if t is not x:
+            q_[:, 512:] *= 1.0e4                    # the values V: the soft-max mixes them into every output row
+        return q_
+
+    qkv_ok_big_v = qkv_base.clone()
+    qkv_ok_big_v[:, 512:] *= 1.2e3                  # V in range as an operand (|4 v| < 65504) ... and so are its convex combinations: NOT reported
+    flow0 = torch.zeros(2, 16, 16, 2, device="cuda")
+    warp_tgt = ops.Split.empty(2 * 16 * 16, 256, "cuda")
     with torch.no_grad():
         for name, fn in cases.items():
             fn(x)
             assert not ops.saturation_raised(), f"{name}: a healthy input set the word"
             fn(big)
+            if name == "attention (operand output, operand qkv)":
+                assert not ops.saturation_raised(), "values inside the operand range set the word"
+                continue
             assert ops.saturation_raised(), f"{name}: a value beyond the fp16 range did not set the word"
             assert not ops.saturation_raised(), "the word was not reset"
         # a map in range as an operand (|4 x| < 65504) whose Winograd transform is not (|B^T d B| / 16 up to 6.25 |x|): reported by the transform
