@@ -133,10 +133,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
             }
             if (out_hl) {  // f16x3 operand of the output projection (obase is a multiple of 8)
                 _Float16 hh, ll;
-                pp_split_f16(a0, hh, ll);
+                pp_split_f16_chk(a0, hh, ll);
                 out_hl[2 * obase + pp_hl_col(d, 0)] = hh;
                 out_hl[2 * obase + pp_hl_col(d, 1)] = ll;
-                pp_split_f16(a1, hh, ll);
+                pp_split_f16_chk(a1, hh, ll);
                 out_hl[2 * obase + pp_hl_col(32 + d, 0)] = hh;
                 out_hl[2 * obase + pp_hl_col(32 + d, 1)] = ll;
             }
@@ -238,10 +238,10 @@ __global__ __launch_bounds__(WPB > 4 ? 64 * WPB : 256) __attribute__((amdgpu_wav
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 _Float16 hh, ll;
-                pp_split_f16(a[i], hh, ll);
+                pp_split_f16_chk(a[i], hh, ll);
                 qh[s][i] = hh;
                 ql[s][i] = ll;
-                pp_split_f16(c[i], hh, ll);
+                pp_split_f16_chk(c[i], hh, ll);
                 qh[s][4 + i] = hh;
                 ql[s][4 + i] = ll;
             }
@@ -354,10 +354,10 @@ __global__ __launch_bounds__(WPB > 4 ? 64 * WPB : 256) __attribute__((amdgpu_wav
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     _Float16 hh, ll;
-                    pp_split_f16(fk[it][i], hh, ll);
+                    pp_split_f16_chk(fk[it][i], hh, ll);
                     khh[i] = hh;
                     kll[i] = ll;
-                    pp_split_f16(fv[it][i], hh, ll);
+                    pp_split_f16_chk(fv[it][i], hh, ll);
                     vhh[i] = hh;
                     vll[i] = ll;
                 }
@@ -580,9 +580,9 @@ __global__ __launch_bounds__(WPB > 4 ? 64 * WPB : 256) __attribute__((amdgpu_wav
                 vf = (float)vp2[0] + (float)vp2[8];
             } else {
                 _Float16 hh, ll;
-                pp_split_f16(kp[(size_t)(Tm + r) * C3 + dd], hh, ll);
+                pp_split_f16_chk(kp[(size_t)(Tm + r) * C3 + dd], hh, ll);
                 kf = (float)hh + (float)ll;
-                pp_split_f16(vp[(size_t)(Tm + r) * C3 + dd], hh, ll);
+                pp_split_f16_chk(vp[(size_t)(Tm + r) * C3 + dd], hh, ll);
                 vf = (float)hh + (float)ll;
             }
             tk[idx] = kf;
