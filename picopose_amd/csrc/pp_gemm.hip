@@ -1339,7 +1339,10 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
             float bt = 1e30f;
             int bc = 0;
             int cands[12], nc = 0;
-            static const bool tail_on = [] { const char* e = getenv("PP_GEMM_TAIL_SPLIT"); return e && e[0] == '1'; }();   // (opt-in: measured neutral on the step, profiles/r06/README.md)
+            // tail-split candidates: pre-split engine opt-in (PP_GEMM_TAIL_SPLIT=1: measured neutral on the f16x3 step), fp32 engine on unless
+            // PP_GEMM_TAIL_SPLIT=0 (fc1 at M = 49 344: 7.18 -> 7.06 ms per burst; exact-mode step +0.5 %) — profiles/r06/README.md
+            static const int tail_env = [] { const char* e = getenv("PP_GEMM_TAIL_SPLIT"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+            const bool tail_on = tail_env == 1, tail_on_f = tail_env != 0;
             if (asplit) {
                 // the 128-row tiles always; the 256-row ones for problems that give at least half the chip a tile of theirs
                 const long long t4 = (long long)((d.M + 255) / 256) * ((d.N + 127) / 128), t5 = (long long)((d.M + 255) / 256) * ((d.N + 255) / 256);
@@ -1358,8 +1361,8 @@ int pp_gemm(const PpGemmDesc* desc, void* stream) {
                 if (t5 >= cus / 2 && d.N > 128) cands[nc++] = 5;
                 // 256x192: layers whose N wastes less of a 192-wide tile than of a 128-wide one (the decoder's 192-channel maps)
                 if ((d.N + 191) / 192 * 192 - d.N < (d.N + 127) / 128 * 128 - d.N && (long long)((d.M + 255) / 256) * ((d.N + 191) / 192) >= cus / 2) cands[nc++] = 7;
-                if (tail_on && d.N > 128 && tail_rows(256, 256)) cands[nc++] = 9;
-                if (tail_on && d.N > 64 && tail_rows(256, 128)) cands[nc++] = 10;
+                if (tail_on_f && d.N > 128 && tail_rows(256, 256)) cands[nc++] = 9;
+                if (tail_on_f && d.N > 64 && tail_rows(256, 128)) cands[nc++] = 10;
             } else {
                 for (int c = 0; c < (vec ? 3 : 2); ++c) cands[nc++] = vec ? c : (c == 0 ? 0 : 2);
             }
