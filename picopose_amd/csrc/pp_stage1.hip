@@ -1160,9 +1160,10 @@ static int stage1_run(const void* bank_, int bank_dtype, const float* query, con
     // persistent workgroups: 8 waves / whole templates / one per CU, or 4 waves / template halves / two per CU.  The 4-wave
     // shape issues twice the query copies (9 % slower per byte when the chip is full) but halves the work item: with fewer than
     // two items per CU (configs[1]: 336 items on 256 CUs) the tail round is shorter (36.4 vs 39.3 us).  PP_S1_WAVES=4|8 pins one.
+    constexpr int S1_F16_DEFAULT_WAVES = 8;      // (fp16-stored bank: see profiles/r06/README.md for the 4-wave measurement)
     const char* nw_env = getenv("PP_S1_WAVES");  // read per call: the tests run both shapes in one process
     const int nw_auto = B * N < 2 * cus ? 4 : 8;
-    const int nw = f16 ? 8 : (nw_env ? (atoi(nw_env) == 4 ? 4 : 8) : nw_auto);   // (the fp16 bank runs the 8-wave shape only)
+    const int nw = nw_env ? (atoi(nw_env) == 4 ? 4 : 8) : (f16 ? S1_F16_DEFAULT_WAVES : nw_auto);
     static signed char lds_state[PP_MAX_DEVICES];   // > 64 KB of dynamic LDS needs the opt-in, per device
     signed char& lds_ok = lds_state[pp_cur_device()];
     if (lds_ok == 0) {
@@ -1175,6 +1176,8 @@ static int stage1_run(const void* bank_, int bank_dtype, const float* query, con
                  set((const void*)s1_main<PP_MATCH_EXACT, 8>, Lay<8>::SMEM_BYTES) &&
                  set((const void*)s1_main<PP_MATCH_FAST, 8, _Float16>, Lay<8>::SMEM_BYTES) &&
                  set((const void*)s1_main<PP_MATCH_EXACT, 8, _Float16>, Lay<8>::SMEM_BYTES) &&
+                 set((const void*)s1_main<PP_MATCH_FAST, 4, _Float16>, Lay<4>::SMEM_BYTES) &&
+                 set((const void*)s1_main<PP_MATCH_EXACT, 4, _Float16>, Lay<4>::SMEM_BYTES) &&
                  set((const void*)s1_resolve<_Float16>, 10 * 2048 * (int)sizeof(float)) &&
                  set((const void*)s1_resolve<float>, 10 * 2048 * (int)sizeof(float))   // 10 * C floats, C <= 2048
                      ? 1 : -1;
@@ -1187,12 +1190,17 @@ static int stage1_run(const void* bank_, int bank_dtype, const float* query, con
 #define S1_LAUNCH(MODE_, NW_)                                                                                  \
     hipLaunchKernelGGL((s1_main<MODE_, NW_>), dim3(grid), dim3(64 * NW_), Lay<NW_>::SMEM_BYTES, stream, bank, w.qh, \
                        w.qf, N, C, total, w.rowrec, w.simt0, w.colmax, w.sim0s)
-#define S1_LAUNCH16(MODE_)                                                                                     \
-    hipLaunchKernelGGL((s1_main<MODE_, 8, _Float16>), dim3(grid), dim3(512), Lay<8>::SMEM_BYTES, stream, bank16, w.qh, \
+#define S1_LAUNCH16(MODE_, NW_)                                                                                \
+    hipLaunchKernelGGL((s1_main<MODE_, NW_, _Float16>), dim3(grid), dim3(64 * NW_), Lay<NW_>::SMEM_BYTES, stream, bank16, w.qh, \
                        w.qf, N, C, total, w.rowrec, w.simt0, w.colmax, w.sim0s)
         if (f16) {
-            if (mode == PP_MATCH_FAST) S1_LAUNCH16(PP_MATCH_FAST);
-            else S1_LAUNCH16(PP_MATCH_EXACT);
+            if (mode == PP_MATCH_FAST) {
+                if (nw == 8) S1_LAUNCH16(PP_MATCH_FAST, 8);
+                else S1_LAUNCH16(PP_MATCH_FAST, 4);
+            } else {
+                if (nw == 8) S1_LAUNCH16(PP_MATCH_EXACT, 8);
+                else S1_LAUNCH16(PP_MATCH_EXACT, 4);
+            }
         } else if (mode == PP_MATCH_FAST) {
             if (nw == 8) S1_LAUNCH(PP_MATCH_FAST, 8);
             else S1_LAUNCH(PP_MATCH_FAST, 4);
