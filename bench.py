@@ -743,7 +743,7 @@ def main():
         _lib.check(L.pp_prof_enable(0), "pp_prof_enable")
         return sum(buf[i] for i in range(cnt.value)) / max(cnt.value, 1)
 
-    gemm = pnp = exact = phases = sharded_leg = None
+    gemm = pnp = exact = phases = sharded_leg = dead_leg = None
     if kind == "stage1" and s1_graphed:     # the kernel's own time: the same launches outside the graph, after the timed region
         n_ev = min(a.steps, 64)
         _lib.check(L.pp_prof_enable(n_ev), "pp_prof_enable")
@@ -791,6 +791,34 @@ def main():
                               "query ViT + query-side DPT head (the query all-gathers are in flight beside the DPT head), exchange = what the "
                               "compute stream still waits for the query / mask all-gathers + the score all-gather and top-k, stage1 = this "
                               "rank's score slices of ALL crops, tail = stages 2-3 of the own crops, pnp = batched PnP/RANSAC + D2H"}
+        # The same serving loop with the DPT head's dead layer_1 branch COMPUTED (dpt.py:252-272 computes projects[0], resize_layers[0] and
+        # layer1_rn and reads only the shape of the result; this build skips them — DESIGN section 4 "Dead layer"): what the step costs when
+        # the reference's dead code is executed too, for a reader who wants the layer count of the reference.  Untimed leg, world 1 only.
+        dead_leg = None
+        if world == 1 and emulate is None and not sharded and not cached and not dead_layer1:
+            from picopose_amd.model import stage3 as _st3
+
+            _st3.COMPUTE_DEAD_LAYER1 = True
+            try:
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                d_steps, pend = 6, None
+                td = time.perf_counter()
+                for _ in range(d_steps):
+                    i_ = seq[0]
+                    h_ = step_launch(i_)
+                    if pend is not None:
+                        pnp_collect(pend, 5, Bl)
+                    pend = h_
+                pnp_collect(pend, 5, Bl)
+                torch.cuda.synchronize()
+                d_dt = (time.perf_counter() - td) / d_steps
+                dead_leg = {"value": Bl / d_dt, "ms_per_step": d_dt * 1e3, "steps": d_steps,
+                            "note": "the headline loop with projects[0] / resize_layers[0] / layer1_rn of the DPT head executed (their result is unused)"}
+            finally:
+                _st3.COMPUTE_DEAD_LAYER1 = False
+            step()      # (back to the default path before the legs below)
         sat_checked = None
         if a.mode in ("fast", "fp16"):    # one more untimed forward that verifies every operand buffer it produces (raises on saturation)
             n0, ops.CHECK_SATURATION = ops.saturation_checks, True
@@ -1065,10 +1093,12 @@ def main():
                     "sharded_exchange_q_ms": ((sharded_leg or {}).get("phases_ms") or {}).get("exchange_q"),
                     "sharded_exchange_s_ms": ((sharded_leg or {}).get("phases_ms") or {}).get("exchange_s"),
                     "rccl_world_size": world}),
-                "kernel_ms_per_step": msum, "share_of_step": msum / ms, "launches_per_step": n, "avg_launch_ms": msum / n,
+                "kernel_ms_per_step": msum, "share_of_step": msum / ms, "launches_per_step": n,
+                "value_with_dead_layer1_computed": (dead_leg or {}).get("value"),
                 "useful_tflops": fl / (msum * 1e-3) / 1e12, "step_direct_conv_equiv_tflops": direct_tf,
                 "dominant_launches": dom["launches"] if dom else None,
                 "algorithmic_flops_per_step": fl, "mfma_flops_per_step": mult * fl,
+                "avg_launch_ms": msum / n,
                 "traffic_bytes_per_step": g_traffic, "traffic_measured_in_this_run": False, "prefetch_query": bool(a.prefetch_query),
                 "dominant_kernel": ((dom["kernel"] + " | " + dom["a_operand"])[:100] if dom else None),
                 "kernel": {"fast": "pp_gemm_u_kernel, all tiles: operands pre-split in 2 f16 terms, 3 MFMAs per product",
@@ -1122,6 +1152,8 @@ def main():
                 if "exact_value" in line["roofline"]:
                     line["roofline"]["exact_value"] = exact["value"]
                     line["roofline"]["exact_direct_value"] = line["exact_direct_value"]
+            if dead_leg is not None:
+                line["dead_layer1_computed"] = dead_leg
             if sharded_leg is not None:
                 line["sharded_leg"] = sharded_leg
                 for k_ in ("crops_per_s", "ms_per_step"):
