@@ -458,6 +458,11 @@ int pp_winograd4_output(const float* Y, int B, int H, int W, int Cout, const flo
 int pp_winograd4_chain(const float* Y, int B, int H, int W, int C, const float* bias, int act, int c_relu, void* U_hl, long long P_pad,
                        void* stream);
 
+/* The same chain for the strict-fp32 mode's F(2x2, 3x3): Y (16, P, C) fp32 of layer k -> U (16, P, C) fp32 of layer k + 1 (P = B H W / 4),
+ * h = act(A^T Y A + bias), then max(h, 0) with relu_next (the next layer's input ReLU: dpt.py:82-86), never stored; bit-identical to
+ * pp_winograd_output_f32 followed by pp_winograd_input_f32.  W in {16, 32, 64}, H even, C % 32 == 0. */
+int pp_winograd_chain_f32(const float* Y, int B, int H, int W, int C, const float* bias, int act, int relu_next, float* U, void* stream);
+
 /* Sticky operand-saturation word.  The f16x3 / f16 operand formats clamp at the fp16 range (|4 x| >= 65504): a clamped term is finite but
  * WRONG.  With a device word registered here, every kernel that writes operand terms ORs bit 0 into it when a term hit the clamp (one
  * atomic per wave that saw one; nothing when none did) — the host reads the word together with its results (no extra synchronisation)

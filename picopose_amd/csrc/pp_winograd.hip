@@ -540,6 +540,94 @@ __global__ __launch_bounds__(2 * (W / 4) * 8) void wino4_chain_kernel(const floa
     wino_note_sat(!(top < 65504.f), sat);
 }
 
+// The same chain for the strict-fp32 mode's F(2x2, 3x3) (round 6): Y (16, P, C) fp32 of layer k -> U (16, P, C) fp32 of layer
+// k + 1, h = act(A^T Y A + bias) (then the consumer's input ReLU) in an LDS ring of four tile rows of two pixel rows each (72 KB at W = 64:
+// two workgroups per CU).  Every sum is the fp32 sum the two separate kernels make, in the same order: bit-identical.
+template <int W>
+__global__ __launch_bounds__(2 * (W / 2) * 8, 4) void wino2_chain_kernel(const float* __restrict__ Y, int H, int C, long long P, const float* __restrict__ bias,
+                                                                       int act, int relu_next, float* __restrict__ U) {
+    constexpr int TW = W / 2, NI = TW * 8;
+    constexpr int SLOT = 2 * W * CHN_PX;
+    extern __shared__ __attribute__((aligned(16))) float chs[];
+    const int th = H >> 1, nsl = C >> 5;
+    const int b = blockIdx.x / nsl, cs = blockIdx.x - b * nsl;
+    const int half = threadIdx.x / NI, it = threadIdx.x - half * NI, tx = it >> 3, q = it & 7;
+    const int c = cs * 32 + 4 * q;
+    const f4 bv = bias ? *(const f4*)(bias + c) : f4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < th + 2; ++r) {
+        if (half == 0 && r < th) {
+            const long long p = ((long long)b * th + r) * TW + tx;
+            f4 y[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) y[a][bb] = *(const f4*)(Y + ((long long)(4 * a + bb) * P + p) * C + c);
+            float* slot = chs + (r & 3) * SLOT;
+#pragma unroll
+            for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                for (int ox = 0; ox < 2; ++ox) {
+                    f4 col[4], o;
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) col[bb] = oy == 0 ? (y[0][bb] + y[1][bb]) + y[2][bb] : (y[1][bb] - y[2][bb]) - y[3][bb];
+                    o = ox == 0 ? (col[0] + col[1]) + col[2] : (col[1] - col[2]) - col[3];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = wino_act(o[e] + bv[e], act);
+                        o[e] = relu_next ? (v > 0.f ? v : 0.f) : v;        // (wino_input_kernel's optional ReLU on its input)
+                    }
+                    *(f4*)(slot + (oy * W + 2 * tx + ox) * CHN_PX + 4 * q) = o;
+                }
+        }
+        if (half == 1 && r >= 2) {
+            const int R = r - 2;
+            // t = B^T d column by column, then u = t B row by row, each row stored at once (the sums of wino_bt_d_b in its order; the tile's
+            // 16 + 16 vectors are never all live: 128 registers keep two 512-thread workgroups on a CU)
+            f4 t[4][4];
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                f4 d[4];
+#pragma unroll
+                for (int dy = 0; dy < 4; ++dy) {
+                    const int g = 2 * R - 1 + dy, px = 2 * tx - 1 + dx;
+                    const int gc = min(max(g, 0), H - 1), pc = min(max(px, 0), W - 1);
+                    f4 v = *(const f4*)(chs + ((gc >> 1) & 3) * SLOT + ((gc & 1) * W + pc) * CHN_PX + 4 * q);
+                    if (!(g >= 0 && g < H && px >= 0 && px < W)) v = f4{0.f, 0.f, 0.f, 0.f};
+                    d[dy] = v;
+                }
+                t[0][dx] = d[0] - d[2];
+                t[1][dx] = d[1] + d[2];
+                t[2][dx] = d[2] - d[1];
+                t[3][dx] = d[1] - d[3];
+            }
+            const long long p = ((long long)b * th + R) * TW + tx;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f4 u0 = t[a][0] - t[a][2], u1 = t[a][1] + t[a][2], u2 = t[a][2] - t[a][1], u3 = t[a][1] - t[a][3];
+                *(f4*)(U + ((long long)(4 * a + 0) * P + p) * C + c) = u0;
+                *(f4*)(U + ((long long)(4 * a + 1) * P + p) * C + c) = u1;
+                *(f4*)(U + ((long long)(4 * a + 2) * P + p) * C + c) = u2;
+                *(f4*)(U + ((long long)(4 * a + 3) * P + p) * C + c) = u3;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int W>
+static int wino2_chain_launch(const float* Y, int B, int H, int C, const float* bias, int act, int relu_next, float* U, hipStream_t st) {
+    constexpr int threads = 2 * (W / 2) * 8;
+    const size_t lds = (size_t)4 * 2 * W * CHN_PX * sizeof(float);
+    static signed char attr[PP_MAX_DEVICES];
+    signed char& ok = attr[pp_cur_device()];
+    if (ok == 0)
+        ok = hipFuncSetAttribute((const void*)wino2_chain_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
+    if (ok < 0) return PP_ELAUNCH;
+    const long long P = (long long)B * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(wino2_chain_kernel<W>, dim3((unsigned)(B * (C / 32))), dim3(threads), lds, st, Y, H, C, P, bias, act, relu_next, U);
+    return pp_last_launch();
+}
+
 template <int W>
 static int wino4_chain_launch(const float* Y, int B, int H, int C, const float* bias, int act, int c_relu, void* U, long long Pp, hipStream_t st) {
     constexpr int threads = 2 * (W / 4) * 8;
@@ -650,6 +738,17 @@ int pp_winograd4_chain(const float* Y, int B, int H, int W, int C, const float* 
     if (W == 64) return wino4_chain_launch<64>(Y, B, H, C, bias, act, c_relu, U_hl, P_pad, st);
     if (W == 32) return wino4_chain_launch<32>(Y, B, H, C, bias, act, c_relu, U_hl, P_pad, st);
     return wino4_chain_launch<16>(Y, B, H, C, bias, act, c_relu, U_hl, P_pad, st);
+}
+
+
+int pp_winograd_chain_f32(const float* Y, int B, int H, int W, int C, const float* bias, int act, int relu_next, float* U, void* stream) {
+    if (!Y || !U || B <= 0 || H < 2 || (H & 1) || (W != 16 && W != 32 && W != 64) || C <= 0 || (C & 31)) return PP_EINVAL;
+    if (act != PP_ACT_NONE && act != PP_ACT_RELU && act != PP_ACT_LEAKY01) return PP_EINVAL;
+    if ((long long)B * (C / 32) >= (1LL << 31) || (((uintptr_t)Y | (uintptr_t)U | (uintptr_t)bias) & 15)) return PP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (W == 64) return wino2_chain_launch<64>(Y, B, H, C, bias, act, relu_next, U, st);
+    if (W == 32) return wino2_chain_launch<32>(Y, B, H, C, bias, act, relu_next, U, st);
+    return wino2_chain_launch<16>(Y, B, H, C, bias, act, relu_next, U, st);
 }
 
 }  // extern "C"

@@ -94,9 +94,11 @@ class DPTHead(Packed):
         # conv1 hands relu(h) to conv2 as operand planes (out_split + split_relu): h itself is never stored.  The
         # unit's fp32 output also carries its relu'd operand form (also_split) for the next unit's conv1.
         xin = getattr(x, "_hl_relu", None)
+        # (strict-fp32 mode: both convolutions by Winograd F(2x2) with conv1's output transform chained into conv2's input transform —
+        # wino_next="relu": through conv2's input ReLU)
         h = ops.conv2d(x if xin is None else xin, pk[key + "_c1"], pk[key + "_b1"], 3, pad=1, relu_in=xin is None,
-                       out_split=True, split_relu=True)
-        return ops.conv2d(h, pk[key + "_c2"], pk[key + "_b2"], 3, pad=1, relu_in=not isinstance(h, ops.Split), residual=x,
+                       out_split=True, split_relu=True, wino_next="relu")
+        return ops.conv2d(h, pk[key + "_c2"], pk[key + "_b2"], 3, pad=1, relu_in=not isinstance(h, (ops.Split, ops.WinoInput)), residual=x,
                           residual2=extra, also_split="relu" if more else None)
 
     def _fuse(self, pk, i, size, x0, x1=None, train=False):

@@ -538,11 +538,18 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     in_cols = (col0, c) with a Split input: the convolution reads operand columns col0 .. col0 + c of the wider Split (a channel
     slice of a shared operand: two layers fused along N hand their halves to their successors without a copy).
     alpha_dev: up to two device scalars the accumulated product is multiplied by inside the launch (PpGemmDesc.alpha_dev: the inverse
-    range scale of a backward operand) — pre-split path only."""
-    if isinstance(x, WinoInput):      # the shared Winograd input of several 3x3 convolutions (strict-fp32 mode)
+    range scale of a backward operand) — pre-split path only.
+    wino (f16x3 engine, 3x3 / stride 1 / pad 1 on an operand image): run the layer by Winograd F(4x4, 3x3) (`_conv3x3_winograd4`).
+    wino_next (True | "relu"): the result feeds ONLY another 3x3 / stride 1 / pad 1 convolution of the same kind ("relu": through that layer's
+    input ReLU) — where both run by Winograd, return the NEXT layer's Winograd input (f16x3 engine, with wino and out_split: a WinoInput4;
+    strict-fp32 mode: a WinoInput) with the output transform chained into its input transform (csrc/pp_winograd.hip wino4_chain_kernel /
+    wino2_chain_kernel: the hidden map is never stored); ignored where the chain does not apply (then the usual result comes back, which the
+    next conv2d takes just the same)."""
+    if isinstance(x, WinoInput):      # the shared / chained Winograd input of 3x3 convolutions (strict-fp32 mode)
         B, H, W, Cx = x.geom
         assert ksize == 3 and stride == 1 and pad == 1 and cin in (None, Cx) and wp.shape[1] == 9 * Cx and hl_into is None
-        return _conv3x3_winograd(x, wp, bias, B, H, W, Cx, Cx, wp.shape[0], act, relu_in, residual, residual2, out)
+        assert not (relu_in and not x.relu), "the shared / chained Winograd input was made without the input ReLU this layer asks for"
+        return _conv3x3_winograd(x, wp, bias, B, H, W, Cx, Cx, wp.shape[0], act, x.relu, residual, residual2, out, chain_next=wino_next)
     if isinstance(x, WinoInput4):     # the shared F(4x4, 3x3) input of several 3x3 convolutions (f16x3 engine)
         B, H, W, Cx = x.geom
         assert ksize == 3 and stride == 1 and pad == 1 and cin in (None, Cx) and wp.shape[1] == 9 * Cx and hl_into is None and not relu_in
@@ -593,7 +600,7 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
     if (xs is None and ksize == 3 and stride == 1 and pad == 1 and Cout >= 32 and act in (None, "none", "relu", "leaky01")
             and _winograd_ok(B, H, W, cin, ld_in, x) and wp.dtype == torch.float32 and wp.is_contiguous()
             and hl_into is None and cache_weight is True):     # (out_split / also_split: f16x3-engine hints, ignored in this mode)
-        return _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, residual, residual2, out)
+        return _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, residual, residual2, out, chain_next=wino_next)
     if (wino and xs is not None and ksize == 3 and stride == 1 and pad == 1 and xs.terms == 2 and hl_into is None and not alpha_dev and cache_weight is True
             and act in (None, "none", "relu", "leaky01") and wp.dtype == torch.float32 and wp.is_contiguous()
             and _winograd4_ok(B, H, W, cin, Cout)):
@@ -719,9 +726,13 @@ def winograd_shared(x, relu=False, cout=None):
     return WinoInput(U, (B, H, W, C), bool(relu))
 
 
-def _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, residual, residual2, out):
+WINO2_CHAIN = os.environ.get("PP_WINOGRAD_CHAIN", "1") != "0"
+
+
+def _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, residual, residual2, out, chain_next=False):
     """3x3 / stride 1 / pad 1 on an fp32 NHWC map (a channel slice is fine) by Winograd F(2x2, 3x3): input transform, 16 dense fp32
-    products on the engine, output transform with bias / activation / residuals.  Everything fp32.  x: the map, or its WinoInput."""
+    products on the engine, output transform with bias / activation / residuals.  Everything fp32.  x: the map, or its WinoInput.
+    chain_next (True | "relu"): return the WinoInput of the next 3x3 layer (Cout -> .) instead of the map (pp_winograd_chain_f32)."""
     P = B * (H // 2) * (W // 2)
     L = _lib.lib()
     V = winograd_weight(wp, cin)
@@ -740,6 +751,13 @@ def _conv3x3_winograd(x, wp, bias, B, H, W, cin, ld_in, Cout, act, relu_in, resi
         n = min(per, 16 - x0)
         _run(_desc(A=_p(U[x0]), B=_p(V[x0]), C=_p(Y[x0]), M=P, N=Cout, K=cin, lda=cin, ldb=cin, ldc=Cout, prec=0, batch0=n,
                    a_bs0=P * cin, b_bs0=Cout * cin, c_bs0=P * Cout))
+    if (chain_next and WINO2_CHAIN and WINOGRAD and out is None and residual is None and residual2 is None and W in (16, 32, 64) and Cout % 32 == 0
+            and B * H * W >= (WINOGRAD_MIN_PIXELS if P % 256 == 0 else 4 * WINOGRAD_MIN_PIXELS)):
+        # the next layer's Winograd input straight from this layer's products: h = act(A^T Y A + bias) lives in LDS only
+        U1 = torch.empty(16, P, Cout, dtype=torch.float32, device=dev)
+        _lib.check(L.pp_winograd_chain_f32(_p(Y), B, H, W, Cout, _p(bias), ACT[act], int(chain_next == "relu"), _p(U1), _lib.stream_ptr()),
+                   "pp_winograd_chain_f32")
+        return WinoInput(U1, (B, H, W, Cout), chain_next == "relu")
     if out is None:
         out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=dev)
     ldc = out.stride(2)

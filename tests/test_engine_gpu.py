@@ -413,6 +413,19 @@ def test_winograd_3x3_of_the_strict_fp32_mode(monkeypatch, engine_precision, B, 
         monkeypatch.delenv("PP_GEMM_FORCE_CFG")
         assert torch.equal(pinned, got)
         assert e_w <= 2e-5
+    # conv -> (ReLU) -> conv with the first output transform chained into the second input transform (pp_winograd_chain_f32: the hidden
+    # map never stored): the same bits as the separate kernels, with and without the second layer's input ReLU
+    w2p = ops.pack_conv_weight((torch.randn(64, cout, 3, 3, generator=g) / (cout * 9) ** 0.5).cuda())
+    for nxt, act in (("relu", None), (True, "relu"), (True, "leaky01")):
+        monkeypatch.setattr(ops, "WINO2_CHAIN", True)
+        ch = ops.conv2d(x.cuda(), wp, b.cuda(), 3, pad=1, act=act, wino_next=nxt)
+        assert isinstance(ch, ops.WinoInput) == (hw in (16, 32, 64) and cout % 32 == 0)
+        a_ = ops.conv2d(ch, w2p, None, 3, pad=1, relu_in=(nxt == "relu") and not isinstance(ch, ops.WinoInput))
+        monkeypatch.setattr(ops, "WINO2_CHAIN", False)
+        sep = ops.conv2d(x.cuda(), wp, b.cuda(), 3, pad=1, act=act, wino_next=nxt)
+        assert torch.is_tensor(sep)
+        assert torch.equal(a_, ops.conv2d(sep, w2p, None, 3, pad=1, relu_in=nxt == "relu"))
+    monkeypatch.setattr(ops, "WINO2_CHAIN", True)
     # a channel-slice output of a wider NHWC buffer
     if cout % 4 == 0:
         buf = torch.zeros(B, hw, hw, cout + 40, device="cuda")
