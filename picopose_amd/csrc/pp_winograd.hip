@@ -452,15 +452,20 @@ __device__ __forceinline__ int wino_opaque(int xi) {
     return k;
 }
 
-template <int W>
-__global__ __launch_bounds__(2 * (W / 4) * 8) void wino4_chain_kernel(const float* __restrict__ Y, int H, int C, const float* __restrict__ bias,
+template <int W, int NB>      // NB: thread groups that share the input-transform side (1, or 2: three frequencies rows each)
+__global__ __launch_bounds__((1 + NB) * ((W / 4) * 8 < 64 ? 64 : (W / 4) * 8)) void wino4_chain_kernel(const float* __restrict__ Y, int H, int C, const float* __restrict__ bias,
                                                                        int act, int c_relu, _Float16* __restrict__ U, long long Pp, unsigned* sat) {
     constexpr int TW = W / 4, NI = TW * 8;                  // tiles per tile row; work items (tile, channel quad) per tile row
+    constexpr int GS = NI < 64 ? 64 : NI;                   // threads per group: whole waves (a wave's group index is uniform)
     constexpr int SLOT = 4 * W * CHN_PX;                    // floats per ring slot (one tile row = 4 pixel rows)
     extern __shared__ __attribute__((aligned(16))) float chs[];
     const int th = H >> 2, nsl = C >> 5;
     const int b = blockIdx.x / nsl, cs = blockIdx.x - b * nsl;
-    const int half = threadIdx.x / NI, it = threadIdx.x - half * NI, tx = it >> 3, q = it & 7;
+    // (NB == 2: the group index picks the frequency rows and must be wave-uniform for the scalar descriptors; NB == 1: left per-lane —
+    // made uniform there, hipcc laid both halves' live ranges over each other: 256 registers + spills instead of 176)
+    const int half = NB == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / GS) : (int)threadIdx.x / GS;
+    const int it = (int)threadIdx.x - half * GS, tx = it >> 3, q = it & 7;
+    const bool live = NI >= GS || it < NI;                  // (W = 16: half of each 64-thread group idles)
     const int c = cs * 32 + 4 * q;                          // first of this thread's 4 channels
     const unsigned long long blk = (unsigned long long)Pp * C * 4;
     const f4 bv = bias ? *(const f4*)(bias + c) : f4{0.f, 0.f, 0.f, 0.f};
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(2 * (W / 4) * 8) void wino4_chain_kernel(const floa
     const float hfloor = c_relu ? 0.f : -INFINITY;          // the consumer's input ReLU folded into the operand, as pp_winograd4_output does
     float top = 0.f;
     for (int r = 0; r < th + 2; ++r) {
-        if (half == 0 && r < th) {
+        if (half == 0 && live && r < th) {
             // ---- tile (b, r, tx): h(4x4) = relu'(A^T Y A + bias), as the operand's value 4 h (hi + lo), into ring slot r % 4
             const long long p = ((long long)b * th + r) * TW + tx;
             const unsigned yoff = (unsigned)((p * C + c) * 4);
@@ -502,9 +507,13 @@ __global__ __launch_bounds__(2 * (W / 4) * 8) void wino4_chain_kernel(const floa
                 }
             }
         }
-        if (half == 1 && r >= 2) {
-            // ---- tile (b, R = r - 2, tx): U = B^T d B / 64 of the 6x6 pixels around it (rows 4 R - 1 .. 4 R + 4 of h: ring slots R - 1, R, R + 1)
-            const int R = r - 2;
+        if (half >= 1 && live && r >= 2) {
+            // ---- tile (b, R = r - 2, tx): U = B^T d B / 64 of the 6x6 pixels around it (rows 4 R - 1 .. 4 R + 4 of h: ring slots R - 1, R, R + 1).
+            // TWO thread groups share a tile: both make the column transform t = B^T d (LDS reads, 84 packed operations), group 1 finishes
+            // frequencies a = 0 .. 2, group 2 a = 3 .. 5 — the row transforms, splits and stores are the bulk of the work, and the output-
+            // transform group is bound by its loads' latency: halving the other side's arithmetic shortens the tile row (NB = 2: W = 64 only)
+            constexpr int RPG = 6 / NB;
+            const int R = r - 2, a0 = NB == 2 ? RPG * (half - 1) : 0;
             f4 t[6][6];
 #pragma unroll
             for (int dx = 0; dx < 6; ++dx) {
@@ -524,14 +533,24 @@ __global__ __launch_bounds__(2 * (W / 4) * 8) void wino4_chain_kernel(const floa
             const long long p = ((long long)b * th + R) * TW + tx;
             const unsigned uoff = (unsigned)((p * 2 * C + gcol + par * 8) * 2);
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
+            for (int ai = 0; ai < RPG; ++ai) {
                 f4 u[6];
-                PP_W4_BT(t[a][0], t[a][1], t[a][2], t[a][3], t[a][4], t[a][5], u[0], u[1], u[2], u[3], u[4], u[5])
+                // (the group's rows: selected from the six by the wave-uniform a0 — both selections are compile-time register names)
+                if constexpr (NB == 2) {
+                    f4 t0 = t[ai][0], t1 = t[ai][1], t2 = t[ai][2], t3 = t[ai][3], t4 = t[ai][4], t5 = t[ai][5];
+                    if (a0) {
+                        t0 = t[3 + ai][0], t1 = t[3 + ai][1], t2 = t[3 + ai][2];
+                        t3 = t[3 + ai][3], t4 = t[3 + ai][4], t5 = t[3 + ai][5];
+                    }
+                    PP_W4_BT(t0, t1, t2, t3, t4, t5, u[0], u[1], u[2], u[3], u[4], u[5])
+                } else {
+                    PP_W4_BT(t[ai][0], t[ai][1], t[ai][2], t[ai][3], t[ai][4], t[ai][5], u[0], u[1], u[2], u[3], u[4], u[5])
+                }
 #pragma unroll
                 for (int bb = 0; bb < 6; ++bb) {
                     hf4 hi, lo;
                     wino_split4(u[bb] * (1.f / 64.f), hi, lo, top);
-                    __builtin_amdgcn_raw_buffer_store_b128(wino_pair_pack(par, hi, lo), wino_block_rsrc(U, wino_opaque(6 * a + bb), blk), uoff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(wino_pair_pack(par, hi, lo), wino_block_rsrc(U, wino_opaque(6 * (a0 + ai) + bb), blk), uoff, 0, 0);
                 }
             }
         }
@@ -630,14 +649,17 @@ static int wino2_chain_launch(const float* Y, int B, int H, int C, const float* 
 
 template <int W>
 static int wino4_chain_launch(const float* Y, int B, int H, int C, const float* bias, int act, int c_relu, void* U, long long Pp, hipStream_t st) {
-    constexpr int threads = 2 * (W / 4) * 8;
+    // two input-transform groups at W = 64 (1.36 -> 1.26 ms per head: the ring leaves one workgroup per CU, more waves hide more); one at
+    // W <= 32, where two workgroups share a CU and the third group's registers cost more than its arithmetic saves (0.35 vs 0.41 ms)
+    constexpr int NB = W == 64 ? 2 : 1;
+    constexpr int threads = (1 + NB) * ((W / 4) * 8 < 64 ? 64 : (W / 4) * 8);
     const size_t lds = (size_t)4 * 4 * W * CHN_PX * sizeof(float);
     static signed char attr[PP_MAX_DEVICES];
     signed char& ok = attr[pp_cur_device()];
     if (ok == 0)
-        ok = hipFuncSetAttribute((const void*)wino4_chain_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
+        ok = hipFuncSetAttribute((const void*)wino4_chain_kernel<W, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
     if (ok < 0) return PP_ELAUNCH;
-    hipLaunchKernelGGL(wino4_chain_kernel<W>, dim3((unsigned)(B * (C / 32))), dim3(threads), lds, st, Y, H, C, bias, act, c_relu, (_Float16*)U, Pp,
+    hipLaunchKernelGGL((wino4_chain_kernel<W, NB>), dim3((unsigned)(B * (C / 32))), dim3(threads), lds, st, Y, H, C, bias, act, c_relu, (_Float16*)U, Pp,
                        pp_saturation_word());
     return pp_last_launch();
 }
