@@ -443,19 +443,20 @@ int pp_winograd_output_f32(const float* Y, int B, int H, int W, int Cout, const 
  *   pp_winograd4_output      Y (36, P, Cout) fp32  ->  A^T Y A + bias, act (none / ReLU / LeakyReLU): as fp32 NHWC map `out` (rows of ldc
  *                            floats; + residual + residual2 laid out like out) and / or as hl operand `out_hl` (rows of ld_h channels,
  *                            the pointer at the first column's group; of max(., 0) with c_relu).  Cout % 4 == 0 (% 8 for out_hl).
+ * ld_y >= Cout: the row pitch of Y in floats (Y may be a column slice of a wider product: two layers that read the same U, fused along N).
  * P_pad >= P: the rows of one frequency block of U and Y (P rounded up to a multiple of 256, the engine's row tile, so that a row tile
  * lies inside one frequency; the pad rows are never read by the output transform). */
 int pp_winograd4_input_hl(const void* x_hl, int ld_x, long long batch_stride, int B, int H, int W, int C, int relu, void* U_hl, long long P_pad,
                           void* stream);
 int pp_winograd4_weight_f32(const float* w, int Cout, int Cin, int ldw, float* V, void* stream);
-int pp_winograd4_output(const float* Y, int B, int H, int W, int Cout, const float* bias, int act, const float* residual, const float* residual2,
-                        float* out, int ldc, void* out_hl, int ld_h, int c_relu, long long P_pad, void* stream);
+int pp_winograd4_output(const float* Y, int ld_y, int B, int H, int W, int Cout, const float* bias, int act, const float* residual,
+                        const float* residual2, float* out, int ldc, void* out_hl, int ld_h, int c_relu, long long P_pad, void* stream);
 
 /* Output transform of a Winograd F(4x4, 3x3) layer CHAINED into the input transform of the next one (conv 3x3 -> ReLU -> conv 3x3,
  * raft_decoder.py:251-289): Y (36, P_pad, C) fp32 of the first layer -> U_hl (36, P_pad, C) hl operand of B^T relu'(A^T Y A + bias) B / 16 of the
  * second, the hidden map never stored; bit-identical to pp_winograd4_output (operand output, c_relu) followed by pp_winograd4_input_hl.
  * W in {16, 32, 64}, H % 4 == 0, C % 32 == 0; act none / ReLU / LeakyReLU, then (c_relu) the consumer's input ReLU. */
-int pp_winograd4_chain(const float* Y, int B, int H, int W, int C, const float* bias, int act, int c_relu, void* U_hl, long long P_pad,
+int pp_winograd4_chain(const float* Y, int ld_y, int B, int H, int W, int C, const float* bias, int act, int c_relu, void* U_hl, long long P_pad,
                        void* stream);
 
 /* The same chain for the strict-fp32 mode's F(2x2, 3x3): Y (16, P, C) fp32 of layer k -> U (16, P, C) fp32 of layer k + 1 (P = B H W / 4),

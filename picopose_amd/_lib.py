@@ -106,8 +106,8 @@ def lib():
         L.pp_winograd_output_f32.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp]
         L.pp_winograd4_input_hl.argtypes = [vp, i32, c.c_longlong, i32, i32, i32, i32, i32, vp, c.c_longlong, vp]
         L.pp_winograd4_weight_f32.argtypes = [vp, i32, i32, i32, vp, vp]
-        L.pp_winograd4_output.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, c.c_longlong, vp]
-        L.pp_winograd4_chain.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, vp, c.c_longlong, vp]
+        L.pp_winograd4_output.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, c.c_longlong, vp]
+        L.pp_winograd4_chain.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, c.c_longlong, vp]
         L.pp_winograd_chain_f32.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, vp, vp]
         L.pp_set_saturation_word.argtypes = [vp]
         L.pp_split_weights_t.argtypes = [vp, c.c_longlong, i32, vp, vp, vp]

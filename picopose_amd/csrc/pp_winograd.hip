@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Y, int B, int H, int W, int Cout, const float* __restrict__ bias,
                                                            int act, const float* __restrict__ residual, const float* __restrict__ residual2,
                                                            float* __restrict__ out, int ldc, _Float16* __restrict__ out_hl, int ld_h, int c_relu,
-                                                           long long Pp, unsigned* sat) {
+                                                           long long Pp, int ldy, unsigned* sat) {
     const int cn = Cout >> 2;
     const int tw = W >> 2, th = H >> 2;
     const long long P = (long long)B * th * tw, total = P * cn;
@@ -391,8 +391,8 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     const long long p = i / cn;
     const int c = (int)(i - p * cn) * 4;
     const int b = (int)(p / ((long long)th * tw)), r = (int)(p - (long long)b * th * tw), ty = r / tw, tx = r - ty * tw;
-    const unsigned long long blk = (unsigned long long)Pp * Cout * 4;
-    const unsigned yoff = (unsigned)((p * Cout + c) * 4);
+    const unsigned long long blk = (unsigned long long)Pp * ldy * 4;     // (ldy >= Cout: Y may be a column slice of a wider product — two layers fused along N)
+    const unsigned yoff = (unsigned)((p * ldy + c) * 4);
     f4 z[4][6];   // z = A^T Y, column by column
 #pragma unroll
     for (int bb = 0; bb < 6; ++bb) {
@@ -454,7 +454,7 @@ __device__ __forceinline__ int wino_opaque(int xi) {
 
 template <int W, int NB>      // NB: thread groups that share the input-transform side (1, or 2: three frequencies rows each)
 __global__ __launch_bounds__((1 + NB) * ((W / 4) * 8 < 64 ? 64 : (W / 4) * 8)) void wino4_chain_kernel(const float* __restrict__ Y, int H, int C, const float* __restrict__ bias,
-                                                                       int act, int c_relu, _Float16* __restrict__ U, long long Pp, unsigned* sat) {
+                                                                       int act, int c_relu, _Float16* __restrict__ U, long long Pp, int ldy, unsigned* sat) {
     constexpr int TW = W / 4, NI = TW * 8;                  // tiles per tile row; work items (tile, channel quad) per tile row
     constexpr int GS = NI < 64 ? 64 : NI;                   // threads per group: whole waves (a wave's group index is uniform)
     constexpr int SLOT = 4 * W * CHN_PX;                    // floats per ring slot (one tile row = 4 pixel rows)
@@ -467,7 +467,7 @@ __global__ __launch_bounds__((1 + NB) * ((W / 4) * 8 < 64 ? 64 : (W / 4) * 8)) v
     const int it = (int)threadIdx.x - half * GS, tx = it >> 3, q = it & 7;
     const bool live = NI >= GS || it < NI;                  // (W = 16: half of each 64-thread group idles)
     const int c = cs * 32 + 4 * q;                          // first of this thread's 4 channels
-    const unsigned long long blk = (unsigned long long)Pp * C * 4;
+    const unsigned long long blk = (unsigned long long)Pp * C * 4, blky = (unsigned long long)Pp * ldy * 4;     // bytes of a frequency block of U / of Y
     const f4 bv = bias ? *(const f4*)(bias + c) : f4{0.f, 0.f, 0.f, 0.f};
     const float slope = act == PP_ACT_RELU ? 0.f : (act == PP_ACT_LEAKY01 ? 0.1f : 1.f);
     const int gcol = (c >> 3) << 4, par = q & 1;
@@ -477,13 +477,13 @@ __global__ __launch_bounds__((1 + NB) * ((W / 4) * 8 < 64 ? 64 : (W / 4) * 8)) v
         if (half == 0 && live && r < th) {
             // ---- tile (b, r, tx): h(4x4) = relu'(A^T Y A + bias), as the operand's value 4 h (hi + lo), into ring slot r % 4
             const long long p = ((long long)b * th + r) * TW + tx;
-            const unsigned yoff = (unsigned)((p * C + c) * 4);
+            const unsigned yoff = (unsigned)((p * ldy + c) * 4);
             f4 z[4][6];
 #pragma unroll
             for (int bb = 0; bb < 6; ++bb) {
                 f4 y[6];
 #pragma unroll
-                for (int a = 0; a < 6; ++a) y[a] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wino_block_rsrc(Y, wino_opaque(6 * a + bb), blk), yoff, 0, 0));
+                for (int a = 0; a < 6; ++a) y[a] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wino_block_rsrc(Y, wino_opaque(6 * a + bb), blky), yoff, 0, 0));
                 PP_W4_AT(y[0], y[1], y[2], y[3], y[4], y[5], z[0][bb], z[1][bb], z[2][bb], z[3][bb])
             }
             float* slot = chs + (r & 3) * SLOT;
@@ -648,7 +648,7 @@ static int wino2_chain_launch(const float* Y, int B, int H, int C, const float* 
 }
 
 template <int W>
-static int wino4_chain_launch(const float* Y, int B, int H, int C, const float* bias, int act, int c_relu, void* U, long long Pp, hipStream_t st) {
+static int wino4_chain_launch(const float* Y, int B, int H, int C, const float* bias, int act, int c_relu, void* U, long long Pp, int ldy, hipStream_t st) {
     // two input-transform groups at W = 64 (1.36 -> 1.26 ms per head: the ring leaves one workgroup per CU, more waves hide more); one at
     // W <= 32, where two workgroups share a CU and the third group's registers cost more than its arithmetic saves (0.35 vs 0.41 ms)
     constexpr int NB = W == 64 ? 2 : 1;
@@ -660,7 +660,7 @@ static int wino4_chain_launch(const float* Y, int B, int H, int C, const float* 
         ok = hipFuncSetAttribute((const void*)wino4_chain_kernel<W, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
     if (ok < 0) return PP_ELAUNCH;
     hipLaunchKernelGGL((wino4_chain_kernel<W, NB>), dim3((unsigned)(B * (C / 32))), dim3(threads), lds, st, Y, H, C, bias, act, c_relu, (_Float16*)U, Pp,
-                       pp_saturation_word());
+                       ldy, pp_saturation_word());
     return pp_last_launch();
 }
 
@@ -734,9 +734,9 @@ int pp_winograd4_weight_f32(const float* w, int Cout, int Cin, int ldw, float* V
     return pp_last_launch();
 }
 
-int pp_winograd4_output(const float* Y, int B, int H, int W, int Cout, const float* bias, int act, const float* residual, const float* residual2,
-                        float* out, int ldc, void* out_hl, int ld_h, int c_relu, long long P_pad, void* stream) {
-    if (P_pad < (long long)B * (H / 4) * (W / 4) || P_pad * Cout * 4 >= 0xFFFFFF00LL) return PP_EINVAL;
+int pp_winograd4_output(const float* Y, int ld_y, int B, int H, int W, int Cout, const float* bias, int act, const float* residual,
+                        const float* residual2, float* out, int ldc, void* out_hl, int ld_h, int c_relu, long long P_pad, void* stream) {
+    if (P_pad < (long long)B * (H / 4) * (W / 4) || ld_y < Cout || (ld_y & 3) || P_pad * ld_y * 4 >= 0xFFFFFF00LL) return PP_EINVAL;
     if (!Y || (!out && !out_hl) || B <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3) || Cout <= 0 || (Cout & 3)) return PP_EINVAL;
     if (act != PP_ACT_NONE && act != PP_ACT_RELU && act != PP_ACT_LEAKY01) return PP_EINVAL;
     if (out && (ldc < Cout || (ldc & 3))) return PP_EINVAL;
@@ -746,20 +746,22 @@ int pp_winograd4_output(const float* Y, int B, int H, int W, int Cout, const flo
     const long long total = (long long)B * (H / 4) * (W / 4) * (Cout / 4);
     if ((total + 255) / 256 + 8 >= (1LL << 31)) return PP_EINVAL;
     hipLaunchKernelGGL(wino4_output_kernel, dim3(grid8_of(total)), dim3(256), 0, (hipStream_t)stream, Y, B, H, W, Cout, bias, act, residual, residual2,
-                       out, ldc, (_Float16*)out_hl, ld_h, c_relu, P_pad, pp_saturation_word());
+                       out, ldc, (_Float16*)out_hl, ld_h, c_relu, P_pad, ld_y, pp_saturation_word());
     return pp_last_launch();
 }
 
 
-int pp_winograd4_chain(const float* Y, int B, int H, int W, int C, const float* bias, int act, int c_relu, void* U_hl, long long P_pad, void* stream) {
-    if (!Y || !U_hl || B <= 0 || H < 4 || (H & 3) || (W != 16 && W != 32 && W != 64) || C <= 0 || (C & 31)) return PP_EINVAL;
+int pp_winograd4_chain(const float* Y, int ld_y, int B, int H, int W, int C, const float* bias, int act, int c_relu, void* U_hl, long long P_pad,
+                       void* stream) {
+    if (!Y || !U_hl || B <= 0 || H < 4 || (H & 3) || (W != 16 && W != 32 && W != 64) || C <= 0 || (C & 31) || ld_y < C || (ld_y & 3)) return PP_EINVAL;
+    if (P_pad * ld_y * 4 >= 0xFFFFFF00LL) return PP_EINVAL;
     if (act != PP_ACT_NONE && act != PP_ACT_RELU && act != PP_ACT_LEAKY01) return PP_EINVAL;
     if (P_pad < (long long)B * (H / 4) * (W / 4) || P_pad * C * 4 >= 0xFFFFFF00LL || (long long)B * (C / 32) >= (1LL << 31)) return PP_EINVAL;
     if (((uintptr_t)Y | (uintptr_t)U_hl | (uintptr_t)bias) & 15) return PP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (W == 64) return wino4_chain_launch<64>(Y, B, H, C, bias, act, c_relu, U_hl, P_pad, st);
-    if (W == 32) return wino4_chain_launch<32>(Y, B, H, C, bias, act, c_relu, U_hl, P_pad, st);
-    return wino4_chain_launch<16>(Y, B, H, C, bias, act, c_relu, U_hl, P_pad, st);
+    if (W == 64) return wino4_chain_launch<64>(Y, B, H, C, bias, act, c_relu, U_hl, P_pad, ld_y, st);
+    if (W == 32) return wino4_chain_launch<32>(Y, B, H, C, bias, act, c_relu, U_hl, P_pad, ld_y, st);
+    return wino4_chain_launch<16>(Y, B, H, C, bias, act, c_relu, U_hl, P_pad, ld_y, st);
 }
 
 

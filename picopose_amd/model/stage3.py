@@ -305,11 +305,17 @@ class FlowDecoder(Packed):
             else:
                 # both heads' first 3x3 convolutions share ONE Winograd input transform (strict-fp32 mode: F(2x2); f16x3 engine: F(4x4))
                 Xs = ops.winograd_shared(Xs, cout=512)
-                h = ops.conv2d(Xs, pk[f"fp{l}_0"], getattr(fp.layers, "0").conv.bias, 3, pad=1, act="relu", out_split=True, wino=True, wino_next=True)
-                h = ops.conv2d(h, pk[f"fp{l}_1"], getattr(fp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True, wino=True)
+                if isinstance(Xs, ops.WinoInput4):
+                    # f16x3 engine: the two heads' first layers as ONE product per Winograd frequency (N = 512 + 512: U read once), each
+                    # head's output transform chained into its second layer's input transform
+                    hf, hm = ops.conv2d_wino_pair(Xs, (pk[f"fp{l}_0"], getattr(fp.layers, "0").conv.bias), (pk[f"mp{l}_0"], getattr(mp.layers, "0").conv.bias),
+                                                  act="relu", out_split=True, wino_next=True)
+                else:
+                    hf = ops.conv2d(Xs, pk[f"fp{l}_0"], getattr(fp.layers, "0").conv.bias, 3, pad=1, act="relu", out_split=True, wino=True, wino_next=True)
+                    hm = ops.conv2d(Xs, pk[f"mp{l}_0"], getattr(mp.layers, "0").conv.bias, 3, pad=1, act="relu", out_split=True, wino=True, wino_next=True)
+                h = ops.conv2d(hf, pk[f"fp{l}_1"], getattr(fp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True, wino=True)
                 flow = ops.conv2d(h, pk[f"fp{l}_p"], fp.predict_layer.bias, 3, pad=1, residual=flow)      # flow + delta
-                h = ops.conv2d(Xs, pk[f"mp{l}_0"], getattr(mp.layers, "0").conv.bias, 3, pad=1, act="relu", out_split=True, wino=True, wino_next=True)
-                h = ops.conv2d(h, pk[f"mp{l}_1"], getattr(mp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True, wino=True)
+                h = ops.conv2d(hm, pk[f"mp{l}_1"], getattr(mp.layers, "1").conv.bias, 3, pad=1, act="relu", out_split=True, wino=True)
                 cert = ops.conv2d(h, pk[f"mp{l}_p"], mp.predict_layer.bias, 1, residual=cert)             # certainty + delta
             flows.append(flow)
             certs.append(cert)

@@ -832,37 +832,32 @@ WINO4_CHAIN = os.environ.get("PP_WINOGRAD4_CHAIN", "1") != "0"
 WINO4_CHAIN_WIDTHS = (32, 64)
 
 
-def _conv3x3_winograd4(x, wp, bias, B, H, W, cin, Cout, act, residual, residual2, out, out_split, split_relu, also_split, chain_next=False):
-    """3x3 / stride 1 / pad 1 on an operand image by Winograd F(4x4, 3x3): input transform (operand -> operand), 36 dense products on the
-    pre-split engine as grouped launches, output transform with bias / activation (/ residuals) into an fp32 map and / or the next
-    layer's operand.  x: a Split with .image, (Split, col0) for a channel slice of it, or its WinoInput4."""
-    P = B * (H // 4) * (W // 4)
-    L = _lib.lib()
-    V, vhl, vscale = winograd4_weight(wp, cin)
-    if isinstance(x, WinoInput4):
-        assert x.geom == (B, H, W, cin)
-        U = x.U
-    elif isinstance(x, tuple):
-        U = _winograd4_input(x[0].col_ptr(x[1]), x[0].shape[1], B, H, W, cin, x[0].device)
-    else:
-        U = _winograd4_input(x.hl.data_ptr(), x.shape[1], B, H, W, cin, x.device)
-    dev = U.device
-    Pp = _wino4_rows(P)
-    assert U.hl.shape[0] == 36 * Pp
-    Y = torch.empty(36, Pp, Cout, dtype=torch.float32, device=dev)
-    per = max(1, min(WINO4_GROUPS_PER_LAUNCH, 0xF0000000 // (4 * Pp * max(cin, Cout))))   # groups per launch: operand / result blocks inside 32-bit byte offsets
+def _wino4_products(U, V, vhl, vscale, Pp, cin, N):
+    """Y (36, Pp, N) fp32 = U_xi (Pp, cin) V_xi (N, cin)^T for the 36 frequencies: grouped launches of the pre-split engine (as many
+    frequencies per launch as keep the stacked operand / result blocks inside 32-bit byte offsets)."""
+    Y = torch.empty(36, Pp, N, dtype=torch.float32, device=U.device)
+    per = max(1, min(WINO4_GROUPS_PER_LAUNCH, 0xF0000000 // (4 * Pp * max(cin, N))))
     for x0 in range(0, 36, per):
         n = min(per, 36 - x0)
-        _run(_desc(A_hl=U.hl.data_ptr() + x0 * Pp * cin * 4, B=_p(V), B_hl=vhl.data_ptr() + x0 * Cout * cin * 4, b_scale=vscale, C=_p(Y[x0]),
-                   M=Pp, N=Cout, K=cin, lda=cin, ldb=cin, ldc=Cout, prec=_PREC["f16x3"], batch0=n, a_bs0=Pp * cin, b_bs0=Cout * cin,
-                   c_bs0=Pp * Cout, alpha=PP_A_SCALE / WINO4_U_SCALE, _keep=(U, vhl, V)))
+        _run(_desc(A_hl=U.hl.data_ptr() + x0 * Pp * cin * 4, B=_p(V), B_hl=vhl.data_ptr() + x0 * N * cin * 4, b_scale=vscale, C=_p(Y[x0]),
+                   M=Pp, N=N, K=cin, lda=cin, ldb=cin, ldc=N, prec=_PREC["f16x3"], batch0=n, a_bs0=Pp * cin, b_bs0=N * cin,
+                   c_bs0=Pp * N, alpha=PP_A_SCALE / WINO4_U_SCALE, _keep=(U, vhl, V)))
+    return Y
+
+
+def _wino4_finish(Y, col0, ldy, bias, B, H, W, Cout, act, residual, residual2, out, out_split, split_relu, also_split, chain_next):
+    """Output side of a Winograd F(4x4) layer whose products are columns col0 .. col0 + Cout of Y (36, Pp, ldy): the chained transform into
+    the next layer's WinoInput4, or the output transform into an operand and / or an fp32 map."""
+    P = B * (H // 4) * (W // 4)
+    Pp, dev, L = _wino4_rows(P), Y.device, _lib.lib()
+    yp = Y.data_ptr() + 4 * col0
     ret, hl_t, ldc = None, None, 0
-    # (W = 16: the chain's one workgroup per (image, slice) is four tile rows long and loses to the two separate kernels, 0.121 vs 0.095 ms)
+    # (W = 16: the chain's one workgroup per (image, slice) is four tile rows long and loses to the two separate kernels, 0.144 vs 0.108 ms)
     if (chain_next and WINO4_CHAIN and out_split and out is None and residual is None and residual2 is None and W in WINO4_CHAIN_WIDTHS and Cout % 32 == 0
             and _winograd4_ok(B, H, W, Cout, Cout)):
         # the next layer's Winograd input straight from this layer's products: h = act(A^T Y A + bias) lives in LDS only
         U1 = Split((torch.empty if Pp == P else torch.zeros)(36 * Pp, 2 * Cout, dtype=torch.float16, device=dev), 2)
-        _lib.check(L.pp_winograd4_chain(_p(Y), B, H, W, Cout, _p(bias), ACT[act], int(split_relu), _p(U1.hl), Pp, _lib.stream_ptr()), "pp_winograd4_chain")
+        _lib.check(L.pp_winograd4_chain(yp, ldy, B, H, W, Cout, _p(bias), ACT[act], int(split_relu), _p(U1.hl), Pp, _lib.stream_ptr()), "pp_winograd4_chain")
         _chk(U1.hl, "pp_winograd4_chain")
         return WinoInput4(U1, (B, H, W, Cout), None)
     if out_split and out is None and residual is None and residual2 is None:
@@ -883,11 +878,77 @@ def _conv3x3_winograd4(x, wp, bias, B, H, W, cin, Cout, act, residual, residual2
             hl_t.image = (B, H, W)
             c_relu = int(also_split == "relu")
             setattr(out, "_hl_relu" if also_split == "relu" else "_hl", hl_t)
-    _lib.check(L.pp_winograd4_output(_p(Y), B, H, W, Cout, _p(bias), ACT[act], _p(residual), _p(residual2), _p(out), ldc,
+    _lib.check(L.pp_winograd4_output(yp, ldy, B, H, W, Cout, _p(bias), ACT[act], _p(residual), _p(residual2), _p(out), ldc,
                                      _p(hl_t.hl) if hl_t is not None else None, Cout, c_relu, Pp, _lib.stream_ptr()), "pp_winograd4_output")
     if hl_t is not None:
         _chk(hl_t.hl, "pp_winograd4_output")
     return ret
+
+
+def _conv3x3_winograd4(x, wp, bias, B, H, W, cin, Cout, act, residual, residual2, out, out_split, split_relu, also_split, chain_next=False):
+    """3x3 / stride 1 / pad 1 on an operand image by Winograd F(4x4, 3x3): input transform (operand -> operand), 36 dense products on the
+    pre-split engine as grouped launches, output transform with bias / activation (/ residuals) into an fp32 map and / or the next
+    layer's operand.  x: a Split with .image, (Split, col0) for a channel slice of it, or its WinoInput4."""
+    P = B * (H // 4) * (W // 4)
+    V, vhl, vscale = winograd4_weight(wp, cin)
+    if isinstance(x, WinoInput4):
+        assert x.geom == (B, H, W, cin)
+        U = x.U
+    elif isinstance(x, tuple):
+        U = _winograd4_input(x[0].col_ptr(x[1]), x[0].shape[1], B, H, W, cin, x[0].device)
+    else:
+        U = _winograd4_input(x.hl.data_ptr(), x.shape[1], B, H, W, cin, x.device)
+    Pp = _wino4_rows(P)
+    assert U.hl.shape[0] == 36 * Pp
+    Y = _wino4_products(U, V, vhl, vscale, Pp, cin, Cout)
+    return _wino4_finish(Y, 0, Cout, bias, B, H, W, Cout, act, residual, residual2, out, out_split, split_relu, also_split, chain_next)
+
+
+WINO4_PAIR = os.environ.get("PP_WINOGRAD4_PAIR", "1") != "0"
+
+
+def winograd4_weight_pair(wp_a, wp_b, cin):
+    """(V (36 (Ca + Cb), Cin), its hl operand, scale) for TWO layers that read the same Winograd input: per frequency the rows of layer a, then
+    those of layer b — one product with N = Ca + Cb serves both (the activation operand U is then read once).  Cached per version pair."""
+    key = (wp_a.data_ptr(), wp_b.data_ptr(), tuple(wp_a.shape), tuple(wp_b.shape), "wino4pair")
+    hit = _wino_cache.get(key)
+    if hit is None or hit[2] != (wp_a._version, wp_b._version):
+        Va, Vb = winograd4_weight(wp_a, cin)[0], winograd4_weight(wp_b, cin)[0]
+        Ca, Cb = wp_a.shape[0], wp_b.shape[0]
+        V = torch.cat([Va.view(36, Ca, cin), Vb.view(36, Cb, cin)], dim=1).reshape(36 * (Ca + Cb), cin).contiguous()
+        hl = torch.empty(V.shape[0], 2 * cin, dtype=torch.float16, device=V.device)
+        scale = torch.empty(1, dtype=torch.float32, device=V.device)
+        _lib.check(_lib.lib().pp_split_weights_t(_p(V), V.numel(), 2, _p(hl), _p(scale), _lib.stream_ptr()), "pp_split_weights_t")
+        hit = _wino_cache[key] = (V, (wp_a, wp_b), (wp_a._version, wp_b._version), hl, float(scale.item()))
+    return hit[0], hit[3], hit[4]
+
+
+def conv2d_wino_pair(x, layer_a, layer_b, act=None, out_split=False, split_relu=False, wino_next=False):
+    """Two 3x3 / stride 1 / pad 1 convolutions (wp, bias) of the SAME operand image (the flow and certainty heads' first layers,
+    flow_decoder.py:58-72) by Winograd F(4x4, 3x3) with ONE product per frequency over the concatenated filters (N = Ca + Cb): the input
+    operand U is read once instead of twice (5.67 -> 5.48 ms for the 640 -> 512 pair at 64 x 64 x 160).  Every output element is the sum the
+    separate products make (the engine's accumulation order does not depend on N) — unless the two filters' power-of-two operand scales
+    differ from the concatenated tensor's (then within fp16 subnormals of the lo terms, as for stage3.FUSE_XHEADS).  Returns the two
+    results (Splits, or WinoInput4s with wino_next); falls back to two conv2d calls where F(4x4) does not apply."""
+    (wa, ba), (wb, bb) = layer_a, layer_b
+    kw = dict(act=act, out_split=out_split, split_relu=split_relu, wino=True, wino_next=wino_next)
+    src = x.src if isinstance(x, WinoInput4) else x
+    if not (WINO4_PAIR and isinstance(x, (WinoInput4, Split)) and out_split):
+        return conv2d(x, wa, ba, 3, pad=1, **kw), conv2d(x, wb, bb, 3, pad=1, **kw)
+    if isinstance(x, WinoInput4):
+        B, H, W, cin = x.geom
+    else:
+        (B, H, W), cin = src.image, src.shape[1]
+    Ca, Cb = wa.shape[0], wb.shape[0]
+    if not (_winograd4_ok(B, H, W, cin, Ca) and _winograd4_ok(B, H, W, cin, Cb) and wa.shape[1] == 9 * cin == wb.shape[1] and Ca % 8 == 0):
+        return conv2d(x, wa, ba, 3, pad=1, **kw), conv2d(x, wb, bb, 3, pad=1, **kw)
+    P = B * (H // 4) * (W // 4)
+    Pp = _wino4_rows(P)
+    U = x.U if isinstance(x, WinoInput4) else _winograd4_input(src.hl.data_ptr(), cin, B, H, W, cin, src.device)
+    V, vhl, vscale = winograd4_weight_pair(wa, wb, cin)
+    Y = _wino4_products(U, V, vhl, vscale, Pp, cin, Ca + Cb)
+    fin = lambda col0, C, bias: _wino4_finish(Y, col0, Ca + Cb, bias, B, H, W, C, act, None, None, None, out_split, split_relu, None, wino_next)  # noqa: E731
+    return fin(0, Ca, ba), fin(Ca, Cb, bb)
 
 
 def conv_transpose2d(x, wp, bias_tiled, r, out_split=False):

@@ -513,6 +513,16 @@ def test_winograd4_3x3_of_the_f16x3_engine(monkeypatch, engine_precision, B, cin
         sep = ops.conv2d(xs, wp, b.cuda(), 3, pad=1, out_split=True, wino=True, **kw)
         assert isinstance(sep, ops.Split)
         assert torch.equal(ops.conv2d(ch, w3p, None, 3, pad=1, wino=True), ops.conv2d(sep, w3p, None, 3, pad=1, wino=True))
+    # two layers that read the same operand as ONE product per frequency (filters concatenated along N): each layer's result equals its
+    # own product's — bit for bit when the operand scales coincide, else within fp16 subnormals of the weights' lo terms (1e-6)
+    for nxt in (False, True):
+        pa, pb = ops.conv2d_wino_pair(sh, (wp, b.cuda()), (w2p, None), act="relu", out_split=True, wino_next=nxt)
+        sa = ops.conv2d(sh, wp, b.cuda(), 3, pad=1, act="relu", out_split=True, wino=True, wino_next=nxt)
+        sb = ops.conv2d(sh, w2p, None, 3, pad=1, act="relu", out_split=True, wino=True, wino_next=nxt)
+        for got_, want_ in ((pa, sa), (pb, sb)):
+            assert type(got_) is type(want_)
+            g_, w_ = (got_.U.hl, want_.U.hl) if isinstance(got_, ops.WinoInput4) else (got_.hl, want_.hl)
+            assert float((g_.float() - w_.float()).abs().max()) <= 1e-6 * float(w_.float().abs().max()) + 1e-7
     # a grouped launch cut into several (32-bit byte offsets of the stacked blocks): the same bits
     one = ops.conv2d(xs, wp, b.cuda(), 3, pad=1, wino=True)
     monkeypatch.setattr(ops, "WINO4_GROUPS_PER_LAUNCH", 7)

@@ -63,13 +63,13 @@ def main():
         Y = torch.empty(36, P, cout, device="cuda")
         hl_t = ops.Split.empty(B * hw * hw, cout, xs.device)
         from picopose_amd import _lib
-        t_out = timed(lambda: _lib.check(_lib.lib().pp_winograd4_output(Y.data_ptr(), B, hw, hw, cout, bias.data_ptr(), 1, None, None, None, 0,
+        t_out = timed(lambda: _lib.check(_lib.lib().pp_winograd4_output(Y.data_ptr(), cout, B, hw, hw, cout, bias.data_ptr(), 1, None, None, None, 0,
                                                                          hl_t.hl.data_ptr(), cout, 0, P, _lib.stream_ptr()), "out"), a.reps)
         t_g = t_shared - t_out
         fl = 2.0 * B * hw * hw * cout * 9 * cin
         if cout % 32 == 0 and hw in (16, 32, 64):   # the chained output -> input transform against the two separate kernels (next layer: cout -> cout)
             U1 = ops.Split(torch.empty(36 * P, 2 * cout, dtype=torch.float16, device="cuda"), 2)
-            t_ch = timed(lambda: _lib.check(_lib.lib().pp_winograd4_chain(Y.data_ptr(), B, hw, hw, cout, bias.data_ptr(), 1, 0, U1.hl.data_ptr(), P,
+            t_ch = timed(lambda: _lib.check(_lib.lib().pp_winograd4_chain(Y.data_ptr(), cout, B, hw, hw, cout, bias.data_ptr(), 1, 0, U1.hl.data_ptr(), P,
                                                                           _lib.stream_ptr()), "chain"), a.reps)
             t_in2 = timed(lambda: ops._winograd4_input(hl_t.hl.data_ptr(), cout, B, hw, hw, cout, xs.device), a.reps)
             name = f"{name} | out+in {t_out + t_in2:.3f} chained {t_ch:.3f}"
