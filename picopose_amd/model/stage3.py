@@ -125,7 +125,7 @@ class DPTHead(Packed):
         # (COMPUTE_DEAD_LAYER1 = True runs them anyway: the bench's A/B, test_dead_layer1_branch_does_not_reach_any_output).
         live = range(4) if COMPUTE_DEAD_LAYER1 else range(1, 4)
         x = {i: ops.conv2d(feats[i], pk[f"proj{i}"], self.projects[i].bias, 1, out_split=True) for i in live}
-        B0, H0, W0, _ = feats[0].shape
+        _, H0, W0, _ = feats[0].shape
         size1 = (4 * H0, 4 * W0)                               # layer_1_rn.shape[2:]: ConvTranspose2d(kernel = stride = 4), then 3x3 / pad 1
         l2 = ops.conv_transpose2d(x[1], pk["up1"], pk["up1_b"], 2, out_split=True)
         l3 = x[2]
