@@ -186,6 +186,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 // The transforms are fp32 sums; their rounding is what F(4x4) costs: ~1e-5 of the map's maximum per layer against ~4e-7 direct
 // (tools/wino_precision_study.py) — inside every parity bar of the f16x3 mode (2e-4 / 5e-4 of the maximum).
 typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+// cache policy of the streamed-once accesses of the transforms (Y read once, U written once): 0 = default, 2 = nt (study: profiles/r06/README.md)
+#ifndef PP_WINO_LD_AUX
+#define PP_WINO_LD_AUX 0
+#endif
+#ifndef PP_WINO_ST_AUX
+#define PP_WINO_ST_AUX 0
+#endif
 
 // XCD-contiguous block order: hardware block b runs on XCD b % 8; logical blocks of one XCD are consecutive, so neighbouring tiles
 // (which share input columns / rows) meet in the same L2
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void wino4_input_kernel(const _Float16* __r
         for (int bb = 0; bb < 6; ++bb) {
             hf4 hi, lo;
             wino_split4(u[bb] * (1.f / 64.f), hi, lo, top);       // (the 4 x of the source operand) / 64 = (B^T d B) / 16
-            __builtin_amdgcn_raw_buffer_store_b128(wino_pair_pack(par, hi, lo), wino_block_rsrc(U, 6 * a + bb, blk), uoff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(wino_pair_pack(par, hi, lo), wino_block_rsrc(U, 6 * a + bb, blk), uoff, 0, PP_WINO_ST_AUX);
         }
     }
     wino_note_sat(!(top < 65504.f), sat);
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     for (int bb = 0; bb < 6; ++bb) {
         f4 y[6];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) y[a] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wino_block_rsrc(Y, 6 * a + bb, blk), yoff, 0, 0));
+        for (int a = 0; a < 6; ++a) y[a] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wino_block_rsrc(Y, 6 * a + bb, blk), yoff, 0, PP_WINO_LD_AUX));
         PP_W4_AT(y[0], y[1], y[2], y[3], y[4], y[5], z[0][bb], z[1][bb], z[2][bb], z[3][bb])
     }
     const f4 bv = bias ? *(const f4*)(bias + c) : f4{0.f, 0.f, 0.f, 0.f};
@@ -483,7 +490,7 @@ __global__ __launch_bounds__((1 + NB) * ((W / 4) * 8 < 64 ? 64 : (W / 4) * 8)) v
             for (int bb = 0; bb < 6; ++bb) {
                 f4 y[6];
 #pragma unroll
-                for (int a = 0; a < 6; ++a) y[a] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wino_block_rsrc(Y, wino_opaque(6 * a + bb), blky), yoff, 0, 0));
+                for (int a = 0; a < 6; ++a) y[a] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wino_block_rsrc(Y, wino_opaque(6 * a + bb), blky), yoff, 0, PP_WINO_LD_AUX));
                 PP_W4_AT(y[0], y[1], y[2], y[3], y[4], y[5], z[0][bb], z[1][bb], z[2][bb], z[3][bb])
             }
             float* slot = chs + (r & 3) * SLOT;
@@ -550,7 +557,7 @@ __global__ __launch_bounds__((1 + NB) * ((W / 4) * 8 < 64 ? 64 : (W / 4) * 8)) v
                 for (int bb = 0; bb < 6; ++bb) {
                     hf4 hi, lo;
                     wino_split4(u[bb] * (1.f / 64.f), hi, lo, top);
-                    __builtin_amdgcn_raw_buffer_store_b128(wino_pair_pack(par, hi, lo), wino_block_rsrc(U, wino_opaque(6 * (a0 + ai) + bb), blk), uoff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(wino_pair_pack(par, hi, lo), wino_block_rsrc(U, wino_opaque(6 * (a0 + ai) + bb), blk), uoff, 0, PP_WINO_ST_AUX);
                 }
             }
         }
