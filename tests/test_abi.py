@@ -47,6 +47,29 @@ def test_argument_validation_needs_no_gpu():
     assert L.pp_corr_lookup_nhwc_hl(None, 256, None, None, None, 1, None, 1, 64, 64, 256, 3, 2, 2, None, 80, None) == -1
     assert L.pp_hl_patch_columns(None, 2, 2, 10, None, 640, 638, None) == -1
     assert L.pp_sum_slices(None, 32, 160, 1024, None, 3, None, None) == -1
+    # round 6: the Winograd F(4x4, 3x3) entries reject null operands, maps that are no multiple of the 4x4 tile, channel counts off
+    # the operand's 8-column groups, a tile count above the padded row count and byte extents beyond the 32-bit buffer offsets
+    import ctypes as c
+    buf = (c.c_char * 64)()
+    p = c.addressof(buf) + (-c.addressof(buf)) % 16
+    assert L.pp_winograd4_input_hl(None, 64, 64 * 64 * 64, 1, 64, 64, 64, 0, None, 256, None) == -1
+    assert L.pp_winograd4_input_hl(p, 64, 62 * 64 * 64, 1, 62, 64, 64, 0, p, 256, None) == -1          # H % 4
+    assert L.pp_winograd4_input_hl(p, 60, 64 * 64 * 60, 1, 64, 64, 60, 0, p, 256, None) == -1          # C % 8
+    assert L.pp_winograd4_input_hl(p, 64, 64 * 64 * 64, 1, 64, 64, 64, 0, p, 255, None) == -1          # P_pad < tiles
+    assert L.pp_winograd4_input_hl(p, 1024, 64 * 64 * 1024, 400, 64, 64, 1024, 0, p, 102400, None) == -1   # operand beyond 4 GiB of offsets
+    assert L.pp_winograd4_weight_f32(None, 64, 64, 576, None, None) == -1
+    assert L.pp_winograd4_weight_f32(p, 64, 64, 575, p, None) == -1                                    # ldw < 9 Cin
+    assert L.pp_winograd4_output(None, 64, 1, 64, 64, 64, None, 0, None, None, None, 64, None, 64, 0, 256, None) == -1
+    assert L.pp_winograd4_output(p, 64, 1, 64, 64, 64, None, 0, None, None, None, 64, None, 64, 0, 256, None) == -1   # neither output
+    assert L.pp_winograd4_output(p, 64, 1, 64, 64, 64, None, 7, None, None, p, 64, None, 64, 0, 256, None) == -1      # activation code
+    assert L.pp_winograd4_output(p, 64, 1, 64, 64, 64, None, 0, p, None, None, 64, p, 64, 0, 256, None) == -1         # residual without fp32 out
+    assert L.pp_winograd4_output(p, 32, 1, 64, 64, 64, None, 0, None, None, p, 64, None, 64, 0, 256, None) == -1      # ld_y < Cout
+    assert L.pp_winograd4_chain(None, 64, 1, 64, 64, 64, None, 0, 0, None, 256, None) == -1
+    assert L.pp_winograd4_chain(p, 64, 1, 64, 48, 64, None, 0, 0, p, 256, None) == -1                  # widths 16 / 32 / 64 only
+    assert L.pp_winograd4_chain(p, 48, 1, 64, 64, 48, None, 0, 0, p, 256, None) == -1                  # C % 32
+    assert L.pp_winograd_chain_f32(None, 1, 64, 64, 64, None, 0, 0, None, None) == -1
+    assert L.pp_winograd_chain_f32(p, 1, 63, 64, 64, None, 0, 0, p, None) == -1                        # H % 2
+    assert L.pp_winograd_chain_f32(p, 1, 64, 24, 64, None, 0, 0, p, None) == -1
 
 
 def test_state_dict_names_shapes_equal_the_reference(golden_dir):
