@@ -637,7 +637,7 @@ def main():
         ep = make_end_points(Bl, N, dev, 100 + rank)                     # this rank's crops + their raw templates
         # a second, different batch: the timed loop alternates the two, so every step's look-ahead prefetches crops that are NOT the
         # ones it is working on (--single-batch: one batch, as in rounds 1-5)
-        two_batches = a.prefetch_query and not a.single_batch and not sharded and kind != "full_cached"
+        two_batches = a.prefetch_query and not a.single_batch and not sharded and not cached   # (extended bank: no template-side pass to ride in)
         ep_b = make_end_points(Bl, N, dev, 200 + rank) if two_batches else None
         fe = net.feature_extractor
         # feature bank (outside the timed region, run_test.py:120-134): this rank's template slice of ALL crops.
@@ -1035,7 +1035,7 @@ def main():
                        "hypotheses": 5, "mode": a.mode, "bank_dtype": "f16" if bpe == 2 else "f32",
                        "weights": "seeded random init, prediction heads calibrated (picopose_amd/utils/seeding.py)",
                        "shard": "none" if world == 1 else a.shard,
-                       "prefetch_query": bool(a.prefetch_query) if kind != "stage1" else None,
+                       "prefetch_query": (bool(a.prefetch_query) and not cached) if kind != "stage1" else None,
                        "input_batches": None if kind == "stage1" else (2 if (kind != "stage1" and ep_b is not None) else 1),
                        "winograd_f4x4_heads": bool(ops.WINOGRAD4) if a.mode == "fast" else False,
                        "dpt_layer1_branch": None if kind == "stage1" else
@@ -1099,7 +1099,7 @@ def main():
                 "dominant_launches": dom["launches"] if dom else None,
                 "algorithmic_flops_per_step": fl, "mfma_flops_per_step": mult * fl,
                 "avg_launch_ms": msum / n,
-                "traffic_bytes_per_step": g_traffic, "traffic_measured_in_this_run": False, "prefetch_query": bool(a.prefetch_query),
+                "traffic_bytes_per_step": g_traffic, "traffic_measured_in_this_run": False, "prefetch_query": bool(a.prefetch_query) and not cached,
                 "dominant_kernel": ((dom["kernel"] + " | " + dom["a_operand"])[:100] if dom else None),
                 "kernel": {"fast": "pp_gemm_u_kernel, all tiles: operands pre-split in 2 f16 terms, 3 MFMAs per product",
                            "fp16": "pp_gemm_u_kernel, all tiles: plain f16 operands, 1 MFMA per product",

@@ -1,5 +1,5 @@
 """Which GEMM / conv launches of ONE inference step (default bench workload) take the time: per-launch engine records grouped by
-(M, N, K, conv, tile configuration).  usage: infer_gemm_trace.py"""
+(M, N, K, conv, tile configuration).  usage: infer_gemm_trace.py [cached]    (cached: the extended template bank)"""
 import collections
 import ctypes
 import os
@@ -23,7 +23,13 @@ net = Net(bench.make_cfg(vit))
 bench.seeded_weights(net, 4, vit)
 net = net.to(dev).eval()
 ep = bench.make_end_points(Bl, N, dev, 100)
-with torch.no_grad():
+if "cached" in sys.argv[1:]:
+    banks = [net.precompute_templates(ep["tem_rgb"][b]) for b in range(Bl)]
+    ep["template_feature"] = torch.stack([bk["feature"] for bk in banks])
+    ep["template_cache"] = {"obj_index": torch.arange(Bl, device=dev), "dpt": [torch.stack([bk["dpt"][k] for bk in banks]) for k in range(3)]}
+    del banks
+else:
+  with torch.no_grad():
     ep["template_feature"] = torch.stack([torch.cat([net.feature_extractor(ep["tem_rgb"][b, s:min(s + 54, N)])[-1] for s in range(0, N, 54)]) for b in range(Bl)])
 L = _lib.lib()
 for i in range(3):
