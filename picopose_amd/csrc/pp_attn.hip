@@ -22,15 +22,20 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int HD = 64, KC = 32, KLD = 68;  // head dim, keys per chunk, floats per LDS row of the K chunk
 
-__global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv, int T, int heads, float scale,
-                                                   float* __restrict__ out, _Float16* __restrict__ out_hl) {
+// WPB waves of 32 queries per workgroup: T = 257 is nine query tiles — three workgroups of three waves, where four-wave workgroups run
+// twelve (round 6).  KTAIL: the T % 32 keys past the last full chunk, when they are few (one for T = 257), are folded in by plain
+// vector fma's per key (64 of them per lane) instead of a ninth chunk whose 64 MFMAs work on 31 masked keys.
+constexpr int KTAIL_MAX = 4;
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void attn_kernel(const float* __restrict__ qkv, int T, int heads, float scale,
+                                                        float* __restrict__ out, _Float16* __restrict__ out_hl) {
     __shared__ __attribute__((aligned(16))) float Ks[KC * KLD];
     __shared__ __attribute__((aligned(16))) float Vs[KC * HD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int b = blockIdx.y / heads, h = blockIdx.y % heads;
     const int C3 = 3 * heads * HD;
     const float* base = qkv + (size_t)b * T * C3 + h * HD;  // q at +0, k at +heads*HD, v at +2*heads*HD, token stride C3
-    const int q = blockIdx.x * 128 + w * 32 + l31;           // this lane's query row
+    const int q = blockIdx.x * (32 * WPB) + w * 32 + l31;    // this lane's query row
     const int qc = q < T ? q : T - 1;
 
     // Q as the B operand of S^T = K Q^T: lane (d part lh, query l31) holds Q[q][32 lh + p] * scale, p = 0..31
@@ -51,12 +56,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
 
     const float* kp = base + heads * HD;
     const float* vp = base + 2 * heads * HD;
-    for (int k0 = 0; k0 < T; k0 += KC) {
+    const int ktail = (T % KC) <= KTAIL_MAX ? T % KC : 0;   // keys left to the vector tail below
+    const int kend = T - ktail;
+    for (int k0 = 0; k0 < kend; k0 += KC) {
         __syncthreads();  // previous chunk fully consumed
-        // stage K and V chunks: 32 keys x 64 floats each = 512 float4: two per thread per tensor
+        // stage K and V chunks: 32 keys x 64 floats each = 512 float4 per tensor
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 4, c4 = (idx & 15) * 4;
+        for (int idx = tid; idx < KC * HD / 4; idx += 64 * WPB) {
+            const int row = idx >> 4, c4 = (idx & 15) * 4;
             f4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
             if (k0 + row < T) {
                 kv = *(const f4*)(kp + (size_t)(k0 + row) * C3 + c4);
@@ -118,6 +125,37 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
             const float v0 = Vs[key * HD + l31], v1 = Vs[key * HD + 32 + l31];
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[e], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[e], o1, 0, 0, 0);
+        }
+    }
+    for (int kx = kend; kx < T; ++kx) {   // (wave-uniform addresses: the loads below are broadcasts)
+        const float* kr = kp + (size_t)kx * C3 + 32 * lh;
+        float sp = 0.f;
+#pragma unroll
+        for (int p = 0; p < 32; p += 4) {
+            const f4 kf = *(const f4*)(kr + p);
+            sp = fmaf(kf.x, qr[p], sp);
+            sp = fmaf(kf.y, qr[p + 1], sp);
+            sp = fmaf(kf.z, qr[p + 2], sp);
+            sp = fmaf(kf.w, qr[p + 3], sp);
+        }
+        const float sc = sp + __shfl_xor(sp, 32);            // the score of (key kx, query l31), the same in both lane halves
+        const float mnew = fmaxf(mrun, sc);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        const float pk = __builtin_amdgcn_exp2f(sc - mnew);
+        lrun = lrun * alpha + pk;
+        mrun = mnew;
+        const float* vr = vp + (size_t)kx * C3 + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                        // accumulator register 4 g + i holds d = 8 g + 4 lh + i (+ 32 for o1)
+            const f4 v0 = *(const f4*)(vr + 8 * g), v1 = *(const f4*)(vr + 32 + 8 * g);
+            o0[4 * g] = fmaf(v0.x, pk, o0[4 * g] * alpha);
+            o0[4 * g + 1] = fmaf(v0.y, pk, o0[4 * g + 1] * alpha);
+            o0[4 * g + 2] = fmaf(v0.z, pk, o0[4 * g + 2] * alpha);
+            o0[4 * g + 3] = fmaf(v0.w, pk, o0[4 * g + 3] * alpha);
+            o1[4 * g] = fmaf(v1.x, pk, o1[4 * g] * alpha);
+            o1[4 * g + 1] = fmaf(v1.y, pk, o1[4 * g + 1] * alpha);
+            o1[4 * g + 2] = fmaf(v1.z, pk, o1[4 * g + 2] * alpha);
+            o1[4 * g + 3] = fmaf(v1.w, pk, o1[4 * g + 3] * alpha);
         }
     }
     if (q < T) {
@@ -752,8 +790,13 @@ static int attention_launch(const void* qkv, bool hl_in, int B, int T, int heads
             hipLaunchKernelGGL(attn_f16x3_kernel<false>, grid, dim3(64 * wpb), kv > os ? kv : os, (hipStream_t)stream, qkv, T, heads, scale, out,
                                (_Float16*)out_hl, lse, ntx, npairs);
     } else {
-        hipLaunchKernelGGL(attn_kernel, dim3((T + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, (const float*)qkv, T, heads,
-                           scale, out, (_Float16*)out_hl);
+        // three-wave workgroups when they run fewer waves in all (T = 257: 9 against 12)
+        if (((T + 95) / 96) * 3 < ((T + 127) / 128) * 4)
+            hipLaunchKernelGGL(attn_kernel<3>, dim3((T + 95) / 96, B * heads), dim3(192), 0, (hipStream_t)stream, (const float*)qkv, T, heads,
+                               scale, out, (_Float16*)out_hl);
+        else
+            hipLaunchKernelGGL(attn_kernel<4>, dim3((T + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, (const float*)qkv, T, heads,
+                               scale, out, (_Float16*)out_hl);
     }
     return pp_last_launch();
 }

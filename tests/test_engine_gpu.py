@@ -627,7 +627,7 @@ def test_gelu_epilogue_accuracy():
 
 
 @gpu
-@pytest.mark.parametrize("B,T,heads", [(1, 1, 1), (2, 33, 2), (3, 100, 6), (2, 257, 12), (1, 300, 3), (1, 1025, 2)])
+@pytest.mark.parametrize("B,T,heads", [(1, 1, 1), (1, 3, 2), (2, 33, 2), (2, 96, 3), (3, 100, 6), (2, 257, 12), (1, 300, 3), (1, 1025, 2)])
 def test_attention_shapes_and_operand_input(B, T, heads, engine_precision):
     """Fused attention for ragged sequence lengths (query tiles / key chunks with tails), from the fp32 qkv tensor
     and — f16x3 engine — from the hl operand the qkv GEMM epilogue writes (same bits)."""
