@@ -917,7 +917,8 @@ def main():
             # ... and with every convolution DIRECT (the reference's operation count, ops.WINOGRAD off): 2 warm-up steps, 3 timed
             xd_dt = None
             if ops.WINOGRAD:
-                ops.WINOGRAD = False
+                from picopose_amd.model import stage3 as _s3
+                ops.WINOGRAD, ocf, _s3.OUT_CONV_FIRST = False, _s3.OUT_CONV_FIRST, False     # (... and the reference's order out_conv(interpolate(.)))
                 try:
                     for j_ in range(2):
                         step()
@@ -928,7 +929,7 @@ def main():
                     torch.cuda.synchronize()
                     xd_dt = (time.perf_counter() - t1) / 4
                 finally:
-                    ops.WINOGRAD = True
+                    ops.WINOGRAD, _s3.OUT_CONV_FIRST = True, ocf
             # its own roofline: HIP events around every GEMM launch of one more (untimed) exact step, fp32-MFMA peak
             _lib.check(L.pp_prof_gemm_enable(8192), "pp_prof_gemm_enable")
             forward()

@@ -294,6 +294,10 @@ int pp_layernorm_t(const float* x, const float* gamma, const float* beta, int ro
                    void* stream);
 int pp_resize_bilinear_nhwc_t(const float* in, int B, int H, int W, int C, int Ho, int Wo, float mul, void* out, int terms,
                               void* stream);
+/* ... the same resize with BOTH results: the fp32 map `out` (B, Ho, Wo, C) and its operand form `out_operand` (the DPT fusion block's
+ * path map, dpt.py:150-155 with out_conv moved in front of the interpolation: an output and the flow decoder's projection input). */
+int pp_resize_bilinear_nhwc_dual(const float* in, int B, int H, int W, int C, int Ho, int Wo, float mul, float* out, void* out_operand,
+                                 int terms, void* stream);
 int pp_warp_nhwc_t(const float* feat, int feat_batch, const float* flow, int B, int H, int W, int C, int ld_flow, void* out,
                    int ld_h, int terms, void* stream);
 /* attention on the operand the qkv GEMM wrote, result as fp32 (out) and / or as an operand (out_operand), both optional */

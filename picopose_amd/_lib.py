@@ -116,6 +116,7 @@ def lib():
         L.pp_hl_patch_columns_t.argtypes = [vp, i32, i32, c.c_longlong, vp, i32, i32, i32, vp]
         L.pp_layernorm_t.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, i32, vp]
         L.pp_resize_bilinear_nhwc_t.argtypes = [vp, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp]
+        L.pp_resize_bilinear_nhwc_dual.argtypes = [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp]
         L.pp_warp_nhwc_t.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
         L.pp_attention_t.argtypes = [vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]
         L.pp_sum_slices.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp]

@@ -24,8 +24,9 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
     const int y0 = (int)fy, y1 = y0 + (y0 < H - 1 ? 1 : 0);
     const float ly = fy - (float)y0, hy = 1.f - ly;
     const float* ib = in + (size_t)b * H * W * C;
-    if (out_hl) {  // the result only as the f16x3 operand of the following 1x1 convolution: 8 channels per thread
+    if (out_hl) {  // the result as the f16x3 operand of the following 1x1 convolution (and, `out` given, as the fp32 map too): 8 channels per thread
         _Float16* oh = out_hl + ((size_t)b * Ho + oy) * Wo * terms * C;   // terms = 2: hl format, 1: h format
+        float* of = out ? out + ((size_t)b * Ho + oy) * Wo * C : nullptr;
         const int C8 = C >> 3;
         for (int i = blockIdx.x * 256 + tid; i < Wo * C8; i += gridDim.x * 256) {
             const int ox = i / C8, c = (i - ox * C8) * 8;
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
                 const int cc = c + 4 * q;
                 const f4 a = *(const f4*)(ib + ((size_t)y0 * W + x0) * C + cc), bq = *(const f4*)(ib + ((size_t)y0 * W + x1) * C + cc);
                 const f4 cq = *(const f4*)(ib + ((size_t)y1 * W + x0) * C + cc), dq = *(const f4*)(ib + ((size_t)y1 * W + x1) * C + cc);
+                f4 vq;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float v = (hy * (hx * a[k] + lx * bq[k]) + ly * (hx * cq[k] + lx * dq[k])) * mul;
@@ -46,7 +48,9 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
                     pp_split_f16_chk(v, h, l);
                     hh[4 * q + k] = h;
                     ll[4 * q + k] = l;
+                    vq[k] = v;
                 }
+                if (of) *(f4*)(of + (size_t)ox * C + cc) = vq;
             }
             *(h8*)(oh + ((size_t)ox * C + c) * terms) = hh;
             if (terms == 2) *(h8*)(oh + (size_t)ox * 2 * C + 2 * c + 8) = ll;
@@ -575,8 +579,8 @@ __global__ __launch_bounds__(256) void depth_points_kernel(const float* __restri
 // On the GEMM engine such a layer pads its 2 (or 1) filters to a 64-wide tile and re-reads every pixel per tap from L2
 // (0.6 ms for the 3x3 at 64 x 64 x 160, 10 TFLOP/s).  Here a workgroup takes a band of 256 / W full image rows (one output
 // pixel per thread), stages the band plus a one-pixel halo per 32-channel slice in LDS (the input is the hl operand its
-// producer wrote: 128 bytes per pixel and slice) and every thread walks the taps of its pixel: x = hi + lo is the exact
-// fp32 value / 4, the weights are the layer's fp32 filters (scalar loads: the index is uniform), fp32 fma accumulation.
+// producer wrote: 128 bytes per pixel and slice; x = hi + lo, the exact fp32 value x 4, is formed once per staged element) and
+// every thread walks the taps of its pixel: the weights are the layer's fp32 filters (scalar loads: the index is uniform), fp32 fma.
 constexpr int NRW_PITCH = 144;   // bytes per staged pixel: 128 + 16 (conflict-free 16-byte reads along a row of pixels)
 
 // F32IN (round 5, ops.PRECISION = "f32"): the input is the fp32 NHWC map itself (ldx floats per pixel; a 32-channel slice of a pixel is
@@ -595,24 +599,32 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const _Float16* __rest
 #pragma unroll
     for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
     const int K = KS * KS * C;
-    // staged pieces of this thread (16 bytes each; at most 13 for the 6 x 66 band of a 64-wide image), fetched one slice ahead
-    constexpr int MAXP = 13;
-    const int npiece = PH * PW * 8;
-    float4 pre[MAXP];
+    // staged items of this thread, fetched one slice ahead.  fp32 input: 16-byte pieces (at most 13 for the 6 x 66 band of a 64-wide
+    // image).  hl input: 32-byte items — the hi and the lo terms of 8 channels — at most 7; they are summed to the fp32 value ONCE as
+    // they are staged (round 6: every tap of every neighbour used to redo the two conversions and the add — 3 of the 5 vector
+    // instructions per product), so LDS holds 32 floats per pixel and slice either way and the tap loop is pure fma.
+    constexpr int MAXP = F32IN ? 13 : 7, PPX = F32IN ? 8 : 4;      // items per thread; items per pixel
+    const int npiece = PH * PW * PPX;
+    float4 pre[F32IN ? MAXP : 2 * MAXP];
     auto fetch = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
             // halo pixels outside the image and slots past the band: the load runs on a clamped pixel and its value is masked
             // to zero bit-wise (zero padding) — no per-lane guarded load, no lane masks held across it
             const int i = min(tid + 256 * j, npiece - 1);
-            const int piece = i & 7, px = i >> 3, sy = px / PW, sx = px - sy * PW;
+            const int piece = i % PPX, px = i / PPX, sy = px / PW, sx = px - sy * PW;
             const int iy = y0 + sy - R, ix = sx - R;
             const unsigned m = 0u - (unsigned)((tid + 256 * j < npiece) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W));
             const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
             typedef unsigned u4n __attribute__((ext_vector_type(4)));
-            const u4n raw = (F32IN ? *(const u4n*)((const float*)x + (((size_t)b * H + iyc) * W + ixc) * (size_t)ldx + c0 + 4 * piece)
-                                   : *(const u4n*)(x + (((size_t)b * H + iyc) * W + ixc) * (size_t)(2 * ldx) + 2 * c0 + 8 * piece)) & m;
-            pre[j] = __builtin_bit_cast(float4, raw);
+            if constexpr (F32IN) {
+                const u4n raw = *(const u4n*)((const float*)x + (((size_t)b * H + iyc) * W + ixc) * (size_t)ldx + c0 + 4 * piece) & m;
+                pre[j] = __builtin_bit_cast(float4, raw);
+            } else {
+                const u4n* src = (const u4n*)(x + (((size_t)b * H + iyc) * W + ixc) * (size_t)(2 * ldx) + 2 * c0 + 16 * piece);
+                pre[2 * j] = __builtin_bit_cast(float4, src[0] & m);       // 8 hi terms
+                pre[2 * j + 1] = __builtin_bit_cast(float4, src[1] & m);   // 8 lo terms
+            }
         }
     };
     fetch(0);
@@ -621,7 +633,19 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const _Float16* __rest
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
             const int i = tid + 256 * j;
-            if (i < npiece) *(float4*)(nsm + (size_t)(i >> 3) * NRW_PITCH + 16 * (i & 7)) = pre[j];
+            if (i >= npiece) continue;
+            if constexpr (F32IN) {
+                *(float4*)(nsm + (size_t)(i >> 3) * NRW_PITCH + 16 * (i & 7)) = pre[j];
+            } else {
+                typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+                const h8v hi = __builtin_bit_cast(h8v, pre[2 * j]), lo = __builtin_bit_cast(h8v, pre[2 * j + 1]);
+                float4 a, c;
+                a.x = (float)hi[0] + (float)lo[0]; a.y = (float)hi[1] + (float)lo[1]; a.z = (float)hi[2] + (float)lo[2]; a.w = (float)hi[3] + (float)lo[3];
+                c.x = (float)hi[4] + (float)lo[4]; c.y = (float)hi[5] + (float)lo[5]; c.z = (float)hi[6] + (float)lo[6]; c.w = (float)hi[7] + (float)lo[7];
+                unsigned char* d = nsm + (size_t)(i >> 2) * NRW_PITCH + 32 * (i & 3);
+                *(float4*)d = a;
+                *(float4*)(d + 16) = c;
+            }
         }
         __syncthreads();
         if (c0 + 32 < C) fetch(c0 + 32);             // in flight under this slice's arithmetic
@@ -631,27 +655,13 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(const _Float16* __rest
             for (int dx = 0; dx < KS; ++dx) {
                 const unsigned char* p = nsm + (size_t)((ty + dy) * PW + tx + dx) * NRW_PITCH;
                 const float* wt = w + (dy * KS + dx) * C + c0;
-                if constexpr (F32IN) {
 #pragma unroll
-                    for (int g = 0; g < 8; ++g) {
-                        const f4 xv = *(const f4*)(p + 16 * g);
+                for (int g = 0; g < 8; ++g) {        // (channels in ascending order, as before the staging change: same bits)
+                    const f4 xv = *(const f4*)(p + 16 * g);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
-                            for (int n = 0; n < NOUT; ++n) acc[n] = fmaf(xv[e], wt[n * K + 4 * g + e], acc[n]);
-                    }
-                    continue;
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-                    const h8v hi = *(const h8v*)(p + 32 * g), lo = *(const h8v*)(p + 32 * g + 16);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float xv = (float)hi[e] + (float)lo[e];
-#pragma unroll
-                        for (int n = 0; n < NOUT; ++n) acc[n] = fmaf(xv, wt[n * K + 8 * g + e], acc[n]);
-                    }
+                        for (int n = 0; n < NOUT; ++n) acc[n] = fmaf(xv[e], wt[n * K + 4 * g + e], acc[n]);
                 }
             }
     }
@@ -689,6 +699,17 @@ int pp_resize_bilinear_nhwc_t(const float* in, int B, int H, int W, int C, int H
     const int gx = (Wo * (C / 8) + 1023) / 1024;
     hipLaunchKernelGGL(resize_kernel, dim3(gx < 64 ? gx : 64, Ho, B), dim3(256), 0, (hipStream_t)stream, in, H, W,
                        C, Ho, Wo, mul, (float*)nullptr, (_Float16*)out_hl, terms);
+    return pp_last_launch();
+}
+
+int pp_resize_bilinear_nhwc_dual(const float* in, int B, int H, int W, int C, int Ho, int Wo, float mul, float* out, void* out_hl,
+                                 int terms, void* stream) {
+    if (!in || !out || !out_hl || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || Ho <= 0 || Wo <= 0 ||
+        (((uintptr_t)in | (uintptr_t)out | (uintptr_t)out_hl) & 15) != 0 || (terms != 1 && terms != 2))
+        return PP_EINVAL;
+    const int gx = (Wo * (C / 8) + 1023) / 1024;
+    hipLaunchKernelGGL(resize_kernel, dim3(gx < 64 ? gx : 64, Ho, B), dim3(256), 0, (hipStream_t)stream, in, H, W,
+                       C, Ho, Wo, mul, out, (_Float16*)out_hl, terms);
     return pp_last_launch();
 }
 

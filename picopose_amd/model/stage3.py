@@ -16,6 +16,10 @@ from .common import Holder, Packed, bn_p, conv_p, convT_p, fold_bn, seq
 
 # ------------------------------------------------------------------------------------------ DPT head
 COMPUTE_DEAD_LAYER1 = os.environ.get("PP_DPT_DEAD_LAYER1", "0") == "1"    # see DPTHead.forward_nhwc
+# FeatureFusionBlock (dpt.py:150-155): out_conv(interpolate(x)).  Both are linear and the bilinear weights of a pixel sum to one, so
+# interpolate(out_conv(x)) is the same map (the bias passes through the interpolation unchanged): the 1x1 convolution then runs on a
+# quarter of the pixels.  Inference only; "0": the reference's order (bench.py's all-direct exact leg keeps the reference's operation count).
+OUT_CONV_FIRST = os.environ.get("PP_DPT_OUT_CONV_FIRST", "1") != "0"
 
 
 def _rcu(c):
@@ -89,8 +93,9 @@ class DPTHead(Packed):
         h = ops.conv2d(h, pkt[f"f{i}_u{j}_c2"], u.conv2.bias, 3, pad=1)
         return ops.batchnorm_train(h, u.bn2, residual=x, residual2=extra)   # bn2(.) + x (+ the fusion block's other input)
 
-    def _rcu(self, pk, key, x, extra=None, more=False):
-        """ResidualConvUnit (dpt.py:72-95): bn2(conv2(relu(bn1(conv1(relu(x)))))) + x (+ extra)."""
+    def _rcu(self, pk, key, x, extra=None, more=False, operand_only=False):
+        """ResidualConvUnit (dpt.py:72-95): bn2(conv2(relu(bn1(conv1(relu(x)))))) + x (+ extra).
+        operand_only: the unit's output feeds one 1x1 convolution and nothing else — it leaves as operand planes (f16x3 engine)."""
         # conv1 hands relu(h) to conv2 as operand planes (out_split + split_relu): h itself is never stored.  The
         # unit's fp32 output also carries its relu'd operand form (also_split) for the next unit's conv1.
         xin = getattr(x, "_hl_relu", None)
@@ -99,7 +104,7 @@ class DPTHead(Packed):
         h = ops.conv2d(x if xin is None else xin, pk[key + "_c1"], pk[key + "_b1"], 3, pad=1, relu_in=xin is None,
                        out_split=True, split_relu=True, wino_next="relu")
         return ops.conv2d(h, pk[key + "_c2"], pk[key + "_b2"], 3, pad=1, relu_in=not isinstance(h, (ops.Split, ops.WinoInput)), residual=x,
-                          residual2=extra, also_split="relu" if more else None)
+                          residual2=extra, also_split="relu" if more else None, out_split=operand_only)
 
     def _fuse(self, pk, i, size, x0, x1=None, train=False):
         """FeatureFusionBlock (dpt.py:129-156)."""
@@ -108,6 +113,12 @@ class DPTHead(Packed):
             out = self._rcu_train(i, 2, out)
         else:
             out = x0 if x1 is None else self._rcu(pk, f"f{i}_u1", x1, extra=x0, more=True)   # feeds resConfUnit2
+            if OUT_CONV_FIRST:
+                # out_conv at the block's own resolution, then the interpolation (the same map, a quarter of the rows in the GEMM);
+                # the path map leaves the resize as fp32 and as the operand of the flow decoder's 1x1 projection
+                out = self._rcu(pk, f"f{i}_u2", out, operand_only=True)
+                out = ops.conv2d(out, pk[f"f{i}_out"], getattr(self.scratch, f"refinenet{i}").out_conv.bias, 1)
+                return ops.resize_bilinear(out, size[0], size[1], also_split=True)
             out = self._rcu(pk, f"f{i}_u2", out)
         out = ops.resize_bilinear(out, size[0], size[1], out_split=True)   # feeds only the 1x1 out_conv
         # the path map is an output (fp32) AND the input of the flow decoder's 1x1 projection: its operand form rides along

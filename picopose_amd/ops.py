@@ -1083,11 +1083,21 @@ def to_nchw(x):
     return out
 
 
-def resize_bilinear(x, Ho, Wo, mul=1.0, out_split=False):
+def resize_bilinear(x, Ho, Wo, mul=1.0, out_split=False, also_split=False):
     """F.interpolate(bilinear, align_corners=True) on NHWC, result times `mul`.  out_split (f16x3 engine): return the
-    result as a Split with .image for the convolution that follows, instead of an fp32 tensor."""
+    result as a Split with .image for the convolution that follows, instead of an fp32 tensor; also_split: the fp32 tensor with
+    its operand form attached as `._hl` (one pass writes both)."""
     B, H, W, C = x.shape
     assert x.is_contiguous()
+    if also_split and _split_ok(C) and x.data_ptr() % 16 == 0:
+        out = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
+        sp = Split.empty(B * Ho * Wo, C, x.device)
+        sp.image = (B, Ho, Wo)
+        _lib.check(_lib.lib().pp_resize_bilinear_nhwc_dual(_p(x), B, H, W, C, Ho, Wo, float(mul), _p(out), _p(sp.hl), sp.terms,
+                                                            _lib.stream_ptr()), "pp_resize_bilinear_nhwc_dual")
+        _chk(sp.hl, "pp_resize_bilinear_nhwc_dual")
+        out._hl = sp
+        return out
     if out_split and _split_ok(C) and x.data_ptr() % 16 == 0:
         sp = Split.empty(B * Ho * Wo, C, x.device)
         sp.image = (B, Ho, Wo)

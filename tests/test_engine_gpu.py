@@ -627,6 +627,24 @@ def test_gelu_epilogue_accuracy():
 
 
 @gpu
+def test_resize_with_both_outputs_equals_the_two_single_output_passes(engine_precision):
+    """pp_resize_bilinear_nhwc_dual: the fp32 map and the operand of pp_resize_bilinear_nhwc_t from one pass."""
+    from picopose_amd import ops
+
+    if engine_precision == "f32":
+        pytest.skip("no operand form in strict-fp32 mode")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(3, 16, 16, 64, device="cuda", generator=g)
+    for (ho, wo) in ((32, 32), (20, 36)):
+        both = ops.resize_bilinear(x, ho, wo, also_split=True)
+        # (the fp32-only kernel branch contracts the blend's multiply-adds differently: the last bit may differ from it)
+        assert (both - ops.resize_bilinear(x, ho, wo)).abs().max().item() <= 2.0 ** -22 * x.abs().max().item()
+        assert torch.equal(both._hl.hl, ops.resize_bilinear(x, ho, wo, out_split=True).hl) and both._hl.image == (3, ho, wo)
+        # the two outputs are the same values: the operand is the split of the fp32 map
+        assert torch.equal(both._hl.hl, ops.split_activation(both, 1, 3 * ho * wo, 64, 0, 64))
+
+
+@gpu
 @pytest.mark.parametrize("B,T,heads", [(1, 1, 1), (1, 3, 2), (2, 33, 2), (2, 96, 3), (3, 100, 6), (2, 257, 12), (1, 300, 3), (1, 1025, 2)])
 def test_attention_shapes_and_operand_input(B, T, heads, engine_precision):
     """Fused attention for ragged sequence lengths (query tiles / key chunks with tails), from the fp32 qkv tensor

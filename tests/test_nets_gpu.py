@@ -161,6 +161,37 @@ def test_dead_layer1_branch_does_not_reach_any_output(golden_dir, monkeypatch, p
 
 
 @gpu
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_out_conv_before_the_interpolation_is_the_same_map(golden_dir, monkeypatch, precision):
+    """FeatureFusionBlock (dpt.py:150-155) is out_conv(interpolate(x)): a 1x1 convolution after a bilinear interpolation whose weights sum
+    to one per pixel — interpolate(out_conv(x)) is the same map, and the build runs the convolution first, on a quarter of the pixels
+    (stage3.OUT_CONV_FIRST).  Against the reference's order: equal up to the rounding of the reordered sums — measured 0.5 - 1.3e-6 of
+    the path maps' max in both arithmetic modes (stated 3e-6) and, carried through the flow decoder of these seeded weights, up to 8e-6
+    of the flows' / certainties' max (stated 3e-5); the reference fixture bars of test_offset_regressor_vs_reference_golden hold in
+    either order (that test runs the default)."""
+    from picopose_amd import ops
+    from picopose_amd.model import stage3
+
+    z, t = _golden(golden_dir)
+    monkeypatch.setattr(ops, "PRECISION", precision)
+    outs = []
+    for first in (True, False):
+        monkeypatch.setattr(stage3, "OUT_CONV_FIRST", first)
+        orr = stage3.OffsetRegressor(small_cfg().stage3)
+        orr.load_state_dict(seeded_state_dict(orr.state_dict(), int(z["s3/seed"])))
+        orr = orr.cuda().eval()
+        ft, fr = [t[f"s3/ft{i}"] for i in range(4)], [t[f"s3/fr{i}"] for i in range(4)]
+        fl, ce = orr(ft, fr, t["s3/init_flow"], t["s3/init_cert"])
+        outs.append([x.cpu() for x in orr.dpt_head(ft) + fl + ce])
+    assert not all(torch.equal(a, b) for a, b in zip(*outs)), "both runs took the same order"
+    dev = [(a - b).abs().max().item() / a.abs().max().item() for a, b in zip(*outs)]
+    print(f"out_conv first vs reference order [{precision}]: max |diff| / max per output (3 path maps, 3 flows, 3 certainties):", " ".join(f"{d:.1e}" for d in dev))
+    assert max(dev[:3]) <= 3e-6 and max(dev[3:]) <= 3e-5, dev
+    _close(outs[0][0], z["s3/dpt_t_path4"], 2e-4)
+    _close(outs[1][0], z["s3/dpt_t_path4"], 2e-4)
+
+
+@gpu
 @pytest.mark.parametrize("precision", ["f16x3", "f16"])
 def test_fused_xhead_first_layers_equal_two_launches(golden_dir, monkeypatch, precision):
     """The flow and certainty heads' first layers (conv 3x3 640 -> 512 each, flow_decoder.py:58-72) run as ONE launch with the
