@@ -626,7 +626,9 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
                    C_hl=tgt.col_ptr(col0), ldc_h=ctot, c_relu=int(split_relu), **wargs),
              written=Split(tgt.cols(col0, Cout), tgt.terms) if CHECK_SATURATION else None)
         return out
-    if out_split and out is None and presplit and _split_ok(Cout) and residual is None and residual2 is None:
+    # (operand-only output with residuals: the epilogue reads them with the row pitch ldc = Cout — contiguous (B, Ho, Wo, Cout) maps)
+    if (out_split and out is None and presplit and _split_ok(Cout)
+            and all(r_ is None or (r_.is_contiguous() and tuple(r_.shape) == (B, Ho, Wo, Cout)) for r_ in (residual, residual2))):
         ret = Split.empty(B * Ho * Wo, Cout, dev)
         ret.image = (B, Ho, Wo)
         sargs = dict(C_hl=_p(ret.hl), ldc_h=Cout, c_relu=int(split_relu))
@@ -638,7 +640,7 @@ def conv2d(x, wp, bias, ksize, stride=1, pad=0, act=None, relu_in=False, residua
         assert out.stride(3) == 1 and out.stride(1) == Wo * ldc and out.stride(0) == Ho * Wo * ldc
         ret = out
     for r_ in (residual, residual2):
-        if r_ is not None:
+        if r_ is not None and out is not None:
             assert r_.stride() == out.stride()
     extra = None
     if also_split is not None and presplit and _split_ok(Cout) and not sargs and out.is_contiguous():

@@ -90,6 +90,15 @@ def test_conv2d_relu_in_residual_and_concat_slices():
     xh = ops.to_nhwc(x.cuda())
     out = ops.conv2d(xh, ops.pack_conv_weight(w.cuda()), b.cuda(), 3, 1, 1, relu_in=True, residual=xh)
     _close(ops.to_nchw(out), ref)
+    if ops.presplit():
+        # the same unit with an OPERAND-ONLY output (it feeds one 1x1 convolution: stage3.OUT_CONV_FIRST): residuals are added in the
+        # epilogue, the fp32 map is never stored — the operand is the split of the fp32 result
+        r2 = torch.randn(B, H, H, C, generator=g).cuda()
+        wp = ops.pack_conv_weight(w.cuda())
+        full = ops.conv2d(xh, wp, b.cuda(), 3, 1, 1, relu_in=True, residual=xh, residual2=r2)
+        sp = ops.conv2d(xh, wp, b.cuda(), 3, 1, 1, relu_in=True, residual=xh, residual2=r2, out_split=True)
+        assert isinstance(sp, ops.Split) and sp.image == (B, H, H)
+        assert torch.equal(sp.hl, ops.split_activation(full, 1, B * H * H, C, 0, C))
     # read from / write into channel slices of wider NHWC buffers (the 640-channel concat of the flow decoder)
     wide_in = torch.randn(B, H, H, 3 * C, generator=g).cuda()
     wide_out = torch.zeros(B, H, H, 2 * C).cuda()
