@@ -403,8 +403,9 @@ int pp_depth_points_nearest(const float* depth_m, int H, int W, int y1, int y2, 
 int pp_corr_lookup_nhwc(const float* f1, int ld_f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
                         int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius,
                         int ld_flow, float* out, int ld_out, void* stream);
-/* The same with the arithmetic as an argument: PP_PREC_F16X3 = the default above, PP_PREC_F32 = exact fp32 fmas (the
- * lane-per-position kernel) whatever the shape — what `ops.PRECISION = "f32"` / `bench.py --mode exact` runs. */
+/* The same with the arithmetic as an argument: PP_PREC_F16X3 = the default above, PP_PREC_F32 = exact fp32 products and sums
+ * whatever the shape — what `ops.PRECISION = "f32"` / `bench.py --mode exact` runs — PP_PREC_F16 = plain fp16 operands, one MFMA
+ * per product, fp32 accumulation (`--mode fp16`: the arithmetic of that mode's convolutions). */
 int pp_corr_lookup_nhwc_ex(const float* f1, int ld_f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
                            int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius,
                            int ld_flow, int prec, float* out, int ld_out, void* stream);

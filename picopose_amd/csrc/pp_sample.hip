@@ -283,7 +283,9 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 // instead of 32 hi + 32 lo halfs) and S is accumulated by v_mfma_f32_32x32x2_f32 — exact fp32 products, a k-ordered fma chain per
 // entry like the lane-per-position kernel's, 5.3 x the matrix time of the f16x3 form but a third less than that kernel's 108 row
 // streams per pixel (9.6 -> measured below, profiles/r05/exact).
-template <bool HLIN, bool EXACT = false>
+// ONE (fp32 input only; ops.PRECISION = "f16" / bench.py --mode fp16): plain fp16 operands — a value is staged as its hi term alone and a
+// product is ONE MFMA (the arithmetic of that mode's convolutions: 11 operand bits, fp32 accumulation); a third of the matrix work.
+template <bool HLIN, bool EXACT = false, bool ONE = false>
 __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const void* __restrict__ f1v, int ld_f1, int f2_batch,
                                                                   const void* __restrict__ f2l0, const void* __restrict__ f2l1,
                                                                   const void* __restrict__ f2l2, const float* __restrict__ flow,
@@ -384,13 +386,18 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const void* __
                     return;
                 }
                 // (staging into LDS, not an operand buffer: the same maps' saturation is reported by the epilogue that wrote their operand form)
+                _Float16* g8 = (_Float16*)rowp + 16 * (part >> 1) + 4 * (part & 1);   // channels 4 part .. + 3 of group part / 2
+                if (ONE) {   // the hi plane alone (the lo plane of the row is never read)
+                    const h4_t hi = {pp_to_f16(v.x), pp_to_f16(v.y), pp_to_f16(v.z), pp_to_f16(v.w)};
+                    *(h4_t*)g8 = hi;
+                    return;
+                }
                 _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
                 pp_split_f16(v.x, h0, l0);
                 pp_split_f16(v.y, h1, l1);
                 pp_split_f16(v.z, h2, l2);
                 pp_split_f16(v.w, h3, l3);
                 const h4_t hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
-                _Float16* g8 = (_Float16*)rowp + 16 * (part >> 1) + 4 * (part & 1);   // channels 4 part .. + 3 of group part / 2
                 *(h4_t*)g8 = hi;
                 *(h4_t*)(g8 + 8) = lo;
             };
@@ -437,17 +444,21 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_mfma_kernel(const void* __
                         const _Float16* ar = (const _Float16*)(As + (i * 32 + l31) * CKP) + 16 * (2 * q + lh);
                         const _Float16* br = (const _Float16*)(Bs + (wv * 64 + i * 32 + l31) * CKP) + 16 * (2 * q + lh);
                         ah[i] = *(const h8_t*)ar;
-                        al[i] = *(const h8_t*)(ar + 8);
                         bh[i] = *(const h8_t*)br;
-                        bl[i] = *(const h8_t*)(br + 8);
+                        if (!ONE) {
+                            al[i] = *(const h8_t*)(ar + 8);
+                            bl[i] = *(const h8_t*)(br + 8);
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            if (!ONE) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            }
                         }
                 }
             };
@@ -753,7 +764,7 @@ int pp_avgpool2_nhwc(const float* in, int B, int H, int W, int C, float* out, vo
 
 static int corr_tiled_launch(bool hl, const void* f1, int ld_f1, const void* f2_l0, const void* f2_l1, const void* f2_l2, int f2_batch,
                              const float* flow, int B, int H, int W, int C, int levels, int radius, int ld_flow, float* out, int ld_out,
-                             void* stream, bool exact = false) {
+                             void* stream, bool exact = false, bool one = false) {
     // matrix-core version: one workgroup per 8 x 8 pixel tile
     const size_t lds = (size_t)(CM * CSP > (CM + CN) * CKP ? CM * CSP : (CM + CN) * CKP) * sizeof(float);
     static signed char attr[PP_MAX_DEVICES];
@@ -761,13 +772,17 @@ static int corr_tiled_launch(bool hl, const void* f1, int ld_f1, const void* f2_
     if (ok == 0)
         ok = hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                      hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                     hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess
+                     hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)corr_lookup_mfma_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess
                  ? 1 : -1;
     if (ok < 0) return PP_ELAUNCH;
     const dim3 grid((unsigned)((H / CT) * (W / CT) * B));
     if (exact)
         hipLaunchKernelGGL((corr_lookup_mfma_kernel<false, true>), grid, dim3(256), lds, (hipStream_t)stream, f1, ld_f1, f2_batch, f2_l0, f2_l1, f2_l2,
                            flow, B, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out, ld_out);
+    else if (one)
+        hipLaunchKernelGGL((corr_lookup_mfma_kernel<false, false, true>), grid, dim3(256), lds, (hipStream_t)stream, f1, ld_f1, f2_batch, f2_l0, f2_l1,
+                           f2_l2, flow, B, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out, ld_out);
     else if (hl)
         hipLaunchKernelGGL(corr_lookup_mfma_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, f1, ld_f1, f2_batch, f2_l0, f2_l1, f2_l2,
                            flow, B, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out, ld_out);
@@ -799,7 +814,7 @@ int pp_conv_narrow_f32(const float* x, int ld_x, int B, int H, int W, int C, con
 int pp_corr_lookup_nhwc_ex(const float* f1, int ld_f1, const float* f2_l0, const float* f2_l1, const float* f2_l2,
                            int f2_batch, const float* flow, int B, int H, int W, int C, int levels, int radius,
                            int ld_flow, int prec, float* out, int ld_out, void* stream) {
-    if (prec != PP_PREC_F32 && prec != PP_PREC_F16X3) return PP_EINVAL;
+    if (prec != PP_PREC_F32 && prec != PP_PREC_F16X3 && prec != PP_PREC_F16) return PP_EINVAL;
     if (!f1 || !f2_l0 || !flow || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return PP_EINVAL;
     if (ld_f1 < C || ld_f1 % 4 != 0 || ((uintptr_t)f1 % 16) != 0 || f2_batch <= 0) return PP_EINVAL;
     if (levels < 1 || levels > MAXL || radius < 1 || radius > MAXR) return PP_EINVAL;
@@ -814,7 +829,8 @@ int pp_corr_lookup_nhwc_ex(const float* f1, int ld_f1, const float* f2_l0, const
     const bool aligned = (((uintptr_t)f2_l0 | (levels > 1 ? (uintptr_t)f2_l1 : 0) | (levels > 2 ? (uintptr_t)f2_l2 : 0)) % 16) == 0;
     if (tiled && H % CT == 0 && W % CT == 0 && C % CK == 0 && aligned)   // (PP_CORR_TILED=0 keeps the lane-per-position kernel)
         return corr_tiled_launch(false, f1, ld_f1, f2_l0, f2_l1, f2_l2, f2_batch, flow, B, H, W, C, levels, radius, ld_flow, out, ld_out, stream,
-                                 prec == PP_PREC_F32);
+                                 prec == PP_PREC_F32, prec == PP_PREC_F16);
+    // (PP_PREC_F16 on the lane-per-position kernel below: fp32 products — finer than the mode asks for)
     const size_t smem = (size_t)4 * (C + MAXL * TW * TW) * sizeof(float);
     hipLaunchKernelGGL(corr_lookup_kernel, dim3((H * W + 3) / 4, B), dim3(256), smem, (hipStream_t)stream, f1, ld_f1,
                        f2_batch, f2_l0, f2_l1, f2_l2, flow, H, W, C, levels, radius, ld_flow, 1.0f / sqrtf((float)C), out,

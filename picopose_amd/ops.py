@@ -1171,7 +1171,7 @@ def corr_lookup(f1, f2, flow, levels, radius, c_pad=None, f1_hl=None, f2_hl=None
         return out
     _lib.check(_lib.lib().pp_corr_lookup_nhwc_ex(_p(f1), f1.stride(2), _p(pyr[0]), _p(pyr[1]) if levels > 1 else None,
                                                  _p(pyr[2]) if levels > 2 else None, f2.shape[0], _p(flow), B, H, W, C,
-                                                 levels, radius, flow.stride(2), _fly_prec(), _p(out), np_,
+                                                 levels, radius, flow.stride(2), 2 if PRECISION == "f16" else _fly_prec(), _p(out), np_,
                                                  _lib.stream_ptr()), "pp_corr_lookup_nhwc_ex")
     return out
 

@@ -290,6 +290,43 @@ def test_tiled_corr_lookup_equals_the_lane_per_position_kernel(monkeypatch, H, l
 
 @gpu
 @pytest.mark.parametrize("H,levels,scale", [(16, 1, 1.0), (32, 2, 3.0), (64, 3, 0.7), (64, 3, 40.0)])
+def test_fp16_mode_tiled_corr_lookup_with_one_term_products(monkeypatch, H, levels, scale):
+    """ops.PRECISION = "f16" (bench.py --mode fp16): the tiled correlation lookup on plain fp16 operands, one MFMA per product (round 6;
+    it ran the three-term form in that mode too).  Against the CPU oracle on the SAME fp16-rounded features — what the mode promises:
+    exact products of 11-bit operands, fp32 sums (bar 2e-5 of the max, the f16x3 kernel's own) — and against the oracle on the
+    unrounded features at the mode's operand rounding (2e-3)."""
+    from picopose_amd import ops
+
+    monkeypatch.setattr(ops, "PRECISION", "f16")
+    g = torch.Generator().manual_seed(H * 10 + levels + 2)
+    B, C = 4, 64
+    f1 = torch.randn(B, H, H, C, generator=g).cuda()
+    f2 = torch.randn(2, H, H, C, generator=g).cuda()
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(H, dtype=torch.float32), indexing="ij")
+    smooth = torch.stack([0.15 * xx - 0.1 * yy + 1.3, 0.1 * xx + 0.2 * yy - 2.1], dim=-1)[None].repeat(B, 1, 1, 1)
+    flow = (smooth + scale * torch.randn(B, H, H, 2, generator=g)).cuda()
+    pad = -(-(levels * 25) // 8) * 8
+    one = ops.corr_lookup(f1, f2, flow, levels, 2, c_pad=pad)
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    three = ops.corr_lookup(f1, f2, flow, levels, 2, c_pad=pad)
+    assert not torch.equal(one, three), "both runs took the three-term form"
+    n = levels * 25
+
+    def oracle(a, b):
+        # (the pyramid levels are average pools of the fp32 map; the kernel rounds each level's values as it stages them)
+        return on.corr_lookup(a.cpu().permute(0, 3, 1, 2), b.cpu().repeat(2, 1, 1, 1).permute(0, 3, 1, 2), flow.cpu().permute(0, 3, 1, 2), levels, 2).permute(0, 2, 3, 1)
+
+    ref = oracle(f1, f2)
+    top = max(1.0, float(ref.abs().max()))
+    assert float((one[..., :n].cpu() - ref).abs().max()) <= 2e-3 * top
+    if levels == 1:   # one level: the staged values are exactly the fp16 roundings of the inputs
+        r16 = oracle(f1.half().float(), f2.half().float())
+        assert float((one[..., :n].cpu() - r16).abs().max()) <= 2e-5 * top
+    assert torch.equal(one[..., n:], torch.zeros_like(one[..., n:]))
+
+
+@gpu
+@pytest.mark.parametrize("H,levels,scale", [(16, 1, 1.0), (32, 2, 3.0), (64, 3, 0.7), (64, 3, 40.0)])
 def test_exact_mode_tiled_corr_lookup_on_fp32_matrix_cores(monkeypatch, H, levels, scale):
     """ops.PRECISION = "f32" (bench.py --mode exact): the tiled correlation lookup with fp32 chunks and v_mfma_f32_32x32x2_f32 (round 5)
     against the lane-per-position fp32 kernel it replaces in that mode (PP_CORR_TILED=0) and the CPU oracle — smooth, noisy and
