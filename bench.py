@@ -436,6 +436,14 @@ def sharded_leg_plan(workload_crops, n_templates, world, rank):
     return workload_crops // world, lo, hi
 
 
+def input_batches(prefetch_query, single_batch, sharded, cached):
+    """How many different input batches the timed loop alternates.  Two when every step looks ahead to the NEXT batch's query crops (a serving
+    loop: the look-ahead must not be the crops the step is working on).  One for the template-sharded forward and for the extended template
+    bank: neither has a template-side ViT pass for the next queries to ride in — and a second batch of the extended-bank workload would
+    have to carry its own cache (round 6: a second batch WITHOUT one made every other step an uncached forward, 601 instead of 862 crops/s)."""
+    return 2 if prefetch_query and not single_batch and not sharded and not cached else 1
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` from a plain shell: run the N ranks as a child torch.distributed.run job (nothing in
     this process has touched the GPU) and hand back its return code; rank 0 of the child prints the JSON line."""
@@ -637,7 +645,7 @@ def main():
         ep = make_end_points(Bl, N, dev, 100 + rank)                     # this rank's crops + their raw templates
         # a second, different batch: the timed loop alternates the two, so every step's look-ahead prefetches crops that are NOT the
         # ones it is working on (--single-batch: one batch, as in rounds 1-5)
-        two_batches = a.prefetch_query and not a.single_batch and not sharded and not cached   # (extended bank: no template-side pass to ride in)
+        two_batches = input_batches(a.prefetch_query, a.single_batch, sharded, cached) == 2
         ep_b = make_end_points(Bl, N, dev, 200 + rank) if two_batches else None
         fe = net.feature_extractor
         # feature bank (outside the timed region, run_test.py:120-134): this rank's template slice of ALL crops.

@@ -120,6 +120,10 @@ def test_bench_batch_plan_weak_and_strong():
     assert plans[0][1] == 0 and plans[-1][2] == 162 and all(plans[r][2] == plans[r + 1][1] for r in range(7))
     assert bench.sharded_leg_plan(32, 162, 2, 1) == (16, 81, 162) and bench.sharded_leg_plan(32, 162, 4, 0) == (8, 0, 41)
     assert bench.sharded_leg_plan(32, 162, 1, 0) is None and bench.sharded_leg_plan(32, 162, 3, 0) is None     # one rank / ranks that do not divide the batch
+    # the timed loop alternates two batches only where a look-ahead exists; the extended-bank workload keeps ONE (its cache belongs to it)
+    assert bench.input_batches(True, False, False, False) == 2
+    assert bench.input_batches(True, False, False, True) == 1 and bench.input_batches(True, False, True, False) == 1
+    assert bench.input_batches(False, False, False, False) == 1 and bench.input_batches(True, True, False, False) == 1
 
 
 def test_compat_import_installs_the_pnp_drop_in(tmp_path):
