@@ -70,6 +70,13 @@ def test_argument_validation_needs_no_gpu():
     assert L.pp_winograd_chain_f32(None, 1, 64, 64, 64, None, 0, 0, None, None) == -1
     assert L.pp_winograd_chain_f32(p, 1, 63, 64, 64, None, 0, 0, p, None) == -1                        # H % 2
     assert L.pp_winograd_chain_f32(p, 1, 64, 24, 64, None, 0, 0, p, None) == -1
+    # ... the resize with both outputs (channel count off the operand's 8-column groups, a missing output, operand format other than 1 / 2 terms)
+    assert L.pp_resize_bilinear_nhwc_dual(None, 1, 16, 16, 64, 32, 32, 1.0, None, None, 2, None) == -1
+    assert L.pp_resize_bilinear_nhwc_dual(p, 1, 16, 16, 60, 32, 32, 1.0, p, p, 2, None) == -1
+    assert L.pp_resize_bilinear_nhwc_dual(p, 1, 16, 16, 64, 32, 32, 1.0, None, p, 2, None) == -1
+    assert L.pp_resize_bilinear_nhwc_dual(p, 1, 16, 16, 64, 32, 32, 1.0, p, p, 3, None) == -1
+    # ... and the correlation lookup's arithmetic argument: PP_PREC_F32 / F16X3 / F16 (0 / 1 / 2), nothing else
+    assert L.pp_corr_lookup_nhwc_ex(p, 64, p, None, None, 1, p, 1, 16, 16, 64, 1, 2, 2, 3, p, 32, None) == -1
 
 
 def test_state_dict_names_shapes_equal_the_reference(golden_dir):
